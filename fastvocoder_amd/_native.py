@@ -1,0 +1,272 @@
+"""ctypes binding of libfastvocoder_hip.so (include/fastvocoder_hip.h).
+
+PyTorch-ROCm is plumbing here: it owns device memory (tensors) and the stream;
+every function below passes raw device pointers and the current HIP stream to
+the C ABI.  There is NO fallback: if the shared library is missing or a tensor
+is not a contiguous fp32 tensor on a ROCm device, these raise.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfastvocoder_hip.so")
+_CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip"]
+
+PAD_ZERO, PAD_REFLECT = 0, 1
+POST_NONE, POST_TANH, POST_RELU = 0, 1, 2
+SLOT_NONE, SLOT_IN, SLOT_OUT, SLOT_TMP0, MAX_SLOTS = -1, 0, 1, 2, 16
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """hipcc the kernels for gfx950 into fastvocoder_amd/libfastvocoder_hip.so
+    (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(_CSRC, "fv_internal.h"),
+                   os.path.join(_HERE, "..", "include", "fastvocoder_hip.h")]
+    if (not force and os.path.exists(LIB_PATH)
+            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps)):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-Wno-unused-value", "-Wno-comment"] + srcs + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the library (never builds implicitly: a GPU box gets the prebuilt .so)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). fastvocoder_amd has no CPU or eager fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i, f, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+    L.fv_version.restype = i
+    L.fv_last_error.restype = ctypes.c_char_p
+    L.fv_fold_weight_norm.argtypes = [vp, vp, vp, i, i64, vp]
+    L.fv_packed_conv1d_floats.argtypes = [i, i, i]
+    L.fv_packed_conv1d_floats.restype = i64
+    L.fv_packed_conv_transpose1d_floats.argtypes = [i, i, i, i, i]
+    L.fv_packed_conv_transpose1d_floats.restype = i64
+    L.fv_pack_conv1d_weight.argtypes = [vp, vp, i, i, i, vp]
+    L.fv_pack_conv_transpose1d_weight.argtypes = [vp, vp, i, i, i, i, i, vp]
+    L.fv_conv1d_fused.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, f, i, vp]
+    L.fv_conv_transpose1d_fused.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, i, vp]
+    L.fv_pqmf_synthesis.argtypes = [vp, vp, vp, i, i, i, i, vp]
+    L.fv_plan_create.argtypes = [i]
+    L.fv_plan_create.restype = vp
+    L.fv_plan_destroy.argtypes = [vp]
+    L.fv_plan_destroy.restype = None
+    L.fv_plan_add_conv1d.argtypes = [vp, i, i, i, i, vp, vp, i, i, i, i, i, i, f, f, i]
+    L.fv_plan_add_conv_transpose1d.argtypes = [vp, i, i, vp, vp, i, i, i, i, i, i, f, i]
+    L.fv_plan_add_pqmf_synthesis.argtypes = [vp, i, i, vp, i, i]
+    L.fv_plan_output_shape.argtypes = [vp, i, ctypes.POINTER(i), ctypes.POINTER(i64)]
+    L.fv_plan_workspace_bytes.argtypes = [vp, i, i]
+    L.fv_plan_workspace_bytes.restype = i64
+    L.fv_plan_run.argtypes = [vp, i, i, vp, vp, vp, i64, vp]
+    L.fv_plan_num_ops.argtypes = [vp]
+    L.fv_profile_enable.argtypes = [i]
+    L.fv_profile_collect.argtypes = [ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_double),
+                                     ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    if L.fv_version() != 1:
+        raise NativeError(f"ABI mismatch: library reports {L.fv_version()}, binding expects 1")
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise NativeError(f"libfastvocoder_hip error {rc}: {lib().fv_last_error().decode()}")
+
+
+def _ptr(t, name="tensor", allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise NativeError(f"{name} is None")
+    if not t.is_cuda:
+        raise NativeError(f"{name} lives on {t.device}; the HIP kernels need a ROCm device "
+                          "tensor (there is no CPU path in fastvocoder_amd)")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise NativeError(f"{name} must be contiguous float32, got {t.dtype} "
+                          f"contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---------------------------------------------------------------------------
+# weight preparation
+# ---------------------------------------------------------------------------
+
+def fold_weight_norm(v, g):
+    """w = v * g/||v|| over all dims but 0 (torch.nn.utils.weight_norm semantics)."""
+    v = v.detach().contiguous().float()
+    g = g.detach().contiguous().float()
+    w = torch.empty_like(v)
+    check(lib().fv_fold_weight_norm(_ptr(v, "v"), _ptr(g, "g"), _ptr(w), v.shape[0],
+                                    v[0].numel(), _stream()))
+    return w
+
+
+def pack_conv1d(w):
+    """Conv1d weight [Cout,Cin,k] -> packed K-major image (flat tensor)."""
+    w = w.detach().contiguous().float()
+    cout, cin, k = w.shape
+    out = torch.empty(lib().fv_packed_conv1d_floats(cout, cin, k), dtype=torch.float32, device=w.device)
+    check(lib().fv_pack_conv1d_weight(_ptr(w, "w"), _ptr(out), cout, cin, k, _stream()))
+    return out
+
+
+def pack_conv_transpose1d(w, stride, pad):
+    """ConvTranspose1d weight [Cin,Cout,k] -> packed polyphase image (flat tensor)."""
+    w = w.detach().contiguous().float()
+    cin, cout, k = w.shape
+    n = lib().fv_packed_conv_transpose1d_floats(cin, cout, k, stride, pad)
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    check(lib().fv_pack_conv_transpose1d_weight(_ptr(w, "w"), _ptr(out), cin, cout, k, stride, pad,
+                                                _stream()))
+    return out
+
+
+# ---------------------------------------------------------------------------
+# single fused operators (used by tests and by modules outside a plan)
+# ---------------------------------------------------------------------------
+
+def conv1d_fused(x, packed, bias, cout, k, dil=1, pad=0, pad_mode=PAD_ZERO, pre_slope=1.0,
+                 res=None, acc_in=None, out_div=1.0, post=POST_NONE, out=None):
+    B, cin, T = x.shape
+    tout = T + 2 * pad - dil * (k - 1)
+    if out is None:
+        out = torch.empty((B, cout, tout), dtype=torch.float32, device=x.device)
+    check(lib().fv_conv1d_fused(_ptr(x, "x"), _ptr(packed, "packed"), _ptr(bias, "bias", True),
+                                _ptr(res, "res", True), _ptr(acc_in, "acc_in", True), _ptr(out, "out"),
+                                B, cin, cout, T, k, dil, pad, pad_mode, float(pre_slope),
+                                float(out_div), post, _stream()))
+    return out
+
+
+def conv_transpose1d_fused(x, packed, bias, cout, k, stride, pad, out_pad, pre_slope=1.0,
+                           post=POST_NONE, out=None):
+    B, cin, T = x.shape
+    tout = (T - 1) * stride - 2 * pad + k + out_pad
+    if out is None:
+        out = torch.empty((B, cout, tout), dtype=torch.float32, device=x.device)
+    check(lib().fv_conv_transpose1d_fused(_ptr(x, "x"), _ptr(packed, "packed"),
+                                          _ptr(bias, "bias", True), _ptr(out, "out"), B, cin, cout,
+                                          T, k, stride, pad, out_pad, float(pre_slope), post,
+                                          _stream()))
+    return out
+
+
+def pqmf_synthesis(x, synthesis_filter, y):
+    """x [B,S,Tsub], synthesis_filter [1,S,ntaps] -> y [B,1,S*Tsub] (filled in place)."""
+    B, S, Tsub = x.shape
+    h = synthesis_filter.reshape(S, -1).contiguous().float()
+    check(lib().fv_pqmf_synthesis(_ptr(x, "x"), _ptr(h, "h"), _ptr(y, "y"), B, S, h.shape[1], Tsub,
+                                  _stream()))
+    return y
+
+
+# ---------------------------------------------------------------------------
+# plans
+# ---------------------------------------------------------------------------
+
+class Plan:
+    """Owner of a native op list (fv_plan_t) plus the tensors its ops point at."""
+
+    def __init__(self, in_channels):
+        self._h = lib().fv_plan_create(in_channels)
+        self._keep = []        # packed weights / biases the native plan references
+        self._ws = None
+        self._ws_key = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.fv_plan_destroy(h)
+
+    def keep(self, t):
+        self._keep.append(t)
+        return t
+
+    def add_conv1d(self, x, y, packed, bias, cin, cout, k, dil=1, pad=0, pad_mode=PAD_ZERO,
+                   pre_slope=1.0, res=SLOT_NONE, acc=SLOT_NONE, out_div=1.0, post=POST_NONE):
+        self.keep(packed)
+        if bias is not None:
+            self.keep(bias)
+        check(lib().fv_plan_add_conv1d(self._h, x, y, res, acc, _ptr(packed, "packed"),
+                                       _ptr(bias, "bias", True), cin, cout, k, dil, pad, pad_mode,
+                                       float(pre_slope), float(out_div), post))
+
+    def add_conv_transpose1d(self, x, y, packed, bias, cin, cout, k, stride, pad, out_pad,
+                             pre_slope=1.0, post=POST_NONE):
+        self.keep(packed)
+        if bias is not None:
+            self.keep(bias)
+        check(lib().fv_plan_add_conv_transpose1d(self._h, x, y, _ptr(packed, "packed"),
+                                                 _ptr(bias, "bias", True), cin, cout, k, stride,
+                                                 pad, out_pad, float(pre_slope), post))
+
+    def add_pqmf_synthesis(self, x, y, h):
+        """h [S, ntaps] contiguous fp32 device tensor."""
+        self.keep(h)
+        check(lib().fv_plan_add_pqmf_synthesis(self._h, x, y, _ptr(h, "h"), h.shape[0], h.shape[1]))
+
+    def output_shape(self, T):
+        c, n = ctypes.c_int(), ctypes.c_int64()
+        check(lib().fv_plan_output_shape(self._h, T, ctypes.byref(c), ctypes.byref(n)))
+        return c.value, n.value
+
+    def num_ops(self):
+        return lib().fv_plan_num_ops(self._h)
+
+    def run(self, x, out=None):
+        """x [B,Cin,T] contiguous fp32 on a ROCm device -> [B,Cout,Tout]."""
+        B, _, T = x.shape
+        c, n = self.output_shape(T)
+        if out is None:
+            out = torch.empty((B, c, n), dtype=torch.float32, device=x.device)
+        key = (B, T, x.device)
+        if self._ws_key != key:
+            nbytes = lib().fv_plan_workspace_bytes(self._h, B, T)
+            if nbytes < 0:
+                check(int(nbytes))
+            self._ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=x.device)
+            self._ws_key = key
+        check(lib().fv_plan_run(self._h, B, T, _ptr(x, "input"), _ptr(out, "out"),
+                                self._ws.data_ptr(), self._ws.numel(), _stream()))
+        return out
+
+
+# ---------------------------------------------------------------------------
+# measurement hook
+# ---------------------------------------------------------------------------
+
+def profile_enable(on):
+    check(lib().fv_profile_enable(1 if on else 0))
+
+
+def profile_collect():
+    n, ms = ctypes.c_int64(), ctypes.c_double()
+    fl, by = ctypes.c_double(), ctypes.c_double()
+    check(lib().fv_profile_collect(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
+    return {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}

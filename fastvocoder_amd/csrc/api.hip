@@ -1,0 +1,510 @@
+// C-ABI entry points of libfastvocoder_hip.so (include/fastvocoder_hip.h):
+// weight preparation kernels, the fused operators, the plan executor and the
+// measurement hook.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <string>
+#include <vector>
+
+#include "fv_internal.h"
+
+namespace fv {
+
+static thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code ? code : FV_ERR_INVALID_ARG;
+}
+
+// ---------------------------------------------------------------------------
+// measurement hook
+// ---------------------------------------------------------------------------
+struct ProfRec {
+    hipEvent_t a, b;
+    double flops, bytes;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static hipEvent_t g_prof_start;
+
+void profile_begin(hipStream_t s) {
+    if (!g_prof_on) return;
+    hipEventCreate(&g_prof_start);
+    hipEventRecord(g_prof_start, s);
+}
+
+void profile_end(hipStream_t s, double flops, double bytes) {
+    if (!g_prof_on) return;
+    ProfRec r;
+    r.a = g_prof_start;
+    hipEventCreate(&r.b);
+    hipEventRecord(r.b, s);
+    r.flops = flops;
+    r.bytes = bytes;
+    g_prof.push_back(r);
+}
+
+// ---------------------------------------------------------------------------
+// weight preparation
+// ---------------------------------------------------------------------------
+
+// One block per dim-0 row: ||v||_2 by a wave-shuffle + LDS tree, then scale.
+__global__ __launch_bounds__(256) void fold_weight_norm_kernel(const float* __restrict__ v,
+                                                               const float* __restrict__ g,
+                                                               float* __restrict__ w,
+                                                               int64_t inner) {
+    __shared__ float part[4];
+    const int r = blockIdx.x;
+    const float* vr = v + (size_t)r * inner;
+    float ss = 0.f;
+    for (int64_t i = threadIdx.x; i < inner; i += 256) ss = fmaf(vr[i], vr[i], ss);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float nrm = sqrtf(part[0] + part[1] + part[2] + part[3]);
+    const float scale = g[r] / nrm;
+    for (int64_t i = threadIdx.x; i < inner; i += 256) w[(size_t)r * inner + i] = vr[i] * scale;
+}
+
+// Conv1d weight [Cout, Cin, k] -> Wp[(ci*k + j)][Mpad], zero in the pad rows.
+__global__ void pack_conv1d_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
+                                   int Cin, int k, int Mpad) {
+    const int64_t total = (int64_t)Cin * k * Mpad;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i % Mpad);
+        const int64_t row = i / Mpad;
+        const int j = (int)(row % k), ci = (int)(row / k);
+        wp[i] = m < Cout ? w[((size_t)m * Cin + ci) * k + j] : 0.f;
+    }
+}
+
+// ConvTranspose1d weight [Cin, Cout, k] -> polyphase image
+// Wp[(ci*taps + jj)][m = co*s + r] = w[ci, co, a + (c - dmin - jj)*s],
+// a = (r+p) % s, c = (r+p) / s, zero where that tap index falls outside [0,k).
+__global__ void pack_convT_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin,
+                                  int Cout, int k, int s, int p, int dmin, int taps, int Mpad) {
+    const int64_t total = (int64_t)Cin * taps * Mpad;
+    const int M = Cout * s;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i % Mpad);
+        const int64_t row = i / Mpad;
+        const int jj = (int)(row % taps), ci = (int)(row / taps);
+        float val = 0.f;
+        if (m < M) {
+            const int co = m / s, r = m - co * s;
+            const int a = (r + p) % s, c = (r + p) / s;
+            const int mi = c - dmin - jj;
+            const int j = a + mi * s;
+            if (mi >= 0 && j < k) val = w[((size_t)ci * Cout + co) * k + j];
+        }
+        wp[i] = val;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+enum OpType { OP_CONV = 0, OP_CONVT = 1, OP_PQMF = 2 };
+
+struct Op {
+    int type;
+    int x, y, res, acc;
+    const float* wp;
+    const float* bias;
+    int Cin, Cout, k, dil, pad, pad_mode, stride, out_pad;
+    float pre_slope, out_div;
+    int post;
+};
+
+struct Shape {
+    int C;
+    int64_t T;
+    bool set;
+};
+
+}  // namespace fv
+
+struct fv_plan {
+    int in_channels;
+    std::vector<fv::Op> ops;
+};
+
+namespace fv {
+
+static int64_t conv_out_len(const Op& o, int64_t Tin) {
+    if (o.type == OP_CONV) return Tin + 2LL * o.pad - (int64_t)o.dil * (o.k - 1);
+    if (o.type == OP_CONVT) return (Tin - 1) * o.stride - 2LL * o.pad + o.k + o.out_pad;
+    return Tin * o.Cin;  // PQMF: S sub-bands interleave into S*Tsub samples
+}
+
+// Propagate shapes through the op list; fills per-slot max element counts.
+static int infer(const fv_plan* plan, int B, int T, Shape* sh, int64_t* slot_elems) {
+    for (int i = 0; i < FV_MAX_SLOTS; ++i) {
+        sh[i].set = false;
+        slot_elems[i] = 0;
+    }
+    sh[FV_SLOT_IN] = {plan->in_channels, T, true};
+    for (size_t n = 0; n < plan->ops.size(); ++n) {
+        const Op& o = plan->ops[n];
+        if (!sh[o.x].set) return fail(FV_ERR_INVALID_ARG, "op %zu reads unset slot %d", n, o.x);
+        if (sh[o.x].C != o.Cin)
+            return fail(FV_ERR_INVALID_ARG, "op %zu: slot %d has %d channels, op expects %d", n,
+                        o.x, sh[o.x].C, o.Cin);
+        const int64_t Tout = conv_out_len(o, sh[o.x].T);
+        if (Tout <= 0) return fail(FV_ERR_INVALID_ARG, "op %zu: empty output (T=%lld)", n, (long long)sh[o.x].T);
+        const int Cout = o.type == OP_PQMF ? 1 : o.Cout;
+        const int aux[2] = {o.res, o.acc};
+        for (int a = 0; a < 2; ++a) {
+            if (aux[a] == FV_SLOT_NONE) continue;
+            if (!sh[aux[a]].set || sh[aux[a]].C != Cout || sh[aux[a]].T != Tout)
+                return fail(FV_ERR_INVALID_ARG, "op %zu: residual/accumulator slot %d shape mismatch", n, aux[a]);
+        }
+        if (o.y == o.x) return fail(FV_ERR_INVALID_ARG, "op %zu: output aliases input", n);
+        sh[o.y] = {Cout, Tout, true};
+        const int64_t e = (int64_t)B * Cout * Tout;
+        if (e > slot_elems[o.y]) slot_elems[o.y] = e;
+    }
+    return 0;
+}
+
+static int run_op(const Op& o, const float* x, float* y, const float* res, const float* acc, int B,
+                  int64_t Tin, hipStream_t s) {
+    if (o.type == OP_PQMF) return launch_pqmf(x, o.wp, y, B, o.Cin, o.k, (int)Tin, s);
+    ConvParams p = {};
+    p.x = x;
+    p.wp = o.wp;
+    p.bias = o.bias;
+    p.res = res;
+    p.acc_in = acc;
+    p.y = y;
+    p.B = B;
+    p.Cin = o.Cin;
+    p.Cout = o.Cout;
+    p.Tin = (int)Tin;
+    p.pad_mode = o.pad_mode;
+    p.pre_slope = o.pre_slope;
+    p.out_div = o.out_div;
+    p.post = o.post;
+    p.Tout = (int)conv_out_len(o, Tin);
+    if (o.type == OP_CONV) {
+        p.M = o.Cout;
+        p.k = o.k;
+        p.dil = o.dil;
+        p.pad = o.pad;
+        p.ups = 1;
+        p.Tq = p.Tout;
+    } else {
+        const Polyphase ph = polyphase(o.k, o.stride, o.pad);
+        p.M = o.Cout * o.stride;
+        p.k = ph.taps;
+        p.dil = 1;
+        p.pad = -ph.dmin;
+        p.pad_mode = FV_PAD_ZERO;
+        p.ups = o.stride;
+        p.Tq = (p.Tout + o.stride - 1) / o.stride;
+    }
+    p.Mpad = pad_rows(p.M);
+    return launch_conv(p, s);
+}
+
+static int check_conv_args(int Cin, int Cout, int k, int dil) {
+    if (Cin <= 0 || Cout <= 0 || k <= 0 || dil <= 0)
+        return fail(FV_ERR_INVALID_ARG, "bad conv shape Cin=%d Cout=%d k=%d dil=%d", Cin, Cout, k, dil);
+    return 0;
+}
+
+}  // namespace fv
+
+using namespace fv;
+
+extern "C" {
+
+int fv_version(void) { return FV_ABI_VERSION; }
+
+const char* fv_last_error(void) { return g_err.c_str(); }
+
+int fv_fold_weight_norm(const float* v, const float* g, float* w, int dim0, int64_t inner,
+                        void* stream) {
+    if (dim0 <= 0 || inner <= 0) return fail(FV_ERR_INVALID_ARG, "fold: dim0=%d inner=%lld", dim0, (long long)inner);
+    hipLaunchKernelGGL(fold_weight_norm_kernel, dim3(dim0), dim3(256), 0, (hipStream_t)stream, v, g,
+                       w, inner);
+    FV_HIP(hipGetLastError());
+    return 0;
+}
+
+int64_t fv_packed_conv1d_floats(int Cout, int Cin, int k) {
+    return (int64_t)Cin * k * pad_rows(Cout);
+}
+
+int64_t fv_packed_conv_transpose1d_floats(int Cin, int Cout, int k, int stride, int pad) {
+    const Polyphase ph = polyphase(k, stride, pad);
+    return (int64_t)Cin * ph.taps * pad_rows(Cout * stride);
+}
+
+int fv_pack_conv1d_weight(const float* w, float* packed, int Cout, int Cin, int k, void* stream) {
+    if (int rc = check_conv_args(Cin, Cout, k, 1)) return rc;
+    const int Mpad = pad_rows(Cout);
+    const int64_t total = (int64_t)Cin * k * Mpad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_conv1d_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
+                       packed, Cout, Cin, k, Mpad);
+    FV_HIP(hipGetLastError());
+    return 0;
+}
+
+int fv_pack_conv_transpose1d_weight(const float* w, float* packed, int Cin, int Cout, int k,
+                                    int stride, int pad, void* stream) {
+    if (int rc = check_conv_args(Cin, Cout, k, 1)) return rc;
+    if (stride <= 0 || pad < 0) return fail(FV_ERR_INVALID_ARG, "convT stride=%d pad=%d", stride, pad);
+    const Polyphase ph = polyphase(k, stride, pad);
+    const int Mpad = pad_rows(Cout * stride);
+    const int64_t total = (int64_t)Cin * ph.taps * Mpad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_convT_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
+                       packed, Cin, Cout, k, stride, pad, ph.dmin, ph.taps, Mpad);
+    FV_HIP(hipGetLastError());
+    return 0;
+}
+
+int fv_conv1d_fused(const float* x, const float* packed, const float* bias, const float* res,
+                    const float* acc_in, float* y, int B, int Cin, int Cout, int Tin, int k,
+                    int dil, int pad, int pad_mode, float pre_slope, float out_div, int post,
+                    void* stream) {
+    if (int rc = check_conv_args(Cin, Cout, k, dil)) return rc;
+    if (!x || !packed || !y) return fail(FV_ERR_INVALID_ARG, "conv1d: null tensor");
+    if (x == y) return fail(FV_ERR_INVALID_ARG, "conv1d: y must not alias x");
+    Op o = {};
+    o.type = OP_CONV;
+    o.wp = packed;
+    o.bias = bias;
+    o.Cin = Cin;
+    o.Cout = Cout;
+    o.k = k;
+    o.dil = dil;
+    o.pad = pad;
+    o.pad_mode = pad_mode;
+    o.pre_slope = pre_slope;
+    o.out_div = out_div;
+    o.post = post;
+    if (conv_out_len(o, Tin) <= 0) return fail(FV_ERR_INVALID_ARG, "conv1d: empty output");
+    return run_op(o, x, y, res, acc_in, B, Tin, (hipStream_t)stream);
+}
+
+int fv_conv_transpose1d_fused(const float* x, const float* packed, const float* bias, float* y,
+                              int B, int Cin, int Cout, int Tin, int k, int stride, int pad,
+                              int out_pad, float pre_slope, int post, void* stream) {
+    if (int rc = check_conv_args(Cin, Cout, k, 1)) return rc;
+    if (!x || !packed || !y) return fail(FV_ERR_INVALID_ARG, "conv_transpose1d: null tensor");
+    if (stride <= 0 || pad < 0 || out_pad < 0 || out_pad >= stride + (stride == 1))
+        return fail(FV_ERR_INVALID_ARG, "conv_transpose1d: stride=%d pad=%d out_pad=%d", stride, pad, out_pad);
+    Op o = {};
+    o.type = OP_CONVT;
+    o.wp = packed;
+    o.bias = bias;
+    o.Cin = Cin;
+    o.Cout = Cout;
+    o.k = k;
+    o.stride = stride;
+    o.pad = pad;
+    o.out_pad = out_pad;
+    o.pre_slope = pre_slope;
+    o.out_div = 1.f;
+    o.post = post;
+    if (conv_out_len(o, Tin) <= 0) return fail(FV_ERR_INVALID_ARG, "conv_transpose1d: empty output");
+    return run_op(o, x, y, nullptr, nullptr, B, Tin, (hipStream_t)stream);
+}
+
+int fv_pqmf_synthesis(const float* x, const float* h, float* y, int B, int S, int ntaps, int Tsub,
+                      void* stream) {
+    if (!x || !h || !y || B < 0 || S <= 0 || ntaps <= 0 || ntaps % 2 == 0 || Tsub < 0)
+        return fail(FV_ERR_INVALID_ARG, "pqmf: B=%d S=%d ntaps=%d Tsub=%d", B, S, ntaps, Tsub);
+    return launch_pqmf(x, h, y, B, S, ntaps, Tsub, (hipStream_t)stream);
+}
+
+fv_plan_t* fv_plan_create(int in_channels) {
+    fv_plan* p = new fv_plan();
+    p->in_channels = in_channels;
+    return p;
+}
+
+void fv_plan_destroy(fv_plan_t* plan) { delete plan; }
+
+static int check_slot(int s, bool allow_none) {
+    if (s == FV_SLOT_NONE && allow_none) return 0;
+    if (s < 0 || s >= FV_MAX_SLOTS) return fail(FV_ERR_INVALID_ARG, "slot %d out of range", s);
+    return 0;
+}
+
+int fv_plan_add_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int res_slot, int acc_slot,
+                       const float* packed, const float* bias, int Cin, int Cout, int k, int dil,
+                       int pad, int pad_mode, float pre_slope, float out_div, int post) {
+    if (!plan || !packed) return fail(FV_ERR_INVALID_ARG, "plan_add_conv1d: null");
+    if (int rc = check_conv_args(Cin, Cout, k, dil)) return rc;
+    if (int rc = check_slot(x_slot, false)) return rc;
+    if (int rc = check_slot(y_slot, false)) return rc;
+    if (int rc = check_slot(res_slot, true)) return rc;
+    if (int rc = check_slot(acc_slot, true)) return rc;
+    if (y_slot == FV_SLOT_IN) return fail(FV_ERR_INVALID_ARG, "plan: the input slot is read-only");
+    Op o = {};
+    o.type = OP_CONV;
+    o.x = x_slot;
+    o.y = y_slot;
+    o.res = res_slot;
+    o.acc = acc_slot;
+    o.wp = packed;
+    o.bias = bias;
+    o.Cin = Cin;
+    o.Cout = Cout;
+    o.k = k;
+    o.dil = dil;
+    o.pad = pad;
+    o.pad_mode = pad_mode;
+    o.pre_slope = pre_slope;
+    o.out_div = out_div;
+    o.post = post;
+    plan->ops.push_back(o);
+    return 0;
+}
+
+int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot, const float* packed,
+                                 const float* bias, int Cin, int Cout, int k, int stride, int pad,
+                                 int out_pad, float pre_slope, int post) {
+    if (!plan || !packed) return fail(FV_ERR_INVALID_ARG, "plan_add_conv_transpose1d: null");
+    if (int rc = check_conv_args(Cin, Cout, k, 1)) return rc;
+    if (stride <= 0 || pad < 0 || out_pad < 0)
+        return fail(FV_ERR_INVALID_ARG, "convT stride=%d pad=%d out_pad=%d", stride, pad, out_pad);
+    if (int rc = check_slot(x_slot, false)) return rc;
+    if (int rc = check_slot(y_slot, false)) return rc;
+    if (y_slot == FV_SLOT_IN) return fail(FV_ERR_INVALID_ARG, "plan: the input slot is read-only");
+    Op o = {};
+    o.type = OP_CONVT;
+    o.x = x_slot;
+    o.y = y_slot;
+    o.res = FV_SLOT_NONE;
+    o.acc = FV_SLOT_NONE;
+    o.wp = packed;
+    o.bias = bias;
+    o.Cin = Cin;
+    o.Cout = Cout;
+    o.k = k;
+    o.stride = stride;
+    o.pad = pad;
+    o.out_pad = out_pad;
+    o.pre_slope = pre_slope;
+    o.out_div = 1.f;
+    o.post = post;
+    plan->ops.push_back(o);
+    return 0;
+}
+
+int fv_plan_add_pqmf_synthesis(fv_plan_t* plan, int x_slot, int y_slot, const float* h, int S,
+                               int ntaps) {
+    if (!plan || !h || S <= 0 || ntaps <= 0 || ntaps % 2 == 0)
+        return fail(FV_ERR_INVALID_ARG, "plan_add_pqmf: S=%d ntaps=%d", S, ntaps);
+    if (int rc = check_slot(x_slot, false)) return rc;
+    if (int rc = check_slot(y_slot, false)) return rc;
+    Op o = {};
+    o.type = OP_PQMF;
+    o.x = x_slot;
+    o.y = y_slot;
+    o.res = FV_SLOT_NONE;
+    o.acc = FV_SLOT_NONE;
+    o.wp = h;
+    o.Cin = S;
+    o.Cout = 1;
+    o.k = ntaps;
+    plan->ops.push_back(o);
+    return 0;
+}
+
+int fv_plan_output_shape(fv_plan_t* plan, int T, int* out_channels, int64_t* out_len) {
+    if (!plan) return fail(FV_ERR_INVALID_ARG, "null plan");
+    Shape sh[FV_MAX_SLOTS];
+    int64_t elems[FV_MAX_SLOTS];
+    if (int rc = infer(plan, 1, T, sh, elems)) return rc;
+    if (!sh[FV_SLOT_OUT].set) return fail(FV_ERR_INVALID_ARG, "plan never writes the output slot");
+    if (out_channels) *out_channels = sh[FV_SLOT_OUT].C;
+    if (out_len) *out_len = sh[FV_SLOT_OUT].T;
+    return 0;
+}
+
+int64_t fv_plan_workspace_bytes(fv_plan_t* plan, int B, int T) {
+    if (!plan) return fail(FV_ERR_INVALID_ARG, "null plan");
+    Shape sh[FV_MAX_SLOTS];
+    int64_t elems[FV_MAX_SLOTS];
+    if (int rc = infer(plan, B, T, sh, elems)) return rc < 0 ? rc : -rc;
+    int64_t bytes = 0;
+    for (int i = FV_SLOT_TMP0; i < FV_MAX_SLOTS; ++i) bytes += (elems[i] * 4 + 255) / 256 * 256;
+    return bytes;
+}
+
+int fv_plan_run(fv_plan_t* plan, int B, int T, const float* in, float* out, void* workspace,
+                int64_t workspace_bytes, void* stream) {
+    if (!plan || !in || !out) return fail(FV_ERR_INVALID_ARG, "plan_run: null argument");
+    if (B <= 0 || T <= 0) return fail(FV_ERR_INVALID_ARG, "plan_run: B=%d T=%d", B, T);
+    Shape sh[FV_MAX_SLOTS];
+    int64_t elems[FV_MAX_SLOTS];
+    if (int rc = infer(plan, B, T, sh, elems)) return rc;
+    float* base[FV_MAX_SLOTS] = {};
+    int64_t off = 0;
+    for (int i = FV_SLOT_TMP0; i < FV_MAX_SLOTS; ++i) {
+        base[i] = reinterpret_cast<float*>(static_cast<char*>(workspace) + off);
+        off += (elems[i] * 4 + 255) / 256 * 256;
+    }
+    if (off > workspace_bytes || (off > 0 && !workspace))
+        return fail(FV_ERR_WORKSPACE, "plan needs %lld workspace bytes, got %lld", (long long)off,
+                    (long long)workspace_bytes);
+    base[FV_SLOT_IN] = const_cast<float*>(in);
+    base[FV_SLOT_OUT] = out;
+    // shapes again, op by op (a slot may change shape when it is reused)
+    for (int i = 0; i < FV_MAX_SLOTS; ++i) sh[i].set = false;
+    sh[FV_SLOT_IN] = {plan->in_channels, T, true};
+    for (const Op& o : plan->ops) {
+        const int64_t Tin = sh[o.x].T;
+        const int64_t Tout = conv_out_len(o, Tin);
+        const float* res = o.res == FV_SLOT_NONE ? nullptr : base[o.res];
+        const float* acc = o.acc == FV_SLOT_NONE ? nullptr : base[o.acc];
+        if (int rc = run_op(o, base[o.x], base[o.y], res, acc, B, Tin, (hipStream_t)stream)) return rc;
+        sh[o.y] = {o.type == OP_PQMF ? 1 : o.Cout, Tout, true};
+    }
+    return 0;
+}
+
+int fv_plan_num_ops(fv_plan_t* plan) { return plan ? (int)plan->ops.size() : 0; }
+
+int fv_profile_enable(int on) {
+    g_prof_on = on != 0;
+    return 0;
+}
+
+int fv_profile_collect(int64_t* launches, double* ms, double* flops, double* bytes) {
+    double tms = 0, tf = 0, tb = 0;
+    for (ProfRec& r : g_prof) {
+        FV_HIP(hipEventSynchronize(r.b));
+        float e = 0.f;
+        FV_HIP(hipEventElapsedTime(&e, r.a, r.b));
+        tms += e;
+        tf += r.flops;
+        tb += r.bytes;
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    if (launches) *launches = (int64_t)g_prof.size();
+    if (ms) *ms = tms;
+    if (flops) *flops = tf;
+    if (bytes) *bytes = tb;
+    g_prof.clear();
+    return 0;
+}
+
+}  // extern "C"

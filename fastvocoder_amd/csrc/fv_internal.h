@@ -1,0 +1,74 @@
+// Internal declarations shared by the translation units of libfastvocoder_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fastvocoder_hip.h"
+
+namespace fv {
+
+int fail(int code, const char* fmt, ...);
+
+#define FV_HIP(call)                                                              \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess)                                                     \
+            return ::fv::fail((int)e_, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Rows of the packed weight image are padded so that every M tile is full.
+static inline int pad_rows(int M) { return M <= 16 ? 16 : round_up(M, 32); }
+
+// Polyphase view of ConvTranspose1d(k, stride s, padding p): output phase r of
+// out[q*s + r] reads input taps x[q + delta], delta in [dmin, dmax].
+struct Polyphase {
+    int dmin, dmax, taps;  // taps = dmax - dmin + 1
+};
+static inline Polyphase polyphase(int k, int s, int p) {
+    int dmin = 1 << 30, dmax = -(1 << 30);
+    for (int r = 0; r < s; ++r) {
+        int a = (r + p) % s, c = (r + p) / s;
+        for (int j = a, m = 0; j < k; j += s, ++m) {
+            int d = c - m;
+            if (d < dmin) dmin = d;
+            if (d > dmax) dmax = d;
+        }
+    }
+    if (dmin > dmax) { dmin = 0; dmax = 0; }
+    Polyphase ph = {dmin, dmax, dmax - dmin + 1};
+    return ph;
+}
+
+// Everything one implicit-GEMM conv launch needs.  The GEMM is
+//   Y[m, q] = sum_{ci, j} Wp[ci, j, m] * act(X[ci, q + j*dil - pad])
+// with M rows (= Cout, or Cout*stride phases for a transposed conv) and Tq
+// columns per batch item; the epilogue scatters row m / column q to
+// y[co, q*ups + ph] with co = m / ups, ph = m % ups.
+struct ConvParams {
+    const float* x;
+    const float* wp;      // [Cin*k][Mpad]
+    const float* bias;    // [Cout] or null
+    const float* res;     // [B,Cout,Tout] or null
+    const float* acc_in;  // [B,Cout,Tout] or null
+    float* y;             // [B,Cout,Tout]
+    int B, Cin, M, Mpad, Cout;
+    int Tin, Tq, Tout;
+    int k, dil, pad, pad_mode;
+    int ups;              // 1 for Conv1d, stride for ConvTranspose1d
+    float pre_slope, out_div;
+    int post;
+    // filled in by the launcher
+    int ci_chunk, xw, vec_ok;
+};
+
+int launch_conv(ConvParams p, hipStream_t stream);
+int launch_pqmf(const float* x, const float* h, float* y, int B, int S, int ntaps, int Tsub,
+                hipStream_t stream);
+
+// measurement hook
+void profile_begin(hipStream_t stream);
+void profile_end(hipStream_t stream, double flops, double bytes);
+
+}  // namespace fv

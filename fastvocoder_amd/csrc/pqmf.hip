@@ -1,0 +1,56 @@
+// PQMF synthesis filter bank in polyphase form (reference:
+// model/generator/pqmf.py:121-135).
+//
+// The reference zero-stuffs each of the S sub-bands by S (a one-hot
+// ConvTranspose1d, scaled by S) and runs a dense (ntaps = 63)-tap FIR over the
+// S channels: y[n] = sum_k sum_j h[k][j] * u_k[n + j - half], u_k[S*m] = S*x_k[m].
+// Only taps with (n + j - half) % S == 0 see a non-zero sample, so per output
+// sample there are at most ceil(ntaps/S) = 16 live taps per band:
+//   j = j0 + S*i,  j0 = (half - n) mod S,  m = (n + j0 - half)/S + i.
+// HBM-bound (~16 FLOP/B): one thread per output sample, coalesced store; the
+// S*ntaps filter (pre-scaled by S) sits in LDS, and the sub-band reads of
+// neighbouring lanes hit the same or adjacent words (L1-resident).
+#include "fv_internal.h"
+
+namespace fv {
+
+__global__ __launch_bounds__(256) void pqmf_synthesis_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ h,
+                                                             float* __restrict__ y, int S,
+                                                             int ntaps, int Tsub) {
+    extern __shared__ float hs[];  // [S][ntaps], scaled by S
+    for (int i = threadIdx.x; i < S * ntaps; i += 256) hs[i] = h[i] * (float)S;
+    __syncthreads();
+    const int64_t T = (int64_t)S * Tsub;
+    const int b = blockIdx.y;
+    const int half = (ntaps - 1) / 2;
+    for (int64_t n = blockIdx.x * 256LL + threadIdx.x; n < T; n += (int64_t)gridDim.x * 256) {
+        int j0 = (int)((half - n) % S);
+        if (j0 < 0) j0 += S;
+        const int64_t mbase = (n + j0 - half) / S;  // exact: divisible by construction
+        float acc = 0.f;
+        for (int kb = 0; kb < S; ++kb) {
+            const float* xr = x + ((size_t)b * S + kb) * (size_t)Tsub;
+            const float* hr = hs + kb * ntaps;
+            for (int j = j0, i = 0; j < ntaps; j += S, ++i) {
+                const int64_t m = mbase + i;
+                if (m >= 0 && m < Tsub) acc = fmaf(hr[j], xr[m], acc);
+            }
+        }
+        y[(size_t)b * T + n] = acc;
+    }
+}
+
+int launch_pqmf(const float* x, const float* h, float* y, int B, int S, int ntaps, int Tsub,
+                hipStream_t s) {
+    if (B <= 0 || Tsub <= 0) return 0;
+    const int64_t T = (int64_t)S * Tsub;
+    int64_t blocks = (T + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pqmf_synthesis_kernel, dim3((unsigned)blocks, B), dim3(256),
+                       (size_t)S * ntaps * sizeof(float), s, x, h, y, S, ntaps, Tsub);
+    FV_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace fv

@@ -1,0 +1,193 @@
+"""Host-side glue between torch parameter containers and native plans.
+
+A generator here is a tree of ordinary ``torch.nn`` modules that exist ONLY to
+own parameters under the reference's names (so ``state_dict()`` /
+``load_state_dict()`` / ``.to()`` / weight-norm utilities behave exactly like
+the reference's) -- their own ``forward`` is never
+called.  Arithmetic happens in libfastvocoder_hip.so: a module *emits* its ops
+into a :class:`PlanBuilder`, which folds weight norm and packs every weight on
+the GPU once, and the resulting native plan is replayed for every call until a
+parameter changes.
+"""
+import warnings
+
+import torch
+
+from .. import _native
+from .._native import (PAD_REFLECT, PAD_ZERO, POST_NONE, POST_RELU, POST_TANH,  # noqa: F401
+                       SLOT_IN, SLOT_NONE, SLOT_OUT)
+
+
+def weight_norm(module):
+    """torch.nn.utils.weight_norm without its deprecation chatter; keeps the
+    ``weight_g`` / ``weight_v`` key names the reference's checkpoints use."""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return torch.nn.utils.weight_norm(module)
+
+
+def effective_weight(conv):
+    """Folded weight of a Conv1d / ConvTranspose1d container, computed on the
+    GPU (fv_fold_weight_norm) when weight norm is attached."""
+    if hasattr(conv, "weight_g") and hasattr(conv, "weight_v"):
+        return _native.fold_weight_norm(conv.weight_v, conv.weight_g)
+    return conv.weight.detach().contiguous().float()
+
+
+class PlanBuilder:
+    """Accumulates ops into a native plan; slots are small integers naming
+    tensors (SLOT_IN / SLOT_OUT / temporaries handed out by :meth:`tmp`)."""
+
+    def __init__(self, in_channels):
+        self.plan = _native.Plan(in_channels)
+        self._next = _native.SLOT_TMP0
+
+    def tmp(self):
+        s = self._next
+        if s >= _native.MAX_SLOTS:
+            raise _native.NativeError("plan needs more than %d tensor slots" % _native.MAX_SLOTS)
+        self._next += 1
+        return s
+
+    @staticmethod
+    def _bias(conv):
+        return None if conv.bias is None else conv.bias.detach().contiguous().float()
+
+    def conv(self, conv, src, dst, pad=None, pad_mode=PAD_ZERO, pre_slope=1.0, res=SLOT_NONE,
+             acc=SLOT_NONE, out_div=1.0, post=POST_NONE):
+        """Emit ``conv`` (a torch.nn.Conv1d container): dst = epilogue(conv(act(src)))."""
+        if conv.stride[0] != 1 or conv.groups != 1:
+            raise _native.NativeError("only stride-1, groups-1 Conv1d layers exist on this path")
+        k, d = conv.kernel_size[0], conv.dilation[0]
+        if pad is None:
+            pad = conv.padding[0]
+        packed = _native.pack_conv1d(effective_weight(conv))
+        self.plan.add_conv1d(src, dst, packed, self._bias(conv), conv.in_channels, conv.out_channels,
+                             k, dil=d, pad=pad, pad_mode=pad_mode, pre_slope=pre_slope, res=res,
+                             acc=acc, out_div=out_div, post=post)
+
+    def conv_transpose(self, convt, src, dst, pre_slope=1.0, post=POST_NONE):
+        """Emit a torch.nn.ConvTranspose1d container in polyphase form."""
+        if convt.groups != 1 or convt.dilation[0] != 1:
+            raise _native.NativeError("only dense, undilated ConvTranspose1d layers exist on this path")
+        k, s = convt.kernel_size[0], convt.stride[0]
+        p, op = convt.padding[0], convt.output_padding[0]
+        packed = _native.pack_conv_transpose1d(effective_weight(convt), s, p)
+        self.plan.add_conv_transpose1d(src, dst, packed, self._bias(convt), convt.in_channels,
+                                       convt.out_channels, k, s, p, op, pre_slope=pre_slope, post=post)
+
+    def basis_overlap_add(self, basis_weight, src, dst, hop, pre_slope=1.0):
+        """frames = act(src)^T @ W^T then overlap-add with hop: a ConvTranspose1d
+        with Cout = 1, kernel L, stride hop (weight [C,1,L] = W^T)."""
+        L, C = basis_weight.shape
+        w = basis_weight.detach().float().t().contiguous().view(C, 1, L)
+        packed = _native.pack_conv_transpose1d(w, hop, 0)
+        self.plan.add_conv_transpose1d(src, dst, packed, None, C, 1, L, hop, 0, 0,
+                                       pre_slope=pre_slope)
+
+    def pqmf_synthesis(self, synthesis_filter, src, dst):
+        S = synthesis_filter.shape[1]
+        h = synthesis_filter.detach().reshape(S, -1).contiguous().float()
+        self.plan.add_pqmf_synthesis(src, dst, h)
+
+
+class NativeModule(torch.nn.Module):
+    """Base of every module on the path: caches native plans keyed by a name and
+    rebuilds them when any parameter/buffer was modified, replaced or moved."""
+
+    def __init__(self):
+        super().__init__()
+        self._fv_plans = {}
+        self._fv_tensors = None
+
+    # -- cache bookkeeping -------------------------------------------------
+    def _fv_state(self):
+        if self._fv_tensors is None:
+            self._fv_tensors = list(self.parameters()) + list(self.buffers())
+        return sum(t._version for t in self._fv_tensors)
+
+    def invalidate_plans(self):
+        """Drop cached native plans (packed weights).  Called automatically on
+        load_state_dict / .to() / weight-norm changes / in-place parameter
+        updates; call it by hand after writing through ``param.data``."""
+        self._fv_plans = {}
+        self._fv_tensors = None
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        for m in self.modules():
+            if isinstance(m, NativeModule):
+                m.invalidate_plans()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        for m in self.modules():
+            if isinstance(m, NativeModule):
+                m.invalidate_plans()
+        return out
+
+    def _device(self):
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise _native.NativeError(
+                f"{type(self).__name__} lives on {dev}: fastvocoder_amd runs only on a ROCm "
+                "device (model.to('cuda')); there is no CPU fallback")
+        return dev
+
+    def _plan(self, name, emit, in_channels):
+        """Return the cached plan ``name`` or build it with ``emit(builder)``."""
+        state = self._fv_state()
+        hit = self._fv_plans.get(name)
+        if hit is not None and hit[0] == state:
+            return hit[1]
+        with torch.no_grad():
+            pb = PlanBuilder(in_channels)
+            emit(pb)
+        self._fv_plans[name] = (state, pb.plan)
+        return pb.plan
+
+    def _prepare(self, x):
+        """Any array-like -> contiguous fp32 tensor on this module's device."""
+        dev = self._device()
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(x, dtype=torch.float)
+        return x.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+    # -- weight-norm lifecycle (reference hifigan.py:58-90 and siblings) ----
+    def remove_weight_norm(self):
+        """Remove weight normalization module from all of the layers."""
+        def _remove(m):
+            try:
+                torch.nn.utils.remove_weight_norm(m)
+            except ValueError:  # this module didn't have weight norm
+                return
+        self.apply(_remove)
+        for m in self.modules():
+            if isinstance(m, NativeModule):
+                m.invalidate_plans()
+
+    def apply_weight_norm(self):
+        """Apply weight normalization module from all of the layers."""
+        def _apply(m):
+            if isinstance(m, (torch.nn.Conv1d, torch.nn.ConvTranspose1d)) and not hasattr(m, "weight_g"):
+                weight_norm(m)
+        self.apply(_apply)
+        for m in self.modules():
+            if isinstance(m, NativeModule):
+                m.invalidate_plans()
+
+    _RESET_STD = 0.01
+
+    def reset_parameters(self):
+        """``m.weight.data.normal_(0, std)`` on every conv, like the reference.
+        With weight norm attached ``weight`` is the derived tensor, so -- exactly
+        as in the reference -- this has no effect on
+        the next forward; after remove_weight_norm it re-initialises for real."""
+        def _reset(m):
+            if isinstance(m, (torch.nn.Conv1d, torch.nn.ConvTranspose1d)):
+                m.weight.data.normal_(0.0, self._RESET_STD)
+        self.apply(_reset)
+        for m in self.modules():
+            if isinstance(m, NativeModule):
+                m.invalidate_plans()

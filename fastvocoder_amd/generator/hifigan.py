@@ -1,0 +1,147 @@
+"""HiFi-GAN and Multiband-HiFi-GAN generators on libfastvocoder_hip.so.
+
+Same constructor kwargs (the conf/hifigan/*.yaml and conf/multiband-hifigan/*.yaml
+keys), method set and ``state_dict`` keys as the reference's
+``HiFiGANGenerator`` (/root/reference/model/generator/hifigan.py:13-129) and
+``MultiBandHiFiGANGenerator`` (multiband_hifigan.py:14-137).
+
+Graph (hifigan.py:92-106):
+    x = conv_pre(mel)
+    per stage i:  x = ConvTranspose1d_i(lrelu(x, 0.1));  x = mean_j ResBlock_{i,j}(x)
+    y = tanh(conv_post(lrelu(x, 0.01)))          # default slope 0.01, not 0.1
+Every activation, bias, residual add, the MRF sum and its /num_kernels, and
+tanh are epilogue/prologue work of the conv kernels: the whole forward is
+``num_convs`` launches (78 for the shipped 4-stage configs) and nothing else.
+"""
+import torch
+
+from .engine import NativeModule, POST_TANH, SLOT_IN, SLOT_NONE, SLOT_OUT, weight_norm  # noqa: F401
+from .modules import LRELU_SLOPE, ResBlock1, ResBlock2, UpsampleLayer
+from .pqmf import PQMF
+
+DEFAULT_LRELU_SLOPE = 0.01  # F.leaky_relu's default, used before conv_post (hifigan.py:104)
+
+
+class _HiFiGANBase(NativeModule):
+    _post_channels = 1
+
+    def __init__(self, resblock_kernel_sizes, upsample_rates, upsample_initial_channel,
+                 resblock_type, upsample_kernel_sizes, resblock_dilation_sizes, transposedconv,
+                 bias):
+        super().__init__()
+        self.num_kernels = len(resblock_kernel_sizes)
+        self.num_upsamples = len(upsample_rates)
+        c0 = upsample_initial_channel
+        self.conv_pre = torch.nn.Conv1d(80, c0, 7, 1, padding=3, bias=bias)
+        block = ResBlock1 if resblock_type == "1" else ResBlock2
+
+        self.ups = torch.nn.ModuleList()
+        for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)):
+            cin, cout = c0 // (2 ** i), c0 // (2 ** (i + 1))
+            if transposedconv:
+                up = torch.nn.ConvTranspose1d(cin, cout, k, u, padding=(u // 2 + u % 2),
+                                              output_padding=u % 2, bias=bias)
+            else:
+                up = UpsampleLayer(cin, cout, upsample_rate=u, kernel_size=k, stride=1,
+                                   padding=k // 2, bias=bias)
+            self.ups.append(up)
+
+        self.resblocks = torch.nn.ModuleList()
+        ch = c0
+        for i in range(len(self.ups)):
+            ch = c0 // (2 ** (i + 1))
+            for k, d in zip(resblock_kernel_sizes, resblock_dilation_sizes):
+                self.resblocks.append(block(ch, k, d, bias=bias))
+        self.conv_post = torch.nn.Conv1d(ch, self._post_channels, 7, 1, padding=3, bias=bias)
+
+    def _finish_init(self):
+        # same order as the reference: weight norm first, then the (therefore
+        # ineffective) normal_(0, 0.01) reset -- SURVEY.md section 8 a-13
+        self.apply_weight_norm()
+        self.reset_parameters()
+
+    # -- op emission ---------------------------------------------------------
+    def _emit_trunk(self, pb, dst):
+        """mel (SLOT_IN) -> tanh(conv_post(...)) in ``dst``."""
+        x, up, acc = pb.tmp(), pb.tmp(), pb.tmp()
+        scratch = [pb.tmp(), pb.tmp(), pb.tmp()]
+        pb.conv(self.conv_pre, SLOT_IN, x)
+        nk = self.num_kernels
+        for i in range(self.num_upsamples):
+            if isinstance(self.ups[i], UpsampleLayer):
+                raise NotImplementedError(
+                    "transposedconv: False (UpsampleLayer) has no HIP kernel yet; every shipped "
+                    "conf/*.yaml uses transposedconv: True")
+            pb.conv_transpose(self.ups[i], x, up, pre_slope=LRELU_SLOPE)
+            for j in range(nk):
+                last = j == nk - 1
+                # running sum in `acc` in resblock order, mean folded into the
+                # last block's final epilogue (reference hifigan.py:97-103)
+                self.resblocks[i * nk + j].emit(
+                    pb, up, x if last else acc, scratch,
+                    acc=acc if j > 0 else SLOT_NONE,
+                    out_div=float(nk) if last else 1.0)
+        pb.conv(self.conv_post, x, dst, pre_slope=DEFAULT_LRELU_SLOPE, post=POST_TANH)
+
+    def _trunk(self, x):
+        return self._plan("trunk", lambda pb: self._emit_trunk(pb, SLOT_OUT), 80).run(x)
+
+
+class HiFiGANGenerator(_HiFiGANBase):
+    """Drop-in for the reference ``HiFiGANGenerator``."""
+
+    def __init__(self, resblock_kernel_sizes=[3, 7, 11], upsample_rates=[8, 5, 3, 2],
+                 upsample_initial_channel=256, resblock_type="1",
+                 upsample_kernel_sizes=[16, 10, 6, 4],
+                 resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+                 transposedconv=True, bias=True):
+        super().__init__(resblock_kernel_sizes, upsample_rates, upsample_initial_channel,
+                         resblock_type, upsample_kernel_sizes, resblock_dilation_sizes,
+                         transposedconv, bias)
+        self._finish_init()
+
+    def forward(self, x):
+        """x [B,80,T] -> waveform [B, prod(upsample_rates)*T]."""
+        return self._trunk(self._prepare(x))[:, 0, :]
+
+    def inference(self, x):
+        """x [T,80] (ndarray or tensor) -> 1-D waveform."""
+        x = self._prepare(x)
+        return self._trunk(x.transpose(1, 0).unsqueeze(0).contiguous()).squeeze()
+
+
+class MultiBandHiFiGANGenerator(_HiFiGANBase):
+    """Drop-in for the reference ``MultiBandHiFiGANGenerator``: ``forward``
+    returns the 4 sub-bands, ``inference`` adds PQMF synthesis."""
+
+    _post_channels = 4
+
+    def __init__(self, resblock_kernel_sizes=[3, 7, 11], upsample_rates=[10, 6],
+                 upsample_initial_channel=256, resblock_type="1",
+                 upsample_kernel_sizes=[20, 12],
+                 resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+                 transposedconv=True, bias=True):
+        super().__init__(resblock_kernel_sizes, upsample_rates, upsample_initial_channel,
+                         resblock_type, upsample_kernel_sizes, resblock_dilation_sizes,
+                         transposedconv, bias)
+        self.pqmf = PQMF()
+        self._finish_init()
+
+    def forward(self, x):
+        """x [B,80,T] -> sub-bands [B,4,T'] (the caller applies pqmf.synthesis,
+        reference bin/train.py:96)."""
+        return self._trunk(self._prepare(x))
+
+    def _emit_full(self, pb):
+        sub = pb.tmp()
+        self._emit_trunk(pb, sub)
+        pb.pqmf_synthesis(self.pqmf.synthesis_filter, sub, SLOT_OUT)
+
+    def inference(self, x):
+        """x [T,80] -> 1-D full-band waveform (trunk + PQMF synthesis, one plan)."""
+        x = self._prepare(x).transpose(1, 0).unsqueeze(0).contiguous()
+        return self._plan("inference", self._emit_full, 80).run(x).squeeze()
+
+    def synthesize_batch(self, x):
+        """x [B,80,T] -> full-band waveforms [B, 4*T'] (batched ``inference``)."""
+        return self._plan("inference", self._emit_full, 80).run(self._prepare(x))[:, 0, :]

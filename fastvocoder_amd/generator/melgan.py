@@ -1,0 +1,197 @@
+"""MelGAN and Basis-MelGAN generators on libfastvocoder_hip.so.
+
+Same constructor kwargs (conf/melgan/original.yaml, conf/basis-melgan/light.yaml
+keys), methods and ``state_dict`` keys as the reference's ``MelGANGenerator``
+(/root/reference/model/generator/melgan.py:17-185) and ``BasisMelGANGenerator``
+(basis_melgan.py:19-212).  The ``melgan`` attribute is a ``Sequential`` with the
+reference's exact index layout (pad, conv, then per upsample: act, ConvTranspose1d,
+``stacks`` x ResidualStack, ...) because checkpoint keys are ``melgan.<index>.*``;
+it is a parameter container only -- calls go through native plans.
+"""
+import torch
+
+from .engine import NativeModule, POST_NONE, POST_RELU, POST_TANH, SLOT_IN, SLOT_OUT
+from .modules import (BasisSignalLayer, LastLayer, ResidualStack, UpsampleLayer,
+                      _activation_slope, _pad_mode)
+
+
+class _MelGANTrunk(NativeModule):
+    _RESET_STD = 0.02  # reference melgan.py:166
+
+    def _build_layers(self, in_channels, kernel_size, channels, bias, upsample_scales,
+                      stack_kernel_size, stacks, nonlinear_activation,
+                      nonlinear_activation_params, pad, pad_params, use_causal_conv,
+                      transposedconv=True):
+        if use_causal_conv:
+            raise NotImplementedError(
+                "use_causal_conv=True is not built: no shipped conf/*.yaml enables it "
+                "(SURVEY.md section 2, row 5)")
+        assert (kernel_size - 1) % 2 == 0, "Not support even number kernel size."
+        self._slope = _activation_slope(nonlinear_activation, nonlinear_activation_params)
+        self._first_pad = ((kernel_size - 1) // 2, _pad_mode(pad, pad_params))
+        self._in_channels = in_channels
+        act = getattr(torch.nn, nonlinear_activation)
+        layers = [getattr(torch.nn, pad)((kernel_size - 1) // 2, **pad_params),
+                  torch.nn.Conv1d(in_channels, channels[0], kernel_size, bias=bias)]
+        for i, s in enumerate(upsample_scales):
+            layers.append(act(**nonlinear_activation_params))
+            if transposedconv:
+                layers.append(torch.nn.ConvTranspose1d(
+                    channels[i], channels[i + 1], s * 2, stride=s, padding=s // 2 + s % 2,
+                    output_padding=s % 2, bias=bias))
+            else:
+                layers.append(UpsampleLayer(channels[i], channels[i + 1], upsample_rate=s,
+                                            kernel_size=s * 2 + 1, stride=1, padding=s, bias=bias))
+            for j in range(stacks):
+                layers.append(ResidualStack(
+                    kernel_size=stack_kernel_size, channels=channels[i + 1],
+                    dilation=stack_kernel_size ** j, bias=bias,
+                    nonlinear_activation=nonlinear_activation,
+                    nonlinear_activation_params=nonlinear_activation_params,
+                    pad=pad, pad_params=pad_params, use_causal_conv=use_causal_conv))
+        return layers
+
+    def _emit_layers(self, pb, dst, final_post):
+        """Walk the Sequential and emit it; the activation modules are folded into
+        the next conv's input stage, and ``final_post`` (tanh / ReLU) into the
+        last conv's epilogue."""
+        mods = list(self.melgan)
+        # index of the last module that owns a conv (gets dst + final_post)
+        convy = [n for n, m in enumerate(mods)
+                 if isinstance(m, (torch.nn.Conv1d, torch.nn.ConvTranspose1d, ResidualStack, LastLayer))]
+        last = convy[-1]
+        a, b = pb.tmp(), pb.tmp()
+        scratch = [pb.tmp(), pb.tmp()]
+        cur, pending_slope = SLOT_IN, 1.0
+        for n, m in enumerate(mods):
+            is_last = n == last
+            nxt = dst if is_last else (a if cur != a else b)
+            post = final_post if is_last else POST_NONE
+            if isinstance(m, torch.nn.Conv1d):
+                pad, mode = self._first_pad
+                pb.conv(m, cur, nxt, pad=pad, pad_mode=mode, pre_slope=pending_slope, post=post)
+            elif isinstance(m, torch.nn.ConvTranspose1d):
+                pb.conv_transpose(m, cur, nxt, pre_slope=pending_slope, post=post)
+            elif isinstance(m, ResidualStack):
+                m.emit(pb, cur, nxt, scratch, post=post)
+            elif isinstance(m, LastLayer):
+                m.emit(pb, cur, nxt, post=post)
+            elif isinstance(m, UpsampleLayer):
+                raise NotImplementedError(
+                    "transposedconv: False (UpsampleLayer) has no HIP kernel yet; every shipped "
+                    "conf/*.yaml uses transposedconv: True")
+            elif isinstance(m, (torch.nn.LeakyReLU, torch.nn.ReLU)):
+                pending_slope = 0.0 if isinstance(m, torch.nn.ReLU) else float(m.negative_slope)
+                continue
+            else:
+                continue  # the leading pad module and the trailing Tanh/ReLU are fused
+            cur, pending_slope = nxt, 1.0
+
+
+class MelGANGenerator(_MelGANTrunk):
+    """Drop-in for the reference ``MelGANGenerator``."""
+
+    def __init__(self, in_channels=80, out_channels=1, kernel_size=7,
+                 channels=[512, 256, 128, 64, 32], bias=True, upsample_scales=[10, 6, 2, 2],
+                 stack_kernel_size=3, stacks=3, nonlinear_activation="LeakyReLU",
+                 nonlinear_activation_params={"negative_slope": 0.2}, pad="ReflectionPad1d",
+                 pad_params={}, use_final_nonlinear_activation=True, use_weight_norm=True,
+                 use_causal_conv=False):
+        super().__init__()
+        layers = self._build_layers(in_channels, kernel_size, channels, bias, upsample_scales,
+                                    stack_kernel_size, stacks, nonlinear_activation,
+                                    nonlinear_activation_params, pad, pad_params, use_causal_conv)
+        layers.append(LastLayer(channels[-1], out_channels, nonlinear_activation,
+                                nonlinear_activation_params, pad, kernel_size, pad_params, bias))
+        self._final_post = POST_TANH if use_final_nonlinear_activation else POST_NONE
+        if use_final_nonlinear_activation:
+            layers.append(torch.nn.Tanh())
+        self.melgan = torch.nn.Sequential(*layers)
+        if use_weight_norm:
+            self.apply_weight_norm()
+        self.reset_parameters()
+        self.pqmf = None  # attribute kept for parity with the reference (melgan.py:123)
+
+    def _run(self, x):
+        return self._plan("trunk", lambda pb: self._emit_layers(pb, SLOT_OUT, self._final_post),
+                          self._in_channels).run(x)
+
+    def forward(self, c):
+        """c [B,in_channels,T] -> [B, T*prod(upsample_scales)] (channel 0)."""
+        return self._run(self._prepare(c))[:, 0, :]
+
+    def inference(self, c):
+        """c [T,in_channels] -> squeezed waveform."""
+        c = self._prepare(c)
+        return self._run(c.transpose(1, 0).unsqueeze(0).contiguous()).squeeze()
+
+
+class BasisMelGANGenerator(_MelGANTrunk):
+    """Drop-in for the reference ``BasisMelGANGenerator``: a MelGAN-style trunk
+    that ends in ReLU and predicts per-frame weights over a learned basis
+    (``basis_signal_weight [L, out_channels]``); samples = overlap-add of
+    ``weight @ basis^T`` with hop L/2."""
+
+    def __init__(self, basis_signal_weight, L=30, in_channels=80, out_channels=256, kernel_size=7,
+                 channels=[256, 256, 256], bias=True, upsample_scales=[4, 4], stack_kernel_size=3,
+                 stacks=3, nonlinear_activation="LeakyReLU",
+                 nonlinear_activation_params={"negative_slope": 0.2}, pad="ReflectionPad1d",
+                 pad_params={}, use_final_nonlinear_activation=True, use_weight_norm=True,
+                 use_causal_conv=False, transposedconv=True, lastlinear=False):
+        super().__init__()
+        if lastlinear:
+            raise NotImplementedError("lastlinear=True (BatchNorm head, reference modules.py:116-132) "
+                                      "is used by no shipped config and is not built")
+        layers = self._build_layers(in_channels, kernel_size, channels, bias, upsample_scales,
+                                    stack_kernel_size, stacks, nonlinear_activation,
+                                    nonlinear_activation_params, pad, pad_params, use_causal_conv,
+                                    transposedconv)
+        self._final_post = POST_RELU if use_final_nonlinear_activation else POST_NONE
+        if use_final_nonlinear_activation:
+            layers.append(torch.nn.ReLU())
+        self.melgan = torch.nn.Sequential(*layers)
+        self.L = L
+        self.basis_signal = BasisSignalLayer(basis_signal_weight, L=L)
+        if use_weight_norm:
+            self.apply_weight_norm()
+        self.reset_parameters()
+        self.pqmf = None
+
+    def _weights(self, x):
+        """Trunk + ReLU in its native layout [B, C, F]."""
+        return self._plan("trunk", lambda pb: self._emit_layers(pb, SLOT_OUT, self._final_post),
+                          self._in_channels).run(x)
+
+    def _emit_full(self, pb):
+        w = pb.tmp()
+        self._emit_layers(pb, w, self._final_post)
+        self.basis_signal.emit(pb, w, SLOT_OUT)
+
+    def _samples(self, x):
+        """mel [B,C,T] -> [B, (F-1)*L/2 + L] in one plan (weights stay on chip/HBM
+        scratch, no [B,F,L] frame tensor)."""
+        return self._plan("full", self._emit_full, self._in_channels).run(x)[:, 0, :]
+
+    def forward(self, c):
+        """Reference semantics (basis_melgan.py:140-162): runs the zero-mel pass
+        too and returns (est - zero_est [B, F*L/2], weight - zero_weight [B,F,C])."""
+        c = self._prepare(c)
+        zero = torch.zeros_like(c)
+        hop = self.L // 2
+        outs = []
+        for inp in (zero, c):
+            w = self._weights(inp)                                   # [B,C,F]
+            src = self._plan("ola", lambda pb: self.basis_signal.emit(pb, SLOT_IN, SLOT_OUT),
+                             w.shape[1]).run(w)[:, 0, :]
+            outs.append((src[:, : w.shape[2] * hop], w.transpose(1, 2)))
+        (zs, zw), (s, w) = outs
+        return s - zs, w - zw
+
+    def inference(self, c):
+        """c [T,in_channels] -> squeezed waveform of (F-1)*L/2 + L samples."""
+        c = self._prepare(c)
+        return self._samples(c.transpose(1, 0).unsqueeze(0).contiguous()).squeeze()
+
+    def test(self, weight):
+        """weight [B,F,C] -> basis synthesis only (reference basis_melgan.py:210-212)."""
+        return self.basis_signal(weight)

@@ -1,0 +1,229 @@
+"""Building blocks of the four generators, as parameter containers that emit
+native ops (see engine.py).  Names, constructor arguments and ``state_dict``
+keys follow /root/reference/model/generator/modules.py so checkpoints and
+calling code carry over; the arithmetic is in csrc/.
+
+Each block can also be called on its own (``block(x)``, x ``[B,C,T]`` on a ROCm
+device): it then runs a private plan SLOT_IN -> SLOT_OUT.
+"""
+import torch
+
+from .engine import (NativeModule, PAD_REFLECT, PAD_ZERO, POST_NONE, SLOT_IN, SLOT_NONE,
+                     SLOT_OUT)
+from .. import _native
+
+LRELU_SLOPE = 0.1  # reference modules.py:9
+
+
+def get_padding(kernel_size, dilation=1):
+    """'same' padding of a dilated odd kernel (reference modules.py:186-187)."""
+    return int((kernel_size * dilation - dilation) / 2)
+
+
+def _resblock_conv(channels, kernel_size, dilation, bias):
+    """Conv1d container initialised like the reference's Conv1d subclass
+    (modules.py:92-103: kaiming-normal weight, zero bias)."""
+    conv = torch.nn.Conv1d(channels, channels, kernel_size, 1, dilation=dilation,
+                           padding=get_padding(kernel_size, dilation), bias=bias)
+    torch.nn.init.kaiming_normal_(conv.weight, nonlinearity="relu")
+    if conv.bias is not None:
+        torch.nn.init.constant_(conv.bias, 0.0)
+    return conv
+
+
+class _Block(NativeModule):
+    """A [B,C,T] -> [B,C,T] block: standalone ``forward`` via a private plan."""
+
+    channels = None
+
+    def emit(self, pb, src, dst, scratch, **epilogue):
+        raise NotImplementedError
+
+    def scratch_slots(self):
+        return 0
+
+    def forward(self, x):
+        x = self._prepare(x)
+
+        def build(pb):
+            self.emit(pb, SLOT_IN, SLOT_OUT, [pb.tmp() for _ in range(self.scratch_slots())])
+        return self._plan("forward", build, self.channels).run(x)
+
+
+class ResBlock1(_Block):
+    """HiFi-GAN residual block, three (dilated conv, conv) pairs
+    (reference modules.py:190-230):  x <- x + c2(lrelu(c1(lrelu(x))))."""
+
+    def __init__(self, channels, kernel_size=3, dilation=(1, 3, 5), bias=True):
+        super().__init__()
+        self.channels = channels
+        self.convs1 = torch.nn.ModuleList(
+            [_resblock_conv(channels, kernel_size, d, bias) for d in dilation])
+        self.convs2 = torch.nn.ModuleList(
+            [_resblock_conv(channels, kernel_size, 1, bias) for _ in dilation])
+
+    def scratch_slots(self):
+        return 3
+
+    def emit(self, pb, src, dst, scratch, acc=SLOT_NONE, out_div=1.0):
+        """src -> dst through the pairs; the LAST conv's epilogue also carries the
+        caller's running MRF sum (``acc``) and mean (``out_div``)."""
+        mid, ping, pong = scratch
+        cur = src
+        n = len(self.convs1)
+        for i, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
+            last = i == n - 1
+            nxt = dst if last else (ping if cur != ping else pong)
+            pb.conv(c1, cur, mid, pre_slope=LRELU_SLOPE)
+            pb.conv(c2, mid, nxt, pre_slope=LRELU_SLOPE, res=cur,
+                    acc=acc if last else SLOT_NONE, out_div=out_div if last else 1.0)
+            cur = nxt
+
+
+class ResBlock2(_Block):
+    """Two single dilated convs with residual (reference modules.py:233-252)."""
+
+    def __init__(self, channels, kernel_size=3, dilation=(1, 3), bias=True):
+        super().__init__()
+        self.channels = channels
+        self.convs = torch.nn.ModuleList(
+            [_resblock_conv(channels, kernel_size, d, bias) for d in dilation])
+
+    def scratch_slots(self):
+        return 2
+
+    def emit(self, pb, src, dst, scratch, acc=SLOT_NONE, out_div=1.0):
+        ping, pong = scratch[:2]
+        cur = src
+        n = len(self.convs)
+        for i, c in enumerate(self.convs):
+            last = i == n - 1
+            nxt = dst if last else (ping if cur != ping else pong)
+            pb.conv(c, cur, nxt, pre_slope=LRELU_SLOPE, res=cur,
+                    acc=acc if last else SLOT_NONE, out_div=out_div if last else 1.0)
+            cur = nxt
+
+
+def _activation_slope(name, params):
+    """Map the reference's (nonlinear_activation, params) pair onto the fused
+    input activation of the conv kernels."""
+    if name == "LeakyReLU":
+        return float(params.get("negative_slope", 0.01))
+    if name == "ReLU":
+        return 0.0
+    raise _native.NativeError(f"activation {name} is not fused into the HIP conv kernels "
+                              "(LeakyReLU / ReLU are)")
+
+
+def _pad_mode(name, params):
+    if name == "ReflectionPad1d":
+        return PAD_REFLECT
+    if name == "ConstantPad1d" and float(params.get("value", 0.0)) == 0.0:
+        return PAD_ZERO
+    raise _native.NativeError(f"padding module {name}{params} is not supported by the HIP conv "
+                              "kernels (ReflectionPad1d / zero ConstantPad1d are)")
+
+
+class ResidualStack(_Block):
+    """MelGAN residual stack (reference modules.py:320-382):
+    ``conv1x1(act(conv_k_dilated(pad(act(c))))) + skip1x1(c)``.
+    ``stack`` keeps the reference's Sequential indices (conv at .2 and .4)."""
+
+    def __init__(self, kernel_size=3, channels=32, dilation=1, bias=True,
+                 nonlinear_activation="LeakyReLU",
+                 nonlinear_activation_params={"negative_slope": 0.2},
+                 pad="ReflectionPad1d", pad_params={}, use_causal_conv=False):
+        super().__init__()
+        if use_causal_conv:
+            raise NotImplementedError(
+                "use_causal_conv=True is not built: no shipped conf/*.yaml enables it "
+                "(SURVEY.md section 2, row 5)")
+        assert (kernel_size - 1) % 2 == 0, "Not support even number kernel size."
+        self.channels = channels
+        self._slope = _activation_slope(nonlinear_activation, nonlinear_activation_params)
+        self._pad_mode = _pad_mode(pad, pad_params)
+        self._pad = (kernel_size - 1) // 2 * dilation
+        act = getattr(torch.nn, nonlinear_activation)
+        self.stack = torch.nn.Sequential(
+            act(**nonlinear_activation_params),
+            getattr(torch.nn, pad)(self._pad, **pad_params),
+            torch.nn.Conv1d(channels, channels, kernel_size, dilation=dilation, bias=bias),
+            act(**nonlinear_activation_params),
+            torch.nn.Conv1d(channels, channels, 1, bias=bias),
+        )
+        self.skip_layer = torch.nn.Conv1d(channels, channels, 1, bias=bias)
+
+    def scratch_slots(self):
+        return 2
+
+    def emit(self, pb, src, dst, scratch, post=POST_NONE):
+        hidden, skip = scratch[:2]
+        pb.conv(self.stack[2], src, hidden, pad=self._pad, pad_mode=self._pad_mode,
+                pre_slope=self._slope)
+        pb.conv(self.skip_layer, src, skip)                       # un-activated input
+        pb.conv(self.stack[4], hidden, dst, pre_slope=self._slope, res=skip, post=post)
+
+
+class LastLayer(NativeModule):
+    """act -> pad -> Conv1d(kernel_size) (reference modules.py:76-89)."""
+
+    def __init__(self, in_channels, out_channels, nonlinear_activation,
+                 nonlinear_activation_params, pad, kernel_size, pad_params, bias):
+        super().__init__()
+        self.in_channels = in_channels
+        self._slope = _activation_slope(nonlinear_activation, nonlinear_activation_params)
+        self._pad_mode = _pad_mode(pad, pad_params)
+        self._pad = (kernel_size - 1) // 2
+        self.activation = getattr(torch.nn, nonlinear_activation)(**nonlinear_activation_params)
+        self.pad = getattr(torch.nn, pad)(self._pad, **pad_params)
+        self.conv = torch.nn.Conv1d(in_channels, out_channels, kernel_size, bias=bias)
+
+    def emit(self, pb, src, dst, post=POST_NONE):
+        pb.conv(self.conv, src, dst, pad=self._pad, pad_mode=self._pad_mode,
+                pre_slope=self._slope, post=post)
+
+    def forward(self, x):
+        x = self._prepare(x)
+        return self._plan("forward", lambda pb: self.emit(pb, SLOT_IN, SLOT_OUT),
+                          self.in_channels).run(x)
+
+
+class BasisSignalLayer(NativeModule):
+    """Learned-basis synthesis (reference modules.py:255-267): ``weight [B,F,C]``
+    times ``W^T [C,L]`` gives frames, overlap-added with hop L/2.  Here both are
+    ONE polyphase transposed-conv launch; no [B,F,L] frame tensor exists."""
+
+    def __init__(self, basis_signal_weight, L=64):
+        super().__init__()
+        self.layer = torch.nn.Linear(basis_signal_weight.size(0), basis_signal_weight.size(1),
+                                     bias=False)
+        self.layer.weight = torch.nn.Parameter(basis_signal_weight)
+        self.L = L
+
+    def emit(self, pb, src, dst, pre_slope=1.0):
+        """src holds the trunk output in its native [B,C,F] layout."""
+        pb.basis_overlap_add(self.layer.weight, src, dst, self.L // 2, pre_slope=pre_slope)
+
+    def forward(self, weight):
+        """weight [B,F,C] (the reference's layout) -> [B,(F-1)*L/2+L]."""
+        w = self._prepare(weight).transpose(1, 2).contiguous()
+        out = self._plan("forward", lambda pb: self.emit(pb, SLOT_IN, SLOT_OUT),
+                         self.layer.weight.shape[1]).run(w)
+        return out[:, 0, :]
+
+
+class UpsampleLayer(torch.nn.Module):
+    """Nearest-repeat + Conv1d upsampler (reference modules.py:160-177), chosen by
+    ``transposedconv: False``.  Every shipped conf/*.yaml sets ``True``; the
+    container exists so such checkpoints load, but no HIP kernel is built for it
+    yet and the generators refuse to run with it (no eager fallback)."""
+
+    def __init__(self, in_channel, out_channel, upsample_rate, kernel_size, stride, padding,
+                 dilation=1, bias=True):
+        super().__init__()
+        self.upsample_rate = upsample_rate
+        self.conv = torch.nn.Conv1d(in_channel, out_channel, kernel_size, stride, padding,
+                                    dilation=dilation, bias=bias)
+
+    def forward(self, x):
+        raise NotImplementedError("UpsampleLayer (transposedconv: False) has no HIP kernel yet")

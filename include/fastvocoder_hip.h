@@ -1,0 +1,176 @@
+/*
+ * fastvocoder_hip.h -- C ABI of libfastvocoder_hip.so, the MI355X (gfx950)
+ * replacement for the ATen calls on FastVocoder's generator forward path.
+ *
+ * The reference has no FFI on this path: its generators are torch.nn.Modules
+ * whose arithmetic is delegated to ATen.  Each entry
+ * point below names the reference call site(s) whose arithmetic it replaces
+ * (paths relative to /root/reference).  The Python host side
+ * (fastvocoder_amd/generator/*.py) mirrors the reference's module API and is
+ * the only caller; INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer to
+ *     contiguous fp32 in the reference's [B, C, T] layout unless stated;
+ *   - the library owns no device memory: callers pass inputs, outputs, packed
+ *     weights and workspace, and keep them alive until the stream has drained;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     every call only enqueues work on it and returns (no device sync);
+ *   - return value: 0 on success, otherwise a hipError_t or FV_ERR_* code,
+ *     with a thread-local message available from fv_last_error();
+ *   - re-entrant per (device, stream); no global mutable state.
+ */
+#ifndef FASTVOCODER_HIP_H
+#define FASTVOCODER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FV_ABI_VERSION 1
+
+#define FV_ERR_INVALID_ARG (-1)
+#define FV_ERR_UNSUPPORTED (-2)
+#define FV_ERR_WORKSPACE (-3)
+
+/* padding of a conv's input: zero "same" padding (torch.nn.Conv1d padding=,
+ * model/generator/modules.py:193-221) or reflection padding + valid conv
+ * (torch.nn.ReflectionPad1d, modules.py:355-356, melgan.py:68-71) */
+#define FV_PAD_ZERO 0
+#define FV_PAD_REFLECT 1
+
+/* activation applied after the epilogue adds */
+#define FV_POST_NONE 0
+#define FV_POST_TANH 1 /* torch.tanh, hifigan.py:106 / melgan.py:108-109 */
+#define FV_POST_RELU 2 /* torch.nn.ReLU, basis_melgan.py:120-121 */
+
+int fv_version(void);
+/* thread-local description of the last non-zero return on this thread */
+const char* fv_last_error(void);
+
+/* ------------------------------------------------------------------ *
+ * one-off weight preparation (at load_state_dict / remove_weight_norm)
+ * ------------------------------------------------------------------ */
+
+/* torch.nn.utils.weight_norm reparametrisation w = v * g / ||v||_2, the norm
+ * over every dim but 0 (hifigan.py:58-76; for ConvTranspose1d dim 0 is the
+ * INPUT channel).  v, w: [dim0, inner]; g: [dim0]. */
+int fv_fold_weight_norm(const float* v, const float* g, float* w, int dim0,
+                        int64_t inner, void* stream);
+
+/* Number of floats of the packed (K-major, M-padded) image of a Conv1d weight
+ * [Cout, Cin, k] / of the polyphase image of a ConvTranspose1d weight
+ * [Cin, Cout, k] with the given stride and padding. */
+int64_t fv_packed_conv1d_floats(int Cout, int Cin, int k);
+int64_t fv_packed_conv_transpose1d_floats(int Cin, int Cout, int k, int stride, int pad);
+
+/* w [Cout, Cin, k] (torch.nn.Conv1d.weight) -> packed image */
+int fv_pack_conv1d_weight(const float* w, float* packed, int Cout, int Cin, int k,
+                          void* stream);
+/* w [Cin, Cout, k] (torch.nn.ConvTranspose1d.weight) -> packed polyphase image */
+int fv_pack_conv_transpose1d_weight(const float* w, float* packed, int Cin, int Cout,
+                                    int k, int stride, int pad, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * fused operators
+ * ------------------------------------------------------------------ */
+
+/*
+ * y = post( ( acc_in + ( conv1d(lrelu(x, pre_slope); w, dil, pad) + bias + res ) ) / out_div )
+ *
+ * Replaces F.leaky_relu + torch.nn.Conv1d (+ the residual add, the MRF running
+ * sum / mean and tanh) at modules.py:223-230 (ResBlock1), :247-252 (ResBlock2),
+ * :372-382 (ResidualStack), :85-89 (LastLayer), hifigan.py:93,99-106,
+ * multiband_hifigan.py:102-115, melgan.py:66-71.
+ *   x [B,Cin,Tin]; packed from fv_pack_conv1d_weight; bias [Cout] or NULL;
+ *   res, acc_in [B,Cout,Tout] or NULL; y [B,Cout,Tout],
+ *   Tout = Tin + 2*pad - dil*(k-1).  pre_slope = 1 disables the input
+ *   activation, 0 is ReLU; out_div = 1 disables the division (it is a true
+ *   fp32 division, hifigan.py:103).  y may alias res or acc_in, never x.
+ */
+int fv_conv1d_fused(const float* x, const float* packed, const float* bias,
+                    const float* res, const float* acc_in, float* y, int B, int Cin,
+                    int Cout, int Tin, int k, int dil, int pad, int pad_mode,
+                    float pre_slope, float out_div, int post, void* stream);
+
+/*
+ * y = post( conv_transpose1d(lrelu(x, pre_slope); w, stride, pad, out_pad) + bias )
+ *
+ * Replaces F.leaky_relu + torch.nn.ConvTranspose1d at hifigan.py:95-96,
+ * multiband_hifigan.py:104-105, melgan.py:75-85, basis_melgan.py:86-97, and --
+ * with Cout = 1, k = L, stride = L/2, pad = 0, packed from W^T -- the
+ * F.linear + overlap_and_add pair of BasisSignalLayer (modules.py:264-267,
+ * :34-73).  x [B,Cin,Tin] -> y [B,Cout,Tout],
+ * Tout = (Tin-1)*stride - 2*pad + k + out_pad.
+ */
+int fv_conv_transpose1d_fused(const float* x, const float* packed, const float* bias,
+                              float* y, int B, int Cin, int Cout, int Tin, int k,
+                              int stride, int pad, int out_pad, float pre_slope, int post,
+                              void* stream);
+
+/*
+ * PQMF.synthesis (model/generator/pqmf.py:121-135) in polyphase form.
+ *   x [B,S,Tsub] sub-bands, h [S,ntaps] (= synthesis_filter[0]), y [B,S*Tsub].
+ */
+int fv_pqmf_synthesis(const float* x, const float* h, float* y, int B, int S, int ntaps,
+                      int Tsub, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * whole-generator plans: an op list replayed over a caller-owned arena
+ * ------------------------------------------------------------------ */
+
+typedef struct fv_plan fv_plan_t;
+
+/* tensor slots inside a plan: FV_SLOT_IN is the caller's mel [B,Cin0,T],
+ * FV_SLOT_OUT the caller's output, slots >= FV_SLOT_TMP0 live in the workspace */
+#define FV_SLOT_NONE (-1)
+#define FV_SLOT_IN 0
+#define FV_SLOT_OUT 1
+#define FV_SLOT_TMP0 2
+#define FV_MAX_SLOTS 16
+
+fv_plan_t* fv_plan_create(int in_channels);
+void fv_plan_destroy(fv_plan_t* plan);
+
+/* append ops; argument meaning as in the fused operators above, tensors named
+ * by slot.  Weight pointers are captured, not copied. */
+int fv_plan_add_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int res_slot,
+                       int acc_slot, const float* packed, const float* bias, int Cin,
+                       int Cout, int k, int dil, int pad, int pad_mode, float pre_slope,
+                       float out_div, int post);
+int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot,
+                                 const float* packed, const float* bias, int Cin, int Cout,
+                                 int k, int stride, int pad, int out_pad, float pre_slope,
+                                 int post);
+int fv_plan_add_pqmf_synthesis(fv_plan_t* plan, int x_slot, int y_slot, const float* h,
+                               int S, int ntaps);
+
+/* shape inference for a (B, T) call: channels / length of the output tensor
+ * and the workspace the plan needs (bytes) */
+int fv_plan_output_shape(fv_plan_t* plan, int T, int* out_channels, int64_t* out_len);
+int64_t fv_plan_workspace_bytes(fv_plan_t* plan, int B, int T);
+
+/* enqueue the whole op list: in [B,Cin0,T] -> out [B,Cout,Tout] */
+int fv_plan_run(fv_plan_t* plan, int B, int T, const float* in, float* out,
+                void* workspace, int64_t workspace_bytes, void* stream);
+
+/* number of kernel launches one fv_plan_run enqueues */
+int fv_plan_num_ops(fv_plan_t* plan);
+
+/* ------------------------------------------------------------------ *
+ * measurement hook (bench.py): per-launch timing of the dominant kernel
+ * with HIP events recorded on the caller's stream
+ * ------------------------------------------------------------------ */
+/* When enabled, every conv kernel launch is bracketed by hipEvents on its
+ * stream; fv_profile_collect() synchronises and returns the accumulated
+ * (launches, milliseconds, flops, algorithmic bytes) and resets them. */
+int fv_profile_enable(int on);
+int fv_profile_collect(int64_t* launches, double* ms, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTVOCODER_HIP_H */
