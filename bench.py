@@ -1,0 +1,189 @@
+"""Headline benchmark: HiFi-GAN-light generator inference on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[1]): conf/hifigan/light.yaml, batch = 1 utterance
+per GPU, mel 80 x 1000 frames of synthetic U[0,1) data already resident in HBM,
+seeded gain-calibrated random-init weights (no checkpoint exists offline),
+weight norm folded.  One "step" = one ``Generator.forward`` over the per-GPU
+batch -> 240 000 samples per utterance.  N > 1 (launched by torch.distributed.run,
+one rank per GPU): weights are built on rank 0 and broadcast over RCCL once,
+every rank then runs its own utterances (weak scaling) and the waveforms are
+gathered to rank 0 inside the timed step.
+
+Prints ONE JSON line: value = whole-job audio samples / second, plus RTF at
+22.05 kHz and 24 kHz, the roofline of the dominant kernel (fp32-MFMA implicit-GEMM
+conv, per-launch HIP-event timing on the launch stream), and the reference's CPU
+path (its ATen op sequence, oracle/torch_port.py) timed on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from fastvocoder_amd import _native  # noqa: E402
+from fastvocoder_amd.bin.synthesize import build_generator  # noqa: E402
+from fastvocoder_amd.synthetic import seeded_mel, seeded_state_dict  # noqa: E402
+
+MODEL, CONF = "hifigan", "conf/hifigan/light.yaml"
+T_FRAMES = 1000
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def load_conf():
+    import yaml
+    with open(os.path.join(ROOT, CONF)) as f:
+        return yaml.safe_load(f)
+
+
+def cpu_baseline(cfg, sd, mel):
+    """The reference's CPU path (un-fused ATen op sequence) on this box's cores:
+    one warm-up + best of 3 passes over ONE utterance of the same workload."""
+    from oracle import torch_port  # the only oracle use in bench: the CPU baseline leg
+    folded = torch_port.fold_state_dict(sd)
+    threads = torch.get_num_threads()
+    torch_port.inference(MODEL, mel, folded, cfg)
+    best = float("inf")
+    n = 0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        y = torch_port.inference(MODEL, mel, folded, cfg)
+        best = min(best, time.perf_counter() - t0)
+        n = int(y.numel())
+    return {"value": n / best, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"1 utterance, mel 80x{mel.shape[0]} -> {n} samples, best of 3 after 1 warm-up, "
+                      f"ATen port of the reference generator, {threads} threads",
+            "seconds": best}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        sys.exit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                 "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = load_conf()
+    from fastvocoder_amd import parallel
+    model = build_generator(MODEL, cfg)
+    sd = seeded_state_dict(MODEL, cfg, seed=0) if rank == 0 else None
+    if rank == 0:
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev).eval()
+    if world > 1:
+        parallel.broadcast_weights(model, src=0)          # RCCL broadcast, once
+    model.remove_weight_norm()
+
+    B = args.batch
+    mel = torch.from_numpy(seeded_mel(T_FRAMES, seed=100 + rank, batch=B)).to(dev)
+    gather = parallel.WaveformGather(world, rank, dev) if world > 1 else None
+
+    def step():
+        with torch.no_grad():
+            wav = model(mel)
+        if gather is not None:
+            gather(wav)
+        return wav
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wav = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    samples_per_utt = int(wav.shape[-1])
+    total_samples = samples_per_utt * B * world * args.steps
+    value = total_samples / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    out = None
+    if rank == 0:
+        # per-launch timing of the dominant kernel family with HIP events on the launch stream
+        _native.profile_enable(True)
+        reps = 5
+        for _ in range(reps):
+            with torch.no_grad():
+                model(mel)
+        torch.cuda.synchronize()
+        _native.profile_enable(False)
+        p32 = _native.profile_collect(_native.KERNEL_CONV_MFMA32)
+        p16 = _native.profile_collect(_native.KERNEL_CONV_MFMA16)
+        pn = _native.profile_collect(_native.KERNEL_CONV_NARROW)
+        mf_launch, mf_ms, mf_flops = (p32["launches"] + p16["launches"], p32["ms"] + p16["ms"],
+                                      p32["flops"] + p16["flops"])
+        achieved = mf_flops / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
+        roofline = {
+            "kernel": "conv_mfma32_kernel/conv_mfma16_kernel (fp32-MFMA implicit-GEMM conv1d, "
+                      "all Conv1d/ConvTranspose1d layers with Cout > 4)",
+            "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "launches_per_step": mf_launch // reps,
+            "avg_launch_us": 1e3 * mf_ms / max(mf_launch, 1),
+            "algorithmic_gflop_per_step": mf_flops / reps / 1e9,
+            "kernel_ms_per_step": mf_ms / reps,
+            "hbm_GBps_algorithmic": (p32["bytes"] + p16["bytes"]) / (mf_ms * 1e-3) / 1e9 if mf_ms > 0 else 0.0,
+            "narrow_conv_ms_per_step": pn["ms"] / reps,
+        }
+        dur22, dur24 = total_samples / 22050.0, total_samples / 24000.0
+        out = {
+            "metric": "audio_samples_per_sec", "value": value, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "rtf_22k05": elapsed / dur22, "rtf_24k": elapsed / dur24,
+            "config": {"workload": "HiFi-GAN light (conf/hifigan/light.yaml) generator forward, "
+                                   f"mel 80x{T_FRAMES}, batch {B} utterance(s) per GPU, "
+                                   f"{samples_per_utt} samples each; BASELINE.json configs[1]",
+                       "global_batch": B * world, "frames": T_FRAMES,
+                       "parallelism": f"utterance-sharded x{world}" if world > 1 else "single GPU",
+                       "launches_per_forward": model._plan("trunk", None, 80).num_ops()},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, seeded_mel(T_FRAMES, seed=100))
+            out["cpu_baseline"]["rtf_22k05"] = out["cpu_baseline"]["seconds"] / (samples_per_utt / 22050.0)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,7 +82,7 @@ def lib():
     L.fv_plan_run.argtypes = [vp, i, i, vp, vp, vp, i64, vp]
     L.fv_plan_num_ops.argtypes = [vp]
     L.fv_profile_enable.argtypes = [i]
-    L.fv_profile_collect.argtypes = [ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_double),
+    L.fv_profile_collect.argtypes = [i, ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     if L.fv_version() != 1:
         raise NativeError(f"ABI mismatch: library reports {L.fv_version()}, binding expects 1")
@@ -265,8 +265,13 @@ def profile_enable(on):
     check(lib().fv_profile_enable(1 if on else 0))
 
 
-def profile_collect():
+KERNEL_CONV_MFMA32, KERNEL_CONV_MFMA16, KERNEL_CONV_NARROW = 0, 1, 2
+
+
+def profile_collect(kind=-1):
+    """Drain the per-launch HIP-event records of one kernel family (-1: all)."""
     n, ms = ctypes.c_int64(), ctypes.c_double()
     fl, by = ctypes.c_double(), ctypes.c_double()
-    check(lib().fv_profile_collect(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
+    check(lib().fv_profile_collect(kind, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl),
+                                   ctypes.byref(by)))
     return {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}

@@ -1,0 +1,103 @@
+"""``MODE=synthesize``: checkpoint + mel.npy -> wav files, on the MI355X engine.
+
+Same surface as the reference's bin/synthesize.py: ``Synthesizer(checkpoint_path,
+config_path, model_name)`` with ``.synthesize(mel[T,80]) -> (est, est - bias,
+bias)`` and ``.test_rtf(mel)``; ``run_synthesizer()`` parses the same flags and
+writes ``<wav>``, ``<wav[:-3]>remove.wav`` and ``<wav[:-3]>bias.wav``.  The
+reference's fourth output (Griffin-Lim ``gl.wav``) needs librosa and is skipped
+with a notice.
+"""
+import argparse
+import os
+
+import numpy as np
+import torch
+import yaml
+
+from .. import hparams as hp
+from ..audio import save_wav
+from ..generator import (BasisMelGANGenerator, HiFiGANGenerator, MelGANGenerator,
+                         MultiBandHiFiGANGenerator)
+
+_HIFI_KEYS = ("resblock_kernel_sizes", "upsample_rates", "upsample_initial_channel",
+              "resblock_type", "upsample_kernel_sizes", "resblock_dilation_sizes",
+              "transposedconv", "bias")
+_MELGAN_KEYS = ("in_channels", "out_channels", "kernel_size", "channels", "upsample_scales",
+                "stack_kernel_size", "stacks", "use_weight_norm", "use_causal_conv")
+
+
+def build_generator(model_name, config):
+    """yaml dict -> generator, the reference's if/elif on ``model_name``
+    (bin/synthesize.py:25-68); training-only yaml keys are ignored and a missing
+    key raises KeyError like there."""
+    if model_name == "melgan":
+        return MelGANGenerator(**{k: config[k] for k in _MELGAN_KEYS})
+    if model_name == "hifigan":
+        return HiFiGANGenerator(**{k: config[k] for k in _HIFI_KEYS})
+    if model_name == "multiband-hifigan":
+        return MultiBandHiFiGANGenerator(**{k: config[k] for k in _HIFI_KEYS})
+    if model_name == "basis-melgan":
+        basis = torch.zeros(config["L"], config["out_channels"]).float()
+        keys = ("L",) + _MELGAN_KEYS + ("transposedconv",)
+        return BasisMelGANGenerator(basis_signal_weight=basis, **{k: config[k] for k in keys})
+    raise Exception("no model find!")
+
+
+def default_device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("fastvocoder_amd needs a ROCm GPU (MI355X); no CPU inference path exists")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class Synthesizer:
+    def __init__(self, checkpoint_path, config_path, model_name, device=None) -> None:
+        self.device = device if device is not None else default_device()
+        self.model = self.load_model(checkpoint_path, config_path, model_name)
+
+    def load_model(self, checkpoint_path, config_path, model_name):
+        with open(config_path) as f:
+            config = yaml.load(f, Loader=yaml.Loader)
+        print(f"Loading Model of {model_name}...")
+        model = build_generator(model_name, config).to(self.device)
+        ckpt = torch.load(os.path.join(checkpoint_path), map_location=self.device, weights_only=False)
+        model.load_state_dict(ckpt["model"])
+        model.eval()
+        model.remove_weight_norm()
+        self.checkpoint = ckpt
+        self.config = config
+        return model
+
+    def synthesize(self, mel):
+        """mel [T,80] ndarray -> (est_source, est_source - bias, bias), each 1-D fp32
+        on the device; ``bias`` is the generator's response to an all-zero mel."""
+        with torch.no_grad():
+            zero_mel = torch.zeros_like(torch.from_numpy(np.asarray(mel)).float())
+            bias = self.model.inference(zero_mel)
+            est_source = self.model.inference(mel)
+            est_source_remove_bias = est_source - bias
+        return est_source, est_source_remove_bias, bias
+
+    def test_rtf(self, mel):
+        with torch.no_grad():
+            self.model.inference(mel)
+
+
+def run_synthesizer():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--checkpoint_path", type=str)
+    parser.add_argument("--mel_path", type=str)
+    parser.add_argument("--wav_path", type=str)
+    parser.add_argument("--model_name", type=str,
+                        help="melgan, hifigan, multiband-hifigan and basis-melgan.")
+    parser.add_argument("--config", type=str, help="path to model configuration file")
+    args = parser.parse_args()
+
+    synthesizer = Synthesizer(args.checkpoint_path, args.config, args.model_name)
+    mel = np.load(args.mel_path)
+    outs = synthesizer.synthesize(mel.T)
+    est_source, est_source_remove_bias, bias = (o.cpu().numpy() for o in outs)
+    stem = args.wav_path[:-3]
+    save_wav(est_source, args.wav_path, hp.sample_rate, rescale_out=hp.rescale_out)
+    save_wav(est_source_remove_bias, stem + "remove.wav", hp.sample_rate, rescale_out=hp.rescale_out)
+    save_wav(bias, stem + "bias.wav", hp.sample_rate, rescale_out=hp.rescale_out)
+    print(f"[fastvocoder_amd] skipped {stem}gl.wav: Griffin-Lim needs librosa (out of scope)")

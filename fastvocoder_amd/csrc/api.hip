@@ -29,6 +29,7 @@ int fail(int code, const char* fmt, ...) {
 struct ProfRec {
     hipEvent_t a, b;
     double flops, bytes;
+    int kind;
 };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
@@ -36,18 +37,19 @@ static hipEvent_t g_prof_start;
 
 void profile_begin(hipStream_t s) {
     if (!g_prof_on) return;
-    hipEventCreate(&g_prof_start);
-    hipEventRecord(g_prof_start, s);
+    (void)hipEventCreate(&g_prof_start);
+    (void)hipEventRecord(g_prof_start, s);
 }
 
-void profile_end(hipStream_t s, double flops, double bytes) {
+void profile_end(hipStream_t s, int kind, double flops, double bytes) {
     if (!g_prof_on) return;
     ProfRec r;
     r.a = g_prof_start;
-    hipEventCreate(&r.b);
-    hipEventRecord(r.b, s);
+    (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.b, s);
     r.flops = flops;
     r.bytes = bytes;
+    r.kind = kind;
     g_prof.push_back(r);
 }
 
@@ -487,23 +489,30 @@ int fv_profile_enable(int on) {
     return 0;
 }
 
-int fv_profile_collect(int64_t* launches, double* ms, double* flops, double* bytes) {
+int fv_profile_collect(int kind, int64_t* launches, double* ms, double* flops, double* bytes) {
     double tms = 0, tf = 0, tb = 0;
+    int64_t n = 0;
+    std::vector<ProfRec> rest;
     for (ProfRec& r : g_prof) {
+        if (kind >= 0 && r.kind != kind) {
+            rest.push_back(r);
+            continue;
+        }
         FV_HIP(hipEventSynchronize(r.b));
         float e = 0.f;
         FV_HIP(hipEventElapsedTime(&e, r.a, r.b));
         tms += e;
         tf += r.flops;
         tb += r.bytes;
-        hipEventDestroy(r.a);
-        hipEventDestroy(r.b);
+        ++n;
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
     }
-    if (launches) *launches = (int64_t)g_prof.size();
+    if (launches) *launches = n;
     if (ms) *ms = tms;
     if (flops) *flops = tf;
     if (bytes) *bytes = tb;
-    g_prof.clear();
+    g_prof.swap(rest);
     return 0;
 }
 

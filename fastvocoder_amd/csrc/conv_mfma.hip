@@ -407,9 +407,10 @@ int launch_conv(ConvParams p, hipStream_t s) {
     const double bytes = 4.0 * ((double)p.B * p.Cin * p.Tin + (double)p.B * p.Cout * p.Tout *
                                 (1 + (p.res != nullptr) + (p.acc_in != nullptr)) +
                                 (double)p.Cin * p.k * p.M);
-    int rc;
+    int rc, kind;
     profile_begin(s);
     if (p.ups == 1 && p.M <= 4) {
+        kind = FV_KERNEL_CONV_NARROW;
         p.xw = row_stride(256, halo, false);
         p.ci_chunk = pick_ci_chunk(p, 16, p.xw, 1);
         const size_t lds = (size_t)p.ci_chunk * (p.xw + p.k * 16) * 4;
@@ -417,6 +418,7 @@ int launch_conv(ConvParams p, hipStream_t s) {
         else if (p.M == 2) rc = launch_one(conv_narrow_kernel<2>, p, p.Mpad, 256, lds, s);
         else rc = launch_one(conv_narrow_kernel<4>, p, p.Mpad, 256, lds, s);
     } else if (p.Mpad == 16) {
+        kind = FV_KERNEL_CONV_MFMA16;
         const bool big = (long)p.B * ((p.Tq + 255) / 256) >= 512;
         const int n_t = big ? 256 : 128;
         p.xw = row_stride(n_t, halo, true);
@@ -424,6 +426,7 @@ int launch_conv(ConvParams p, hipStream_t s) {
         const size_t lds = (size_t)p.ci_chunk * (p.xw + p.k * 16) * 4;
         rc = big ? launch16<4>(p, lds, s) : launch16<2>(p, lds, s);
     } else if (p.Mpad % 64 == 0) {
+        kind = FV_KERNEL_CONV_MFMA32;
         const long blocks128 = (long)p.B * (p.Mpad / 64) * ((p.Tq + 127) / 128);
         const bool big = blocks128 >= 512;
         const int n_t = big ? 128 : 64;
@@ -432,6 +435,7 @@ int launch_conv(ConvParams p, hipStream_t s) {
         const size_t lds = (size_t)p.ci_chunk * (p.xw + p.k * 64) * 4;
         rc = big ? launch32<2, 2, 2>(p, lds, s) : launch32<2, 2, 1>(p, lds, s);
     } else {
+        kind = FV_KERNEL_CONV_MFMA32;
         const long blocks256 = (long)p.B * (p.Mpad / 32) * ((p.Tq + 255) / 256);
         const bool big = blocks256 >= 512;
         const int n_t = big ? 256 : 128;
@@ -440,7 +444,7 @@ int launch_conv(ConvParams p, hipStream_t s) {
         const size_t lds = (size_t)p.ci_chunk * (p.xw + p.k * 32) * 4;
         rc = big ? launch32<1, 4, 2>(p, lds, s) : launch32<1, 4, 1>(p, lds, s);
     }
-    profile_end(s, flops, bytes);
+    profile_end(s, kind, flops, bytes);
     return rc;
 }
 

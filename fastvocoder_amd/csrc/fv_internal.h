@@ -69,6 +69,6 @@ int launch_pqmf(const float* x, const float* h, float* y, int B, int S, int ntap
 
 // measurement hook
 void profile_begin(hipStream_t stream);
-void profile_end(hipStream_t stream, double flops, double bytes);
+void profile_end(hipStream_t stream, int kind, double flops, double bytes);
 
 }  // namespace fv

@@ -1,0 +1,83 @@
+"""Utterance sharding across the GPUs of one node (one process per GPU,
+torch.distributed; backend "nccl" = RCCL over xGMI on ROCm, "gloo" in CPU tests).
+
+The reference is single-process / single-device: nothing
+is translated here.  The generators have no cross-utterance op, so the batch
+partitions exactly: contiguous blocks of utterances per rank, and the only
+traffic is
+  * once:      broadcast of the checkpoint tensors from rank 0  (14-55 MB)
+  * per batch: gather of the waveforms to rank 0 -- a flat root gather, so each
+               peer sends over its own direct xGMI link to the root (7 links
+               used concurrently) instead of a ring bound by one link.
+There is no all-reduce and no collective inside the generator.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, world_size, rank):
+    """Contiguous [lo, hi) block of ``n_items`` for ``rank``; blocks differ by at
+    most one item and concatenate, in rank order, to range(n_items)."""
+    base, extra = divmod(n_items, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def broadcast_weights(model, src=0, group=None):
+    """Broadcast every parameter and buffer of ``model`` from ``src`` in place."""
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=src, group=group)
+    if hasattr(model, "invalidate_plans"):
+        for m in model.modules():
+            if hasattr(m, "invalidate_plans"):
+                m.invalidate_plans()
+    return model
+
+
+class WaveformGather:
+    """Root gather of equally-shaped per-rank waveform blocks [b, n] -> [world*b, n]
+    on rank 0 (None elsewhere).  Buffers are allocated once and reused."""
+
+    def __init__(self, world_size, rank, device, dst=0, group=None):
+        self.world, self.rank, self.dst, self.group = world_size, rank, dst, group
+        self.device = device
+        self._bufs = None
+        self._shape = None
+
+    def __call__(self, wav):
+        wav = wav.contiguous()
+        if self.rank == self.dst:
+            if self._shape != tuple(wav.shape):
+                self._bufs = [torch.empty_like(wav) for _ in range(self.world)]
+                self._shape = tuple(wav.shape)
+            dist.gather(wav, gather_list=self._bufs, dst=self.dst, group=self.group)
+            return self._bufs
+        dist.gather(wav, gather_list=None, dst=self.dst, group=self.group)
+        return None
+
+
+def synthesize_sharded(forward_fn, mels, world_size=None, rank=None, dst=0, group=None):
+    """Run ``forward_fn(mels[lo:hi]) -> [hi-lo, n]`` on this rank's contiguous block
+    of ``mels [B, C, T]`` and gather all waveforms, in utterance order, on ``dst``.
+    Ragged blocks (B not divisible by the world size) are padded for the gather
+    and trimmed on the root.  Returns [B, n] on ``dst`` and None elsewhere."""
+    world_size = dist.get_world_size(group) if world_size is None else world_size
+    rank = dist.get_rank(group) if rank is None else rank
+    B = mels.shape[0]
+    lo, hi = shard_range(B, world_size, rank)
+    per = (B + world_size - 1) // world_size
+    block = mels[lo:hi]
+    if hi - lo < per:   # pad with a copy of the last row (or a zero row for an empty block)
+        filler = block[-1:] if hi > lo else torch.zeros_like(mels[:1])
+        block = torch.cat([block] + [filler] * (per - (hi - lo)), dim=0)
+    wav = forward_fn(block.contiguous()).contiguous()
+    bufs = [torch.empty_like(wav) for _ in range(world_size)] if rank == dst else None
+    dist.gather(wav, gather_list=bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    rows = []
+    for r in range(world_size):
+        a, b = shard_range(B, world_size, r)
+        rows.append(bufs[r][: b - a])
+    return torch.cat(rows, dim=0)

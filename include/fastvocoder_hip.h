@@ -6,7 +6,7 @@
  * whose arithmetic is delegated to ATen.  Each entry
  * point below names the reference call site(s) whose arithmetic it replaces
  * (paths relative to /root/reference).  The Python host side
- * (fastvocoder_amd/generator/*.py) mirrors the reference's module API and is
+ * (the fastvocoder_amd/generator package) mirrors the reference's module API and is
  * the only caller; INTEGRATION.md shows the ctypes binding.
  *
  * Conventions
@@ -166,9 +166,13 @@ int fv_plan_num_ops(fv_plan_t* plan);
  * ------------------------------------------------------------------ */
 /* When enabled, every conv kernel launch is bracketed by hipEvents on its
  * stream; fv_profile_collect() synchronises and returns the accumulated
- * (launches, milliseconds, flops, algorithmic bytes) and resets them. */
+ * (launches, milliseconds, algorithmic flops, algorithmic bytes) of one kernel
+ * family and removes those records.  kind: FV_KERNEL_* or -1 for all. */
+#define FV_KERNEL_CONV_MFMA32 0 /* 32x32x2 fp32-MFMA implicit-GEMM conv (M > 16 rows) */
+#define FV_KERNEL_CONV_MFMA16 1 /* 16x16x4 fp32-MFMA implicit-GEMM conv (M <= 16 rows) */
+#define FV_KERNEL_CONV_NARROW 2 /* VALU conv for Cout <= 4 */
 int fv_profile_enable(int on);
-int fv_profile_collect(int64_t* launches, double* ms, double* flops, double* bytes);
+int fv_profile_collect(int kind, int64_t* launches, double* ms, double* flops, double* bytes);
 
 #ifdef __cplusplus
 }

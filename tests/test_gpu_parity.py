@@ -1,0 +1,331 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle on the
+same seeded inputs, against the committed reference goldens, and -- at the
+BASELINE sizes -- through size-independent properties.
+
+Tolerance: BASELINE.json's north_star asks for <= 1e-4 fp32 max-abs on the
+generator output (|output| <= 1 after tanh); op/block-level checks whose outputs
+are not O(1) use the same bound relative to the tensor's scale.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fastvocoder_amd as fa
+from fastvocoder_amd import _native
+from fastvocoder_amd.bin.synthesize import build_generator
+from fastvocoder_amd.synthetic import seeded_mel, seeded_state_dict
+from oracle import generators as og
+from oracle import ops as oo
+from oracle import torch_port
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # north_star: outputs match the reference generator within 1e-4 fp32 max-abs
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _err(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max())
+
+
+def _rel(a, b):
+    b = np.asarray(b)
+    return _err(a, b) / max(1.0, float(np.abs(b).max()))
+
+
+def _model(name, cfg, seed):
+    m = build_generator(name, cfg)
+    sd = seeded_state_dict(name, cfg, seed=seed)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m.to(_dev()).eval(), sd
+
+
+def test_native_library_is_loaded():
+    L = _native.lib()
+    assert L.fv_version() == 1
+    with open("/proc/self/maps") as f:
+        assert "libfastvocoder_hip.so" in f.read()
+
+
+# ---------------------------------------------------------------------------
+# operators vs the C oracle
+# ---------------------------------------------------------------------------
+CONV_CASES = [
+    # B, Cin, Cout, T, k, dil, pad, pad_mode, pre_slope
+    (2, 16, 16, 257, 3, 1, 1, 0, 0.1),
+    (1, 16, 16, 1000, 11, 5, 25, 0, 0.1),
+    (2, 32, 32, 301, 7, 3, 9, 0, 0.1),
+    (1, 64, 64, 500, 11, 1, 5, 0, 0.1),
+    (1, 128, 128, 130, 3, 5, 5, 0, 0.1),
+    (2, 80, 64, 64, 7, 1, 3, 0, 1.0),       # conv_pre shape class
+    (1, 80, 96, 33, 7, 1, 3, 1, 1.0),       # reflect first layer, Cout not a multiple of 64
+    (2, 32, 32, 200, 3, 9, 9, 1, 0.2),      # ResidualStack dilated conv, reflect
+    (1, 64, 64, 77, 1, 1, 0, 0, 0.2),       # 1x1
+    (2, 16, 1, 999, 7, 1, 3, 0, 0.01),      # conv_post
+    (1, 32, 1, 130, 7, 1, 3, 1, 0.2),       # LastLayer
+    (3, 64, 4, 250, 7, 1, 3, 0, 0.01),      # multiband conv_post
+    (1, 8, 8, 100, 5, 2, 4, 0, 0.1),        # M = 8 rows (padded tile), generic tap count
+    (1, 4, 4, 90, 3, 1, 1, 1, 0.2),         # narrow kernel with Cin = 4
+    (1, 24, 40, 75, 3, 2, 2, 0, 0.0),       # odd channel counts, ReLU pre-activation
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv1d_fused_vs_oracle(case):
+    B, Cin, Cout, T, k, dil, pad, mode, slope = case
+    rng = np.random.RandomState(hash(case) % (2 ** 31))
+    x = rng.randn(B, Cin, T).astype(np.float32)
+    w = (rng.randn(Cout, Cin, k) / np.sqrt(Cin * k)).astype(np.float32)
+    b = rng.randn(Cout).astype(np.float32)
+    ref = oo.conv1d(x, w, b, dil=dil, pad=pad, pad_mode=mode, pre_slope=slope)
+    dev = _dev()
+    packed = _native.pack_conv1d(torch.from_numpy(w).to(dev))
+    y = _native.conv1d_fused(torch.from_numpy(x).to(dev), packed, torch.from_numpy(b).to(dev), Cout, k,
+                             dil=dil, pad=pad, pad_mode=mode, pre_slope=slope)
+    assert _rel(y, ref) <= 2e-5
+    # fused epilogue: residual + running sum + true division + tanh
+    res = rng.randn(*ref.shape).astype(np.float32)
+    acc = rng.randn(*ref.shape).astype(np.float32)
+    ref2 = np.tanh(((acc + (ref + res)) / np.float32(3.0)).astype(np.float64)).astype(np.float32)
+    y2 = _native.conv1d_fused(torch.from_numpy(x).to(dev), packed, torch.from_numpy(b).to(dev), Cout, k,
+                              dil=dil, pad=pad, pad_mode=mode, pre_slope=slope,
+                              res=torch.from_numpy(res).to(dev), acc_in=torch.from_numpy(acc).to(dev),
+                              out_div=3.0, post=_native.POST_TANH)
+    assert _err(y2, ref2) <= 2e-5
+
+
+CONVT_CASES = [
+    # B, Cin, Cout, T, k, stride   (pad = s//2 + s%2, out_pad = s%2, like the generators)
+    (1, 64, 32, 50, 16, 8), (2, 32, 16, 41, 10, 5), (1, 32, 16, 100, 6, 3), (2, 32, 16, 77, 4, 2),
+    (1, 64, 32, 30, 20, 10), (1, 32, 16, 55, 12, 6),        # MB light / MelGAN
+    (1, 32, 16, 30, 16, 10), (1, 16, 8, 40, 16, 6),         # MB large: k < 2s and k > 2s
+    (1, 32, 32, 60, 8, 4),                                  # Basis
+    (1, 128, 64, 9, 16, 8),                                 # very short input
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_transpose1d_fused_vs_oracle(case):
+    B, Cin, Cout, T, k, s = case
+    p, op = s // 2 + s % 2, s % 2
+    rng = np.random.RandomState(hash(case) % (2 ** 31))
+    x = rng.randn(B, Cin, T).astype(np.float32)
+    w = (rng.randn(Cin, Cout, k) / np.sqrt(Cin * k / s)).astype(np.float32)
+    b = rng.randn(Cout).astype(np.float32)
+    ref = oo.conv_transpose1d(x, w, b, s, p, op, pre_slope=0.1)
+    dev = _dev()
+    packed = _native.pack_conv_transpose1d(torch.from_numpy(w).to(dev), s, p)
+    y = _native.conv_transpose1d_fused(torch.from_numpy(x).to(dev), packed, torch.from_numpy(b).to(dev),
+                                       Cout, k, s, p, op, pre_slope=0.1)
+    assert _rel(y, ref) <= 2e-5
+
+
+def test_conv_transpose_no_padding_is_overlap_add():
+    """ConvTranspose1d(Cout=1, k=L, stride=L/2, pad=0) == linear + overlap_and_add."""
+    rng = np.random.RandomState(5)
+    W = rng.uniform(-0.2, 0.2, size=(30, 48)).astype(np.float32)
+    wt = np.abs(rng.randn(2, 48, 37)).astype(np.float32)
+    ref = oo.basis_ola(wt, W, 15)
+    dev = _dev()
+    w = torch.from_numpy(W).to(dev).t().contiguous().view(48, 1, 30)
+    packed = _native.pack_conv_transpose1d(w, 15, 0)
+    y = _native.conv_transpose1d_fused(torch.from_numpy(wt).to(dev), packed, None, 1, 30, 15, 0, 0)
+    assert _rel(y[:, 0, :], ref) <= 2e-5
+
+
+def test_fold_weight_norm_vs_torch():
+    rng = np.random.RandomState(9)
+    for shape in [(64, 32, 7), (128, 64, 16), (5, 3, 1)]:
+        v = torch.from_numpy(rng.randn(*shape).astype(np.float32))
+        g = torch.from_numpy((rng.rand(shape[0], 1, 1) + 0.5).astype(np.float32))
+        ref = torch._weight_norm(v, g, 0)
+        w = _native.fold_weight_norm(v.to(_dev()), g.to(_dev()))
+        assert _rel(w, ref.numpy()) <= 1e-6
+
+
+def test_pqmf_synthesis_vs_golden_and_oracle(golden_dir):
+    g = np.load(os.path.join(golden_dir, "blocks.npz"))
+    pq = fa.PQMF().to(_dev())
+    assert _err(pq.synthesis_filter, g["pqmf_synthesis_filter"]) == 0.0
+    assert _err(pq.analysis_filter, g["pqmf_analysis_filter"]) == 0.0
+    y = pq.synthesis(torch.from_numpy(g["pqmf_sub"]).to(_dev()))
+    assert _err(y, g["pqmf_synth_out"]) <= 1e-5
+    # odd sizes vs the oracle
+    rng = np.random.RandomState(2)
+    sub = rng.uniform(-1, 1, size=(3, 4, 333)).astype(np.float32)
+    ref = oo.pqmf_synthesis(sub, g["pqmf_synthesis_filter"][0])
+    y = pq.synthesis(torch.from_numpy(sub).to(_dev()))
+    assert _err(y[:, 0, :], ref) <= 1e-5
+    # analysis (oracle) -> synthesis (GPU) reconstructs the interior
+    a = oo.pqmf_analysis(g["pqmf_wav"][:, 0, :], g["pqmf_analysis_filter"][:, 0, :])
+    r = pq.synthesis(torch.from_numpy(a).to(_dev())).cpu().numpy()
+    assert np.abs(r[0, 0, 200:-200] - g["pqmf_wav"][0, 0, 200:-200]).max() < 2e-3
+
+
+# ---------------------------------------------------------------------------
+# blocks vs the reference goldens
+# ---------------------------------------------------------------------------
+def _fill(mod, flat):
+    off = 0
+    with torch.no_grad():
+        for p in mod.parameters():
+            n = p.numel()
+            p.copy_(torch.from_numpy(flat[off:off + n].reshape(tuple(p.shape))))
+            off += n
+    assert off == flat.size
+    return mod.to(_dev())
+
+
+def test_blocks_vs_reference_goldens(golden_dir):
+    from fastvocoder_amd.generator import modules as M
+    g = np.load(os.path.join(golden_dir, "blocks.npz"))
+    x = torch.from_numpy(g["x16"]).to(_dev())
+    for k in (3, 7, 11):
+        rb = _fill(M.ResBlock1(16, k, (1, 3, 5)), g[f"rb1_k{k}_params"])
+        assert _rel(rb(x), g[f"rb1_k{k}_out"]) <= 2e-5
+    rb = _fill(M.ResBlock2(16, 5, (1, 3)), g["rb2_params"])
+    assert _rel(rb(x), g["rb2_out"]) <= 2e-5
+    for d in (1, 3, 9):
+        rs = _fill(M.ResidualStack(kernel_size=3, channels=16, dilation=d), g[f"rs_d{d}_params"])
+        assert _rel(rs(x), g[f"rs_d{d}_out"]) <= 2e-5
+    ll = _fill(M.LastLayer(16, 1, "LeakyReLU", {"negative_slope": 0.2}, "ReflectionPad1d", 7, {}, True),
+               g["last_params"])
+    assert _rel(ll(x), g["last_out"]) <= 2e-5
+    bs = M.BasisSignalLayer(torch.from_numpy(g["basis_W"]), L=30).to(_dev())
+    assert _rel(bs(torch.from_numpy(g["basis_weight"]).to(_dev())), g["basis_out"]) <= 2e-5
+
+
+# ---------------------------------------------------------------------------
+# whole generators: shrunken configs (full tensors) and the shipped yamls
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,name,cfg", cases.SMALL, ids=[c[0] for c in cases.SMALL])
+def test_small_configs_vs_reference_golden_and_oracle(golden_dir, tag, name, cfg):
+    g = np.load(os.path.join(golden_dir, f"small_{tag}.npz"))
+    m, sd = _model(name, cfg, seed=7)
+    mel = seeded_mel(cases.SMALL_T, seed=5)
+    melb = seeded_mel(cases.SMALL_T, seed=6, batch=cases.SMALL_B)
+    with torch.no_grad():
+        y = m.inference(mel)
+        f = m(torch.from_numpy(melb))
+    assert _err(y, g["inference"]) <= TOL
+    assert _err(y, og.INFERENCE[name](mel, sd, cfg)) <= TOL
+    if name == "basis-melgan":
+        assert _err(f[0], g["forward_src"]) <= TOL
+        assert _rel(f[1], g["forward_w"]) <= TOL
+    else:
+        assert _err(f, g["forward"]) <= TOL
+    # weight-norm lifecycle: removing it must not change the function
+    m.remove_weight_norm()
+    assert not any(k.endswith("weight_g") for k in m.state_dict())
+    with torch.no_grad():
+        y2 = m.inference(mel)
+    assert _err(y2, g["inference"]) <= TOL
+    # ... and re-applying it keeps the state_dict layout of a training checkpoint
+    m.apply_weight_norm()
+    if cfg.get("use_weight_norm", True):
+        assert set(m.state_dict().keys()) == set(sd.keys())
+    with torch.no_grad():
+        assert _err(m.inference(mel), g["inference"]) <= TOL
+
+
+@pytest.mark.parametrize("tag,name,path", cases.SHIPPED, ids=[c[0] for c in cases.SHIPPED])
+def test_shipped_configs_vs_reference_golden(golden_dir, tag, name, path):
+    g = np.load(os.path.join(golden_dir, f"full_{tag}.npz"))
+    cfg = cases.load_conf(path)
+    m, sd = _model(name, cfg, seed=0)
+    with torch.no_grad():
+        y = m.inference(seeded_mel(cases.FULL_T, seed=0))
+        assert _err(y, g["inference_T64"]) <= TOL
+        f = m(torch.from_numpy(seeded_mel(16, seed=3, batch=2)))
+        if name == "basis-melgan":
+            assert _err(f[0], g["forward_T16_src"]) <= TOL
+            assert _rel(f[1], g["forward_T16_w"]) <= TOL
+        else:
+            assert _err(f, g["forward_T16"]) <= TOL
+        # benchmark length (T=1000): strided samples and float64 sums of the reference
+        y = m.inference(seeded_mel(cases.STATS_T, seed=1)).double().cpu().numpy().reshape(-1)
+    assert y.size == int(g["T1000_n"])
+    assert np.abs(y[g["T1000_idx"]] - g["T1000_samples"]).max() <= TOL
+    # distance to the float64 run of the reference: same order as the reference's own fp32 noise
+    assert np.abs(y[g["T1000_idx"]] - g["T1000_samples64"]).max() <= TOL
+    assert abs(y.sum() - float(g["T1000_sum"])) <= TOL * y.size * 0.05
+    assert abs(np.abs(y).sum() - float(g["T1000_abssum"])) <= TOL * y.size * 0.05
+
+
+@pytest.mark.parametrize("tag,name,path", cases.SHIPPED, ids=[c[0] for c in cases.SHIPPED])
+def test_shipped_configs_vs_aten_port_full_length(tag, name, path):
+    """Full tensor at T=250 against the validated ATen port on the host."""
+    cfg = cases.load_conf(path)
+    m, sd = _model(name, cfg, seed=4)
+    mel = seeded_mel(250, seed=8)
+    with torch.no_grad():
+        y = m.inference(mel)
+    ref = torch_port.inference(name, mel, sd, cfg).numpy()
+    assert _err(y, ref) <= TOL
+
+
+def test_batch_rows_are_independent_and_bit_identical():
+    """Utterances never mix: row b of a batched forward equals the single-row call
+    bit for bit (this is what makes N-GPU sharding exact)."""
+    cfg = cases.load_conf("conf/hifigan/light.yaml")
+    m, _ = _model("hifigan", cfg, seed=0)
+    x = torch.from_numpy(seeded_mel(200, seed=11, batch=3)).to(_dev())
+    with torch.no_grad():
+        full = m(x)
+        for b in range(3):
+            one = m(x[b:b + 1].contiguous())
+            assert torch.equal(one[0], full[b])
+
+
+def test_conv_is_linear_without_activation():
+    """conv(a*x1 + x2) == a*conv(x1) + conv(x2) - bias terms (size-independent property)."""
+    dev = _dev()
+    rng = np.random.RandomState(4)
+    w = torch.from_numpy((rng.randn(64, 64, 7) / 21).astype(np.float32)).to(dev)
+    packed = _native.pack_conv1d(w)
+    x1 = torch.from_numpy(rng.randn(1, 64, 100000).astype(np.float32)).to(dev)
+    x2 = torch.from_numpy(rng.randn(1, 64, 100000).astype(np.float32)).to(dev)
+    f = lambda t: _native.conv1d_fused(t, packed, None, 64, 7, dil=3, pad=9)  # noqa: E731
+    lhs = f(2.0 * x1 + x2)
+    rhs = 2.0 * f(x1) + f(x2)
+    assert float((lhs - rhs).abs().max()) <= 2e-5 * float(rhs.abs().max())
+
+
+def test_synthesize_triple_config1(golden_dir, tmp_path):
+    """BASELINE config 1 through the drop-in Synthesizer: checkpoint file with
+    weight norm attached -> (est, est - bias, bias)."""
+    from fastvocoder_amd.bin.synthesize import Synthesizer
+    g = np.load(os.path.join(golden_dir, "synthesize_melgan.npz"))
+    cfg_path = os.path.join(cases.ROOT, "conf/melgan/original.yaml")
+    sd = seeded_state_dict("melgan", cases.load_conf("conf/melgan/original.yaml"), seed=0)
+    ck = str(tmp_path / "ckpt.pth.tar")
+    torch.save({"model": {k: torch.from_numpy(v) for k, v in sd.items()}}, ck)
+    syn = Synthesizer(ck, cfg_path, "melgan")
+    mel = np.random.RandomState(0).rand(80, 200)
+    est, rem, bias = syn.synthesize(mel.T)
+    assert est.shape == (48000,)
+    assert _err(est, g["est"]) <= TOL
+    assert _err(bias, g["bias"]) <= TOL
+    assert _err(rem, g["remove"]) <= TOL
+
+
+def test_errors_are_loud():
+    with pytest.raises(_native.NativeError):
+        fa.HiFiGANGenerator()(torch.zeros(1, 80, 8))      # CPU module: no fallback
+    with pytest.raises(Exception, match="no model find"):
+        build_generator("wavenet", {})
+    dev = _dev()
+    x = torch.zeros(1, 8, 4, device=dev)
+    packed = _native.pack_conv1d(torch.zeros(8, 8, 3, device=dev))
+    with pytest.raises(_native.NativeError):               # reflection pad longer than the input
+        _native.conv1d_fused(x, packed, None, 8, 3, dil=9, pad=9, pad_mode=_native.PAD_REFLECT)
