@@ -36,7 +36,7 @@ def build(force=False, verbose=False):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-value", "-Wno-comment"] + srcs + ["-o", LIB_PATH]
+           "-Wno-unused-value", "-Wno-comment", "-Wno-pass-failed"] + srcs + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1,6 +1,6 @@
 // Implicit-GEMM 1-D convolution on the gfx950 fp32 matrix cores.
 //
-// One kernel family serves every wide convolution on the generator path
+// One kernel family serves every convolution on the generator path
 // (reference call sites: model/generator/modules.py:223-230 ResBlock1,
 // :372-382 ResidualStack, hifigan.py:93-96 conv_pre / ConvTranspose1d,
 // melgan.py:66-85, basis_melgan.py:72-97, modules.py:264-267 basis matmul+OLA):
@@ -15,23 +15,49 @@
 // which is what the 1e-4 end-to-end budget over ~80 chained layers needs
 // (bf16/fp16 MFMA does not fit it; SURVEY.md section 7 "hard parts").
 //
-// Block = 256 threads = 4 wave64.  Per input-channel chunk the block stages
-//   xs[ci_chunk][xw]      the activated input tile with its dilation halo
-//   ws[ci_chunk*k][M_T]   the K-major weight slice (coalesced: Wp is K-major)
-// in LDS, then every wave walks K = ci_chunk*k in steps of 2 (32x32x2) or 4
-// (16x16x4) reading its A (weights) and B (shifted input window) operands with
-// conflict-free ds_read_b32: lanes are consecutive in m for A and consecutive
-// in time for B, so a dilated tap is just an address offset into the same row.
-// The epilogue fuses bias, residual add, the MRF running sum / mean and
-// tanh / ReLU, so no elementwise kernel exists on the path.
+// Structure (per workgroup of WM x WN x WK wave64), shaped by two measured
+// facts: memory latency under load is ~2 us while one (tile, channel-chunk)
+// stage holds only ~0.5-2 us of matrix work per wave, and the fp32 MFMA needs
+// just one ds_read per operand -- so the kernel is latency-, not issue-bound:
+//   * a block walks a run of (time-tile, channel-chunk) STAGES.  Per stage
+//         xs[ci_chunk][xw]      raw input tile with its dilation halo
+//         ws[ci_chunk*k][M_T]   K-major weight slice (dense 2-D block of Wp)
+//     are brought in by LDS-DMA (buffer_load_dwordx4 ... lds): no staging
+//     VGPRs, no ds_write pass, bounds-checked by the buffer descriptor (rows
+//     past Cin read as 0).  The DMA of stage s+1 is issued before the MFMA loop
+//     of stage s into the other LDS buffer; one barrier per stage;
+//   * registers stay at accumulators + addresses, so 4-8 waves per SIMD are
+//     resident and other blocks' matrix work covers what the one-stage
+//     prefetch does not (work units are sized for >= ~1000 blocks per launch);
+//   * the input activation is applied when the B operand is read from LDS
+//     (max(x, slope*x): 2 VALU per 64-cycle MFMA), which is what lets the
+//     staging be a pure copy;
+//   * every wave walks its share of K in steps of 2 (32x32x2) or 4 (16x16x4):
+//     A (weights) and B (shifted input window) operands are ds_read_b32 with
+//     lanes consecutive in m / in time; a dilated tap is an address offset;
+//   * WK > 1 splits the K range of every stage over WK wave groups that share
+//     the staged tiles and reduce through LDS at the end of the tile: more
+//     waves and finer work units when the grid alone cannot fill 256 CUs;
+//   * tiles that touch the sequence ends (zero / reflection padding) and
+//     unaligned tensors take a synchronous register path (stage_x_edge);
+//   * the epilogue fuses bias, residual add, the MRF running sum / mean and
+//     tanh / ReLU through bounds-checked buffer loads/stores (no per-element
+//     branches), so no elementwise kernel exists on the path.
+#include <stdlib.h>
+
 #include "fv_internal.h"
 
 namespace fv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.f ? v : v * slope; }
+constexpr unsigned kOutOfRange = 0xFFFFFFF0u;   // byte offset no descriptor covers -> reads 0
+
+// leaky-ReLU / ReLU / identity for 0 <= slope <= 1 as max(x, slope*x): bitwise
+// equal to x >= 0 ? x : slope*x, branch-free (slope is wave-uniform)
+__device__ __forceinline__ float act(float v, float slope) { return fmaxf(v, v * slope); }
 
 __device__ __forceinline__ int reflect_idx(int i, int T) {
     if (i < 0) i = -i;
@@ -41,83 +67,176 @@ __device__ __forceinline__ int reflect_idx(int i, int T) {
     return min(max(i, 0), T - 1);
 }
 
-// Stage the activated input tile for channels [ci0, ci0+ci_chunk) and global
-// times [tA, tA + 4*ncol4) into xs (row stride p.xw).
-__device__ __forceinline__ void stage_input(const ConvParams& p, float* xs, int b, int ci0,
-                                            int tA, int ncol4, int tid) {
-    const int total = p.ci_chunk * ncol4;
-    for (int idx = tid; idx < total; idx += 256) {
-        const int row = idx / ncol4;
-        const int c4 = idx - row * ncol4;
+// Geometry of one time tile's input window.
+struct Window {
+    int tA;     // global time of LDS column 0 (a multiple of 4, may be negative)
+    int aoff;   // LDS column of the tile's first tap position
+};
+
+__device__ __forceinline__ Window window_of(const ConvParams& p, int t0) {
+    const int tstart = t0 - p.pad;
+    Window w;
+    w.aoff = ((tstart % 4) + 4) % 4;
+    w.tA = tstart - w.aoff;
+    return w;
+}
+
+// interior <=> every column the tile reads is a real sample and rows are 16-byte
+// aligned, so the window can be copied verbatim by the DMA engine
+__device__ __forceinline__ bool interior(const ConvParams& p, int tA) {
+    return p.vec_ok && tA >= 0 && tA + 4 * p.ncol4 <= p.Tin;
+}
+
+// Buffer descriptor over [base, base+bytes): accesses through it are
+// bounds-checked by the hardware (out of range: loads give 0, stores are
+// dropped), so masked lanes need no branch -- they get an out-of-range offset.
+// Built from kernel arguments and blockIdx only => provably wave-uniform.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buffer_load1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ void buffer_store1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)byte_off, 0, 0);
+}
+// 16 bytes per lane straight into LDS: lane l lands at lds + 16*l (wave-uniform base)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, float* lds, unsigned byte_off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 16, (int)byte_off, 0, 0, 0);
+}
+
+// --- asynchronous staging (LDS-DMA) --------------------------------------------
+// The x image is [ci_chunk][ncol4c] float4, the w image [ci_chunk*k][M_T/4]
+// float4, both linear in their float4 index, so instruction j of a wave covers
+// float4s [64j, 64j+64).  Waves take instructions round-robin.
+template <int NW>
+__device__ __forceinline__ void dma_x(const ConvParams& p, __amdgpu_buffer_rsrc_t rx, float* xs,
+                                      int ci0, int tA, int wave, int lane) {
+    const int total = p.ci_chunk * p.ncol4c;
+    for (int j = wave; j * 64 < total; j += NW) {
+        const int idx = j * 64 + lane;
+        const int row = (int)__umulhi((unsigned)idx, p.ncol4c_magic);
+        const int c4 = idx - row * p.ncol4c;
         const int ci = ci0 + row;
-        const int t = tA + 4 * c4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ci < p.Cin) {
-            const float* xr = p.x + ((size_t)b * p.Cin + ci) * (size_t)p.Tin;
-            if (p.vec_ok && t >= 0 && t + 3 < p.Tin) {
-                v = *reinterpret_cast<const float4*>(xr + t);
-            } else if (p.pad_mode == FV_PAD_REFLECT) {
-                v.x = xr[reflect_idx(t, p.Tin)];
-                v.y = xr[reflect_idx(t + 1, p.Tin)];
-                v.z = xr[reflect_idx(t + 2, p.Tin)];
-                v.w = xr[reflect_idx(t + 3, p.Tin)];
-            } else {
-                if (t >= 0 && t < p.Tin) v.x = xr[t];
-                if (t + 1 >= 0 && t + 1 < p.Tin) v.y = xr[t + 1];
-                if (t + 2 >= 0 && t + 2 < p.Tin) v.z = xr[t + 2];
-                if (t + 3 >= 0 && t + 3 < p.Tin) v.w = xr[t + 3];
-            }
-            if (p.pre_slope != 1.f) {
-                v.x = lrelu(v.x, p.pre_slope);
-                v.y = lrelu(v.y, p.pre_slope);
-                v.z = lrelu(v.z, p.pre_slope);
-                v.w = lrelu(v.w, p.pre_slope);
-            }
-        }
-        *reinterpret_cast<float4*>(xs + row * p.xw + 4 * c4) = v;
+        const bool ok = row < p.ci_chunk && ci < p.Cin;
+        dma16(rx, xs + j * 256, ok ? (unsigned)(ci * p.Tin + tA + 4 * c4) * 4u : kOutOfRange);
     }
 }
 
-// Stage the weight slice rows [ci0*k, (ci0+ci_chunk)*k) x columns [m0, m0+M_T).
-template <int M_T>
-__device__ __forceinline__ void stage_weights(const ConvParams& p, float* ws, int ci0, int m0,
-                                              int tid) {
+template <int NW, int M_T>
+__device__ __forceinline__ void dma_w(const ConvParams& p, __amdgpu_buffer_rsrc_t rw, float* ws,
+                                      int ci0, int m0, int wave, int lane) {
     constexpr int C4 = M_T / 4;
-    const int nrow = p.ci_chunk * p.k;
+    const int total = p.ci_chunk * p.k * C4;
     const int krows = p.Cin * p.k;
     const int row0 = ci0 * p.k;
-    for (int idx = tid; idx < nrow * C4; idx += 256) {
-        const int row = idx / C4;
-        const int c = idx - row * C4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + row < krows)
-            v = *reinterpret_cast<const float4*>(p.wp + (size_t)(row0 + row) * p.Mpad + m0 + 4 * c);
-        *reinterpret_cast<float4*>(ws + row * M_T + 4 * c) = v;
+    for (int j = wave; j * 64 < total; j += NW) {
+        const int idx = j * 64 + lane;
+        const int row = row0 + idx / C4, c = idx % C4;
+        const bool ok = idx < total && row < krows;
+        dma16(rw, ws + j * 256, ok ? (unsigned)(row * p.Mpad + m0 + 4 * c) * 4u : kOutOfRange);
     }
 }
 
-// One output element through the fused epilogue.
-__device__ __forceinline__ void epilogue_store(const ConvParams& p, int b, int m, int q, float v) {
-    if (m >= p.M || q >= p.Tq) return;
-    int co = m, t = q;
-    if (p.ups != 1) {
-        co = m / p.ups;
-        t = q * p.ups + (m - co * p.ups);
-        if (t >= p.Tout) return;
+// Synchronous path for tiles that touch the sequence ends or unaligned tensors:
+// zero / reflection padding resolved per element, raw values written to LDS.
+template <int NT>
+__device__ __forceinline__ void stage_x_edge(const ConvParams& p, float* xs, int b, int ci0, int tA,
+                                             int tid) {
+    const int total = p.ci_chunk * p.ncol4c;
+    for (int idx = tid; idx < total; idx += NT) {
+        const int row = (int)__umulhi((unsigned)idx, p.ncol4c_magic);
+        const int c4 = idx - row * p.ncol4c;
+        const int ci = ci0 + row;
+        const int t = tA + 4 * c4;
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ci < p.Cin) {
+            const float* xr = p.x + ((size_t)b * p.Cin + ci) * (size_t)p.Tin;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tj = t + j;
+                if (p.pad_mode == FV_PAD_REFLECT) e[j] = xr[reflect_idx(tj, p.Tin)];
+                else if (tj >= 0 && tj < p.Tin) e[j] = xr[tj];
+            }
+        }
+        *reinterpret_cast<float4*>(xs + idx * 4) = make_float4(e[0], e[1], e[2], e[3]);
     }
-    const size_t o = ((size_t)b * p.Cout + co) * (size_t)p.Tout + t;
-    if (p.bias) v += p.bias[co];
-    if (p.res) v += p.res[o];
-    if (p.acc_in) v = p.acc_in[o] + v;
-    if (p.out_div != 1.f) v = v / p.out_div;
-    if (p.post == FV_POST_TANH) v = tanhf(v);
-    else if (p.post == FV_POST_RELU) v = fmaxf(v, 0.f);
-    p.y[o] = v;
 }
 
-// XCD-aware tile order: the dispatcher places linear block id b on XCD b % 8,
-// so give each XCD a contiguous run of time tiles (neighbouring tiles share
-// halo columns and, for Cout > M_T, the same input tile) -- speed only.
+// --- fused epilogue --------------------------------------------------------------
+// Descriptors of the epilogue tensors of batch item b: a masked element simply
+// gets an out-of-range offset (loads 0, store dropped), so the loads of a tile
+// issue back to back instead of one s_waitcnt vmcnt(0) per element.
+struct EpilogueRsrc {
+    __amdgpu_buffer_rsrc_t y, res, acc, bias;
+};
+
+__device__ __forceinline__ EpilogueRsrc epilogue_rsrc(const ConvParams& p, int b) {
+    const size_t boff = (size_t)b * p.Cout * (size_t)p.Tout;
+    const unsigned bytes = (unsigned)p.Cout * (unsigned)p.Tout * 4u;
+    EpilogueRsrc e;
+    e.y = make_rsrc(p.y + boff, bytes);
+    e.res = make_rsrc(p.res ? p.res + boff : p.y + boff, bytes);
+    e.acc = make_rsrc(p.acc_in ? p.acc_in + boff : p.y + boff, bytes);
+    e.bias = make_rsrc(p.bias ? p.bias : p.y, p.bias ? (unsigned)p.Cout * 4u : 0u);
+    return e;
+}
+
+// N output elements of one thread:  y = post( ( acc_in + ( (v + bias) + res ) ) / out_div )
+// rows m[i] (GEMM rows) at column q; all uniform switches are hoisted.
+template <int N>
+__device__ __forceinline__ void epilogue_store(const ConvParams& p, const EpilogueRsrc& e,
+                                               const int (&m)[N], int q, float (&v)[N]) {
+    unsigned off[N], boff[N];
+    const bool qok = q < p.Tq;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        int co = m[i], t = q;
+        if (p.ups != 1) {
+            co = m[i] / p.ups;
+            t = q * p.ups + (m[i] - co * p.ups);
+        }
+        const bool ok = qok && m[i] < p.M && t < p.Tout;
+        off[i] = ok ? (unsigned)(co * p.Tout + t) * 4u : kOutOfRange;
+        boff[i] = ok ? (unsigned)co * 4u : kOutOfRange;
+    }
+    // issue every load of the batch before the first use (one latency, not three)
+    float bv[N], rv[N], av[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) bv[i] = rv[i] = av[i] = 0.f;
+    if (p.bias) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) bv[i] = buffer_load1(e.bias, boff[i]);
+    }
+    if (p.res) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) rv[i] = buffer_load1(e.res, off[i]);
+    }
+    if (p.acc_in) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) av[i] = buffer_load1(e.acc, off[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = av[i] + ((v[i] + bv[i]) + rv[i]);
+    if (p.out_div != 1.f) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = v[i] / p.out_div;
+    }
+    if (p.post == FV_POST_TANH) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = tanhf(v[i]);
+    } else if (p.post == FV_POST_RELU) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) buffer_store1(e.y, off[i], v[i]);
+}
+
+// XCD-aware block order: the dispatcher places linear block id b on XCD b % 8,
+// so give each XCD a contiguous run of work (blocks that share an input tile
+// because Cout > M_T, and neighbours in time that share halo columns, then
+// meet in one L2) -- speed only, never correctness.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = bid & 7, within = bid >> 3;
@@ -125,207 +244,241 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return base + within;
 }
 
+// MFMA shape traits: MF = 32 -> v_mfma_f32_32x32x2_f32 (K step 2, 16 acc regs),
+//                    MF = 16 -> v_mfma_f32_16x16x4_f32 (K step 4,  4 acc regs).
+template <int MF>
+struct Frag;
+template <>
+struct Frag<32> {
+    typedef f32x16 acc_t;
+    static constexpr int KS = 2, REGS = 16;
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    // C/D map: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+    static __device__ __forceinline__ int row(int reg, int lane) {
+        return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    }
+};
+template <>
+struct Frag<16> {
+    typedef f32x4 acc_t;
+    static constexpr int KS = 4, REGS = 4;
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    // C/D map: col = lane & 15, row = 4*(lane >> 4) + reg
+    static __device__ __forceinline__ int row(int reg, int lane) { return 4 * (lane >> 4) + reg; }
+};
+
 // ---------------------------------------------------------------------------
-// 32x32x2 variant: block tile (32*WM) x (32*NR*WN), WM*WN = 4 waves.
+// The kernel.  Block tile (MF*WM) x (MF*NR*WN); WK wave groups split K.
 // KT > 0 fixes the tap count at compile time (full unroll of the tap loop).
 // ---------------------------------------------------------------------------
-template <int WM, int WN, int NR, int KT>
-__global__ __launch_bounds__(256) void conv_mfma32_kernel(ConvParams p) {
-    constexpr int M_T = 32 * WM;
-    constexpr int N_T = 32 * NR * WN;
+template <int MF, int WM, int WN, int WK, int NR, int KT>
+__global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvParams p) {
+    typedef Frag<MF> F;
+    typedef typename F::acc_t acc_t;
+    constexpr int NW = WM * WN * WK;
+    constexpr int NT = 64 * NW;
+    constexpr int M_T = MF * WM;
+    constexpr int N_T = MF * NR * WN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int k = KT > 0 ? KT : p.k;
-    float* xs = smem;
-    float* ws = smem + p.ci_chunk * p.xw;
+    float* const xs0 = smem;                      // 2 x p.xbuf floats
+    float* const ws0 = smem + 2 * p.xbuf;         // 2 x p.wbuf floats
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int wave_m = wave / WN, wave_n = wave % WN;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
+    const int lm = lane & (MF - 1), kq = lane / MF;   // position inside the MFMA operand
+    const int wk = wave / (WM * WN);
+    const int wave_m = (wave / WN) % WM, wave_n = wave % WN;
 
-    const int n_tiles = (p.Tq + N_T - 1) / N_T;
+    // this block's run of time tiles [tile_lo, tile_hi) for its m tile
     const int m_tiles = p.Mpad / M_T;
     const int lin = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = lin % m_tiles, nt = lin / m_tiles;
+    const int mt = lin % m_tiles, run = lin / m_tiles;
+    const int runs = gridDim.x / m_tiles;
+    const int tile_lo = (int)((long long)run * p.n_tiles / runs);
+    const int tile_hi = (int)((long long)(run + 1) * p.n_tiles / runs);
     const int b = blockIdx.y;
-    const int m0 = mt * M_T, t0 = nt * N_T;
-    (void)n_tiles;
+    const int m0 = mt * M_T;
+    const int nchunks = (p.Cin + p.ci_chunk - 1) / p.ci_chunk;
+    const int nstages = (tile_hi - tile_lo) * nchunks;
+    if (nstages <= 0) return;
 
-    const int halo = (k - 1) * p.dil;
-    const int tstart = t0 - p.pad;
-    const int aoff = ((tstart % 4) + 4) % 4;
-    const int tA = tstart - aoff;
-    const int ncol4 = (N_T + halo + aoff + 3) >> 2;
+    acc_t acc[NR];
+    const __amdgpu_buffer_rsrc_t rx =
+        make_rsrc(p.x + (size_t)b * p.Cin * (size_t)p.Tin, (unsigned)p.Cin * (unsigned)p.Tin * 4u);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.wp, (unsigned)p.Cin * (unsigned)p.k * (unsigned)p.Mpad * 4u);
+    const EpilogueRsrc ersrc = epilogue_rsrc(p, b);
 
-    f32x16 acc[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+    // prologue: stage 0 -> buffer 0
+    {
+        const Window w = window_of(p, tile_lo * N_T);
+        dma_w<NW, M_T>(p, rw, ws0, 0, m0, wave, lane);
+        if (interior(p, w.tA)) dma_x<NW>(p, rx, xs0, 0, w.tA, wave, lane);
+        else stage_x_edge<NT>(p, xs0, b, 0, w.tA, tid);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
-    const float* wsA = ws + wave_m * 32 + l31;
-    const float* xsB = xs + aoff + wave_n * (32 * NR) + l31;
-
-    for (int ci0 = 0; ci0 < p.Cin; ci0 += p.ci_chunk) {
-        stage_input(p, xs, b, ci0, tA, ncol4, tid);
-        stage_weights<M_T>(p, ws, ci0, m0, tid);
-        __syncthreads();
-        for (int c2 = 0; c2 < p.ci_chunk; c2 += 2) {
-            const int ci = c2 + hi;
-            const float* pa = wsA + ci * k * M_T;
-            const float* pb = xsB + ci * p.xw;
-            if constexpr (KT > 0) {
+    int tile = tile_lo, chunk = 0;
+    for (int s = 0; s < nstages; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        // next stage's coordinates
+        int ntile = tile, nchunk = chunk + 1;
+        if (nchunk == nchunks) {
+            nchunk = 0;
+            ++ntile;
+        }
+        const bool more = s + 1 < nstages && !(p.dbg & 2);
+        const Window wn = window_of(p, ntile * N_T);
+        const bool fast = interior(p, wn.tA);
+        if (more) {
+            // asynchronous: lands in the other buffer while this stage computes
+            if (fast) dma_x<NW>(p, rx, xs0 + nxt * p.xbuf, nchunk * p.ci_chunk, wn.tA, wave, lane);
+            if (nchunks > 1) dma_w<NW, M_T>(p, rw, ws0 + nxt * p.wbuf, nchunk * p.ci_chunk, m0, wave, lane);
+        }
+        if (chunk == 0) {
 #pragma unroll
-                for (int tap = 0; tap < KT; ++tap) {
-                    const float a = pa[tap * M_T];
+            for (int r = 0; r < NR; ++r)
 #pragma unroll
-                    for (int r = 0; r < NR; ++r)
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[tap * p.dil + r * 32],
-                                                                      acc[r], 0, 0, 0);
-                }
-            } else {
-                for (int tap = 0; tap < k; ++tap) {
-                    const float a = pa[tap * M_T];
+                for (int i = 0; i < F::REGS; ++i) acc[r][i] = 0.f;
+        }
+        // ---- matrix work on the current buffers ----
+        {
+            const Window w = window_of(p, tile * N_T);
+            // with a single chunk the weights never change: they stay in buffer 0
+            const float* wsA = ws0 + (nchunks > 1 ? cur * p.wbuf : 0) + wave_m * MF + lm;
+            const float* xsB = xs0 + cur * p.xbuf + w.aoff + wave_n * (MF * NR) + lm;
+            const float slope = p.pre_slope;
+            for (int c = wk * F::KS; c < ((p.dbg & 4) ? 0 : p.ci_chunk); c += F::KS * WK) {
+                const int ci = c + kq;
+                const float* pa = wsA + ci * k * M_T;
+                const float* pb = xsB + ci * p.xw;
+                if constexpr (KT > 0) {
 #pragma unroll
-                    for (int r = 0; r < NR; ++r)
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[tap * p.dil + r * 32],
-                                                                      acc[r], 0, 0, 0);
+                    for (int tap = 0; tap < KT; ++tap) {
+                        const float a = pa[tap * M_T];
+#pragma unroll
+                        for (int r = 0; r < NR; ++r)
+                            acc[r] = F::mfma(a, act(pb[tap * p.dil + r * MF], slope), acc[r]);
+                    }
+                } else {
+                    for (int tap = 0; tap < k; ++tap) {
+                        const float a = pa[tap * M_T];
+#pragma unroll
+                        for (int r = 0; r < NR; ++r)
+                            acc[r] = F::mfma(a, act(pb[tap * p.dil + r * MF], slope), acc[r]);
+                    }
                 }
             }
         }
-        __syncthreads();
-    }
-
-    // C/D map of 32x32: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const int q = t0 + wave_n * (32 * NR) + r * 32 + l31;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int m = m0 + wave_m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi;
-            epilogue_store(p, b, m, q, acc[r][i]);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// 16x16x4 variant for M <= 16 rows (the C = 16 stage, the basis matmul+OLA):
-// block tile 16 x (16*NR*4), four waves side by side in time.
-// ---------------------------------------------------------------------------
-template <int NR, int KT>
-__global__ __launch_bounds__(256) void conv_mfma16_kernel(ConvParams p) {
-    constexpr int M_T = 16;
-    constexpr int N_T = 16 * NR * 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int k = KT > 0 ? KT : p.k;
-    float* xs = smem;
-    float* ws = smem + p.ci_chunk * p.xw;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, kq = lane >> 4;
-
-    const int m_tiles = p.Mpad / M_T;
-    const int lin = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = lin % m_tiles, nt = lin / m_tiles;
-    const int b = blockIdx.y;
-    const int m0 = mt * M_T, t0 = nt * N_T;
-
-    const int halo = (k - 1) * p.dil;
-    const int tstart = t0 - p.pad;
-    const int aoff = ((tstart % 4) + 4) % 4;
-    const int tA = tstart - aoff;
-    const int ncol4 = (N_T + halo + aoff + 3) >> 2;
-
-    f32x4 acc[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[r][i] = 0.f;
-
-    const float* wsA = ws + l15;
-    const float* xsB = xs + aoff + wave * (16 * NR) + l15;
-
-    for (int ci0 = 0; ci0 < p.Cin; ci0 += p.ci_chunk) {
-        stage_input(p, xs, b, ci0, tA, ncol4, tid);
-        stage_weights<M_T>(p, ws, ci0, m0, tid);
-        __syncthreads();
-        for (int c4 = 0; c4 < p.ci_chunk; c4 += 4) {
-            const int ci = c4 + kq;
-            const float* pa = wsA + ci * k * M_T;
-            const float* pb = xsB + ci * p.xw;
-            if constexpr (KT > 0) {
-#pragma unroll
-                for (int tap = 0; tap < KT; ++tap) {
-                    const float a = pa[tap * M_T];
+        if (more && !fast)
+            stage_x_edge<NT>(p, xs0 + nxt * p.xbuf, b, nchunk * p.ci_chunk, wn.tA, tid);
+        if (chunk == nchunks - 1) {
+            // ---- tile finished: (split-K reduce and) fused epilogue ----
+            const int t0 = tile * N_T;
+            if constexpr (WK > 1) {
+                // partial sums of groups 1..WK-1 go through a dedicated LDS area
+                float* red = smem + p.red_off;
+                if (wk > 0) {
+                    float* dst = red + ((wk - 1) * (WM * WN) + wave_m * WN + wave_n) *
+                                           (NR * F::REGS * 64) + lane;
 #pragma unroll
                     for (int r = 0; r < NR; ++r)
-                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pb[tap * p.dil + r * 16],
-                                                                      acc[r], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < F::REGS; ++i) dst[(r * F::REGS + i) * 64] = acc[r][i];
                 }
-            } else {
-                for (int tap = 0; tap < k; ++tap) {
-                    const float a = pa[tap * M_T];
+                __syncthreads();
+                if (wk == 0) {
 #pragma unroll
-                    for (int r = 0; r < NR; ++r)
-                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pb[tap * p.dil + r * 16],
-                                                                      acc[r], 0, 0, 0);
+                    for (int g = 1; g < WK; ++g) {
+                        const float* src = red + ((g - 1) * (WM * WN) + wave_m * WN + wave_n) *
+                                                     (NR * F::REGS * 64) + lane;
+#pragma unroll
+                        for (int r = 0; r < NR; ++r)
+#pragma unroll
+                            for (int i = 0; i < F::REGS; ++i) acc[r][i] += src[(r * F::REGS + i) * 64];
+                    }
+                }
+            }
+            if ((WK == 1 || wk == 0) && !(p.dbg & 1)) {
+                constexpr int EN = F::REGS < 8 ? F::REGS : 8;   // elements per epilogue batch
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int q = t0 + wave_n * (MF * NR) + r * MF + lm;
+#pragma unroll
+                    for (int h = 0; h < F::REGS / EN; ++h) {
+                        int mm[EN];
+                        float vv[EN];
+#pragma unroll
+                        for (int i = 0; i < EN; ++i) {
+                            mm[i] = m0 + wave_m * MF + F::row(h * EN + i, lane);
+                            vv[i] = acc[r][h * EN + i];
+                        }
+                        epilogue_store<EN>(p, ersrc, mm, q, vv);
+                    }
                 }
             }
         }
+        // the DMA issued above must have landed (own wave: vmcnt; others: barrier)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-    }
-
-    // C/D map of 16x16: col = lane & 15, row = 4*(lane >> 4) + reg
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const int q = t0 + wave * (16 * NR) + r * 16 + l15;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) epilogue_store(p, b, m0 + 4 * kq + i, q, acc[r][i]);
+        tile = ntile;
+        chunk = nchunk;
     }
 }
 
 // ---------------------------------------------------------------------------
 // Narrow-output variant (Cout <= 4: conv_post hifigan.py:105 /
 // multiband_hifigan.py:114, LastLayer modules.py:85-89).  HBM-bound
-// (3.3 FLOP/B): one thread per output time step, weights broadcast from LDS,
-// the input tile staged exactly like the MFMA variants.
+// (3.3 FLOP/B): one thread per output time step, weights broadcast from LDS.
 // ---------------------------------------------------------------------------
 template <int MO>
 __global__ __launch_bounds__(256) void conv_narrow_kernel(ConvParams p) {
-    constexpr int N_T = 256;
+    constexpr int N_T = 256, NT = 256, NW = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;
-    float* ws = smem + p.ci_chunk * p.xw;  // [ci_chunk*k][16]
+    float* ws = smem + p.xbuf;  // [ci_chunk*k][16]
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
     const int t0 = xcd_remap(blockIdx.x, gridDim.x) * N_T;
     const int k = p.k;
-    const int halo = (k - 1) * p.dil;
-    const int tstart = t0 - p.pad;
-    const int aoff = ((tstart % 4) + 4) % 4;
-    const int tA = tstart - aoff;
-    const int ncol4 = (N_T + halo + aoff + 3) >> 2;
+    const Window w = window_of(p, t0);
     float acc[MO];
 #pragma unroll
     for (int m = 0; m < MO; ++m) acc[m] = 0.f;
+    const __amdgpu_buffer_rsrc_t rx =
+        make_rsrc(p.x + (size_t)b * p.Cin * (size_t)p.Tin, (unsigned)p.Cin * (unsigned)p.Tin * 4u);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.wp, (unsigned)p.Cin * (unsigned)p.k * (unsigned)p.Mpad * 4u);
+    const float slope = p.pre_slope;
     for (int ci0 = 0; ci0 < p.Cin; ci0 += p.ci_chunk) {
-        stage_input(p, xs, b, ci0, tA, ncol4, tid);
-        stage_weights<16>(p, ws, ci0, 0, tid);
+        dma_w<NW, 16>(p, rw, ws, ci0, 0, wave, lane);
+        if (interior(p, w.tA)) dma_x<NW>(p, rx, xs, ci0, w.tA, wave, lane);
+        else stage_x_edge<NT>(p, xs, b, ci0, w.tA, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const float* pb = xs + aoff + tid;
+        const float* pb = xs + w.aoff + tid;
         for (int ci = 0; ci < p.ci_chunk; ++ci) {
             for (int tap = 0; tap < k; ++tap) {
-                const float xv = pb[ci * p.xw + tap * p.dil];
-                const float* wr = ws + (ci * k + tap) * 16;
+                const float xv = act(pb[ci * p.xw + tap * p.dil], slope);
+                const float* wrow = ws + (ci * k + tap) * 16;
 #pragma unroll
-                for (int m = 0; m < MO; ++m) acc[m] = fmaf(wr[m], xv, acc[m]);
+                for (int m = 0; m < MO; ++m) acc[m] = fmaf(wrow[m], xv, acc[m]);
             }
         }
         __syncthreads();
     }
+    const EpilogueRsrc ersrc = epilogue_rsrc(p, b);
+    int mm[MO];
 #pragma unroll
-    for (int m = 0; m < MO; ++m) epilogue_store(p, b, m, t0 + tid, acc[m]);
+    for (int m = 0; m < MO; ++m) mm[m] = m;
+    epilogue_store<MO>(p, ersrc, mm, t0 + tid, acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -333,64 +486,103 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(ConvParams p) {
 // ---------------------------------------------------------------------------
 namespace {
 
-template <typename K>
-int launch_one(K kernel, const ConvParams& p, int m_t, int n_t, size_t lds, hipStream_t s) {
-    const int n_tiles = (p.Tq + n_t - 1) / n_t;
-    const int m_tiles = p.Mpad / m_t;
-    dim3 grid(n_tiles * m_tiles, p.B), block(256);
-    if (lds > 64 * 1024) {
-        FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+struct Geometry {
+    int mf, wm, wn, wk, nr;
+    int m_t() const { return mf * wm; }
+    int n_t() const { return mf * nr * wn; }
+    int threads() const { return 64 * wm * wn * wk; }
+};
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// LDS image of the input tile: ncol4c float4 columns per channel row.  For the
+// 16x16x4 MFMA the row stride is made = 16 (mod 32) floats so the two k-rows a
+// half-wave reads sit on disjoint banks.
+void plan_x_image(ConvParams& p, int n_t, bool mfma16) {
+    const int halo = (p.k - 1) * p.dil;
+    p.ncol4 = (n_t + halo + 3 + 3) / 4;
+    int c = p.ncol4;
+    if (mfma16) {
+        while (c % 8 != 4) ++c;
     }
-    hipLaunchKernelGGL(kernel, grid, block, lds, s, p);
+    p.ncol4c = c;
+    p.xw = 4 * c;
+    p.ncol4c_magic = (unsigned)(((1ull << 32) + c - 1) / c);
+}
+
+// Fill in the staging geometry for tile shape g; returns the dynamic LDS bytes
+// or 0 when the shape cannot be staged within the LDS budget.
+size_t plan_staging(ConvParams& p, const Geometry& g, int k_rows_target) {
+    plan_x_image(p, g.n_t(), g.mf == 16);
+    const int ks = (g.mf == 32 ? 2 : 4) * g.wk;     // ci granularity of one MFMA step x split
+    const int cin_pad = round_up(p.Cin, ks);
+    // stage size: about k_rows_target MFMA K-rows (ci_chunk*k), both buffers <= ~40 KiB
+    // so that several blocks stay resident per CU; prefer chunks dividing Cin
+    int best = 0;
+    for (int c = ks; c <= cin_pad; c += ks) {
+        const size_t per_buf = (size_t)round_up(c * p.ncol4c, 64) * 16 + (size_t)round_up(c * p.k * g.m_t() / 4, 64) * 16;
+        if (best && 2 * per_buf > (size_t)env_int("FV_LDS_BUDGET", 40) * 1024) break;
+        if (cin_pad % c == 0 || !best) best = c;
+        if (c * p.k >= k_rows_target && cin_pad % c == 0) break;
+    }
+    p.ci_chunk = best;
+    p.xbuf = round_up(best * p.ncol4c, 64) * 4;
+    p.wbuf = round_up(best * p.k * g.m_t() / 4, 64) * 4;
+    size_t floats = (size_t)2 * (p.xbuf + p.wbuf);
+    p.red_off = (int)floats;
+    if (g.wk > 1) floats += (size_t)(g.wk - 1) * g.wm * g.wn * g.nr * (g.mf == 32 ? 16 : 4) * 64;
+    return floats * 4;
+}
+
+template <int MF, int WM, int WN, int WK, int NR>
+int launch_geom(const ConvParams& p, size_t lds, int grid_x, hipStream_t s) {
+    dim3 grid(grid_x, p.B), block(64 * WM * WN * WK);
+#define FV_LAUNCH(KT)                                                                         \
+    do {                                                                                      \
+        auto kern = conv_mfma_kernel<MF, WM, WN, WK, NR, KT>;                                 \
+        if (lds > 64 * 1024)                                                                  \
+            FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, p);                                     \
+    } while (0)
+    switch (p.k) {
+        case 1: FV_LAUNCH(1); break;
+        case 3: FV_LAUNCH(3); break;
+        case 7: FV_LAUNCH(7); break;
+        case 11: FV_LAUNCH(11); break;
+        default: FV_LAUNCH(0); break;
+    }
+#undef FV_LAUNCH
     FV_HIP(hipGetLastError());
     return 0;
 }
 
-template <int WM, int WN, int NR>
-int launch32(const ConvParams& p, size_t lds, hipStream_t s) {
-    constexpr int m_t = 32 * WM, n_t = 32 * NR * WN;
-    switch (p.k) {
-        case 1: return launch_one(conv_mfma32_kernel<WM, WN, NR, 1>, p, m_t, n_t, lds, s);
-        case 3: return launch_one(conv_mfma32_kernel<WM, WN, NR, 3>, p, m_t, n_t, lds, s);
-        case 7: return launch_one(conv_mfma32_kernel<WM, WN, NR, 7>, p, m_t, n_t, lds, s);
-        case 11: return launch_one(conv_mfma32_kernel<WM, WN, NR, 11>, p, m_t, n_t, lds, s);
-        default: return launch_one(conv_mfma32_kernel<WM, WN, NR, 0>, p, m_t, n_t, lds, s);
-    }
-}
+// The tile shapes built into the library, by id.
+const Geometry kShapes[] = {
+    {16, 1, 4, 1, 2},   // 0: 16 x 128
+    {16, 1, 2, 2, 2},   // 1: 16 x 64,  K split 2
+    {32, 1, 4, 1, 1},   // 2: 32 x 128
+    {32, 1, 2, 2, 1},   // 3: 32 x 64,  K split 2
+    {32, 1, 1, 4, 1},   // 4: 32 x 32,  K split 4
+    {32, 2, 2, 1, 1},   // 5: 64 x 64
+    {32, 2, 1, 2, 1},   // 6: 64 x 32,  K split 2
+    {32, 2, 2, 1, 2},   // 7: 64 x 128
+};
 
-template <int NR>
-int launch16(const ConvParams& p, size_t lds, hipStream_t s) {
-    constexpr int n_t = 16 * NR * 4;
-    switch (p.k) {
-        case 3: return launch_one(conv_mfma16_kernel<NR, 3>, p, 16, n_t, lds, s);
-        case 7: return launch_one(conv_mfma16_kernel<NR, 7>, p, 16, n_t, lds, s);
-        case 11: return launch_one(conv_mfma16_kernel<NR, 11>, p, 16, n_t, lds, s);
-        default: return launch_one(conv_mfma16_kernel<NR, 0>, p, 16, n_t, lds, s);
+int launch_shape(int id, const ConvParams& p, size_t lds, int grid_x, hipStream_t s) {
+    switch (id) {
+        case 0: return launch_geom<16, 1, 4, 1, 2>(p, lds, grid_x, s);
+        case 1: return launch_geom<16, 1, 2, 2, 2>(p, lds, grid_x, s);
+        case 2: return launch_geom<32, 1, 4, 1, 1>(p, lds, grid_x, s);
+        case 3: return launch_geom<32, 1, 2, 2, 1>(p, lds, grid_x, s);
+        case 4: return launch_geom<32, 1, 1, 4, 1>(p, lds, grid_x, s);
+        case 5: return launch_geom<32, 2, 2, 1, 1>(p, lds, grid_x, s);
+        case 6: return launch_geom<32, 2, 1, 2, 1>(p, lds, grid_x, s);
+        default: return launch_geom<32, 2, 2, 1, 2>(p, lds, grid_x, s);
     }
-}
-
-// LDS row stride of the input tile: room for the tile, its halo and the
-// alignment slack, a multiple of 4 floats (float4 staging writes) and, for the
-// 16x16x4 variant, = 16 (mod 32) so the two k-rows a half-wave reads sit on
-// disjoint banks.
-int row_stride(int n_t, int halo, bool mfma16) {
-    int xw = round_up(n_t + halo + 3, 4) + 4;
-    if (mfma16) {
-        while (xw % 32 != 16) xw += 4;
-    }
-    return xw;
-}
-
-// Input channels staged per LDS round: enough K per barrier pair to amortise
-// it (>= ~64 MFMA k-steps), bounded by Cin and by ~48 KiB of LDS.
-int pick_ci_chunk(const ConvParams& p, int m_t, int xw, int step) {
-    int want = (96 + p.k - 1) / p.k;             // ci_chunk * k ~ 96
-    want = round_up(want < step ? step : want, step);
-    int cin_pad = round_up(p.Cin, step);
-    if (want > cin_pad) want = cin_pad;
-    while (want > step && (size_t)want * (xw + p.k * m_t) * 4 > 48 * 1024) want -= step;
-    return want;
 }
 
 }  // namespace
@@ -401,48 +593,69 @@ int launch_conv(ConvParams p, hipStream_t s) {
     if (p.pad_mode == FV_PAD_REFLECT && p.pad >= p.Tin)
         return fail(FV_ERR_INVALID_ARG, "reflection pad %d needs an input longer than it (T=%d)",
                     p.pad, p.Tin);
+    if (p.pre_slope < 0.f || p.pre_slope > 1.f)
+        return fail(FV_ERR_INVALID_ARG, "conv: input activation slope %g outside [0, 1]", p.pre_slope);
+    if ((double)p.Cin * p.Tin * 4.0 >= 2147483648.0 || (double)p.Cin * p.k * p.Mpad * 4.0 >= 2147483648.0 ||
+        (double)p.Cout * p.Tout * 4.0 >= 2147483648.0)
+        return fail(FV_ERR_UNSUPPORTED, "conv: one utterance's tensor (%d x %d floats) exceeds the 2 GiB "
+                    "buffer-descriptor range; split the utterance", p.Cin, p.Tin);
     p.vec_ok = (p.Tin % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
-    const int halo = (p.k - 1) * p.dil;
     const double flops = 2.0 * p.B * (double)p.M * p.Tq * p.Cin * p.k;
     const double bytes = 4.0 * ((double)p.B * p.Cin * p.Tin + (double)p.B * p.Cout * p.Tout *
                                 (1 + (p.res != nullptr) + (p.acc_in != nullptr)) +
                                 (double)p.Cin * p.k * p.M);
-    int rc, kind;
+    int rc = 0, kind;
+    p.dbg = env_int("FV_DBG", 0);
     profile_begin(s);
     if (p.ups == 1 && p.M <= 4) {
         kind = FV_KERNEL_CONV_NARROW;
-        p.xw = row_stride(256, halo, false);
-        p.ci_chunk = pick_ci_chunk(p, 16, p.xw, 1);
-        const size_t lds = (size_t)p.ci_chunk * (p.xw + p.k * 16) * 4;
-        if (p.M == 1) rc = launch_one(conv_narrow_kernel<1>, p, p.Mpad, 256, lds, s);
-        else if (p.M == 2) rc = launch_one(conv_narrow_kernel<2>, p, p.Mpad, 256, lds, s);
-        else rc = launch_one(conv_narrow_kernel<4>, p, p.Mpad, 256, lds, s);
-    } else if (p.Mpad == 16) {
-        kind = FV_KERNEL_CONV_MFMA16;
-        const bool big = (long)p.B * ((p.Tq + 255) / 256) >= 512;
-        const int n_t = big ? 256 : 128;
-        p.xw = row_stride(n_t, halo, true);
-        p.ci_chunk = pick_ci_chunk(p, 16, p.xw, 4);
-        const size_t lds = (size_t)p.ci_chunk * (p.xw + p.k * 16) * 4;
-        rc = big ? launch16<4>(p, lds, s) : launch16<2>(p, lds, s);
-    } else if (p.Mpad % 64 == 0) {
-        kind = FV_KERNEL_CONV_MFMA32;
-        const long blocks128 = (long)p.B * (p.Mpad / 64) * ((p.Tq + 127) / 128);
-        const bool big = blocks128 >= 512;
-        const int n_t = big ? 128 : 64;
-        p.xw = row_stride(n_t, halo, false);
-        p.ci_chunk = pick_ci_chunk(p, 64, p.xw, 2);
-        const size_t lds = (size_t)p.ci_chunk * (p.xw + p.k * 64) * 4;
-        rc = big ? launch32<2, 2, 2>(p, lds, s) : launch32<2, 2, 1>(p, lds, s);
+        plan_x_image(p, 256, false);
+        int c = 1;
+        while (c + 1 <= p.Cin && (size_t)(round_up((c + 1) * p.ncol4c, 64) + round_up((c + 1) * p.k * 4, 64)) * 16 <= 48 * 1024)
+            ++c;
+        p.ci_chunk = c;
+        p.xbuf = round_up(c * p.ncol4c, 64) * 4;
+        p.wbuf = round_up(c * p.k * 4, 64) * 4;
+        const size_t lds = (size_t)(p.xbuf + p.wbuf) * 4;
+        dim3 grid((p.Tq + 255) / 256, p.B), block(256);
+        if (p.M == 1) hipLaunchKernelGGL(conv_narrow_kernel<1>, grid, block, lds, s, p);
+        else if (p.M == 2) hipLaunchKernelGGL(conv_narrow_kernel<2>, grid, block, lds, s, p);
+        else hipLaunchKernelGGL(conv_narrow_kernel<4>, grid, block, lds, s, p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = fail((int)e, "narrow conv launch: %s", hipGetErrorString(e));
     } else {
-        kind = FV_KERNEL_CONV_MFMA32;
-        const long blocks256 = (long)p.B * (p.Mpad / 32) * ((p.Tq + 255) / 256);
-        const bool big = blocks256 >= 512;
-        const int n_t = big ? 256 : 128;
-        p.xw = row_stride(n_t, halo, false);
-        p.ci_chunk = pick_ci_chunk(p, 32, p.xw, 2);
-        const size_t lds = (size_t)p.ci_chunk * (p.xw + p.k * 32) * 4;
-        rc = big ? launch32<1, 4, 2>(p, lds, s) : launch32<1, 4, 1>(p, lds, s);
+        // ---- tile shape: wide tiles when the utterance alone yields enough work
+        // units, otherwise narrower tiles with the K range split over more waves.
+        // The choice depends on per-utterance sizes only (never on B), so a
+        // batch sharded over GPUs reproduces the single-GPU result bit for bit.
+        const bool m16 = p.Mpad == 16;
+        const bool m64 = !m16 && p.Mpad % 64 == 0;
+        kind = m16 ? FV_KERNEL_CONV_MFMA16 : FV_KERNEL_CONV_MFMA32;
+        auto units = [&](int id) {
+            const Geometry& gg = kShapes[id];
+            return (long)(p.Mpad / gg.m_t()) * ((p.Tq + gg.n_t() - 1) / gg.n_t());
+        };
+        const int want = env_int("FV_UNITS", 900);
+        int shape;
+        if (m16) shape = units(0) >= want ? 0 : 1;
+        else if (units(2) >= want && !m64) shape = 2;
+        else if (m64 && units(5) >= want) shape = 5;
+        else if (units(3) >= want) shape = 3;
+        else shape = 4;
+        const int force = env_int(m16 ? "FV_SHAPE16" : (m64 ? "FV_SHAPE64" : "FV_SHAPE32"), -1);
+        if (force >= 0 && force < 8 && kShapes[force].mf == (m16 ? 16 : 32) &&
+            p.Mpad % kShapes[force].m_t() == 0)
+            shape = force;
+        const Geometry g = kShapes[shape];
+        const size_t lds = plan_staging(p, g, env_int("FV_KROWS", 96));
+        p.n_tiles = (p.Tq + g.n_t() - 1) / g.n_t();
+        const int m_tiles = p.Mpad / g.m_t();
+        // runs of consecutive time tiles per block: cap the grid (launch cost only)
+        const int cap = env_int("FV_GRID_CAP", 8192);
+        int runs = p.n_tiles;
+        const long per_batch_cap = cap / ((long)p.B * m_tiles) > 0 ? cap / ((long)p.B * m_tiles) : 1;
+        if (runs > per_batch_cap) runs = (int)per_batch_cap;
+        rc = launch_shape(shape, p, lds, runs * m_tiles, s);
     }
     profile_end(s, kind, flops, bytes);
     return rc;

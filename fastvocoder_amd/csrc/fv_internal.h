@@ -60,7 +60,16 @@ struct ConvParams {
     float pre_slope, out_div;
     int post;
     // filled in by the launcher
-    int ci_chunk, xw, vec_ok;
+    int ci_chunk;   // input channels staged per LDS stage
+    int xw;         // LDS row stride of the input tile (floats)
+    int ncol4;      // float4 columns of an input row the tile actually reads
+    int ncol4c;     // float4 columns per row of the LDS image (>= ncol4; xw = 4*ncol4c)
+    unsigned ncol4c_magic;  // ceil(2^32 / ncol4c): idx / ncol4c == umulhi(idx, magic)
+    int xbuf, wbuf; // floats per LDS buffer of the x / w image (multiples of 256)
+    int n_tiles;    // time tiles per batch item
+    int red_off;    // float offset of the split-K reduction area in LDS
+    int vec_ok;     // rows are 16-byte aligned: float4 global loads allowed
+    int dbg;        // ablation switches (FV_DBG, tuning only): 1 no epilogue, 2 no restaging, 4 no MFMA
 };
 
 int launch_conv(ConvParams p, hipStream_t stream);
