@@ -563,14 +563,23 @@ int launch_geom(const ConvParams& p, size_t lds, int grid_x, hipStream_t s) {
 // The tile shapes built into the library, by id.
 const Geometry kShapes[] = {
     {16, 1, 4, 1, 2},   // 0: 16 x 128
-    {16, 1, 2, 2, 2},   // 1: 16 x 64,  K split 2
+    {16, 1, 2, 2, 2},   // 1: 16 x 64,   K split 2
     {32, 1, 4, 1, 1},   // 2: 32 x 128
-    {32, 1, 2, 2, 1},   // 3: 32 x 64,  K split 2
-    {32, 1, 1, 4, 1},   // 4: 32 x 32,  K split 4
+    {32, 1, 2, 2, 1},   // 3: 32 x 64,   K split 2
+    {32, 1, 1, 4, 1},   // 4: 32 x 32,   K split 4
     {32, 2, 2, 1, 1},   // 5: 64 x 64
-    {32, 2, 1, 2, 1},   // 6: 64 x 32,  K split 2
+    {32, 2, 1, 2, 1},   // 6: 64 x 32,   K split 2
     {32, 2, 2, 1, 2},   // 7: 64 x 128
+    {16, 1, 4, 1, 4},   // 8: 16 x 256
+    {16, 1, 2, 2, 4},   // 9: 16 x 128,  K split 2
+    {32, 1, 2, 2, 2},   // 10: 32 x 128, K split 2, 2 accumulators per wave
+    {32, 1, 4, 1, 2},   // 11: 32 x 256, 2 accumulators per wave
+    {32, 1, 1, 4, 2},   // 12: 32 x 64,  K split 4, 2 accumulators per wave
+    {32, 2, 1, 2, 2},   // 13: 64 x 64,  K split 2, 2 accumulators per wave
+    {32, 1, 2, 2, 4},   // 14: 32 x 256, K split 2, 4 accumulators per wave
+    {32, 2, 1, 2, 4},   // 15: 64 x 128, K split 2, 4 accumulators per wave
 };
+constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
 
 int launch_shape(int id, const ConvParams& p, size_t lds, int grid_x, hipStream_t s) {
     switch (id) {
@@ -581,7 +590,15 @@ int launch_shape(int id, const ConvParams& p, size_t lds, int grid_x, hipStream_
         case 4: return launch_geom<32, 1, 1, 4, 1>(p, lds, grid_x, s);
         case 5: return launch_geom<32, 2, 2, 1, 1>(p, lds, grid_x, s);
         case 6: return launch_geom<32, 2, 1, 2, 1>(p, lds, grid_x, s);
-        default: return launch_geom<32, 2, 2, 1, 2>(p, lds, grid_x, s);
+        case 7: return launch_geom<32, 2, 2, 1, 2>(p, lds, grid_x, s);
+        case 8: return launch_geom<16, 1, 4, 1, 4>(p, lds, grid_x, s);
+        case 9: return launch_geom<16, 1, 2, 2, 4>(p, lds, grid_x, s);
+        case 10: return launch_geom<32, 1, 2, 2, 2>(p, lds, grid_x, s);
+        case 11: return launch_geom<32, 1, 4, 1, 2>(p, lds, grid_x, s);
+        case 12: return launch_geom<32, 1, 1, 4, 2>(p, lds, grid_x, s);
+        case 13: return launch_geom<32, 2, 1, 2, 2>(p, lds, grid_x, s);
+        case 14: return launch_geom<32, 1, 2, 2, 4>(p, lds, grid_x, s);
+        default: return launch_geom<32, 2, 1, 2, 4>(p, lds, grid_x, s);
     }
 }
 
@@ -635,15 +652,16 @@ int launch_conv(ConvParams p, hipStream_t s) {
             const Geometry& gg = kShapes[id];
             return (long)(p.Mpad / gg.m_t()) * ((p.Tq + gg.n_t() - 1) / gg.n_t());
         };
+        // thresholds from per-layer sweeps on MI355X (tools/conv_bench.py, B = 1)
         const int want = env_int("FV_UNITS", 900);
         int shape;
         if (m16) shape = units(0) >= want ? 0 : 1;
-        else if (units(2) >= want && !m64) shape = 2;
+        else if (!m64 && units(2) >= want) shape = 2;
         else if (m64 && units(5) >= want) shape = 5;
-        else if (units(3) >= want) shape = 3;
+        else if (units(3) >= 400) shape = 3;
         else shape = 4;
         const int force = env_int(m16 ? "FV_SHAPE16" : (m64 ? "FV_SHAPE64" : "FV_SHAPE32"), -1);
-        if (force >= 0 && force < 8 && kShapes[force].mf == (m16 ? 16 : 32) &&
+        if (force >= 0 && force < kNumShapes && kShapes[force].mf == (m16 ? 16 : 32) &&
             p.Mpad % kShapes[force].m_t() == 0)
             shape = force;
         const Geometry g = kShapes[shape];

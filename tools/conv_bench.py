@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--model", default="light")
     ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--only", default="", help="substring filter on '<name> k<k> d<d>', e.g. 'res C32 k11 d1'")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     c0 = 256 if args.model == "light" else 512
@@ -55,6 +56,8 @@ def main():
     tot_t = 0.0
     print(f"{'layer':12s} {'Cin':>4s} {'Cout':>4s} {'T':>7s} {'k':>2s} {'d':>2s} {'us':>8s} {'TF/s':>7s} {'GB/s':>7s}")
     for name, cin, cout, tt, k, d, up in shapes:
+        if args.only and args.only not in f"{name} k{k} d{d}":
+            continue
         x = torch.randn(B, cin, tt, device=dev)
         if up is None:
             w = torch.randn(cout, cin, k, device=dev) / (cin * k) ** 0.5
