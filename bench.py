@@ -149,11 +149,23 @@ def main():
         mf_launch, mf_ms, mf_flops = (p32["launches"] + p16["launches"], p32["ms"] + p16["ms"],
                                       p32["flops"] + p16["flops"])
         achieved = mf_flops / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
+        # HBM bytes per launch of this kernel family from the committed rocprofv3 PMC
+        # passes of this same command (tools/pmc_traffic.py: (2*FETCH_SIZE + WRITE_SIZE)*1024)
+        traffic, traffic_src = None, None
+        for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles"))
+                            if f.endswith("_hbm_traffic.json")), reverse=True) \
+                if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+            with open(os.path.join(ROOT, "profiles", cand)) as f:
+                traffic = json.load(f)["conv_mfma_family"]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/" + cand
+            break
         roofline = {
-            "kernel": "conv_mfma32_kernel/conv_mfma16_kernel (fp32-MFMA implicit-GEMM conv1d, "
-                      "all Conv1d/ConvTranspose1d layers with Cout > 4)",
+            "kernel": "fv::conv_mfma_kernel<32|16, ...> (fp32-MFMA implicit-GEMM conv1d: every "
+                      "Conv1d / ConvTranspose1d layer with Cout > 4; 77 of the 78 launches per forward)",
             "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (PMC, offline pass)", "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": (p32["bytes"] + p16["bytes"]) / max(mf_launch, 1),
             "launches_per_step": mf_launch // reps,
             "avg_launch_us": 1e3 * mf_ms / max(mf_launch, 1),
             "algorithmic_gflop_per_step": mf_flops / reps / 1e9,

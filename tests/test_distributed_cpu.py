@@ -1,0 +1,83 @@
+"""world_size-2 (and 3) gloo tests of the utterance-sharding layer
+(fastvocoder_amd/parallel.py): the N>1 code path of bench.py / serving, on CPU
+with a stand-in forward (the HIP generator itself needs a GPU)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from fastvocoder_amd import parallel
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_generator(mels):
+    """Deterministic per-utterance 'waveform': depends only on that row."""
+    B, C, T = mels.shape
+    w = torch.arange(1, C + 1, dtype=torch.float32).view(1, C, 1)
+    return (mels * w).sum(1).repeat_interleave(3, dim=1)      # [B, 3T]
+
+
+def _worker(rank, world, port, B, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # 1) weights: rank 0 holds the checkpoint, everyone ends up with it
+        torch.manual_seed(rank)
+        lin = torch.nn.Linear(4, 3)
+        parallel.broadcast_weights(lin, src=0)
+        ref = torch.nn.Linear(4, 3)
+        torch.manual_seed(0)
+        ref = torch.nn.Linear(4, 3)
+        assert torch.equal(lin.weight, ref.weight) and torch.equal(lin.bias, ref.bias)
+        # 2) sharded synthesis, ragged batch, gathered in utterance order on rank 0
+        g = torch.Generator().manual_seed(123)
+        mels = torch.rand(B, 5, 7, generator=g)
+        out = parallel.synthesize_sharded(_fake_generator, mels)
+        if rank == 0:
+            assert out.shape == (B, 21)
+            assert torch.equal(out, _fake_generator(mels))        # bit-identical to one process
+            np.save(out_path, out.numpy())
+        else:
+            assert out is None
+        # 3) the fixed-shape gather used by bench.py
+        gather = parallel.WaveformGather(world, rank, torch.device("cpu"))
+        mine = torch.full((2, 6), float(rank))
+        bufs = gather(mine)
+        if rank == 0:
+            assert [float(b[0, 0]) for b in bufs] == [float(r) for r in range(world)]
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B", [(2, 5), (2, 4), (3, 7), (2, 1)])
+def test_sharded_synthesis_gloo(tmp_path, world, B):
+    port = _free_port()
+    out = str(tmp_path / "out.npy")
+    mp.spawn(_worker, args=(world, port, B, out), nprocs=world, join=True)
+    got = np.load(out)
+    g = torch.Generator().manual_seed(123)
+    mels = torch.rand(B, 5, 7, generator=g)
+    assert np.array_equal(got, _fake_generator(mels).numpy())
+
+
+def test_shard_ranges_partition_the_batch():
+    for n in (0, 1, 5, 8, 64, 513):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_range(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
