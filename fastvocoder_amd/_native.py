@@ -18,7 +18,8 @@ SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip"]
 
 PAD_ZERO, PAD_REFLECT = 0, 1
 POST_NONE, POST_TANH, POST_RELU = 0, 1, 2
-SLOT_NONE, SLOT_IN, SLOT_OUT, SLOT_TMP0, MAX_SLOTS = -1, 0, 1, 2, 16
+SLOT_NONE, SLOT_IN, SLOT_OUT, SLOT_TMP0, MAX_SLOTS = -1, 0, 1, 2, 32
+ABI_VERSION = 2
 
 
 class NativeError(RuntimeError):
@@ -66,16 +67,17 @@ def lib():
     L.fv_packed_conv_transpose1d_floats.restype = i64
     L.fv_pack_conv1d_weight.argtypes = [vp, vp, i, i, i, vp]
     L.fv_pack_conv_transpose1d_weight.argtypes = [vp, vp, i, i, i, i, i, vp]
-    L.fv_conv1d_fused.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, f, i, vp]
-    L.fv_conv_transpose1d_fused.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, i, vp]
+    L.fv_conv1d_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, f, i, f, vp]
+    L.fv_conv_transpose1d_fused.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, i, f, vp]
     L.fv_pqmf_synthesis.argtypes = [vp, vp, vp, i, i, i, i, vp]
     L.fv_plan_create.argtypes = [i]
     L.fv_plan_create.restype = vp
     L.fv_plan_destroy.argtypes = [vp]
     L.fv_plan_destroy.restype = None
-    L.fv_plan_add_conv1d.argtypes = [vp, i, i, i, i, vp, vp, i, i, i, i, i, i, f, f, i]
-    L.fv_plan_add_conv_transpose1d.argtypes = [vp, i, i, vp, vp, i, i, i, i, i, i, f, i]
+    L.fv_plan_add_conv1d.argtypes = [vp, i, i, i, i, i, vp, vp, i, i, i, i, i, i, f, f, i, f]
+    L.fv_plan_add_conv_transpose1d.argtypes = [vp, i, i, i, vp, vp, i, i, i, i, i, i, f, i, f]
     L.fv_plan_add_pqmf_synthesis.argtypes = [vp, i, i, vp, i, i]
+    L.fv_plan_set_lane.argtypes = [vp, i]
     L.fv_plan_output_shape.argtypes = [vp, i, ctypes.POINTER(i), ctypes.POINTER(i64)]
     L.fv_plan_workspace_bytes.argtypes = [vp, i, i]
     L.fv_plan_workspace_bytes.restype = i64
@@ -84,8 +86,8 @@ def lib():
     L.fv_profile_enable.argtypes = [i]
     L.fv_profile_collect.argtypes = [i, ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
-    if L.fv_version() != 1:
-        raise NativeError(f"ABI mismatch: library reports {L.fv_version()}, binding expects 1")
+    if L.fv_version() != ABI_VERSION:
+        raise NativeError(f"ABI mismatch: library reports {L.fv_version()}, binding expects {ABI_VERSION}")
     _lib = L
     return L
 
@@ -152,27 +154,30 @@ def pack_conv_transpose1d(w, stride, pad):
 # ---------------------------------------------------------------------------
 
 def conv1d_fused(x, packed, bias, cout, k, dil=1, pad=0, pad_mode=PAD_ZERO, pre_slope=1.0,
-                 res=None, acc_in=None, out_div=1.0, post=POST_NONE, out=None):
+                 res=None, acc_in=None, out_div=1.0, post=POST_NONE, out=None, out_act=None,
+                 act_slope=1.0):
+    """One fused conv launch; ``out_act`` (optional) receives lrelu(out, act_slope)."""
     B, cin, T = x.shape
     tout = T + 2 * pad - dil * (k - 1)
     if out is None:
         out = torch.empty((B, cout, tout), dtype=torch.float32, device=x.device)
     check(lib().fv_conv1d_fused(_ptr(x, "x"), _ptr(packed, "packed"), _ptr(bias, "bias", True),
                                 _ptr(res, "res", True), _ptr(acc_in, "acc_in", True), _ptr(out, "out"),
-                                B, cin, cout, T, k, dil, pad, pad_mode, float(pre_slope),
-                                float(out_div), post, _stream()))
+                                _ptr(out_act, "out_act", True), B, cin, cout, T, k, dil, pad, pad_mode,
+                                float(pre_slope), float(out_div), post, float(act_slope), _stream()))
     return out
 
 
 def conv_transpose1d_fused(x, packed, bias, cout, k, stride, pad, out_pad, pre_slope=1.0,
-                           post=POST_NONE, out=None):
+                           post=POST_NONE, out=None, out_act=None, act_slope=1.0):
     B, cin, T = x.shape
     tout = (T - 1) * stride - 2 * pad + k + out_pad
     if out is None:
         out = torch.empty((B, cout, tout), dtype=torch.float32, device=x.device)
     check(lib().fv_conv_transpose1d_fused(_ptr(x, "x"), _ptr(packed, "packed"),
-                                          _ptr(bias, "bias", True), _ptr(out, "out"), B, cin, cout,
-                                          T, k, stride, pad, out_pad, float(pre_slope), post,
+                                          _ptr(bias, "bias", True), _ptr(out, "out"),
+                                          _ptr(out_act, "out_act", True), B, cin, cout, T, k, stride,
+                                          pad, out_pad, float(pre_slope), post, float(act_slope),
                                           _stream()))
     return out
 
@@ -209,22 +214,27 @@ class Plan:
         return t
 
     def add_conv1d(self, x, y, packed, bias, cin, cout, k, dil=1, pad=0, pad_mode=PAD_ZERO,
-                   pre_slope=1.0, res=SLOT_NONE, acc=SLOT_NONE, out_div=1.0, post=POST_NONE):
+                   pre_slope=1.0, res=SLOT_NONE, acc=SLOT_NONE, out_div=1.0, post=POST_NONE,
+                   y_act=SLOT_NONE, act_slope=1.0):
         self.keep(packed)
         if bias is not None:
             self.keep(bias)
-        check(lib().fv_plan_add_conv1d(self._h, x, y, res, acc, _ptr(packed, "packed"),
+        check(lib().fv_plan_add_conv1d(self._h, x, y, y_act, res, acc, _ptr(packed, "packed"),
                                        _ptr(bias, "bias", True), cin, cout, k, dil, pad, pad_mode,
-                                       float(pre_slope), float(out_div), post))
+                                       float(pre_slope), float(out_div), post, float(act_slope)))
 
     def add_conv_transpose1d(self, x, y, packed, bias, cin, cout, k, stride, pad, out_pad,
-                             pre_slope=1.0, post=POST_NONE):
+                             pre_slope=1.0, post=POST_NONE, y_act=SLOT_NONE, act_slope=1.0):
         self.keep(packed)
         if bias is not None:
             self.keep(bias)
-        check(lib().fv_plan_add_conv_transpose1d(self._h, x, y, _ptr(packed, "packed"),
+        check(lib().fv_plan_add_conv_transpose1d(self._h, x, y, y_act, _ptr(packed, "packed"),
                                                  _ptr(bias, "bias", True), cin, cout, k, stride,
-                                                 pad, out_pad, float(pre_slope), post))
+                                                 pad, out_pad, float(pre_slope), post,
+                                                 float(act_slope)))
+
+    def set_lane(self, lane):
+        check(lib().fv_plan_set_lane(self._h, lane))
 
     def add_pqmf_synthesis(self, x, y, h):
         """h [S, ntaps] contiguous fp32 device tensor."""

@@ -3,6 +3,7 @@
 // measurement hook.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -120,13 +121,21 @@ enum OpType { OP_CONV = 0, OP_CONVT = 1, OP_PQMF = 2 };
 
 struct Op {
     int type;
-    int x, y, res, acc;
+    int x, y, res, acc, y2;
     const float* wp;
     const float* bias;
     int Cin, Cout, k, dil, pad, pad_mode, stride, out_pad;
-    float pre_slope, out_div;
+    float pre_slope, out_div, act_slope;
     int post;
+    // concurrency: ops on different lanes run on different streams; deps[] are the ops on
+    // OTHER lanes this op must wait for (derived from slot reads/writes by compile_lanes)
+    int lane;
+    int ndeps;
+    int deps[3];
+    bool signal;   // some op on another lane waits for this one: record its event
 };
+
+constexpr int kMaxLanes = 4;
 
 struct Shape {
     int C;
@@ -139,6 +148,23 @@ struct Shape {
 struct fv_plan {
     int in_channels;
     std::vector<fv::Op> ops;
+    int cur_lane = 0;
+    int n_lanes = 1;
+    bool compiled = false;
+    // lanes 1.. run on plan-owned streams; one event per signalling op + fork/join events
+    hipStream_t lane_stream[fv::kMaxLanes] = {};
+    std::vector<hipEvent_t> op_event;
+    hipEvent_t fork_event = nullptr;
+    hipEvent_t join_event[fv::kMaxLanes] = {};
+    ~fv_plan() {
+        for (hipEvent_t e : op_event)
+            if (e) (void)hipEventDestroy(e);
+        if (fork_event) (void)hipEventDestroy(fork_event);
+        for (int l = 0; l < fv::kMaxLanes; ++l) {
+            if (join_event[l]) (void)hipEventDestroy(join_event[l]);
+            if (lane_stream[l]) (void)hipStreamDestroy(lane_stream[l]);
+        }
+    }
 };
 
 namespace fv {
@@ -175,12 +201,18 @@ static int infer(const fv_plan* plan, int B, int T, Shape* sh, int64_t* slot_ele
         sh[o.y] = {Cout, Tout, true};
         const int64_t e = (int64_t)B * Cout * Tout;
         if (e > slot_elems[o.y]) slot_elems[o.y] = e;
+        if (o.y2 != FV_SLOT_NONE) {
+            if (o.y2 == o.x || o.y2 == o.y)
+                return fail(FV_ERR_INVALID_ARG, "op %zu: activated twin aliases another tensor of the op", n);
+            sh[o.y2] = {Cout, Tout, true};
+            if (e > slot_elems[o.y2]) slot_elems[o.y2] = e;
+        }
     }
     return 0;
 }
 
-static int run_op(const Op& o, const float* x, float* y, const float* res, const float* acc, int B,
-                  int64_t Tin, hipStream_t s) {
+static int run_op(const Op& o, const float* x, float* y, float* y2, const float* res, const float* acc,
+                  int B, int64_t Tin, hipStream_t s) {
     if (o.type == OP_PQMF) return launch_pqmf(x, o.wp, y, B, o.Cin, o.k, (int)Tin, s);
     ConvParams p = {};
     p.x = x;
@@ -189,6 +221,8 @@ static int run_op(const Op& o, const float* x, float* y, const float* res, const
     p.res = res;
     p.acc_in = acc;
     p.y = y;
+    p.y_act = y2;
+    p.act_slope = o.act_slope;
     p.B = B;
     p.Cin = o.Cin;
     p.Cout = o.Cout;
@@ -217,6 +251,67 @@ static int run_op(const Op& o, const float* x, float* y, const float* res, const
     }
     p.Mpad = pad_rows(p.M);
     return launch_conv(p, s);
+}
+
+// Cross-lane dependencies from the slots each op reads and writes (RAW, WAR, WAW):
+// same-lane order is the stream's; for every other lane only its latest
+// conflicting op matters.  Creates the lane streams and events on first use.
+static int compile_lanes(fv_plan* plan) {
+    if (plan->compiled) return 0;
+    const int n = (int)plan->ops.size();
+    int last_write[FV_MAX_SLOTS];
+    std::vector<int> readers[FV_MAX_SLOTS];
+    for (int i = 0; i < FV_MAX_SLOTS; ++i) last_write[i] = -1;
+    plan->n_lanes = 1;
+    for (Op& o : plan->ops) {
+        o.ndeps = 0;
+        o.signal = false;
+        if (o.lane + 1 > plan->n_lanes) plan->n_lanes = o.lane + 1;
+    }
+    for (int i = 0; i < n; ++i) {
+        Op& o = plan->ops[i];
+        int latest[kMaxLanes];
+        for (int l = 0; l < kMaxLanes; ++l) latest[l] = -1;
+        auto need = [&](int j) {
+            if (j >= 0 && plan->ops[j].lane != o.lane && j > latest[plan->ops[j].lane])
+                latest[plan->ops[j].lane] = j;
+        };
+        const int reads[3] = {o.x, o.res, o.acc};
+        const int writes[2] = {o.y, o.y2};
+        for (int s : reads)
+            if (s != FV_SLOT_NONE) need(last_write[s]);
+        for (int s : writes) {
+            if (s == FV_SLOT_NONE) continue;
+            need(last_write[s]);
+            for (int r : readers[s]) need(r);
+        }
+        for (int l = 0; l < kMaxLanes; ++l) {
+            if (latest[l] < 0) continue;
+            o.deps[o.ndeps++] = latest[l];
+            plan->ops[latest[l]].signal = true;
+        }
+        for (int s : reads)
+            if (s != FV_SLOT_NONE) readers[s].push_back(i);
+        for (int s : writes) {
+            if (s == FV_SLOT_NONE) continue;
+            last_write[s] = i;
+            readers[s].clear();
+        }
+    }
+    for (hipEvent_t e : plan->op_event)
+        if (e) (void)hipEventDestroy(e);
+    plan->op_event.assign(n, nullptr);
+    if (plan->n_lanes > 1) {
+        for (int i = 0; i < n; ++i)
+            if (plan->ops[i].signal) FV_HIP(hipEventCreateWithFlags(&plan->op_event[i], hipEventDisableTiming));
+        if (!plan->fork_event) FV_HIP(hipEventCreateWithFlags(&plan->fork_event, hipEventDisableTiming));
+        for (int l = 1; l < plan->n_lanes; ++l) {
+            if (!plan->lane_stream[l]) FV_HIP(hipStreamCreateWithFlags(&plan->lane_stream[l], hipStreamNonBlocking));
+            if (!plan->join_event[l]) FV_HIP(hipEventCreateWithFlags(&plan->join_event[l], hipEventDisableTiming));
+        }
+    }
+    plan->compiled = true;
+    return 0;
 }
 
 static int check_conv_args(int Cin, int Cout, int k, int dil) {
@@ -279,14 +374,16 @@ int fv_pack_conv_transpose1d_weight(const float* w, float* packed, int Cin, int 
 }
 
 int fv_conv1d_fused(const float* x, const float* packed, const float* bias, const float* res,
-                    const float* acc_in, float* y, int B, int Cin, int Cout, int Tin, int k,
-                    int dil, int pad, int pad_mode, float pre_slope, float out_div, int post,
-                    void* stream) {
+                    const float* acc_in, float* y, float* y_act, int B, int Cin, int Cout, int Tin,
+                    int k, int dil, int pad, int pad_mode, float pre_slope, float out_div, int post,
+                    float act_slope, void* stream) {
     if (int rc = check_conv_args(Cin, Cout, k, dil)) return rc;
     if (!x || !packed || !y) return fail(FV_ERR_INVALID_ARG, "conv1d: null tensor");
-    if (x == y) return fail(FV_ERR_INVALID_ARG, "conv1d: y must not alias x");
+    if (x == y || x == y_act || (y_act && y_act == y))
+        return fail(FV_ERR_INVALID_ARG, "conv1d: y / y_act must not alias x or each other");
     Op o = {};
     o.type = OP_CONV;
+    o.act_slope = act_slope;
     o.wp = packed;
     o.bias = bias;
     o.Cin = Cin;
@@ -299,16 +396,19 @@ int fv_conv1d_fused(const float* x, const float* packed, const float* bias, cons
     o.out_div = out_div;
     o.post = post;
     if (conv_out_len(o, Tin) <= 0) return fail(FV_ERR_INVALID_ARG, "conv1d: empty output");
-    return run_op(o, x, y, res, acc_in, B, Tin, (hipStream_t)stream);
+    return run_op(o, x, y, y_act, res, acc_in, B, Tin, (hipStream_t)stream);
 }
 
 int fv_conv_transpose1d_fused(const float* x, const float* packed, const float* bias, float* y,
-                              int B, int Cin, int Cout, int Tin, int k, int stride, int pad,
-                              int out_pad, float pre_slope, int post, void* stream) {
+                              float* y_act, int B, int Cin, int Cout, int Tin, int k, int stride,
+                              int pad, int out_pad, float pre_slope, int post, float act_slope,
+                              void* stream) {
     if (int rc = check_conv_args(Cin, Cout, k, 1)) return rc;
     if (!x || !packed || !y) return fail(FV_ERR_INVALID_ARG, "conv_transpose1d: null tensor");
     if (stride <= 0 || pad < 0 || out_pad < 0 || out_pad >= stride + (stride == 1))
         return fail(FV_ERR_INVALID_ARG, "conv_transpose1d: stride=%d pad=%d out_pad=%d", stride, pad, out_pad);
+    if (x == y || x == y_act || (y_act && y_act == y))
+        return fail(FV_ERR_INVALID_ARG, "conv_transpose1d: y / y_act must not alias x or each other");
     Op o = {};
     o.type = OP_CONVT;
     o.wp = packed;
@@ -321,9 +421,10 @@ int fv_conv_transpose1d_fused(const float* x, const float* packed, const float* 
     o.out_pad = out_pad;
     o.pre_slope = pre_slope;
     o.out_div = 1.f;
+    o.act_slope = act_slope;
     o.post = post;
     if (conv_out_len(o, Tin) <= 0) return fail(FV_ERR_INVALID_ARG, "conv_transpose1d: empty output");
-    return run_op(o, x, y, nullptr, nullptr, B, Tin, (hipStream_t)stream);
+    return run_op(o, x, y, y_act, nullptr, nullptr, B, Tin, (hipStream_t)stream);
 }
 
 int fv_pqmf_synthesis(const float* x, const float* h, float* y, int B, int S, int ntaps, int Tsub,
@@ -347,20 +448,25 @@ static int check_slot(int s, bool allow_none) {
     return 0;
 }
 
-int fv_plan_add_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int res_slot, int acc_slot,
-                       const float* packed, const float* bias, int Cin, int Cout, int k, int dil,
-                       int pad, int pad_mode, float pre_slope, float out_div, int post) {
+int fv_plan_add_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, int res_slot,
+                       int acc_slot, const float* packed, const float* bias, int Cin, int Cout, int k,
+                       int dil, int pad, int pad_mode, float pre_slope, float out_div, int post,
+                       float act_slope) {
     if (!plan || !packed) return fail(FV_ERR_INVALID_ARG, "plan_add_conv1d: null");
     if (int rc = check_conv_args(Cin, Cout, k, dil)) return rc;
     if (int rc = check_slot(x_slot, false)) return rc;
     if (int rc = check_slot(y_slot, false)) return rc;
     if (int rc = check_slot(res_slot, true)) return rc;
     if (int rc = check_slot(acc_slot, true)) return rc;
-    if (y_slot == FV_SLOT_IN) return fail(FV_ERR_INVALID_ARG, "plan: the input slot is read-only");
+    if (int rc = check_slot(y_act_slot, true)) return rc;
+    if (y_slot == FV_SLOT_IN || y_act_slot == FV_SLOT_IN)
+        return fail(FV_ERR_INVALID_ARG, "plan: the input slot is read-only");
     Op o = {};
     o.type = OP_CONV;
     o.x = x_slot;
     o.y = y_slot;
+    o.y2 = y_act_slot;
+    o.act_slope = act_slope;
     o.res = res_slot;
     o.acc = acc_slot;
     o.wp = packed;
@@ -374,24 +480,31 @@ int fv_plan_add_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int res_slot, in
     o.pre_slope = pre_slope;
     o.out_div = out_div;
     o.post = post;
+    o.lane = plan->cur_lane;
+    plan->compiled = false;
     plan->ops.push_back(o);
     return 0;
 }
 
-int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot, const float* packed,
-                                 const float* bias, int Cin, int Cout, int k, int stride, int pad,
-                                 int out_pad, float pre_slope, int post) {
+int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot,
+                                 const float* packed, const float* bias, int Cin, int Cout, int k,
+                                 int stride, int pad, int out_pad, float pre_slope, int post,
+                                 float act_slope) {
     if (!plan || !packed) return fail(FV_ERR_INVALID_ARG, "plan_add_conv_transpose1d: null");
     if (int rc = check_conv_args(Cin, Cout, k, 1)) return rc;
     if (stride <= 0 || pad < 0 || out_pad < 0)
         return fail(FV_ERR_INVALID_ARG, "convT stride=%d pad=%d out_pad=%d", stride, pad, out_pad);
     if (int rc = check_slot(x_slot, false)) return rc;
     if (int rc = check_slot(y_slot, false)) return rc;
-    if (y_slot == FV_SLOT_IN) return fail(FV_ERR_INVALID_ARG, "plan: the input slot is read-only");
+    if (int rc = check_slot(y_act_slot, true)) return rc;
+    if (y_slot == FV_SLOT_IN || y_act_slot == FV_SLOT_IN)
+        return fail(FV_ERR_INVALID_ARG, "plan: the input slot is read-only");
     Op o = {};
     o.type = OP_CONVT;
     o.x = x_slot;
     o.y = y_slot;
+    o.y2 = y_act_slot;
+    o.act_slope = act_slope;
     o.res = FV_SLOT_NONE;
     o.acc = FV_SLOT_NONE;
     o.wp = packed;
@@ -405,6 +518,8 @@ int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot, const 
     o.pre_slope = pre_slope;
     o.out_div = 1.f;
     o.post = post;
+    o.lane = plan->cur_lane;
+    plan->compiled = false;
     plan->ops.push_back(o);
     return 0;
 }
@@ -419,13 +534,22 @@ int fv_plan_add_pqmf_synthesis(fv_plan_t* plan, int x_slot, int y_slot, const fl
     o.type = OP_PQMF;
     o.x = x_slot;
     o.y = y_slot;
+    o.y2 = FV_SLOT_NONE;
     o.res = FV_SLOT_NONE;
     o.acc = FV_SLOT_NONE;
     o.wp = h;
     o.Cin = S;
     o.Cout = 1;
     o.k = ntaps;
+    o.lane = plan->cur_lane;
+    plan->compiled = false;
     plan->ops.push_back(o);
+    return 0;
+}
+
+int fv_plan_set_lane(fv_plan_t* plan, int lane) {
+    if (!plan || lane < 0 || lane >= kMaxLanes) return fail(FV_ERR_INVALID_ARG, "plan_set_lane: lane %d (0..%d)", lane, kMaxLanes - 1);
+    plan->cur_lane = lane;
     return 0;
 }
 
@@ -468,16 +592,40 @@ int fv_plan_run(fv_plan_t* plan, int B, int T, const float* in, float* out, void
                     (long long)workspace_bytes);
     base[FV_SLOT_IN] = const_cast<float*>(in);
     base[FV_SLOT_OUT] = out;
+    if (int rc = compile_lanes(plan)) return rc;
+    hipStream_t lanes[kMaxLanes];
+    lanes[0] = (hipStream_t)stream;
+    const bool multi = plan->n_lanes > 1 && !getenv("FV_SINGLE_LANE");
+    for (int l = 1; l < kMaxLanes; ++l) lanes[l] = multi && l < plan->n_lanes ? plan->lane_stream[l] : lanes[0];
+    if (multi) {
+        // fork: the side lanes start after everything already queued on the caller's stream
+        FV_HIP(hipEventRecord(plan->fork_event, lanes[0]));
+        for (int l = 1; l < plan->n_lanes; ++l) FV_HIP(hipStreamWaitEvent(lanes[l], plan->fork_event, 0));
+    }
     // shapes again, op by op (a slot may change shape when it is reused)
     for (int i = 0; i < FV_MAX_SLOTS; ++i) sh[i].set = false;
     sh[FV_SLOT_IN] = {plan->in_channels, T, true};
-    for (const Op& o : plan->ops) {
+    for (size_t n = 0; n < plan->ops.size(); ++n) {
+        const Op& o = plan->ops[n];
         const int64_t Tin = sh[o.x].T;
         const int64_t Tout = conv_out_len(o, Tin);
         const float* res = o.res == FV_SLOT_NONE ? nullptr : base[o.res];
         const float* acc = o.acc == FV_SLOT_NONE ? nullptr : base[o.acc];
-        if (int rc = run_op(o, base[o.x], base[o.y], res, acc, B, Tin, (hipStream_t)stream)) return rc;
+        float* y2 = o.y2 == FV_SLOT_NONE ? nullptr : base[o.y2];
+        hipStream_t s = lanes[o.lane];
+        if (multi)
+            for (int d = 0; d < o.ndeps; ++d) FV_HIP(hipStreamWaitEvent(s, plan->op_event[o.deps[d]], 0));
+        if (int rc = run_op(o, base[o.x], base[o.y], y2, res, acc, B, Tin, s)) return rc;
+        if (multi && o.signal) FV_HIP(hipEventRecord(plan->op_event[n], s));
         sh[o.y] = {o.type == OP_PQMF ? 1 : o.Cout, Tout, true};
+        if (o.y2 != FV_SLOT_NONE) sh[o.y2] = sh[o.y];
+    }
+    if (multi) {
+        // join: later work on the caller's stream sees every lane's results
+        for (int l = 1; l < plan->n_lanes; ++l) {
+            FV_HIP(hipEventRecord(plan->join_event[l], lanes[l]));
+            FV_HIP(hipStreamWaitEvent(lanes[0], plan->join_event[l], 0));
+        }
     }
     return 0;
 }

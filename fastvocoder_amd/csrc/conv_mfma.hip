@@ -15,34 +15,36 @@
 // which is what the 1e-4 end-to-end budget over ~80 chained layers needs
 // (bf16/fp16 MFMA does not fit it; SURVEY.md section 7 "hard parts").
 //
-// Structure (per workgroup of WM x WN x WK wave64), shaped by two measured
-// facts: memory latency under load is ~2 us while one (tile, channel-chunk)
-// stage holds only ~0.5-2 us of matrix work per wave, and the fp32 MFMA needs
-// just one ds_read per operand -- so the kernel is latency-, not issue-bound:
-//   * a block walks a run of (time-tile, channel-chunk) STAGES.  Per stage
-//         xs[ci_chunk][xw]      raw input tile with its dilation halo
+// Structure (per workgroup of WM x WN x WK wave64), shaped by measured facts
+// (tools/*_probe.hip, profiles/): memory latency under load is ~2 us while one
+// (tile, channel-chunk) stage holds 0.5-2 us of matrix work; and on gfx950 plain
+// VALU instructions do NOT co-execute with v_mfma_f32_* -- every VALU costs ~3
+// cycles of matrix time -- so the hot loop must be MFMA + ds_read and nothing else:
+//   * a block walks a run of time tiles; per (tile, channel-chunk) STAGE
+//         xs[ci_chunk][xw]      input window with its dilation halo
 //         ws[ci_chunk*k][M_T]   K-major weight slice (dense 2-D block of Wp)
-//     are brought in by LDS-DMA (buffer_load_dwordx4 ... lds): no staging
-//     VGPRs, no ds_write pass, bounds-checked by the buffer descriptor (rows
-//     past Cin read as 0).  The DMA of stage s+1 is issued before the MFMA loop
-//     of stage s into the other LDS buffer; one barrier per stage;
-//   * registers stay at accumulators + addresses, so 4-8 waves per SIMD are
-//     resident and other blocks' matrix work covers what the one-stage
-//     prefetch does not (work units are sized for >= ~1000 blocks per launch);
-//   * the input activation is applied when the B operand is read from LDS
-//     (max(x, slope*x): 2 VALU per 64-cycle MFMA), which is what lets the
-//     staging be a pure copy;
-//   * every wave walks its share of K in steps of 2 (32x32x2) or 4 (16x16x4):
-//     A (weights) and B (shifted input window) operands are ds_read_b32 with
-//     lanes consecutive in m / in time; a dilated tap is an address offset;
+//     are brought in by LDS-DMA (buffer_load_dwordx4 ... lds): no staging VGPRs,
+//     no ds_write pass, bounds-checked by the buffer descriptor (rows past Cin
+//     read as 0).  The DMA of stage s+1 is issued before the MFMA loop of stage
+//     s into the other LDS buffer; one barrier per stage; per-lane DMA offsets
+//     are computed once per block;
+//   * the input activation is NOT in the hot loop: plans feed every conv a
+//     tensor that already holds act(x) (the producing epilogue writes it, next
+//     to the raw tensor when a residual also needs that), see engine.py.  A
+//     read-time activation (max(x, slope*x)) exists only for the stand-alone
+//     operator entry points (ACT = true variants);
+//   * tap count and dilation are template parameters for the hot shapes, so
+//     every A/B operand is a ds_read with an immediate offset (paired into
+//     ds_read2_b32 by the compiler): zero address arithmetic per MFMA;
+//   * registers stay at accumulators + a few addresses, so 4-8 waves per SIMD
+//     are resident and cover what the one-stage prefetch does not;
 //   * WK > 1 splits the K range of every stage over WK wave groups that share
-//     the staged tiles and reduce through LDS at the end of the tile: more
-//     waves and finer work units when the grid alone cannot fill 256 CUs;
+//     the staged tiles and reduce through LDS at the end of the tile;
 //   * tiles that touch the sequence ends (zero / reflection padding) and
 //     unaligned tensors take a synchronous register path (stage_x_edge);
-//   * the epilogue fuses bias, residual add, the MRF running sum / mean and
-//     tanh / ReLU through bounds-checked buffer loads/stores (no per-element
-//     branches), so no elementwise kernel exists on the path.
+//   * the epilogue fuses bias, residual add, the MRF running sum / mean,
+//     tanh / ReLU and the optional activated twin output through bounds-checked
+//     buffer loads/stores (row offsets and bias are per-block constants).
 #include <stdlib.h>
 
 #include "fv_internal.h"
@@ -65,20 +67,6 @@ __device__ __forceinline__ int reflect_idx(int i, int T) {
     // columns staged only for alignment slack or tile overhang may still fall
     // outside; they feed masked outputs only, so clamp instead of faulting
     return min(max(i, 0), T - 1);
-}
-
-// Geometry of one time tile's input window.
-struct Window {
-    int tA;     // global time of LDS column 0 (a multiple of 4, may be negative)
-    int aoff;   // LDS column of the tile's first tap position
-};
-
-__device__ __forceinline__ Window window_of(const ConvParams& p, int t0) {
-    const int tstart = t0 - p.pad;
-    Window w;
-    w.aoff = ((tstart % 4) + 4) % 4;
-    w.tA = tstart - w.aoff;
-    return w;
 }
 
 // interior <=> every column the tile reads is a real sample and rows are 16-byte
@@ -107,34 +95,64 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, float* lds, unsi
 
 // --- asynchronous staging (LDS-DMA) --------------------------------------------
 // The x image is [ci_chunk][ncol4c] float4, the w image [ci_chunk*k][M_T/4]
-// float4, both linear in their float4 index, so instruction j of a wave covers
-// float4s [64j, 64j+64).  Waves take instructions round-robin.
-template <int NW>
-__device__ __forceinline__ void dma_x(const ConvParams& p, __amdgpu_buffer_rsrc_t rx, float* xs,
-                                      int ci0, int tA, int wave, int lane) {
-    const int total = p.ci_chunk * p.ncol4c;
-    for (int j = wave; j * 64 < total; j += NW) {
-        const int idx = j * 64 + lane;
+// float4, both linear in their float4 index: DMA instruction j of the block
+// covers float4s [64j, 64j+64); waves take instructions round-robin.  The
+// per-lane source offsets do not depend on the stage except for a uniform
+// base, so they are computed once (DmaPlan) and each stage costs one add per
+// instruction.
+constexpr int kMaxDmaX = 4, kMaxDmaW = 8;   // instructions per wave per stage (host-checked)
+
+// (rows past Cin / past Cin*k need no test: their offsets fall outside the
+// buffer descriptors, which cover exactly this utterance's input / the weights)
+struct DmaPlan {
+    unsigned xoff[kMaxDmaX];   // byte offset inside the (ci0, tA) window, or kOutOfRange
+    unsigned woff[kMaxDmaW];   // byte offset inside the chunk's weight rows, or kOutOfRange
+};
+
+template <int NW, int M_T>
+__device__ __forceinline__ void dma_plan(const ConvParams& p, DmaPlan& d, int m0, int wave, int lane) {
+    constexpr int C4 = M_T / 4;
+    const int xtotal = p.ci_chunk * p.ncol4c;
+    const int wtotal = p.ci_chunk * p.k * C4;
+#pragma unroll
+    for (int i = 0; i < kMaxDmaX; ++i) {
+        const int idx = (wave + i * NW) * 64 + lane;
         const int row = (int)__umulhi((unsigned)idx, p.ncol4c_magic);
         const int c4 = idx - row * p.ncol4c;
-        const int ci = ci0 + row;
-        const bool ok = row < p.ci_chunk && ci < p.Cin;
-        dma16(rx, xs + j * 256, ok ? (unsigned)(ci * p.Tin + tA + 4 * c4) * 4u : kOutOfRange);
+        d.xoff[i] = idx < xtotal ? (unsigned)(row * p.Tin + 4 * c4) * 4u : kOutOfRange;
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxDmaW; ++i) {
+        const int idx = (wave + i * NW) * 64 + lane;
+        const int row = idx / C4, c = idx % C4;
+        d.woff[i] = idx < wtotal ? (unsigned)(row * p.Mpad + m0 + 4 * c) * 4u : kOutOfRange;
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ void dma_x(const ConvParams& p, const DmaPlan& d, __amdgpu_buffer_rsrc_t rx,
+                                      float* xs, int ci0, int tA, int wave) {
+    const unsigned base = (unsigned)(ci0 * p.Tin + tA) * 4u;
+#pragma unroll
+    for (int i = 0; i < kMaxDmaX; ++i) {
+        const int j = wave + i * NW;
+        if (j * 64 < p.ci_chunk * p.ncol4c) {   // wave-uniform
+            dma16(rx, xs + j * 256, d.xoff[i] != kOutOfRange ? d.xoff[i] + base : kOutOfRange);
+        }
     }
 }
 
 template <int NW, int M_T>
-__device__ __forceinline__ void dma_w(const ConvParams& p, __amdgpu_buffer_rsrc_t rw, float* ws,
-                                      int ci0, int m0, int wave, int lane) {
+__device__ __forceinline__ void dma_w(const ConvParams& p, const DmaPlan& d, __amdgpu_buffer_rsrc_t rw,
+                                      float* ws, int ci0, int wave) {
     constexpr int C4 = M_T / 4;
-    const int total = p.ci_chunk * p.k * C4;
-    const int krows = p.Cin * p.k;
-    const int row0 = ci0 * p.k;
-    for (int j = wave; j * 64 < total; j += NW) {
-        const int idx = j * 64 + lane;
-        const int row = row0 + idx / C4, c = idx % C4;
-        const bool ok = idx < total && row < krows;
-        dma16(rw, ws + j * 256, ok ? (unsigned)(row * p.Mpad + m0 + 4 * c) * 4u : kOutOfRange);
+    const unsigned base = (unsigned)(ci0 * p.k * p.Mpad) * 4u;
+#pragma unroll
+    for (int i = 0; i < kMaxDmaW; ++i) {
+        const int j = wave + i * NW;
+        if (j * 64 < p.ci_chunk * p.k * C4) {   // wave-uniform
+            dma16(rw, ws + j * 256, d.woff[i] != kOutOfRange ? d.woff[i] + base : kOutOfRange);
+        }
     }
 }
 
@@ -168,7 +186,7 @@ __device__ __forceinline__ void stage_x_edge(const ConvParams& p, float* xs, int
 // gets an out-of-range offset (loads 0, store dropped), so the loads of a tile
 // issue back to back instead of one s_waitcnt vmcnt(0) per element.
 struct EpilogueRsrc {
-    __amdgpu_buffer_rsrc_t y, res, acc, bias;
+    __amdgpu_buffer_rsrc_t y, y2, res, acc;
 };
 
 __device__ __forceinline__ EpilogueRsrc epilogue_rsrc(const ConvParams& p, int b) {
@@ -176,38 +194,55 @@ __device__ __forceinline__ EpilogueRsrc epilogue_rsrc(const ConvParams& p, int b
     const unsigned bytes = (unsigned)p.Cout * (unsigned)p.Tout * 4u;
     EpilogueRsrc e;
     e.y = make_rsrc(p.y + boff, bytes);
+    e.y2 = make_rsrc(p.y_act ? p.y_act + boff : p.y + boff, bytes);
     e.res = make_rsrc(p.res ? p.res + boff : p.y + boff, bytes);
     e.acc = make_rsrc(p.acc_in ? p.acc_in + boff : p.y + boff, bytes);
-    e.bias = make_rsrc(p.bias ? p.bias : p.y, p.bias ? (unsigned)p.Cout * 4u : 0u);
     return e;
 }
 
-// N output elements of one thread:  y = post( ( acc_in + ( (v + bias) + res ) ) / out_div )
-// rows m[i] (GEMM rows) at column q; all uniform switches are hoisted.
+// Per-thread constants of the N GEMM rows it owns: byte offset of (row, t = 0) in
+// the output tensor (or kOutOfRange for padded rows) and the row's bias.
 template <int N>
-__device__ __forceinline__ void epilogue_store(const ConvParams& p, const EpilogueRsrc& e,
-                                               const int (&m)[N], int q, float (&v)[N]) {
-    unsigned off[N], boff[N];
-    const bool qok = q < p.Tq;
+struct RowInfo {
+    unsigned off[N];
+    float bias[N];
+};
+
+template <int N>
+__device__ __forceinline__ void row_info(const ConvParams& p, const int (&m)[N], RowInfo<N>& ri) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        int co = m[i], t = q;
+        int co = m[i], ph = 0;
         if (p.ups != 1) {
             co = m[i] / p.ups;
-            t = q * p.ups + (m[i] - co * p.ups);
+            ph = m[i] - co * p.ups;
         }
-        const bool ok = qok && m[i] < p.M && t < p.Tout;
-        off[i] = ok ? (unsigned)(co * p.Tout + t) * 4u : kOutOfRange;
-        boff[i] = ok ? (unsigned)co * 4u : kOutOfRange;
+        const bool ok = m[i] < p.M;
+        ri.off[i] = ok ? (unsigned)(co * p.Tout + ph) * 4u : kOutOfRange;
+        ri.bias[i] = (ok && p.bias) ? p.bias[co] : 0.f;
     }
-    // issue every load of the batch before the first use (one latency, not three)
-    float bv[N], rv[N], av[N];
+}
+
+// N output elements of one thread at GEMM column q:
+//   y = post( ( acc_in + ( (v + bias) + res ) ) / out_div );   y_act = act(y, act_slope)
+// all uniform switches are hoisted; loads are issued as one batch.
+template <int N>
+__device__ __forceinline__ void epilogue_store(const ConvParams& p, const EpilogueRsrc& e,
+                                               const RowInfo<N>& ri, const int (&m)[N], int q,
+                                               float (&v)[N]) {
+    unsigned off[N];
+    const bool qok = q < p.Tq;
+    const unsigned qoff = (unsigned)(q * p.ups) * 4u;
 #pragma unroll
-    for (int i = 0; i < N; ++i) bv[i] = rv[i] = av[i] = 0.f;
-    if (p.bias) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) bv[i] = buffer_load1(e.bias, boff[i]);
+    for (int i = 0; i < N; ++i) {
+        bool ok = qok && ri.off[i] != kOutOfRange;
+        // a transposed conv's last column can run past Tout (Tout need not be a multiple of ups)
+        if (p.ups != 1) ok = ok && q * p.ups + m[i] % p.ups < p.Tout;
+        off[i] = ok ? ri.off[i] + qoff : kOutOfRange;
     }
+    float rv[N], av[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) rv[i] = av[i] = 0.f;
     if (p.res) {
 #pragma unroll
         for (int i = 0; i < N; ++i) rv[i] = buffer_load1(e.res, off[i]);
@@ -217,7 +252,7 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, const Epilog
         for (int i = 0; i < N; ++i) av[i] = buffer_load1(e.acc, off[i]);
     }
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = av[i] + ((v[i] + bv[i]) + rv[i]);
+    for (int i = 0; i < N; ++i) v[i] = av[i] + ((v[i] + ri.bias[i]) + rv[i]);
     if (p.out_div != 1.f) {
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = v[i] / p.out_div;
@@ -229,8 +264,20 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, const Epilog
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = fmaxf(v[i], 0.f);
     }
+    if (p.y_act) {
+        // raw tensor for residual consumers + activated twin for conv consumers
 #pragma unroll
-    for (int i = 0; i < N; ++i) buffer_store1(e.y, off[i], v[i]);
+        for (int i = 0; i < N; ++i) buffer_store1(e.y, off[i], v[i]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) buffer_store1(e.y2, off[i], act(v[i], p.act_slope));
+    } else {
+        if (p.act_slope != 1.f) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = act(v[i], p.act_slope);
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) buffer_store1(e.y, off[i], v[i]);
+    }
 }
 
 // XCD-aware block order: the dispatcher places linear block id b on XCD b % 8,
@@ -273,9 +320,10 @@ struct Frag<16> {
 
 // ---------------------------------------------------------------------------
 // The kernel.  Block tile (MF*WM) x (MF*NR*WN); WK wave groups split K.
-// KT > 0 fixes the tap count at compile time (full unroll of the tap loop).
+// KT > 0 / DIL > 0 fix the tap count / dilation at compile time; ACT enables the
+// read-time input activation (stand-alone operator calls only).
 // ---------------------------------------------------------------------------
-template <int MF, int WM, int WN, int WK, int NR, int KT>
+template <int MF, int WM, int WN, int WK, int NR, int KT, int DIL, bool ACT>
 __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvParams p) {
     typedef Frag<MF> F;
     typedef typename F::acc_t acc_t;
@@ -283,8 +331,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvParams
     constexpr int NT = 64 * NW;
     constexpr int M_T = MF * WM;
     constexpr int N_T = MF * NR * WN;
+    constexpr int EN = F::REGS < 8 ? F::REGS : 8;   // epilogue batch
+    constexpr int EH = F::REGS / EN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int k = KT > 0 ? KT : p.k;
+    const int dil = DIL > 0 ? DIL : p.dil;
     float* const xs0 = smem;                      // 2 x p.xbuf floats
     float* const ws0 = smem + 2 * p.xbuf;         // 2 x p.wbuf floats
 
@@ -300,135 +351,143 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvParams
     const int lin = xcd_remap(blockIdx.x, gridDim.x);
     const int mt = lin % m_tiles, run = lin / m_tiles;
     const int runs = gridDim.x / m_tiles;
-    const int tile_lo = (int)((long long)run * p.n_tiles / runs);
-    const int tile_hi = (int)((long long)(run + 1) * p.n_tiles / runs);
+    const int tile_lo = (int)(((unsigned)run * (unsigned)p.n_tiles) / (unsigned)runs);
+    const int tile_hi = (int)(((unsigned)(run + 1) * (unsigned)p.n_tiles) / (unsigned)runs);
     const int b = blockIdx.y;
     const int m0 = mt * M_T;
-    const int nchunks = (p.Cin + p.ci_chunk - 1) / p.ci_chunk;
-    const int nstages = (tile_hi - tile_lo) * nchunks;
-    if (nstages <= 0) return;
+    const int nchunks = p.nchunks;
+    if (tile_hi <= tile_lo) return;
 
-    acc_t acc[NR];
     const __amdgpu_buffer_rsrc_t rx =
         make_rsrc(p.x + (size_t)b * p.Cin * (size_t)p.Tin, (unsigned)p.Cin * (unsigned)p.Tin * 4u);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.wp, (unsigned)p.Cin * (unsigned)p.k * (unsigned)p.Mpad * 4u);
     const EpilogueRsrc ersrc = epilogue_rsrc(p, b);
+    DmaPlan dp;
+    dma_plan<NW, M_T>(p, dp, m0, wave, lane);
+    RowInfo<EN> ri[EH];
+#pragma unroll
+    for (int h = 0; h < EH; ++h) {
+        int mm[EN];
+#pragma unroll
+        for (int i = 0; i < EN; ++i) mm[i] = m0 + wave_m * MF + F::row(h * EN + i, lane);
+        row_info<EN>(p, mm, ri[h]);
+    }
+    // the tile's window start is t0 - pad; with N_T a multiple of 4 only pad sets the phase
+    const int aoff = (((-p.pad) % 4) + 4) % 4;
 
-    // prologue: stage 0 -> buffer 0
+    // prologue: stage (tile_lo, chunk 0) -> buffer 0
     {
-        const Window w = window_of(p, tile_lo * N_T);
-        dma_w<NW, M_T>(p, rw, ws0, 0, m0, wave, lane);
-        if (interior(p, w.tA)) dma_x<NW>(p, rx, xs0, 0, w.tA, wave, lane);
-        else stage_x_edge<NT>(p, xs0, b, 0, w.tA, tid);
+        const int tA = tile_lo * N_T - p.pad - aoff;
+        dma_w<NW, M_T>(p, dp, rw, ws0, 0, wave);
+        if (interior(p, tA)) dma_x<NW>(p, dp, rx, xs0, 0, tA, wave);
+        else stage_x_edge<NT>(p, xs0, b, 0, tA, tid);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    int tile = tile_lo, chunk = 0;
-    for (int s = 0; s < nstages; ++s) {
-        const int cur = s & 1, nxt = cur ^ 1;
-        // next stage's coordinates
-        int ntile = tile, nchunk = chunk + 1;
-        if (nchunk == nchunks) {
-            nchunk = 0;
-            ++ntile;
-        }
-        const bool more = s + 1 < nstages && !(p.dbg & 2);
-        const Window wn = window_of(p, ntile * N_T);
-        const bool fast = interior(p, wn.tA);
-        if (more) {
-            // asynchronous: lands in the other buffer while this stage computes
-            if (fast) dma_x<NW>(p, rx, xs0 + nxt * p.xbuf, nchunk * p.ci_chunk, wn.tA, wave, lane);
-            if (nchunks > 1) dma_w<NW, M_T>(p, rw, ws0 + nxt * p.wbuf, nchunk * p.ci_chunk, m0, wave, lane);
-        }
-        if (chunk == 0) {
+    int cur = 0;
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+        acc_t acc[NR];
 #pragma unroll
-            for (int r = 0; r < NR; ++r)
+        for (int r = 0; r < NR; ++r)
 #pragma unroll
-                for (int i = 0; i < F::REGS; ++i) acc[r][i] = 0.f;
-        }
-        // ---- matrix work on the current buffers ----
-        {
-            const Window w = window_of(p, tile * N_T);
-            // with a single chunk the weights never change: they stay in buffer 0
-            const float* wsA = ws0 + (nchunks > 1 ? cur * p.wbuf : 0) + wave_m * MF + lm;
-            const float* xsB = xs0 + cur * p.xbuf + w.aoff + wave_n * (MF * NR) + lm;
-            const float slope = p.pre_slope;
-            for (int c = wk * F::KS; c < ((p.dbg & 4) ? 0 : p.ci_chunk); c += F::KS * WK) {
-                const int ci = c + kq;
-                const float* pa = wsA + ci * k * M_T;
-                const float* pb = xsB + ci * p.xw;
-                if constexpr (KT > 0) {
-#pragma unroll
-                    for (int tap = 0; tap < KT; ++tap) {
-                        const float a = pa[tap * M_T];
-#pragma unroll
-                        for (int r = 0; r < NR; ++r)
-                            acc[r] = F::mfma(a, act(pb[tap * p.dil + r * MF], slope), acc[r]);
-                    }
-                } else {
-                    for (int tap = 0; tap < k; ++tap) {
-                        const float a = pa[tap * M_T];
-#pragma unroll
-                        for (int r = 0; r < NR; ++r)
-                            acc[r] = F::mfma(a, act(pb[tap * p.dil + r * MF], slope), acc[r]);
-                    }
-                }
+            for (int i = 0; i < F::REGS; ++i) acc[r][i] = 0.f;
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int nxt = cur ^ 1;
+            // ---- next stage's coordinates; its DMA runs while this stage computes ----
+            const bool last_chunk = chunk == nchunks - 1;
+            const int ntile = last_chunk ? tile + 1 : tile;
+            const int nci0 = last_chunk ? 0 : (chunk + 1) * p.ci_chunk;
+            const bool more = ntile < tile_hi && !(p.dbg & 2);
+            const int ntA = ntile * N_T - p.pad - aoff;
+            const bool fast = interior(p, ntA);
+            if (more) {
+                if (fast) dma_x<NW>(p, dp, rx, xs0 + nxt * p.xbuf, nci0, ntA, wave);
+                if (nchunks > 1) dma_w<NW, M_T>(p, dp, rw, ws0 + nxt * p.wbuf, nci0, wave);
             }
-        }
-        if (more && !fast)
-            stage_x_edge<NT>(p, xs0 + nxt * p.xbuf, b, nchunk * p.ci_chunk, wn.tA, tid);
-        if (chunk == nchunks - 1) {
-            // ---- tile finished: (split-K reduce and) fused epilogue ----
-            const int t0 = tile * N_T;
-            if constexpr (WK > 1) {
-                // partial sums of groups 1..WK-1 go through a dedicated LDS area
-                float* red = smem + p.red_off;
-                if (wk > 0) {
-                    float* dst = red + ((wk - 1) * (WM * WN) + wave_m * WN + wave_n) *
-                                           (NR * F::REGS * 64) + lane;
+            // ---- matrix work on the current buffers ----
+            {
+                // with a single chunk the weights never change: they stay in buffer 0
+                const float* wsA = ws0 + (nchunks > 1 ? cur * p.wbuf : 0) + wave_m * MF + lm + kq * (k * M_T);
+                const float* xsB = xs0 + cur * p.xbuf + aoff + wave_n * (MF * NR) + lm + kq * p.xw;
+                const float slope = p.pre_slope;
+                const int cend = (p.dbg & 4) ? 0 : p.ci_chunk;
+                for (int c = wk * F::KS; c < cend; c += F::KS * WK) {
+                    const float* pa = wsA + c * (k * M_T);
+                    const float* pb = xsB + c * p.xw;
+                    if constexpr (KT > 0) {
 #pragma unroll
-                    for (int r = 0; r < NR; ++r)
+                        for (int tap = 0; tap < KT; ++tap) {
+                            const float a = pa[tap * M_T];
 #pragma unroll
-                        for (int i = 0; i < F::REGS; ++i) dst[(r * F::REGS + i) * 64] = acc[r][i];
-                }
-                __syncthreads();
-                if (wk == 0) {
-#pragma unroll
-                    for (int g = 1; g < WK; ++g) {
-                        const float* src = red + ((g - 1) * (WM * WN) + wave_m * WN + wave_n) *
-                                                     (NR * F::REGS * 64) + lane;
-#pragma unroll
-                        for (int r = 0; r < NR; ++r)
-#pragma unroll
-                            for (int i = 0; i < F::REGS; ++i) acc[r][i] += src[(r * F::REGS + i) * 64];
-                    }
-                }
-            }
-            if ((WK == 1 || wk == 0) && !(p.dbg & 1)) {
-                constexpr int EN = F::REGS < 8 ? F::REGS : 8;   // elements per epilogue batch
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const int q = t0 + wave_n * (MF * NR) + r * MF + lm;
-#pragma unroll
-                    for (int h = 0; h < F::REGS / EN; ++h) {
-                        int mm[EN];
-                        float vv[EN];
-#pragma unroll
-                        for (int i = 0; i < EN; ++i) {
-                            mm[i] = m0 + wave_m * MF + F::row(h * EN + i, lane);
-                            vv[i] = acc[r][h * EN + i];
+                            for (int r = 0; r < NR; ++r) {
+                                float bv = pb[tap * dil + r * MF];
+                                if constexpr (ACT) bv = act(bv, slope);
+                                acc[r] = F::mfma(a, bv, acc[r]);
+                            }
                         }
-                        epilogue_store<EN>(p, ersrc, mm, q, vv);
+                    } else {
+                        for (int tap = 0; tap < k; ++tap) {
+                            const float a = pa[tap * M_T];
+#pragma unroll
+                            for (int r = 0; r < NR; ++r) {
+                                float bv = pb[tap * dil + r * MF];
+                                if constexpr (ACT) bv = act(bv, slope);
+                                acc[r] = F::mfma(a, bv, acc[r]);
+                            }
+                        }
                     }
                 }
             }
+            if (more && !fast) stage_x_edge<NT>(p, xs0 + nxt * p.xbuf, b, nci0, ntA, tid);
+            if (last_chunk) {
+                // ---- tile finished: (split-K reduce and) fused epilogue ----
+                if constexpr (WK > 1) {
+                    float* red = smem + p.red_off;
+                    if (wk > 0) {
+                        float* dst = red + ((wk - 1) * (WM * WN) + wave_m * WN + wave_n) *
+                                               (NR * F::REGS * 64) + lane;
+#pragma unroll
+                        for (int r = 0; r < NR; ++r)
+#pragma unroll
+                            for (int i = 0; i < F::REGS; ++i) dst[(r * F::REGS + i) * 64] = acc[r][i];
+                    }
+                    __syncthreads();
+                    if (wk == 0) {
+#pragma unroll
+                        for (int g = 1; g < WK; ++g) {
+                            const float* src = red + ((g - 1) * (WM * WN) + wave_m * WN + wave_n) *
+                                                         (NR * F::REGS * 64) + lane;
+#pragma unroll
+                            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                                for (int i = 0; i < F::REGS; ++i) acc[r][i] += src[(r * F::REGS + i) * 64];
+                        }
+                    }
+                }
+                if ((WK == 1 || wk == 0) && !(p.dbg & 1)) {
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const int q = tile * N_T + wave_n * (MF * NR) + r * MF + lm;
+#pragma unroll
+                        for (int h = 0; h < EH; ++h) {
+                            float vv[EN];
+                            int mm[EN];
+#pragma unroll
+                            for (int i = 0; i < EN; ++i) {
+                                vv[i] = acc[r][h * EN + i];
+                                mm[i] = m0 + wave_m * MF + F::row(h * EN + i, lane);
+                            }
+                            epilogue_store<EN>(p, ersrc, ri[h], mm, q, vv);
+                        }
+                    }
+                }
+            }
+            // the DMA issued above must have landed (own wave: vmcnt; others: barrier)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur = nxt;
         }
-        // the DMA issued above must have landed (own wave: vmcnt; others: barrier)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        tile = ntile;
-        chunk = nchunk;
     }
 }
 
@@ -449,21 +508,24 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(ConvParams p) {
     const int b = blockIdx.y;
     const int t0 = xcd_remap(blockIdx.x, gridDim.x) * N_T;
     const int k = p.k;
-    const Window w = window_of(p, t0);
+    const int aoff = (((-p.pad) % 4) + 4) % 4;
+    const int tA = t0 - p.pad - aoff;
     float acc[MO];
 #pragma unroll
     for (int m = 0; m < MO; ++m) acc[m] = 0.f;
     const __amdgpu_buffer_rsrc_t rx =
         make_rsrc(p.x + (size_t)b * p.Cin * (size_t)p.Tin, (unsigned)p.Cin * (unsigned)p.Tin * 4u);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.wp, (unsigned)p.Cin * (unsigned)p.k * (unsigned)p.Mpad * 4u);
+    DmaPlan dp;
+    dma_plan<NW, 16>(p, dp, 0, wave, lane);
     const float slope = p.pre_slope;
     for (int ci0 = 0; ci0 < p.Cin; ci0 += p.ci_chunk) {
-        dma_w<NW, 16>(p, rw, ws, ci0, 0, wave, lane);
-        if (interior(p, w.tA)) dma_x<NW>(p, rx, xs, ci0, w.tA, wave, lane);
-        else stage_x_edge<NT>(p, xs, b, ci0, w.tA, tid);
+        dma_w<NW, 16>(p, dp, rw, ws, ci0, wave);
+        if (interior(p, tA)) dma_x<NW>(p, dp, rx, xs, ci0, tA, wave);
+        else stage_x_edge<NT>(p, xs, b, ci0, tA, tid);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const float* pb = xs + w.aoff + tid;
+        const float* pb = xs + aoff + tid;
         for (int ci = 0; ci < p.ci_chunk; ++ci) {
             for (int tap = 0; tap < k; ++tap) {
                 const float xv = act(pb[ci * p.xw + tap * p.dil], slope);
@@ -478,7 +540,9 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(ConvParams p) {
     int mm[MO];
 #pragma unroll
     for (int m = 0; m < MO; ++m) mm[m] = m;
-    epilogue_store<MO>(p, ersrc, mm, t0 + tid, acc);
+    RowInfo<MO> ri;
+    row_info<MO>(p, mm, ri);
+    epilogue_store<MO>(p, ersrc, ri, mm, t0 + tid, acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -524,11 +588,16 @@ size_t plan_staging(ConvParams& p, const Geometry& g, int k_rows_target) {
     int best = 0;
     for (int c = ks; c <= cin_pad; c += ks) {
         const size_t per_buf = (size_t)round_up(c * p.ncol4c, 64) * 16 + (size_t)round_up(c * p.k * g.m_t() / 4, 64) * 16;
-        if (best && 2 * per_buf > (size_t)env_int("FV_LDS_BUDGET", 40) * 1024) break;
+        const int nw = g.wm * g.wn * g.wk;
+        const bool dma_ok = round_up(c * p.ncol4c, 64) / 64 <= kMaxDmaX * nw &&
+                            round_up(c * p.k * g.m_t() / 4, 64) / 64 <= kMaxDmaW * nw;
+        if (best && (!dma_ok || 2 * per_buf > (size_t)env_int("FV_LDS_BUDGET", 40) * 1024)) break;
+        if (!dma_ok) return 0;
         if (cin_pad % c == 0 || !best) best = c;
         if (c * p.k >= k_rows_target && cin_pad % c == 0) break;
     }
     p.ci_chunk = best;
+    p.nchunks = (p.Cin + best - 1) / best;
     p.xbuf = round_up(best * p.ncol4c, 64) * 4;
     p.wbuf = round_up(best * p.k * g.m_t() / 4, 64) * 4;
     size_t floats = (size_t)2 * (p.xbuf + p.wbuf);
@@ -540,21 +609,33 @@ size_t plan_staging(ConvParams& p, const Geometry& g, int k_rows_target) {
 template <int MF, int WM, int WN, int WK, int NR>
 int launch_geom(const ConvParams& p, size_t lds, int grid_x, hipStream_t s) {
     dim3 grid(grid_x, p.B), block(64 * WM * WN * WK);
-#define FV_LAUNCH(KT)                                                                         \
+#define FV_LAUNCH(KT, DIL, ACT)                                                               \
     do {                                                                                      \
-        auto kern = conv_mfma_kernel<MF, WM, WN, WK, NR, KT>;                                 \
+        auto kern = conv_mfma_kernel<MF, WM, WN, WK, NR, KT, DIL, ACT>;                       \
         if (lds > 64 * 1024)                                                                  \
             FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, grid, block, lds, s, p);                                     \
     } while (0)
-    switch (p.k) {
-        case 1: FV_LAUNCH(1); break;
-        case 3: FV_LAUNCH(3); break;
-        case 7: FV_LAUNCH(7); break;
-        case 11: FV_LAUNCH(11); break;
-        default: FV_LAUNCH(0); break;
+#define FV_LAUNCH_DIL(KT)                                  \
+    switch (p.dil) {                                       \
+        case 1: FV_LAUNCH(KT, 1, false); break;            \
+        case 3: FV_LAUNCH(KT, 3, false); break;            \
+        case 5: FV_LAUNCH(KT, 5, false); break;            \
+        default: FV_LAUNCH(KT, 0, false); break;           \
     }
+    if (p.pre_slope != 1.f) {
+        FV_LAUNCH(0, 0, true);            // read-time activation: generic variant only
+    } else {
+        switch (p.k) {
+            case 1: FV_LAUNCH(1, 1, false); break;
+            case 3: FV_LAUNCH_DIL(3); break;
+            case 7: FV_LAUNCH_DIL(7); break;
+            case 11: FV_LAUNCH_DIL(11); break;
+            default: FV_LAUNCH(0, 0, false); break;
+        }
+    }
+#undef FV_LAUNCH_DIL
 #undef FV_LAUNCH
     FV_HIP(hipGetLastError());
     return 0;
@@ -569,15 +650,7 @@ const Geometry kShapes[] = {
     {32, 1, 1, 4, 1},   // 4: 32 x 32,   K split 4
     {32, 2, 2, 1, 1},   // 5: 64 x 64
     {32, 2, 1, 2, 1},   // 6: 64 x 32,   K split 2
-    {32, 2, 2, 1, 2},   // 7: 64 x 128
-    {16, 1, 4, 1, 4},   // 8: 16 x 256
-    {16, 1, 2, 2, 4},   // 9: 16 x 128,  K split 2
-    {32, 1, 2, 2, 2},   // 10: 32 x 128, K split 2, 2 accumulators per wave
-    {32, 1, 4, 1, 2},   // 11: 32 x 256, 2 accumulators per wave
-    {32, 1, 1, 4, 2},   // 12: 32 x 64,  K split 4, 2 accumulators per wave
-    {32, 2, 1, 2, 2},   // 13: 64 x 64,  K split 2, 2 accumulators per wave
-    {32, 1, 2, 2, 4},   // 14: 32 x 256, K split 2, 4 accumulators per wave
-    {32, 2, 1, 2, 4},   // 15: 64 x 128, K split 2, 4 accumulators per wave
+    {32, 1, 2, 2, 2},   // 7: 32 x 128,  K split 2, 2 accumulators per wave
 };
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
 
@@ -590,15 +663,7 @@ int launch_shape(int id, const ConvParams& p, size_t lds, int grid_x, hipStream_
         case 4: return launch_geom<32, 1, 1, 4, 1>(p, lds, grid_x, s);
         case 5: return launch_geom<32, 2, 2, 1, 1>(p, lds, grid_x, s);
         case 6: return launch_geom<32, 2, 1, 2, 1>(p, lds, grid_x, s);
-        case 7: return launch_geom<32, 2, 2, 1, 2>(p, lds, grid_x, s);
-        case 8: return launch_geom<16, 1, 4, 1, 4>(p, lds, grid_x, s);
-        case 9: return launch_geom<16, 1, 2, 2, 4>(p, lds, grid_x, s);
-        case 10: return launch_geom<32, 1, 2, 2, 2>(p, lds, grid_x, s);
-        case 11: return launch_geom<32, 1, 4, 1, 2>(p, lds, grid_x, s);
-        case 12: return launch_geom<32, 1, 1, 4, 2>(p, lds, grid_x, s);
-        case 13: return launch_geom<32, 2, 1, 2, 2>(p, lds, grid_x, s);
-        case 14: return launch_geom<32, 1, 2, 2, 4>(p, lds, grid_x, s);
-        default: return launch_geom<32, 2, 1, 2, 4>(p, lds, grid_x, s);
+        default: return launch_geom<32, 1, 2, 2, 2>(p, lds, grid_x, s);
     }
 }
 
@@ -628,8 +693,10 @@ int launch_conv(ConvParams p, hipStream_t s) {
         kind = FV_KERNEL_CONV_NARROW;
         plan_x_image(p, 256, false);
         int c = 1;
-        while (c + 1 <= p.Cin && (size_t)(round_up((c + 1) * p.ncol4c, 64) + round_up((c + 1) * p.k * 4, 64)) * 16 <= 48 * 1024)
+        while (c + 1 <= p.Cin && (size_t)(round_up((c + 1) * p.ncol4c, 64) + round_up((c + 1) * p.k * 4, 64)) * 16 <= 48 * 1024 &&
+               round_up((c + 1) * p.ncol4c, 64) / 64 <= kMaxDmaX * 4 && round_up((c + 1) * p.k * 4, 64) / 64 <= kMaxDmaW * 4)
             ++c;
+        p.nchunks = (p.Cin + c - 1) / c;
         p.ci_chunk = c;
         p.xbuf = round_up(c * p.ncol4c, 64) * 4;
         p.wbuf = round_up(c * p.k * 4, 64) * 4;
@@ -666,6 +733,7 @@ int launch_conv(ConvParams p, hipStream_t s) {
             shape = force;
         const Geometry g = kShapes[shape];
         const size_t lds = plan_staging(p, g, env_int("FV_KROWS", 96));
+        if (!lds) return fail(FV_ERR_UNSUPPORTED, "conv: k=%d dil=%d cannot be staged (window too wide)", p.k, p.dil);
         p.n_tiles = (p.Tq + g.n_t() - 1) / g.n_t();
         const int m_tiles = p.Mpad / g.m_t();
         // runs of consecutive time tiles per block: cap the grid (launch cost only)

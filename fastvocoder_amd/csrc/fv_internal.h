@@ -53,14 +53,17 @@ struct ConvParams {
     const float* res;     // [B,Cout,Tout] or null
     const float* acc_in;  // [B,Cout,Tout] or null
     float* y;             // [B,Cout,Tout]
+    float* y_act;         // optional activated twin of y: act(y, act_slope), or null
     int B, Cin, M, Mpad, Cout;
     int Tin, Tq, Tout;
     int k, dil, pad, pad_mode;
     int ups;              // 1 for Conv1d, stride for ConvTranspose1d
     float pre_slope, out_div;
+    float act_slope;      // with y_act: slope of the twin; without: y itself is stored as act(y, act_slope)
     int post;
     // filled in by the launcher
     int ci_chunk;   // input channels staged per LDS stage
+    int nchunks;    // ceil(Cin / ci_chunk)
     int xw;         // LDS row stride of the input tile (floats)
     int ncol4;      // float4 columns of an input row the tile actually reads
     int ncol4c;     // float4 columns per row of the LDS image (>= ncol4; xw = 4*ncol4c)

@@ -35,12 +35,24 @@ def effective_weight(conv):
 
 
 class PlanBuilder:
-    """Accumulates ops into a native plan; slots are small integers naming
-    tensors (SLOT_IN / SLOT_OUT / temporaries handed out by :meth:`tmp`)."""
+    """Accumulates ops, runs the activation-hoisting pass, then emits a native
+    plan.  Slots are small integers naming tensors (SLOT_IN / SLOT_OUT /
+    temporaries handed out by :meth:`tmp`).
+
+    Activation hoisting: on gfx950 plain VALU instructions do not overlap the
+    fp32 MFMA (each costs matrix time), so ``conv(leaky_relu(x))`` must not apply
+    the activation per operand read.  :meth:`finalize` rewrites the op list so
+    that the op PRODUCING ``x`` stores ``leaky_relu(x, slope)`` -- in place when
+    every consumer wants the activated tensor, or into a twin slot next to the
+    raw tensor when a residual add also needs the raw one -- and the consuming
+    convs read it with ``pre_slope = 1``.
+    """
 
     def __init__(self, in_channels):
         self.plan = _native.Plan(in_channels)
         self._next = _native.SLOT_TMP0
+        self.ops = []
+        self.lane = 0       # concurrency lane of the ops being recorded (see fv_plan_set_lane)
 
     def tmp(self):
         s = self._next
@@ -55,40 +67,100 @@ class PlanBuilder:
 
     def conv(self, conv, src, dst, pad=None, pad_mode=PAD_ZERO, pre_slope=1.0, res=SLOT_NONE,
              acc=SLOT_NONE, out_div=1.0, post=POST_NONE):
-        """Emit ``conv`` (a torch.nn.Conv1d container): dst = epilogue(conv(act(src)))."""
+        """Record ``conv`` (a torch.nn.Conv1d container): dst = epilogue(conv(act(src)))."""
         if conv.stride[0] != 1 or conv.groups != 1:
             raise _native.NativeError("only stride-1, groups-1 Conv1d layers exist on this path")
         k, d = conv.kernel_size[0], conv.dilation[0]
         if pad is None:
             pad = conv.padding[0]
-        packed = _native.pack_conv1d(effective_weight(conv))
-        self.plan.add_conv1d(src, dst, packed, self._bias(conv), conv.in_channels, conv.out_channels,
-                             k, dil=d, pad=pad, pad_mode=pad_mode, pre_slope=pre_slope, res=res,
-                             acc=acc, out_div=out_div, post=post)
+        self.ops.append(dict(kind="conv", lane=self.lane, x=src, y=dst, res=res, acc=acc, pre_slope=float(pre_slope),
+                             packed=_native.pack_conv1d(effective_weight(conv)), bias=self._bias(conv),
+                             cin=conv.in_channels, cout=conv.out_channels, k=k, dil=d, pad=pad,
+                             pad_mode=pad_mode, out_div=out_div, post=post))
 
     def conv_transpose(self, convt, src, dst, pre_slope=1.0, post=POST_NONE):
-        """Emit a torch.nn.ConvTranspose1d container in polyphase form."""
+        """Record a torch.nn.ConvTranspose1d container (polyphase form)."""
         if convt.groups != 1 or convt.dilation[0] != 1:
             raise _native.NativeError("only dense, undilated ConvTranspose1d layers exist on this path")
         k, s = convt.kernel_size[0], convt.stride[0]
         p, op = convt.padding[0], convt.output_padding[0]
-        packed = _native.pack_conv_transpose1d(effective_weight(convt), s, p)
-        self.plan.add_conv_transpose1d(src, dst, packed, self._bias(convt), convt.in_channels,
-                                       convt.out_channels, k, s, p, op, pre_slope=pre_slope, post=post)
+        self.ops.append(dict(kind="convT", lane=self.lane, x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE,
+                             pre_slope=float(pre_slope),
+                             packed=_native.pack_conv_transpose1d(effective_weight(convt), s, p),
+                             bias=self._bias(convt), cin=convt.in_channels, cout=convt.out_channels,
+                             k=k, stride=s, pad=p, out_pad=op, post=post))
 
     def basis_overlap_add(self, basis_weight, src, dst, hop, pre_slope=1.0):
         """frames = act(src)^T @ W^T then overlap-add with hop: a ConvTranspose1d
         with Cout = 1, kernel L, stride hop (weight [C,1,L] = W^T)."""
         L, C = basis_weight.shape
         w = basis_weight.detach().float().t().contiguous().view(C, 1, L)
-        packed = _native.pack_conv_transpose1d(w, hop, 0)
-        self.plan.add_conv_transpose1d(src, dst, packed, None, C, 1, L, hop, 0, 0,
-                                       pre_slope=pre_slope)
+        self.ops.append(dict(kind="convT", lane=self.lane, x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE,
+                             pre_slope=float(pre_slope), packed=_native.pack_conv_transpose1d(w, hop, 0),
+                             bias=None, cin=C, cout=1, k=L, stride=hop, pad=0, out_pad=0, post=POST_NONE))
 
     def pqmf_synthesis(self, synthesis_filter, src, dst):
         S = synthesis_filter.shape[1]
         h = synthesis_filter.detach().reshape(S, -1).contiguous().float()
-        self.plan.add_pqmf_synthesis(src, dst, h)
+        self.ops.append(dict(kind="pqmf", lane=self.lane, x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE, pre_slope=1.0, h=h))
+
+    # -- activation hoisting ---------------------------------------------------
+    def _hoist_activations(self):
+        ops = self.ops
+        twin_of = {}
+        for i, op in enumerate(ops):
+            op.setdefault("y_act", SLOT_NONE)
+            op.setdefault("act_slope", 1.0)
+        for i, op in enumerate(ops):
+            if op["kind"] == "pqmf":
+                continue
+            y = op["y"]
+            # consumers of this definition of slot y: until the slot is written again
+            act_uses, raw_needed = {}, y == SLOT_OUT
+            for j in range(i + 1, len(ops)):
+                c = ops[j]
+                if c["x"] == y:
+                    if c["pre_slope"] != 1.0:
+                        act_uses.setdefault(c["pre_slope"], []).append(j)
+                    else:
+                        raw_needed = True
+                if c["res"] == y or c["acc"] == y:
+                    raw_needed = True
+                if c["y"] == y or c.get("y_act") == y:
+                    break
+            if not act_uses:
+                continue
+            slope = max(act_uses, key=lambda s: len(act_uses[s]))
+            if len(act_uses) > 1:
+                raw_needed = True          # the other slopes keep activating at read time
+            if raw_needed:
+                if y not in twin_of:
+                    twin_of[y] = self.tmp()
+                op["y_act"], op["act_slope"], target = twin_of[y], slope, twin_of[y]
+            else:
+                op["act_slope"], target = slope, y
+            for j in act_uses[slope]:
+                ops[j]["x"], ops[j]["pre_slope"] = target, 1.0
+
+    def finalize(self):
+        """Hoist activations and emit the recorded ops into the native plan."""
+        self._hoist_activations()
+        for op in self.ops:
+            self.plan.set_lane(op["lane"])
+            if op["kind"] == "conv":
+                self.plan.add_conv1d(op["x"], op["y"], op["packed"], op["bias"], op["cin"], op["cout"],
+                                     op["k"], dil=op["dil"], pad=op["pad"], pad_mode=op["pad_mode"],
+                                     pre_slope=op["pre_slope"], res=op["res"], acc=op["acc"],
+                                     out_div=op["out_div"], post=op["post"], y_act=op["y_act"],
+                                     act_slope=op["act_slope"])
+            elif op["kind"] == "convT":
+                self.plan.add_conv_transpose1d(op["x"], op["y"], op["packed"], op["bias"], op["cin"],
+                                               op["cout"], op["k"], op["stride"], op["pad"],
+                                               op["out_pad"], pre_slope=op["pre_slope"], post=op["post"],
+                                               y_act=op["y_act"], act_slope=op["act_slope"])
+            else:
+                self.plan.add_pqmf_synthesis(op["x"], op["y"], op["h"])
+        return self.plan
 
 
 class NativeModule(torch.nn.Module):
@@ -144,8 +216,9 @@ class NativeModule(torch.nn.Module):
         with torch.no_grad():
             pb = PlanBuilder(in_channels)
             emit(pb)
-        self._fv_plans[name] = (state, pb.plan)
-        return pb.plan
+            plan = pb.finalize()
+        self._fv_plans[name] = (state, plan)
+        return plan
 
     def _prepare(self, x):
         """Any array-like -> contiguous fp32 tensor on this module's device."""

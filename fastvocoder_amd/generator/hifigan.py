@@ -64,9 +64,13 @@ class _HiFiGANBase(NativeModule):
     def _emit_trunk(self, pb, dst):
         """mel (SLOT_IN) -> tanh(conv_post(...)) in ``dst``."""
         x, up, acc = pb.tmp(), pb.tmp(), pb.tmp()
-        scratch = [pb.tmp(), pb.tmp(), pb.tmp()]
-        pb.conv(self.conv_pre, SLOT_IN, x)
         nk = self.num_kernels
+        # the nk ResBlocks of a stage are independent given the upsampled input: each
+        # gets its own concurrency lane (stream) and scratch, so that at batch 1, where
+        # one conv cannot fill 256 CUs, three of them run side by side
+        lanes = min(nk, 3)
+        scratch = [[pb.tmp(), pb.tmp(), pb.tmp()] for _ in range(lanes)]
+        pb.conv(self.conv_pre, SLOT_IN, x)
         for i in range(self.num_upsamples):
             if isinstance(self.ups[i], UpsampleLayer):
                 raise NotImplementedError(
@@ -77,10 +81,12 @@ class _HiFiGANBase(NativeModule):
                 last = j == nk - 1
                 # running sum in `acc` in resblock order, mean folded into the
                 # last block's final epilogue (reference hifigan.py:97-103)
+                pb.lane = j % lanes
                 self.resblocks[i * nk + j].emit(
-                    pb, up, x if last else acc, scratch,
+                    pb, up, x if last else acc, scratch[j % lanes],
                     acc=acc if j > 0 else SLOT_NONE,
                     out_div=float(nk) if last else 1.0)
+            pb.lane = 0
         pb.conv(self.conv_post, x, dst, pre_slope=DEFAULT_LRELU_SLOPE, post=POST_TANH)
 
     def _trunk(self, x):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FV_ABI_VERSION 1
+#define FV_ABI_VERSION 2
 
 #define FV_ERR_INVALID_ARG (-1)
 #define FV_ERR_UNSUPPORTED (-2)
@@ -79,7 +79,8 @@ int fv_pack_conv_transpose1d_weight(const float* w, float* packed, int Cin, int 
  * ------------------------------------------------------------------ */
 
 /*
- * y = post( ( acc_in + ( conv1d(lrelu(x, pre_slope); w, dil, pad) + bias + res ) ) / out_div )
+ * y     = post( ( acc_in + ( conv1d(lrelu(x, pre_slope); w, dil, pad) + bias + res ) ) / out_div )
+ * y_act = lrelu(y, act_slope)            (optional second output, see below)
  *
  * Replaces F.leaky_relu + torch.nn.Conv1d (+ the residual add, the MRF running
  * sum / mean and tanh) at modules.py:223-230 (ResBlock1), :247-252 (ResBlock2),
@@ -90,11 +91,17 @@ int fv_pack_conv_transpose1d_weight(const float* w, float* packed, int Cin, int 
  *   Tout = Tin + 2*pad - dil*(k-1).  pre_slope = 1 disables the input
  *   activation, 0 is ReLU; out_div = 1 disables the division (it is a true
  *   fp32 division, hifigan.py:103).  y may alias res or acc_in, never x.
+ *   Activation hoisting: plain VALU work does not overlap the fp32 MFMA on gfx950,
+ *   so the fastest way to feed the NEXT conv's F.leaky_relu(x, s) is to have THIS
+ *   conv store it.  With y_act != NULL the raw y (for residual consumers) and
+ *   y_act = lrelu(y, act_slope) (for conv consumers, which then pass
+ *   pre_slope = 1) are both written; with y_act == NULL and act_slope != 1 only
+ *   the activated tensor is written, to y.  act_slope = 1 disables both.
  */
 int fv_conv1d_fused(const float* x, const float* packed, const float* bias,
-                    const float* res, const float* acc_in, float* y, int B, int Cin,
-                    int Cout, int Tin, int k, int dil, int pad, int pad_mode,
-                    float pre_slope, float out_div, int post, void* stream);
+                    const float* res, const float* acc_in, float* y, float* y_act, int B,
+                    int Cin, int Cout, int Tin, int k, int dil, int pad, int pad_mode,
+                    float pre_slope, float out_div, int post, float act_slope, void* stream);
 
 /*
  * y = post( conv_transpose1d(lrelu(x, pre_slope); w, stride, pad, out_pad) + bias )
@@ -107,9 +114,9 @@ int fv_conv1d_fused(const float* x, const float* packed, const float* bias,
  * Tout = (Tin-1)*stride - 2*pad + k + out_pad.
  */
 int fv_conv_transpose1d_fused(const float* x, const float* packed, const float* bias,
-                              float* y, int B, int Cin, int Cout, int Tin, int k,
-                              int stride, int pad, int out_pad, float pre_slope, int post,
-                              void* stream);
+                              float* y, float* y_act, int B, int Cin, int Cout, int Tin,
+                              int k, int stride, int pad, int out_pad, float pre_slope,
+                              int post, float act_slope, void* stream);
 
 /*
  * PQMF.synthesis (model/generator/pqmf.py:121-135) in polyphase form.
@@ -130,23 +137,31 @@ typedef struct fv_plan fv_plan_t;
 #define FV_SLOT_IN 0
 #define FV_SLOT_OUT 1
 #define FV_SLOT_TMP0 2
-#define FV_MAX_SLOTS 16
+#define FV_MAX_SLOTS 32
 
 fv_plan_t* fv_plan_create(int in_channels);
 void fv_plan_destroy(fv_plan_t* plan);
 
 /* append ops; argument meaning as in the fused operators above, tensors named
  * by slot.  Weight pointers are captured, not copied. */
-int fv_plan_add_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int res_slot,
-                       int acc_slot, const float* packed, const float* bias, int Cin,
-                       int Cout, int k, int dil, int pad, int pad_mode, float pre_slope,
-                       float out_div, int post);
-int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot,
+int fv_plan_add_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot,
+                       int res_slot, int acc_slot, const float* packed, const float* bias,
+                       int Cin, int Cout, int k, int dil, int pad, int pad_mode,
+                       float pre_slope, float out_div, int post, float act_slope);
+int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot,
                                  const float* packed, const float* bias, int Cin, int Cout,
                                  int k, int stride, int pad, int out_pad, float pre_slope,
-                                 int post);
+                                 int post, float act_slope);
 int fv_plan_add_pqmf_synthesis(fv_plan_t* plan, int x_slot, int y_slot, const float* h,
                                int S, int ntaps);
+
+/* Concurrency lanes (0..3): ops appended after this call belong to `lane`.  Lane 0
+ * runs on the caller's stream, other lanes on plan-owned streams; cross-lane
+ * ordering is derived from the slots each op reads and writes (events), with a
+ * fork/join around every fv_plan_run.  Used to run the independent ResBlocks of
+ * an MRF stage (hifigan.py:97-103) side by side when one utterance alone cannot
+ * fill 256 CUs. */
+int fv_plan_set_lane(fv_plan_t* plan, int lane);
 
 /* shape inference for a (B, T) call: channels / length of the output tensor
  * and the workspace the plan needs (bytes) */

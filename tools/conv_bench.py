@@ -66,7 +66,7 @@ def main():
             pad = (k - 1) * d // 2
             out = torch.empty(B, cout, tt, device=dev)
             res = torch.randn(B, cout, tt, device=dev) if cin == cout else None
-            fn = lambda: _native.conv1d_fused(x, packed, bias, cout, k, dil=d, pad=pad, pre_slope=0.1,
+            fn = lambda: _native.conv1d_fused(x, packed, bias, cout, k, dil=d, pad=pad, pre_slope=1.0,
                                               res=res, out=out)
             flops = 2.0 * B * cout * tt * cin * k
             byts = 4.0 * B * tt * (cin + cout * (2 if res is not None else 1))
@@ -77,7 +77,7 @@ def main():
             bias = torch.randn(cout, device=dev)
             out = torch.empty(B, cout, tt * up, device=dev)
             fn = lambda: _native.conv_transpose1d_fused(x, packed, bias, cout, k, up, p, up % 2,
-                                                        pre_slope=0.1, out=out)
+                                                        pre_slope=1.0, out=out)
             flops = 2.0 * B * tt * cin * cout * k
             byts = 4.0 * B * tt * (cin + cout * up)
         s = time_op(fn, args.iters)
