@@ -583,15 +583,16 @@ size_t plan_staging(ConvParams& p, const Geometry& g, int k_rows_target) {
     plan_x_image(p, g.n_t(), g.mf == 16);
     const int ks = (g.mf == 32 ? 2 : 4) * g.wk;     // ci granularity of one MFMA step x split
     const int cin_pad = round_up(p.Cin, ks);
-    // stage size: about k_rows_target MFMA K-rows (ci_chunk*k), both buffers <= ~40 KiB
-    // so that several blocks stay resident per CU; prefer chunks dividing Cin
+    // stage size: about k_rows_target MFMA K-rows (ci_chunk*k), both buffers <= 64 KiB
+    // so that 2+ blocks stay resident per CU; prefer chunks dividing Cin
+    // (defaults from end-to-end sweeps on MI355X, tools/bench_sweep.sh)
     int best = 0;
     for (int c = ks; c <= cin_pad; c += ks) {
         const size_t per_buf = (size_t)round_up(c * p.ncol4c, 64) * 16 + (size_t)round_up(c * p.k * g.m_t() / 4, 64) * 16;
         const int nw = g.wm * g.wn * g.wk;
         const bool dma_ok = round_up(c * p.ncol4c, 64) / 64 <= kMaxDmaX * nw &&
                             round_up(c * p.k * g.m_t() / 4, 64) / 64 <= kMaxDmaW * nw;
-        if (best && (!dma_ok || 2 * per_buf > (size_t)env_int("FV_LDS_BUDGET", 40) * 1024)) break;
+        if (best && (!dma_ok || 2 * per_buf > (size_t)env_int("FV_LDS_BUDGET", 64) * 1024)) break;
         if (!dma_ok) return 0;
         if (cin_pad % c == 0 || !best) best = c;
         if (c * p.k >= k_rows_target && cin_pad % c == 0) break;
@@ -720,7 +721,7 @@ int launch_conv(ConvParams p, hipStream_t s) {
             return (long)(p.Mpad / gg.m_t()) * ((p.Tq + gg.n_t() - 1) / gg.n_t());
         };
         // thresholds from per-layer sweeps on MI355X (tools/conv_bench.py, B = 1)
-        const int want = env_int("FV_UNITS", 900);
+        const int want = env_int("FV_UNITS", 500);
         int shape;
         if (m16) shape = units(0) >= want ? 0 : 1;
         else if (!m64 && units(2) >= want) shape = 2;
@@ -732,12 +733,12 @@ int launch_conv(ConvParams p, hipStream_t s) {
             p.Mpad % kShapes[force].m_t() == 0)
             shape = force;
         const Geometry g = kShapes[shape];
-        const size_t lds = plan_staging(p, g, env_int("FV_KROWS", 96));
+        const size_t lds = plan_staging(p, g, env_int("FV_KROWS", 176));
         if (!lds) return fail(FV_ERR_UNSUPPORTED, "conv: k=%d dil=%d cannot be staged (window too wide)", p.k, p.dil);
         p.n_tiles = (p.Tq + g.n_t() - 1) / g.n_t();
         const int m_tiles = p.Mpad / g.m_t();
         // runs of consecutive time tiles per block: cap the grid (launch cost only)
-        const int cap = env_int("FV_GRID_CAP", 8192);
+        const int cap = env_int("FV_GRID_CAP", 768);
         int runs = p.n_tiles;
         const long per_batch_cap = cap / ((long)p.B * m_tiles) > 0 ? cap / ((long)p.B * m_tiles) : 1;
         if (runs > per_batch_cap) runs = (int)per_batch_cap;
