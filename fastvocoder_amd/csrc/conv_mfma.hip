@@ -100,7 +100,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, float* lds, unsi
 // per-lane source offsets do not depend on the stage except for a uniform
 // base, so they are computed once (DmaPlan) and each stage costs one add per
 // instruction.
-constexpr int kMaxDmaX = 4, kMaxDmaW = 8;   // instructions per wave per stage (host-checked)
+constexpr int kMaxDmaX = 6, kMaxDmaW = 8;   // instructions per wave per stage (host-checked)
 
 // (rows past Cin / past Cin*k need no test: their offsets fall outside the
 // buffer descriptors, which cover exactly this utterance's input / the weights)

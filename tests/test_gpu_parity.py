@@ -130,6 +130,50 @@ def test_conv_transpose1d_fused_vs_oracle(case):
     assert _rel(y, ref) <= 2e-5
 
 
+def test_activated_twin_outputs():
+    """Activation hoisting at operator level: y raw + y_act = lrelu(y, s) in one launch, and the
+    in-place form; a consumer reading y_act with pre_slope = 1 equals reading y with pre_slope = s."""
+    dev = _dev()
+    rng = np.random.RandomState(12)
+    x = torch.from_numpy(rng.randn(2, 32, 500).astype(np.float32)).to(dev)
+    w = torch.from_numpy((rng.randn(32, 32, 7) / 15).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rng.randn(32).astype(np.float32)).to(dev)
+    packed = _native.pack_conv1d(w)
+    y = _native.conv1d_fused(x, packed, b, 32, 7, dil=3, pad=9)
+    y_act = torch.empty_like(y)
+    y2 = _native.conv1d_fused(x, packed, b, 32, 7, dil=3, pad=9, out_act=y_act, act_slope=0.1)
+    assert torch.equal(y2, y)
+    assert torch.equal(y_act, torch.where(y >= 0, y, y * 0.1))
+    y3 = _native.conv1d_fused(x, packed, b, 32, 7, dil=3, pad=9, act_slope=0.1)     # in place
+    assert torch.equal(y3, y_act)
+    a = _native.conv1d_fused(y, packed, b, 32, 7, dil=1, pad=3, pre_slope=0.1)       # read-time activation
+    c = _native.conv1d_fused(y_act, packed, b, 32, 7, dil=1, pad=3, pre_slope=1.0)   # hoisted
+    assert float((a - c).abs().max()) <= 1e-5 * float(a.abs().max())
+    # transposed conv with a twin
+    wt = torch.from_numpy((rng.randn(32, 16, 10) / 8).astype(np.float32)).to(dev)
+    pt = _native.pack_conv_transpose1d(wt, 5, 3)
+    u = _native.conv_transpose1d_fused(x, pt, None, 16, 10, 5, 3, 1)
+    u_act = torch.empty_like(u)
+    u2 = _native.conv_transpose1d_fused(x, pt, None, 16, 10, 5, 3, 1, out_act=u_act, act_slope=0.2)
+    assert torch.equal(u2, u) and torch.equal(u_act, torch.where(u >= 0, u, u * 0.2))
+
+
+def test_concurrency_lanes_do_not_change_results(monkeypatch):
+    """The three ResBlocks of an MRF stage run on separate streams; forcing a single
+    stream must give the same waveform bit for bit."""
+    cfg = cases.load_conf("conf/hifigan/light.yaml")
+    m, _ = _model("hifigan", cfg, seed=0)
+    x = torch.from_numpy(seeded_mel(300, seed=21, batch=2)).to(_dev())
+    with torch.no_grad():
+        a = m(x).clone()
+        monkeypatch.setenv("FV_SINGLE_LANE", "1")
+        b = m(x).clone()
+        monkeypatch.delenv("FV_SINGLE_LANE")
+        c = m(x).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, c)
+
+
 def test_conv_transpose_no_padding_is_overlap_add():
     """ConvTranspose1d(Cout=1, k=L, stride=L/2, pad=0) == linear + overlap_and_add."""
     rng = np.random.RandomState(5)

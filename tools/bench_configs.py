@@ -1,0 +1,66 @@
+"""Throughput of the other BASELINE.json configs (parity-test cases, not the headline bench):
+    python tools/bench_configs.py [--steps K]
+prints one line per config: samples/s, RTF@22.05k, ms/step, algorithmic TFLOP/s."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+import yaml
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fastvocoder_amd import _native  # noqa: E402
+from fastvocoder_amd.bin.synthesize import build_generator  # noqa: E402
+from fastvocoder_amd.synthetic import seeded_mel, seeded_state_dict  # noqa: E402
+
+CONFIGS = [
+    ("melgan T=200 B=1 (config 1)", "melgan", "conf/melgan/original.yaml", 1, 200),
+    ("hifigan light T=1000 B=1 (config 2)", "hifigan", "conf/hifigan/light.yaml", 1, 1000),
+    ("mb-hifigan light +PQMF T=1000 B=32 (config 3)", "multiband-hifigan", "conf/multiband-hifigan/light.yaml", 32, 1000),
+    ("basis-melgan light T=1000 B=64 (config 4)", "basis-melgan", "conf/basis-melgan/light.yaml", 64, 1000),
+    ("hifigan large T=1000 B=64 (config 5, one GPU's share)", "hifigan", "conf/hifigan/large.yaml", 64, 1000),
+    ("hifigan light T=1000 B=16", "hifigan", "conf/hifigan/light.yaml", 16, 1000),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    for label, name, path, B, T in CONFIGS:
+        cfg = yaml.safe_load(open(path))
+        m = build_generator(name, cfg)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(name, cfg).items()})
+        m = m.to(dev).eval()
+        m.remove_weight_norm()
+        mel = torch.from_numpy(seeded_mel(T, seed=1, batch=B)).to(dev)
+        if name == "multiband-hifigan":
+            fn = lambda: m.synthesize_batch(mel)
+        elif name == "basis-melgan":
+            fn = lambda: m._samples(mel)
+        else:
+            fn = lambda: m(mel)
+        with torch.no_grad():
+            y = fn()
+            torch.cuda.synchronize()
+            _native.profile_enable(True)
+            fn()
+            torch.cuda.synchronize()
+            _native.profile_enable(False)
+            prof = _native.profile_collect(-1)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.steps
+        n = y.numel()
+        print(f"{label:52s} {n/dt/1e6:9.1f} Msamples/s  RTF@22.05k {dt/(n/22050):.2e}  {dt*1e3:9.3f} ms/step  "
+              f"{prof['flops']/dt/1e12:6.1f} TFLOP/s algorithmic", flush=True)
+        del m, mel, y
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
