@@ -116,16 +116,22 @@ __device__ __forceinline__ void dma_plan(const ConvParams& p, DmaPlan& d, int m0
     const int wtotal = p.ci_chunk * p.k * C4;
 #pragma unroll
     for (int i = 0; i < kMaxDmaX; ++i) {
-        const int idx = (wave + i * NW) * 64 + lane;
-        const int row = (int)__umulhi((unsigned)idx, p.ncol4c_magic);
-        const int c4 = idx - row * p.ncol4c;
-        d.xoff[i] = idx < xtotal ? (unsigned)(row * p.Tin + 4 * c4) * 4u : kOutOfRange;
+        d.xoff[i] = kOutOfRange;
+        if (wave + i * NW < p.nx_inst) {   // wave-uniform: unused slots cost nothing
+            const int idx = (wave + i * NW) * 64 + lane;
+            const int row = (int)__umulhi((unsigned)idx, p.ncol4c_magic);
+            const int c4 = idx - row * p.ncol4c;
+            if (idx < xtotal) d.xoff[i] = (unsigned)(row * p.Tin + 4 * c4) * 4u;
+        }
     }
 #pragma unroll
     for (int i = 0; i < kMaxDmaW; ++i) {
-        const int idx = (wave + i * NW) * 64 + lane;
-        const int row = idx / C4, c = idx % C4;
-        d.woff[i] = idx < wtotal ? (unsigned)(row * p.Mpad + m0 + 4 * c) * 4u : kOutOfRange;
+        d.woff[i] = kOutOfRange;
+        if (wave + i * NW < p.nw_inst) {
+            const int idx = (wave + i * NW) * 64 + lane;
+            const int row = idx / C4, c = idx % C4;
+            if (idx < wtotal) d.woff[i] = (unsigned)(row * p.Mpad + m0 + 4 * c) * 4u;
+        }
     }
 }
 
@@ -136,23 +142,35 @@ __device__ __forceinline__ void dma_x(const ConvParams& p, const DmaPlan& d, __a
 #pragma unroll
     for (int i = 0; i < kMaxDmaX; ++i) {
         const int j = wave + i * NW;
-        if (j * 64 < p.ci_chunk * p.ncol4c) {   // wave-uniform
+        if (j < p.nx_inst)   // wave-uniform
             dma16(rx, xs + j * 256, d.xoff[i] != kOutOfRange ? d.xoff[i] + base : kOutOfRange);
-        }
+    }
+}
+
+// Zero-padded tiles at the sequence ends, still by DMA: with 16-byte aligned rows
+// (Tin % 4 == 0) and tA a multiple of 4, every float4 lies entirely inside or
+// entirely outside [0, Tin), so padding is just one more out-of-range case.
+template <int NW>
+__device__ __forceinline__ void dma_x_zero_edge(const ConvParams& p, __amdgpu_buffer_rsrc_t rx,
+                                                float* xs, int ci0, int tA, int wave, int lane) {
+    for (int j = wave; j < p.nx_inst; j += NW) {
+        const int idx = j * 64 + lane;
+        const int row = (int)__umulhi((unsigned)idx, p.ncol4c_magic);
+        const int t = tA + 4 * (idx - row * p.ncol4c);
+        const bool ok = row < p.ci_chunk && ci0 + row < p.Cin && t >= 0 && t < p.Tin;
+        dma16(rx, xs + j * 256, ok ? (unsigned)((ci0 + row) * p.Tin + t) * 4u : kOutOfRange);
     }
 }
 
 template <int NW, int M_T>
 __device__ __forceinline__ void dma_w(const ConvParams& p, const DmaPlan& d, __amdgpu_buffer_rsrc_t rw,
                                       float* ws, int ci0, int wave) {
-    constexpr int C4 = M_T / 4;
     const unsigned base = (unsigned)(ci0 * p.k * p.Mpad) * 4u;
 #pragma unroll
     for (int i = 0; i < kMaxDmaW; ++i) {
         const int j = wave + i * NW;
-        if (j * 64 < p.ci_chunk * p.k * C4) {   // wave-uniform
+        if (j < p.nw_inst)   // wave-uniform
             dma16(rw, ws + j * 256, d.woff[i] != kOutOfRange ? d.woff[i] + base : kOutOfRange);
-        }
     }
 }
 
@@ -178,6 +196,25 @@ __device__ __forceinline__ void stage_x_edge(const ConvParams& p, float* xs, int
             }
         }
         *reinterpret_cast<float4*>(xs + idx * 4) = make_float4(e[0], e[1], e[2], e[3]);
+    }
+}
+
+// Stage one input window: DMA for interior tiles, masked DMA for zero-padded edge
+// tiles of aligned tensors; SLOW variants (reflection padding, unaligned rows) fall
+// back to the synchronous per-element path.  Returns true when the data is in flight
+// asynchronously (false: it was written synchronously by stage_x_edge).
+template <int NW, int NT, bool SLOW>
+__device__ __forceinline__ void stage_x(const ConvParams& p, const DmaPlan& d, __amdgpu_buffer_rsrc_t rx,
+                                        float* xs, int b, int ci0, int tA, int wave, int lane, int tid) {
+    if (interior(p, tA)) {
+        dma_x<NW>(p, d, rx, xs, ci0, tA, wave);
+    } else {
+        if constexpr (SLOW) {
+            if (p.vec_ok && p.pad_mode == FV_PAD_ZERO) dma_x_zero_edge<NW>(p, rx, xs, ci0, tA, wave, lane);
+            else stage_x_edge<NT>(p, xs, b, ci0, tA, tid);
+        } else {
+            dma_x_zero_edge<NW>(p, rx, xs, ci0, tA, wave, lane);
+        }
     }
 }
 
@@ -323,7 +360,7 @@ struct Frag<16> {
 // KT > 0 / DIL > 0 fix the tap count / dilation at compile time; ACT enables the
 // read-time input activation (stand-alone operator calls only).
 // ---------------------------------------------------------------------------
-template <int MF, int WM, int WN, int WK, int NR, int KT, int DIL, bool ACT>
+template <int MF, int WM, int WN, int WK, int NR, int KT, int DIL, bool ACT, bool SLOW>
 __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvParams p) {
     typedef Frag<MF> F;
     typedef typename F::acc_t acc_t;
@@ -347,12 +384,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvParams
     const int wave_m = (wave / WN) % WM, wave_n = wave % WN;
 
     // this block's run of time tiles [tile_lo, tile_hi) for its m tile
-    const int m_tiles = p.Mpad / M_T;
+    const int m_tiles = p.m_tiles;
     const int lin = xcd_remap(blockIdx.x, gridDim.x);
     const int mt = lin % m_tiles, run = lin / m_tiles;
-    const int runs = gridDim.x / m_tiles;
-    const int tile_lo = (int)(((unsigned)run * (unsigned)p.n_tiles) / (unsigned)runs);
-    const int tile_hi = (int)(((unsigned)(run + 1) * (unsigned)p.n_tiles) / (unsigned)runs);
+    const int tile_lo = run * p.tiles_per_run;
+    const int tile_hi = min(tile_lo + p.tiles_per_run, p.n_tiles);
     const int b = blockIdx.y;
     const int m0 = mt * M_T;
     const int nchunks = p.nchunks;
@@ -361,7 +397,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvParams
     const __amdgpu_buffer_rsrc_t rx =
         make_rsrc(p.x + (size_t)b * p.Cin * (size_t)p.Tin, (unsigned)p.Cin * (unsigned)p.Tin * 4u);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.wp, (unsigned)p.Cin * (unsigned)p.k * (unsigned)p.Mpad * 4u);
-    const EpilogueRsrc ersrc = epilogue_rsrc(p, b);
     DmaPlan dp;
     dma_plan<NW, M_T>(p, dp, m0, wave, lane);
     RowInfo<EN> ri[EH];
@@ -379,8 +414,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvParams
     {
         const int tA = tile_lo * N_T - p.pad - aoff;
         dma_w<NW, M_T>(p, dp, rw, ws0, 0, wave);
-        if (interior(p, tA)) dma_x<NW>(p, dp, rx, xs0, 0, tA, wave);
-        else stage_x_edge<NT>(p, xs0, b, 0, tA, tid);
+        stage_x<NW, NT, SLOW>(p, dp, rx, xs0, b, 0, tA, wave, lane, tid);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -400,9 +434,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvParams
             const int nci0 = last_chunk ? 0 : (chunk + 1) * p.ci_chunk;
             const bool more = ntile < tile_hi && !(p.dbg & 2);
             const int ntA = ntile * N_T - p.pad - aoff;
-            const bool fast = interior(p, ntA);
             if (more) {
-                if (fast) dma_x<NW>(p, dp, rx, xs0 + nxt * p.xbuf, nci0, ntA, wave);
+                // (a SLOW variant's per-element path writes LDS synchronously here: the
+                //  buffer it fills was last read one stage ago, before a barrier)
+                stage_x<NW, NT, SLOW>(p, dp, rx, xs0 + nxt * p.xbuf, b, nci0, ntA, wave, lane, tid);
                 if (nchunks > 1) dma_w<NW, M_T>(p, dp, rw, ws0 + nxt * p.wbuf, nci0, wave);
             }
             // ---- matrix work on the current buffers ----
@@ -439,7 +474,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvParams
                     }
                 }
             }
-            if (more && !fast) stage_x_edge<NT>(p, xs0 + nxt * p.xbuf, b, nci0, ntA, tid);
             if (last_chunk) {
                 // ---- tile finished: (split-K reduce and) fused epilogue ----
                 if constexpr (WK > 1) {
@@ -466,6 +500,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvParams
                     }
                 }
                 if ((WK == 1 || wk == 0) && !(p.dbg & 1)) {
+                    const EpilogueRsrc ersrc = epilogue_rsrc(p, b);   // built here: no SGPRs held across the MFMA loop
 #pragma unroll
                     for (int r = 0; r < NR; ++r) {
                         const int q = tile * N_T + wave_n * (MF * NR) + r * MF + lm;
@@ -521,8 +556,7 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(ConvParams p) {
     const float slope = p.pre_slope;
     for (int ci0 = 0; ci0 < p.Cin; ci0 += p.ci_chunk) {
         dma_w<NW, 16>(p, dp, rw, ws, ci0, wave);
-        if (interior(p, tA)) dma_x<NW>(p, dp, rx, xs, ci0, tA, wave);
-        else stage_x_edge<NT>(p, xs, b, ci0, tA, tid);
+        stage_x<NW, NT, true>(p, dp, rx, xs, b, ci0, tA, wave, lane, tid);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const float* pb = xs + aoff + tid;
@@ -599,6 +633,8 @@ size_t plan_staging(ConvParams& p, const Geometry& g, int k_rows_target) {
     }
     p.ci_chunk = best;
     p.nchunks = (p.Cin + best - 1) / best;
+    p.nx_inst = round_up(best * p.ncol4c, 64) / 64;
+    p.nw_inst = round_up(best * p.k * g.m_t() / 4, 64) / 64;
     p.xbuf = round_up(best * p.ncol4c, 64) * 4;
     p.wbuf = round_up(best * p.k * g.m_t() / 4, 64) * 4;
     size_t floats = (size_t)2 * (p.xbuf + p.wbuf);
@@ -610,9 +646,9 @@ size_t plan_staging(ConvParams& p, const Geometry& g, int k_rows_target) {
 template <int MF, int WM, int WN, int WK, int NR>
 int launch_geom(const ConvParams& p, size_t lds, int grid_x, hipStream_t s) {
     dim3 grid(grid_x, p.B), block(64 * WM * WN * WK);
-#define FV_LAUNCH(KT, DIL, ACT)                                                               \
+#define FV_LAUNCH(KT, DIL, ACT, SLOW)                                                         \
     do {                                                                                      \
-        auto kern = conv_mfma_kernel<MF, WM, WN, WK, NR, KT, DIL, ACT>;                       \
+        auto kern = conv_mfma_kernel<MF, WM, WN, WK, NR, KT, DIL, ACT, SLOW>;                 \
         if (lds > 64 * 1024)                                                                  \
             FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -620,20 +656,29 @@ int launch_geom(const ConvParams& p, size_t lds, int grid_x, hipStream_t s) {
     } while (0)
 #define FV_LAUNCH_DIL(KT)                                  \
     switch (p.dil) {                                       \
-        case 1: FV_LAUNCH(KT, 1, false); break;            \
-        case 3: FV_LAUNCH(KT, 3, false); break;            \
-        case 5: FV_LAUNCH(KT, 5, false); break;            \
-        default: FV_LAUNCH(KT, 0, false); break;           \
+        case 1: FV_LAUNCH(KT, 1, false, false); break;     \
+        case 3: FV_LAUNCH(KT, 3, false, false); break;     \
+        case 5: FV_LAUNCH(KT, 5, false, false); break;     \
+        default: FV_LAUNCH(KT, 0, false, false); break;    \
     }
+    // SLOW variants carry the per-element staging path (reflection padding, rows
+    // that are not 16-byte aligned); read-time activation exists only there too
+    const bool slow = p.pad_mode == FV_PAD_REFLECT || !p.vec_ok;
     if (p.pre_slope != 1.f) {
-        FV_LAUNCH(0, 0, true);            // read-time activation: generic variant only
+        FV_LAUNCH(0, 0, true, true);
+    } else if (slow) {
+        switch (p.k) {
+            case 3: FV_LAUNCH(3, 0, false, true); break;
+            case 7: FV_LAUNCH(7, 0, false, true); break;
+            default: FV_LAUNCH(0, 0, false, true); break;
+        }
     } else {
         switch (p.k) {
-            case 1: FV_LAUNCH(1, 1, false); break;
+            case 1: FV_LAUNCH(1, 1, false, false); break;
             case 3: FV_LAUNCH_DIL(3); break;
             case 7: FV_LAUNCH_DIL(7); break;
             case 11: FV_LAUNCH_DIL(11); break;
-            default: FV_LAUNCH(0, 0, false); break;
+            default: FV_LAUNCH(0, 0, false, false); break;
         }
     }
 #undef FV_LAUNCH_DIL
@@ -698,6 +743,8 @@ int launch_conv(ConvParams p, hipStream_t s) {
                round_up((c + 1) * p.ncol4c, 64) / 64 <= kMaxDmaX * 4 && round_up((c + 1) * p.k * 4, 64) / 64 <= kMaxDmaW * 4)
             ++c;
         p.nchunks = (p.Cin + c - 1) / c;
+        p.nx_inst = round_up(c * p.ncol4c, 64) / 64;
+        p.nw_inst = round_up(c * p.k * 4, 64) / 64;
         p.ci_chunk = c;
         p.xbuf = round_up(c * p.ncol4c, 64) * 4;
         p.wbuf = round_up(c * p.k * 4, 64) * 4;
@@ -742,6 +789,9 @@ int launch_conv(ConvParams p, hipStream_t s) {
         int runs = p.n_tiles;
         const long per_batch_cap = cap / ((long)p.B * m_tiles) > 0 ? cap / ((long)p.B * m_tiles) : 1;
         if (runs > per_batch_cap) runs = (int)per_batch_cap;
+        p.m_tiles = m_tiles;
+        p.tiles_per_run = (p.n_tiles + runs - 1) / runs;
+        runs = (p.n_tiles + p.tiles_per_run - 1) / p.tiles_per_run;   // no empty runs
         rc = launch_shape(shape, p, lds, runs * m_tiles, s);
     }
     profile_end(s, kind, flops, bytes);

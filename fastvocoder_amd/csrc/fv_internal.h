@@ -70,6 +70,8 @@ struct ConvParams {
     unsigned ncol4c_magic;  // ceil(2^32 / ncol4c): idx / ncol4c == umulhi(idx, magic)
     int xbuf, wbuf; // floats per LDS buffer of the x / w image (multiples of 256)
     int n_tiles;    // time tiles per batch item
+    int m_tiles, tiles_per_run;   // row tiles; consecutive time tiles per block
+    int nx_inst, nw_inst;         // 64-lane DMA instructions per stage for the x / w image
     int red_off;    // float offset of the split-K reduction area in LDS
     int vec_ok;     // rows are 16-byte aligned: float4 global loads allowed
     int dbg;        // ablation switches (FV_DBG, tuning only): 1 no epilogue, 2 no restaging, 4 no MFMA
