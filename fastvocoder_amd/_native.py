@@ -37,7 +37,10 @@ def build(force=False, verbose=False):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-value", "-Wno-comment", "-Wno-pass-failed"] + srcs + ["-o", LIB_PATH]
+           "-Wno-unused-value", "-Wno-comment", "-Wno-pass-failed",
+           # MFMA results straight in VGPRs (unified register file on gfx950): no
+           # v_accvgpr_read/write pairs around every stage -- VALU work costs MFMA time
+           "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + srcs + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
