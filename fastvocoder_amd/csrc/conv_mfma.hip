@@ -55,7 +55,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr unsigned kOutOfRange = 0xFFFFFFF0u;   // byte offset no descriptor covers -> reads 0
+// Out-of-range marker for buffer offsets.  Descriptors never cover more than 1 GiB
+// (host-checked), so any offset with bit 30 or 31 set is out of range (loads give 0,
+// stores are dropped).  The marker is ADDITIVE: marker + valid offset and marker +
+// marker stay out of range, so masked lanes need neither a compare nor a select --
+// hoisted per-lane predicates would otherwise pile up as 64-bit SGPR masks and spill.
+constexpr unsigned kOutOfRange = 0x40000000u;
 
 // leaky-ReLU / ReLU / identity for 0 <= slope <= 1 as max(x, slope*x): bitwise
 // equal to x >= 0 ? x : slope*x, branch-free (slope is wave-uniform)
@@ -143,7 +148,7 @@ __device__ __forceinline__ void dma_x(const ConvParams& p, const DmaPlan& d, __a
     for (int i = 0; i < kMaxDmaX; ++i) {
         const int j = wave + i * NW;
         if (j < p.nx_inst)   // wave-uniform
-            dma16(rx, xs + j * 256, d.xoff[i] != kOutOfRange ? d.xoff[i] + base : kOutOfRange);
+            dma16(rx, xs + j * 256, d.xoff[i] + base);
     }
 }
 
@@ -170,7 +175,7 @@ __device__ __forceinline__ void dma_w(const ConvParams& p, const DmaPlan& d, __a
     for (int i = 0; i < kMaxDmaW; ++i) {
         const int j = wave + i * NW;
         if (j < p.nw_inst)   // wave-uniform
-            dma16(rw, ws + j * 256, d.woff[i] != kOutOfRange ? d.woff[i] + base : kOutOfRange);
+            dma16(rw, ws + j * 256, d.woff[i] + base);
     }
 }
 
@@ -268,14 +273,15 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, const Epilog
                                                const RowInfo<N>& ri, const int (&m)[N], int q,
                                                float (&v)[N]) {
     unsigned off[N];
-    const bool qok = q < p.Tq;
-    const unsigned qoff = (unsigned)(q * p.ups) * 4u;
+    // additive masking (see kOutOfRange): no per-element predicate
+    const unsigned qoff = q < p.Tq ? (unsigned)(q * p.ups) * 4u : kOutOfRange;
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        bool ok = qok && ri.off[i] != kOutOfRange;
+    for (int i = 0; i < N; ++i) off[i] = ri.off[i] + qoff;
+    if (p.ups != 1) {
         // a transposed conv's last column can run past Tout (Tout need not be a multiple of ups)
-        if (p.ups != 1) ok = ok && q * p.ups + m[i] % p.ups < p.Tout;
-        off[i] = ok ? ri.off[i] + qoff : kOutOfRange;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (q * p.ups + m[i] % p.ups >= p.Tout) off[i] = kOutOfRange;
     }
     float rv[N], av[N];
 #pragma unroll
@@ -723,10 +729,11 @@ int launch_conv(ConvParams p, hipStream_t s) {
                     p.pad, p.Tin);
     if (p.pre_slope < 0.f || p.pre_slope > 1.f)
         return fail(FV_ERR_INVALID_ARG, "conv: input activation slope %g outside [0, 1]", p.pre_slope);
-    if ((double)p.Cin * p.Tin * 4.0 >= 2147483648.0 || (double)p.Cin * p.k * p.Mpad * 4.0 >= 2147483648.0 ||
-        (double)p.Cout * p.Tout * 4.0 >= 2147483648.0)
-        return fail(FV_ERR_UNSUPPORTED, "conv: one utterance's tensor (%d x %d floats) exceeds the 2 GiB "
-                    "buffer-descriptor range; split the utterance", p.Cin, p.Tin);
+    if ((double)p.Cin * p.Tin * 4.0 >= 1073741824.0 || (double)p.Cin * p.k * p.Mpad * 4.0 >= 1073741824.0 ||
+        (double)p.Cout * p.Tout * 4.0 >= 1073741824.0)
+        return fail(FV_ERR_UNSUPPORTED, "conv: one utterance's tensor (%d x %d or %d x %d floats) exceeds the "
+                    "1 GiB buffer-descriptor range of the kernels; split the utterance", p.Cin, p.Tin,
+                    p.Cout, p.Tout);
     p.vec_ok = (p.Tin % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
     const double flops = 2.0 * p.B * (double)p.M * p.Tq * p.Cin * p.k;
     const double bytes = 4.0 * ((double)p.B * p.Cin * p.Tin + (double)p.B * p.Cout * p.Tout *
