@@ -13,6 +13,8 @@ Every activation, bias, residual add, the MRF sum and its /num_kernels, and
 tanh are epilogue/prologue work of the conv kernels: the whole forward is
 ``num_convs`` launches (78 for the shipped 4-stage configs) and nothing else.
 """
+import os
+
 import torch
 
 from .engine import NativeModule, POST_TANH, SLOT_IN, SLOT_NONE, SLOT_OUT, weight_norm  # noqa: F401
@@ -65,11 +67,13 @@ class _HiFiGANBase(NativeModule):
         """mel (SLOT_IN) -> tanh(conv_post(...)) in ``dst``."""
         x, up, acc = pb.tmp(), pb.tmp(), pb.tmp()
         nk = self.num_kernels
-        # the nk ResBlocks of a stage are independent given the upsampled input: each
-        # gets its own concurrency lane (stream) and scratch, so that at batch 1, where
-        # one conv cannot fill 256 CUs, three of them run side by side
-        lanes = min(nk, 3)
-        scratch = [[pb.tmp(), pb.tmp(), pb.tmp()] for _ in range(lanes)]
+        # The nk ResBlocks of a stage are independent given the upsampled input, and at
+        # batch 1 one conv cannot fill 256 CUs: each block gets its own concurrency lane
+        # (stream) and scratch.  Measured on MI355X (HiFi-GAN light, B=1): 3 lanes 1.86 ms,
+        # 2 lanes balanced by kernel size 1.99 ms, 1 lane 2.07 ms per forward.
+        n_lanes = max(1, min(nk, 3, int(os.environ.get("FV_LANES", "3"))))
+        lane_of = [j % n_lanes for j in range(nk)]
+        scratch = [[pb.tmp(), pb.tmp(), pb.tmp()] for _ in range(n_lanes)]
         pb.conv(self.conv_pre, SLOT_IN, x)
         for i in range(self.num_upsamples):
             if isinstance(self.ups[i], UpsampleLayer):
@@ -81,9 +85,9 @@ class _HiFiGANBase(NativeModule):
                 last = j == nk - 1
                 # running sum in `acc` in resblock order, mean folded into the
                 # last block's final epilogue (reference hifigan.py:97-103)
-                pb.lane = j % lanes
+                pb.lane = lane_of[j]
                 self.resblocks[i * nk + j].emit(
-                    pb, up, x if last else acc, scratch[j % lanes],
+                    pb, up, x if last else acc, scratch[lane_of[j]],
                     acc=acc if j > 0 else SLOT_NONE,
                     out_div=float(nk) if last else 1.0)
             pb.lane = 0
