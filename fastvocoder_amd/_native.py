@@ -19,7 +19,7 @@ SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip"]
 PAD_ZERO, PAD_REFLECT = 0, 1
 POST_NONE, POST_TANH, POST_RELU = 0, 1, 2
 SLOT_NONE, SLOT_IN, SLOT_OUT, SLOT_TMP0, MAX_SLOTS = -1, 0, 1, 2, 32
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class NativeError(RuntimeError):
@@ -70,17 +70,18 @@ def lib():
     L.fv_packed_conv_transpose1d_floats.restype = i64
     L.fv_pack_conv1d_weight.argtypes = [vp, vp, i, i, i, vp]
     L.fv_pack_conv_transpose1d_weight.argtypes = [vp, vp, i, i, i, i, i, vp]
-    L.fv_conv1d_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, f, i, f, vp]
+    L.fv_conv1d_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, f, i, f, vp]
     L.fv_conv_transpose1d_fused.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, i, f, vp]
     L.fv_pqmf_synthesis.argtypes = [vp, vp, vp, i, i, i, i, vp]
     L.fv_plan_create.argtypes = [i]
     L.fv_plan_create.restype = vp
     L.fv_plan_destroy.argtypes = [vp]
     L.fv_plan_destroy.restype = None
-    L.fv_plan_add_conv1d.argtypes = [vp, i, i, i, i, i, vp, vp, i, i, i, i, i, i, f, f, i, f]
+    L.fv_plan_add_conv1d.argtypes = [vp, i, i, i, i, i, i, vp, vp, i, i, i, i, i, i, f, f, i, f]
     L.fv_plan_add_conv_transpose1d.argtypes = [vp, i, i, i, vp, vp, i, i, i, i, i, i, f, i, f]
     L.fv_plan_add_pqmf_synthesis.argtypes = [vp, i, i, vp, i, i]
     L.fv_plan_set_lane.argtypes = [vp, i]
+    L.fv_plan_set_group.argtypes = [vp, i]
     L.fv_plan_output_shape.argtypes = [vp, i, ctypes.POINTER(i), ctypes.POINTER(i64)]
     L.fv_plan_workspace_bytes.argtypes = [vp, i, i]
     L.fv_plan_workspace_bytes.restype = i64
@@ -158,14 +159,15 @@ def pack_conv_transpose1d(w, stride, pad):
 
 def conv1d_fused(x, packed, bias, cout, k, dil=1, pad=0, pad_mode=PAD_ZERO, pre_slope=1.0,
                  res=None, acc_in=None, out_div=1.0, post=POST_NONE, out=None, out_act=None,
-                 act_slope=1.0):
+                 act_slope=1.0, acc_in2=None):
     """One fused conv launch; ``out_act`` (optional) receives lrelu(out, act_slope)."""
     B, cin, T = x.shape
     tout = T + 2 * pad - dil * (k - 1)
     if out is None:
         out = torch.empty((B, cout, tout), dtype=torch.float32, device=x.device)
     check(lib().fv_conv1d_fused(_ptr(x, "x"), _ptr(packed, "packed"), _ptr(bias, "bias", True),
-                                _ptr(res, "res", True), _ptr(acc_in, "acc_in", True), _ptr(out, "out"),
+                                _ptr(res, "res", True), _ptr(acc_in, "acc_in", True),
+                                _ptr(acc_in2, "acc_in2", True), _ptr(out, "out"),
                                 _ptr(out_act, "out_act", True), B, cin, cout, T, k, dil, pad, pad_mode,
                                 float(pre_slope), float(out_div), post, float(act_slope), _stream()))
     return out
@@ -218,11 +220,11 @@ class Plan:
 
     def add_conv1d(self, x, y, packed, bias, cin, cout, k, dil=1, pad=0, pad_mode=PAD_ZERO,
                    pre_slope=1.0, res=SLOT_NONE, acc=SLOT_NONE, out_div=1.0, post=POST_NONE,
-                   y_act=SLOT_NONE, act_slope=1.0):
+                   y_act=SLOT_NONE, act_slope=1.0, acc2=SLOT_NONE):
         self.keep(packed)
         if bias is not None:
             self.keep(bias)
-        check(lib().fv_plan_add_conv1d(self._h, x, y, y_act, res, acc, _ptr(packed, "packed"),
+        check(lib().fv_plan_add_conv1d(self._h, x, y, y_act, res, acc, acc2, _ptr(packed, "packed"),
                                        _ptr(bias, "bias", True), cin, cout, k, dil, pad, pad_mode,
                                        float(pre_slope), float(out_div), post, float(act_slope)))
 
@@ -238,6 +240,9 @@ class Plan:
 
     def set_lane(self, lane):
         check(lib().fv_plan_set_lane(self._h, lane))
+
+    def set_group(self, group):
+        check(lib().fv_plan_set_group(self._h, group))
 
     def add_pqmf_synthesis(self, x, y, h):
         """h [S, ntaps] contiguous fp32 device tensor."""

@@ -121,7 +121,8 @@ enum OpType { OP_CONV = 0, OP_CONVT = 1, OP_PQMF = 2 };
 
 struct Op {
     int type;
-    int x, y, res, acc, y2;
+    int x, y, res, acc, y2, acc2;
+    int group;     // ops with the same non-zero id are mutually independent: one grouped launch
     const float* wp;
     const float* bias;
     int Cin, Cout, k, dil, pad, pad_mode, stride, out_pad;
@@ -149,6 +150,7 @@ struct fv_plan {
     int in_channels;
     std::vector<fv::Op> ops;
     int cur_lane = 0;
+    int cur_group = 0;
     int n_lanes = 1;
     bool compiled = false;
     // lanes 1.. run on plan-owned streams; one event per signalling op + fork/join events
@@ -191,8 +193,8 @@ static int infer(const fv_plan* plan, int B, int T, Shape* sh, int64_t* slot_ele
         const int64_t Tout = conv_out_len(o, sh[o.x].T);
         if (Tout <= 0) return fail(FV_ERR_INVALID_ARG, "op %zu: empty output (T=%lld)", n, (long long)sh[o.x].T);
         const int Cout = o.type == OP_PQMF ? 1 : o.Cout;
-        const int aux[2] = {o.res, o.acc};
-        for (int a = 0; a < 2; ++a) {
+        const int aux[3] = {o.res, o.acc, o.acc2};
+        for (int a = 0; a < 3; ++a) {
             if (aux[a] == FV_SLOT_NONE) continue;
             if (!sh[aux[a]].set || sh[aux[a]].C != Cout || sh[aux[a]].T != Tout)
                 return fail(FV_ERR_INVALID_ARG, "op %zu: residual/accumulator slot %d shape mismatch", n, aux[a]);
@@ -211,15 +213,15 @@ static int infer(const fv_plan* plan, int B, int T, Shape* sh, int64_t* slot_ele
     return 0;
 }
 
-static int run_op(const Op& o, const float* x, float* y, float* y2, const float* res, const float* acc,
-                  int B, int64_t Tin, hipStream_t s) {
-    if (o.type == OP_PQMF) return launch_pqmf(x, o.wp, y, B, o.Cin, o.k, (int)Tin, s);
+static ConvParams make_params(const Op& o, const float* x, float* y, float* y2, const float* res,
+                              const float* acc, const float* acc2, int B, int64_t Tin) {
     ConvParams p = {};
     p.x = x;
     p.wp = o.wp;
     p.bias = o.bias;
     p.res = res;
     p.acc_in = acc;
+    p.acc_in2 = acc2;
     p.y = y;
     p.y_act = y2;
     p.act_slope = o.act_slope;
@@ -250,7 +252,13 @@ static int run_op(const Op& o, const float* x, float* y, float* y2, const float*
         p.Tq = (p.Tout + o.stride - 1) / o.stride;
     }
     p.Mpad = pad_rows(p.M);
-    return launch_conv(p, s);
+    return p;
+}
+
+static int run_op(const Op& o, const float* x, float* y, float* y2, const float* res, const float* acc,
+                  const float* acc2, int B, int64_t Tin, hipStream_t s) {
+    if (o.type == OP_PQMF) return launch_pqmf(x, o.wp, y, B, o.Cin, o.k, (int)Tin, s);
+    return launch_conv(make_params(o, x, y, y2, res, acc, acc2, B, Tin), s);
 }
 
 // Cross-lane dependencies from the slots each op reads and writes (RAW, WAR, WAW):
@@ -276,7 +284,7 @@ static int compile_lanes(fv_plan* plan) {
             if (j >= 0 && plan->ops[j].lane != o.lane && j > latest[plan->ops[j].lane])
                 latest[plan->ops[j].lane] = j;
         };
-        const int reads[3] = {o.x, o.res, o.acc};
+        const int reads[4] = {o.x, o.res, o.acc, o.acc2};
         const int writes[2] = {o.y, o.y2};
         for (int s : reads)
             if (s != FV_SLOT_NONE) need(last_write[s]);
@@ -306,7 +314,15 @@ static int compile_lanes(fv_plan* plan) {
             if (plan->ops[i].signal) FV_HIP(hipEventCreateWithFlags(&plan->op_event[i], hipEventDisableTiming));
         if (!plan->fork_event) FV_HIP(hipEventCreateWithFlags(&plan->fork_event, hipEventDisableTiming));
         for (int l = 1; l < plan->n_lanes; ++l) {
-            if (!plan->lane_stream[l]) FV_HIP(hipStreamCreateWithFlags(&plan->lane_stream[l], hipStreamNonBlocking));
+            if (!plan->lane_stream[l]) {
+                // FV_LANE_PRIO=1: the highest lane (the ResBlock with the largest kernel, i.e.
+                // the critical chain of an MRF stage) gets the greatest stream priority
+                int lo = 0, hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+                const bool prio = getenv("FV_LANE_PRIO") && atoi(getenv("FV_LANE_PRIO")) != 0;
+                const int pr = (prio && l == plan->n_lanes - 1) ? hi : lo;
+                FV_HIP(hipStreamCreateWithPriority(&plan->lane_stream[l], hipStreamNonBlocking, pr));
+            }
             if (!plan->join_event[l]) FV_HIP(hipEventCreateWithFlags(&plan->join_event[l], hipEventDisableTiming));
         }
     }
@@ -374,9 +390,9 @@ int fv_pack_conv_transpose1d_weight(const float* w, float* packed, int Cin, int 
 }
 
 int fv_conv1d_fused(const float* x, const float* packed, const float* bias, const float* res,
-                    const float* acc_in, float* y, float* y_act, int B, int Cin, int Cout, int Tin,
-                    int k, int dil, int pad, int pad_mode, float pre_slope, float out_div, int post,
-                    float act_slope, void* stream) {
+                    const float* acc_in, const float* acc_in2, float* y, float* y_act, int B, int Cin,
+                    int Cout, int Tin, int k, int dil, int pad, int pad_mode, float pre_slope,
+                    float out_div, int post, float act_slope, void* stream) {
     if (int rc = check_conv_args(Cin, Cout, k, dil)) return rc;
     if (!x || !packed || !y) return fail(FV_ERR_INVALID_ARG, "conv1d: null tensor");
     if (x == y || x == y_act || (y_act && y_act == y))
@@ -396,7 +412,7 @@ int fv_conv1d_fused(const float* x, const float* packed, const float* bias, cons
     o.out_div = out_div;
     o.post = post;
     if (conv_out_len(o, Tin) <= 0) return fail(FV_ERR_INVALID_ARG, "conv1d: empty output");
-    return run_op(o, x, y, y_act, res, acc_in, B, Tin, (hipStream_t)stream);
+    return run_op(o, x, y, y_act, res, acc_in, acc_in2, B, Tin, (hipStream_t)stream);
 }
 
 int fv_conv_transpose1d_fused(const float* x, const float* packed, const float* bias, float* y,
@@ -424,7 +440,7 @@ int fv_conv_transpose1d_fused(const float* x, const float* packed, const float* 
     o.act_slope = act_slope;
     o.post = post;
     if (conv_out_len(o, Tin) <= 0) return fail(FV_ERR_INVALID_ARG, "conv_transpose1d: empty output");
-    return run_op(o, x, y, y_act, nullptr, nullptr, B, Tin, (hipStream_t)stream);
+    return run_op(o, x, y, y_act, nullptr, nullptr, nullptr, B, Tin, (hipStream_t)stream);
 }
 
 int fv_pqmf_synthesis(const float* x, const float* h, float* y, int B, int S, int ntaps, int Tsub,
@@ -449,9 +465,9 @@ static int check_slot(int s, bool allow_none) {
 }
 
 int fv_plan_add_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, int res_slot,
-                       int acc_slot, const float* packed, const float* bias, int Cin, int Cout, int k,
-                       int dil, int pad, int pad_mode, float pre_slope, float out_div, int post,
-                       float act_slope) {
+                       int acc_slot, int acc2_slot, const float* packed, const float* bias, int Cin,
+                       int Cout, int k, int dil, int pad, int pad_mode, float pre_slope, float out_div,
+                       int post, float act_slope) {
     if (!plan || !packed) return fail(FV_ERR_INVALID_ARG, "plan_add_conv1d: null");
     if (int rc = check_conv_args(Cin, Cout, k, dil)) return rc;
     if (int rc = check_slot(x_slot, false)) return rc;
@@ -459,6 +475,7 @@ int fv_plan_add_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, 
     if (int rc = check_slot(res_slot, true)) return rc;
     if (int rc = check_slot(acc_slot, true)) return rc;
     if (int rc = check_slot(y_act_slot, true)) return rc;
+    if (int rc = check_slot(acc2_slot, true)) return rc;
     if (y_slot == FV_SLOT_IN || y_act_slot == FV_SLOT_IN)
         return fail(FV_ERR_INVALID_ARG, "plan: the input slot is read-only");
     Op o = {};
@@ -469,6 +486,8 @@ int fv_plan_add_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, 
     o.act_slope = act_slope;
     o.res = res_slot;
     o.acc = acc_slot;
+    o.acc2 = acc2_slot;
+    o.group = plan->cur_group;
     o.wp = packed;
     o.bias = bias;
     o.Cin = Cin;
@@ -507,6 +526,7 @@ int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot, int y_
     o.act_slope = act_slope;
     o.res = FV_SLOT_NONE;
     o.acc = FV_SLOT_NONE;
+    o.acc2 = FV_SLOT_NONE;
     o.wp = packed;
     o.bias = bias;
     o.Cin = Cin;
@@ -537,6 +557,7 @@ int fv_plan_add_pqmf_synthesis(fv_plan_t* plan, int x_slot, int y_slot, const fl
     o.y2 = FV_SLOT_NONE;
     o.res = FV_SLOT_NONE;
     o.acc = FV_SLOT_NONE;
+    o.acc2 = FV_SLOT_NONE;
     o.wp = h;
     o.Cin = S;
     o.Cout = 1;
@@ -544,6 +565,12 @@ int fv_plan_add_pqmf_synthesis(fv_plan_t* plan, int x_slot, int y_slot, const fl
     o.lane = plan->cur_lane;
     plan->compiled = false;
     plan->ops.push_back(o);
+    return 0;
+}
+
+int fv_plan_set_group(fv_plan_t* plan, int group) {
+    if (!plan || group < 0) return fail(FV_ERR_INVALID_ARG, "plan_set_group: group %d", group);
+    plan->cur_group = group;
     return 0;
 }
 
@@ -607,15 +634,45 @@ int fv_plan_run(fv_plan_t* plan, int B, int T, const float* in, float* out, void
     sh[FV_SLOT_IN] = {plan->in_channels, T, true};
     for (size_t n = 0; n < plan->ops.size(); ++n) {
         const Op& o = plan->ops[n];
+        // ---- a group of mutually independent convs: one launch when possible ----
+        if (o.group != 0 && o.type == OP_CONV) {
+            size_t m = n;
+            ConvParams gp[3];
+            int cnt = 0;
+            while (m < plan->ops.size() && plan->ops[m].group == o.group && plan->ops[m].type == OP_CONV &&
+                   plan->ops[m].lane == o.lane && cnt < 3) {
+                const Op& q = plan->ops[m];
+                gp[cnt++] = make_params(q, base[q.x], base[q.y], q.y2 == FV_SLOT_NONE ? nullptr : base[q.y2],
+                                        q.res == FV_SLOT_NONE ? nullptr : base[q.res],
+                                        q.acc == FV_SLOT_NONE ? nullptr : base[q.acc],
+                                        q.acc2 == FV_SLOT_NONE ? nullptr : base[q.acc2], B, sh[q.x].T);
+                ++m;
+            }
+            hipStream_t s = lanes[o.lane];
+            if (multi)
+                for (size_t q = n; q < m; ++q)
+                    for (int d = 0; d < plan->ops[q].ndeps; ++d)
+                        FV_HIP(hipStreamWaitEvent(s, plan->op_event[plan->ops[q].deps[d]], 0));
+            if (int rc = launch_conv_group(gp, cnt, s)) return rc;
+            for (size_t q = n; q < m; ++q) {
+                const Op& qo = plan->ops[q];
+                if (multi && qo.signal) FV_HIP(hipEventRecord(plan->op_event[q], s));
+                sh[qo.y] = {qo.Cout, conv_out_len(qo, sh[qo.x].T), true};
+                if (qo.y2 != FV_SLOT_NONE) sh[qo.y2] = sh[qo.y];
+            }
+            n = m - 1;
+            continue;
+        }
         const int64_t Tin = sh[o.x].T;
         const int64_t Tout = conv_out_len(o, Tin);
         const float* res = o.res == FV_SLOT_NONE ? nullptr : base[o.res];
         const float* acc = o.acc == FV_SLOT_NONE ? nullptr : base[o.acc];
+        const float* acc2 = o.acc2 == FV_SLOT_NONE ? nullptr : base[o.acc2];
         float* y2 = o.y2 == FV_SLOT_NONE ? nullptr : base[o.y2];
         hipStream_t s = lanes[o.lane];
         if (multi)
             for (int d = 0; d < o.ndeps; ++d) FV_HIP(hipStreamWaitEvent(s, plan->op_event[o.deps[d]], 0));
-        if (int rc = run_op(o, base[o.x], base[o.y], y2, res, acc, B, Tin, s)) return rc;
+        if (int rc = run_op(o, base[o.x], base[o.y], y2, res, acc, acc2, B, Tin, s)) return rc;
         if (multi && o.signal) FV_HIP(hipEventRecord(plan->op_event[n], s));
         sh[o.y] = {o.type == OP_PQMF ? 1 : o.Cout, Tout, true};
         if (o.y2 != FV_SLOT_NONE) sh[o.y2] = sh[o.y];

@@ -228,7 +228,7 @@ __device__ __forceinline__ void stage_x(const ConvParams& p, const DmaPlan& d, _
 // gets an out-of-range offset (loads 0, store dropped), so the loads of a tile
 // issue back to back instead of one s_waitcnt vmcnt(0) per element.
 struct EpilogueRsrc {
-    __amdgpu_buffer_rsrc_t y, y2, res, acc;
+    __amdgpu_buffer_rsrc_t y, y2, res, acc, acc2;
 };
 
 __device__ __forceinline__ EpilogueRsrc epilogue_rsrc(const ConvParams& p, int b) {
@@ -239,6 +239,7 @@ __device__ __forceinline__ EpilogueRsrc epilogue_rsrc(const ConvParams& p, int b
     e.y2 = make_rsrc(p.y_act ? p.y_act + boff : p.y + boff, bytes);
     e.res = make_rsrc(p.res ? p.res + boff : p.y + boff, bytes);
     e.acc = make_rsrc(p.acc_in ? p.acc_in + boff : p.y + boff, bytes);
+    e.acc2 = make_rsrc(p.acc_in2 ? p.acc_in2 + boff : p.y + boff, bytes);
     return e;
 }
 
@@ -266,7 +267,7 @@ __device__ __forceinline__ void row_info(const ConvParams& p, const int (&m)[N],
 }
 
 // N output elements of one thread at GEMM column q:
-//   y = post( ( acc_in + ( (v + bias) + res ) ) / out_div );   y_act = act(y, act_slope)
+//   y = post( ( (acc_in + acc_in2) + ( (v + bias) + res ) ) / out_div );   y_act = act(y, act_slope)
 // all uniform switches are hoisted; loads are issued as one batch.
 template <int N>
 __device__ __forceinline__ void epilogue_store(const ConvParams& p, const EpilogueRsrc& e,
@@ -293,6 +294,13 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, const Epilog
     if (p.acc_in) {
 #pragma unroll
         for (int i = 0; i < N; ++i) av[i] = buffer_load1(e.acc, off[i]);
+    }
+    if (p.acc_in2) {   // second running-sum input: (acc_in + acc_in2) first, like xs = r0; xs += r1
+        float a2[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) a2[i] = buffer_load1(e.acc2, off[i]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) av[i] = av[i] + a2[i];
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = av[i] + ((v[i] + ri.bias[i]) + rv[i]);
@@ -367,7 +375,8 @@ struct Frag<16> {
 // read-time input activation (stand-alone operator calls only).
 // ---------------------------------------------------------------------------
 template <int MF, int WM, int WN, int WK, int NR, int KT, int DIL, bool ACT, bool SLOW>
-__global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvParams p) {
+__device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x, const int grid_x,
+                                          const int b) {
     typedef Frag<MF> F;
     typedef typename F::acc_t acc_t;
     constexpr int NW = WM * WN * WK;
@@ -391,11 +400,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvParams
 
     // this block's run of time tiles [tile_lo, tile_hi) for its m tile
     const int m_tiles = p.m_tiles;
-    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int lin = xcd_remap(block_x, grid_x);
     const int mt = lin % m_tiles, run = lin / m_tiles;
     const int tile_lo = run * p.tiles_per_run;
     const int tile_hi = min(tile_lo + p.tiles_per_run, p.n_tiles);
-    const int b = blockIdx.y;
     const int m0 = mt * M_T;
     const int nchunks = p.nchunks;
     if (tile_hi <= tile_lo) return;
@@ -530,6 +538,31 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvParams
             cur = nxt;
         }
     }
+}
+
+template <int MF, int WM, int WN, int WK, int NR, int KT, int DIL, bool ACT, bool SLOW>
+__global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvParams p) {
+    conv_body<MF, WM, WN, WK, NR, KT, DIL, ACT, SLOW>(p, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+// Grouped launch: the convolutions at the same position of the three ResBlocks of
+// an MRF stage (kernel sizes 11 / 7 / 3, everything else equal: hifigan.py:97-103,
+// modules.py:223-230) are independent, and at batch 1 none of them fills 256 CUs
+// alone.  One launch runs all three -- blockIdx.z picks the problem, largest
+// kernel first -- so the block scheduler balances them, with one kernel boundary
+// instead of three and no cross-stream hand-offs.
+struct GroupParams {
+    ConvParams p[3];   // sorted k = 11, 7, 3
+    int grid_x[3];
+};
+
+template <int MF, int WM, int WN, int WK, int NR, int DIL>
+__global__ __launch_bounds__(64 * WM * WN * WK) void conv_group3_kernel(GroupParams gp) {
+    const int g = blockIdx.z;
+    if ((int)blockIdx.x >= gp.grid_x[g]) return;
+    if (g == 0) conv_body<MF, WM, WN, WK, NR, 11, DIL, false, false>(gp.p[0], blockIdx.x, gp.grid_x[0], blockIdx.y);
+    else if (g == 1) conv_body<MF, WM, WN, WK, NR, 7, DIL, false, false>(gp.p[1], blockIdx.x, gp.grid_x[1], blockIdx.y);
+    else conv_body<MF, WM, WN, WK, NR, 3, DIL, false, false>(gp.p[2], blockIdx.x, gp.grid_x[2], blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------
@@ -721,8 +754,17 @@ int launch_shape(int id, const ConvParams& p, size_t lds, int grid_x, hipStream_
 
 }  // namespace
 
-int launch_conv(ConvParams p, hipStream_t s) {
-    if (p.B <= 0 || p.Tq <= 0 || p.Cin <= 0 || p.M <= 0) return 0;
+namespace {
+
+struct LaunchInfo {
+    int kind, shape, grid_x;
+    size_t lds;
+    double flops, bytes;
+    bool narrow;
+};
+
+// Validate one conv, pick its tile shape and fill in the staging geometry.
+int prepare_conv(ConvParams& p, LaunchInfo& li) {
     if (p.k < 1 || p.dil < 1) return fail(FV_ERR_INVALID_ARG, "conv: k=%d dil=%d", p.k, p.dil);
     if (p.pad_mode == FV_PAD_REFLECT && p.pad >= p.Tin)
         return fail(FV_ERR_INVALID_ARG, "reflection pad %d needs an input longer than it (T=%d)",
@@ -735,15 +777,15 @@ int launch_conv(ConvParams p, hipStream_t s) {
                     "1 GiB buffer-descriptor range of the kernels; split the utterance", p.Cin, p.Tin,
                     p.Cout, p.Tout);
     p.vec_ok = (p.Tin % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
-    const double flops = 2.0 * p.B * (double)p.M * p.Tq * p.Cin * p.k;
-    const double bytes = 4.0 * ((double)p.B * p.Cin * p.Tin + (double)p.B * p.Cout * p.Tout *
-                                (1 + (p.res != nullptr) + (p.acc_in != nullptr)) +
-                                (double)p.Cin * p.k * p.M);
-    int rc = 0, kind;
+    li.flops = 2.0 * p.B * (double)p.M * p.Tq * p.Cin * p.k;
+    li.bytes = 4.0 * ((double)p.B * p.Cin * p.Tin + (double)p.B * p.Cout * p.Tout *
+                      (1 + (p.res != nullptr) + (p.acc_in != nullptr) + (p.acc_in2 != nullptr) +
+                       (p.y_act != nullptr)) +
+                      (double)p.Cin * p.k * p.M);
     p.dbg = env_int("FV_DBG", 0);
-    profile_begin(s);
-    if (p.ups == 1 && p.M <= 4) {
-        kind = FV_KERNEL_CONV_NARROW;
+    li.narrow = p.ups == 1 && p.M <= 4;
+    if (li.narrow) {
+        li.kind = FV_KERNEL_CONV_NARROW;
         plan_x_image(p, 256, false);
         int c = 1;
         while (c + 1 <= p.Cin && (size_t)(round_up((c + 1) * p.ncol4c, 64) + round_up((c + 1) * p.k * 4, 64)) * 16 <= 48 * 1024 &&
@@ -755,53 +797,153 @@ int launch_conv(ConvParams p, hipStream_t s) {
         p.ci_chunk = c;
         p.xbuf = round_up(c * p.ncol4c, 64) * 4;
         p.wbuf = round_up(c * p.k * 4, 64) * 4;
-        const size_t lds = (size_t)(p.xbuf + p.wbuf) * 4;
-        dim3 grid((p.Tq + 255) / 256, p.B), block(256);
-        if (p.M == 1) hipLaunchKernelGGL(conv_narrow_kernel<1>, grid, block, lds, s, p);
-        else if (p.M == 2) hipLaunchKernelGGL(conv_narrow_kernel<2>, grid, block, lds, s, p);
-        else hipLaunchKernelGGL(conv_narrow_kernel<4>, grid, block, lds, s, p);
+        li.lds = (size_t)(p.xbuf + p.wbuf) * 4;
+        li.grid_x = (p.Tq + 255) / 256;
+        li.shape = -1;
+        return 0;
+    }
+    // ---- tile shape: wide tiles when the utterance alone yields enough work
+    // units, otherwise narrower tiles with the K range split over more waves.
+    // The choice depends on per-utterance sizes only (never on B), so a
+    // batch sharded over GPUs reproduces the single-GPU result bit for bit.
+    const bool m16 = p.Mpad == 16;
+    const bool m64 = !m16 && p.Mpad % 64 == 0;
+    li.kind = m16 ? FV_KERNEL_CONV_MFMA16 : FV_KERNEL_CONV_MFMA32;
+    auto units = [&](int id) {
+        const Geometry& gg = kShapes[id];
+        return (long)(p.Mpad / gg.m_t()) * ((p.Tq + gg.n_t() - 1) / gg.n_t());
+    };
+    // thresholds from per-layer and end-to-end sweeps on MI355X (tools/conv_bench.py, bench_sweep.sh)
+    const int want = env_int("FV_UNITS", 500);
+    int shape;
+    if (m16) shape = units(0) >= want ? 0 : 1;
+    else if (!m64 && units(2) >= want) shape = 2;
+    else if (m64 && units(5) >= want) shape = 5;
+    else if (units(3) >= 400) shape = 3;
+    else shape = 4;
+    const int force = env_int(m16 ? "FV_SHAPE16" : (m64 ? "FV_SHAPE64" : "FV_SHAPE32"), -1);
+    if (force >= 0 && force < kNumShapes && kShapes[force].mf == (m16 ? 16 : 32) &&
+        p.Mpad % kShapes[force].m_t() == 0)
+        shape = force;
+    const Geometry g = kShapes[shape];
+    li.shape = shape;
+    li.lds = plan_staging(p, g, env_int("FV_KROWS", 176));
+    if (!li.lds) return fail(FV_ERR_UNSUPPORTED, "conv: k=%d dil=%d cannot be staged (window too wide)", p.k, p.dil);
+    p.n_tiles = (p.Tq + g.n_t() - 1) / g.n_t();
+    const int m_tiles = p.Mpad / g.m_t();
+    // runs of consecutive time tiles per block: cap the grid
+    const int cap = env_int("FV_GRID_CAP", 768);
+    int runs = p.n_tiles;
+    const long per_batch_cap = cap / ((long)p.B * m_tiles) > 0 ? cap / ((long)p.B * m_tiles) : 1;
+    if (runs > per_batch_cap) runs = (int)per_batch_cap;
+    p.m_tiles = m_tiles;
+    p.tiles_per_run = (p.n_tiles + runs - 1) / runs;
+    runs = (p.n_tiles + p.tiles_per_run - 1) / p.tiles_per_run;   // no empty runs
+    li.grid_x = runs * m_tiles;
+    return 0;
+}
+
+template <int MF, int WM, int WN, int WK, int NR>
+int launch_group_geom(const GroupParams& gp, size_t lds, int grid_x, int B, int dil, hipStream_t s) {
+    dim3 grid(grid_x, B, 3), block(64 * WM * WN * WK);
+#define FV_GROUP(DIL)                                                                          \
+    do {                                                                                       \
+        auto kern = conv_group3_kernel<MF, WM, WN, WK, NR, DIL>;                               \
+        if (lds > 64 * 1024)                                                                   \
+            FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, gp);                                     \
+    } while (0)
+    switch (dil) {
+        case 1: FV_GROUP(1); break;
+        case 3: FV_GROUP(3); break;
+        default: FV_GROUP(5); break;
+    }
+#undef FV_GROUP
+    FV_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+int launch_conv(ConvParams p, hipStream_t s) {
+    if (p.B <= 0 || p.Tq <= 0 || p.Cin <= 0 || p.M <= 0) return 0;
+    LaunchInfo li;
+    if (int rc = prepare_conv(p, li)) return rc;
+    int rc = 0;
+    profile_begin(s);
+    if (li.narrow) {
+        dim3 grid(li.grid_x, p.B), block(256);
+        if (p.M == 1) hipLaunchKernelGGL(conv_narrow_kernel<1>, grid, block, li.lds, s, p);
+        else if (p.M == 2) hipLaunchKernelGGL(conv_narrow_kernel<2>, grid, block, li.lds, s, p);
+        else hipLaunchKernelGGL(conv_narrow_kernel<4>, grid, block, li.lds, s, p);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) rc = fail((int)e, "narrow conv launch: %s", hipGetErrorString(e));
     } else {
-        // ---- tile shape: wide tiles when the utterance alone yields enough work
-        // units, otherwise narrower tiles with the K range split over more waves.
-        // The choice depends on per-utterance sizes only (never on B), so a
-        // batch sharded over GPUs reproduces the single-GPU result bit for bit.
-        const bool m16 = p.Mpad == 16;
-        const bool m64 = !m16 && p.Mpad % 64 == 0;
-        kind = m16 ? FV_KERNEL_CONV_MFMA16 : FV_KERNEL_CONV_MFMA32;
-        auto units = [&](int id) {
-            const Geometry& gg = kShapes[id];
-            return (long)(p.Mpad / gg.m_t()) * ((p.Tq + gg.n_t() - 1) / gg.n_t());
-        };
-        // thresholds from per-layer sweeps on MI355X (tools/conv_bench.py, B = 1)
-        const int want = env_int("FV_UNITS", 500);
-        int shape;
-        if (m16) shape = units(0) >= want ? 0 : 1;
-        else if (!m64 && units(2) >= want) shape = 2;
-        else if (m64 && units(5) >= want) shape = 5;
-        else if (units(3) >= 400) shape = 3;
-        else shape = 4;
-        const int force = env_int(m16 ? "FV_SHAPE16" : (m64 ? "FV_SHAPE64" : "FV_SHAPE32"), -1);
-        if (force >= 0 && force < kNumShapes && kShapes[force].mf == (m16 ? 16 : 32) &&
-            p.Mpad % kShapes[force].m_t() == 0)
-            shape = force;
-        const Geometry g = kShapes[shape];
-        const size_t lds = plan_staging(p, g, env_int("FV_KROWS", 176));
-        if (!lds) return fail(FV_ERR_UNSUPPORTED, "conv: k=%d dil=%d cannot be staged (window too wide)", p.k, p.dil);
-        p.n_tiles = (p.Tq + g.n_t() - 1) / g.n_t();
-        const int m_tiles = p.Mpad / g.m_t();
-        // runs of consecutive time tiles per block: cap the grid (launch cost only)
-        const int cap = env_int("FV_GRID_CAP", 768);
-        int runs = p.n_tiles;
-        const long per_batch_cap = cap / ((long)p.B * m_tiles) > 0 ? cap / ((long)p.B * m_tiles) : 1;
-        if (runs > per_batch_cap) runs = (int)per_batch_cap;
-        p.m_tiles = m_tiles;
-        p.tiles_per_run = (p.n_tiles + runs - 1) / runs;
-        runs = (p.n_tiles + p.tiles_per_run - 1) / p.tiles_per_run;   // no empty runs
-        rc = launch_shape(shape, p, lds, runs * m_tiles, s);
+        rc = launch_shape(li.shape, p, li.lds, li.grid_x, s);
     }
-    profile_end(s, kind, flops, bytes);
+    profile_end(s, li.kind, li.flops, li.bytes);
+    return rc;
+}
+
+// Three mutually independent convs in one launch when they are the (11, 7, 3)-tap
+// members of an MRF position and agree on everything else; otherwise three launches.
+int launch_conv_group(ConvParams* ps, int n, hipStream_t s) {
+    bool ok = n == 3 && !env_int("FV_NO_GROUP", 0);
+    LaunchInfo li[3];
+    int order[3] = {0, 1, 2};
+    if (ok) {
+        for (int i = 0; i < 3 && ok; ++i) {
+            if (ps[i].B <= 0 || ps[i].Tq <= 0) ok = false;
+            else if (prepare_conv(ps[i], li[i])) ok = false;
+        }
+    }
+    if (ok) {
+        for (int i = 0; i < 3; ++i)       // sort by taps, largest first
+            for (int j = i + 1; j < 3; ++j)
+                if (ps[order[j]].k > ps[order[i]].k) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+        const ConvParams& a = ps[order[0]];
+        ok = a.k == 11 && ps[order[1]].k == 7 && ps[order[2]].k == 3 && !li[order[0]].narrow &&
+             (a.dil == 1 || a.dil == 3 || a.dil == 5) && a.ups == 1;
+        for (int i = 0; i < 3 && ok; ++i) {
+            const ConvParams& q = ps[order[i]];
+            const LaunchInfo& l = li[order[i]];
+            ok = !l.narrow && l.shape == li[order[0]].shape && q.dil == a.dil && q.B == a.B &&
+                 q.Cin == a.Cin && q.M == a.M && q.Tq == a.Tq && q.ups == 1 && q.pre_slope == 1.f &&
+                 q.pad_mode == FV_PAD_ZERO && q.vec_ok;
+        }
+    }
+    if (!ok) {
+        for (int i = 0; i < n; ++i)
+            if (int rc = launch_conv(ps[i], s)) return rc;
+        return 0;
+    }
+    GroupParams gp;
+    size_t lds = 0;
+    int grid_x = 0;
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < 3; ++i) {
+        gp.p[i] = ps[order[i]];
+        gp.grid_x[i] = li[order[i]].grid_x;
+        if (li[order[i]].lds > lds) lds = li[order[i]].lds;
+        if (gp.grid_x[i] > grid_x) grid_x = gp.grid_x[i];
+        flops += li[order[i]].flops;
+        bytes += li[order[i]].bytes;
+    }
+    profile_begin(s);
+    int rc;
+    const int B = gp.p[0].B, dil = gp.p[0].dil;
+    switch (li[order[0]].shape) {
+        case 0: rc = launch_group_geom<16, 1, 4, 1, 2>(gp, lds, grid_x, B, dil, s); break;
+        case 1: rc = launch_group_geom<16, 1, 2, 2, 2>(gp, lds, grid_x, B, dil, s); break;
+        case 2: rc = launch_group_geom<32, 1, 4, 1, 1>(gp, lds, grid_x, B, dil, s); break;
+        case 3: rc = launch_group_geom<32, 1, 2, 2, 1>(gp, lds, grid_x, B, dil, s); break;
+        case 4: rc = launch_group_geom<32, 1, 1, 4, 1>(gp, lds, grid_x, B, dil, s); break;
+        case 5: rc = launch_group_geom<32, 2, 2, 1, 1>(gp, lds, grid_x, B, dil, s); break;
+        case 6: rc = launch_group_geom<32, 2, 1, 2, 1>(gp, lds, grid_x, B, dil, s); break;
+        default: rc = launch_group_geom<32, 1, 2, 2, 2>(gp, lds, grid_x, B, dil, s); break;
+    }
+    profile_end(s, li[order[0]].kind, flops, bytes);
     return rc;
 }
 

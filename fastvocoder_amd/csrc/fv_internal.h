@@ -52,6 +52,7 @@ struct ConvParams {
     const float* bias;    // [Cout] or null
     const float* res;     // [B,Cout,Tout] or null
     const float* acc_in;  // [B,Cout,Tout] or null
+    const float* acc_in2; // second running-sum input (added to acc_in first) or null
     float* y;             // [B,Cout,Tout]
     float* y_act;         // optional activated twin of y: act(y, act_slope), or null
     int B, Cin, M, Mpad, Cout;
@@ -78,6 +79,8 @@ struct ConvParams {
 };
 
 int launch_conv(ConvParams p, hipStream_t stream);
+// n mutually independent convs; one grouped launch when they form an MRF position
+int launch_conv_group(ConvParams* ps, int n, hipStream_t stream);
 int launch_pqmf(const float* x, const float* h, float* y, int B, int S, int ntaps, int Tsub,
                 hipStream_t stream);
 

@@ -53,6 +53,8 @@ class PlanBuilder:
         self._next = _native.SLOT_TMP0
         self.ops = []
         self.lane = 0       # concurrency lane of the ops being recorded (see fv_plan_set_lane)
+        self.group = 0      # non-zero: ops recorded under it are mutually independent (fv_plan_set_group)
+        self._groups = 0
 
     def tmp(self):
         s = self._next
@@ -65,15 +67,25 @@ class PlanBuilder:
     def _bias(conv):
         return None if conv.bias is None else conv.bias.detach().contiguous().float()
 
+    def begin_group(self):
+        """Ops recorded until :meth:`end_group` are mutually independent (no op reads or
+        overwrites what another writes): the executor may run them as one launch."""
+        self._groups += 1
+        self.group = self._groups
+
+    def end_group(self):
+        self.group = 0
+
     def conv(self, conv, src, dst, pad=None, pad_mode=PAD_ZERO, pre_slope=1.0, res=SLOT_NONE,
-             acc=SLOT_NONE, out_div=1.0, post=POST_NONE):
+             acc=SLOT_NONE, out_div=1.0, post=POST_NONE, acc2=SLOT_NONE):
         """Record ``conv`` (a torch.nn.Conv1d container): dst = epilogue(conv(act(src)))."""
         if conv.stride[0] != 1 or conv.groups != 1:
             raise _native.NativeError("only stride-1, groups-1 Conv1d layers exist on this path")
         k, d = conv.kernel_size[0], conv.dilation[0]
         if pad is None:
             pad = conv.padding[0]
-        self.ops.append(dict(kind="conv", lane=self.lane, x=src, y=dst, res=res, acc=acc, pre_slope=float(pre_slope),
+        self.ops.append(dict(kind="conv", lane=self.lane, group=self.group, x=src, y=dst, res=res, acc=acc,
+                             acc2=acc2, pre_slope=float(pre_slope),
                              packed=_native.pack_conv1d(effective_weight(conv)), bias=self._bias(conv),
                              cin=conv.in_channels, cout=conv.out_channels, k=k, dil=d, pad=pad,
                              pad_mode=pad_mode, out_div=out_div, post=post))
@@ -124,7 +136,7 @@ class PlanBuilder:
                         act_uses.setdefault(c["pre_slope"], []).append(j)
                     else:
                         raw_needed = True
-                if c["res"] == y or c["acc"] == y:
+                if c["res"] == y or c["acc"] == y or c.get("acc2", SLOT_NONE) == y:
                     raw_needed = True
                 if c["y"] == y or c.get("y_act") == y:
                     break
@@ -147,12 +159,13 @@ class PlanBuilder:
         self._hoist_activations()
         for op in self.ops:
             self.plan.set_lane(op["lane"])
+            self.plan.set_group(op.get("group", 0))
             if op["kind"] == "conv":
                 self.plan.add_conv1d(op["x"], op["y"], op["packed"], op["bias"], op["cin"], op["cout"],
                                      op["k"], dil=op["dil"], pad=op["pad"], pad_mode=op["pad_mode"],
                                      pre_slope=op["pre_slope"], res=op["res"], acc=op["acc"],
                                      out_div=op["out_div"], post=op["post"], y_act=op["y_act"],
-                                     act_slope=op["act_slope"])
+                                     act_slope=op["act_slope"], acc2=op.get("acc2", SLOT_NONE))
             elif op["kind"] == "convT":
                 self.plan.add_conv_transpose1d(op["x"], op["y"], op["packed"], op["bias"], op["cin"],
                                                op["cout"], op["k"], op["stride"], op["pad"],

@@ -65,15 +65,20 @@ class _HiFiGANBase(NativeModule):
     # -- op emission ---------------------------------------------------------
     def _emit_trunk(self, pb, dst):
         """mel (SLOT_IN) -> tanh(conv_post(...)) in ``dst``."""
-        x, up, acc = pb.tmp(), pb.tmp(), pb.tmp()
+        x, up = pb.tmp(), pb.tmp()
         nk = self.num_kernels
         # The nk ResBlocks of a stage are independent given the upsampled input, and at
-        # batch 1 one conv cannot fill 256 CUs: each block gets its own concurrency lane
-        # (stream) and scratch.  Measured on MI355X (HiFi-GAN light, B=1): 3 lanes 1.86 ms,
-        # 2 lanes balanced by kernel size 1.99 ms, 1 lane 2.07 ms per forward.
-        n_lanes = max(1, min(nk, 3, int(os.environ.get("FV_LANES", "3"))))
-        lane_of = [j % n_lanes for j in range(nk)]
-        scratch = [[pb.tmp(), pb.tmp(), pb.tmp()] for _ in range(n_lanes)]
+        # batch 1 one conv cannot fill 256 CUs.  Their steps are therefore emitted
+        # interleaved -- conv number s of every block forms one GROUP, which the
+        # executor runs as a single launch when the blocks are the classic 3/7/11-tap
+        # trio (fv_plan_set_group), else one launch each.  The last block's final conv
+        # is emitted alone: its epilogue forms ((r0 + r1) + r2) / nk, the reference's
+        # summation order (hifigan.py:97-103), from the other blocks' outputs.
+        # Measured on MI355X (HiFi-GAN light, B = 1, per forward): grouped launches
+        # see DESIGN.md; three concurrent streams 1.84 ms; one stream 2.0 ms.
+        mode = os.environ.get("FV_MRF", "group")
+        parts = [pb.tmp() for _ in range(nk - 1)]          # r_0 .. r_{nk-2}
+        scratch = [[pb.tmp(), pb.tmp(), pb.tmp()] for _ in range(nk)]
         pb.conv(self.conv_pre, SLOT_IN, x)
         for i in range(self.num_upsamples):
             if isinstance(self.ups[i], UpsampleLayer):
@@ -81,16 +86,36 @@ class _HiFiGANBase(NativeModule):
                     "transposedconv: False (UpsampleLayer) has no HIP kernel yet; every shipped "
                     "conf/*.yaml uses transposedconv: True")
             pb.conv_transpose(self.ups[i], x, up, pre_slope=LRELU_SLOPE)
-            for j in range(nk):
-                last = j == nk - 1
-                # running sum in `acc` in resblock order, mean folded into the
-                # last block's final epilogue (reference hifigan.py:97-103)
-                pb.lane = lane_of[j]
-                self.resblocks[i * nk + j].emit(
-                    pb, up, x if last else acc, scratch[lane_of[j]],
-                    acc=acc if j > 0 else SLOT_NONE,
-                    out_div=float(nk) if last else 1.0)
-            pb.lane = 0
+            blocks = [self.resblocks[i * nk + j] for j in range(nk)]
+            if nk <= 3 and mode != "chain":
+                steps = blocks[0].num_steps()
+                states = [dict() for _ in range(nk)]
+                for st in range(steps):
+                    final = st == steps - 1
+                    members = range(nk - 1) if final else range(nk)
+                    if mode == "lanes":
+                        for j in members:
+                            pb.lane = j
+                            blocks[j].emit_step(pb, st, states[j], up, parts[j] if j < nk - 1 else x,
+                                                scratch[j])
+                        pb.lane = 0
+                    else:
+                        pb.begin_group()
+                        for j in members:
+                            blocks[j].emit_step(pb, st, states[j], up, parts[j] if j < nk - 1 else x,
+                                                scratch[j])
+                        pb.end_group()
+                # the last block's final conv: + r_0 (+ r_1), / nk
+                blocks[nk - 1].emit_step(pb, steps - 1, states[nk - 1], up, x, scratch[nk - 1],
+                                         acc=parts[0] if nk > 1 else SLOT_NONE,
+                                         acc2=parts[1] if nk > 2 else SLOT_NONE, out_div=float(nk))
+            else:
+                # generic: a running sum chained through the blocks, one after the other
+                for j in range(nk):
+                    last = j == nk - 1
+                    blocks[j].emit(pb, up, x if last else parts[0], scratch[0],
+                                   acc=parts[0] if j > 0 else SLOT_NONE,
+                                   out_div=float(nk) if last else 1.0)
         pb.conv(self.conv_post, x, dst, pre_slope=DEFAULT_LRELU_SLOPE, post=POST_TANH)
 
     def _trunk(self, x):

@@ -65,19 +65,32 @@ class ResBlock1(_Block):
     def scratch_slots(self):
         return 3
 
+    def num_steps(self):
+        return 2 * len(self.convs1)
+
+    def emit_step(self, pb, step, state, src, dst, scratch, acc=SLOT_NONE, acc2=SLOT_NONE, out_div=1.0):
+        """Emit conv number ``step`` (0 .. num_steps()-1) of the block; ``state`` is a dict
+        the caller keeps per block between steps.  Lets a generator interleave the steps
+        of several independent blocks (one group per step)."""
+        mid, ping, pong = scratch
+        cur = state.get("cur", src)
+        i, second = divmod(step, 2)
+        if not second:
+            pb.conv(self.convs1[i], cur, mid, pre_slope=LRELU_SLOPE)
+            return
+        last = i == len(self.convs1) - 1
+        nxt = dst if last else (ping if cur != ping else pong)
+        pb.conv(self.convs2[i], mid, nxt, pre_slope=LRELU_SLOPE, res=cur,
+                acc=acc if last else SLOT_NONE, acc2=acc2 if last else SLOT_NONE,
+                out_div=out_div if last else 1.0)
+        state["cur"] = nxt
+
     def emit(self, pb, src, dst, scratch, acc=SLOT_NONE, out_div=1.0):
         """src -> dst through the pairs; the LAST conv's epilogue also carries the
         caller's running MRF sum (``acc``) and mean (``out_div``)."""
-        mid, ping, pong = scratch
-        cur = src
-        n = len(self.convs1)
-        for i, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
-            last = i == n - 1
-            nxt = dst if last else (ping if cur != ping else pong)
-            pb.conv(c1, cur, mid, pre_slope=LRELU_SLOPE)
-            pb.conv(c2, mid, nxt, pre_slope=LRELU_SLOPE, res=cur,
-                    acc=acc if last else SLOT_NONE, out_div=out_div if last else 1.0)
-            cur = nxt
+        state = {}
+        for step in range(self.num_steps()):
+            self.emit_step(pb, step, state, src, dst, scratch, acc=acc, out_div=out_div)
 
 
 class ResBlock2(_Block):
@@ -92,16 +105,23 @@ class ResBlock2(_Block):
     def scratch_slots(self):
         return 2
 
-    def emit(self, pb, src, dst, scratch, acc=SLOT_NONE, out_div=1.0):
+    def num_steps(self):
+        return len(self.convs)
+
+    def emit_step(self, pb, step, state, src, dst, scratch, acc=SLOT_NONE, acc2=SLOT_NONE, out_div=1.0):
         ping, pong = scratch[:2]
-        cur = src
-        n = len(self.convs)
-        for i, c in enumerate(self.convs):
-            last = i == n - 1
-            nxt = dst if last else (ping if cur != ping else pong)
-            pb.conv(c, cur, nxt, pre_slope=LRELU_SLOPE, res=cur,
-                    acc=acc if last else SLOT_NONE, out_div=out_div if last else 1.0)
-            cur = nxt
+        cur = state.get("cur", src)
+        last = step == len(self.convs) - 1
+        nxt = dst if last else (ping if cur != ping else pong)
+        pb.conv(self.convs[step], cur, nxt, pre_slope=LRELU_SLOPE, res=cur,
+                acc=acc if last else SLOT_NONE, acc2=acc2 if last else SLOT_NONE,
+                out_div=out_div if last else 1.0)
+        state["cur"] = nxt
+
+    def emit(self, pb, src, dst, scratch, acc=SLOT_NONE, out_div=1.0):
+        state = {}
+        for step in range(self.num_steps()):
+            self.emit_step(pb, step, state, src, dst, scratch, acc=acc, out_div=out_div)
 
 
 def _activation_slope(name, params):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FV_ABI_VERSION 2
+#define FV_ABI_VERSION 3
 
 #define FV_ERR_INVALID_ARG (-1)
 #define FV_ERR_UNSUPPORTED (-2)
@@ -79,7 +79,7 @@ int fv_pack_conv_transpose1d_weight(const float* w, float* packed, int Cin, int 
  * ------------------------------------------------------------------ */
 
 /*
- * y     = post( ( acc_in + ( conv1d(lrelu(x, pre_slope); w, dil, pad) + bias + res ) ) / out_div )
+ * y     = post( ( (acc_in + acc_in2) + ( conv1d(lrelu(x, pre_slope); w, dil, pad) + bias + res ) ) / out_div )
  * y_act = lrelu(y, act_slope)            (optional second output, see below)
  *
  * Replaces F.leaky_relu + torch.nn.Conv1d (+ the residual add, the MRF running
@@ -87,7 +87,8 @@ int fv_pack_conv_transpose1d_weight(const float* w, float* packed, int Cin, int 
  * :372-382 (ResidualStack), :85-89 (LastLayer), hifigan.py:93,99-106,
  * multiband_hifigan.py:102-115, melgan.py:66-71.
  *   x [B,Cin,Tin]; packed from fv_pack_conv1d_weight; bias [Cout] or NULL;
- *   res, acc_in [B,Cout,Tout] or NULL; y [B,Cout,Tout],
+ *   res, acc_in, acc_in2 [B,Cout,Tout] or NULL (acc_in + acc_in2 is formed first: the
+ *   reference's xs = r0; xs += r1; xs += r2 order, hifigan.py:99-102); y [B,Cout,Tout],
  *   Tout = Tin + 2*pad - dil*(k-1).  pre_slope = 1 disables the input
  *   activation, 0 is ReLU; out_div = 1 disables the division (it is a true
  *   fp32 division, hifigan.py:103).  y may alias res or acc_in, never x.
@@ -99,9 +100,10 @@ int fv_pack_conv_transpose1d_weight(const float* w, float* packed, int Cin, int 
  *   the activated tensor is written, to y.  act_slope = 1 disables both.
  */
 int fv_conv1d_fused(const float* x, const float* packed, const float* bias,
-                    const float* res, const float* acc_in, float* y, float* y_act, int B,
-                    int Cin, int Cout, int Tin, int k, int dil, int pad, int pad_mode,
-                    float pre_slope, float out_div, int post, float act_slope, void* stream);
+                    const float* res, const float* acc_in, const float* acc_in2, float* y,
+                    float* y_act, int B, int Cin, int Cout, int Tin, int k, int dil, int pad,
+                    int pad_mode, float pre_slope, float out_div, int post, float act_slope,
+                    void* stream);
 
 /*
  * y = post( conv_transpose1d(lrelu(x, pre_slope); w, stride, pad, out_pad) + bias )
@@ -145,9 +147,10 @@ void fv_plan_destroy(fv_plan_t* plan);
 /* append ops; argument meaning as in the fused operators above, tensors named
  * by slot.  Weight pointers are captured, not copied. */
 int fv_plan_add_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot,
-                       int res_slot, int acc_slot, const float* packed, const float* bias,
-                       int Cin, int Cout, int k, int dil, int pad, int pad_mode,
-                       float pre_slope, float out_div, int post, float act_slope);
+                       int res_slot, int acc_slot, int acc2_slot, const float* packed,
+                       const float* bias, int Cin, int Cout, int k, int dil, int pad,
+                       int pad_mode, float pre_slope, float out_div, int post,
+                       float act_slope);
 int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot,
                                  const float* packed, const float* bias, int Cin, int Cout,
                                  int k, int stride, int pad, int out_pad, float pre_slope,
@@ -162,6 +165,13 @@ int fv_plan_add_pqmf_synthesis(fv_plan_t* plan, int x_slot, int y_slot, const fl
  * an MRF stage (hifigan.py:97-103) side by side when one utterance alone cannot
  * fill 256 CUs. */
 int fv_plan_set_lane(fv_plan_t* plan, int lane);
+
+/* Grouping: consecutive conv1d ops appended under the same non-zero group id are
+ * declared mutually independent by the caller.  When they are the 11/7/3-tap
+ * convolutions at one position of the three ResBlocks of an MRF stage (same
+ * shapes, dilation and activation state) the executor runs them as ONE launch
+ * (blockIdx.z selects the problem); otherwise one launch each.  0 ends a group. */
+int fv_plan_set_group(fv_plan_t* plan, int group);
 
 /* shape inference for a (B, T) call: channels / length of the output tensor
  * and the workspace the plan needs (bytes) */

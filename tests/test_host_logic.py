@@ -152,7 +152,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_native.LIB_PATH)
     for n in sorted(names):
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
-    assert _native.lib().fv_version() == 2
+    assert _native.lib().fv_version() == 3
     # host-only entry points that need no device
     assert _native.lib().fv_packed_conv1d_floats(128, 128, 11) == 128 * 11 * 128
     assert _native.lib().fv_packed_conv_transpose1d_floats(256, 128, 16, 8, 4) == 256 * 3 * 1024
@@ -166,10 +166,10 @@ def test_plan_shape_inference_without_gpu():
     L = _native.lib()
     h = L.fv_plan_create(80)
     dummy = ctypes.c_void_p(16)     # never dereferenced by the host-side shape walk
-    assert L.fv_plan_add_conv1d(h, 0, 2, -1, -1, -1, dummy, None, 80, 32, 7, 1, 3, 0, 1.0, 1.0, 0, 0.1) == 0
+    assert L.fv_plan_add_conv1d(h, 0, 2, -1, -1, -1, -1, dummy, None, 80, 32, 7, 1, 3, 0, 1.0, 1.0, 0, 0.1) == 0
     assert L.fv_plan_add_conv_transpose1d(h, 2, 3, 4, dummy, None, 32, 16, 16, 10, 5, 0, 1.0, 0, 0.1) == 0
     assert L.fv_plan_add_conv_transpose1d(h, 4, 2, -1, dummy, None, 16, 8, 16, 6, 3, 0, 1.0, 0, 0.01) == 0
-    assert L.fv_plan_add_conv1d(h, 2, 3, -1, -1, -1, dummy, None, 8, 4, 7, 1, 3, 0, 1.0, 1.0, 1, 1.0) == 0
+    assert L.fv_plan_add_conv1d(h, 2, 3, -1, -1, -1, -1, dummy, None, 8, 4, 7, 1, 3, 0, 1.0, 1.0, 1, 1.0) == 0
     assert L.fv_plan_add_pqmf_synthesis(h, 3, 1, dummy, 4, 63) == 0
     c, n = ctypes.c_int(), ctypes.c_int64()
     assert L.fv_plan_output_shape(h, 100, ctypes.byref(c), ctypes.byref(n)) == 0
@@ -177,7 +177,7 @@ def test_plan_shape_inference_without_gpu():
     assert L.fv_plan_workspace_bytes(h, 2, 100) > 0
     assert L.fv_plan_num_ops(h) == 5
     # channel mismatch is caught at shape-inference time with a message
-    assert L.fv_plan_add_conv1d(h, 1, 5, -1, -1, -1, dummy, None, 7, 4, 3, 1, 1, 0, 1.0, 1.0, 0, 1.0) == 0
+    assert L.fv_plan_add_conv1d(h, 1, 5, -1, -1, -1, -1, dummy, None, 7, 4, 3, 1, 1, 0, 1.0, 1.0, 0, 1.0) == 0
     assert L.fv_plan_output_shape(h, 100, ctypes.byref(c), ctypes.byref(n)) != 0
     assert b"channels" in L.fv_last_error()
     L.fv_plan_destroy(h)
