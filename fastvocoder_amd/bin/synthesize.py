@@ -67,12 +67,22 @@ class Synthesizer:
         self.config = config
         return model
 
+    def zero_mel_response(self, frames):
+        """The generator's output for an all-zero mel of ``frames`` frames.  It depends
+        only on (weights, frames), so it is computed once per length and cached
+        (the reference recomputes it for every utterance, bin/synthesize.py:76-77)."""
+        cache = self.__dict__.setdefault("_zero_cache", {})
+        if frames not in cache:
+            with torch.no_grad():
+                cache[frames] = self.model.inference(
+                    torch.zeros(frames, self.config.get("in_channels", 80))).clone()
+        return cache[frames]
+
     def synthesize(self, mel):
         """mel [T,80] ndarray -> (est_source, est_source - bias, bias), each 1-D fp32
         on the device; ``bias`` is the generator's response to an all-zero mel."""
         with torch.no_grad():
-            zero_mel = torch.zeros_like(torch.from_numpy(np.asarray(mel)).float())
-            bias = self.model.inference(zero_mel)
+            bias = self.zero_mel_response(int(np.asarray(mel).shape[0]))
             est_source = self.model.inference(mel)
             est_source_remove_bias = est_source - bias
         return est_source, est_source_remove_bias, bias
