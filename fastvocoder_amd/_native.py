@@ -19,7 +19,7 @@ SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip"]
 PAD_ZERO, PAD_REFLECT = 0, 1
 POST_NONE, POST_TANH, POST_RELU = 0, 1, 2
 SLOT_NONE, SLOT_IN, SLOT_OUT, SLOT_TMP0, MAX_SLOTS = -1, 0, 1, 2, 32
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class NativeError(RuntimeError):
@@ -73,6 +73,11 @@ def lib():
     L.fv_conv1d_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, f, i, f, vp]
     L.fv_conv_transpose1d_fused.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, i, f, vp]
     L.fv_pqmf_synthesis.argtypes = [vp, vp, vp, i, i, i, i, vp]
+    L.fv_packed_upsample_conv1d_floats.argtypes = [i, i, i, i, i]
+    L.fv_packed_upsample_conv1d_floats.restype = i64
+    L.fv_pack_upsample_conv1d_weight.argtypes = [vp, vp, i, i, i, i, i, vp]
+    L.fv_upsample_conv1d_fused.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, i, f, vp]
+    L.fv_plan_add_upsample_conv1d.argtypes = [vp, i, i, i, vp, vp, i, i, i, i, i, f, i, f]
     L.fv_plan_create.argtypes = [i]
     L.fv_plan_create.restype = vp
     L.fv_plan_destroy.argtypes = [vp]
@@ -153,6 +158,16 @@ def pack_conv_transpose1d(w, stride, pad):
     return out
 
 
+def pack_upsample_conv1d(w, rate, pad):
+    """UpsampleLayer conv weight [Cout,Cin,k] -> packed phase image (flat tensor)."""
+    w = w.detach().contiguous().float()
+    cout, cin, k = w.shape
+    n = lib().fv_packed_upsample_conv1d_floats(cout, cin, k, rate, pad)
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    check(lib().fv_pack_upsample_conv1d_weight(_ptr(w, "w"), _ptr(out), cout, cin, k, rate, pad, _stream()))
+    return out
+
+
 # ---------------------------------------------------------------------------
 # single fused operators (used by tests and by modules outside a plan)
 # ---------------------------------------------------------------------------
@@ -184,6 +199,19 @@ def conv_transpose1d_fused(x, packed, bias, cout, k, stride, pad, out_pad, pre_s
                                           _ptr(out_act, "out_act", True), B, cin, cout, T, k, stride,
                                           pad, out_pad, float(pre_slope), post, float(act_slope),
                                           _stream()))
+    return out
+
+
+def upsample_conv1d_fused(x, packed, bias, cout, k, rate, pad, pre_slope=1.0, post=POST_NONE,
+                          out=None, out_act=None, act_slope=1.0):
+    B, cin, T = x.shape
+    tout = T * rate + 2 * pad - (k - 1)
+    if out is None:
+        out = torch.empty((B, cout, tout), dtype=torch.float32, device=x.device)
+    check(lib().fv_upsample_conv1d_fused(_ptr(x, "x"), _ptr(packed, "packed"), _ptr(bias, "bias", True),
+                                         _ptr(out, "out"), _ptr(out_act, "out_act", True), B, cin, cout,
+                                         T, k, rate, pad, float(pre_slope), post, float(act_slope),
+                                         _stream()))
     return out
 
 
@@ -237,6 +265,15 @@ class Plan:
                                                  _ptr(bias, "bias", True), cin, cout, k, stride,
                                                  pad, out_pad, float(pre_slope), post,
                                                  float(act_slope)))
+
+    def add_upsample_conv1d(self, x, y, packed, bias, cin, cout, k, rate, pad, pre_slope=1.0,
+                            post=POST_NONE, y_act=SLOT_NONE, act_slope=1.0):
+        self.keep(packed)
+        if bias is not None:
+            self.keep(bias)
+        check(lib().fv_plan_add_upsample_conv1d(self._h, x, y, y_act, _ptr(packed, "packed"),
+                                                _ptr(bias, "bias", True), cin, cout, k, rate, pad,
+                                                float(pre_slope), post, float(act_slope)))
 
     def set_lane(self, lane):
         check(lib().fv_plan_set_lane(self._h, lane))

@@ -114,10 +114,32 @@ __global__ void pack_convT_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
+// UpsampleLayer weight [Cout, Cin, k] (nearest-repeat x u, then conv with zero padding p) ->
+// phase image Wp[(ci*taps + jj)][m = co*u + r] = sum of w[co, ci, j] over the taps j with
+// floor((r + j - p) / u) == dmin + jj (they all read the same input sample).
+__global__ void pack_upconv_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
+                                   int Cin, int k, int u, int p, int dmin, int taps, int Mpad) {
+    const int64_t total = (int64_t)Cin * taps * Mpad;
+    const int M = Cout * u;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i % Mpad);
+        const int64_t row = i / Mpad;
+        const int jj = (int)(row % taps), ci = (int)(row / taps);
+        float val = 0.f;
+        if (m < M) {
+            const int co = m / u, r = m - co * u;
+            const int j0 = (dmin + jj) * u - r + p;      // first tap of this delta
+            for (int j = max(j0, 0); j < min(j0 + u, k); ++j) val += w[((size_t)co * Cin + ci) * k + j];
+        }
+        wp[i] = val;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------
-enum OpType { OP_CONV = 0, OP_CONVT = 1, OP_PQMF = 2 };
+enum OpType { OP_CONV = 0, OP_CONVT = 1, OP_PQMF = 2, OP_UPCONV = 3 };
 
 struct Op {
     int type;
@@ -174,6 +196,7 @@ namespace fv {
 static int64_t conv_out_len(const Op& o, int64_t Tin) {
     if (o.type == OP_CONV) return Tin + 2LL * o.pad - (int64_t)o.dil * (o.k - 1);
     if (o.type == OP_CONVT) return (Tin - 1) * o.stride - 2LL * o.pad + o.k + o.out_pad;
+    if (o.type == OP_UPCONV) return Tin * o.stride + 2LL * o.pad - (o.k - 1);
     return Tin * o.Cin;  // PQMF: S sub-bands interleave into S*Tsub samples
 }
 
@@ -242,7 +265,8 @@ static ConvParams make_params(const Op& o, const float* x, float* y, float* y2, 
         p.ups = 1;
         p.Tq = p.Tout;
     } else {
-        const Polyphase ph = polyphase(o.k, o.stride, o.pad);
+        const Polyphase ph = o.type == OP_UPCONV ? upsample_phases(o.k, o.stride, o.pad)
+                                                 : polyphase(o.k, o.stride, o.pad);
         p.M = o.Cout * o.stride;
         p.k = ph.taps;
         p.dil = 1;
@@ -386,6 +410,60 @@ int fv_pack_conv_transpose1d_weight(const float* w, float* packed, int Cin, int 
     hipLaunchKernelGGL(pack_convT_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
                        packed, Cin, Cout, k, stride, pad, ph.dmin, ph.taps, Mpad);
     FV_HIP(hipGetLastError());
+    return 0;
+}
+
+int64_t fv_packed_upsample_conv1d_floats(int Cout, int Cin, int k, int rate, int pad) {
+    const Polyphase ph = upsample_phases(k, rate, pad);
+    return (int64_t)Cin * ph.taps * pad_rows(Cout * rate);
+}
+
+int fv_pack_upsample_conv1d_weight(const float* w, float* packed, int Cout, int Cin, int k, int rate,
+                                   int pad, void* stream) {
+    if (int rc = check_conv_args(Cin, Cout, k, 1)) return rc;
+    if (rate <= 0 || pad < 0) return fail(FV_ERR_INVALID_ARG, "upsample conv rate=%d pad=%d", rate, pad);
+    const Polyphase ph = upsample_phases(k, rate, pad);
+    const int Mpad = pad_rows(Cout * rate);
+    const int64_t total = (int64_t)Cin * ph.taps * Mpad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_upconv_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed,
+                       Cout, Cin, k, rate, pad, ph.dmin, ph.taps, Mpad);
+    FV_HIP(hipGetLastError());
+    return 0;
+}
+
+int fv_upsample_conv1d_fused(const float* x, const float* packed, const float* bias, float* y,
+                             float* y_act, int B, int Cin, int Cout, int Tin, int k, int rate, int pad,
+                             float pre_slope, int post, float act_slope, void* stream) {
+    if (int rc = check_conv_args(Cin, Cout, k, 1)) return rc;
+    if (!x || !packed || !y) return fail(FV_ERR_INVALID_ARG, "upsample_conv1d: null tensor");
+    if (rate <= 0 || pad < 0) return fail(FV_ERR_INVALID_ARG, "upsample_conv1d: rate=%d pad=%d", rate, pad);
+    if (x == y || x == y_act || (y_act && y_act == y))
+        return fail(FV_ERR_INVALID_ARG, "upsample_conv1d: y / y_act must not alias x or each other");
+    Op o = {};
+    o.type = OP_UPCONV;
+    o.wp = packed;
+    o.bias = bias;
+    o.Cin = Cin;
+    o.Cout = Cout;
+    o.k = k;
+    o.stride = rate;
+    o.pad = pad;
+    o.pre_slope = pre_slope;
+    o.out_div = 1.f;
+    o.act_slope = act_slope;
+    o.post = post;
+    if (conv_out_len(o, Tin) <= 0) return fail(FV_ERR_INVALID_ARG, "upsample_conv1d: empty output");
+    return run_op(o, x, y, y_act, nullptr, nullptr, nullptr, B, Tin, (hipStream_t)stream);
+}
+
+int fv_plan_add_upsample_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot,
+                                const float* packed, const float* bias, int Cin, int Cout, int k,
+                                int rate, int pad, float pre_slope, int post, float act_slope) {
+    if (int rc = fv_plan_add_conv_transpose1d(plan, x_slot, y_slot, y_act_slot, packed, bias, Cin, Cout, k,
+                                              rate, pad, 0, pre_slope, post, act_slope))
+        return rc;
+    plan->ops.back().type = OP_UPCONV;
     return 0;
 }
 

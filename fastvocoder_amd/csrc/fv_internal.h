@@ -41,6 +41,17 @@ static inline Polyphase polyphase(int k, int s, int p) {
     return ph;
 }
 
+// Nearest-repeat x u followed by Conv1d(k, zero padding p) (the reference's UpsampleLayer,
+// model/generator/modules.py:160-177) in the same phase form: output t = q*u + r reads
+// x[q + delta], delta = floor((r + j - p) / u); taps j that land on the same input
+// sample are summed into one weight at pack time.
+static inline int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+static inline Polyphase upsample_phases(int k, int u, int p) {
+    Polyphase ph = {floor_div(-p, u), floor_div(u - 1 + k - 1 - p, u), 0};
+    ph.taps = ph.dmax - ph.dmin + 1;
+    return ph;
+}
+
 // Everything one implicit-GEMM conv launch needs.  The GEMM is
 //   Y[m, q] = sum_{ci, j} Wp[ci, j, m] * act(X[ci, q + j*dil - pad])
 // with M rows (= Cout, or Cout*stride phases for a transposed conv) and Tq

@@ -102,6 +102,18 @@ class PlanBuilder:
                              bias=self._bias(convt), cin=convt.in_channels, cout=convt.out_channels,
                              k=k, stride=s, pad=p, out_pad=op, post=post))
 
+    def upsample_conv(self, layer, src, dst, pre_slope=1.0, post=POST_NONE):
+        """Record an UpsampleLayer container (nearest-repeat x rate, then its Conv1d)."""
+        conv = layer.conv
+        if conv.stride[0] != 1 or conv.dilation[0] != 1 or conv.groups != 1:
+            raise _native.NativeError("UpsampleLayer: only a stride-1, undilated, dense conv is supported")
+        k, p, u = conv.kernel_size[0], conv.padding[0], layer.upsample_rate
+        self.ops.append(dict(kind="upconv", lane=self.lane, x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE,
+                             pre_slope=float(pre_slope),
+                             packed=_native.pack_upsample_conv1d(effective_weight(conv), u, p),
+                             bias=self._bias(conv), cin=conv.in_channels, cout=conv.out_channels,
+                             k=k, rate=u, pad=p, post=post))
+
     def basis_overlap_add(self, basis_weight, src, dst, hop, pre_slope=1.0):
         """frames = act(src)^T @ W^T then overlap-add with hop: a ConvTranspose1d
         with Cout = 1, kernel L, stride hop (weight [C,1,L] = W^T)."""
@@ -171,6 +183,11 @@ class PlanBuilder:
                                                op["cout"], op["k"], op["stride"], op["pad"],
                                                op["out_pad"], pre_slope=op["pre_slope"], post=op["post"],
                                                y_act=op["y_act"], act_slope=op["act_slope"])
+            elif op["kind"] == "upconv":
+                self.plan.add_upsample_conv1d(op["x"], op["y"], op["packed"], op["bias"], op["cin"],
+                                              op["cout"], op["k"], op["rate"], op["pad"],
+                                              pre_slope=op["pre_slope"], post=op["post"],
+                                              y_act=op["y_act"], act_slope=op["act_slope"])
             else:
                 self.plan.add_pqmf_synthesis(op["x"], op["y"], op["h"])
         return self.plan

@@ -82,10 +82,9 @@ class _HiFiGANBase(NativeModule):
         pb.conv(self.conv_pre, SLOT_IN, x)
         for i in range(self.num_upsamples):
             if isinstance(self.ups[i], UpsampleLayer):
-                raise NotImplementedError(
-                    "transposedconv: False (UpsampleLayer) has no HIP kernel yet; every shipped "
-                    "conf/*.yaml uses transposedconv: True")
-            pb.conv_transpose(self.ups[i], x, up, pre_slope=LRELU_SLOPE)
+                pb.upsample_conv(self.ups[i], x, up, pre_slope=LRELU_SLOPE)
+            else:
+                pb.conv_transpose(self.ups[i], x, up, pre_slope=LRELU_SLOPE)
             blocks = [self.resblocks[i * nk + j] for j in range(nk)]
             if nk <= 3 and mode != "chain":
                 steps = blocks[0].num_steps()

@@ -58,7 +58,8 @@ class _MelGANTrunk(NativeModule):
         mods = list(self.melgan)
         # index of the last module that owns a conv (gets dst + final_post)
         convy = [n for n, m in enumerate(mods)
-                 if isinstance(m, (torch.nn.Conv1d, torch.nn.ConvTranspose1d, ResidualStack, LastLayer))]
+                 if isinstance(m, (torch.nn.Conv1d, torch.nn.ConvTranspose1d, ResidualStack, LastLayer,
+                                   UpsampleLayer))]
         last = convy[-1]
         a, b = pb.tmp(), pb.tmp()
         scratch = [pb.tmp(), pb.tmp()]
@@ -77,9 +78,7 @@ class _MelGANTrunk(NativeModule):
             elif isinstance(m, LastLayer):
                 m.emit(pb, cur, nxt, post=post)
             elif isinstance(m, UpsampleLayer):
-                raise NotImplementedError(
-                    "transposedconv: False (UpsampleLayer) has no HIP kernel yet; every shipped "
-                    "conf/*.yaml uses transposedconv: True")
+                pb.upsample_conv(m, cur, nxt, pre_slope=pending_slope, post=post)
             elif isinstance(m, (torch.nn.LeakyReLU, torch.nn.ReLU)):
                 pending_slope = 0.0 if isinstance(m, torch.nn.ReLU) else float(m.negative_slope)
                 continue

@@ -232,18 +232,22 @@ class BasisSignalLayer(NativeModule):
         return out[:, 0, :]
 
 
-class UpsampleLayer(torch.nn.Module):
-    """Nearest-repeat + Conv1d upsampler (reference modules.py:160-177), chosen by
-    ``transposedconv: False``.  Every shipped conf/*.yaml sets ``True``; the
-    container exists so such checkpoints load, but no HIP kernel is built for it
-    yet and the generators refuse to run with it (no eager fallback)."""
+class UpsampleLayer(NativeModule):
+    """Nearest-repeat + Conv1d upsampler (reference modules.py:135-177: ``Stretch2d`` then
+    ``conv``), chosen by ``transposedconv: False``.  The repeated signal is never built:
+    taps that read the same input sample are summed when the weight is packed and the
+    layer runs as a short dense conv over ``out_channel * upsample_rate`` phase rows
+    (csrc/api.hip pack_upconv_kernel)."""
 
     def __init__(self, in_channel, out_channel, upsample_rate, kernel_size, stride, padding,
                  dilation=1, bias=True):
         super().__init__()
         self.upsample_rate = upsample_rate
+        self.in_channel = in_channel
         self.conv = torch.nn.Conv1d(in_channel, out_channel, kernel_size, stride, padding,
                                     dilation=dilation, bias=bias)
 
     def forward(self, x):
-        raise NotImplementedError("UpsampleLayer (transposedconv: False) has no HIP kernel yet")
+        x = self._prepare(x)
+        return self._plan("forward", lambda pb: pb.upsample_conv(self, SLOT_IN, SLOT_OUT),
+                          self.in_channel).run(x)

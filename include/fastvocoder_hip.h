@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FV_ABI_VERSION 3
+#define FV_ABI_VERSION 4
 
 #define FV_ERR_INVALID_ARG (-1)
 #define FV_ERR_UNSUPPORTED (-2)
@@ -121,6 +121,22 @@ int fv_conv_transpose1d_fused(const float* x, const float* packed, const float* 
                               int post, float act_slope, void* stream);
 
 /*
+ * y = post( conv1d( nearest_repeat(lrelu(x, pre_slope), rate); w, padding = pad ) + bias )
+ *
+ * Replaces the reference's UpsampleLayer (modules.py:160-177: Stretch2d nearest x rate,
+ * then Conv1d(k, padding)), selected by `transposedconv: False`.  The repeat is never
+ * materialised: taps that read the same input sample are summed at pack time
+ * (fv_pack_upsample_conv1d_weight) and the layer runs as a short dense conv over
+ * Cout*rate phase rows.  x [B,Cin,Tin] -> y [B,Cout,Tout], Tout = rate*Tin + 2*pad - (k-1).
+ */
+int64_t fv_packed_upsample_conv1d_floats(int Cout, int Cin, int k, int rate, int pad);
+int fv_pack_upsample_conv1d_weight(const float* w, float* packed, int Cout, int Cin, int k,
+                                   int rate, int pad, void* stream);
+int fv_upsample_conv1d_fused(const float* x, const float* packed, const float* bias, float* y,
+                             float* y_act, int B, int Cin, int Cout, int Tin, int k, int rate,
+                             int pad, float pre_slope, int post, float act_slope, void* stream);
+
+/*
  * PQMF.synthesis (model/generator/pqmf.py:121-135) in polyphase form.
  *   x [B,S,Tsub] sub-bands, h [S,ntaps] (= synthesis_filter[0]), y [B,S*Tsub].
  */
@@ -155,6 +171,10 @@ int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot, int y_
                                  const float* packed, const float* bias, int Cin, int Cout,
                                  int k, int stride, int pad, int out_pad, float pre_slope,
                                  int post, float act_slope);
+int fv_plan_add_upsample_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot,
+                                const float* packed, const float* bias, int Cin, int Cout,
+                                int k, int rate, int pad, float pre_slope, int post,
+                                float act_slope);
 int fv_plan_add_pqmf_synthesis(fv_plan_t* plan, int x_slot, int y_slot, const float* h,
                                int S, int ntaps);
 

@@ -46,6 +46,11 @@ SMALL = [
                                    use_weight_norm=False)),
     ("basis_s", "basis-melgan", dict(_M, L=30, out_channels=32, channels=[32, 32, 32],
                                      upsample_scales=[4, 4], transposedconv=True)),
+    # transposedconv: False -> UpsampleLayer (nearest repeat + conv), even and odd kernels
+    ("hifigan_up", "hifigan", dict(_H, transposedconv=False, upsample_rates=[8, 3],
+                                   upsample_initial_channel=64, upsample_kernel_sizes=[16, 7])),
+    ("basis_up", "basis-melgan", dict(_M, L=30, out_channels=32, channels=[32, 16, 32],
+                                      upsample_scales=[4, 3], transposedconv=False)),
 ]
 SMALL_T = 24
 SMALL_B = 3

@@ -96,8 +96,37 @@ def stats(y):
                 idx=idx, samples=y[idx].astype(np.float32), n=np.int64(y.size))
 
 
+def small_fixtures(out, only=None):
+    """Full-tensor fixtures of the shrunken configs (``only``: a set of tags)."""
+    for tag, name, cfg in cases.SMALL:
+        if only and tag not in only:
+            continue
+        m, sd = loaded(name, cfg, seed=7)
+        rec = {}
+        with torch.no_grad():
+            mel = seeded_mel(cases.SMALL_T, seed=5)
+            rec["inference"] = tonp(m.inference(mel))
+            melb = seeded_mel(cases.SMALL_T, seed=6, batch=cases.SMALL_B)
+            f = m(torch.from_numpy(melb))
+            if name == "basis-melgan":
+                rec["forward_src"], rec["forward_w"] = tonp(f[0]), tonp(f[1])
+            else:
+                rec["forward"] = tonp(f)
+            # weight norm removed must not change anything (SURVEY 8 a-13)
+            m.remove_weight_norm()
+            g = m(torch.from_numpy(melb))
+            g0 = g[0] if name == "basis-melgan" else g
+            f0 = f[0] if name == "basis-melgan" else f
+            assert np.abs(tonp(g0) - tonp(f0)).max() <= 1e-5
+        print(f"{tag:14s} inference {rec['inference'].shape} std={rec['inference'].std():.3f}")
+        np.savez_compressed(os.path.join(out, f"small_{tag}.npz"), **rec)
+
+
 def main():
     out = HERE
+    if len(sys.argv) > 2 and sys.argv[1] == "--small-only":
+        # regenerate only the named shrunken-config fixtures (leaves the rest untouched)
+        return small_fixtures(out, set(sys.argv[2].split(",")))
     keys = {}
     # ---- shipped yamls ------------------------------------------------------
     for tag, name, path in cases.SHIPPED:
@@ -143,26 +172,7 @@ def main():
         json.dump(keys, f, indent=0, sort_keys=True)
 
     # ---- shrunken configs: full tensors --------------------------------------
-    for tag, name, cfg in cases.SMALL:
-        m, sd = loaded(name, cfg, seed=7)
-        rec = {}
-        with torch.no_grad():
-            mel = seeded_mel(cases.SMALL_T, seed=5)
-            rec["inference"] = tonp(m.inference(mel))
-            melb = seeded_mel(cases.SMALL_T, seed=6, batch=cases.SMALL_B)
-            f = m(torch.from_numpy(melb))
-            if name == "basis-melgan":
-                rec["forward_src"], rec["forward_w"] = tonp(f[0]), tonp(f[1])
-            else:
-                rec["forward"] = tonp(f)
-            # weight norm removed must not change anything
-            m.remove_weight_norm()
-            g = m(torch.from_numpy(melb))
-            g0 = g[0] if name == "basis-melgan" else g
-            f0 = f[0] if name == "basis-melgan" else f
-            assert np.abs(tonp(g0) - tonp(f0)).max() <= 1e-5
-        print(f"{tag:14s} inference {rec['inference'].shape} std={rec['inference'].std():.3f}")
-        np.savez_compressed(os.path.join(out, f"small_{tag}.npz"), **rec)
+    small_fixtures(out)
 
     # ---- blocks ---------------------------------------------------------------
     rng = np.random.RandomState(11)

@@ -52,7 +52,7 @@ def _model(name, cfg, seed):
 
 def test_native_library_is_loaded():
     L = _native.lib()
-    assert L.fv_version() == 3
+    assert L.fv_version() == 4
     with open("/proc/self/maps") as f:
         assert "libfastvocoder_hip.so" in f.read()
 
@@ -128,6 +128,42 @@ def test_conv_transpose1d_fused_vs_oracle(case):
     y = _native.conv_transpose1d_fused(torch.from_numpy(x).to(dev), packed, torch.from_numpy(b).to(dev),
                                        Cout, k, s, p, op, pre_slope=0.1)
     assert _rel(y, ref) <= 2e-5
+
+
+UPCONV_CASES = [
+    # B, Cin, Cout, T, k, rate, pad   (HiFi-GAN: pad = k//2; MelGAN/Basis: k = 2*rate+1, pad = rate)
+    (1, 64, 32, 50, 16, 8, 8), (2, 32, 16, 41, 10, 5, 5), (1, 32, 16, 33, 7, 3, 3), (2, 16, 8, 40, 4, 2, 2),
+    (1, 32, 32, 60, 9, 4, 4), (1, 32, 16, 25, 21, 10, 10),
+    (1, 16, 16, 12, 5, 3, 0), (1, 16, 8, 9, 3, 4, 1),         # no padding; kernel shorter than rate
+]
+
+
+@pytest.mark.parametrize("case", UPCONV_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_upsample_conv1d_fused_vs_oracle(case):
+    """UpsampleLayer (nearest repeat x rate + Conv1d) as summed-phase weights vs the literal
+    repeat-then-convolve oracle (oracle/generators.py upsample_layer)."""
+    B, Cin, Cout, T, k, u, p = case
+    rng = np.random.RandomState(hash(case) % (2 ** 31))
+    x = rng.randn(B, Cin, T).astype(np.float32)
+    w = (rng.randn(Cout, Cin, k) / np.sqrt(Cin * k)).astype(np.float32)
+    b = rng.randn(Cout).astype(np.float32)
+    ref = oo.conv1d(np.repeat(x, u, axis=2), w, b, dil=1, pad=p, pre_slope=0.1)
+    dev = _dev()
+    packed = _native.pack_upsample_conv1d(torch.from_numpy(w).to(dev), u, p)
+    y = _native.upsample_conv1d_fused(torch.from_numpy(x).to(dev), packed, torch.from_numpy(b).to(dev),
+                                      Cout, k, u, p, pre_slope=0.1)
+    assert tuple(y.shape) == ref.shape
+    assert _rel(y, ref) <= 2e-5
+
+
+def test_upsample_layer_module_standalone():
+    from fastvocoder_amd.generator.modules import UpsampleLayer
+    torch.manual_seed(3)
+    layer = UpsampleLayer(24, 12, upsample_rate=5, kernel_size=11, stride=1, padding=5).to(_dev())
+    x = torch.randn(2, 24, 37)
+    ref = oo.conv1d(np.repeat(x.numpy(), 5, axis=2), layer.conv.weight.detach().cpu().numpy(),
+                    layer.conv.bias.detach().cpu().numpy(), dil=1, pad=5)
+    assert _rel(layer(x.to(_dev())), ref) <= 2e-5
 
 
 def test_activated_twin_outputs():

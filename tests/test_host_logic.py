@@ -73,8 +73,11 @@ def test_no_cpu_fallback():
 def test_unbuilt_variants_fail_loudly():
     with pytest.raises(NotImplementedError):
         fa.MelGANGenerator(use_causal_conv=True)
+    with pytest.raises(NotImplementedError):
+        fa.BasisMelGANGenerator(torch.zeros(30, 256), lastlinear=True)
+    # transposedconv: False keeps the reference's UpsampleLayer checkpoint keys
     m = fa.HiFiGANGenerator(transposedconv=False, upsample_initial_channel=32)
-    assert any(k.startswith("ups.0.conv.") for k in m.state_dict())   # checkpoint still loads
+    assert any(k.startswith("ups.0.conv.weight_v") for k in m.state_dict())
 
 
 def test_seeded_checkpoint_is_reproducible_and_gain_calibrated():
@@ -152,12 +155,45 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_native.LIB_PATH)
     for n in sorted(names):
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
-    assert _native.lib().fv_version() == 3
+    assert _native.lib().fv_version() == 4
     # host-only entry points that need no device
     assert _native.lib().fv_packed_conv1d_floats(128, 128, 11) == 128 * 11 * 128
     assert _native.lib().fv_packed_conv_transpose1d_floats(256, 128, 16, 8, 4) == 256 * 3 * 1024
     assert _native.lib().fv_packed_conv1d_floats(1, 16, 7) == 16 * 7 * 16      # rows padded to 16
     assert _native.lib().fv_last_error() is not None
+
+
+@pytest.mark.parametrize("k,u,p", [(16, 8, 8), (10, 5, 5), (7, 3, 3), (4, 2, 2), (9, 4, 4), (21, 10, 10),
+                                   (5, 3, 0), (3, 4, 1)])
+def test_summed_phase_form_of_upsample_layer(k, u, p):
+    """The identity behind fv_pack_upsample_conv1d_weight (api.hip pack_upconv_kernel,
+    fv_internal.h upsample_phases): nearest-repeat x u then Conv1d(k, padding p) == a
+    (dmax-dmin+1)-tap dense conv over Cout*u phase rows whose weights are the sums of the
+    taps that read the same input sample, then interleaving the phases in time."""
+    rng = np.random.RandomState(k * 100 + u)
+    cin, cout, T = 3, 2, 9
+    x = rng.randn(1, cin, T).astype(np.float32)
+    w = rng.randn(cout, cin, k).astype(np.float32)
+    ref = oo.conv1d(np.repeat(x, u, axis=2), w, None, dil=1, pad=p)
+    dmin, dmax = (-p) // u, (u - 1 + k - 1 - p) // u          # python // floors, like floor_div()
+    taps = dmax - dmin + 1
+    wp = np.zeros((cout * u, cin, taps), np.float32)
+    for co in range(cout):
+        for r in range(u):
+            for j in range(k):
+                wp[co * u + r, :, (r + j - p) // u - dmin] += w[co, :, j]
+    Tout = ref.shape[2]
+    assert Tout == u * T + 2 * p - (k - 1)
+    Tq = (Tout + u - 1) // u
+    out = np.zeros((1, cout, Tq * u), np.float64)
+    for q in range(Tq):
+        for jj in range(taps):
+            i = q + dmin + jj
+            if 0 <= i < T:
+                out[0, :, q * u:(q + 1) * u] += (wp[:, :, jj].astype(np.float64) @ x[0, :, i]).reshape(cout, u)
+    assert np.abs(out[:, :, :Tout] - ref).max() <= 1e-5
+    mpad = 16 if cout * u <= 16 else -(-cout * u // 32) * 32
+    assert _native.lib().fv_packed_upsample_conv1d_floats(cout, cin, k, u, p) == cin * taps * mpad
 
 
 def test_plan_shape_inference_without_gpu():
@@ -176,6 +212,12 @@ def test_plan_shape_inference_without_gpu():
     assert (c.value, n.value) == (1, 4 * (60 * 100 - 20))
     assert L.fv_plan_workspace_bytes(h, 2, 100) > 0
     assert L.fv_plan_num_ops(h) == 5
+    # UpsampleLayer: rate*T + 2*pad - (k-1)
+    u = L.fv_plan_create(8)
+    assert L.fv_plan_add_upsample_conv1d(u, 0, 1, -1, dummy, None, 8, 4, 16, 8, 8, 0.1, 0, 1.0) == 0
+    assert L.fv_plan_output_shape(u, 100, ctypes.byref(c), ctypes.byref(n)) == 0
+    assert (c.value, n.value) == (4, 801)
+    L.fv_plan_destroy(u)
     # channel mismatch is caught at shape-inference time with a message
     assert L.fv_plan_add_conv1d(h, 1, 5, -1, -1, -1, -1, dummy, None, 7, 4, 3, 1, 1, 0, 1.0, 1.0, 0, 1.0) == 0
     assert L.fv_plan_output_shape(h, 100, ctypes.byref(c), ctypes.byref(n)) != 0
