@@ -17,6 +17,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip"]
 
 PAD_ZERO, PAD_REFLECT = 0, 1
+PAD_CAUSAL = 2      # flag: pad (k-1)*dil on both sides, keep the first Tin outputs (CausalConv1d)
 POST_NONE, POST_TANH, POST_RELU = 0, 1, 2
 SLOT_NONE, SLOT_IN, SLOT_OUT, SLOT_TMP0, MAX_SLOTS = -1, 0, 1, 2, 32
 ABI_VERSION = 4
@@ -73,6 +74,7 @@ def lib():
     L.fv_conv1d_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, f, i, f, vp]
     L.fv_conv_transpose1d_fused.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, i, f, vp]
     L.fv_pqmf_synthesis.argtypes = [vp, vp, vp, i, i, i, i, vp]
+    L.fv_fold_batchnorm_conv.argtypes = [vp, vp, vp, vp, vp, vp, f, vp, vp, i, i, i, vp]
     L.fv_packed_upsample_conv1d_floats.argtypes = [i, i, i, i, i]
     L.fv_packed_upsample_conv1d_floats.restype = i64
     L.fv_pack_upsample_conv1d_weight.argtypes = [vp, vp, i, i, i, i, i, vp]
@@ -158,6 +160,22 @@ def pack_conv_transpose1d(w, stride, pad):
     return out
 
 
+def fold_batchnorm_conv(w, b, bn):
+    """Fold an eval-mode ``torch.nn.BatchNorm1d`` into the conv weight/bias that follow it;
+    returns (w', b') on w's device."""
+    w = w.detach().contiguous().float()
+    cout, cin, k = w.shape
+    w_out = torch.empty_like(w)
+    b_out = torch.empty(cout, dtype=torch.float32, device=w.device)
+    t = lambda a: None if a is None else a.detach().contiguous().float()  # noqa: E731
+    b, gamma, beta, mean, var = t(b), t(bn.weight), t(bn.bias), t(bn.running_mean), t(bn.running_var)
+    check(lib().fv_fold_batchnorm_conv(_ptr(w, "w"), _ptr(b, "b", True), _ptr(gamma, "gamma", True),
+                                       _ptr(beta, "beta", True), _ptr(mean, "running_mean"),
+                                       _ptr(var, "running_var"), float(bn.eps), _ptr(w_out), _ptr(b_out),
+                                       cout, cin, k, _stream()))
+    return w_out, b_out
+
+
 def pack_upsample_conv1d(w, rate, pad):
     """UpsampleLayer conv weight [Cout,Cin,k] -> packed phase image (flat tensor)."""
     w = w.detach().contiguous().float()
@@ -177,7 +195,7 @@ def conv1d_fused(x, packed, bias, cout, k, dil=1, pad=0, pad_mode=PAD_ZERO, pre_
                  act_slope=1.0, acc_in2=None):
     """One fused conv launch; ``out_act`` (optional) receives lrelu(out, act_slope)."""
     B, cin, T = x.shape
-    tout = T + 2 * pad - dil * (k - 1)
+    tout = T if pad_mode & PAD_CAUSAL else T + 2 * pad - dil * (k - 1)
     if out is None:
         out = torch.empty((B, cout, tout), dtype=torch.float32, device=x.device)
     check(lib().fv_conv1d_fused(_ptr(x, "x"), _ptr(packed, "packed"), _ptr(bias, "bias", True),

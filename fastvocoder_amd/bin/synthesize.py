@@ -39,7 +39,10 @@ def build_generator(model_name, config):
     if model_name == "basis-melgan":
         basis = torch.zeros(config["L"], config["out_channels"]).float()
         keys = ("L",) + _MELGAN_KEYS + ("transposedconv",)
-        return BasisMelGANGenerator(basis_signal_weight=basis, **{k: config[k] for k in keys})
+        # ``lastlinear`` is a constructor option the reference's launcher never forwards
+        # (basis_melgan.py:41); a yaml that names it gets it here
+        extra = {"lastlinear": config["lastlinear"]} if "lastlinear" in config else {}
+        return BasisMelGANGenerator(basis_signal_weight=basis, **{k: config[k] for k in keys}, **extra)
     raise Exception("no model find!")
 
 

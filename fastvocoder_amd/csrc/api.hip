@@ -77,6 +77,31 @@ __global__ __launch_bounds__(256) void fold_weight_norm_kernel(const float* __re
     for (int64_t i = threadIdx.x; i < inner; i += 256) w[(size_t)r * inner + i] = vr[i] * scale;
 }
 
+// Eval-mode BatchNorm folded into the conv after it; one block per output channel:
+// w'[co,ci,j] = w * a[ci], b'[co] = b + sum w * c[ci]  (a = gamma/sqrt(var+eps), c = beta - mean*a).
+__global__ __launch_bounds__(256) void fold_batchnorm_conv_kernel(
+    const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var,
+    float eps, float* __restrict__ w_out, float* __restrict__ b_out, int Cin, int k) {
+    __shared__ float part[4];
+    const int co = blockIdx.x;
+    const int inner = Cin * k;
+    float shift = 0.f;
+    for (int i = threadIdx.x; i < inner; i += 256) {
+        const int ci = i / k;
+        const float a = (gamma ? gamma[ci] : 1.f) / sqrtf(var[ci] + eps);
+        const float c = (beta ? beta[ci] : 0.f) - mean[ci] * a;
+        const float wv = w[(size_t)co * inner + i];
+        w_out[(size_t)co * inner + i] = wv * a;
+        shift = fmaf(wv, c, shift);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) shift += __shfl_down(shift, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = shift;
+    __syncthreads();
+    if (threadIdx.x == 0) b_out[co] = (b ? b[co] : 0.f) + ((part[0] + part[1]) + (part[2] + part[3]));
+}
+
 // Conv1d weight [Cout, Cin, k] -> Wp[(ci*k + j)][Mpad], zero in the pad rows.
 __global__ void pack_conv1d_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
                                    int Cin, int k, int Mpad) {
@@ -194,7 +219,8 @@ struct fv_plan {
 namespace fv {
 
 static int64_t conv_out_len(const Op& o, int64_t Tin) {
-    if (o.type == OP_CONV) return Tin + 2LL * o.pad - (int64_t)o.dil * (o.k - 1);
+    if (o.type == OP_CONV)
+        return (o.pad_mode & FV_PAD_CAUSAL) ? Tin : Tin + 2LL * o.pad - (int64_t)o.dil * (o.k - 1);
     if (o.type == OP_CONVT) return (Tin - 1) * o.stride - 2LL * o.pad + o.k + o.out_pad;
     if (o.type == OP_UPCONV) return Tin * o.stride + 2LL * o.pad - (o.k - 1);
     return Tin * o.Cin;  // PQMF: S sub-bands interleave into S*Tsub samples
@@ -252,7 +278,7 @@ static ConvParams make_params(const Op& o, const float* x, float* y, float* y2, 
     p.Cin = o.Cin;
     p.Cout = o.Cout;
     p.Tin = (int)Tin;
-    p.pad_mode = o.pad_mode;
+    p.pad_mode = o.pad_mode & ~FV_PAD_CAUSAL;
     p.pre_slope = o.pre_slope;
     p.out_div = o.out_div;
     p.post = o.post;
@@ -354,6 +380,17 @@ static int compile_lanes(fv_plan* plan) {
     return 0;
 }
 
+// CausalConv1d keeps the first Tin outputs of a conv padded on both sides: only a pad of
+// at least (k-1)*dil - which makes that many outputs exist - is meaningful.
+static int check_pad_mode(int pad_mode, int pad, int k, int dil) {
+    if (pad_mode < 0 || pad_mode > (FV_PAD_REFLECT | FV_PAD_CAUSAL))
+        return fail(FV_ERR_INVALID_ARG, "unknown pad_mode %d", pad_mode);
+    if ((pad_mode & FV_PAD_CAUSAL) && 2LL * pad < (int64_t)dil * (k - 1))
+        return fail(FV_ERR_INVALID_ARG, "causal conv: pad=%d leaves fewer than Tin outputs (k=%d dil=%d)",
+                    pad, k, dil);
+    return 0;
+}
+
 static int check_conv_args(int Cin, int Cout, int k, int dil) {
     if (Cin <= 0 || Cout <= 0 || k <= 0 || dil <= 0)
         return fail(FV_ERR_INVALID_ARG, "bad conv shape Cin=%d Cout=%d k=%d dil=%d", Cin, Cout, k, dil);
@@ -375,6 +412,17 @@ int fv_fold_weight_norm(const float* v, const float* g, float* w, int dim0, int6
     if (dim0 <= 0 || inner <= 0) return fail(FV_ERR_INVALID_ARG, "fold: dim0=%d inner=%lld", dim0, (long long)inner);
     hipLaunchKernelGGL(fold_weight_norm_kernel, dim3(dim0), dim3(256), 0, (hipStream_t)stream, v, g,
                        w, inner);
+    FV_HIP(hipGetLastError());
+    return 0;
+}
+
+int fv_fold_batchnorm_conv(const float* w, const float* b, const float* gamma, const float* beta,
+                           const float* mean, const float* var, float eps, float* w_out, float* b_out,
+                           int Cout, int Cin, int k, void* stream) {
+    if (int rc = check_conv_args(Cin, Cout, k, 1)) return rc;
+    if (!w || !mean || !var || !w_out || !b_out) return fail(FV_ERR_INVALID_ARG, "fold_batchnorm: null tensor");
+    hipLaunchKernelGGL(fold_batchnorm_conv_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, w, b,
+                       gamma, beta, mean, var, eps, w_out, b_out, Cin, k);
     FV_HIP(hipGetLastError());
     return 0;
 }
@@ -472,6 +520,7 @@ int fv_conv1d_fused(const float* x, const float* packed, const float* bias, cons
                     int Cout, int Tin, int k, int dil, int pad, int pad_mode, float pre_slope,
                     float out_div, int post, float act_slope, void* stream) {
     if (int rc = check_conv_args(Cin, Cout, k, dil)) return rc;
+    if (int rc = check_pad_mode(pad_mode, pad, k, dil)) return rc;
     if (!x || !packed || !y) return fail(FV_ERR_INVALID_ARG, "conv1d: null tensor");
     if (x == y || x == y_act || (y_act && y_act == y))
         return fail(FV_ERR_INVALID_ARG, "conv1d: y / y_act must not alias x or each other");
@@ -548,6 +597,7 @@ int fv_plan_add_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, 
                        int post, float act_slope) {
     if (!plan || !packed) return fail(FV_ERR_INVALID_ARG, "plan_add_conv1d: null");
     if (int rc = check_conv_args(Cin, Cout, k, dil)) return rc;
+    if (int rc = check_pad_mode(pad_mode, pad, k, dil)) return rc;
     if (int rc = check_slot(x_slot, false)) return rc;
     if (int rc = check_slot(y_slot, false)) return rc;
     if (int rc = check_slot(res_slot, true)) return rc;

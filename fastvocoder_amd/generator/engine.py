@@ -14,7 +14,7 @@ import warnings
 import torch
 
 from .. import _native
-from .._native import (PAD_REFLECT, PAD_ZERO, POST_NONE, POST_RELU, POST_TANH,  # noqa: F401
+from .._native import (PAD_CAUSAL, PAD_REFLECT, PAD_ZERO, POST_NONE, POST_RELU, POST_TANH,  # noqa: F401
                        SLOT_IN, SLOT_NONE, SLOT_OUT)
 
 
@@ -77,16 +77,23 @@ class PlanBuilder:
         self.group = 0
 
     def conv(self, conv, src, dst, pad=None, pad_mode=PAD_ZERO, pre_slope=1.0, res=SLOT_NONE,
-             acc=SLOT_NONE, out_div=1.0, post=POST_NONE, acc2=SLOT_NONE):
-        """Record ``conv`` (a torch.nn.Conv1d container): dst = epilogue(conv(act(src)))."""
+             acc=SLOT_NONE, out_div=1.0, post=POST_NONE, acc2=SLOT_NONE, batchnorm=None):
+        """Record ``conv`` (a torch.nn.Conv1d container): dst = epilogue(conv(bn(act(src)))).
+        ``batchnorm`` (an eval-mode BatchNorm1d container applied to the conv's input) is
+        folded into the weight and bias (fv_fold_batchnorm_conv)."""
         if conv.stride[0] != 1 or conv.groups != 1:
             raise _native.NativeError("only stride-1, groups-1 Conv1d layers exist on this path")
         k, d = conv.kernel_size[0], conv.dilation[0]
         if pad is None:
             pad = conv.padding[0]
+        weight, bias = effective_weight(conv), self._bias(conv)
+        if batchnorm is not None:
+            if pad != 0:
+                raise _native.NativeError("BatchNorm folds only into an unpadded conv")
+            weight, bias = _native.fold_batchnorm_conv(weight, bias, batchnorm)
         self.ops.append(dict(kind="conv", lane=self.lane, group=self.group, x=src, y=dst, res=res, acc=acc,
                              acc2=acc2, pre_slope=float(pre_slope),
-                             packed=_native.pack_conv1d(effective_weight(conv)), bias=self._bias(conv),
+                             packed=_native.pack_conv1d(weight), bias=bias,
                              cin=conv.in_channels, cout=conv.out_channels, k=k, dil=d, pad=pad,
                              pad_mode=pad_mode, out_div=out_div, post=post))
 
@@ -227,6 +234,15 @@ class NativeModule(torch.nn.Module):
         for m in self.modules():
             if isinstance(m, NativeModule):
                 m.invalidate_plans()
+        return out
+
+    def train(self, mode=True):
+        changed = any(m.training != mode for m in self.modules())
+        out = super().train(mode)
+        if changed:                      # eval-mode-only layers (BatchNorm) are baked into plans
+            for m in self.modules():
+                if isinstance(m, NativeModule):
+                    m.invalidate_plans()
         return out
 
     def _device(self):

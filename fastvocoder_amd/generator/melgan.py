@@ -11,7 +11,7 @@ it is a parameter container only -- calls go through native plans.
 import torch
 
 from .engine import NativeModule, POST_NONE, POST_RELU, POST_TANH, SLOT_IN, SLOT_OUT
-from .modules import (BasisSignalLayer, LastLayer, ResidualStack, UpsampleLayer,
+from .modules import (BasisSignalLayer, LastLayer, LastLinear, ResidualStack, UpsampleLayer,
                       _activation_slope, _pad_mode)
 
 
@@ -22,11 +22,8 @@ class _MelGANTrunk(NativeModule):
                       stack_kernel_size, stacks, nonlinear_activation,
                       nonlinear_activation_params, pad, pad_params, use_causal_conv,
                       transposedconv=True):
-        if use_causal_conv:
-            raise NotImplementedError(
-                "use_causal_conv=True is not built: no shipped conf/*.yaml enables it "
-                "(SURVEY.md section 2, row 5)")
-        assert (kernel_size - 1) % 2 == 0, "Not support even number kernel size."
+        if not use_causal_conv:
+            assert (kernel_size - 1) % 2 == 0, "Not support even number kernel size."
         self._slope = _activation_slope(nonlinear_activation, nonlinear_activation_params)
         self._first_pad = ((kernel_size - 1) // 2, _pad_mode(pad, pad_params))
         self._in_channels = in_channels
@@ -59,7 +56,7 @@ class _MelGANTrunk(NativeModule):
         # index of the last module that owns a conv (gets dst + final_post)
         convy = [n for n, m in enumerate(mods)
                  if isinstance(m, (torch.nn.Conv1d, torch.nn.ConvTranspose1d, ResidualStack, LastLayer,
-                                   UpsampleLayer))]
+                                   UpsampleLayer, LastLinear))]
         last = convy[-1]
         a, b = pb.tmp(), pb.tmp()
         scratch = [pb.tmp(), pb.tmp()]
@@ -79,6 +76,8 @@ class _MelGANTrunk(NativeModule):
                 m.emit(pb, cur, nxt, post=post)
             elif isinstance(m, UpsampleLayer):
                 pb.upsample_conv(m, cur, nxt, pre_slope=pending_slope, post=post)
+            elif isinstance(m, LastLinear):
+                m.emit(pb, cur, nxt, scratch, post=post)
             elif isinstance(m, (torch.nn.LeakyReLU, torch.nn.ReLU)):
                 pending_slope = 0.0 if isinstance(m, torch.nn.ReLU) else float(m.negative_slope)
                 continue
@@ -138,13 +137,12 @@ class BasisMelGANGenerator(_MelGANTrunk):
                  pad_params={}, use_final_nonlinear_activation=True, use_weight_norm=True,
                  use_causal_conv=False, transposedconv=True, lastlinear=False):
         super().__init__()
-        if lastlinear:
-            raise NotImplementedError("lastlinear=True (BatchNorm head, reference modules.py:116-132) "
-                                      "is used by no shipped config and is not built")
         layers = self._build_layers(in_channels, kernel_size, channels, bias, upsample_scales,
                                     stack_kernel_size, stacks, nonlinear_activation,
                                     nonlinear_activation_params, pad, pad_params, use_causal_conv,
                                     transposedconv)
+        if lastlinear:
+            layers.append(LastLinear(channels[-1], out_channels, bias=bias))
         self._final_post = POST_RELU if use_final_nonlinear_activation else POST_NONE
         if use_final_nonlinear_activation:
             layers.append(torch.nn.ReLU())

@@ -8,7 +8,7 @@ device): it then runs a private plan SLOT_IN -> SLOT_OUT.
 """
 import torch
 
-from .engine import (NativeModule, PAD_REFLECT, PAD_ZERO, POST_NONE, SLOT_IN, SLOT_NONE,
+from .engine import (NativeModule, PAD_CAUSAL, PAD_REFLECT, PAD_ZERO, POST_NONE, SLOT_IN, SLOT_NONE,
                      SLOT_OUT)
 from .. import _native
 
@@ -144,33 +144,59 @@ def _pad_mode(name, params):
                               "kernels (ReflectionPad1d / zero ConstantPad1d are)")
 
 
+class CausalConv1d(torch.nn.Module):
+    """Parameter container with the reference's layout (modules.py:273-294): ``pad`` module +
+    ``conv``; checkpoint keys ``<prefix>.conv.*``.  Semantics: pad (k-1)*dil on BOTH sides
+    with the configured pad module, valid conv, keep the first T outputs -- one
+    FV_PAD_CAUSAL conv launch here."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, dilation=1, bias=True,
+                 pad="ConstantPad1d", pad_params={"value": 0.0}):
+        super().__init__()
+        self.pad_amount = (kernel_size - 1) * dilation
+        self.pad_mode = _pad_mode(pad, pad_params)
+        self.pad = getattr(torch.nn, pad)(self.pad_amount, **pad_params)
+        self.conv = torch.nn.Conv1d(in_channels, out_channels, kernel_size, dilation=dilation,
+                                    bias=bias)
+
+
 class ResidualStack(_Block):
     """MelGAN residual stack (reference modules.py:320-382):
     ``conv1x1(act(conv_k_dilated(pad(act(c))))) + skip1x1(c)``.
-    ``stack`` keeps the reference's Sequential indices (conv at .2 and .4)."""
+    ``stack`` keeps the reference's Sequential indices: conv at .2 and .4, or, with
+    ``use_causal_conv``, a CausalConv1d at .1 (keys ``stack.1.conv.*``) and the 1x1 at .3."""
 
     def __init__(self, kernel_size=3, channels=32, dilation=1, bias=True,
                  nonlinear_activation="LeakyReLU",
                  nonlinear_activation_params={"negative_slope": 0.2},
                  pad="ReflectionPad1d", pad_params={}, use_causal_conv=False):
         super().__init__()
-        if use_causal_conv:
-            raise NotImplementedError(
-                "use_causal_conv=True is not built: no shipped conf/*.yaml enables it "
-                "(SURVEY.md section 2, row 5)")
-        assert (kernel_size - 1) % 2 == 0, "Not support even number kernel size."
         self.channels = channels
         self._slope = _activation_slope(nonlinear_activation, nonlinear_activation_params)
         self._pad_mode = _pad_mode(pad, pad_params)
-        self._pad = (kernel_size - 1) // 2 * dilation
         act = getattr(torch.nn, nonlinear_activation)
-        self.stack = torch.nn.Sequential(
-            act(**nonlinear_activation_params),
-            getattr(torch.nn, pad)(self._pad, **pad_params),
-            torch.nn.Conv1d(channels, channels, kernel_size, dilation=dilation, bias=bias),
-            act(**nonlinear_activation_params),
-            torch.nn.Conv1d(channels, channels, 1, bias=bias),
-        )
+        if not use_causal_conv:
+            assert (kernel_size - 1) % 2 == 0, "Not support even number kernel size."
+            self._pad = (kernel_size - 1) // 2 * dilation
+            self.stack = torch.nn.Sequential(
+                act(**nonlinear_activation_params),
+                getattr(torch.nn, pad)(self._pad, **pad_params),
+                torch.nn.Conv1d(channels, channels, kernel_size, dilation=dilation, bias=bias),
+                act(**nonlinear_activation_params),
+                torch.nn.Conv1d(channels, channels, 1, bias=bias),
+            )
+            self._conv_at = (2, 4)
+        else:
+            self._pad = (kernel_size - 1) * dilation
+            self._pad_mode |= PAD_CAUSAL
+            self.stack = torch.nn.Sequential(
+                act(**nonlinear_activation_params),
+                CausalConv1d(channels, channels, kernel_size, dilation=dilation, bias=bias, pad=pad,
+                             pad_params=pad_params),
+                act(**nonlinear_activation_params),
+                torch.nn.Conv1d(channels, channels, 1, bias=bias),
+            )
+            self._conv_at = (1, 3)
         self.skip_layer = torch.nn.Conv1d(channels, channels, 1, bias=bias)
 
     def scratch_slots(self):
@@ -178,10 +204,46 @@ class ResidualStack(_Block):
 
     def emit(self, pb, src, dst, scratch, post=POST_NONE):
         hidden, skip = scratch[:2]
-        pb.conv(self.stack[2], src, hidden, pad=self._pad, pad_mode=self._pad_mode,
-                pre_slope=self._slope)
+        dilated, pointwise = (self.stack[i] for i in self._conv_at)
+        dilated = getattr(dilated, "conv", dilated)               # CausalConv1d wraps its conv
+        pb.conv(dilated, src, hidden, pad=self._pad, pad_mode=self._pad_mode, pre_slope=self._slope)
         pb.conv(self.skip_layer, src, skip)                       # un-activated input
-        pb.conv(self.stack[4], hidden, dst, pre_slope=self._slope, res=skip, post=post)
+        pb.conv(pointwise, hidden, dst, pre_slope=self._slope, res=skip, post=post)
+
+
+class LastLinear(NativeModule):
+    """Basis-MelGAN's optional head (reference modules.py:116-132, ``lastlinear: True``):
+    LeakyReLU(0.2) -> BatchNorm1d -> conv1x1 -> LeakyReLU(0.2) -> BatchNorm1d -> conv1x1.
+    Inference only: in eval mode each BatchNorm is a per-channel affine map and is folded
+    into the 1x1 conv behind it when the plan is built (fv_fold_batchnorm_conv), leaving two
+    conv launches.  Train-mode BatchNorm (batch statistics) belongs to training, which this
+    library does not do: it raises."""
+
+    def __init__(self, hidden_channel, out_channel, bias=True):
+        super().__init__()
+        self.hidden_channel = hidden_channel
+        self.activation = torch.nn.LeakyReLU(negative_slope=0.2)
+        self.bn_1 = torch.nn.BatchNorm1d(hidden_channel)
+        self.linear_1 = torch.nn.Conv1d(hidden_channel, hidden_channel, 1, bias=bias)
+        self.bn_2 = torch.nn.BatchNorm1d(hidden_channel)
+        self.linear_2 = torch.nn.Conv1d(hidden_channel, out_channel, 1, bias=bias)
+        for conv in (self.linear_1, self.linear_2):                # reference Conv1d1x1 init
+            torch.nn.init.kaiming_normal_(conv.weight, nonlinearity="relu")
+            if conv.bias is not None:
+                torch.nn.init.constant_(conv.bias, 0.0)
+
+    def emit(self, pb, src, dst, scratch, post=POST_NONE):
+        if self.bn_1.training or self.bn_2.training:
+            raise _native.NativeError(
+                "LastLinear: BatchNorm1d in train mode uses batch statistics, which only training "
+                "needs; call .eval() (the synthesize/test flows do)")
+        pb.conv(self.linear_1, src, scratch[0], pre_slope=0.2, batchnorm=self.bn_1)
+        pb.conv(self.linear_2, scratch[0], dst, pre_slope=0.2, batchnorm=self.bn_2, post=post)
+
+    def forward(self, x):
+        x = self._prepare(x)
+        return self._plan("forward", lambda pb: self.emit(pb, SLOT_IN, SLOT_OUT, [pb.tmp()]),
+                          self.hidden_channel).run(x)
 
 
 class LastLayer(NativeModule):

@@ -31,6 +31,15 @@ def _conv(spec, prefix, cout, cin, k, bias, wn):
         spec.append((prefix + ".weight_v", (cout, cin, k), ("v", cin * k)))
 
 
+def _batchnorm(spec, prefix, c):
+    """torch.nn.BatchNorm1d(c) keys, with non-trivial statistics so the fold is exercised."""
+    spec.append((prefix + ".weight", (c,), ("u", 0.7, 1.3)))
+    spec.append((prefix + ".bias", (c,), ("u", -0.2, 0.2)))
+    spec.append((prefix + ".running_mean", (c,), ("u", -0.3, 0.3)))
+    spec.append((prefix + ".running_var", (c,), ("u", 0.5, 1.5)))
+    spec.append((prefix + ".num_batches_tracked", (), ("count",)))
+
+
 def _convT(spec, prefix, cin, cout, k, stride, bias, wn):
     """torch.nn.ConvTranspose1d(cin, cout, k) keys; weight [cin,cout,k], g per INPUT channel."""
     fan = max(1, cin * k // stride)
@@ -77,7 +86,7 @@ def state_dict_spec(model_name, cfg, weight_norm=True):
             spec.append(("pqmf.updown_filter", (4, 4, 4), ("pqmf", "updown")))
         return spec
     if model_name in ("melgan", "basis-melgan"):
-        assert not cfg.get("use_causal_conv", False), "causal variants are not generated"
+        causal = cfg.get("use_causal_conv", False)
         bias = cfg.get("bias", True)
         wn = weight_norm and cfg.get("use_weight_norm", True)
         K = cfg.get("kernel_size", 7)
@@ -95,13 +104,22 @@ def state_dict_spec(model_name, cfg, weight_norm=True):
             idx += 1
             for _ in range(stacks):
                 c = ch[i + 1]
-                _conv(spec, f"melgan.{idx}.stack.2", c, c, sk, bias, wn)
-                _conv(spec, f"melgan.{idx}.stack.4", c, c, 1, bias, wn)
+                if causal:      # CausalConv1d at stack.1 (owns .conv), 1x1 at stack.3
+                    _conv(spec, f"melgan.{idx}.stack.1.conv", c, c, sk, bias, wn)
+                    _conv(spec, f"melgan.{idx}.stack.3", c, c, 1, bias, wn)
+                else:
+                    _conv(spec, f"melgan.{idx}.stack.2", c, c, sk, bias, wn)
+                    _conv(spec, f"melgan.{idx}.stack.4", c, c, 1, bias, wn)
                 _conv(spec, f"melgan.{idx}.skip_layer", c, c, 1, bias, wn)
                 idx += 1
         if model_name == "melgan":
             _conv(spec, f"melgan.{idx}.conv", cfg.get("out_channels", 1), ch[-1], K, bias, wn)
         else:
+            if cfg.get("lastlinear", False):     # LastLinear head (modules.py:116-132)
+                h, o = ch[-1], cfg.get("out_channels", 256)
+                for n, cout in (("1", h), ("2", o)):
+                    _batchnorm(spec, f"melgan.{idx}.bn_{n}", h)
+                    _conv(spec, f"melgan.{idx}.linear_{n}", cout, h, 1, bias, wn)
             spec.append(("basis_signal.layer.weight", (cfg.get("L", 30), cfg.get("out_channels", 256)),
                          ("basis", cfg.get("out_channels", 256))))
         return spec
@@ -124,6 +142,10 @@ def seeded_state_dict(model_name, cfg, seed=0, gain=None, weight_norm=True):
             sd[key] = rng.uniform(-bound, bound, size=shape).astype(np.float32)
             if key.endswith(".weight_v"):
                 vs[key[: -len(".weight_v")]] = sd[key]
+        elif tag == "u":
+            sd[key] = rng.uniform(kind[1], kind[2], size=shape).astype(np.float32)
+        elif tag == "count":
+            sd[key] = np.array(1000, dtype=np.int64)
         elif tag == "basis":
             bound = 0.35 / np.sqrt(kind[1])
             sd[key] = rng.uniform(-bound, bound, size=shape).astype(np.float32)

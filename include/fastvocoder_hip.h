@@ -41,6 +41,10 @@ extern "C" {
  * (torch.nn.ReflectionPad1d, modules.py:355-356, melgan.py:68-71) */
 #define FV_PAD_ZERO 0
 #define FV_PAD_REFLECT 1
+/* flag ORed into pad_mode: keep only the first Tin outputs (the reference's CausalConv1d,
+ * modules.py:273-294: pad (k-1)*dil on BOTH sides with the configured pad module, valid
+ * conv, then [:, :, :T]); pass pad = (k-1)*dil */
+#define FV_PAD_CAUSAL 2
 
 /* activation applied after the epilogue adds */
 #define FV_POST_NONE 0
@@ -60,6 +64,17 @@ const char* fv_last_error(void);
  * INPUT channel).  v, w: [dim0, inner]; g: [dim0]. */
 int fv_fold_weight_norm(const float* v, const float* g, float* w, int dim0,
                         int64_t inner, void* stream);
+
+/* Eval-mode BatchNorm1d folded into the 1x1/short conv that FOLLOWS it (LastLinear,
+ * modules.py:116-132: act -> bn -> conv1x1):  conv(bn(x)) = conv'(x) with
+ *   w'[co,ci,j] = w[co,ci,j] * a[ci],  b'[co] = b[co] + sum_{ci,j} w[co,ci,j] * c[ci],
+ *   a = gamma / sqrt(var + eps),  c = beta - mean * a.
+ * w [Cout,Cin,k]; b [Cout] or NULL (treated as 0); gamma/beta may be NULL (1 / 0);
+ * w_out [Cout,Cin,k], b_out [Cout] (always written).  Exact only for valid / unpadded
+ * convs (LastLinear's are 1x1). */
+int fv_fold_batchnorm_conv(const float* w, const float* b, const float* gamma, const float* beta,
+                           const float* mean, const float* var, float eps, float* w_out,
+                           float* b_out, int Cout, int Cin, int k, void* stream);
 
 /* Number of floats of the packed (K-major, M-padded) image of a Conv1d weight
  * [Cout, Cin, k] / of the polyphase image of a ConvTranspose1d weight
@@ -89,7 +104,7 @@ int fv_pack_conv_transpose1d_weight(const float* w, float* packed, int Cin, int 
  *   x [B,Cin,Tin]; packed from fv_pack_conv1d_weight; bias [Cout] or NULL;
  *   res, acc_in, acc_in2 [B,Cout,Tout] or NULL (acc_in + acc_in2 is formed first: the
  *   reference's xs = r0; xs += r1; xs += r2 order, hifigan.py:99-102); y [B,Cout,Tout],
- *   Tout = Tin + 2*pad - dil*(k-1).  pre_slope = 1 disables the input
+ *   Tout = Tin + 2*pad - dil*(k-1) (Tin with FV_PAD_CAUSAL).  pre_slope = 1 disables the input
  *   activation, 0 is ReLU; out_div = 1 disables the division (it is a true
  *   fp32 division, hifigan.py:103).  y may alias res or acc_in, never x.
  *   Activation hoisting: plain VALU work does not overlap the fp32 MFMA on gfx950,

@@ -159,14 +159,39 @@ def pqmf_filters(subbands=4, taps=62, cutoff_ratio=0.142, beta=9.0):
 # MelGAN family
 # --------------------------------------------------------------------------
 
-def residual_stack(x, sd, prefix, k, d):
-    """ResidualStack.forward (modules.py:372-382): stack(c) + skip_layer(c)."""
-    h = ops.conv1d(x, weight_of(sd, prefix + ".stack.2"), bias_of(sd, prefix + ".stack.2"),
-                   dil=d, pad=(k - 1) // 2 * d, pad_mode=ops.PAD_REFLECT, pre_slope=MELGAN_SLOPE)
-    h = ops.conv1d(h, weight_of(sd, prefix + ".stack.4"), bias_of(sd, prefix + ".stack.4"),
-                   pre_slope=MELGAN_SLOPE)
+def residual_stack(x, sd, prefix, k, d, causal=False):
+    """ResidualStack.forward (modules.py:372-382): stack(c) + skip_layer(c).  With
+    ``use_causal_conv`` the dilated conv is a CausalConv1d (modules.py:273-294): the
+    configured pad module -- ReflectionPad1d, both sides -- by (k-1)*d, valid conv, then
+    ``[:, :, :T]``; it sits at stack.1 (its conv at .conv) and the 1x1 at stack.3."""
+    if causal:
+        h = ops.conv1d(x, weight_of(sd, prefix + ".stack.1.conv"), bias_of(sd, prefix + ".stack.1.conv"),
+                       dil=d, pad=(k - 1) * d, pad_mode=ops.PAD_REFLECT, pre_slope=MELGAN_SLOPE)
+        h = np.ascontiguousarray(h[:, :, : x.shape[2]])
+        pw = prefix + ".stack.3"
+    else:
+        h = ops.conv1d(x, weight_of(sd, prefix + ".stack.2"), bias_of(sd, prefix + ".stack.2"),
+                       dil=d, pad=(k - 1) // 2 * d, pad_mode=ops.PAD_REFLECT, pre_slope=MELGAN_SLOPE)
+        pw = prefix + ".stack.4"
+    h = ops.conv1d(h, weight_of(sd, pw), bias_of(sd, pw), pre_slope=MELGAN_SLOPE)
     s = ops.conv1d(x, weight_of(sd, prefix + ".skip_layer"), bias_of(sd, prefix + ".skip_layer"))
     return h + s
+
+
+def batchnorm_eval(x, sd, prefix, eps=1e-5):
+    """torch.nn.BatchNorm1d in eval mode: (x - running_mean) / sqrt(running_var + eps) * weight + bias
+    per channel, in float64 then rounded once to fp32."""
+    g, b = (_np(sd[prefix + k]).astype(np.float64)[None, :, None] for k in (".weight", ".bias"))
+    m, v = (_np(sd[prefix + k]).astype(np.float64)[None, :, None] for k in (".running_mean", ".running_var"))
+    return ((x.astype(np.float64) - m) / np.sqrt(v + eps) * g + b).astype(np.float32)
+
+
+def last_linear(x, sd, prefix):
+    """LastLinear.forward (modules.py:125-132): act, bn_1, linear_1, act, bn_2, linear_2."""
+    for n in ("1", "2"):
+        x = batchnorm_eval(ops.lrelu(x, MELGAN_SLOPE), sd, f"{prefix}.bn_{n}")
+        x = ops.conv1d(x, weight_of(sd, f"{prefix}.linear_{n}"), bias_of(sd, f"{prefix}.linear_{n}"))
+    return x
 
 
 def melgan_trunk(x, sd, cfg, with_last=True, taps=None):
@@ -193,8 +218,10 @@ def melgan_trunk(x, sd, cfg, with_last=True, taps=None):
             taps.append(x.copy())
         idx += 1
         for j in range(stacks):
-            x = residual_stack(x, sd, f"melgan.{idx}", sk, sk ** j)
+            x = residual_stack(x, sd, f"melgan.{idx}", sk, sk ** j, cfg.get("use_causal_conv", False))
             idx += 1
+    if not with_last and cfg.get("lastlinear", False):
+        x = last_linear(x, sd, f"melgan.{idx}")          # Basis-MelGAN's optional head
     if with_last:
         # LastLayer (modules.py:76-89)
         x = ops.conv1d(x, weight_of(sd, f"melgan.{idx}.conv"), bias_of(sd, f"melgan.{idx}.conv"),

@@ -125,12 +125,19 @@ def overlap_and_add(signal, frame_step):
     return res.view(*outer, -1)
 
 
-def _residual_stack(x, sd, p, k, d):
+def _residual_stack(x, sd, p, k, d, causal=False):
     h = F.leaky_relu(x, MELGAN_SLOPE)
-    h = F.pad(h, ((k - 1) // 2 * d,) * 2, mode="reflect")
-    h = F.conv1d(h, weight_of(sd, p + ".stack.2"), bias_of(sd, p + ".stack.2"), dilation=d)
+    if causal:                          # CausalConv1d, modules.py:273-294
+        h = F.pad(h, ((k - 1) * d,) * 2, mode="reflect")
+        h = F.conv1d(h, weight_of(sd, p + ".stack.1.conv"), bias_of(sd, p + ".stack.1.conv"),
+                     dilation=d)[:, :, : x.size(2)]
+        pw = p + ".stack.3"
+    else:
+        h = F.pad(h, ((k - 1) // 2 * d,) * 2, mode="reflect")
+        h = F.conv1d(h, weight_of(sd, p + ".stack.2"), bias_of(sd, p + ".stack.2"), dilation=d)
+        pw = p + ".stack.4"
     h = F.leaky_relu(h, MELGAN_SLOPE)
-    h = F.conv1d(h, weight_of(sd, p + ".stack.4"), bias_of(sd, p + ".stack.4"))
+    h = F.conv1d(h, weight_of(sd, pw), bias_of(sd, pw))
     return h + F.conv1d(x, weight_of(sd, p + ".skip_layer"), bias_of(sd, p + ".skip_layer"))
 
 
@@ -151,8 +158,15 @@ def melgan_trunk(x, sd, cfg, with_last=True):
             x = _upsample_layer(x, sd, f"melgan.{idx}", s, 2 * s + 1)
         idx += 1
         for j in range(stacks):
-            x = _residual_stack(x, sd, f"melgan.{idx}", sk, sk ** j)
+            x = _residual_stack(x, sd, f"melgan.{idx}", sk, sk ** j, cfg.get("use_causal_conv", False))
             idx += 1
+    if not with_last and cfg.get("lastlinear", False):   # LastLinear, modules.py:116-132
+        for n in ("1", "2"):
+            q = f"melgan.{idx}.bn_{n}"
+            x = F.batch_norm(F.leaky_relu(x, MELGAN_SLOPE), _t(sd[q + ".running_mean"]).float(),
+                             _t(sd[q + ".running_var"]).float(), _t(sd[q + ".weight"]).float(),
+                             _t(sd[q + ".bias"]).float(), False, 0.1, 1e-5)
+            x = F.conv1d(x, weight_of(sd, f"melgan.{idx}.linear_{n}"), bias_of(sd, f"melgan.{idx}.linear_{n}"))
     if with_last:
         x = F.leaky_relu(x, MELGAN_SLOPE)
         x = F.conv1d(F.pad(x, ((K - 1) // 2,) * 2, mode="reflect"),

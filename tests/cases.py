@@ -51,6 +51,12 @@ SMALL = [
                                    upsample_initial_channel=64, upsample_kernel_sizes=[16, 7])),
     ("basis_up", "basis-melgan", dict(_M, L=30, out_channels=32, channels=[32, 16, 32],
                                       upsample_scales=[4, 3], transposedconv=False)),
+    # use_causal_conv: CausalConv1d inside every ResidualStack; lastlinear: BatchNorm head
+    ("melgan_causal", "melgan", dict(_M, out_channels=1, channels=[32, 32, 16], upsample_scales=[5, 3],
+                                     use_causal_conv=True)),
+    ("basis_causal_ll", "basis-melgan", dict(_M, L=30, out_channels=24, channels=[32, 32, 16],
+                                             upsample_scales=[4, 4], transposedconv=True,
+                                             use_causal_conv=True, lastlinear=True)),
 ]
 SMALL_T = 24
 SMALL_B = 3

@@ -69,7 +69,7 @@ def ref_build(name, cfg):
                 "stack_kernel_size", "stacks", "use_weight_norm", "use_causal_conv", "transposedconv"]
         return refgen.BasisMelGANGenerator(
             basis_signal_weight=torch.zeros(cfg["L"], cfg["out_channels"]).float(),
-            **{k: cfg[k] for k in keys})
+            lastlinear=cfg.get("lastlinear", False), **{k: cfg[k] for k in keys})
     raise Exception("no model find!")
 
 

@@ -166,6 +166,54 @@ def test_upsample_layer_module_standalone():
     assert _rel(layer(x.to(_dev())), ref) <= 2e-5
 
 
+@pytest.mark.parametrize("case", [(2, 16, 16, 50, 3, 9, 1), (1, 32, 16, 64, 3, 1, 0), (1, 8, 8, 40, 4, 2, 1),
+                                  (1, 64, 64, 300, 3, 3, 1)],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_causal_conv_vs_oracle(case):
+    """CausalConv1d (modules.py:273-294): pad (k-1)*dil on both sides, valid conv, first T kept."""
+    B, Cin, Cout, T, k, dil, mode = case
+    rng = np.random.RandomState(hash(case) % (2 ** 31))
+    x = rng.randn(B, Cin, T).astype(np.float32)
+    w = (rng.randn(Cout, Cin, k) / np.sqrt(Cin * k)).astype(np.float32)
+    b = rng.randn(Cout).astype(np.float32)
+    pad = (k - 1) * dil
+    ref = oo.conv1d(x, w, b, dil=dil, pad=pad, pad_mode=mode, pre_slope=0.2)[:, :, :T]
+    dev = _dev()
+    packed = _native.pack_conv1d(torch.from_numpy(w).to(dev))
+    y = _native.conv1d_fused(torch.from_numpy(x).to(dev), packed, torch.from_numpy(b).to(dev), Cout, k,
+                             dil=dil, pad=pad, pad_mode=mode | _native.PAD_CAUSAL, pre_slope=0.2)
+    assert tuple(y.shape) == (B, Cout, T)
+    assert _rel(y, ref) <= 2e-5
+    with pytest.raises(_native.NativeError, match="causal"):
+        _native.conv1d_fused(torch.from_numpy(x).to(dev), packed, None, Cout, k, dil=dil, pad=0,
+                             pad_mode=_native.PAD_CAUSAL)
+
+
+def test_batchnorm_fold_and_last_linear():
+    """fv_fold_batchnorm_conv vs the literal eval-mode BatchNorm + conv, then the LastLinear head."""
+    from fastvocoder_amd.generator.modules import LastLinear
+    torch.manual_seed(5)
+    head = LastLinear(24, 12)
+    for bn in (head.bn_1, head.bn_2):
+        bn.weight.data.uniform_(0.7, 1.3)
+        bn.bias.data.uniform_(-0.2, 0.2)
+        bn.running_mean.uniform_(-0.3, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+    head = head.to(_dev())
+    x = torch.randn(2, 24, 50)
+    sd = {"h." + k: v for k, v in head.state_dict().items()}
+    ref = og.last_linear(x.numpy(), sd, "h")
+    with pytest.raises(_native.NativeError, match="eval"):
+        head(x.to(_dev()))                      # train mode: batch statistics are training-only
+    head.eval()
+    assert _rel(head(x.to(_dev())), ref) <= 2e-5
+    w2, b2 = _native.fold_batchnorm_conv(head.linear_2.weight, head.linear_2.bias, head.bn_2)
+    bn = og.batchnorm_eval(x.numpy(), sd, "h.bn_2")
+    lit = oo.conv1d(bn, head.linear_2.weight.detach().cpu().numpy(), head.linear_2.bias.detach().cpu().numpy())
+    fold = oo.conv1d(x.numpy(), w2.cpu().numpy(), b2.cpu().numpy())
+    assert _rel(torch.from_numpy(fold), lit) <= 2e-5
+
+
 def test_activated_twin_outputs():
     """Activation hoisting at operator level: y raw + y_act = lrelu(y, s) in one launch, and the
     in-place form; a consumer reading y_act with pre_slope = 1 equals reading y with pre_slope = s."""

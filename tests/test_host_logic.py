@@ -70,14 +70,23 @@ def test_no_cpu_fallback():
         fa.PQMF().synthesis(torch.zeros(1, 4, 8))
 
 
-def test_unbuilt_variants_fail_loudly():
-    with pytest.raises(NotImplementedError):
-        fa.MelGANGenerator(use_causal_conv=True)
-    with pytest.raises(NotImplementedError):
-        fa.BasisMelGANGenerator(torch.zeros(30, 256), lastlinear=True)
-    # transposedconv: False keeps the reference's UpsampleLayer checkpoint keys
+def test_optional_variants_keep_the_reference_checkpoint_layout():
+    """transposedconv: False, use_causal_conv and lastlinear are constructor options no shipped
+    yaml sets; the containers still follow the reference's key layout (pinned by
+    tests/golden/make_golden.py, which asserts state_dict_spec == the reference's keys)."""
+    from fastvocoder_amd.synthetic import state_dict_spec
+    for tag, name, cfg in cases.SMALL:
+        if tag not in ("hifigan_up", "basis_up", "melgan_causal", "basis_causal_ll"):
+            continue
+        m = build_generator(name, cfg)
+        spec = state_dict_spec(name, cfg)
+        assert [k for k, _, _ in spec] == list(m.state_dict().keys()), tag
+        for k, shp, _ in spec:
+            assert tuple(m.state_dict()[k].shape) == tuple(shp), (tag, k)
     m = fa.HiFiGANGenerator(transposedconv=False, upsample_initial_channel=32)
     assert any(k.startswith("ups.0.conv.weight_v") for k in m.state_dict())
+    with pytest.raises(AssertionError):          # even kernels are only legal with causal convs
+        fa.MelGANGenerator(kernel_size=6)
 
 
 def test_seeded_checkpoint_is_reproducible_and_gain_calibrated():
