@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfastvocoder_hip.so")
 _CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip"]
+SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip", "wav_sink.hip"]
 
 PAD_ZERO, PAD_REFLECT = 0, 1
 PAD_CAUSAL = 2      # flag: pad (k-1)*dil on both sides, keep the first Tin outputs (CausalConv1d)
@@ -74,6 +74,8 @@ def lib():
     L.fv_conv1d_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, f, i, f, vp]
     L.fv_conv_transpose1d_fused.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, i, f, vp]
     L.fv_pqmf_synthesis.argtypes = [vp, vp, vp, i, i, i, i, vp]
+    L.fv_encode_16bits.argtypes = [vp, vp, vp, i, i64, f, i, vp]
+    L.fv_pqmf_analysis.argtypes = [vp, vp, vp, i, i, i, i64, vp]
     L.fv_fold_batchnorm_conv.argtypes = [vp, vp, vp, vp, vp, vp, f, vp, vp, i, i, i, vp]
     L.fv_packed_upsample_conv1d_floats.argtypes = [i, i, i, i, i]
     L.fv_packed_upsample_conv1d_floats.restype = i64
@@ -231,6 +233,30 @@ def upsample_conv1d_fused(x, packed, bias, cout, k, rate, pad, pre_slope=1.0, po
                                          T, k, rate, pad, float(pre_slope), post, float(act_slope),
                                          _stream()))
     return out
+
+
+def encode_16bits(x, rescale_out=1.0, scale_in_place=True):
+    """x [n] or [B,n] float32 device tensor -> (int16 tensor of the same shape, peaks [B]).
+    Row-wise ``encode_16bits`` of the reference; with ``scale_in_place`` x is scaled like
+    the reference scales its argument."""
+    flat = x if x.dim() == 2 else x.reshape(1, -1)
+    B, n = flat.shape
+    out = torch.empty((B, n), dtype=torch.int16, device=x.device)
+    peak = torch.empty(B, dtype=torch.float32, device=x.device)
+    check(lib().fv_encode_16bits(_ptr(flat, "x"), out.data_ptr(), _ptr(peak), B, n, float(rescale_out),
+                                 1 if scale_in_place else 0, _stream()))
+    return out.reshape(x.shape), peak
+
+
+def pqmf_analysis(x, analysis_filter):
+    """x [B,1,T] or [B,T] full band, analysis_filter [S,1,ntaps] -> [B,S,(T-S)//S+1]."""
+    S, ntaps = analysis_filter.shape[0], analysis_filter.shape[-1]
+    x = x.reshape(x.shape[0], -1)
+    B, T = x.shape
+    h = analysis_filter.detach().reshape(S, ntaps).contiguous().float()
+    y = torch.empty((B, S, (T - S) // S + 1), dtype=torch.float32, device=x.device)
+    check(lib().fv_pqmf_analysis(_ptr(x, "x"), _ptr(h, "analysis_filter"), _ptr(y), B, S, ntaps, T, _stream()))
+    return y
 
 
 def pqmf_synthesis(x, synthesis_filter, y):

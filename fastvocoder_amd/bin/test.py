@@ -69,7 +69,8 @@ def run_test():
     if args.model_name == "basis-melgan":
         for mel, filename in zip(mels, names):
             est_source = synthesizer.synthesize(mel)
-            save_wav(est_source.cpu().numpy(), os.path.join(args.file_path, f"{filename}.wav"),
+            # device tensor -> int16 on the GPU (fv_encode_16bits), then 2 B/sample over PCIe
+            save_wav(est_source.contiguous(), os.path.join(args.file_path, f"{filename}.wav"),
                      sample_rate=hp.sample_rate)
 
     if TEST_RTF:

@@ -577,6 +577,21 @@ int fv_pqmf_synthesis(const float* x, const float* h, float* y, int B, int S, in
     return launch_pqmf(x, h, y, B, S, ntaps, Tsub, (hipStream_t)stream);
 }
 
+int fv_pqmf_analysis(const float* x, const float* h, float* y, int B, int S, int ntaps, int64_t T,
+                     void* stream) {
+    if (!x || !h || !y || B < 0 || S <= 0 || ntaps <= 0 || ntaps % 2 == 0 || T < S)
+        return fail(FV_ERR_INVALID_ARG, "pqmf analysis: B=%d S=%d ntaps=%d T=%lld", B, S, ntaps, (long long)T);
+    return launch_pqmf_analysis(x, h, y, B, S, ntaps, T, (hipStream_t)stream);
+}
+
+int fv_encode_16bits(float* x, int16_t* out, float* peak, int B, int64_t n, float rescale_out,
+                     int scale_in_place, void* stream) {
+    if (!x || !out || !peak || B < 0 || n < 0)
+        return fail(FV_ERR_INVALID_ARG, "encode_16bits: null tensor or B=%d n=%lld", B, (long long)n);
+    return launch_encode16(x, B, n, rescale_out, reinterpret_cast<short*>(out),
+                           reinterpret_cast<unsigned*>(peak), scale_in_place, (hipStream_t)stream);
+}
+
 fv_plan_t* fv_plan_create(int in_channels) {
     fv_plan* p = new fv_plan();
     p->in_channels = in_channels;

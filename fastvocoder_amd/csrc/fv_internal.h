@@ -94,6 +94,10 @@ int launch_conv(ConvParams p, hipStream_t stream);
 int launch_conv_group(ConvParams* ps, int n, hipStream_t stream);
 int launch_pqmf(const float* x, const float* h, float* y, int B, int S, int ntaps, int Tsub,
                 hipStream_t stream);
+int launch_encode16(float* x, int B, int64_t n, float rescale, short* out, unsigned* peak_bits,
+                    int scale_in_place, hipStream_t s);
+int launch_pqmf_analysis(const float* xin, const float* ha, float* x, int B, int S, int ntaps,
+                         int64_t T, hipStream_t s);
 
 // measurement hook
 void profile_begin(hipStream_t stream);

@@ -41,6 +41,48 @@ __global__ __launch_bounds__(256) void pqmf_synthesis_kernel(const float* __rest
     }
 }
 
+// PQMF analysis (reference pqmf.py:108-119): a dense ntaps-tap FIR per band over the
+// zero-padded full-band signal, then keep every S-th sample (the one-hot strided conv):
+//   x_k[m] = sum_j ha[k][j] * xin[S*m + j - half],  m < (T - S)/S + 1.
+// The reference computes all T samples of every band and discards (S-1)/S of them; here
+// only the kept ones are formed.  One thread per (b, m): the S bands share the same
+// ntaps input samples (read once into registers' worth of L1 traffic), filter in LDS.
+__global__ __launch_bounds__(256) void pqmf_analysis_kernel(const float* __restrict__ xin,
+                                                            const float* __restrict__ ha,
+                                                            float* __restrict__ x, int S, int ntaps,
+                                                            int64_t T, int64_t Tsub) {
+    extern __shared__ float hs[];  // [S][ntaps]
+    for (int i = threadIdx.x; i < S * ntaps; i += 256) hs[i] = ha[i];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int half = (ntaps - 1) / 2;
+    const float* xr = xin + (size_t)b * T;
+    for (int64_t m = blockIdx.x * 256LL + threadIdx.x; m < Tsub; m += (int64_t)gridDim.x * 256) {
+        const int64_t p0 = (int64_t)S * m - half;
+        for (int kb = 0; kb < S; ++kb) {
+            const float* hr = hs + kb * ntaps;
+            float acc = 0.f;
+            for (int j = 0; j < ntaps; ++j) {
+                const int64_t p = p0 + j;
+                if (p >= 0 && p < T) acc = fmaf(hr[j], xr[p], acc);
+            }
+            x[((size_t)b * S + kb) * (size_t)Tsub + m] = acc;
+        }
+    }
+}
+
+int launch_pqmf_analysis(const float* xin, const float* ha, float* x, int B, int S, int ntaps, int64_t T,
+                         hipStream_t s) {
+    const int64_t Tsub = (T - S) / S + 1;
+    if (B <= 0 || T < S) return 0;
+    int64_t blocks = (Tsub + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pqmf_analysis_kernel, dim3((unsigned)blocks, B), dim3(256),
+                       (size_t)S * ntaps * sizeof(float), s, xin, ha, x, S, ntaps, T, Tsub);
+    FV_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_pqmf(const float* x, const float* h, float* y, int B, int S, int ntaps, int Tsub,
                 hipStream_t s) {
     if (B <= 0 || Tsub <= 0) return 0;

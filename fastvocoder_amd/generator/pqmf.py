@@ -70,7 +70,10 @@ class PQMF(torch.nn.Module):
         return y
 
     def analysis(self, x):
-        """Training-side op (reference pqmf.py:108-119); out of the hot-path scope
-        (SURVEY.md section 2, row 6)."""
-        raise NotImplementedError("PQMF.analysis is training-only and out of scope; "
-                                  "see oracle/ for the CPU known-answer version")
+        """x [B, 1, T] -> [B, subbands, T // subbands] (reference pqmf.py:108-119).  Used by the
+        reference only for the multiband training loss; kept so the class is whole and for the
+        analysis -> synthesis reconstruction check."""
+        x = x.contiguous().float()
+        if x.dim() != 3 or x.shape[1] != 1:
+            raise _native.NativeError(f"PQMF.analysis expects [B, 1, T], got {tuple(x.shape)}")
+        return _native.pqmf_analysis(x, self.analysis_filter)

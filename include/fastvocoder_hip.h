@@ -158,6 +158,26 @@ int fv_upsample_conv1d_fused(const float* x, const float* packed, const float* b
 int fv_pqmf_synthesis(const float* x, const float* h, float* y, int B, int S, int ntaps,
                       int Tsub, void* stream);
 
+/*
+ * PQMF.analysis (pqmf.py:108-119): ntaps-tap FIR per band over the zero-padded signal,
+ * decimated by S; only the kept samples are computed.
+ *   x [B,T] full band, h [S,ntaps] (= analysis_filter[:,0]), y [B,S,(T-S)/S+1].
+ * Not on the inference path (the reference uses it for the multiband training loss); it is
+ * here so the PQMF class is whole and for the analysis->synthesis reconstruction check.
+ */
+int fv_pqmf_analysis(const float* x, const float* h, float* y, int B, int S, int ntaps,
+                     int64_t T, void* stream);
+
+/*
+ * The wav sink's arithmetic (data/audio.py:12-14 encode_16bits) on the device, per waveform
+ * (row) of x [B,n]:  s = 32767 / max(0.01, max|x|) * rescale_out;  out = int16(trunc(x * s)).
+ * peak [B] receives max|x| per row (device scratch, also an output).  scale_in_place != 0
+ * also writes x * s back to x, the reference's in-place mutation of its argument.
+ * Results equal numpy's for a float32 array bit for bit (tests/test_gpu_parity.py).
+ */
+int fv_encode_16bits(float* x, int16_t* out, float* peak, int B, int64_t n, float rescale_out,
+                     int scale_in_place, void* stream);
+
 /* ------------------------------------------------------------------ *
  * whole-generator plans: an op list replayed over a caller-owned arena
  * ------------------------------------------------------------------ */

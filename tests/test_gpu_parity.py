@@ -300,6 +300,26 @@ def test_pqmf_synthesis_vs_golden_and_oracle(golden_dir):
     assert np.abs(r[0, 0, 200:-200] - g["pqmf_wav"][0, 0, 200:-200]).max() < 2e-3
 
 
+def test_pqmf_analysis_vs_golden_and_roundtrip(golden_dir):
+    """PQMF.analysis (pqmf.py:108-119) on the GPU vs the reference's output, odd lengths vs the
+    oracle, and the analysis -> synthesis known-answer check fully on the GPU."""
+    g = np.load(os.path.join(golden_dir, "blocks.npz"))
+    pq = fa.PQMF().to(_dev())
+    wav = torch.from_numpy(g["pqmf_wav"]).to(_dev())
+    a = pq.analysis(wav)
+    assert _err(a, g["pqmf_analysis_out"]) <= 1e-5
+    assert _err(pq.synthesis(a), g["pqmf_roundtrip"]) <= 1e-5
+    r = pq.synthesis(a).cpu().numpy()
+    assert np.abs(r[0, 0, 200:-200] - g["pqmf_wav"][0, 0, 200:-200]).max() < 2e-3
+    rng = np.random.RandomState(4)
+    for T in (4, 63, 1001, 4098):
+        x = rng.uniform(-1, 1, size=(2, 1, T)).astype(np.float32)
+        ref = oo.pqmf_analysis(x[:, 0, :], g["pqmf_analysis_filter"][:, 0, :])
+        assert _err(pq.analysis(torch.from_numpy(x).to(_dev())), ref) <= 1e-5
+    with pytest.raises(_native.NativeError):
+        pq.analysis(wav[:, 0, :])
+
+
 # ---------------------------------------------------------------------------
 # blocks vs the reference goldens
 # ---------------------------------------------------------------------------
@@ -445,6 +465,32 @@ def test_synthesize_triple_config1(golden_dir, tmp_path):
     assert _err(est, g["est"]) <= TOL
     assert _err(bias, g["bias"]) <= TOL
     assert _err(rem, g["remove"]) <= TOL
+
+
+@pytest.mark.parametrize("n,peak,rescale", [(48000, 0.7, 1.0), (240015, 0.93, 0.4), (1001, 0.004, 1.0),
+                                            (7, 1.7, 0.4), (1, 0.5, 1.0)])
+def test_encode_16bits_on_device_is_bit_exact(n, peak, rescale):
+    """fv_encode_16bits vs the reference arithmetic in numpy (data/audio.py:12-14): int16 samples,
+    the in-place scaled waveform and the peak, all bit for bit (integer work: no tolerance)."""
+    from fastvocoder_amd import audio
+    rng = np.random.RandomState(n)
+    x = (rng.uniform(-1, 1, size=n) * peak).astype(np.float32)
+    host = x.copy()
+    want = audio.encode_16bits(host, rescale)                 # numpy route, mutates host
+    dev = torch.from_numpy(x.copy()).to(_dev())
+    got = audio.encode_16bits(dev, rescale)
+    assert got.dtype == torch.int16 and got.is_cuda
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(dev.cpu().numpy(), host)            # same in-place mutation
+    # batched rows are normalised independently; unaligned rows (odd n) take the scalar path
+    xb = np.stack([x, 0.5 * x, -2.0 * x]).astype(np.float32)
+    q, pk = _native.encode_16bits(torch.from_numpy(xb.copy()).to(_dev()), rescale, scale_in_place=False)
+    for r in range(3):
+        row = xb[r].copy()
+        assert np.array_equal(q[r].cpu().numpy(), audio.encode_16bits(row, rescale))
+        assert float(pk[r]) == float(np.abs(xb[r]).max())
+    with pytest.raises(_native.NativeError):
+        audio.encode_16bits(torch.zeros(4))
 
 
 def test_errors_are_loud():
