@@ -173,9 +173,36 @@ class PlanBuilder:
             for j in act_uses[slope]:
                 ops[j]["x"], ops[j]["pre_slope"] = target, 1.0
 
+    # -- receptive field (for time-chunked runs) -------------------------------
+    def receptive_halo(self):
+        """Input frames of context, per side, that every output sample of the recorded graph
+        can depend on -- a backward dataflow walk over the ops (slots are reused, so a slot's
+        requirement is reset at the op that defines it).  Used by
+        :meth:`NativeModule._run_chunked`; slightly generous (transposed convs are bounded by
+        ceil(k/stride)+1 taps)."""
+        need = {}
+        for op in reversed(self.ops):
+            h_out = max(need.pop(op["y"], 0), need.pop(op.get("y_act", SLOT_NONE), 0))
+            if op["kind"] == "conv":
+                reach = op["dil"] * (op["k"] - 1)
+                own, rate = max(op["pad"], reach - op["pad"]), 1
+            elif op["kind"] == "convT":
+                own, rate = -(-op["k"] // op["stride"]) + 1, op["stride"]
+            elif op["kind"] == "upconv":
+                own, rate = -(-(op["k"] + op["rate"]) // op["rate"]) + 1, op["rate"]
+            else:                                           # pqmf synthesis: S bands, ntaps taps
+                S, ntaps = op["h"].shape
+                own, rate = -(-(ntaps // 2) // S) + 1, S
+            need[op["x"]] = max(need.get(op["x"], 0), -(-h_out // rate) + own)
+            for aux in (op["res"], op["acc"], op.get("acc2", SLOT_NONE)):
+                if aux != SLOT_NONE:
+                    need[aux] = max(need.get(aux, 0), h_out)
+        return need.get(SLOT_IN, 0)
+
     def finalize(self):
         """Hoist activations and emit the recorded ops into the native plan."""
         self._hoist_activations()
+        self.plan.halo_frames = self.receptive_halo()
         for op in self.ops:
             self.plan.set_lane(op["lane"])
             self.plan.set_group(op.get("group", 0))
@@ -265,6 +292,44 @@ class NativeModule(torch.nn.Module):
             plan = pb.finalize()
         self._fv_plans[name] = (state, plan)
         return plan
+
+    # Longest input (frames) handed to one plan run; longer inputs are cut into chunks with
+    # receptive-field halos.  One launch addresses < 1 GiB per
+    # tensor row (csrc/conv_mfma.hip kOutOfRange), which the widest shipped layer
+    # (MelGAN 256 ch x 10T) reaches near T = 100k frames; 16384 frames (~3 min of audio)
+    # keeps the workspace bounded and costs < 1 % in halo recomputation.
+    max_frames_per_run = 16384
+
+    def _run_plan(self, plan, x, chunk_frames=None):
+        """plan.run(x), time-chunked when x is longer than ``chunk_frames``
+        (default ``max_frames_per_run``)."""
+        chunk = self.max_frames_per_run if chunk_frames is None else int(chunk_frames)
+        if chunk <= 0 or x.shape[2] <= chunk:
+            return plan.run(x)
+        return self._run_chunked(plan, x, chunk)
+
+    @staticmethod
+    def _run_chunked(plan, x, chunk):
+        """Exact chunked evaluation: each chunk of ``chunk`` frames is run with ``halo`` extra
+        frames of real input on both sides (clipped at the utterance ends, where the layers'
+        own zero / reflection padding applies as in a whole run) and only its interior is
+        kept.  Output length law out = hop*T + c is read from the plan: c < 0 is a symmetric
+        crop (MB-large), c > 0 a tail (Basis overlap-add); either way a chunk that starts at
+        frame ``lo`` produces final samples [lo*hop, lo*hop + len)."""
+        B, _, T = x.shape
+        halo = plan.halo_frames
+        (_, n1), (cout, n2) = plan.output_shape(halo + 64), plan.output_shape(halo + 65)
+        hop = n2 - n1
+        total = plan.output_shape(T)[1]
+        out = torch.empty((B, cout, total), dtype=torch.float32, device=x.device)
+        for a in range(0, T, chunk):
+            b = min(T, a + chunk)
+            lo, hi = max(0, a - halo), min(T, b + halo)
+            y = plan.run(x[:, :, lo:hi].contiguous())
+            first = a * hop if a > 0 else 0
+            last = b * hop if b < T else total
+            out[:, :, first:last] = y[:, :, first - lo * hop: last - lo * hop]
+        return out
 
     def _prepare(self, x):
         """Any array-like -> contiguous fp32 tensor on this module's device."""

@@ -118,7 +118,7 @@ class _HiFiGANBase(NativeModule):
         pb.conv(self.conv_post, x, dst, pre_slope=DEFAULT_LRELU_SLOPE, post=POST_TANH)
 
     def _trunk(self, x):
-        return self._plan("trunk", lambda pb: self._emit_trunk(pb, SLOT_OUT), 80).run(x)
+        return self._run_plan(self._plan("trunk", lambda pb: self._emit_trunk(pb, SLOT_OUT), 80), x)
 
 
 class HiFiGANGenerator(_HiFiGANBase):
@@ -174,8 +174,8 @@ class MultiBandHiFiGANGenerator(_HiFiGANBase):
     def inference(self, x):
         """x [T,80] -> 1-D full-band waveform (trunk + PQMF synthesis, one plan)."""
         x = self._prepare(x).transpose(1, 0).unsqueeze(0).contiguous()
-        return self._plan("inference", self._emit_full, 80).run(x).squeeze()
+        return self._run_plan(self._plan("inference", self._emit_full, 80), x).squeeze()
 
     def synthesize_batch(self, x):
         """x [B,80,T] -> full-band waveforms [B, 4*T'] (batched ``inference``)."""
-        return self._plan("inference", self._emit_full, 80).run(self._prepare(x))[:, 0, :]
+        return self._run_plan(self._plan("inference", self._emit_full, 80), self._prepare(x))[:, 0, :]

@@ -111,8 +111,8 @@ class MelGANGenerator(_MelGANTrunk):
         self.pqmf = None  # attribute kept for parity with the reference (melgan.py:123)
 
     def _run(self, x):
-        return self._plan("trunk", lambda pb: self._emit_layers(pb, SLOT_OUT, self._final_post),
-                          self._in_channels).run(x)
+        return self._run_plan(self._plan("trunk", lambda pb: self._emit_layers(pb, SLOT_OUT, self._final_post),
+                                    self._in_channels), x)
 
     def forward(self, c):
         """c [B,in_channels,T] -> [B, T*prod(upsample_scales)] (channel 0)."""
@@ -156,8 +156,8 @@ class BasisMelGANGenerator(_MelGANTrunk):
 
     def _weights(self, x):
         """Trunk + ReLU in its native layout [B, C, F]."""
-        return self._plan("trunk", lambda pb: self._emit_layers(pb, SLOT_OUT, self._final_post),
-                          self._in_channels).run(x)
+        return self._run_plan(self._plan("trunk", lambda pb: self._emit_layers(pb, SLOT_OUT, self._final_post),
+                                    self._in_channels), x)
 
     def _emit_full(self, pb):
         w = pb.tmp()
@@ -167,7 +167,7 @@ class BasisMelGANGenerator(_MelGANTrunk):
     def _samples(self, x):
         """mel [B,C,T] -> [B, (F-1)*L/2 + L] in one plan (weights stay on chip/HBM
         scratch, no [B,F,L] frame tensor)."""
-        return self._plan("full", self._emit_full, self._in_channels).run(x)[:, 0, :]
+        return self._run_plan(self._plan("full", self._emit_full, self._in_channels), x)[:, 0, :]
 
     def forward(self, c):
         """Reference semantics (basis_melgan.py:140-162): runs the zero-mel pass

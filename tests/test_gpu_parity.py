@@ -493,6 +493,41 @@ def test_encode_16bits_on_device_is_bit_exact(n, peak, rescale):
         audio.encode_16bits(torch.zeros(4))
 
 
+@pytest.mark.parametrize("tag,name,cfg", cases.SMALL, ids=[c[0] for c in cases.SMALL])
+def test_time_chunked_run_equals_whole_run(tag, name, cfg):
+    """inputs longer than ``max_frames_per_run`` are cut into chunks with
+    receptive-field halos; the stitched result must equal the whole-utterance run (same
+    arithmetic per sample; only the tile shapes, hence fp32 summation order, may differ)."""
+    m, _ = _model(name, cfg, seed=7)
+    T = 61
+    mel = seeded_mel(T, seed=9)
+    whole = m.inference(mel).cpu().numpy()
+    melb = torch.from_numpy(seeded_mel(T, seed=10, batch=2)).to(_dev())
+    whole_f = m(melb)
+    whole_f = whole_f[0] if isinstance(whole_f, tuple) else whole_f
+    plan_halo = next(iter(m._fv_plans.values()))[1].halo_frames
+    assert 0 < plan_halo < 64
+    for chunk in (7, 16, 60):
+        m.max_frames_per_run = chunk
+        got = m.inference(mel).cpu().numpy()
+        assert got.shape == whole.shape
+        assert np.abs(got - whole).max() <= 1e-5, (tag, chunk)
+        f = m(melb)
+        f = f[0] if isinstance(f, tuple) else f
+        assert _err(f, whole_f.cpu().numpy()) <= 1e-5, (tag, chunk)
+
+
+def test_time_chunked_shipped_hifigan_light():
+    cfg = cases.load_conf("conf/hifigan/light.yaml")
+    m, _ = _model("hifigan", cfg, seed=0)
+    mel = seeded_mel(700, seed=4)
+    whole = m.inference(mel)
+    m.max_frames_per_run = 256
+    got = m.inference(mel)
+    assert got.shape == whole.shape == (700 * 240,)
+    assert _err(got, whole.cpu().numpy()) <= 1e-5
+
+
 def test_errors_are_loud():
     with pytest.raises(_native.NativeError):
         fa.HiFiGANGenerator()(torch.zeros(1, 80, 8))      # CPU module: no fallback
