@@ -49,6 +49,11 @@
 
 #include "fv_internal.h"
 
+#ifndef FV_PREFETCH_RES
+#define FV_PREFETCH_RES 0   // measured: issuing the residual read before the tile's last MFMAs costs
+                            // more (registers, spills in the split-K shapes) than the latency it hides
+#endif
+
 namespace fv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -268,12 +273,13 @@ __device__ __forceinline__ void row_info(const ConvParams& p, const int (&m)[N],
 
 // N output elements of one thread at GEMM column q:
 //   y = post( ( (acc_in + acc_in2) + ( (v + bias) + res ) ) / out_div );   y_act = act(y, act_slope)
-// all uniform switches are hoisted; loads are issued as one batch.
+// all uniform switches are hoisted; loads are issued as one batch.  The tensor reads
+// (res, acc_in, acc_in2) are a separate step so that a caller can issue them BEFORE the
+// tile's last run of MFMAs (done for res, the common one): ~2 us of latency then overlaps
+// matrix work instead of standing between the last MFMA and the first store.
 template <int N>
-__device__ __forceinline__ void epilogue_store(const ConvParams& p, const EpilogueRsrc& e,
-                                               const RowInfo<N>& ri, const int (&m)[N], int q,
-                                               float (&v)[N]) {
-    unsigned off[N];
+__device__ __forceinline__ void epilogue_offsets(const ConvParams& p, const RowInfo<N>& ri,
+                                                 const int (&m)[N], int q, unsigned (&off)[N]) {
     // additive masking (see kOutOfRange): no per-element predicate
     const unsigned qoff = q < p.Tq ? (unsigned)(q * p.ups) * 4u : kOutOfRange;
 #pragma unroll
@@ -284,10 +290,16 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, const Epilog
         for (int i = 0; i < N; ++i)
             if (q * p.ups + m[i] % p.ups >= p.Tout) off[i] = kOutOfRange;
     }
-    float rv[N], av[N];
+}
+
+// rv = res, av = acc_in + acc_in2 (formed first, like xs = r0; xs += r1); zeros when absent
+template <int N>
+__device__ __forceinline__ void epilogue_load(const ConvParams& p, const EpilogueRsrc& e,
+                                              const unsigned (&off)[N], float (&rv)[N], float (&av)[N],
+                                              float (&a2)[N], bool with_res = true) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) rv[i] = av[i] = 0.f;
-    if (p.res) {
+    for (int i = 0; i < N; ++i) rv[i] = av[i] = a2[i] = 0.f;
+    if (with_res && p.res) {
 #pragma unroll
         for (int i = 0; i < N; ++i) rv[i] = buffer_load1(e.res, off[i]);
     }
@@ -295,15 +307,19 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, const Epilog
 #pragma unroll
         for (int i = 0; i < N; ++i) av[i] = buffer_load1(e.acc, off[i]);
     }
-    if (p.acc_in2) {   // second running-sum input: (acc_in + acc_in2) first, like xs = r0; xs += r1
-        float a2[N];
+    if (p.acc_in2) {
 #pragma unroll
         for (int i = 0; i < N; ++i) a2[i] = buffer_load1(e.acc2, off[i]);
-#pragma unroll
-        for (int i = 0; i < N; ++i) av[i] = av[i] + a2[i];
     }
+}
+
+template <int N>
+__device__ __forceinline__ void epilogue_finish(const ConvParams& p, const EpilogueRsrc& e,
+                                                const RowInfo<N>& ri, const unsigned (&off)[N],
+                                                float (&v)[N], const float (&rv)[N],
+                                                const float (&av)[N], const float (&a2)[N]) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = av[i] + ((v[i] + ri.bias[i]) + rv[i]);
+    for (int i = 0; i < N; ++i) v[i] = (av[i] + a2[i]) + ((v[i] + ri.bias[i]) + rv[i]);
     if (p.out_div != 1.f) {
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = v[i] / p.out_div;
@@ -329,6 +345,17 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, const Epilog
 #pragma unroll
         for (int i = 0; i < N; ++i) buffer_store1(e.y, off[i], v[i]);
     }
+}
+
+template <int N>
+__device__ __forceinline__ void epilogue_store(const ConvParams& p, const EpilogueRsrc& e,
+                                               const RowInfo<N>& ri, const int (&m)[N], int q,
+                                               float (&v)[N]) {
+    unsigned off[N];
+    float rv[N], av[N], a2[N];
+    epilogue_offsets<N>(p, ri, m, q, off);
+    epilogue_load<N>(p, e, off, rv, av, a2);
+    epilogue_finish<N>(p, e, ri, off, v, rv, av, a2);
 }
 
 // XCD-aware block order: the dispatcher places linear block id b on XCD b % 8,
@@ -454,6 +481,30 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
                 stage_x<NW, NT, SLOW>(p, dp, rx, xs0 + nxt * p.xbuf, b, nci0, ntA, wave, lane, tid);
                 if (nchunks > 1) dma_w<NW, M_T>(p, dp, rw, ws0 + nxt * p.wbuf, nci0, wave);
             }
+            // ---- last stage of a tile: issue the epilogue's tensor reads now (NR == 1 shapes;
+            //      the two-accumulator shapes have no registers to spare) ----
+            constexpr bool PRE = FV_PREFETCH_RES && NR == 1;
+            float pre_r[PRE ? F::REGS : 1];
+            if constexpr (PRE) {
+#pragma unroll
+                for (int i = 0; i < F::REGS; ++i) pre_r[i] = 0.f;
+                if (last_chunk && (WK == 1 || wk == 0) && !(p.dbg & 1) && p.res) {
+                    const size_t boff = (size_t)b * p.Cout * (size_t)p.Tout;
+                    const __amdgpu_buffer_rsrc_t rres =
+                        make_rsrc(p.res + boff, (unsigned)p.Cout * (unsigned)p.Tout * 4u);
+                    const int q = tile * N_T + wave_n * MF + lm;
+#pragma unroll
+                    for (int h = 0; h < EH; ++h) {
+                        int mm[EN];
+                        unsigned off[EN];
+#pragma unroll
+                        for (int i = 0; i < EN; ++i) mm[i] = m0 + wave_m * MF + F::row(h * EN + i, lane);
+                        epilogue_offsets<EN>(p, ri[h], mm, q, off);
+#pragma unroll
+                        for (int i = 0; i < EN; ++i) pre_r[h * EN + i] = buffer_load1(rres, off[i]);
+                    }
+                }
+            }
             // ---- matrix work on the current buffers ----
             {
                 // with a single chunk the weights never change: they stay in buffer 0
@@ -520,19 +571,28 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
                         const int q = tile * N_T + wave_n * (MF * NR) + r * MF + lm;
 #pragma unroll
                         for (int h = 0; h < EH; ++h) {
-                            float vv[EN];
+                            float vv[EN], rv[EN], av[EN], a2[EN];
                             int mm[EN];
+                            unsigned off[EN];
 #pragma unroll
                             for (int i = 0; i < EN; ++i) {
                                 vv[i] = acc[r][h * EN + i];
                                 mm[i] = m0 + wave_m * MF + F::row(h * EN + i, lane);
                             }
-                            epilogue_store<EN>(p, ersrc, ri[h], mm, q, vv);
+                            epilogue_offsets<EN>(p, ri[h], mm, q, off);
+                            epilogue_load<EN>(p, ersrc, off, rv, av, a2, /*with_res=*/!PRE);
+                            if constexpr (PRE) {
+#pragma unroll
+                                for (int i = 0; i < EN; ++i) rv[i] = pre_r[h * EN + i];
+                            }
+                            epilogue_finish<EN>(p, ersrc, ri[h], off, vv, rv, av, a2);
                         }
                     }
                 }
             }
-            // the DMA issued above must have landed (own wave: vmcnt; others: barrier)
+            // the DMA issued above must have landed (own wave: vmcnt; others: barrier); after the
+            // block's last tile nothing was issued and the stores may drain after the wave ends
+            if (last_chunk && tile + 1 >= tile_hi) break;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             cur = nxt;
@@ -540,8 +600,16 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
     }
 }
 
+// At least FV_MIN_WAVES waves per SIMD: caps the VGPR budget (512 / waves per SIMD) so that as
+// many blocks as the LDS budget allows stay resident on a CU.
+// (The two-accumulator 32x32 shapes need > 168 VGPRs and keep 2.)
+#ifndef FV_MIN_WAVES
+#define FV_MIN_WAVES 3
+#endif
+#define FV_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((MF == 32 && NR == 2) ? 2 : FV_MIN_WAVES)))
+
 template <int MF, int WM, int WN, int WK, int NR, int KT, int DIL, bool ACT, bool SLOW>
-__global__ __launch_bounds__(64 * WM * WN * WK) void conv_mfma_kernel(ConvParams p) {
+__global__ __launch_bounds__(64 * WM * WN * WK) FV_WAVES_ATTR void conv_mfma_kernel(ConvParams p) {
     conv_body<MF, WM, WN, WK, NR, KT, DIL, ACT, SLOW>(p, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
@@ -557,7 +625,7 @@ struct GroupParams {
 };
 
 template <int MF, int WM, int WN, int WK, int NR, int DIL>
-__global__ __launch_bounds__(64 * WM * WN * WK) void conv_group3_kernel(GroupParams gp) {
+__global__ __launch_bounds__(64 * WM * WN * WK) FV_WAVES_ATTR void conv_group3_kernel(GroupParams gp) {
     const int g = blockIdx.z;
     if ((int)blockIdx.x >= gp.grid_x[g]) return;
     if (g == 0) conv_body<MF, WM, WN, WK, NR, 11, DIL, false, false>(gp.p[0], blockIdx.x, gp.grid_x[0], blockIdx.y);
@@ -656,8 +724,8 @@ size_t plan_staging(ConvParams& p, const Geometry& g, int k_rows_target) {
     plan_x_image(p, g.n_t(), g.mf == 16);
     const int ks = (g.mf == 32 ? 2 : 4) * g.wk;     // ci granularity of one MFMA step x split
     const int cin_pad = round_up(p.Cin, ks);
-    // stage size: about k_rows_target MFMA K-rows (ci_chunk*k), both buffers <= 64 KiB
-    // so that 2+ blocks stay resident per CU; prefer chunks dividing Cin
+    // stage size: about k_rows_target MFMA K-rows (ci_chunk*k), both buffers <= 52 KiB
+    // so that 3 blocks stay resident per CU (160 KiB LDS; 168 VGPRs at 3 waves/SIMD); prefer chunks dividing Cin
     // (defaults from end-to-end sweeps on MI355X, tools/bench_sweep.sh)
     int best = 0;
     for (int c = ks; c <= cin_pad; c += ks) {
@@ -665,7 +733,7 @@ size_t plan_staging(ConvParams& p, const Geometry& g, int k_rows_target) {
         const int nw = g.wm * g.wn * g.wk;
         const bool dma_ok = round_up(c * p.ncol4c, 64) / 64 <= kMaxDmaX * nw &&
                             round_up(c * p.k * g.m_t() / 4, 64) / 64 <= kMaxDmaW * nw;
-        if (best && (!dma_ok || 2 * per_buf > (size_t)env_int("FV_LDS_BUDGET", 64) * 1024)) break;
+        if (best && (!dma_ok || 2 * per_buf > (size_t)env_int("FV_LDS_BUDGET", 52) * 1024)) break;
         if (!dma_ok) return 0;
         if (cin_pad % c == 0 || !best) best = c;
         if (c * p.k >= k_rows_target && cin_pad % c == 0) break;
