@@ -8,8 +8,8 @@ seeded gain-calibrated random-init weights (no checkpoint exists offline),
 weight norm folded.  One "step" = one ``Generator.forward`` over the per-GPU
 batch -> 240 000 samples per utterance.  N > 1 (launched by torch.distributed.run,
 one rank per GPU): weights are built on rank 0 and broadcast over RCCL once,
-every rank then runs its own utterances (weak scaling) and the waveforms are
-gathered to rank 0 inside the timed step.
+every rank then runs its own utterances (weak scaling, no collective inside the
+generator) and the waveforms are gathered to rank 0 inside the timed step.
 
 Prints ONE JSON line: value = whole-job audio samples / second, plus RTF at
 22.05 kHz and 24 kHz, the roofline of the dominant kernel (fp32-MFMA implicit-GEMM
@@ -64,6 +64,36 @@ def cpu_baseline(cfg, sd, mel):
             "seconds": best}
 
 
+def timed_steps(step, steps, warmup, dist, dev):
+    """``warmup`` untimed calls of ``step()``, then EXACTLY ``steps`` timed ones bracketed by
+    (device sync, barrier, device sync) on both sides; returns (seconds = MAX over ranks,
+    last step's result).  ``dist`` is torch.distributed or None (single process); covered on
+    CPU by tests/test_distributed_cpu.py with the gloo backend."""
+    def sync():
+        # drain this GPU, meet the other ranks, drain the barrier's own collective
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+
+    out = None
+    for _ in range(warmup):
+        out = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,23 +140,7 @@ def main():
             gather(wav)
         return wav
 
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wav = step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, wav = timed_steps(step, args.steps, args.warmup, dist, dev)
 
     samples_per_utt = int(wav.shape[-1])
     total_samples = samples_per_utt * B * world * args.steps
@@ -136,9 +150,9 @@ def main():
     out = None
     if rank == 0:
         # per-launch timing of the dominant kernel family with HIP events on the launch stream.
-        # The timed region above runs the three ResBlocks of a stage on concurrent streams; a
-        # per-launch duration is only well defined without that overlap, so this leg replays
-        # the same forward on ONE stream (FV_SINGLE_LANE, read by fv_plan_run at every call).
+        # A per-launch duration is only well defined without stream overlap, so this leg pins
+        # the replay of the same forward to ONE stream (FV_SINGLE_LANE, read by fv_plan_run at
+        # every call; the default grouped plan already is single-stream, FV_MRF=lanes is not).
         os.environ["FV_SINGLE_LANE"] = "1"
         for _ in range(2):
             with torch.no_grad():
@@ -199,7 +213,7 @@ def main():
                                    f"{samples_per_utt} samples each; BASELINE.json configs[1]",
                        "global_batch": B * world, "frames": T_FRAMES,
                        "parallelism": f"utterance-sharded x{world}" if world > 1 else "single GPU",
-                       "launches_per_forward": model._plan("trunk", None, 80).num_ops()},
+                       "convs_per_forward": model._plan("trunk", None, 80).num_ops()},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:

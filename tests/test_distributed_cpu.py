@@ -57,6 +57,23 @@ def _worker(rank, world, port, B, out_path):
         bufs = gather(mine)
         if rank == 0:
             assert [float(b[0, 0]) for b in bufs] == [float(r) for r in range(world)]
+        # 4) bench.py's timing bracket: K steps, barrier on both sides, MAX over ranks
+        import time
+
+        import bench
+        calls = []
+
+        def step():
+            calls.append(1)
+            time.sleep(0.02 * (rank + 1))          # rank r is (r+1)x slower
+            return rank
+        elapsed, last = bench.timed_steps(step, steps=3, warmup=1, dist=dist, dev=torch.device("cpu"))
+        assert len(calls) == 4 and last == rank
+        assert elapsed >= 3 * 0.02 * world - 1e-3    # every rank reports the slowest rank's time
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        lo = t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        assert float(lo) == float(t)                 # identical on all ranks
         dist.barrier()
     finally:
         dist.destroy_process_group()
