@@ -832,7 +832,7 @@ struct LaunchInfo {
 };
 
 // Validate one conv, pick its tile shape and fill in the staging geometry.
-int prepare_conv(ConvParams& p, LaunchInfo& li) {
+int prepare_conv(ConvParams& p, LaunchInfo& li, int members = 1) {
     if (p.k < 1 || p.dil < 1) return fail(FV_ERR_INVALID_ARG, "conv: k=%d dil=%d", p.k, p.dil);
     if (p.pad_mode == FV_PAD_REFLECT && p.pad >= p.Tin)
         return fail(FV_ERR_INVALID_ARG, "reflection pad %d needs an input longer than it (T=%d)",
@@ -881,13 +881,16 @@ int prepare_conv(ConvParams& p, LaunchInfo& li) {
         const Geometry& gg = kShapes[id];
         return (long)(p.Mpad / gg.m_t()) * ((p.Tq + gg.n_t() - 1) / gg.n_t());
     };
-    // thresholds from per-layer and end-to-end sweeps on MI355X (tools/conv_bench.py, bench_sweep.sh)
+    // thresholds from per-layer and end-to-end sweeps on MI355X (tools/conv_bench.py, bench_sweep.sh).
+    // ``members`` = convs sharing the launch (3 in a grouped MRF launch): that many times the
+    // units, so the wide 32x128 tile -- least weight re-streaming per MFMA (64 B vs 128 B of
+    // L2->LDS traffic per instruction for the 64-column shapes) -- already pays at C = 128, T = 8000.
     const int want = env_int("FV_UNITS", 500);
     int shape;
     if (m16) shape = units(0) >= want ? 0 : 1;
-    else if (!m64 && units(2) >= want) shape = 2;
-    else if (m64 && units(5) >= want) shape = 5;
-    else if (units(3) >= 400) shape = 3;
+    else if (units(2) * members >= want) shape = 2;
+    else if (m64 && units(5) * members >= want) shape = 5;
+    else if (units(3) * members >= 400) shape = 3;
     else shape = 4;
     const int force = env_int(m16 ? "FV_SHAPE16" : (m64 ? "FV_SHAPE64" : "FV_SHAPE32"), -1);
     if (force >= 0 && force < kNumShapes && kShapes[force].mf == (m16 ? 16 : 32) &&
@@ -963,7 +966,7 @@ int launch_conv_group(ConvParams* ps, int n, hipStream_t s) {
     if (ok) {
         for (int i = 0; i < 3 && ok; ++i) {
             if (ps[i].B <= 0 || ps[i].Tq <= 0) ok = false;
-            else if (prepare_conv(ps[i], li[i])) ok = false;
+            else if (prepare_conv(ps[i], li[i], n)) ok = false;
         }
     }
     if (ok) {
