@@ -20,7 +20,7 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 PAD_CAUSAL = 2      # flag: pad (k-1)*dil on both sides, keep the first Tin outputs (CausalConv1d)
 POST_NONE, POST_TANH, POST_RELU = 0, 1, 2
 SLOT_NONE, SLOT_IN, SLOT_OUT, SLOT_TMP0, MAX_SLOTS = -1, 0, 1, 2, 32
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class NativeError(RuntimeError):
@@ -74,6 +74,8 @@ def lib():
     L.fv_conv1d_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, f, i, f, vp]
     L.fv_conv_transpose1d_fused.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, i, f, vp]
     L.fv_pqmf_synthesis.argtypes = [vp, vp, vp, i, i, i, i, vp]
+    L.fv_conv1d_2src_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, f, vp]
+    L.fv_plan_add_conv1d_2src.argtypes = [vp, i, i, i, i, i, vp, vp, i, i, i, i, f]
     L.fv_encode_16bits.argtypes = [vp, vp, vp, i, i64, f, i, vp]
     L.fv_pqmf_analysis.argtypes = [vp, vp, vp, i, i, i, i64, vp]
     L.fv_fold_batchnorm_conv.argtypes = [vp, vp, vp, vp, vp, vp, f, vp, vp, i, i, i, vp]
@@ -208,6 +210,20 @@ def conv1d_fused(x, packed, bias, cout, k, dil=1, pad=0, pad_mode=PAD_ZERO, pre_
     return out
 
 
+def conv1d_2src_fused(x, x2, packed, bias, cout, res=None, post=POST_NONE, out=None, out_act=None,
+                      act_slope=1.0):
+    """y = post(W1 x + W2 x2 + bias + res) with packed = pack_conv1d(cat([W1, W2], 1)); 1-tap convs."""
+    B, c1, T = x.shape
+    c2 = x2.shape[1]
+    if out is None:
+        out = torch.empty((B, cout, T), dtype=torch.float32, device=x.device)
+    check(lib().fv_conv1d_2src_fused(_ptr(x, "x"), _ptr(x2, "x2"), _ptr(packed, "packed"),
+                                     _ptr(bias, "bias", True), _ptr(res, "res", True), _ptr(out, "out"),
+                                     _ptr(out_act, "out_act", True), B, c1, c2, cout, T, post,
+                                     float(act_slope), _stream()))
+    return out
+
+
 def conv_transpose1d_fused(x, packed, bias, cout, k, stride, pad, out_pad, pre_slope=1.0,
                            post=POST_NONE, out=None, out_act=None, act_slope=1.0):
     B, cin, T = x.shape
@@ -309,6 +325,15 @@ class Plan:
                                                  _ptr(bias, "bias", True), cin, cout, k, stride,
                                                  pad, out_pad, float(pre_slope), post,
                                                  float(act_slope)))
+
+    def add_conv1d_2src(self, x, x2, y, packed, bias, cin1, cin2, cout, res=SLOT_NONE, post=POST_NONE,
+                        y_act=SLOT_NONE, act_slope=1.0):
+        self.keep(packed)
+        if bias is not None:
+            self.keep(bias)
+        check(lib().fv_plan_add_conv1d_2src(self._h, x, x2, y, y_act, res, _ptr(packed, "packed"),
+                                            _ptr(bias, "bias", True), cin1, cin2, cout, post,
+                                            float(act_slope)))
 
     def add_upsample_conv1d(self, x, y, packed, bias, cin, cout, k, rate, pad, pre_slope=1.0,
                             post=POST_NONE, y_act=SLOT_NONE, act_slope=1.0):

@@ -181,6 +181,9 @@ struct Op {
     int ndeps;
     int deps[3];
     bool signal;   // some op on another lane waits for this one: record its event
+    // two-source conv (1 tap): GEMM rows ci >= Cin1 are read from slot x2 (Cin - Cin1 channels)
+    int x2 = FV_SLOT_NONE;
+    int Cin1 = 0;
 };
 
 constexpr int kMaxLanes = 4;
@@ -236,9 +239,14 @@ static int infer(const fv_plan* plan, int B, int T, Shape* sh, int64_t* slot_ele
     for (size_t n = 0; n < plan->ops.size(); ++n) {
         const Op& o = plan->ops[n];
         if (!sh[o.x].set) return fail(FV_ERR_INVALID_ARG, "op %zu reads unset slot %d", n, o.x);
-        if (sh[o.x].C != o.Cin)
+        const int cin_x = o.x2 == FV_SLOT_NONE ? o.Cin : o.Cin1;
+        if (sh[o.x].C != cin_x)
             return fail(FV_ERR_INVALID_ARG, "op %zu: slot %d has %d channels, op expects %d", n,
-                        o.x, sh[o.x].C, o.Cin);
+                        o.x, sh[o.x].C, cin_x);
+        if (o.x2 != FV_SLOT_NONE &&
+            (!sh[o.x2].set || sh[o.x2].C != o.Cin - o.Cin1 || sh[o.x2].T != sh[o.x].T))
+            return fail(FV_ERR_INVALID_ARG, "op %zu: second input slot %d must be [%d, T] like the first", n,
+                        o.x2, o.Cin - o.Cin1);
         const int64_t Tout = conv_out_len(o, sh[o.x].T);
         if (Tout <= 0) return fail(FV_ERR_INVALID_ARG, "op %zu: empty output (T=%lld)", n, (long long)sh[o.x].T);
         const int Cout = o.type == OP_PQMF ? 1 : o.Cout;
@@ -248,12 +256,12 @@ static int infer(const fv_plan* plan, int B, int T, Shape* sh, int64_t* slot_ele
             if (!sh[aux[a]].set || sh[aux[a]].C != Cout || sh[aux[a]].T != Tout)
                 return fail(FV_ERR_INVALID_ARG, "op %zu: residual/accumulator slot %d shape mismatch", n, aux[a]);
         }
-        if (o.y == o.x) return fail(FV_ERR_INVALID_ARG, "op %zu: output aliases input", n);
+        if (o.y == o.x || o.y == o.x2) return fail(FV_ERR_INVALID_ARG, "op %zu: output aliases input", n);
         sh[o.y] = {Cout, Tout, true};
         const int64_t e = (int64_t)B * Cout * Tout;
         if (e > slot_elems[o.y]) slot_elems[o.y] = e;
         if (o.y2 != FV_SLOT_NONE) {
-            if (o.y2 == o.x || o.y2 == o.y)
+            if (o.y2 == o.x || o.y2 == o.y || o.y2 == o.x2)
                 return fail(FV_ERR_INVALID_ARG, "op %zu: activated twin aliases another tensor of the op", n);
             sh[o.y2] = {Cout, Tout, true};
             if (e > slot_elems[o.y2]) slot_elems[o.y2] = e;
@@ -263,9 +271,12 @@ static int infer(const fv_plan* plan, int B, int T, Shape* sh, int64_t* slot_ele
 }
 
 static ConvParams make_params(const Op& o, const float* x, float* y, float* y2, const float* res,
-                              const float* acc, const float* acc2, int B, int64_t Tin) {
+                              const float* acc, const float* acc2, int B, int64_t Tin,
+                              const float* x2 = nullptr) {
     ConvParams p = {};
     p.x = x;
+    p.x2 = x2;
+    p.Cin1 = x2 ? o.Cin1 : o.Cin;
     p.wp = o.wp;
     p.bias = o.bias;
     p.res = res;
@@ -306,9 +317,9 @@ static ConvParams make_params(const Op& o, const float* x, float* y, float* y2, 
 }
 
 static int run_op(const Op& o, const float* x, float* y, float* y2, const float* res, const float* acc,
-                  const float* acc2, int B, int64_t Tin, hipStream_t s) {
+                  const float* acc2, int B, int64_t Tin, hipStream_t s, const float* x2 = nullptr) {
     if (o.type == OP_PQMF) return launch_pqmf(x, o.wp, y, B, o.Cin, o.k, (int)Tin, s);
-    return launch_conv(make_params(o, x, y, y2, res, acc, acc2, B, Tin), s);
+    return launch_conv(make_params(o, x, y, y2, res, acc, acc2, B, Tin, x2), s);
 }
 
 // Cross-lane dependencies from the slots each op reads and writes (RAW, WAR, WAW):
@@ -334,7 +345,7 @@ static int compile_lanes(fv_plan* plan) {
             if (j >= 0 && plan->ops[j].lane != o.lane && j > latest[plan->ops[j].lane])
                 latest[plan->ops[j].lane] = j;
         };
-        const int reads[4] = {o.x, o.res, o.acc, o.acc2};
+        const int reads[5] = {o.x, o.res, o.acc, o.acc2, o.x2};
         const int writes[2] = {o.y, o.y2};
         for (int s : reads)
             if (s != FV_SLOT_NONE) need(last_write[s]);
@@ -648,6 +659,47 @@ int fv_plan_add_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, 
     return 0;
 }
 
+int fv_plan_add_conv1d_2src(fv_plan_t* plan, int x_slot, int x2_slot, int y_slot, int y_act_slot,
+                            int res_slot, const float* packed, const float* bias, int Cin1, int Cin2,
+                            int Cout, int post, float act_slope) {
+    if (Cin1 <= 0 || Cin2 <= 0) return fail(FV_ERR_INVALID_ARG, "conv1d_2src: Cin1=%d Cin2=%d", Cin1, Cin2);
+    if (int rc = check_slot(x2_slot, false)) return rc;
+    if (int rc = fv_plan_add_conv1d(plan, x_slot, y_slot, y_act_slot, res_slot, FV_SLOT_NONE, FV_SLOT_NONE,
+                                    packed, bias, Cin1 + Cin2, Cout, 1, 1, 0, FV_PAD_ZERO, 1.f, 1.f, post,
+                                    act_slope))
+        return rc;
+    Op& o = plan->ops.back();
+    o.x2 = x2_slot;
+    o.Cin1 = Cin1;
+    o.group = 0;
+    return 0;
+}
+
+int fv_conv1d_2src_fused(const float* x, const float* x2, const float* packed, const float* bias,
+                         const float* res, float* y, float* y_act, int B, int Cin1, int Cin2, int Cout,
+                         int T, int post, float act_slope, void* stream) {
+    if (Cin1 <= 0 || Cin2 <= 0) return fail(FV_ERR_INVALID_ARG, "conv1d_2src: Cin1=%d Cin2=%d", Cin1, Cin2);
+    if (int rc = check_conv_args(Cin1 + Cin2, Cout, 1, 1)) return rc;
+    if (!x || !x2 || !packed || !y) return fail(FV_ERR_INVALID_ARG, "conv1d_2src: null tensor");
+    if (x == y || x2 == y || x == y_act || x2 == y_act || (y_act && y_act == y))
+        return fail(FV_ERR_INVALID_ARG, "conv1d_2src: y / y_act must not alias an input or each other");
+    if (T <= 0) return fail(FV_ERR_INVALID_ARG, "conv1d_2src: empty output");
+    Op o = {};
+    o.type = OP_CONV;
+    o.act_slope = act_slope;
+    o.wp = packed;
+    o.bias = bias;
+    o.Cin = Cin1 + Cin2;
+    o.Cin1 = Cin1;
+    o.Cout = Cout;
+    o.k = 1;
+    o.dil = 1;
+    o.pre_slope = 1.f;
+    o.out_div = 1.f;
+    o.post = post;
+    return run_op(o, x, y, y_act, res, nullptr, nullptr, B, T, (hipStream_t)stream, x2);
+}
+
 int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot,
                                  const float* packed, const float* bias, int Cin, int Cout, int k,
                                  int stride, int pad, int out_pad, float pre_slope, int post,
@@ -788,7 +840,8 @@ int fv_plan_run(fv_plan_t* plan, int B, int T, const float* in, float* out, void
                 gp[cnt++] = make_params(q, base[q.x], base[q.y], q.y2 == FV_SLOT_NONE ? nullptr : base[q.y2],
                                         q.res == FV_SLOT_NONE ? nullptr : base[q.res],
                                         q.acc == FV_SLOT_NONE ? nullptr : base[q.acc],
-                                        q.acc2 == FV_SLOT_NONE ? nullptr : base[q.acc2], B, sh[q.x].T);
+                                        q.acc2 == FV_SLOT_NONE ? nullptr : base[q.acc2], B, sh[q.x].T,
+                                        q.x2 == FV_SLOT_NONE ? nullptr : base[q.x2]);
                 ++m;
             }
             hipStream_t s = lanes[o.lane];
@@ -815,7 +868,9 @@ int fv_plan_run(fv_plan_t* plan, int B, int T, const float* in, float* out, void
         hipStream_t s = lanes[o.lane];
         if (multi)
             for (int d = 0; d < o.ndeps; ++d) FV_HIP(hipStreamWaitEvent(s, plan->op_event[o.deps[d]], 0));
-        if (int rc = run_op(o, base[o.x], base[o.y], y2, res, acc, acc2, B, Tin, s)) return rc;
+        if (int rc = run_op(o, base[o.x], base[o.y], y2, res, acc, acc2, B, Tin, s,
+                            o.x2 == FV_SLOT_NONE ? nullptr : base[o.x2]))
+            return rc;
         if (multi && o.signal) FV_HIP(hipEventRecord(plan->op_event[n], s));
         sh[o.y] = {o.type == OP_PQMF ? 1 : o.Cout, Tout, true};
         if (o.y2 != FV_SLOT_NONE) sh[o.y2] = sh[o.y];

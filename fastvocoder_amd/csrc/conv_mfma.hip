@@ -162,12 +162,13 @@ __device__ __forceinline__ void dma_x(const ConvParams& p, const DmaPlan& d, __a
 // entirely outside [0, Tin), so padding is just one more out-of-range case.
 template <int NW>
 __device__ __forceinline__ void dma_x_zero_edge(const ConvParams& p, __amdgpu_buffer_rsrc_t rx,
-                                                float* xs, int ci0, int tA, int wave, int lane) {
+                                                float* xs, int cin_src, int ci0, int tA, int wave,
+                                                int lane) {
     for (int j = wave; j < p.nx_inst; j += NW) {
         const int idx = j * 64 + lane;
         const int row = (int)__umulhi((unsigned)idx, p.ncol4c_magic);
         const int t = tA + 4 * (idx - row * p.ncol4c);
-        const bool ok = row < p.ci_chunk && ci0 + row < p.Cin && t >= 0 && t < p.Tin;
+        const bool ok = row < p.ci_chunk && ci0 + row < cin_src && t >= 0 && t < p.Tin;
         dma16(rx, xs + j * 256, ok ? (unsigned)((ci0 + row) * p.Tin + t) * 4u : kOutOfRange);
     }
 }
@@ -187,8 +188,8 @@ __device__ __forceinline__ void dma_w(const ConvParams& p, const DmaPlan& d, __a
 // Synchronous path for tiles that touch the sequence ends or unaligned tensors:
 // zero / reflection padding resolved per element, raw values written to LDS.
 template <int NT>
-__device__ __forceinline__ void stage_x_edge(const ConvParams& p, float* xs, int b, int ci0, int tA,
-                                             int tid) {
+__device__ __forceinline__ void stage_x_edge(const ConvParams& p, float* xs, const float* xb, int cin_src,
+                                             int ci0, int tA, int tid) {
     const int total = p.ci_chunk * p.ncol4c;
     for (int idx = tid; idx < total; idx += NT) {
         const int row = (int)__umulhi((unsigned)idx, p.ncol4c_magic);
@@ -196,8 +197,8 @@ __device__ __forceinline__ void stage_x_edge(const ConvParams& p, float* xs, int
         const int ci = ci0 + row;
         const int t = tA + 4 * c4;
         float e[4] = {0.f, 0.f, 0.f, 0.f};
-        if (ci < p.Cin) {
-            const float* xr = p.x + ((size_t)b * p.Cin + ci) * (size_t)p.Tin;
+        if (ci < cin_src) {
+            const float* xr = xb + (size_t)ci * (size_t)p.Tin;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int tj = t + j;
@@ -213,17 +214,20 @@ __device__ __forceinline__ void stage_x_edge(const ConvParams& p, float* xs, int
 // tiles of aligned tensors; SLOW variants (reflection padding, unaligned rows) fall
 // back to the synchronous per-element path.  Returns true when the data is in flight
 // asynchronously (false: it was written synchronously by stage_x_edge).
+// (xb, cin_src, rx) describe the source tensor of this stage for batch item b -- p.x, or
+// p.x2 for the rows past Cin1 of a two-source conv; ci0 counts channels inside that source.
 template <int NW, int NT, bool SLOW>
 __device__ __forceinline__ void stage_x(const ConvParams& p, const DmaPlan& d, __amdgpu_buffer_rsrc_t rx,
-                                        float* xs, int b, int ci0, int tA, int wave, int lane, int tid) {
+                                        float* xs, const float* xb, int cin_src, int ci0, int tA, int wave,
+                                        int lane, int tid) {
     if (interior(p, tA)) {
         dma_x<NW>(p, d, rx, xs, ci0, tA, wave);
     } else {
         if constexpr (SLOW) {
-            if (p.vec_ok && p.pad_mode == FV_PAD_ZERO) dma_x_zero_edge<NW>(p, rx, xs, ci0, tA, wave, lane);
-            else stage_x_edge<NT>(p, xs, b, ci0, tA, tid);
+            if (p.vec_ok && p.pad_mode == FV_PAD_ZERO) dma_x_zero_edge<NW>(p, rx, xs, cin_src, ci0, tA, wave, lane);
+            else stage_x_edge<NT>(p, xs, xb, cin_src, ci0, tA, tid);
         } else {
-            dma_x_zero_edge<NW>(p, rx, xs, ci0, tA, wave, lane);
+            dma_x_zero_edge<NW>(p, rx, xs, cin_src, ci0, tA, wave, lane);
         }
     }
 }
@@ -435,11 +439,28 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
     const int nchunks = p.nchunks;
     if (tile_hi <= tile_lo) return;
 
-    const __amdgpu_buffer_rsrc_t rx =
-        make_rsrc(p.x + (size_t)b * p.Cin * (size_t)p.Tin, (unsigned)p.Cin * (unsigned)p.Tin * 4u);
+    // Two-source convs (p.x2: the K range is the concatenation of two tensors) exist for 1-tap
+    // kernels only, which run in the KT <= 1 instantiations; every other instantiation is
+    // compiled without the second descriptor.
+    constexpr bool TWO = KT <= 1;
+    const int cin_a = TWO ? p.Cin1 : p.Cin;
+    const float* const xb = p.x + (size_t)b * cin_a * (size_t)p.Tin;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)cin_a * (unsigned)p.Tin * 4u);
+    const float* const xb2 = (TWO && p.x2) ? p.x2 + (size_t)b * (p.Cin - cin_a) * (size_t)p.Tin : xb;
+    const __amdgpu_buffer_rsrc_t rx2 = make_rsrc(xb2, (unsigned)(TWO && p.x2 ? p.Cin - cin_a : cin_a) * (unsigned)p.Tin * 4u);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.wp, (unsigned)p.Cin * (unsigned)p.k * (unsigned)p.Mpad * 4u);
     DmaPlan dp;
     dma_plan<NW, M_T>(p, dp, m0, wave, lane);
+    // stage the input window of channels [ci0, ci0 + ci_chunk) (a chunk never straddles Cin1: host-checked)
+    auto stage = [&](float* xs, int ci0, int tA) {
+        if constexpr (TWO) {
+            if (ci0 >= cin_a) {
+                stage_x<NW, NT, SLOW>(p, dp, rx2, xs, xb2, p.Cin - cin_a, ci0 - cin_a, tA, wave, lane, tid);
+                return;
+            }
+        }
+        stage_x<NW, NT, SLOW>(p, dp, rx, xs, xb, cin_a, ci0, tA, wave, lane, tid);
+    };
     RowInfo<EN> ri[EH];
 #pragma unroll
     for (int h = 0; h < EH; ++h) {
@@ -455,7 +476,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
     {
         const int tA = tile_lo * N_T - p.pad - aoff;
         dma_w<NW, M_T>(p, dp, rw, ws0, 0, wave);
-        stage_x<NW, NT, SLOW>(p, dp, rx, xs0, b, 0, tA, wave, lane, tid);
+        stage(xs0, 0, tA);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -478,7 +499,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
             if (more) {
                 // (a SLOW variant's per-element path writes LDS synchronously here: the
                 //  buffer it fills was last read one stage ago, before a barrier)
-                stage_x<NW, NT, SLOW>(p, dp, rx, xs0 + nxt * p.xbuf, b, nci0, ntA, wave, lane, tid);
+                stage(xs0 + nxt * p.xbuf, nci0, ntA);
                 if (nchunks > 1) dma_w<NW, M_T>(p, dp, rw, ws0 + nxt * p.wbuf, nci0, wave);
             }
             // ---- last stage of a tile: issue the epilogue's tensor reads now (NR == 1 shapes;
@@ -663,7 +684,7 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(ConvParams p) {
     const float slope = p.pre_slope;
     for (int ci0 = 0; ci0 < p.Cin; ci0 += p.ci_chunk) {
         dma_w<NW, 16>(p, dp, rw, ws, ci0, wave);
-        stage_x<NW, NT, true>(p, dp, rx, xs, b, ci0, tA, wave, lane, tid);
+        stage_x<NW, NT, true>(p, dp, rx, xs, p.x + (size_t)b * p.Cin * (size_t)p.Tin, p.Cin, ci0, tA, wave, lane, tid);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const float* pb = xs + aoff + tid;
@@ -735,9 +756,12 @@ size_t plan_staging(ConvParams& p, const Geometry& g, int k_rows_target) {
                             round_up(c * p.k * g.m_t() / 4, 64) / 64 <= kMaxDmaW * nw;
         if (best && (!dma_ok || 2 * per_buf > (size_t)env_int("FV_LDS_BUDGET", 52) * 1024)) break;
         if (!dma_ok) return 0;
-        if (cin_pad % c == 0 || !best) best = c;
-        if (c * p.k >= k_rows_target && cin_pad % c == 0) break;
+        // a stage of a two-source conv must not straddle the boundary between its tensors
+        const bool src_ok = !p.x2 || p.Cin1 % c == 0;
+        if (src_ok && (cin_pad % c == 0 || !best)) best = c;
+        if (best == c && c * p.k >= k_rows_target && cin_pad % c == 0) break;
     }
+    if (!best) return 0;
     p.ci_chunk = best;
     p.nchunks = (p.Cin + best - 1) / best;
     p.nx_inst = round_up(best * p.ncol4c, 64) / 64;
@@ -839,12 +863,17 @@ int prepare_conv(ConvParams& p, LaunchInfo& li, int members = 1) {
                     p.pad, p.Tin);
     if (p.pre_slope < 0.f || p.pre_slope > 1.f)
         return fail(FV_ERR_INVALID_ARG, "conv: input activation slope %g outside [0, 1]", p.pre_slope);
+    if (p.x2 && (p.k != 1 || p.ups != 1 || p.pre_slope != 1.f || p.Cin1 <= 0 || p.Cin1 >= p.Cin || p.M <= 4))
+        return fail(FV_ERR_UNSUPPORTED, "two-source conv: needs k = 1, no input activation, Cout > 4 "
+                    "(k=%d Cin1=%d Cin=%d Cout=%d)", p.k, p.Cin1, p.Cin, p.Cout);
+    if (!p.x2) p.Cin1 = p.Cin;
     if ((double)p.Cin * p.Tin * 4.0 >= 1073741824.0 || (double)p.Cin * p.k * p.Mpad * 4.0 >= 1073741824.0 ||
         (double)p.Cout * p.Tout * 4.0 >= 1073741824.0)
         return fail(FV_ERR_UNSUPPORTED, "conv: one utterance's tensor (%d x %d or %d x %d floats) exceeds the "
                     "1 GiB buffer-descriptor range of the kernels; split the utterance", p.Cin, p.Tin,
                     p.Cout, p.Tout);
-    p.vec_ok = (p.Tin % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+    p.vec_ok = (p.Tin % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) &&
+               ((reinterpret_cast<uintptr_t>(p.x2) & 15) == 0);
     li.flops = 2.0 * p.B * (double)p.M * p.Tq * p.Cin * p.k;
     li.bytes = 4.0 * ((double)p.B * p.Cin * p.Tin + (double)p.B * p.Cout * p.Tout *
                       (1 + (p.res != nullptr) + (p.acc_in != nullptr) + (p.acc_in2 != nullptr) +

@@ -59,6 +59,10 @@ static inline Polyphase upsample_phases(int k, int u, int p) {
 // y[co, q*ups + ph] with co = m / ups, ph = m % ups.
 struct ConvParams {
     const float* x;
+    const float* x2;      // optional second input tensor [B, Cin - Cin1, Tin]: GEMM rows ci >= Cin1
+                          // come from it (K-concatenation of two convs that sum, e.g. ResidualStack's
+                          // 1x1 + skip 1x1); null otherwise.  1-tap kernels only.
+    int Cin1;             // channels read from x (== Cin without x2)
     const float* wp;      // [Cin*k][Mpad]
     const float* bias;    // [Cout] or null
     const float* res;     // [B,Cout,Tout] or null

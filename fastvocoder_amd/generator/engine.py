@@ -97,6 +97,26 @@ class PlanBuilder:
                              cin=conv.in_channels, cout=conv.out_channels, k=k, dil=d, pad=pad,
                              pad_mode=pad_mode, out_div=out_div, post=post))
 
+    def conv_sum_1x1(self, conv_a, src_a, conv_b, src_b, dst, pre_slope_a=1.0, res=SLOT_NONE,
+                     post=POST_NONE):
+        """dst = post(conv_a(act(src_a)) + conv_b(src_b) [+ res]) for two 1x1 Conv1d containers, as
+        ONE launch: the K range of the GEMM is the concatenation of the two inputs
+        (fv_conv1d_2src_fused).  The kernel applies no input activation, so ``pre_slope_a`` must
+        be absorbed by the producer of ``src_a`` -- activation hoisting does that whenever
+        ``src_a`` has no consumer that needs it raw (checked in :meth:`finalize`)."""
+        for c in (conv_a, conv_b):
+            if c.kernel_size[0] != 1 or c.stride[0] != 1 or c.groups != 1 or c.padding[0] != 0:
+                raise _native.NativeError("conv_sum_1x1: both layers must be plain 1x1 convs")
+        if conv_a.out_channels != conv_b.out_channels:
+            raise _native.NativeError("conv_sum_1x1: the two convs must have the same output channels")
+        w = torch.cat([effective_weight(conv_a), effective_weight(conv_b)], dim=1).contiguous()
+        ba, bb = self._bias(conv_a), self._bias(conv_b)
+        bias = ba if bb is None else (bb if ba is None else (ba + bb).contiguous())
+        self.ops.append(dict(kind="conv2", lane=self.lane, x=src_a, x2=src_b, y=dst, res=res, acc=SLOT_NONE,
+                             pre_slope=float(pre_slope_a), packed=_native.pack_conv1d(w), bias=bias,
+                             cin1=conv_a.in_channels, cin2=conv_b.in_channels, cout=conv_a.out_channels,
+                             post=post))
+
     def conv_transpose(self, convt, src, dst, pre_slope=1.0, post=POST_NONE):
         """Record a torch.nn.ConvTranspose1d container (polyphase form)."""
         if convt.groups != 1 or convt.dilation[0] != 1:
@@ -155,7 +175,8 @@ class PlanBuilder:
                         act_uses.setdefault(c["pre_slope"], []).append(j)
                     else:
                         raw_needed = True
-                if c["res"] == y or c["acc"] == y or c.get("acc2", SLOT_NONE) == y:
+                if c["res"] == y or c["acc"] == y or c.get("acc2", SLOT_NONE) == y or \
+                        c.get("x2", SLOT_NONE) == y:
                     raw_needed = True
                 if c["y"] == y or c.get("y_act") == y:
                     break
@@ -186,6 +207,8 @@ class PlanBuilder:
             if op["kind"] == "conv":
                 reach = op["dil"] * (op["k"] - 1)
                 own, rate = max(op["pad"], reach - op["pad"]), 1
+            elif op["kind"] == "conv2":
+                own, rate = 0, 1
             elif op["kind"] == "convT":
                 own, rate = -(-op["k"] // op["stride"]) + 1, op["stride"]
             elif op["kind"] == "upconv":
@@ -194,7 +217,7 @@ class PlanBuilder:
                 S, ntaps = op["h"].shape
                 own, rate = -(-(ntaps // 2) // S) + 1, S
             need[op["x"]] = max(need.get(op["x"], 0), -(-h_out // rate) + own)
-            for aux in (op["res"], op["acc"], op.get("acc2", SLOT_NONE)):
+            for aux in (op["res"], op["acc"], op.get("acc2", SLOT_NONE), op.get("x2", SLOT_NONE)):
                 if aux != SLOT_NONE:
                     need[aux] = max(need.get(aux, 0), h_out)
         return need.get(SLOT_IN, 0)
@@ -212,6 +235,13 @@ class PlanBuilder:
                                      pre_slope=op["pre_slope"], res=op["res"], acc=op["acc"],
                                      out_div=op["out_div"], post=op["post"], y_act=op["y_act"],
                                      act_slope=op["act_slope"], acc2=op.get("acc2", SLOT_NONE))
+            elif op["kind"] == "conv2":
+                if op["pre_slope"] != 1.0:
+                    raise _native.NativeError("conv_sum_1x1: the activation of the first input could not "
+                                              "be hoisted into its producer")
+                self.plan.add_conv1d_2src(op["x"], op["x2"], op["y"], op["packed"], op["bias"], op["cin1"],
+                                          op["cin2"], op["cout"], res=op["res"], post=op["post"],
+                                          y_act=op["y_act"], act_slope=op["act_slope"])
             elif op["kind"] == "convT":
                 self.plan.add_conv_transpose1d(op["x"], op["y"], op["packed"], op["bias"], op["cin"],
                                                op["cout"], op["k"], op["stride"], op["pad"],

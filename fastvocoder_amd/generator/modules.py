@@ -6,6 +6,8 @@ calling code carry over; the arithmetic is in csrc/.
 Each block can also be called on its own (``block(x)``, x ``[B,C,T]`` on a ROCm
 device): it then runs a private plan SLOT_IN -> SLOT_OUT.
 """
+import os
+
 import torch
 
 from .engine import (NativeModule, PAD_CAUSAL, PAD_REFLECT, PAD_ZERO, POST_NONE, SLOT_IN, SLOT_NONE,
@@ -13,6 +15,7 @@ from .engine import (NativeModule, PAD_CAUSAL, PAD_REFLECT, PAD_ZERO, POST_NONE,
 from .. import _native
 
 LRELU_SLOPE = 0.1  # reference modules.py:9
+_FUSE_SKIP = os.environ.get("FV_FUSE_SKIP", "1") != "0"   # ResidualStack: 1x1 + skip 1x1 as one launch
 
 
 def get_padding(kernel_size, dilation=1):
@@ -207,8 +210,13 @@ class ResidualStack(_Block):
         dilated, pointwise = (self.stack[i] for i in self._conv_at)
         dilated = getattr(dilated, "conv", dilated)               # CausalConv1d wraps its conv
         pb.conv(dilated, src, hidden, pad=self._pad, pad_mode=self._pad_mode, pre_slope=self._slope)
-        pb.conv(self.skip_layer, src, skip)                       # un-activated input
-        pb.conv(pointwise, hidden, dst, pre_slope=self._slope, res=skip, post=post)
+        if _FUSE_SKIP and self.channels > 4:
+            # stack[4](act(hidden)) + skip_layer(src): one GEMM over the concatenated K range;
+            # the skip branch costs no launch and no [B,C,T] round trip (src is read raw)
+            pb.conv_sum_1x1(pointwise, hidden, self.skip_layer, src, dst, pre_slope_a=self._slope, post=post)
+        else:
+            pb.conv(self.skip_layer, src, skip)                   # un-activated input
+            pb.conv(pointwise, hidden, dst, pre_slope=self._slope, res=skip, post=post)
 
 
 class LastLinear(NativeModule):

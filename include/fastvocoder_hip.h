@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FV_ABI_VERSION 4
+#define FV_ABI_VERSION 5
 
 #define FV_ERR_INVALID_ARG (-1)
 #define FV_ERR_UNSUPPORTED (-2)
@@ -121,6 +121,20 @@ int fv_conv1d_fused(const float* x, const float* packed, const float* bias,
                     void* stream);
 
 /*
+ * y = post( W1 * x + W2 * x2 + bias + res )    (two 1-tap convs that are summed, as ONE GEMM)
+ *
+ * Replaces ResidualStack's tail (modules.py:362-366,382): stack[4](act(h)) + skip_layer(c) --
+ * the K range of the 1x1 conv is the concatenation of the two input tensors, so the skip
+ * branch costs no launch, no [B,C,T] round trip through HBM and no separate add.
+ *   x [B,Cin1,T], x2 [B,Cin2,T] (both already activated as the graph requires: there is no
+ *   input activation here), packed = fv_pack_conv1d_weight of cat([W1, W2], dim=1)
+ *   [Cout, Cin1+Cin2, 1], bias = b1 + b2 (or NULL), res [B,Cout,T] or NULL, Cout > 4.
+ */
+int fv_conv1d_2src_fused(const float* x, const float* x2, const float* packed, const float* bias,
+                         const float* res, float* y, float* y_act, int B, int Cin1, int Cin2,
+                         int Cout, int T, int post, float act_slope, void* stream);
+
+/*
  * y = post( conv_transpose1d(lrelu(x, pre_slope); w, stride, pad, out_pad) + bias )
  *
  * Replaces F.leaky_relu + torch.nn.ConvTranspose1d at hifigan.py:95-96,
@@ -206,6 +220,9 @@ int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot, int y_
                                  const float* packed, const float* bias, int Cin, int Cout,
                                  int k, int stride, int pad, int out_pad, float pre_slope,
                                  int post, float act_slope);
+int fv_plan_add_conv1d_2src(fv_plan_t* plan, int x_slot, int x2_slot, int y_slot, int y_act_slot,
+                            int res_slot, const float* packed, const float* bias, int Cin1,
+                            int Cin2, int Cout, int post, float act_slope);
 int fv_plan_add_upsample_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot,
                                 const float* packed, const float* bias, int Cin, int Cout,
                                 int k, int rate, int pad, float pre_slope, int post,

@@ -52,7 +52,7 @@ def _model(name, cfg, seed):
 
 def test_native_library_is_loaded():
     L = _native.lib()
-    assert L.fv_version() == 4
+    assert L.fv_version() == 5
     with open("/proc/self/maps") as f:
         assert "libfastvocoder_hip.so" in f.read()
 
@@ -212,6 +212,46 @@ def test_batchnorm_fold_and_last_linear():
     lit = oo.conv1d(bn, head.linear_2.weight.detach().cpu().numpy(), head.linear_2.bias.detach().cpu().numpy())
     fold = oo.conv1d(x.numpy(), w2.cpu().numpy(), b2.cpu().numpy())
     assert _rel(torch.from_numpy(fold), lit) <= 2e-5
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 32, 200), (1, 64, 64, 64, 1000), (1, 16, 48, 32, 333),
+                                  (3, 256, 256, 256, 61), (1, 8, 8, 16, 7)],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_two_source_1x1_conv_vs_oracle(case):
+    """fv_conv1d_2src_fused: W1 x + W2 x2 + (b1 + b2) [+ res] as one GEMM over the concatenated K
+    range (ResidualStack's 1x1 + skip 1x1, modules.py:362-366,382) vs the two convs of the oracle;
+    aligned and unaligned T (the latter takes the per-element staging path)."""
+    B, C1, C2, Cout, T = case
+    rng = np.random.RandomState(hash(case) % (2 ** 31))
+    x1 = rng.randn(B, C1, T).astype(np.float32)
+    x2 = rng.randn(B, C2, T).astype(np.float32)
+    w1 = (rng.randn(Cout, C1, 1) / np.sqrt(C1)).astype(np.float32)
+    w2 = (rng.randn(Cout, C2, 1) / np.sqrt(C2)).astype(np.float32)
+    b1, b2 = rng.randn(Cout).astype(np.float32), rng.randn(Cout).astype(np.float32)
+    res = rng.randn(B, Cout, T).astype(np.float32)
+    ref = oo.conv1d(x1, w1, b1) + oo.conv1d(x2, w2, b2)
+    dev = _dev()
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    packed = _native.pack_conv1d(torch.cat([t(w1), t(w2)], dim=1).contiguous())
+    y = _native.conv1d_2src_fused(t(x1), t(x2), packed, t(b1 + b2), Cout)
+    assert _rel(y, ref) <= 2e-5
+    y = _native.conv1d_2src_fused(t(x1), t(x2), packed, None, Cout, res=t(res), post=_native.POST_RELU)
+    assert _rel(y, np.maximum(ref - (b1 + b2)[None, :, None] + res, 0)) <= 2e-5
+
+
+def test_fused_skip_equals_unfused_residual_stack(monkeypatch):
+    """The K-concatenated ResidualStack tail vs the three-launch form (FV_FUSE_SKIP=0)."""
+    from fastvocoder_amd.generator import modules
+    torch.manual_seed(1)
+    rs = modules.ResidualStack(kernel_size=3, channels=64, dilation=3).to(_dev())
+    x = torch.randn(2, 64, 500, device=_dev())
+    fused = rs(x).cpu().numpy()
+    assert rs._fv_plans["forward"][1].num_ops() == 2
+    monkeypatch.setattr(modules, "_FUSE_SKIP", False)
+    rs.invalidate_plans()
+    plain = rs(x).cpu().numpy()
+    assert rs._fv_plans["forward"][1].num_ops() == 3
+    assert np.abs(fused - plain).max() <= 1e-5 * max(1.0, np.abs(plain).max())
 
 
 def test_activated_twin_outputs():

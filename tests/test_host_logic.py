@@ -164,7 +164,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_native.LIB_PATH)
     for n in sorted(names):
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
-    assert _native.lib().fv_version() == 4
+    assert _native.lib().fv_version() == 5
     # host-only entry points that need no device
     assert _native.lib().fv_packed_conv1d_floats(128, 128, 11) == 128 * 11 * 128
     assert _native.lib().fv_packed_conv_transpose1d_floats(256, 128, 16, 8, 4) == 256 * 3 * 1024
