@@ -49,6 +49,9 @@
 
 #include "fv_internal.h"
 
+#ifndef FV_MFMA_PRIO
+#define FV_MFMA_PRIO 0     // s_setprio around the matrix loop: +1 measured 1.5 % slower, -2 (staging first) within noise
+#endif
 #ifndef FV_PREFETCH_RES
 #define FV_PREFETCH_RES 0   // measured: issuing the residual read before the tile's last MFMAs costs
                             // more (registers, spills in the split-K shapes) than the latency it hides
@@ -425,6 +428,9 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
+#if FV_MFMA_PRIO < 0
+    __builtin_amdgcn_s_setprio(-FV_MFMA_PRIO);
+#endif
     const int lm = lane & (MF - 1), kq = lane / MF;   // position inside the MFMA operand
     const int wk = wave / (WM * WN);
     const int wave_m = (wave / WN) % WM, wave_n = wave % WN;
@@ -533,6 +539,11 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
                 const float* xsB = xs0 + cur * p.xbuf + aoff + wave_n * (MF * NR) + lm + kq * p.xw;
                 const float slope = p.pre_slope;
                 const int cend = (p.dbg & 4) ? 0 : p.ci_chunk;
+#if FV_MFMA_PRIO > 0
+                __builtin_amdgcn_s_setprio(FV_MFMA_PRIO);   // matrix phase ahead of other waves' staging/epilogue VALU
+#elif FV_MFMA_PRIO < 0
+                __builtin_amdgcn_s_setprio(0);              // staging / epilogue instructions of other waves first
+#endif
                 for (int c = wk * F::KS; c < cend; c += F::KS * WK) {
                     const float* pa = wsA + c * (k * M_T);
                     const float* pb = xsB + c * p.xw;
@@ -559,6 +570,11 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
                         }
                     }
                 }
+#if FV_MFMA_PRIO > 0
+                __builtin_amdgcn_s_setprio(0);
+#elif FV_MFMA_PRIO < 0
+                __builtin_amdgcn_s_setprio(-FV_MFMA_PRIO);
+#endif
             }
             if (last_chunk) {
                 // ---- tile finished: (split-K reduce and) fused epilogue ----
