@@ -49,8 +49,10 @@
 
 #include "fv_internal.h"
 
-#ifndef FV_MFMA_PRIO
-#define FV_MFMA_PRIO 0     // s_setprio around the matrix loop: +1 measured 1.5 % slower, -2 (staging first) within noise
+#ifndef FV_RING
+#define FV_RING 2          // stage buffers of the LDS-DMA ring in the plain (aligned, zero-padded) kernels.
+                           // Measured (HiFi-GAN light, B = 1): 2 -> 1.66 ms/step, 3 -> 1.71 ms (the third
+                           // buffer halves the stage size of the 7- and 3-tap kernels under the LDS budget)
 #endif
 #ifndef FV_PREFETCH_RES
 #define FV_PREFETCH_RES 0   // measured: issuing the residual read before the tile's last MFMAs costs
@@ -403,6 +405,22 @@ struct Frag<16> {
     static __device__ __forceinline__ int row(int reg, int lane) { return 4 * (lane >> 4) + reg; }
 };
 
+// Stage buffers of the DMA ring per kernel variant (see conv_body).
+__host__ __device__ constexpr int kRingStages(bool slow, bool act) { return (slow || act) ? 2 : FV_RING; }
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate);
+// n <= 2 * (kMaxDmaX + kMaxDmaW).  Larger or unexpected values wait for everything.
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define FV_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (n) {
+        FV_W(1) FV_W(2) FV_W(3) FV_W(4) FV_W(5) FV_W(6) FV_W(7) FV_W(8) FV_W(9) FV_W(10) FV_W(11) FV_W(12)
+        FV_W(13) FV_W(14) FV_W(15) FV_W(16) FV_W(17) FV_W(18) FV_W(19) FV_W(20) FV_W(21) FV_W(22) FV_W(23)
+        FV_W(24) FV_W(25) FV_W(26) FV_W(27) FV_W(28)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef FV_W
+}
+
 // ---------------------------------------------------------------------------
 // The kernel.  Block tile (MF*WM) x (MF*NR*WN); WK wave groups split K.
 // KT > 0 / DIL > 0 fix the tap count / dilation at compile time; ACT enables the
@@ -422,15 +440,11 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int k = KT > 0 ? KT : p.k;
     const int dil = DIL > 0 ? DIL : p.dil;
-    float* const xs0 = smem;                      // 2 x p.xbuf floats
-    float* const ws0 = smem + 2 * p.xbuf;         // 2 x p.wbuf floats
+    float* const xs0 = smem;                      // NS x p.xbuf floats, then NS x p.wbuf (see the ring below)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
-#if FV_MFMA_PRIO < 0
-    __builtin_amdgcn_s_setprio(-FV_MFMA_PRIO);
-#endif
     const int lm = lane & (MF - 1), kq = lane / MF;   // position inside the MFMA operand
     const int wk = wave / (WM * WN);
     const int wave_m = (wave / WN) % WM, wave_n = wave % WN;
@@ -478,162 +492,140 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
     // the tile's window start is t0 - pad; with N_T a multiple of 4 only pad sets the phase
     const int aoff = (((-p.pad) % 4) + 4) % 4;
 
-    // prologue: stage (tile_lo, chunk 0) -> buffer 0
-    {
-        const int tA = tile_lo * N_T - p.pad - aoff;
-        dma_w<NW, M_T>(p, dp, rw, ws0, 0, wave);
-        stage(xs0, 0, tA);
+    // ---- software pipeline over this block's stages s = (tile, channel chunk) -----------------
+    // LDS holds NS stage buffers; stage s lives in buffer s % NS and its DMA is issued NS-1
+    // stages ahead (across tile boundaries too).  Per stage: wait for OWN DMA instructions of
+    // stage s (counted vmcnt: the later stages' stay in flight), barrier (everyone's landed,
+    // and everyone is done reading buffer (s-1) % NS), issue stage s+NS-1 into that buffer,
+    // then the matrix work of stage s.  NS = FV_RING (2: one stage ahead; deeper rings were
+    // measured slower, see FV_RING).  The SLOW / ACT variants stage some tiles synchronously (no
+    // fixed instruction count per stage): they always use NS = 2 and full waits.
+    constexpr int NS = kRingStages(SLOW, ACT);
+    const int total = (tile_hi - tile_lo) * nchunks;
+    int n_inst = 0;   // this wave's DMA instructions per stage
+#pragma unroll
+    for (int i = 0; i < kMaxDmaX; ++i) n_inst += (wave + i * NW < p.nx_inst) ? 1 : 0;
+    if (nchunks > 1) {
+#pragma unroll
+        for (int i = 0; i < kMaxDmaW; ++i) n_inst += (wave + i * NW < p.nw_inst) ? 1 : 0;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    float* const ws_base = smem + NS * p.xbuf;
+    int it = tile_lo, ic = 0, ibuf = 0, issued = 0;   // next stage to issue: (tile, chunk), its buffer
+    const int issue_limit = (p.dbg & 2) ? min(total, NS - 1) : total;
+    auto issue = [&]() {
+        const int tA = it * N_T - p.pad - aoff;
+        stage(xs0 + ibuf * p.xbuf, ic * p.ci_chunk, tA);
+        if (nchunks > 1) dma_w<NW, M_T>(p, dp, rw, ws_base + ibuf * p.wbuf, ic * p.ci_chunk, wave);
+        if (++ic == nchunks) { ic = 0; ++it; }
+        if (++ibuf == NS) ibuf = 0;
+        ++issued;
+    };
+    // with a single chunk the weights never change: staged once, into buffer 0
+    if (nchunks == 1) dma_w<NW, M_T>(p, dp, rw, ws_base, 0, wave);
+    for (int i = 0; i < NS - 1 && issued < issue_limit; ++i) issue();
 
-    int cur = 0;
-    for (int tile = tile_lo; tile < tile_hi; ++tile) {
-        acc_t acc[NR];
+    int tile = tile_lo, chunk = 0, cur = 0;
+    bool stores_in_flight = false;   // stores and loads retire out of order w.r.t. each other: full wait then
+    acc_t acc[NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r)
+    for (int r = 0; r < NR; ++r)
 #pragma unroll
-            for (int i = 0; i < F::REGS; ++i) acc[r][i] = 0.f;
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            const int nxt = cur ^ 1;
-            // ---- next stage's coordinates; its DMA runs while this stage computes ----
-            const bool last_chunk = chunk == nchunks - 1;
-            const int ntile = last_chunk ? tile + 1 : tile;
-            const int nci0 = last_chunk ? 0 : (chunk + 1) * p.ci_chunk;
-            const bool more = ntile < tile_hi && !(p.dbg & 2);
-            const int ntA = ntile * N_T - p.pad - aoff;
-            if (more) {
-                // (a SLOW variant's per-element path writes LDS synchronously here: the
-                //  buffer it fills was last read one stage ago, before a barrier)
-                stage(xs0 + nxt * p.xbuf, nci0, ntA);
-                if (nchunks > 1) dma_w<NW, M_T>(p, dp, rw, ws0 + nxt * p.wbuf, nci0, wave);
-            }
-            // ---- last stage of a tile: issue the epilogue's tensor reads now (NR == 1 shapes;
-            //      the two-accumulator shapes have no registers to spare) ----
-            constexpr bool PRE = FV_PREFETCH_RES && NR == 1;
-            float pre_r[PRE ? F::REGS : 1];
-            if constexpr (PRE) {
+        for (int i = 0; i < F::REGS; ++i) acc[r][i] = 0.f;
+    for (int s = 0; s < total; ++s) {
+        // ---- stage s has landed (own wave: vmcnt; others: barrier) ----
+        if (NS == 2 || stores_in_flight) wait_vmcnt(0);
+        else wait_vmcnt((issued - s - 1) * n_inst);
+        stores_in_flight = false;
+        __syncthreads();
+        if (issued < issue_limit) issue();
+        const bool last_chunk = chunk == nchunks - 1;
+        // ---- matrix work on buffer cur ----
+        {
+            const float* wsA = ws_base + (nchunks > 1 ? cur * p.wbuf : 0) + wave_m * MF + lm + kq * (k * M_T);
+            const float* xsB = xs0 + cur * p.xbuf + aoff + wave_n * (MF * NR) + lm + kq * p.xw;
+            const float slope = p.pre_slope;
+            const int cend = (p.dbg & 4) ? 0 : p.ci_chunk;
+            for (int c = wk * F::KS; c < cend; c += F::KS * WK) {
+                const float* pa = wsA + c * (k * M_T);
+                const float* pb = xsB + c * p.xw;
+                if constexpr (KT > 0) {
 #pragma unroll
-                for (int i = 0; i < F::REGS; ++i) pre_r[i] = 0.f;
-                if (last_chunk && (WK == 1 || wk == 0) && !(p.dbg & 1) && p.res) {
-                    const size_t boff = (size_t)b * p.Cout * (size_t)p.Tout;
-                    const __amdgpu_buffer_rsrc_t rres =
-                        make_rsrc(p.res + boff, (unsigned)p.Cout * (unsigned)p.Tout * 4u);
-                    const int q = tile * N_T + wave_n * MF + lm;
+                    for (int tap = 0; tap < KT; ++tap) {
+                        const float a = pa[tap * M_T];
 #pragma unroll
-                    for (int h = 0; h < EH; ++h) {
-                        int mm[EN];
-                        unsigned off[EN];
-#pragma unroll
-                        for (int i = 0; i < EN; ++i) mm[i] = m0 + wave_m * MF + F::row(h * EN + i, lane);
-                        epilogue_offsets<EN>(p, ri[h], mm, q, off);
-#pragma unroll
-                        for (int i = 0; i < EN; ++i) pre_r[h * EN + i] = buffer_load1(rres, off[i]);
-                    }
-                }
-            }
-            // ---- matrix work on the current buffers ----
-            {
-                // with a single chunk the weights never change: they stay in buffer 0
-                const float* wsA = ws0 + (nchunks > 1 ? cur * p.wbuf : 0) + wave_m * MF + lm + kq * (k * M_T);
-                const float* xsB = xs0 + cur * p.xbuf + aoff + wave_n * (MF * NR) + lm + kq * p.xw;
-                const float slope = p.pre_slope;
-                const int cend = (p.dbg & 4) ? 0 : p.ci_chunk;
-#if FV_MFMA_PRIO > 0
-                __builtin_amdgcn_s_setprio(FV_MFMA_PRIO);   // matrix phase ahead of other waves' staging/epilogue VALU
-#elif FV_MFMA_PRIO < 0
-                __builtin_amdgcn_s_setprio(0);              // staging / epilogue instructions of other waves first
-#endif
-                for (int c = wk * F::KS; c < cend; c += F::KS * WK) {
-                    const float* pa = wsA + c * (k * M_T);
-                    const float* pb = xsB + c * p.xw;
-                    if constexpr (KT > 0) {
-#pragma unroll
-                        for (int tap = 0; tap < KT; ++tap) {
-                            const float a = pa[tap * M_T];
-#pragma unroll
-                            for (int r = 0; r < NR; ++r) {
-                                float bv = pb[tap * dil + r * MF];
-                                if constexpr (ACT) bv = act(bv, slope);
-                                acc[r] = F::mfma(a, bv, acc[r]);
-                            }
+                        for (int r = 0; r < NR; ++r) {
+                            float bv = pb[tap * dil + r * MF];
+                            if constexpr (ACT) bv = act(bv, slope);
+                            acc[r] = F::mfma(a, bv, acc[r]);
                         }
-                    } else {
-                        for (int tap = 0; tap < k; ++tap) {
-                            const float a = pa[tap * M_T];
+                    }
+                } else {
+                    for (int tap = 0; tap < k; ++tap) {
+                        const float a = pa[tap * M_T];
 #pragma unroll
-                            for (int r = 0; r < NR; ++r) {
-                                float bv = pb[tap * dil + r * MF];
-                                if constexpr (ACT) bv = act(bv, slope);
-                                acc[r] = F::mfma(a, bv, acc[r]);
-                            }
+                        for (int r = 0; r < NR; ++r) {
+                            float bv = pb[tap * dil + r * MF];
+                            if constexpr (ACT) bv = act(bv, slope);
+                            acc[r] = F::mfma(a, bv, acc[r]);
                         }
                     }
                 }
-#if FV_MFMA_PRIO > 0
-                __builtin_amdgcn_s_setprio(0);
-#elif FV_MFMA_PRIO < 0
-                __builtin_amdgcn_s_setprio(-FV_MFMA_PRIO);
-#endif
             }
-            if (last_chunk) {
-                // ---- tile finished: (split-K reduce and) fused epilogue ----
-                if constexpr (WK > 1) {
-                    float* red = smem + p.red_off;
-                    if (wk > 0) {
-                        float* dst = red + ((wk - 1) * (WM * WN) + wave_m * WN + wave_n) *
-                                               (NR * F::REGS * 64) + lane;
+        }
+        if (last_chunk) {
+            // ---- tile finished: (split-K reduce and) fused epilogue ----
+            if constexpr (WK > 1) {
+                float* red = smem + p.red_off;
+                if (wk > 0) {
+                    float* dst = red + ((wk - 1) * (WM * WN) + wave_m * WN + wave_n) *
+                                           (NR * F::REGS * 64) + lane;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+#pragma unroll
+                        for (int i = 0; i < F::REGS; ++i) dst[(r * F::REGS + i) * 64] = acc[r][i];
+                }
+                __syncthreads();
+                if (wk == 0) {
+#pragma unroll
+                    for (int g = 1; g < WK; ++g) {
+                        const float* src = red + ((g - 1) * (WM * WN) + wave_m * WN + wave_n) *
+                                                     (NR * F::REGS * 64) + lane;
 #pragma unroll
                         for (int r = 0; r < NR; ++r)
 #pragma unroll
-                            for (int i = 0; i < F::REGS; ++i) dst[(r * F::REGS + i) * 64] = acc[r][i];
-                    }
-                    __syncthreads();
-                    if (wk == 0) {
-#pragma unroll
-                        for (int g = 1; g < WK; ++g) {
-                            const float* src = red + ((g - 1) * (WM * WN) + wave_m * WN + wave_n) *
-                                                         (NR * F::REGS * 64) + lane;
-#pragma unroll
-                            for (int r = 0; r < NR; ++r)
-#pragma unroll
-                                for (int i = 0; i < F::REGS; ++i) acc[r][i] += src[(r * F::REGS + i) * 64];
-                        }
-                    }
-                }
-                if ((WK == 1 || wk == 0) && !(p.dbg & 1)) {
-                    const EpilogueRsrc ersrc = epilogue_rsrc(p, b);   // built here: no SGPRs held across the MFMA loop
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) {
-                        const int q = tile * N_T + wave_n * (MF * NR) + r * MF + lm;
-#pragma unroll
-                        for (int h = 0; h < EH; ++h) {
-                            float vv[EN], rv[EN], av[EN], a2[EN];
-                            int mm[EN];
-                            unsigned off[EN];
-#pragma unroll
-                            for (int i = 0; i < EN; ++i) {
-                                vv[i] = acc[r][h * EN + i];
-                                mm[i] = m0 + wave_m * MF + F::row(h * EN + i, lane);
-                            }
-                            epilogue_offsets<EN>(p, ri[h], mm, q, off);
-                            epilogue_load<EN>(p, ersrc, off, rv, av, a2, /*with_res=*/!PRE);
-                            if constexpr (PRE) {
-#pragma unroll
-                                for (int i = 0; i < EN; ++i) rv[i] = pre_r[h * EN + i];
-                            }
-                            epilogue_finish<EN>(p, ersrc, ri[h], off, vv, rv, av, a2);
-                        }
+                            for (int i = 0; i < F::REGS; ++i) acc[r][i] += src[(r * F::REGS + i) * 64];
                     }
                 }
             }
-            // the DMA issued above must have landed (own wave: vmcnt; others: barrier); after the
-            // block's last tile nothing was issued and the stores may drain after the wave ends
-            if (last_chunk && tile + 1 >= tile_hi) break;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            cur = nxt;
+            if ((WK == 1 || wk == 0) && !(p.dbg & 1)) {
+                const EpilogueRsrc ersrc = epilogue_rsrc(p, b);   // built here: no SGPRs held across the MFMA loop
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int q = tile * N_T + wave_n * (MF * NR) + r * MF + lm;
+#pragma unroll
+                    for (int h = 0; h < EH; ++h) {
+                        float vv[EN];
+                        int mm[EN];
+#pragma unroll
+                        for (int i = 0; i < EN; ++i) {
+                            vv[i] = acc[r][h * EN + i];
+                            mm[i] = m0 + wave_m * MF + F::row(h * EN + i, lane);
+                        }
+                        epilogue_store<EN>(p, ersrc, ri[h], mm, q, vv);
+                    }
+                }
+                stores_in_flight = true;
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int i = 0; i < F::REGS; ++i) acc[r][i] = 0.f;
+            chunk = 0;
+            ++tile;
+        } else {
+            ++chunk;
         }
+        if (++cur == NS) cur = 0;
     }
 }
 
@@ -761,7 +753,8 @@ size_t plan_staging(ConvParams& p, const Geometry& g, int k_rows_target) {
     plan_x_image(p, g.n_t(), g.mf == 16);
     const int ks = (g.mf == 32 ? 2 : 4) * g.wk;     // ci granularity of one MFMA step x split
     const int cin_pad = round_up(p.Cin, ks);
-    // stage size: about k_rows_target MFMA K-rows (ci_chunk*k), both buffers <= 52 KiB
+    const int ns = kRingStages(p.pad_mode == FV_PAD_REFLECT || !p.vec_ok, p.pre_slope != 1.f);
+    // stage size: about k_rows_target MFMA K-rows (ci_chunk*k), all ns ring buffers <= 52 KiB
     // so that 3 blocks stay resident per CU (160 KiB LDS; 168 VGPRs at 3 waves/SIMD); prefer chunks dividing Cin
     // (defaults from end-to-end sweeps on MI355X, tools/bench_sweep.sh)
     int best = 0;
@@ -770,7 +763,7 @@ size_t plan_staging(ConvParams& p, const Geometry& g, int k_rows_target) {
         const int nw = g.wm * g.wn * g.wk;
         const bool dma_ok = round_up(c * p.ncol4c, 64) / 64 <= kMaxDmaX * nw &&
                             round_up(c * p.k * g.m_t() / 4, 64) / 64 <= kMaxDmaW * nw;
-        if (best && (!dma_ok || 2 * per_buf > (size_t)env_int("FV_LDS_BUDGET", 52) * 1024)) break;
+        if (best && (!dma_ok || ns * per_buf > (size_t)env_int("FV_LDS_BUDGET", 52) * 1024)) break;
         if (!dma_ok) return 0;
         // a stage of a two-source conv must not straddle the boundary between its tensors
         const bool src_ok = !p.x2 || p.Cin1 % c == 0;
@@ -784,7 +777,7 @@ size_t plan_staging(ConvParams& p, const Geometry& g, int k_rows_target) {
     p.nw_inst = round_up(best * p.k * g.m_t() / 4, 64) / 64;
     p.xbuf = round_up(best * p.ncol4c, 64) * 4;
     p.wbuf = round_up(best * p.k * g.m_t() / 4, 64) * 4;
-    size_t floats = (size_t)2 * (p.xbuf + p.wbuf);
+    size_t floats = (size_t)ns * (p.xbuf + p.wbuf);
     p.red_off = (int)floats;
     if (g.wk > 1) floats += (size_t)(g.wk - 1) * g.wm * g.wn * g.nr * (g.mf == 32 ? 16 : 4) * 64;
     return floats * 4;
