@@ -630,12 +630,14 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
 }
 
 // At least FV_MIN_WAVES waves per SIMD: caps the VGPR budget (512 / waves per SIMD) so that as
-// many blocks as the LDS budget allows stay resident on a CU.
-// (The two-accumulator 32x32 shapes need > 168 VGPRs and keep 2.)
+// many blocks as the LDS budget allows stay resident on a CU.  The plain shapes need 123-124
+// VGPRs (4 waves); the split-K shapes would spill there and keep 3, the two-accumulator
+// 32x32 shapes (> 168 VGPRs) keep 2.
 #ifndef FV_MIN_WAVES
-#define FV_MIN_WAVES 3
+#define FV_MIN_WAVES 4
 #endif
-#define FV_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((MF == 32 && NR == 2) ? 2 : FV_MIN_WAVES)))
+#define FV_WAVES_ATTR \
+    __attribute__((amdgpu_waves_per_eu((MF == 32 && NR == 2) ? 2 : ((WK > 1 && FV_MIN_WAVES > 3) ? 3 : FV_MIN_WAVES))))
 
 template <int MF, int WM, int WN, int WK, int NR, int KT, int DIL, bool ACT, bool SLOW>
 __global__ __launch_bounds__(64 * WM * WN * WK) FV_WAVES_ATTR void conv_mfma_kernel(ConvParams p) {
@@ -754,8 +756,8 @@ size_t plan_staging(ConvParams& p, const Geometry& g, int k_rows_target) {
     const int ks = (g.mf == 32 ? 2 : 4) * g.wk;     // ci granularity of one MFMA step x split
     const int cin_pad = round_up(p.Cin, ks);
     const int ns = kRingStages(p.pad_mode == FV_PAD_REFLECT || !p.vec_ok, p.pre_slope != 1.f);
-    // stage size: about k_rows_target MFMA K-rows (ci_chunk*k), all ns ring buffers <= 52 KiB
-    // so that 3 blocks stay resident per CU (160 KiB LDS; 168 VGPRs at 3 waves/SIMD); prefer chunks dividing Cin
+    // stage size: about k_rows_target MFMA K-rows (ci_chunk*k), all ns ring buffers <= 39 KiB
+    // so that 4 blocks stay resident per CU (160 KiB LDS; <= 128 VGPRs at 4 waves/SIMD); prefer chunks dividing Cin
     // (defaults from end-to-end sweeps on MI355X, tools/bench_sweep.sh)
     int best = 0;
     for (int c = ks; c <= cin_pad; c += ks) {
@@ -763,7 +765,7 @@ size_t plan_staging(ConvParams& p, const Geometry& g, int k_rows_target) {
         const int nw = g.wm * g.wn * g.wk;
         const bool dma_ok = round_up(c * p.ncol4c, 64) / 64 <= kMaxDmaX * nw &&
                             round_up(c * p.k * g.m_t() / 4, 64) / 64 <= kMaxDmaW * nw;
-        if (best && (!dma_ok || ns * per_buf > (size_t)env_int("FV_LDS_BUDGET", 52) * 1024)) break;
+        if (best && (!dma_ok || ns * per_buf > (size_t)env_int("FV_LDS_BUDGET", 39) * 1024)) break;
         if (!dma_ok) return 0;
         // a stage of a two-source conv must not straddle the boundary between its tensors
         const bool src_ok = !p.x2 || p.Cin1 % c == 0;
@@ -941,7 +943,7 @@ int prepare_conv(ConvParams& p, LaunchInfo& li, int members = 1) {
     p.n_tiles = (p.Tq + g.n_t() - 1) / g.n_t();
     const int m_tiles = p.Mpad / g.m_t();
     // runs of consecutive time tiles per block: cap the grid
-    const int cap = env_int("FV_GRID_CAP", 768);
+    const int cap = env_int("FV_GRID_CAP", 1024);
     int runs = p.n_tiles;
     const long per_batch_cap = cap / ((long)p.B * m_tiles) > 0 ? cap / ((long)p.B * m_tiles) : 1;
     if (runs > per_batch_cap) runs = (int)per_batch_cap;
