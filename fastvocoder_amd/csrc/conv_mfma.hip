@@ -150,16 +150,32 @@ __device__ __forceinline__ void dma_plan(const ConvParams& p, DmaPlan& d, int m0
     }
 }
 
+// A wave-uniform value the optimiser must treat as unknown at this point.  The DMA issue code
+// runs once per stage inside the tile/chunk loops; left alone, LLVM hoists every per-instruction
+// predicate (as a 64-bit lane mask) and LDS address out of those loops, runs out of SGPRs and
+// spills them to VGPR lanes -- ~3 v_readlane per DMA slot per stage, i.e. more issue slots than
+// the staging itself.  Laundering the two scalars they derive from keeps them as one compare
+// with an immediate and one s_add with a literal at the point of use.
+__device__ __forceinline__ int opaque_uniform(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
+// number of DMA instructions of a stage image with n_inst instructions that fall to this wave
+template <int NW>
+__device__ __forceinline__ int wave_share(int n_inst, int wave) {
+    return n_inst > wave ? (n_inst - wave + NW - 1) / NW : 0;
+}
+
 template <int NW>
 __device__ __forceinline__ void dma_x(const ConvParams& p, const DmaPlan& d, __amdgpu_buffer_rsrc_t rx,
                                       float* xs, int ci0, int tA, int wave) {
     const unsigned base = (unsigned)(ci0 * p.Tin + tA) * 4u;
+    const int n = opaque_uniform(wave_share<NW>(p.nx_inst, wave));
+    float* const xw = xs + opaque_uniform(wave * 256);
 #pragma unroll
-    for (int i = 0; i < kMaxDmaX; ++i) {
-        const int j = wave + i * NW;
-        if (j < p.nx_inst)   // wave-uniform
-            dma16(rx, xs + j * 256, d.xoff[i] + base);
-    }
+    for (int i = 0; i < kMaxDmaX; ++i)
+        if (i < n) dma16(rx, xw + i * (NW * 256), d.xoff[i] + base);
 }
 
 // Zero-padded tiles at the sequence ends, still by DMA: with 16-byte aligned rows
@@ -182,12 +198,11 @@ template <int NW, int M_T>
 __device__ __forceinline__ void dma_w(const ConvParams& p, const DmaPlan& d, __amdgpu_buffer_rsrc_t rw,
                                       float* ws, int ci0, int wave) {
     const unsigned base = (unsigned)(ci0 * p.k * p.Mpad) * 4u;
+    const int n = opaque_uniform(wave_share<NW>(p.nw_inst, wave));
+    float* const ww = ws + opaque_uniform(wave * 256);
 #pragma unroll
-    for (int i = 0; i < kMaxDmaW; ++i) {
-        const int j = wave + i * NW;
-        if (j < p.nw_inst)   // wave-uniform
-            dma16(rw, ws + j * 256, d.woff[i] + base);
-    }
+    for (int i = 0; i < kMaxDmaW; ++i)
+        if (i < n) dma16(rw, ww + i * (NW * 256), d.woff[i] + base);
 }
 
 // Synchronous path for tiles that touch the sequence ends or unaligned tensors:
@@ -502,13 +517,8 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
     // fixed instruction count per stage): they always use NS = 2 and full waits.
     constexpr int NS = kRingStages(SLOW, ACT);
     const int total = (tile_hi - tile_lo) * nchunks;
-    int n_inst = 0;   // this wave's DMA instructions per stage
-#pragma unroll
-    for (int i = 0; i < kMaxDmaX; ++i) n_inst += (wave + i * NW < p.nx_inst) ? 1 : 0;
-    if (nchunks > 1) {
-#pragma unroll
-        for (int i = 0; i < kMaxDmaW; ++i) n_inst += (wave + i * NW < p.nw_inst) ? 1 : 0;
-    }
+    // this wave's DMA instructions per stage
+    const int n_inst = wave_share<NW>(p.nx_inst, wave) + (nchunks > 1 ? wave_share<NW>(p.nw_inst, wave) : 0);
     float* const ws_base = smem + NS * p.xbuf;
     int it = tile_lo, ic = 0, ibuf = 0, issued = 0;   // next stage to issue: (tile, chunk), its buffer
     const int issue_limit = (p.dbg & 2) ? min(total, NS - 1) : total;
