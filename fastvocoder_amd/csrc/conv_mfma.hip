@@ -280,18 +280,25 @@ struct RowInfo {
     float bias[N];
 };
 
+// Branch-free: the bias comes through a bounds-checked descriptor over exactly Cout floats
+// (zero records when the layer has no bias), so padded rows and bias-less layers read 0
+// without a predicate; the row offset of a padded row gets the additive out-of-range marker.
 template <int N>
 __device__ __forceinline__ void row_info(const ConvParams& p, const int (&m)[N], RowInfo<N>& ri) {
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.bias ? p.bias : p.wp, p.bias ? (unsigned)p.Cout * 4u : 0u);
+    if (p.ups == 1) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        int co = m[i], ph = 0;
-        if (p.ups != 1) {
-            co = m[i] / p.ups;
-            ph = m[i] - co * p.ups;
+        for (int i = 0; i < N; ++i) {
+            ri.off[i] = (unsigned)(m[i] * p.Tout) * 4u + (m[i] < p.M ? 0u : kOutOfRange);
+            ri.bias[i] = buffer_load1(rb, (unsigned)m[i] * 4u);
         }
-        const bool ok = m[i] < p.M;
-        ri.off[i] = ok ? (unsigned)(co * p.Tout + ph) * 4u : kOutOfRange;
-        ri.bias[i] = (ok && p.bias) ? p.bias[co] : 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int co = m[i] / p.ups, ph = m[i] - co * p.ups;
+            ri.off[i] = (unsigned)(co * p.Tout + ph) * 4u + (m[i] < p.M ? 0u : kOutOfRange);
+            ri.bias[i] = buffer_load1(rb, (unsigned)co * 4u);
+        }
     }
 }
 
