@@ -854,9 +854,7 @@ const Geometry kShapes[] = {
     {32, 1, 2, 2, 1},   // 3: 32 x 64,   K split 2
     {32, 1, 1, 4, 1},   // 4: 32 x 32,   K split 4
     {32, 2, 2, 1, 1},   // 5: 64 x 64
-    {32, 2, 1, 2, 1},   // 6: 64 x 32,   K split 2
-    {32, 1, 2, 2, 2},   // 7: 32 x 128,  K split 2, 2 accumulators per wave
-};
+};   // (tried and dropped: 64x32 split-K, 32x128 with two accumulators per wave, 16x256 -- none faster)
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
 
 int launch_shape(int id, const ConvParams& p, size_t lds, int grid_x, hipStream_t s) {
@@ -866,9 +864,7 @@ int launch_shape(int id, const ConvParams& p, size_t lds, int grid_x, hipStream_
         case 2: return launch_geom<32, 1, 4, 1, 1>(p, lds, grid_x, s);
         case 3: return launch_geom<32, 1, 2, 2, 1>(p, lds, grid_x, s);
         case 4: return launch_geom<32, 1, 1, 4, 1>(p, lds, grid_x, s);
-        case 5: return launch_geom<32, 2, 2, 1, 1>(p, lds, grid_x, s);
-        case 6: return launch_geom<32, 2, 1, 2, 1>(p, lds, grid_x, s);
-        default: return launch_geom<32, 1, 2, 2, 2>(p, lds, grid_x, s);
+        default: return launch_geom<32, 2, 2, 1, 1>(p, lds, grid_x, s);
     }
 }
 
@@ -1067,9 +1063,7 @@ int launch_conv_group(ConvParams* ps, int n, hipStream_t s) {
         case 2: rc = launch_group_geom<32, 1, 4, 1, 1>(gp, lds, grid_x, B, dil, s); break;
         case 3: rc = launch_group_geom<32, 1, 2, 2, 1>(gp, lds, grid_x, B, dil, s); break;
         case 4: rc = launch_group_geom<32, 1, 1, 4, 1>(gp, lds, grid_x, B, dil, s); break;
-        case 5: rc = launch_group_geom<32, 2, 2, 1, 1>(gp, lds, grid_x, B, dil, s); break;
-        case 6: rc = launch_group_geom<32, 2, 1, 2, 1>(gp, lds, grid_x, B, dil, s); break;
-        default: rc = launch_group_geom<32, 1, 2, 2, 2>(gp, lds, grid_x, B, dil, s); break;
+        default: rc = launch_group_geom<32, 2, 2, 1, 1>(gp, lds, grid_x, B, dil, s); break;
     }
     profile_end(s, li[order[0]].kind, flops, bytes);
     return rc;
