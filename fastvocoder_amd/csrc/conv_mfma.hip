@@ -54,10 +54,6 @@
                            // Measured (HiFi-GAN light, B = 1): 2 -> 1.66 ms/step, 3 -> 1.71 ms (the third
                            // buffer halves the stage size of the 7- and 3-tap kernels under the LDS budget)
 #endif
-#ifndef FV_PREFETCH_RES
-#define FV_PREFETCH_RES 0   // measured: issuing the residual read before the tile's last MFMAs costs
-                            // more (registers, spills in the split-K shapes) than the latency it hides
-#endif
 
 namespace fv {
 
@@ -304,10 +300,9 @@ __device__ __forceinline__ void row_info(const ConvParams& p, const int (&m)[N],
 
 // N output elements of one thread at GEMM column q:
 //   y = post( ( (acc_in + acc_in2) + ( (v + bias) + res ) ) / out_div );   y_act = act(y, act_slope)
-// all uniform switches are hoisted; loads are issued as one batch.  The tensor reads
-// (res, acc_in, acc_in2) are a separate step so that a caller can issue them BEFORE the
-// tile's last run of MFMAs (done for res, the common one): ~2 us of latency then overlaps
-// matrix work instead of standing between the last MFMA and the first store.
+// all uniform switches are hoisted; loads are issued as one batch.  (Issuing the residual read
+// before the tile's last MFMAs was tried: the 16 extra live registers cost more than the ~2 us
+// of latency they hid.)
 template <int N>
 __device__ __forceinline__ void epilogue_offsets(const ConvParams& p, const RowInfo<N>& ri,
                                                  const int (&m)[N], int q, unsigned (&off)[N]) {
@@ -323,34 +318,34 @@ __device__ __forceinline__ void epilogue_offsets(const ConvParams& p, const RowI
     }
 }
 
-// rv = res, av = acc_in + acc_in2 (formed first, like xs = r0; xs += r1); zeros when absent
-template <int N>
-__device__ __forceinline__ void epilogue_load(const ConvParams& p, const EpilogueRsrc& e,
-                                              const unsigned (&off)[N], float (&rv)[N], float (&av)[N],
-                                              float (&a2)[N], bool with_res = true) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) rv[i] = av[i] = a2[i] = 0.f;
-    if (with_res && p.res) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) rv[i] = buffer_load1(e.res, off[i]);
-    }
-    if (p.acc_in) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) av[i] = buffer_load1(e.acc, off[i]);
-    }
-    if (p.acc_in2) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) a2[i] = buffer_load1(e.acc2, off[i]);
-    }
-}
-
+// The tensor reads: res for every conv2 of a ResBlock; acc_in / acc_in2 only on the last conv
+// of an MRF stage -- those live in a branch so that the common path neither zero-fills nor
+// adds 2 x N registers.  All loads of a batch are issued before the first use.
 template <int N>
 __device__ __forceinline__ void epilogue_finish(const ConvParams& p, const EpilogueRsrc& e,
                                                 const RowInfo<N>& ri, const unsigned (&off)[N],
-                                                float (&v)[N], const float (&rv)[N],
-                                                const float (&av)[N], const float (&a2)[N]) {
+                                                float (&v)[N]) {
+    if (p.acc_in) {
+        // (acc_in + acc_in2) first, like xs = r0; xs += r1; then + this block's output (hifigan.py:99-102)
+        float rv[N], av[N], a2[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = (av[i] + a2[i]) + ((v[i] + ri.bias[i]) + rv[i]);
+        for (int i = 0; i < N; ++i) rv[i] = p.res ? buffer_load1(e.res, off[i]) : 0.f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) av[i] = buffer_load1(e.acc, off[i]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) a2[i] = p.acc_in2 ? buffer_load1(e.acc2, off[i]) : 0.f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = (av[i] + a2[i]) + ((v[i] + ri.bias[i]) + rv[i]);
+    } else if (p.res) {
+        float rv[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) rv[i] = buffer_load1(e.res, off[i]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = (v[i] + ri.bias[i]) + rv[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = v[i] + ri.bias[i];
+    }
     if (p.out_div != 1.f) {
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = v[i] / p.out_div;
@@ -383,10 +378,8 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, const Epilog
                                                const RowInfo<N>& ri, const int (&m)[N], int q,
                                                float (&v)[N]) {
     unsigned off[N];
-    float rv[N], av[N], a2[N];
     epilogue_offsets<N>(p, ri, m, q, off);
-    epilogue_load<N>(p, e, off, rv, av, a2);
-    epilogue_finish<N>(p, e, ri, off, v, rv, av, a2);
+    epilogue_finish<N>(p, e, ri, off, v);
 }
 
 // XCD-aware block order: the dispatcher places linear block id b on XCD b % 8,
