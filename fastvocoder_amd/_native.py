@@ -76,6 +76,7 @@ def lib():
     L.fv_pqmf_synthesis.argtypes = [vp, vp, vp, i, i, i, i, vp]
     L.fv_conv1d_2src_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, f, vp]
     L.fv_plan_add_conv1d_2src.argtypes = [vp, i, i, i, i, i, vp, vp, i, i, i, i, f]
+    L.fv_plan_set_sum_order.argtypes = [vp, i]
     L.fv_encode_16bits.argtypes = [vp, vp, vp, i, i64, f, i, vp]
     L.fv_pqmf_analysis.argtypes = [vp, vp, vp, i, i, i, i64, vp]
     L.fv_fold_batchnorm_conv.argtypes = [vp, vp, vp, vp, vp, vp, f, vp, vp, i, i, i, vp]
@@ -343,6 +344,9 @@ class Plan:
         check(lib().fv_plan_add_upsample_conv1d(self._h, x, y, y_act, _ptr(packed, "packed"),
                                                 _ptr(bias, "bias", True), cin, cout, k, rate, pad,
                                                 float(pre_slope), post, float(act_slope)))
+
+    def set_sum_order(self, own_first):
+        check(lib().fv_plan_set_sum_order(self._h, 1 if own_first else 0))
 
     def set_lane(self, lane):
         check(lib().fv_plan_set_lane(self._h, lane))

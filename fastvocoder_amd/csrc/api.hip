@@ -184,6 +184,7 @@ struct Op {
     // two-source conv (1 tap): GEMM rows ci >= Cin1 are read from slot x2 (Cin - Cin1 channels)
     int x2 = FV_SLOT_NONE;
     int Cin1 = 0;
+    int own_first = 0;   // association of the MRF sum in the epilogue (ConvParams::own_first)
 };
 
 constexpr int kMaxLanes = 4;
@@ -201,6 +202,7 @@ struct fv_plan {
     std::vector<fv::Op> ops;
     int cur_lane = 0;
     int cur_group = 0;
+    int cur_own_first = 0;
     int n_lanes = 1;
     bool compiled = false;
     // lanes 1.. run on plan-owned streams; one event per signalling op + fork/join events
@@ -293,6 +295,7 @@ static ConvParams make_params(const Op& o, const float* x, float* y, float* y2, 
     p.pre_slope = o.pre_slope;
     p.out_div = o.out_div;
     p.post = o.post;
+    p.own_first = o.own_first;
     p.Tout = (int)conv_out_len(o, Tin);
     if (o.type == OP_CONV) {
         p.M = o.Cout;
@@ -642,6 +645,7 @@ int fv_plan_add_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, 
     o.acc = acc_slot;
     o.acc2 = acc2_slot;
     o.group = plan->cur_group;
+    o.own_first = plan->cur_own_first;
     o.wp = packed;
     o.bias = bias;
     o.Cin = Cin;
@@ -766,6 +770,12 @@ int fv_plan_add_pqmf_synthesis(fv_plan_t* plan, int x_slot, int y_slot, const fl
 int fv_plan_set_group(fv_plan_t* plan, int group) {
     if (!plan || group < 0) return fail(FV_ERR_INVALID_ARG, "plan_set_group: group %d", group);
     plan->cur_group = group;
+    return 0;
+}
+
+int fv_plan_set_sum_order(fv_plan_t* plan, int own_first) {
+    if (!plan) return fail(FV_ERR_INVALID_ARG, "plan_set_sum_order: null plan");
+    plan->cur_own_first = own_first ? 1 : 0;
     return 0;
 }
 

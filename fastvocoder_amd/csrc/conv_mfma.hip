@@ -334,8 +334,15 @@ __device__ __forceinline__ void epilogue_finish(const ConvParams& p, const Epilo
         for (int i = 0; i < N; ++i) av[i] = buffer_load1(e.acc, off[i]);
 #pragma unroll
         for (int i = 0; i < N; ++i) a2[i] = p.acc_in2 ? buffer_load1(e.acc2, off[i]) : 0.f;
+        // either association reproduces xs = r0; xs += r1; xs += r2 exactly, depending on which
+        // block's conv carries the sum: the last one (own = r2) or the first (own = r0)
+        if (p.own_first) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = (av[i] + a2[i]) + ((v[i] + ri.bias[i]) + rv[i]);
+            for (int i = 0; i < N; ++i) v[i] = (((v[i] + ri.bias[i]) + rv[i]) + av[i]) + a2[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = (av[i] + a2[i]) + ((v[i] + ri.bias[i]) + rv[i]);
+        }
     } else if (p.res) {
         float rv[N];
 #pragma unroll
@@ -1006,28 +1013,30 @@ int launch_conv(ConvParams p, hipStream_t s) {
 // Three mutually independent convs in one launch when they are the (11, 7, 3)-tap
 // members of an MRF position and agree on everything else; otherwise three launches.
 int launch_conv_group(ConvParams* ps, int n, hipStream_t s) {
-    bool ok = n == 3 && !env_int("FV_NO_GROUP", 0);
+    // three members (11, 7, 3 taps) or the two large ones (11, 7): the kernel is the same, the
+    // third problem just has an empty grid
+    bool ok = (n == 3 || n == 2) && !env_int("FV_NO_GROUP", 0);
     LaunchInfo li[3];
     int order[3] = {0, 1, 2};
     if (ok) {
-        for (int i = 0; i < 3 && ok; ++i) {
+        for (int i = 0; i < n && ok; ++i) {
             if (ps[i].B <= 0 || ps[i].Tq <= 0) ok = false;
             else if (prepare_conv(ps[i], li[i], n)) ok = false;
         }
     }
     if (ok) {
-        for (int i = 0; i < 3; ++i)       // sort by taps, largest first
-            for (int j = i + 1; j < 3; ++j)
+        for (int i = 0; i < n; ++i)       // sort by taps, largest first
+            for (int j = i + 1; j < n; ++j)
                 if (ps[order[j]].k > ps[order[i]].k) { int t = order[i]; order[i] = order[j]; order[j] = t; }
         const ConvParams& a = ps[order[0]];
-        ok = a.k == 11 && ps[order[1]].k == 7 && ps[order[2]].k == 3 && !li[order[0]].narrow &&
+        ok = a.k == 11 && ps[order[1]].k == 7 && (n == 2 || ps[order[2]].k == 3) && !li[order[0]].narrow &&
              (a.dil == 1 || a.dil == 3 || a.dil == 5) && a.ups == 1;
-        for (int i = 0; i < 3 && ok; ++i) {
+        for (int i = 0; i < n && ok; ++i) {
             const ConvParams& q = ps[order[i]];
             const LaunchInfo& l = li[order[i]];
             ok = !l.narrow && l.shape == li[order[0]].shape && q.dil == a.dil && q.B == a.B &&
                  q.Cin == a.Cin && q.M == a.M && q.Tq == a.Tq && q.ups == 1 && q.pre_slope == 1.f &&
-                 q.pad_mode == FV_PAD_ZERO && q.vec_ok;
+                 q.pad_mode == FV_PAD_ZERO && q.vec_ok && !q.x2;
         }
     }
     if (!ok) {
@@ -1039,13 +1048,17 @@ int launch_conv_group(ConvParams* ps, int n, hipStream_t s) {
     size_t lds = 0;
     int grid_x = 0;
     double flops = 0, bytes = 0;
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < n; ++i) {
         gp.p[i] = ps[order[i]];
         gp.grid_x[i] = li[order[i]].grid_x;
         if (li[order[i]].lds > lds) lds = li[order[i]].lds;
         if (gp.grid_x[i] > grid_x) grid_x = gp.grid_x[i];
         flops += li[order[i]].flops;
         bytes += li[order[i]].bytes;
+    }
+    for (int i = n; i < 3; ++i) {   // absent member: its blocks return at once
+        gp.p[i] = gp.p[0];
+        gp.grid_x[i] = 0;
     }
     profile_begin(s);
     int rc;

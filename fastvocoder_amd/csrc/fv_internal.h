@@ -77,6 +77,7 @@ struct ConvParams {
     float pre_slope, out_div;
     float act_slope;      // with y_act: slope of the twin; without: y itself is stored as act(y, act_slope)
     int post;
+    int own_first;        // 0: y = (acc_in + acc_in2) + own;  1: y = (own + acc_in) + acc_in2  (own = conv + bias + res)
     // filled in by the launcher
     int ci_chunk;   // input channels staged per LDS stage
     int nchunks;    // ceil(Cin / ci_chunk)

@@ -77,7 +77,8 @@ class PlanBuilder:
         self.group = 0
 
     def conv(self, conv, src, dst, pad=None, pad_mode=PAD_ZERO, pre_slope=1.0, res=SLOT_NONE,
-             acc=SLOT_NONE, out_div=1.0, post=POST_NONE, acc2=SLOT_NONE, batchnorm=None):
+             acc=SLOT_NONE, out_div=1.0, post=POST_NONE, acc2=SLOT_NONE, batchnorm=None,
+             own_first=False):
         """Record ``conv`` (a torch.nn.Conv1d container): dst = epilogue(conv(bn(act(src)))).
         ``batchnorm`` (an eval-mode BatchNorm1d container applied to the conv's input) is
         folded into the weight and bias (fv_fold_batchnorm_conv)."""
@@ -92,7 +93,7 @@ class PlanBuilder:
                 raise _native.NativeError("BatchNorm folds only into an unpadded conv")
             weight, bias = _native.fold_batchnorm_conv(weight, bias, batchnorm)
         self.ops.append(dict(kind="conv", lane=self.lane, group=self.group, x=src, y=dst, res=res, acc=acc,
-                             acc2=acc2, pre_slope=float(pre_slope),
+                             acc2=acc2, pre_slope=float(pre_slope), own_first=bool(own_first),
                              packed=_native.pack_conv1d(weight), bias=bias,
                              cin=conv.in_channels, cout=conv.out_channels, k=k, dil=d, pad=pad,
                              pad_mode=pad_mode, out_div=out_div, post=post))
@@ -229,6 +230,7 @@ class PlanBuilder:
         for op in self.ops:
             self.plan.set_lane(op["lane"])
             self.plan.set_group(op.get("group", 0))
+            self.plan.set_sum_order(op.get("own_first", False))
             if op["kind"] == "conv":
                 self.plan.add_conv1d(op["x"], op["y"], op["packed"], op["bias"], op["cin"], op["cout"],
                                      op["k"], dil=op["dil"], pad=op["pad"], pad_mode=op["pad_mode"],

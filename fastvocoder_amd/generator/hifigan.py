@@ -71,13 +71,14 @@ class _HiFiGANBase(NativeModule):
         # batch 1 one conv cannot fill 256 CUs.  Their steps are therefore emitted
         # interleaved -- conv number s of every block forms one GROUP, which the
         # executor runs as a single launch when the blocks are the classic 3/7/11-tap
-        # trio (fv_plan_set_group), else one launch each.  The last block's final conv
-        # is emitted alone: its epilogue forms ((r0 + r1) + r2) / nk, the reference's
-        # summation order (hifigan.py:97-103), from the other blocks' outputs.
-        # Measured on MI355X (HiFi-GAN light, B = 1, per forward): grouped launches
-        # see DESIGN.md; three concurrent streams 1.84 ms; one stream 2.0 ms.
+        # trio (fv_plan_set_group), else one launch each.  At the last step the blocks after
+        # the first (the 7- and 11-tap ones) still share a launch and store r_1, r_2; the
+        # FIRST block's final conv -- the cheapest -- runs after them and forms
+        # ((r_0 + r_1) + r_2) / nk in its epilogue (own value first: fv_plan_set_sum_order),
+        # which is the reference's summation order bit for bit (hifigan.py:97-103).
+        # Measured on MI355X (HiFi-GAN light, B = 1, per forward): see DESIGN.md section 3.2.
         mode = os.environ.get("FV_MRF", "group")
-        parts = [pb.tmp() for _ in range(nk - 1)]          # r_0 .. r_{nk-2}
+        parts = [pb.tmp() for _ in range(nk - 1)]          # r_1 .. r_{nk-1}
         scratch = [[pb.tmp(), pb.tmp(), pb.tmp()] for _ in range(nk)]
         pb.conv(self.conv_pre, SLOT_IN, x)
         for i in range(self.num_upsamples):
@@ -89,25 +90,30 @@ class _HiFiGANBase(NativeModule):
             if nk <= 3 and mode != "chain":
                 steps = blocks[0].num_steps()
                 states = [dict() for _ in range(nk)]
+                # which block's final conv carries the sum: the first (cheapest; the others' final
+                # convs then share a launch) or, FV_MRF_CARRIER=last, the last
+                carrier = nk - 1 if os.environ.get("FV_MRF_CARRIER", "first") == "last" else 0
+                others = [j for j in range(nk) if j != carrier]
                 for st in range(steps):
                     final = st == steps - 1
-                    members = range(nk - 1) if final else range(nk)
+                    members = others if final else range(nk)
                     if mode == "lanes":
                         for j in members:
                             pb.lane = j
-                            blocks[j].emit_step(pb, st, states[j], up, parts[j] if j < nk - 1 else x,
+                            blocks[j].emit_step(pb, st, states[j], up, parts[others.index(j)] if final else x,
                                                 scratch[j])
                         pb.lane = 0
                     else:
                         pb.begin_group()
                         for j in members:
-                            blocks[j].emit_step(pb, st, states[j], up, parts[j] if j < nk - 1 else x,
+                            blocks[j].emit_step(pb, st, states[j], up, parts[others.index(j)] if final else x,
                                                 scratch[j])
                         pb.end_group()
-                # the last block's final conv: + r_0 (+ r_1), / nk
-                blocks[nk - 1].emit_step(pb, steps - 1, states[nk - 1], up, x, scratch[nk - 1],
-                                         acc=parts[0] if nk > 1 else SLOT_NONE,
-                                         acc2=parts[1] if nk > 2 else SLOT_NONE, out_div=float(nk))
+                # the carrier's final conv: ((r_0 + r_1) + r_2) / nk in the reference's order
+                blocks[carrier].emit_step(pb, steps - 1, states[carrier], up, x, scratch[carrier],
+                                          acc=parts[0] if nk > 1 else SLOT_NONE,
+                                          acc2=parts[1] if nk > 2 else SLOT_NONE, out_div=float(nk),
+                                          own_first=carrier == 0)
             else:
                 # generic: a running sum chained through the blocks, one after the other
                 for j in range(nk):

@@ -71,7 +71,8 @@ class ResBlock1(_Block):
     def num_steps(self):
         return 2 * len(self.convs1)
 
-    def emit_step(self, pb, step, state, src, dst, scratch, acc=SLOT_NONE, acc2=SLOT_NONE, out_div=1.0):
+    def emit_step(self, pb, step, state, src, dst, scratch, acc=SLOT_NONE, acc2=SLOT_NONE, out_div=1.0,
+                  own_first=False):
         """Emit conv number ``step`` (0 .. num_steps()-1) of the block; ``state`` is a dict
         the caller keeps per block between steps.  Lets a generator interleave the steps
         of several independent blocks (one group per step)."""
@@ -85,7 +86,7 @@ class ResBlock1(_Block):
         nxt = dst if last else (ping if cur != ping else pong)
         pb.conv(self.convs2[i], mid, nxt, pre_slope=LRELU_SLOPE, res=cur,
                 acc=acc if last else SLOT_NONE, acc2=acc2 if last else SLOT_NONE,
-                out_div=out_div if last else 1.0)
+                out_div=out_div if last else 1.0, own_first=own_first and last)
         state["cur"] = nxt
 
     def emit(self, pb, src, dst, scratch, acc=SLOT_NONE, out_div=1.0):
@@ -111,14 +112,15 @@ class ResBlock2(_Block):
     def num_steps(self):
         return len(self.convs)
 
-    def emit_step(self, pb, step, state, src, dst, scratch, acc=SLOT_NONE, acc2=SLOT_NONE, out_div=1.0):
+    def emit_step(self, pb, step, state, src, dst, scratch, acc=SLOT_NONE, acc2=SLOT_NONE, out_div=1.0,
+                  own_first=False):
         ping, pong = scratch[:2]
         cur = state.get("cur", src)
         last = step == len(self.convs) - 1
         nxt = dst if last else (ping if cur != ping else pong)
         pb.conv(self.convs[step], cur, nxt, pre_slope=LRELU_SLOPE, res=cur,
                 acc=acc if last else SLOT_NONE, acc2=acc2 if last else SLOT_NONE,
-                out_div=out_div if last else 1.0)
+                out_div=out_div if last else 1.0, own_first=own_first and last)
         state["cur"] = nxt
 
     def emit(self, pb, src, dst, scratch, acc=SLOT_NONE, out_div=1.0):

@@ -236,6 +236,13 @@ int fv_plan_add_pqmf_synthesis(fv_plan_t* plan, int x_slot, int y_slot, const fl
  * fork/join around every fv_plan_run.  Used to run the independent ResBlocks of
  * an MRF stage (hifigan.py:97-103) side by side when one utterance alone cannot
  * fill 256 CUs. */
+/* Association of the MRF running sum in the epilogue of the conv1d ops added from now on:
+ * 0 (default)  y = ((acc + acc2) + own) / out_div   -- the LAST ResBlock's conv carries the sum
+ * 1            y = ((own + acc) + acc2) / out_div   -- the FIRST ResBlock's conv carries it
+ * (own = conv + bias + res).  Both reproduce xs = r0; xs += r1; xs += r2 (hifigan.py:99-102)
+ * bit for bit; 1 lets the two large-kernel blocks finish as one grouped launch while the
+ * cheapest (3-tap) conv forms the sum. */
+int fv_plan_set_sum_order(fv_plan_t* plan, int own_first);
 int fv_plan_set_lane(fv_plan_t* plan, int lane);
 
 /* Grouping: consecutive conv1d ops appended under the same non-zero group id are

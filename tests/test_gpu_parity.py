@@ -298,6 +298,25 @@ def test_concurrency_lanes_do_not_change_results(monkeypatch):
     assert torch.equal(a, b) and torch.equal(a, c)
 
 
+@pytest.mark.parametrize("mrf,carrier", [("group", "last"), ("lanes", "first"), ("chain", "first")])
+def test_mrf_schedules_agree(monkeypatch, mrf, carrier):
+    """The MRF stage can be scheduled as grouped launches with the first block's conv carrying
+    the sum (default), with the last block's, on three streams, or as the plain sequential
+    chain: same arithmetic per element (only tile shapes, i.e. fp32 summation order inside a
+    conv, may differ), and every schedule stays within tolerance of the oracle elsewhere."""
+    cfg = cases.load_conf("conf/hifigan/light.yaml")
+    x = torch.from_numpy(seeded_mel(200, seed=22, batch=1)).to(_dev())
+    ref_model, _ = _model("hifigan", cfg, seed=0)
+    with torch.no_grad():
+        ref = ref_model(x).cpu().numpy()
+    monkeypatch.setenv("FV_MRF", mrf)
+    monkeypatch.setenv("FV_MRF_CARRIER", carrier)
+    m, _ = _model("hifigan", cfg, seed=0)
+    with torch.no_grad():
+        got = m(x).cpu().numpy()
+    assert np.abs(got - ref).max() <= 2e-6
+
+
 def test_conv_transpose_no_padding_is_overlap_add():
     """ConvTranspose1d(Cout=1, k=L, stride=L/2, pad=0) == linear + overlap_and_add."""
     rng = np.random.RandomState(5)
