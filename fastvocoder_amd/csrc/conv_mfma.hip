@@ -72,6 +72,17 @@ constexpr unsigned kOutOfRange = 0x40000000u;
 // equal to x >= 0 ? x : slope*x, branch-free (slope is wave-uniform)
 __device__ __forceinline__ float act(float v, float slope) { return fmaxf(v, v * slope); }
 
+// A wave-uniform value the optimiser must treat as unknown at this point.  The DMA issue code
+// runs once per stage inside the tile/chunk loops; left alone, LLVM hoists every per-instruction
+// predicate (as a 64-bit lane mask) and LDS address out of those loops, runs out of SGPRs and
+// spills them to VGPR lanes -- ~3 v_readlane per DMA slot per stage, i.e. more issue slots than
+// the staging itself.  Laundering the two scalars they derive from keeps them as one compare
+// with an immediate and one s_add with a literal at the point of use.
+__device__ __forceinline__ int opaque_uniform(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
 __device__ __forceinline__ int reflect_idx(int i, int T) {
     if (i < 0) i = -i;
     if (i >= T) i = 2 * (T - 1) - i;
@@ -144,17 +155,6 @@ __device__ __forceinline__ void dma_plan(const ConvParams& p, DmaPlan& d, int m0
             if (idx < wtotal) d.woff[i] = (unsigned)(row * p.Mpad + m0 + 4 * c) * 4u;
         }
     }
-}
-
-// A wave-uniform value the optimiser must treat as unknown at this point.  The DMA issue code
-// runs once per stage inside the tile/chunk loops; left alone, LLVM hoists every per-instruction
-// predicate (as a 64-bit lane mask) and LDS address out of those loops, runs out of SGPRs and
-// spills them to VGPR lanes -- ~3 v_readlane per DMA slot per stage, i.e. more issue slots than
-// the staging itself.  Laundering the two scalars they derive from keeps them as one compare
-// with an immediate and one s_add with a literal at the point of use.
-__device__ __forceinline__ int opaque_uniform(int v) {
-    asm volatile("" : "+s"(v));
-    return v;
 }
 
 // number of DMA instructions of a stage image with n_inst instructions that fall to this wave
@@ -289,10 +289,12 @@ __device__ __forceinline__ void row_info(const ConvParams& p, const int (&m)[N],
             ri.bias[i] = buffer_load1(rb, (unsigned)m[i] * 4u);
         }
     } else {
+        const int rem = p.Tout - (p.Tq - 1) * p.ups;   // phases present in the last column
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int co = m[i] / p.ups, ph = m[i] - co * p.ups;
-            ri.off[i] = (unsigned)(co * p.Tout + ph) * 4u + (m[i] < p.M ? 0u : kOutOfRange);
+            ri.off[i] = (unsigned)(co * p.Tout + ph) * 4u + (m[i] < p.M ? 0u : kOutOfRange) +
+                        (ph >= rem ? 1u : 0u);   // bit 0: see epilogue_offsets
             ri.bias[i] = buffer_load1(rb, (unsigned)co * 4u);
         }
     }
@@ -311,10 +313,15 @@ __device__ __forceinline__ void epilogue_offsets(const ConvParams& p, const RowI
 #pragma unroll
     for (int i = 0; i < N; ++i) off[i] = ri.off[i] + qoff;
     if (p.ups != 1) {
-        // a transposed conv's last column can run past Tout (Tout need not be a multiple of ups)
+        // A transposed conv's last column can run past Tout (Tout need not be a multiple of ups):
+        // row_info marked the rows whose phase does not exist in the last column with bit 0 of
+        // the row offset; here that bit becomes the out-of-range marker when q is the last
+        // column, and is cleared otherwise.  (Testing q*ups + m % ups >= Tout here instead made
+        // LLVM hoist N modulo computations out of the tile loop and above this branch: ~280
+        // VALU instructions per tile for EVERY conv, transposed or not.)
+        const unsigned last = q == p.Tq - 1 ? 1u : 0u;
 #pragma unroll
-        for (int i = 0; i < N; ++i)
-            if (q * p.ups + m[i] % p.ups >= p.Tout) off[i] = kOutOfRange;
+        for (int i = 0; i < N; ++i) off[i] = (off[i] & ~1u) + ((off[i] & last) << 30);
     }
 }
 
