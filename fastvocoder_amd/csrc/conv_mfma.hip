@@ -274,6 +274,7 @@ template <int N>
 struct RowInfo {
     unsigned off[N];
     float bias[N];
+    unsigned short_mask;   // transposed convs: bit i set = row i has no sample in the last column
 };
 
 // Branch-free: the bias comes through a bounds-checked descriptor over exactly Cout floats
@@ -282,6 +283,7 @@ struct RowInfo {
 template <int N>
 __device__ __forceinline__ void row_info(const ConvParams& p, const int (&m)[N], RowInfo<N>& ri) {
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.bias ? p.bias : p.wp, p.bias ? (unsigned)p.Cout * 4u : 0u);
+    ri.short_mask = 0u;
     if (p.ups == 1) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -293,8 +295,8 @@ __device__ __forceinline__ void row_info(const ConvParams& p, const int (&m)[N],
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int co = m[i] / p.ups, ph = m[i] - co * p.ups;
-            ri.off[i] = (unsigned)(co * p.Tout + ph) * 4u + (m[i] < p.M ? 0u : kOutOfRange) +
-                        (ph >= rem ? 1u : 0u);   // bit 0: see epilogue_offsets
+            ri.off[i] = (unsigned)(co * p.Tout + ph) * 4u + (m[i] < p.M ? 0u : kOutOfRange);
+            ri.short_mask |= (ph >= rem ? 1u : 0u) << i;   // see epilogue_offsets
             ri.bias[i] = buffer_load1(rb, (unsigned)co * 4u);
         }
     }
@@ -314,14 +316,17 @@ __device__ __forceinline__ void epilogue_offsets(const ConvParams& p, const RowI
     for (int i = 0; i < N; ++i) off[i] = ri.off[i] + qoff;
     if (p.ups != 1) {
         // A transposed conv's last column can run past Tout (Tout need not be a multiple of ups):
-        // row_info marked the rows whose phase does not exist in the last column with bit 0 of
-        // the row offset; here that bit becomes the out-of-range marker when q is the last
-        // column, and is cleared otherwise.  (Testing q*ups + m % ups >= Tout here instead made
-        // LLVM hoist N modulo computations out of the tile loop and above this branch: ~280
-        // VALU instructions per tile for EVERY conv, transposed or not.)
-        const unsigned last = q == p.Tq - 1 ? 1u : 0u;
+        // row_info recorded which rows have no sample there (short_mask), and those get the
+        // out-of-range marker when q is the last column.  The mask goes through an empty asm so
+        // that nothing derived from it can be hoisted out of the tile loop: LLVM hoists any
+        // loop-invariant arithmetic above this (uniform) branch -- with the original test
+        // q*ups + m % ups >= Tout that was N modulo computations, ~280 VALU instructions per
+        // tile for EVERY conv, transposed or not.
+        unsigned sm = ri.short_mask;
+        asm volatile("" : "+v"(sm));
+        const unsigned sel = q == p.Tq - 1 ? sm : 0u;
 #pragma unroll
-        for (int i = 0; i < N; ++i) off[i] = (off[i] & ~1u) + ((off[i] & last) << 30);
+        for (int i = 0; i < N; ++i) off[i] += ((sel >> i) & 1u) << 30;
     }
 }
 
