@@ -554,7 +554,12 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
     for (int i = 0; i < NS - 1 && issued < issue_limit; ++i) issue();
 
     int tile = tile_lo, chunk = 0, cur = 0;
-    bool stores_in_flight = false;   // stores and loads retire out of order w.r.t. each other: full wait then
+    // Stores and loads share vmcnt but retire out of order with respect to each other, so no
+    // counted wait is valid while a tile's stores are in flight -- and draining them costs ~2 us.
+    // A block that goes on to another tile therefore makes sure of its NEXT stage before it
+    // stores (that DMA was issued a whole stage of matrix work earlier), and skips the wait at
+    // the top of that stage.
+    bool landed = false;
     acc_t acc[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r)
@@ -562,9 +567,11 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
         for (int i = 0; i < F::REGS; ++i) acc[r][i] = 0.f;
     for (int s = 0; s < total; ++s) {
         // ---- stage s has landed (own wave: vmcnt; others: barrier) ----
-        if (NS == 2 || stores_in_flight) wait_vmcnt(0);
-        else wait_vmcnt((issued - s - 1) * n_inst);
-        stores_in_flight = false;
+        if (!landed) {
+            if (NS == 2) wait_vmcnt(0);
+            else wait_vmcnt((issued - s - 1) * n_inst);
+        }
+        landed = false;
         __syncthreads();
         if (issued < issue_limit) issue();
         const bool last_chunk = chunk == nchunks - 1;
@@ -626,6 +633,10 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
                     }
                 }
             }
+            if (s + 1 < total) {
+                wait_vmcnt(0);   // the next stage's DMA; nothing else of this wave is in flight
+                landed = true;
+            }
             if ((WK == 1 || wk == 0) && !(p.dbg & 1)) {
                 const EpilogueRsrc ersrc = epilogue_rsrc(p, b);   // built here: no SGPRs held across the MFMA loop
 #pragma unroll
@@ -643,7 +654,6 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
                         epilogue_store<EN>(p, ersrc, ri[h], mm, q, vv);
                     }
                 }
-                stores_in_flight = true;
             }
 #pragma unroll
             for (int r = 0; r < NR; ++r)
