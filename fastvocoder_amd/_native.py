@@ -294,6 +294,7 @@ class Plan:
 
     def __init__(self, in_channels):
         self._h = lib().fv_plan_create(in_channels)
+        self.in_channels = in_channels
         self._keep = []        # packed weights / biases the native plan references
         self._ws = None
         self._ws_key = None
@@ -369,7 +370,11 @@ class Plan:
 
     def run(self, x, out=None):
         """x [B,Cin,T] contiguous fp32 on a ROCm device -> [B,Cout,Tout]."""
+        if x.dim() != 3 or x.shape[1] != self.in_channels:
+            raise NativeError(f"plan input must be [B, {self.in_channels}, T], got {tuple(x.shape)}")
         B, _, T = x.shape
+        if B == 0 or T == 0:
+            raise NativeError(f"plan input is empty: {tuple(x.shape)}")
         c, n = self.output_shape(T)
         if out is None:
             out = torch.empty((B, c, n), dtype=torch.float32, device=x.device)

@@ -597,3 +597,29 @@ def test_errors_are_loud():
     packed = _native.pack_conv1d(torch.zeros(8, 8, 3, device=dev))
     with pytest.raises(_native.NativeError):               # reflection pad longer than the input
         _native.conv1d_fused(x, packed, None, 8, 3, dil=9, pad=9, pad_mode=_native.PAD_REFLECT)
+
+
+def test_edge_inputs_match_the_reference_behaviour():
+    """Shortest and odd inputs: a single mel frame, lengths that are not multiples of the DMA
+    vector width or of any tile, the empty utterance (the reference's conv raises there too),
+    wrong channel count, and a ragged set of utterances run one by one (the reference has no
+    padding/masking: ragged batches are separate calls)."""
+    cfg = dict(cases.SMALL[0][2])
+    m, sd = _model("hifigan", cfg, seed=7)
+    for T in (1, 2, 3, 5, 17, 33):
+        mel = seeded_mel(T, seed=T)
+        want = og.hifigan_inference(mel, sd, cfg) if hasattr(og, "hifigan_inference") else None
+        got = m.inference(mel)
+        assert got.numel() == T * int(np.prod(cfg["upsample_rates"]))
+        if want is not None:
+            assert _err(got.reshape(-1), np.asarray(want).reshape(-1)) <= TOL
+    with pytest.raises(_native.NativeError):
+        m(torch.zeros(1, 80, 0, device=_dev()))               # empty utterance
+    with pytest.raises(_native.NativeError):
+        m(torch.zeros(1, 79, 8, device=_dev()))               # wrong number of mel channels
+    # ragged utterances, one call each, equal the same utterances inside an equal-length batch slice
+    mels = [seeded_mel(T, seed=40 + T) for T in (7, 19, 12)]
+    outs = [m.inference(x) for x in mels]
+    for x, y in zip(mels, outs):
+        again = m(torch.from_numpy(x.T[None].copy()).to(_dev()))[0]
+        assert torch.equal(again, y)
