@@ -107,6 +107,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, u
 __device__ __forceinline__ float buffer_load1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
 }
+// the same with a wave-uniform byte offset in the instruction's SGPR operand (no VALU add); the
+// hardware bounds check covers the VGPR part only, so the scalar part must stay inside the buffer
+__device__ __forceinline__ float buffer_load1s(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned s_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, (int)s_off, 0));
+}
+__device__ __forceinline__ void buffer_store1s(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned s_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)byte_off, (int)s_off, 0);
+}
 __device__ __forceinline__ void buffer_store1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)byte_off, 0, 0);
 }
@@ -333,37 +341,38 @@ __device__ __forceinline__ void epilogue_offsets(const ConvParams& p, const RowI
 // The tensor reads: res for every conv2 of a ResBlock; acc_in / acc_in2 only on the last conv
 // of an MRF stage -- those live in a branch so that the common path neither zero-fills nor
 // adds 2 x N registers.  All loads of a batch are issued before the first use.
+// Element i lives at byte offset off[i] + so[i], so[i] being wave-uniform (0 in the general case).
 template <int N>
 __device__ __forceinline__ void epilogue_finish(const ConvParams& p, const EpilogueRsrc& e,
-                                                const RowInfo<N>& ri, const unsigned (&off)[N],
-                                                float (&v)[N]) {
+                                                const float (&bias)[N], const unsigned (&off)[N],
+                                                const unsigned (&so)[N], float (&v)[N]) {
     if (p.acc_in) {
         // (acc_in + acc_in2) first, like xs = r0; xs += r1; then + this block's output (hifigan.py:99-102)
         float rv[N], av[N], a2[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) rv[i] = p.res ? buffer_load1(e.res, off[i]) : 0.f;
+        for (int i = 0; i < N; ++i) rv[i] = p.res ? buffer_load1s(e.res, off[i], so[i]) : 0.f;
 #pragma unroll
-        for (int i = 0; i < N; ++i) av[i] = buffer_load1(e.acc, off[i]);
+        for (int i = 0; i < N; ++i) av[i] = buffer_load1s(e.acc, off[i], so[i]);
 #pragma unroll
-        for (int i = 0; i < N; ++i) a2[i] = p.acc_in2 ? buffer_load1(e.acc2, off[i]) : 0.f;
+        for (int i = 0; i < N; ++i) a2[i] = p.acc_in2 ? buffer_load1s(e.acc2, off[i], so[i]) : 0.f;
         // either association reproduces xs = r0; xs += r1; xs += r2 exactly, depending on which
         // block's conv carries the sum: the last one (own = r2) or the first (own = r0)
         if (p.own_first) {
 #pragma unroll
-            for (int i = 0; i < N; ++i) v[i] = (((v[i] + ri.bias[i]) + rv[i]) + av[i]) + a2[i];
+            for (int i = 0; i < N; ++i) v[i] = (((v[i] + bias[i]) + rv[i]) + av[i]) + a2[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < N; ++i) v[i] = (av[i] + a2[i]) + ((v[i] + ri.bias[i]) + rv[i]);
+            for (int i = 0; i < N; ++i) v[i] = (av[i] + a2[i]) + ((v[i] + bias[i]) + rv[i]);
         }
     } else if (p.res) {
         float rv[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) rv[i] = buffer_load1(e.res, off[i]);
+        for (int i = 0; i < N; ++i) rv[i] = buffer_load1s(e.res, off[i], so[i]);
 #pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = (v[i] + ri.bias[i]) + rv[i];
+        for (int i = 0; i < N; ++i) v[i] = (v[i] + bias[i]) + rv[i];
     } else {
 #pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = v[i] + ri.bias[i];
+        for (int i = 0; i < N; ++i) v[i] = v[i] + bias[i];
     }
     if (p.out_div != 1.f) {
 #pragma unroll
@@ -379,16 +388,16 @@ __device__ __forceinline__ void epilogue_finish(const ConvParams& p, const Epilo
     if (p.y_act) {
         // raw tensor for residual consumers + activated twin for conv consumers
 #pragma unroll
-        for (int i = 0; i < N; ++i) buffer_store1(e.y, off[i], v[i]);
+        for (int i = 0; i < N; ++i) buffer_store1s(e.y, off[i], so[i], v[i]);
 #pragma unroll
-        for (int i = 0; i < N; ++i) buffer_store1(e.y2, off[i], act(v[i], p.act_slope));
+        for (int i = 0; i < N; ++i) buffer_store1s(e.y2, off[i], so[i], act(v[i], p.act_slope));
     } else {
         if (p.act_slope != 1.f) {
 #pragma unroll
             for (int i = 0; i < N; ++i) v[i] = act(v[i], p.act_slope);
         }
 #pragma unroll
-        for (int i = 0; i < N; ++i) buffer_store1(e.y, off[i], v[i]);
+        for (int i = 0; i < N; ++i) buffer_store1s(e.y, off[i], so[i], v[i]);
     }
 }
 
@@ -396,9 +405,32 @@ template <int N>
 __device__ __forceinline__ void epilogue_store(const ConvParams& p, const EpilogueRsrc& e,
                                                const RowInfo<N>& ri, const int (&m)[N], int q,
                                                float (&v)[N]) {
-    unsigned off[N];
+    unsigned off[N], so[N];
     epilogue_offsets<N>(p, ri, m, q, off);
-    epilogue_finish<N>(p, e, ri, off, v);
+#pragma unroll
+    for (int i = 0; i < N; ++i) so[i] = 0u;
+    epilogue_finish<N>(p, e, ri.bias, off, so, v);
+}
+
+// Plain conv (ups == 1) whose row tile lies entirely inside the output: row r of the thread is
+// mlane + rc[r] with rc compile-time, so every element of the batch shares ONE vector offset
+// ((mlane*Tout + q)*4, or the out-of-range marker past the last column) and differs only in
+// the wave-uniform rc*Tout*4, which rides in the instruction's scalar offset: no per-row
+// offset registers, no per-row adds.  (Tout through opaque_uniform so that the scalar products
+// are formed here, not hoisted and then spilled.)
+template <int N, typename F>
+__device__ __forceinline__ void epilogue_store_affine(const ConvParams& p, const EpilogueRsrc& e,
+                                                      const float (&bias)[N], int mlane, int reg0,
+                                                      int q, float (&v)[N]) {
+    const unsigned t4 = (unsigned)opaque_uniform(p.Tout) * 4u;
+    const unsigned voff = q < p.Tq ? (unsigned)(mlane * p.Tout + q) * 4u : kOutOfRange;
+    unsigned off[N], so[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        off[i] = voff;
+        so[i] = (unsigned)F::row(reg0 + i, 0) * t4;
+    }
+    epilogue_finish<N>(p, e, bias, off, so, v);
 }
 
 // XCD-aware block order: the dispatcher places linear block id b on XCD b % 8,
@@ -515,13 +547,30 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
         }
         stage_x<NW, NT, SLOW>(p, dp, rx, xs, xb, cin_a, ci0, tA, wave, lane, tid);
     };
+    // epilogue addressing: affine (see epilogue_store_affine) unless this is a transposed conv
+    // or the row tile sticks out of the output rows
+    const bool affine = p.ups == 1 && m0 + M_T <= p.M && !(p.dbg & 8);   // FV_DBG=8: general path (A/B)
+    const int mlane = m0 + wave_m * MF + F::row(0, lane);
     RowInfo<EN> ri[EH];
+    if (affine) {
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.bias ? p.bias : p.wp, p.bias ? (unsigned)p.Cout * 4u : 0u);
 #pragma unroll
-    for (int h = 0; h < EH; ++h) {
-        int mm[EN];
+        for (int h = 0; h < EH; ++h) {
+            ri[h].short_mask = 0u;
 #pragma unroll
-        for (int i = 0; i < EN; ++i) mm[i] = m0 + wave_m * MF + F::row(h * EN + i, lane);
-        row_info<EN>(p, mm, ri[h]);
+            for (int i = 0; i < EN; ++i) {
+                ri[h].off[i] = 0u;
+                ri[h].bias[i] = buffer_load1s(rb, (unsigned)mlane * 4u, (unsigned)F::row(h * EN + i, 0) * 4u);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int h = 0; h < EH; ++h) {
+            int mm[EN];
+#pragma unroll
+            for (int i = 0; i < EN; ++i) mm[i] = m0 + wave_m * MF + F::row(h * EN + i, lane);
+            row_info<EN>(p, mm, ri[h]);
+        }
     }
     // the tile's window start is t0 - pad; with N_T a multiple of 4 only pad sets the phase
     const int aoff = (((-p.pad) % 4) + 4) % 4;
@@ -645,13 +694,16 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
 #pragma unroll
                     for (int h = 0; h < EH; ++h) {
                         float vv[EN];
-                        int mm[EN];
 #pragma unroll
-                        for (int i = 0; i < EN; ++i) {
-                            vv[i] = acc[r][h * EN + i];
-                            mm[i] = m0 + wave_m * MF + F::row(h * EN + i, lane);
+                        for (int i = 0; i < EN; ++i) vv[i] = acc[r][h * EN + i];
+                        if (affine) {
+                            epilogue_store_affine<EN, F>(p, ersrc, ri[h].bias, mlane, h * EN, q, vv);
+                        } else {
+                            int mm[EN];
+#pragma unroll
+                            for (int i = 0; i < EN; ++i) mm[i] = m0 + wave_m * MF + F::row(h * EN + i, lane);
+                            epilogue_store<EN>(p, ersrc, ri[h], mm, q, vv);
                         }
-                        epilogue_store<EN>(p, ersrc, ri[h], mm, q, vv);
                     }
                 }
             }
