@@ -8,8 +8,10 @@ seeded gain-calibrated random-init weights (no checkpoint exists offline),
 weight norm folded.  One "step" = one ``Generator.forward`` over the per-GPU
 batch -> 240 000 samples per utterance.  N > 1 (launched by torch.distributed.run,
 one rank per GPU): weights are built on rank 0 and broadcast over RCCL once,
-every rank then runs its own utterances (weak scaling, no collective inside the
-generator) and the waveforms are gathered to rank 0 inside the timed step.
+every rank then runs its own utterances (weak scaling: the path has no exchange
+step, so the timed steps contain no collective); one root gather after the timed
+region checks the RCCL data path, and ``--gather`` puts an asynchronous per-step
+gather inside the timed region instead.
 
 Prints ONE JSON line: value = whole-job audio samples / second, plus RTF at
 22.05 kHz and 24 kHz, the roofline of the dominant kernel (fp32-MFMA implicit-GEMM
@@ -64,11 +66,12 @@ def cpu_baseline(cfg, sd, mel):
             "seconds": best}
 
 
-def timed_steps(step, steps, warmup, dist, dev):
+def timed_steps(step, steps, warmup, dist, dev, after=None):
     """``warmup`` untimed calls of ``step()``, then EXACTLY ``steps`` timed ones bracketed by
     (device sync, barrier, device sync) on both sides; returns (seconds = MAX over ranks,
-    last step's result).  ``dist`` is torch.distributed or None (single process); covered on
-    CPU by tests/test_distributed_cpu.py with the gloo backend."""
+    last step's result).  ``after`` (optional) runs after the last warm-up and after the last
+    timed step, inside the bracket.  ``dist`` is torch.distributed or None (single process);
+    covered on CPU by tests/test_distributed_cpu.py with the gloo backend."""
     def sync():
         # drain this GPU, meet the other ranks, drain the barrier's own collective
         if dev.type == "cuda":
@@ -81,10 +84,14 @@ def timed_steps(step, steps, warmup, dist, dev):
     out = None
     for _ in range(warmup):
         out = step()
+    if after is not None:
+        after()
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
+    if after is not None:
+        after()             # e.g. complete asynchronous transfers started by the last step
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -101,6 +108,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: also gather every step's waveforms to rank 0 inside the timed region "
+                         "(asynchronously, overlapping the next step); default: utterances stay on "
+                         "the rank that made them and one gather after the timed region checks the path")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,7 +124,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # FV_BENCH_FORCE_DIST=1: take the N > 1 code path (RCCL init, broadcast, gather, barrier,
+    # all-reduce) with a single rank too -- a self-test of that path on a 1-GPU box
+    force_dist = os.environ.get("FV_BENCH_FORCE_DIST", "0") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -125,23 +139,35 @@ def main():
     if rank == 0:
         model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model = model.to(dev).eval()
-    if world > 1:
+    if dist is not None:
         parallel.broadcast_weights(model, src=0)          # RCCL broadcast, once
     model.remove_weight_norm()
 
     B = args.batch
     mel = torch.from_numpy(seeded_mel(T_FRAMES, seed=100 + rank, batch=B)).to(dev)
-    gather = parallel.WaveformGather(world, rank, dev) if world > 1 else None
+    gather = parallel.WaveformGather(world, rank, dev) if dist is not None else None
 
     def step():
         with torch.no_grad():
             wav = model(mel)
-        if gather is not None:
-            gather(wav)
+        if gather is not None and args.gather:
+            gather(wav)           # asynchronous: overlaps the next step's forward
         return wav
 
-    elapsed, wav = timed_steps(step, args.steps, args.warmup, dist, dev)
+    def last_step_done():
+        if gather is not None and args.gather:
+            gather.flush()        # the last gather belongs to the timed region
 
+    elapsed, wav = timed_steps(step, args.steps, args.warmup, dist, dev, after=last_step_done)
+
+    if gather is not None and not args.gather:
+        # outside the timed region: one root gather, so that the RCCL data path is exercised and
+        # rank 0 ends up holding every rank's last waveforms, as a serving front-end would
+        gather(wav)
+        bufs = gather.flush()
+        if rank == 0:
+            assert len(bufs) == world and all(tuple(b.shape) == tuple(wav.shape) for b in bufs)
+            assert torch.equal(bufs[0], wav)
     samples_per_utt = int(wav.shape[-1])
     total_samples = samples_per_utt * B * world * args.steps
     value = total_samples / elapsed

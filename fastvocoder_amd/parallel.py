@@ -36,24 +36,40 @@ def broadcast_weights(model, src=0, group=None):
 
 
 class WaveformGather:
-    """Root gather of equally-shaped per-rank waveform blocks [b, n] -> [world*b, n]
-    on rank 0 (None elsewhere).  Buffers are allocated once and reused."""
+    """Root gather of equally-shaped per-rank waveform blocks [b, n] -> [world*b, n] on rank 0
+    (None elsewhere).  Buffers are allocated once and reused.
+
+    The gather is issued asynchronously (on the communicator's own stream) and only the
+    PREVIOUS one is waited for when the next is issued, so the transfer of batch i overlaps
+    the generator's work on batch i+1 -- the generator itself has no collective to wait for.
+    ``flush()`` completes the last one; the list returned by a call is valid after the next
+    call or ``flush()``."""
 
     def __init__(self, world_size, rank, device, dst=0, group=None):
         self.world, self.rank, self.dst, self.group = world_size, rank, dst, group
         self.device = device
         self._bufs = None
         self._shape = None
+        self._pending = None     # (work handle, tensor kept alive while in flight)
+
+    def flush(self):
+        if self._pending is not None:
+            self._pending[0].wait()
+            self._pending = None
+        return self._bufs
 
     def __call__(self, wav):
         wav = wav.contiguous()
+        self.flush()             # the receive buffers are about to be reused
         if self.rank == self.dst:
             if self._shape != tuple(wav.shape):
                 self._bufs = [torch.empty_like(wav) for _ in range(self.world)]
                 self._shape = tuple(wav.shape)
-            dist.gather(wav, gather_list=self._bufs, dst=self.dst, group=self.group)
+            work = dist.gather(wav, gather_list=self._bufs, dst=self.dst, group=self.group, async_op=True)
+            self._pending = (work, wav)
             return self._bufs
-        dist.gather(wav, gather_list=None, dst=self.dst, group=self.group)
+        work = dist.gather(wav, gather_list=None, dst=self.dst, group=self.group, async_op=True)
+        self._pending = (work, wav)
         return None
 
 

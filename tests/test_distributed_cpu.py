@@ -55,8 +55,15 @@ def _worker(rank, world, port, B, out_path):
         gather = parallel.WaveformGather(world, rank, torch.device("cpu"))
         mine = torch.full((2, 6), float(rank))
         bufs = gather(mine)
+        gather.flush()                                   # asynchronous gather: complete it
         if rank == 0:
             assert [float(b[0, 0]) for b in bufs] == [float(r) for r in range(world)]
+        # back-to-back gathers reuse the buffers; each call completes the previous one first
+        for it in range(3):
+            gather(torch.full((2, 6), float(rank + 10 * it)))
+        bufs = gather.flush()
+        if rank == 0:
+            assert [float(b[1, 5]) for b in bufs] == [float(r + 20) for r in range(world)]
         # 4) bench.py's timing bracket: K steps, barrier on both sides, MAX over ranks
         import time
 
