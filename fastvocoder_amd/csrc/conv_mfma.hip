@@ -20,14 +20,15 @@
 // (tile, channel-chunk) stage holds 0.5-2 us of matrix work; and on gfx950 plain
 // VALU instructions do NOT co-execute with v_mfma_f32_* -- every VALU costs ~3
 // cycles of matrix time -- so the hot loop must be MFMA + ds_read and nothing else:
-//   * a block walks a run of time tiles; per (tile, channel-chunk) STAGE
+//   * a block handles one time tile (a run of tiles only when the grid would exceed
+//     FV_GRID_CAP blocks); per (tile, channel-chunk) STAGE
 //         xs[ci_chunk][xw]      input window with its dilation halo
 //         ws[ci_chunk*k][M_T]   K-major weight slice (dense 2-D block of Wp)
 //     are brought in by LDS-DMA (buffer_load_dwordx4 ... lds): no staging VGPRs,
 //     no ds_write pass, bounds-checked by the buffer descriptor (rows past Cin
-//     read as 0).  The DMA of stage s+1 is issued before the MFMA loop of stage
-//     s into the other LDS buffer; one barrier per stage; per-lane DMA offsets
-//     are computed once per block;
+//     read as 0).  Stages form one linear pipeline across chunk and tile
+//     boundaries: the DMA of stage s+1 is issued before the MFMA loop of stage s
+//     into the other LDS buffer; one barrier per stage;
 //   * the input activation is NOT in the hot loop: plans feed every conv a
 //     tensor that already holds act(x) (the producing epilogue writes it, next
 //     to the raw tensor when a residual also needs that), see engine.py.  A
@@ -35,16 +36,21 @@
 //     operator entry points (ACT = true variants);
 //   * tap count and dilation are template parameters for the hot shapes, so
 //     every A/B operand is a ds_read with an immediate offset (paired into
-//     ds_read2_b32 by the compiler): zero address arithmetic per MFMA;
-//   * registers stay at accumulators + a few addresses, so 4-8 waves per SIMD
-//     are resident and cover what the one-stage prefetch does not;
+//     ds_read2_b32 by the compiler): two address adds per K step, nothing per MFMA;
+//   * everything AROUND the hot loop is written for instruction count too (a tile
+//     has only 100-350 MFMAs per wave): per-lane DMA offsets once per block and
+//     an issue sequence LLVM cannot hoist into spilled SGPRs (opaque_uniform),
+//     branch-free row setup through bounds-checked descriptors, affine epilogue
+//     addressing (one vector offset + a scalar per row) for plain convs;
+//   * 118-124 VGPRs => 4 waves per SIMD, 39 KiB of LDS per block => 4 blocks per CU;
 //   * WK > 1 splits the K range of every stage over WK wave groups that share
 //     the staged tiles and reduce through LDS at the end of the tile;
-//   * tiles that touch the sequence ends (zero / reflection padding) and
-//     unaligned tensors take a synchronous register path (stage_x_edge);
+//   * tiles that touch the sequence ends with reflection padding, and unaligned
+//     tensors, take a synchronous register path (stage_x_edge, SLOW variants);
+//     zero-padded edges of aligned tensors are still DMA (masked lanes);
 //   * the epilogue fuses bias, residual add, the MRF running sum / mean,
 //     tanh / ReLU and the optional activated twin output through bounds-checked
-//     buffer loads/stores (row offsets and bias are per-block constants).
+//     buffer loads/stores.
 #include <stdlib.h>
 
 #include "fv_internal.h"
