@@ -494,6 +494,33 @@ def test_batch_rows_are_independent_and_bit_identical():
             assert torch.equal(one[0], full[b])
 
 
+@pytest.mark.parametrize("name,path,B", [("multiband-hifigan", "conf/multiband-hifigan/light.yaml", 32),
+                                         ("basis-melgan", "conf/basis-melgan/light.yaml", 64),
+                                         ("hifigan", "conf/hifigan/large.yaml", 64)],
+                         ids=["config3_mb_light_B32", "config4_basis_B64", "config5_hifigan_large_B64"])
+def test_baseline_batch_sizes_by_size_independent_properties(name, path, B):
+    """BASELINE.json configs 3-5 at their full batch and T = 1000 (too large for the oracle):
+    (i) sampled rows of the batch equal the single-utterance run bit for bit -- which the
+    shipped-config tests tie to the reference within 1e-4 --, (ii) the run is deterministic
+    (checksum of checksums of two runs), (iii) output lengths follow the reference's law."""
+    cfg = cases.load_conf(path)
+    m, _ = _model(name, cfg, seed=0)
+    T = 1000
+    x = torch.from_numpy(seeded_mel(T, seed=77, batch=B)).to(_dev())
+    run = (lambda z: m.synthesize_batch(z)) if name == "multiband-hifigan" else \
+          (lambda z: m._samples(z)) if name == "basis-melgan" else (lambda z: m(z))
+    with torch.no_grad():
+        full = run(x)
+        again = run(x)
+        assert full.shape == (B, 240 * T + (15 if name == "basis-melgan" else 0))
+        assert torch.equal(full, again)
+        assert float(full.double().sum(dim=1).abs().sum()) == float(again.double().sum(dim=1).abs().sum())
+        for b in (0, B // 2, B - 1):
+            one = run(x[b:b + 1].contiguous())
+            assert torch.equal(one[0], full[b]), (name, b)
+    assert bool(torch.isfinite(full).all())
+
+
 def test_conv_is_linear_without_activation():
     """conv(a*x1 + x2) == a*conv(x1) + conv(x2) - bias terms (size-independent property)."""
     dev = _dev()
