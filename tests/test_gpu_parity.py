@@ -104,6 +104,65 @@ def test_conv1d_fused_vs_oracle(case):
     assert _err(y2, ref2) <= 2e-5
 
 
+def test_random_conv_shapes_vs_oracle():
+    """Seeded sweep over shapes no generator uses: odd channel counts (row tiles that stick out
+    of the output, channel chunks that do not divide Cin), every tap count / dilation / padding
+    combination the launcher dispatches differently, pre-activation on and off, with and
+    without residual -- each against the C oracle."""
+    rng = np.random.RandomState(20260927)
+    dev = _dev()
+    for n in range(60):
+        B = int(rng.choice([1, 2, 3]))
+        Cin, Cout = int(rng.randint(1, 72)), int(rng.randint(5, 72))
+        k = int(rng.choice([1, 2, 3, 5, 7, 11]))
+        dil = int(rng.choice([1, 2, 3, 5])) if k > 1 else 1
+        T = int(rng.randint(max(2, dil * (k - 1) + 1), 700))
+        mode = int(rng.choice([0, 1]))
+        pad = int(rng.choice([0, dil * (k - 1) // 2, dil * (k - 1)]))
+        if mode == 1 and pad >= T:
+            pad = 0
+        if T + 2 * pad - dil * (k - 1) <= 0:
+            continue
+        slope = float(rng.choice([1.0, 0.1, 0.0]))
+        x = rng.randn(B, Cin, T).astype(np.float32)
+        w = (rng.randn(Cout, Cin, k) / np.sqrt(Cin * k)).astype(np.float32)
+        b = rng.randn(Cout).astype(np.float32) if rng.rand() < 0.8 else None
+        ref = oo.conv1d(x, w, b, dil=dil, pad=pad, pad_mode=mode, pre_slope=slope)
+        res = rng.randn(*ref.shape).astype(np.float32) if rng.rand() < 0.5 else None
+        want = ref + res if res is not None else ref
+        t = lambda a: None if a is None else torch.from_numpy(a).to(dev)  # noqa: E731
+        y = _native.conv1d_fused(t(x), _native.pack_conv1d(t(w)), t(b), Cout, k, dil=dil, pad=pad,
+                                 pad_mode=mode, pre_slope=slope, res=t(res))
+        assert _rel(y, want) <= 2e-5, (n, B, Cin, Cout, T, k, dil, pad, mode, slope)
+
+
+def test_random_transposed_conv_shapes_vs_oracle():
+    """Same for ConvTranspose1d: strides 2..10, kernels from s to 3s, paddings / output paddings
+    that make Tout not a multiple of the stride (the overflow rows of the last column)."""
+    rng = np.random.RandomState(4242)
+    dev = _dev()
+    for n in range(40):
+        B = int(rng.choice([1, 2]))
+        Cin, Cout = int(rng.randint(1, 48)), int(rng.randint(1, 40))
+        s_ = int(rng.randint(2, 11))
+        k = int(rng.randint(s_, 3 * s_ + 1))
+        p_ = int(rng.randint(0, min(k // 2, s_) + 1))
+        op = int(rng.randint(0, s_))
+        T = int(rng.randint(1, 200))
+        if (T - 1) * s_ - 2 * p_ + k + op <= 0:
+            continue
+        slope = float(rng.choice([1.0, 0.2]))
+        x = rng.randn(B, Cin, T).astype(np.float32)
+        w = (rng.randn(Cin, Cout, k) / np.sqrt(max(1, Cin * k // s_))).astype(np.float32)
+        b = rng.randn(Cout).astype(np.float32)
+        ref = oo.conv_transpose1d(x, w, b, s_, p_, op, pre_slope=slope)
+        t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+        y = _native.conv_transpose1d_fused(t(x), _native.pack_conv_transpose1d(t(w), s_, p_), t(b), Cout, k,
+                                           s_, p_, op, pre_slope=slope)
+        assert tuple(y.shape) == ref.shape, (n, ref.shape)
+        assert _rel(y, ref) <= 2e-5, (n, B, Cin, Cout, T, k, s_, p_, op)
+
+
 CONVT_CASES = [
     # B, Cin, Cout, T, k, stride   (pad = s//2 + s%2, out_pad = s%2, like the generators)
     (1, 64, 32, 50, 16, 8), (2, 32, 16, 41, 10, 5), (1, 32, 16, 100, 6, 3), (2, 32, 16, 77, 4, 2),
