@@ -906,9 +906,21 @@ int launch_geom(const ConvParams& p, size_t lds, int grid_x, hipStream_t s) {
     if (p.pre_slope != 1.f) {
         FV_LAUNCH(0, 0, true, true);
     } else if (slow) {
+        // MelGAN / Basis-MelGAN: reflect-padded 3-tap convs with dilation 3^j (modules.py:351-357,
+        // melgan.py:97-108) carry 60 % of their FLOPs; first / last layer: 7 taps, undilated
         switch (p.k) {
-            case 3: FV_LAUNCH(3, 0, false, true); break;
-            case 7: FV_LAUNCH(7, 0, false, true); break;
+            case 3:
+                switch (p.dil) {
+                    case 1: FV_LAUNCH(3, 1, false, true); break;
+                    case 3: FV_LAUNCH(3, 3, false, true); break;
+                    case 9: FV_LAUNCH(3, 9, false, true); break;
+                    default: FV_LAUNCH(3, 0, false, true); break;
+                }
+                break;
+            case 7:
+                if (p.dil == 1) FV_LAUNCH(7, 1, false, true);
+                else FV_LAUNCH(7, 0, false, true);
+                break;
             default: FV_LAUNCH(0, 0, false, true); break;
         }
     } else {
