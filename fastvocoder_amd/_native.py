@@ -14,7 +14,11 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfastvocoder_hip.so")
 _CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip", "wav_sink.hip"]
+# conv_inst_s*.hip instantiate the conv kernel templates (conv_kernels.hpp) one tile shape each,
+# so that the ~170 kernel variants compile in parallel
+SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip", "wav_sink.hip", "conv_inst_narrow.hip"] + \
+          [f"conv_inst_s{i}.hip" for i in range(6)]
+HEADERS = ["fv_internal.h", "conv_kernels.hpp"]
 
 PAD_ZERO, PAD_REFLECT = 0, 1
 PAD_CAUSAL = 2      # flag: pad (k-1)*dil on both sides, keep the first Tin outputs (CausalConv1d)
@@ -29,22 +33,38 @@ class NativeError(RuntimeError):
 
 def build(force=False, verbose=False):
     """hipcc the kernels for gfx950 into fastvocoder_amd/libfastvocoder_hip.so
-    (cross-compiles without a GPU)."""
+    (cross-compiles without a GPU): one object per source, compiled in parallel, then linked."""
     srcs = [os.path.join(_CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(_CSRC, "fv_internal.h"),
-                   os.path.join(_HERE, "..", "include", "fastvocoder_hip.h")]
+    deps = srcs + [os.path.join(_CSRC, h) for h in HEADERS] + \
+        [os.path.join(_HERE, "..", "include", "fastvocoder_hip.h")]
     if (not force and os.path.exists(LIB_PATH)
             and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps)):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-value", "-Wno-comment", "-Wno-pass-failed",
-           # MFMA results straight in VGPRs (unified register file on gfx950): no
-           # v_accvgpr_read/write pairs around every stage -- VALU work costs MFMA time
-           "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + srcs + ["-o", LIB_PATH]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+             "-Wno-unused-value", "-Wno-comment", "-Wno-pass-failed",
+             # MFMA results straight in VGPRs (unified register file on gfx950): no
+             # v_accvgpr_read/write pairs around every stage -- VALU work costs MFMA time
+             "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+    objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((cmd, obj, subprocess.Popen(cmd)))
+    for cmd, obj, proc in jobs:
+        if proc.wait() != 0:
+            for _, _, other in jobs:
+                if other.poll() is None:
+                    other.kill()
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj for _, obj, _ in jobs] + ["-o", LIB_PATH]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return LIB_PATH
 
 

@@ -1,0 +1,7 @@
+// Tile shape 3 of conv_mfma.hip's kShapes[]: every kernel variant of this shape.
+#include "conv_kernels.hpp"
+
+namespace fv {
+template int launch_geom<32, 1, 2, 2, 1>(const ConvParams&, size_t, int, hipStream_t);
+template int launch_group_geom<32, 1, 2, 2, 1>(const GroupParams&, size_t, int, int, int, hipStream_t);
+}  // namespace fv

@@ -94,6 +94,23 @@ struct ConvParams {
     int dbg;        // ablation switches (FV_DBG, tuning only): 1 no epilogue, 2 no restaging, 4 no MFMA
 };
 
+// Three (or two: the third grid empty) mutually independent convs of one MRF position in
+// one launch: conv_group3_kernel, blockIdx.z picks the problem, largest kernel first.
+struct GroupParams {
+    ConvParams p[3];   // sorted k = 11, 7, 3
+    int grid_x[3];
+};
+
+// Shared between the host launcher (conv_mfma.hip) and the kernels (conv_kernels.hpp):
+#ifndef FV_RING
+#define FV_RING 2          // stage buffers of the LDS-DMA ring in the plain (aligned, zero-padded) kernels.
+                           // Measured (HiFi-GAN light, B = 1): 2 -> 1.66 ms/step, 3 -> 1.71 ms (the third
+                           // buffer halves the stage size of the 7- and 3-tap kernels under the LDS budget)
+#endif
+// the SLOW / ACT variants stage some tiles synchronously: always two buffers, full waits
+constexpr int kRingStages(bool slow, bool act) { return (slow || act) ? 2 : FV_RING; }
+constexpr int kMaxDmaX = 6, kMaxDmaW = 8;   // LDS-DMA instructions per wave per stage (host-checked)
+
 int launch_conv(ConvParams p, hipStream_t stream);
 // n mutually independent convs; one grouped launch when they form an MRF position
 int launch_conv_group(ConvParams* ps, int n, hipStream_t stream);
