@@ -242,6 +242,22 @@ def main():
                        "convs_per_forward": model._plan("trunk", None, 80).num_ops()},
             "roofline": roofline,
         }
+        # PCIe-inclusive rate of the drop-in boundary (never `value`): Generator.inference takes a
+        # HOST mel [T,80] and the caller wants a HOST waveform -- pageable numpy in, numpy out,
+        # one utterance per call, fully synchronous (H2D + forward + D2H per call)
+        if world == 1:
+            mel_np = seeded_mel(T_FRAMES, seed=100)
+            for _ in range(3):
+                model.inference(mel_np).cpu()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps_io = 20
+            for _ in range(reps_io):
+                y_host = model.inference(mel_np).cpu().numpy()
+            dt = (time.perf_counter() - t0) / reps_io
+            out["host_to_host"] = {"ms_per_utterance": 1e3 * dt, "samples_per_s": y_host.size / dt,
+                                   "what": "Generator.inference(numpy mel) -> numpy waveform, per call: "
+                                           "H2D 320 KB + forward + D2H 960 KB, pageable memory, synchronous"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, seeded_mel(T_FRAMES, seed=100))
             out["cpu_baseline"]["rtf_22k05"] = out["cpu_baseline"]["seconds"] / (samples_per_utt / 22050.0)
