@@ -139,6 +139,27 @@ __global__ void pack_convT_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
+// ConvTranspose1d weight [Cin, Cout, k], k = tp*s -> phase-major image
+// Wp[(ci*tp + jj)][m = r*Cout + co] = w[ci, co, (r+p) % s + (tp-1-jj)*s]   (fv_internal.h convt_phase_major)
+__global__ void pack_convT_phase_major_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin,
+                                              int Cout, int k, int s, int p, int tp, int Mpad) {
+    const int64_t total = (int64_t)Cin * tp * Mpad;
+    const int M = Cout * s;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i % Mpad);
+        const int64_t row = i / Mpad;
+        const int jj = (int)(row % tp), ci = (int)(row / tp);
+        float val = 0.f;
+        if (m < M) {
+            const int r = m / Cout, co = m - r * Cout;
+            const int j = (r + p) % s + (tp - 1 - jj) * s;
+            val = w[((size_t)ci * Cout + co) * k + j];
+        }
+        wp[i] = val;
+    }
+}
+
 // UpsampleLayer weight [Cout, Cin, k] (nearest-repeat x u, then conv with zero padding p) ->
 // phase image Wp[(ci*taps + jj)][m = co*u + r] = sum of w[co, ci, j] over the taps j with
 // floor((r + j - p) / u) == dmin + jj (they all read the same input sample).
@@ -311,6 +332,12 @@ static ConvParams make_params(const Op& o, const float* x, float* y, float* y2, 
         p.k = ph.taps;
         p.dil = 1;
         p.pad = -ph.dmin;
+        if (o.type == OP_CONVT && convt_phase_major(o.Cout, o.k, o.stride, o.pad)) {
+            p.phase_major = 1;
+            p.pad_orig = o.pad;
+            p.k = o.k / o.stride;          // taps of every phase
+            p.pad = p.k - 1;               // the widest window shift (phases with (r+p)/s == 0)
+        }
         p.pad_mode = FV_PAD_ZERO;
         p.ups = o.stride;
         p.Tq = (p.Tout + o.stride - 1) / o.stride;
@@ -446,6 +473,7 @@ int64_t fv_packed_conv1d_floats(int Cout, int Cin, int k) {
 }
 
 int64_t fv_packed_conv_transpose1d_floats(int Cin, int Cout, int k, int stride, int pad) {
+    if (convt_phase_major(Cout, k, stride, pad)) return (int64_t)Cin * (k / stride) * pad_rows(Cout * stride);
     const Polyphase ph = polyphase(k, stride, pad);
     return (int64_t)Cin * ph.taps * pad_rows(Cout * stride);
 }
@@ -465,6 +493,15 @@ int fv_pack_conv_transpose1d_weight(const float* w, float* packed, int Cin, int 
                                     int stride, int pad, void* stream) {
     if (int rc = check_conv_args(Cin, Cout, k, 1)) return rc;
     if (stride <= 0 || pad < 0) return fail(FV_ERR_INVALID_ARG, "convT stride=%d pad=%d", stride, pad);
+    if (convt_phase_major(Cout, k, stride, pad)) {
+        const int tp = k / stride, Mp = pad_rows(Cout * stride);
+        const int64_t tot = (int64_t)Cin * tp * Mp;
+        const int nb = (int)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
+        hipLaunchKernelGGL(pack_convT_phase_major_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w,
+                           packed, Cin, Cout, k, stride, pad, tp, Mp);
+        FV_HIP(hipGetLastError());
+        return 0;
+    }
     const Polyphase ph = polyphase(k, stride, pad);
     const int Mpad = pad_rows(Cout * stride);
     const int64_t total = (int64_t)Cin * ph.taps * Mpad;

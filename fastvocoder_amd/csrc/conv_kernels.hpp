@@ -302,7 +302,11 @@ __device__ __forceinline__ void row_info(const ConvParams& p, const int (&m)[N],
         const int rem = p.Tout - (p.Tq - 1) * p.ups;   // phases present in the last column
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int co = m[i] / p.ups, ph = m[i] - co * p.ups;
+            int co = m[i] / p.ups, ph = m[i] - co * p.ups;         // rows co-major: m = co*ups + phase
+            if (p.phase_major) {                                    // rows phase-major: m = phase*Cout + co
+                ph = m[i] / p.Cout;
+                co = m[i] - ph * p.Cout;
+            }
             ri.off[i] = (unsigned)(co * p.Tout + ph) * 4u + (m[i] < p.M ? 0u : kOutOfRange);
             ri.short_mask |= (ph >= rem ? 1u : 0u) << i;   // see epilogue_offsets
             ri.bias[i] = buffer_load1(rb, (unsigned)co * 4u);
@@ -569,8 +573,10 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
             row_info<EN>(p, mm, ri[h]);
         }
     }
-    // the tile's window start is t0 - pad; with N_T a multiple of 4 only pad sets the phase
-    const int aoff = (((-p.pad) % 4) + 4) % 4;
+    // the tile's window start is t0 - pad; with N_T a multiple of 4 only pad sets the phase.
+    // A phase-major transposed conv shifts the window per row tile (= per output phase).
+    const int pad_t = p.phase_major ? p.k - 1 - ((m0 / p.Cout + p.pad_orig) / p.ups) : p.pad;
+    const int aoff = (((-pad_t) % 4) + 4) % 4;
 
     // ---- software pipeline over this block's stages s = (tile, channel chunk) -----------------
     // LDS holds NS stage buffers; stage s lives in buffer s % NS and its DMA is issued NS-1
@@ -588,7 +594,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
     int it = tile_lo, ic = 0, ibuf = 0, issued = 0;   // next stage to issue: (tile, chunk), its buffer
     const int issue_limit = (p.dbg & 2) ? min(total, NS - 1) : total;
     auto issue = [&]() {
-        const int tA = it * N_T - p.pad - aoff;
+        const int tA = it * N_T - pad_t - aoff;
         stage(xs0 + ibuf * p.xbuf, ic * p.ci_chunk, tA);
         if (nchunks > 1) dma_w<NW, M_T>(p, dp, rw, ws_base + ibuf * p.wbuf, ic * p.ci_chunk, wave);
         if (++ic == nchunks) { ic = 0; ++it; }
@@ -848,6 +854,10 @@ int launch_geom(const ConvParams& p, size_t lds, int grid_x, hipStream_t s) {
     } else {
         switch (p.k) {
             case 1: FV_LAUNCH(1, 1, false, false); break;
+            case 2:   // the phase-major transposed convs (k = 2*stride)
+                if (p.dil == 1) FV_LAUNCH(2, 1, false, false);
+                else FV_LAUNCH(0, 0, false, false);
+                break;
             case 3: FV_LAUNCH_DIL(3); break;
             case 7: FV_LAUNCH_DIL(7); break;
             case 11: FV_LAUNCH_DIL(11); break;

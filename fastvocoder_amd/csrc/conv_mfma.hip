@@ -190,9 +190,11 @@ int prepare_conv(ConvParams& p, LaunchInfo& li, int members = 1) {
     else if (m64 && units(5) * members >= want) shape = 5;
     else if (units(3) * members >= 400) shape = 3;
     else shape = 4;
+    // a phase-major transposed conv needs row tiles that hold one phase: m_t must divide Cout
+    if (p.phase_major && p.Cout % kShapes[shape].m_t() != 0) shape = units(3) * members >= 400 ? 3 : 4;
     const int force = env_int(m16 ? "FV_SHAPE16" : (m64 ? "FV_SHAPE64" : "FV_SHAPE32"), -1);
     if (force >= 0 && force < kNumShapes && kShapes[force].mf == (m16 ? 16 : 32) &&
-        p.Mpad % kShapes[force].m_t() == 0)
+        p.Mpad % kShapes[force].m_t() == 0 && !(p.phase_major && p.Cout % kShapes[force].m_t() != 0))
         shape = force;
     const Geometry g = kShapes[shape];
     li.shape = shape;

@@ -41,6 +41,16 @@ static inline Polyphase polyphase(int k, int s, int p) {
     return ph;
 }
 
+// PHASE-MAJOR form of a transposed conv whose kernel is a whole number of strides (k = tp*s,
+// every shipped upsampler: k = 2s): every output phase r then has exactly tp taps, the window
+// x[q + d0(r) .. q + d0(r) + tp - 1] with d0(r) = (r+p)/s - tp + 1.  With the GEMM rows ordered
+// phase-major (m = r*Cout + co) and Cout a multiple of the row tile, a row tile holds ONE
+// phase, so it runs a dense tp-tap conv with its own window shift -- none of the zero taps
+// of the co-major form (1/3 of its MACs at k = 2s).
+static inline bool convt_phase_major(int Cout, int k, int s, int p) {
+    return s > 1 && k % s == 0 && k / s >= 2 && p <= s && Cout % 32 == 0;
+}
+
 // Nearest-repeat x u followed by Conv1d(k, zero padding p) (the reference's UpsampleLayer,
 // model/generator/modules.py:160-177) in the same phase form: output t = q*u + r reads
 // x[q + delta], delta = floor((r + j - p) / u); taps j that land on the same input
@@ -78,6 +88,8 @@ struct ConvParams {
     float act_slope;      // with y_act: slope of the twin; without: y itself is stored as act(y, act_slope)
     int post;
     int own_first;        // 0: y = (acc_in + acc_in2) + own;  1: y = (own + acc_in) + acc_in2  (own = conv + bias + res)
+    int phase_major;      // transposed conv in phase-major form (see convt_phase_major): rows m = r*Cout + co,
+    int pad_orig;         //   the window shift of a row tile comes from its phase and the layer's padding
     // filled in by the launcher
     int ci_chunk;   // input channels staged per LDS stage
     int nchunks;    // ceil(Cin / ci_chunk)

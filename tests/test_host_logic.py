@@ -167,7 +167,9 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert _native.lib().fv_version() == 5
     # host-only entry points that need no device
     assert _native.lib().fv_packed_conv1d_floats(128, 128, 11) == 128 * 11 * 128
-    assert _native.lib().fv_packed_conv_transpose1d_floats(256, 128, 16, 8, 4) == 256 * 3 * 1024
+    # k = 2*stride, Cout % 32 == 0: phase-major form, 2 taps per phase (3 in the co-major form)
+    assert _native.lib().fv_packed_conv_transpose1d_floats(256, 128, 16, 8, 4) == 256 * 2 * 1024
+    assert _native.lib().fv_packed_conv_transpose1d_floats(32, 16, 4, 2, 1) == 32 * 3 * 32
     assert _native.lib().fv_packed_conv1d_floats(1, 16, 7) == 16 * 7 * 16      # rows padded to 16
     assert _native.lib().fv_last_error() is not None
 
