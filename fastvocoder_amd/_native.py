@@ -97,6 +97,9 @@ def lib():
     L.fv_conv1d_2src_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, f, vp]
     L.fv_plan_add_conv1d_2src.argtypes = [vp, i, i, i, i, i, vp, vp, i, i, i, i, f]
     L.fv_plan_set_sum_order.argtypes = [vp, i]
+    L.fv_plan_add_conv1d_sum3.argtypes = [vp, ctypes.POINTER(i), ctypes.POINTER(i), ctypes.POINTER(i), i, i,
+                                          ctypes.POINTER(vp), vp,
+                                          i, ctypes.POINTER(i), f, i, f]
     L.fv_encode_16bits.argtypes = [vp, vp, vp, i, i64, f, i, vp]
     L.fv_pqmf_analysis.argtypes = [vp, vp, vp, i, i, i, i64, vp]
     L.fv_fold_batchnorm_conv.argtypes = [vp, vp, vp, vp, vp, vp, f, vp, vp, i, i, i, vp]
@@ -365,6 +368,19 @@ class Plan:
         check(lib().fv_plan_add_upsample_conv1d(self._h, x, y, y_act, _ptr(packed, "packed"),
                                                 _ptr(bias, "bias", True), cin, cout, k, rate, pad,
                                                 float(pre_slope), post, float(act_slope)))
+
+    def add_conv1d_sum3(self, xs, ress, tmps, y, packed, bias_sum, channels, ks, out_div=1.0, post=POST_NONE,
+                        y_act=SLOT_NONE, act_slope=1.0):
+        """The three last convs of an MRF stage into one output (fv_plan_add_conv1d_sum3)."""
+        for t in packed:
+            self.keep(t)
+        if bias_sum is not None:
+            self.keep(bias_sum)
+        i3 = ctypes.c_int * 3
+        wp = (ctypes.c_void_p * 3)(*[_ptr(t, "packed") for t in packed])
+        check(lib().fv_plan_add_conv1d_sum3(self._h, i3(*xs), i3(*ress), (ctypes.c_int * 2)(*tmps), y, y_act, wp,
+                                            _ptr(bias_sum, "bias_sum", True), channels, i3(*ks),
+                                            float(out_div), post, float(act_slope)))
 
     def set_sum_order(self, own_first):
         check(lib().fv_plan_set_sum_order(self._h, 1 if own_first else 0))

@@ -206,6 +206,14 @@ struct Op {
     int x2 = FV_SLOT_NONE;
     int Cin1 = 0;
     int own_first = 0;   // association of the MRF sum in the epilogue (ConvParams::own_first)
+    // sum3 (fv_plan_add_conv1d_sum3): two more (input, residual, weight, taps) members; this op's own
+    // x / res / wp / k / bias (summed) / y are member 0
+    bool sum3 = false;
+    int xb = FV_SLOT_NONE, xc = FV_SLOT_NONE, resb = FV_SLOT_NONE, resc = FV_SLOT_NONE;
+    int tmpb = FV_SLOT_NONE, tmpc = FV_SLOT_NONE;   // [B,C,T] scratch for the two-launch form (few tiles)
+    const float* wpb = nullptr;
+    const float* wpc = nullptr;
+    int kb = 0, kc = 0;
 };
 
 constexpr int kMaxLanes = 4;
@@ -278,6 +286,25 @@ static int infer(const fv_plan* plan, int B, int T, Shape* sh, int64_t* slot_ele
             if (aux[a] == FV_SLOT_NONE) continue;
             if (!sh[aux[a]].set || sh[aux[a]].C != Cout || sh[aux[a]].T != Tout)
                 return fail(FV_ERR_INVALID_ARG, "op %zu: residual/accumulator slot %d shape mismatch", n, aux[a]);
+        }
+        if (o.sum3) {
+            const int extra[4] = {o.xb, o.xc, o.resb, o.resc};
+            for (int e = 0; e < 4; ++e)
+                if (!sh[extra[e]].set || sh[extra[e]].C != o.Cin || sh[extra[e]].T != sh[o.x].T || extra[e] == o.y ||
+                    extra[e] == o.y2)
+                    return fail(FV_ERR_INVALID_ARG, "op %zu: sum3 member slot %d must be [%d, T] and not the output",
+                                n, extra[e], o.Cin);
+        }
+        if (o.sum3) {   // the scratch tensors of the two-launch form
+            const int t2[2] = {o.tmpb, o.tmpc};
+            for (int e = 0; e < 2; ++e) {
+                if (t2[e] == o.x || t2[e] == o.xb || t2[e] == o.xc || t2[e] == o.res || t2[e] == o.resb ||
+                    t2[e] == o.resc || t2[e] == o.y || t2[e] == o.y2 || t2[e] == FV_SLOT_IN)
+                    return fail(FV_ERR_INVALID_ARG, "op %zu: sum3 scratch slot %d aliases an operand", n, t2[e]);
+                sh[t2[e]] = {o.Cout, sh[o.x].T, true};
+                const int64_t es = (int64_t)B * o.Cout * sh[o.x].T;
+                if (es > slot_elems[t2[e]]) slot_elems[t2[e]] = es;
+            }
         }
         if (o.y == o.x || o.y == o.x2) return fail(FV_ERR_INVALID_ARG, "op %zu: output aliases input", n);
         sh[o.y] = {Cout, Tout, true};
@@ -375,8 +402,8 @@ static int compile_lanes(fv_plan* plan) {
             if (j >= 0 && plan->ops[j].lane != o.lane && j > latest[plan->ops[j].lane])
                 latest[plan->ops[j].lane] = j;
         };
-        const int reads[5] = {o.x, o.res, o.acc, o.acc2, o.x2};
-        const int writes[2] = {o.y, o.y2};
+        const int reads[9] = {o.x, o.res, o.acc, o.acc2, o.x2, o.xb, o.xc, o.resb, o.resc};
+        const int writes[4] = {o.y, o.y2, o.tmpb, o.tmpc};
         for (int s : reads)
             if (s != FV_SLOT_NONE) need(last_write[s]);
         for (int s : writes) {
@@ -700,6 +727,39 @@ int fv_plan_add_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, 
     return 0;
 }
 
+int fv_plan_add_conv1d_sum3(fv_plan_t* plan, const int* x_slots, const int* res_slots, const int* tmp_slots,
+                            int y_slot, int y_act_slot, const float* const* packed, const float* bias_sum,
+                            int C, const int* k, float out_div, int post, float act_slope) {
+    if (!plan || !x_slots || !res_slots || !tmp_slots || !packed || !k)
+        return fail(FV_ERR_INVALID_ARG, "plan_add_conv1d_sum3: null");
+    for (int j = 0; j < 2; ++j)
+        if (int rc = check_slot(tmp_slots[j], false)) return rc;
+    for (int j = 0; j < 3; ++j) {
+        if (!packed[j] || k[j] < 1 || k[j] % 2 == 0)
+            return fail(FV_ERR_INVALID_ARG, "plan_add_conv1d_sum3: member %d needs packed weights and an odd tap count", j);
+        if (int rc = check_slot(x_slots[j], false)) return rc;
+        if (int rc = check_slot(res_slots[j], false)) return rc;
+    }
+    if (int rc = fv_plan_add_conv1d(plan, x_slots[0], y_slot, y_act_slot, res_slots[0], FV_SLOT_NONE, FV_SLOT_NONE,
+                                    packed[0], bias_sum, C, C, k[0], 1, (k[0] - 1) / 2, FV_PAD_ZERO, 1.f, out_div,
+                                    post, act_slope))
+        return rc;
+    Op& o = plan->ops.back();
+    o.sum3 = true;
+    o.group = 0;
+    o.xb = x_slots[1];
+    o.xc = x_slots[2];
+    o.resb = res_slots[1];
+    o.resc = res_slots[2];
+    o.wpb = packed[1];
+    o.wpc = packed[2];
+    o.kb = k[1];
+    o.kc = k[2];
+    o.tmpb = tmp_slots[0];
+    o.tmpc = tmp_slots[1];
+    return 0;
+}
+
 int fv_plan_add_conv1d_2src(fv_plan_t* plan, int x_slot, int x2_slot, int y_slot, int y_act_slot,
                             int res_slot, const float* packed, const float* bias, int Cin1, int Cin2,
                             int Cout, int post, float act_slope) {
@@ -904,6 +964,50 @@ int fv_plan_run(fv_plan_t* plan, int B, int T, const float* in, float* out, void
                 if (qo.y2 != FV_SLOT_NONE) sh[qo.y2] = sh[qo.y];
             }
             n = m - 1;
+            continue;
+        }
+        if (o.sum3) {
+            hipStream_t s3 = lanes[o.lane];
+            if (multi)
+                for (int d = 0; d < o.ndeps; ++d) FV_HIP(hipStreamWaitEvent(s3, plan->op_event[o.deps[d]], 0));
+            Op mb = o, mc = o;           // members 1, 2: same layer geometry, their own taps / weights
+            mb.k = o.kb; mb.pad = (o.kb - 1) / 2; mb.wp = o.wpb; mb.bias = nullptr;
+            mc.k = o.kc; mc.pad = (o.kc - 1) / 2; mc.wp = o.wpc; mc.bias = nullptr;
+            float* y2s = o.y2 == FV_SLOT_NONE ? nullptr : base[o.y2];
+            // One launch pays when the three K loops in a row still leave enough blocks to fill the
+            // GPU (tiles of 32 x 128, or 16 x 128); otherwise the two-launch form: members 1, 2 as a
+            // grouped launch into scratch, then member 0 with both as running-sum inputs.
+            const int64_t T3 = sh[o.x].T;
+            const int Mp = pad_rows(o.Cout);
+            const int64_t blocks = (int64_t)(Mp == 16 ? 1 : Mp / 32) * ((T3 + 127) / 128);
+            const int min_blocks = getenv("FV_SUM3_MIN") ? atoi(getenv("FV_SUM3_MIN")) : 800;   // measured: HiFi-GAN light, B = 1
+            int rc3;
+            if (blocks >= min_blocks && o.Cout > 4) {
+                ConvParams ps[3] = {
+                    make_params(o, base[o.x], base[o.y], y2s, base[o.res], nullptr, nullptr, B, T3),
+                    make_params(mb, base[o.xb], base[o.y], y2s, base[o.resb], nullptr, nullptr, B, T3),
+                    make_params(mc, base[o.xc], base[o.y], y2s, base[o.resc], nullptr, nullptr, B, T3)};
+                rc3 = launch_conv_sum3(ps, s3);
+            } else {
+                Op duo_b = mb, duo_c = mc;                 // r_b, r_c: conv + residual, raw, no mean / activation
+                duo_b.out_div = duo_c.out_div = 1.f;
+                duo_b.act_slope = duo_c.act_slope = 1.f;
+                duo_b.post = duo_c.post = FV_POST_NONE;
+                ConvParams duo[2] = {
+                    make_params(duo_b, base[o.xb], base[o.tmpb], nullptr, base[o.resb], nullptr, nullptr, B, T3),
+                    make_params(duo_c, base[o.xc], base[o.tmpc], nullptr, base[o.resc], nullptr, nullptr, B, T3)};
+                rc3 = launch_conv_group(duo, 2, s3);
+                if (!rc3) {
+                    Op car = o;                            // ((own + r_b) + r_c) / out_div, summed bias on this one
+                    car.own_first = 1;
+                    rc3 = launch_conv(make_params(car, base[o.x], base[o.y], y2s, base[o.res], base[o.tmpb],
+                                                  base[o.tmpc], B, T3), s3);
+                }
+            }
+            if (rc3) return rc3;
+            if (multi && o.signal) FV_HIP(hipEventRecord(plan->op_event[n], s3));
+            sh[o.y] = {o.Cout, conv_out_len(o, sh[o.x].T), true};
+            if (o.y2 != FV_SLOT_NONE) sh[o.y2] = sh[o.y];
             continue;
         }
         const int64_t Tin = sh[o.x].T;

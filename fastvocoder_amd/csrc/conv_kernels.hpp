@@ -730,6 +730,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
 #ifndef FV_MIN_WAVES
 #define FV_MIN_WAVES 4
 #endif
+#define FV_SUM3_WAVES __attribute__((amdgpu_waves_per_eu(FV_MIN_WAVES)))
 #define FV_WAVES_ATTR \
     __attribute__((amdgpu_waves_per_eu((MF == 32 && NR == 2) ? 2 : ((WK > 1 && FV_MIN_WAVES > 3) ? 3 : FV_MIN_WAVES))))
 
@@ -751,6 +752,195 @@ __global__ __launch_bounds__(64 * WM * WN * WK) FV_WAVES_ATTR void conv_group3_k
     if (g == 0) conv_body<MF, WM, WN, WK, NR, 11, DIL, false, false>(gp.p[0], blockIdx.x, gp.grid_x[0], blockIdx.y);
     else if (g == 1) conv_body<MF, WM, WN, WK, NR, 7, DIL, false, false>(gp.p[1], blockIdx.x, gp.grid_x[1], blockIdx.y);
     else conv_body<MF, WM, WN, WK, NR, 3, DIL, false, false>(gp.p[2], blockIdx.x, gp.grid_x[2], blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------
+// MRF merge in one launch: the LAST convs of the three ResBlocks of a stage (11 / 7 / 3 taps,
+// undilated, modules.py:226-229) all add into the same output tile,
+//     y = act( ( sum_j ( conv_j(mid_j) + b_j + cur_j ) ) / 3 )            (hifigan.py:97-103)
+// so one block runs the three K loops back to back into ONE accumulator and stores once:
+// no r_1 / r_2 tensors (4 of the 11 tensor passes of the separate form) and no third launch.
+// The sum is then formed inside the fp32 accumulator instead of as ((r0 + r1) + r2): same
+// value up to fp32 rounding of the additions (<= 2e-7 relative; FV_MRF_FINAL=carrier keeps
+// the reference's association exactly).  Stages of the three members form one linear DMA
+// pipeline (two LDS buffers, one stage ahead, across member boundaries); the staging is the
+// SLOW-capable one, so unaligned sequence lengths need no other variant.
+// sp.p[0] carries y / y_act / out_div / act_slope / post and the SUMMED bias; p[j].res are
+// the three residual inputs.
+// ---------------------------------------------------------------------------
+template <int MF, int KT, int NR>
+__device__ __forceinline__ void sum3_mma(const float* wsA, const float* xsB, int cend, int xw,
+                                         typename Frag<MF>::acc_t (&acc)[NR]) {
+    typedef Frag<MF> F;
+    constexpr int M_T = MF;   // WM == 1 in the shapes this kernel is built for
+    for (int c = 0; c < cend; c += F::KS) {
+        const float* pa = wsA + c * (KT * M_T);
+        const float* pb = xsB + c * xw;
+#pragma unroll
+        for (int tap = 0; tap < KT; ++tap) {
+            const float a = pa[tap * M_T];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc[r] = F::mfma(a, pb[tap + r * MF], acc[r]);
+        }
+    }
+}
+
+template <int MF, int WN, int NR>
+__global__ __launch_bounds__(64 * WN) FV_SUM3_WAVES void conv_sum3_kernel(Sum3Params sp) {
+    typedef Frag<MF> F;
+    typedef typename F::acc_t acc_t;
+    constexpr int NW = WN, NT = 64 * NW, M_T = MF, N_T = MF * NR * WN;
+    constexpr int EN = F::REGS < 8 ? F::REGS : 8, EH = F::REGS / EN;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const ConvParams& p0 = sp.p[0];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & (MF - 1), kq = lane / MF;
+    const int wave_n = wave;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = lin % p0.m_tiles, run = lin / p0.m_tiles;
+    const int tile_lo = run * p0.tiles_per_run;
+    const int tile_hi = min(tile_lo + p0.tiles_per_run, p0.n_tiles);
+    const int m0 = mt * M_T;
+    if (tile_hi <= tile_lo) return;
+    float* const xs0 = smem;
+    float* const ws0 = smem + 2 * sp.xbuf_max;
+
+    // epilogue addressing (all three members write the same rows)
+    const bool affine = m0 + M_T <= p0.M;
+    const int mlane = m0 + F::row(0, lane);
+    RowInfo<EN> ri[EH];
+    if (affine) {
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(p0.bias ? p0.bias : p0.wp, p0.bias ? (unsigned)p0.Cout * 4u : 0u);
+#pragma unroll
+        for (int h = 0; h < EH; ++h) {
+            ri[h].short_mask = 0u;
+#pragma unroll
+            for (int i = 0; i < EN; ++i) {
+                ri[h].off[i] = 0u;
+                ri[h].bias[i] = buffer_load1s(rb, (unsigned)mlane * 4u, (unsigned)F::row(h * EN + i, 0) * 4u);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int h = 0; h < EH; ++h) {
+            int mm[EN];
+#pragma unroll
+            for (int i = 0; i < EN; ++i) mm[i] = m0 + F::row(h * EN + i, lane);
+            row_info<EN>(p0, mm, ri[h]);
+        }
+    }
+
+    const int total = sp.p[0].nchunks + sp.p[1].nchunks + sp.p[2].nchunks;   // stages per tile
+    DmaPlan dp;
+    __amdgpu_buffer_rsrc_t rx = make_rsrc(p0.x, 0u), rw = make_rsrc(p0.wp, 0u);
+    const float* xb = p0.x;
+    int im = 0, ic = 0, ibuf = 0;   // next stage to issue: member, chunk, LDS buffer
+    auto issue = [&](int tile) {
+        const ConvParams& q = sp.p[im];
+        if (ic == 0) {   // entering a member: its DMA offsets and descriptors
+            dma_plan<NW, M_T>(q, dp, m0, wave, lane);
+            xb = q.x + (size_t)b * q.Cin * (size_t)q.Tin;
+            rx = make_rsrc(xb, (unsigned)q.Cin * (unsigned)q.Tin * 4u);
+            rw = make_rsrc(q.wp, (unsigned)q.Cin * (unsigned)q.k * (unsigned)q.Mpad * 4u);
+        }
+        const int aoff = (((-q.pad) % 4) + 4) % 4;
+        const int tA = tile * N_T - q.pad - aoff;
+        stage_x<NW, NT, true>(q, dp, rx, xs0 + ibuf * sp.xbuf_max, xb, q.Cin, ic * q.ci_chunk, tA, wave, lane, tid);
+        dma_w<NW, M_T>(q, dp, rw, ws0 + ibuf * sp.wbuf_max, ic * q.ci_chunk, wave);
+        if (++ic == q.nchunks) {
+            ic = 0;
+            if (++im == 3) im = 0;
+        }
+        ibuf ^= 1;
+    };
+
+    int cur = 0;
+    bool landed = false;
+    issue(tile_lo);
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+        acc_t acc[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int i = 0; i < F::REGS; ++i) acc[r][i] = 0.f;
+        int cm = 0, cc = 0;
+        for (int s = 0; s < total; ++s) {
+            if (!landed) wait_vmcnt(0);   // stage s landed (own wave); the barrier: everyone's, and buffer cur^1 is free
+            landed = false;
+            __syncthreads();
+            const bool more = s + 1 < total || tile + 1 < tile_hi;
+            if (more) issue(s + 1 < total ? tile : tile + 1);
+            const ConvParams& q = sp.p[cm];
+            const int aoff = (((-q.pad) % 4) + 4) % 4;
+            const float* wsA = ws0 + cur * sp.wbuf_max + lm + kq * (q.k * M_T);
+            const float* xsB = xs0 + cur * sp.xbuf_max + aoff + wave_n * (MF * NR) + lm + kq * q.xw;
+            if (cm == 0) sum3_mma<MF, 11, NR>(wsA, xsB, q.ci_chunk, q.xw, acc);
+            else if (cm == 1) sum3_mma<MF, 7, NR>(wsA, xsB, q.ci_chunk, q.xw, acc);
+            else sum3_mma<MF, 3, NR>(wsA, xsB, q.ci_chunk, q.xw, acc);
+            if (++cc == q.nchunks) {
+                cc = 0;
+                ++cm;
+            }
+            cur ^= 1;
+        }
+        // ---- epilogue: + the other two residuals, then the standard fused one on p[0] ----
+        if (tile + 1 < tile_hi) {   // next tile's first stage before any store (see conv_body)
+            wait_vmcnt(0);
+            landed = true;
+        }
+        const EpilogueRsrc ersrc = epilogue_rsrc(p0, b);
+        const size_t boff = (size_t)b * p0.Cout * (size_t)p0.Tout;
+        const unsigned bytes = (unsigned)p0.Cout * (unsigned)p0.Tout * 4u;
+        const __amdgpu_buffer_rsrc_t r1 = make_rsrc(sp.p[1].res + boff, bytes), r2 = make_rsrc(sp.p[2].res + boff, bytes);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int q = tile * N_T + wave_n * (MF * NR) + r * MF + lm;
+#pragma unroll
+            for (int h = 0; h < EH; ++h) {
+                float vv[EN];
+                unsigned off[EN], so[EN];
+#pragma unroll
+                for (int i = 0; i < EN; ++i) vv[i] = acc[r][h * EN + i];
+                if (affine) {
+                    const unsigned t4 = (unsigned)opaque_uniform(p0.Tout) * 4u;
+                    const unsigned voff = q < p0.Tq ? (unsigned)(mlane * p0.Tout + q) * 4u : kOutOfRange;
+#pragma unroll
+                    for (int i = 0; i < EN; ++i) {
+                        off[i] = voff;
+                        so[i] = (unsigned)F::row(h * EN + i, 0) * t4;
+                    }
+                } else {
+                    int mm[EN];
+#pragma unroll
+                    for (int i = 0; i < EN; ++i) mm[i] = m0 + F::row(h * EN + i, lane);
+                    epilogue_offsets<EN>(p0, ri[h], mm, q, off);
+#pragma unroll
+                    for (int i = 0; i < EN; ++i) so[i] = 0u;
+                }
+                float e1[EN], e2[EN];
+#pragma unroll
+                for (int i = 0; i < EN; ++i) e1[i] = buffer_load1s(r1, off[i], so[i]);
+#pragma unroll
+                for (int i = 0; i < EN; ++i) e2[i] = buffer_load1s(r2, off[i], so[i]);
+#pragma unroll
+                for (int i = 0; i < EN; ++i) vv[i] += e1[i] + e2[i];
+                epilogue_finish<EN>(p0, ersrc, ri[h].bias, off, so, vv);
+            }
+        }
+    }
+}
+
+template <int MF, int WN, int NR>
+int launch_sum3_geom(const Sum3Params& sp, size_t lds, int grid_x, hipStream_t s) {
+    auto kern = conv_sum3_kernel<MF, WN, NR>;
+    if (lds > 64 * 1024)
+        FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid_x, sp.p[0].B), dim3(64 * WN), lds, s, sp);
+    FV_HIP(hipGetLastError());
+    return 0;
 }
 
 // ---------------------------------------------------------------------------

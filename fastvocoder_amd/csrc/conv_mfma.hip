@@ -12,6 +12,10 @@ int launch_geom(const ConvParams& p, size_t lds, int grid_x, hipStream_t s);
 template <int MF, int WM, int WN, int WK, int NR>
 int launch_group_geom(const GroupParams& gp, size_t lds, int grid_x, int B, int dil, hipStream_t s);
 int launch_narrow(const ConvParams& p, size_t lds, int grid_x, hipStream_t s);
+template <int MF, int WN, int NR>
+int launch_sum3_geom(const Sum3Params& sp, size_t lds, int grid_x, hipStream_t s);
+extern template int launch_sum3_geom<32, 4, 1>(const Sum3Params&, size_t, int, hipStream_t);
+extern template int launch_sum3_geom<16, 4, 2>(const Sum3Params&, size_t, int, hipStream_t);
 #define FV_SHAPE_DECL(MF, WM, WN, WK, NR)                                                            \
     extern template int launch_geom<MF, WM, WN, WK, NR>(const ConvParams&, size_t, int, hipStream_t); \
     extern template int launch_group_geom<MF, WM, WN, WK, NR>(const GroupParams&, size_t, int, int, int, hipStream_t);
@@ -125,7 +129,7 @@ struct LaunchInfo {
 };
 
 // Validate one conv, pick its tile shape and fill in the staging geometry.
-int prepare_conv(ConvParams& p, LaunchInfo& li, int members = 1) {
+int prepare_conv(ConvParams& p, LaunchInfo& li, int members = 1, int force_shape = -1) {
     if (p.k < 1 || p.dil < 1) return fail(FV_ERR_INVALID_ARG, "conv: k=%d dil=%d", p.k, p.dil);
     if (p.pad_mode == FV_PAD_REFLECT && p.pad >= p.Tin)
         return fail(FV_ERR_INVALID_ARG, "reflection pad %d needs an input longer than it (T=%d)",
@@ -192,7 +196,8 @@ int prepare_conv(ConvParams& p, LaunchInfo& li, int members = 1) {
     else shape = 4;
     // a phase-major transposed conv needs row tiles that hold one phase: m_t must divide Cout
     if (p.phase_major && p.Cout % kShapes[shape].m_t() != 0) shape = units(3) * members >= 400 ? 3 : 4;
-    const int force = env_int(m16 ? "FV_SHAPE16" : (m64 ? "FV_SHAPE64" : "FV_SHAPE32"), -1);
+    int force = env_int(m16 ? "FV_SHAPE16" : (m64 ? "FV_SHAPE64" : "FV_SHAPE32"), -1);
+    if (force_shape >= 0) force = force_shape;
     if (force >= 0 && force < kNumShapes && kShapes[force].mf == (m16 ? 16 : 32) &&
         p.Mpad % kShapes[force].m_t() == 0 && !(p.phase_major && p.Cout % kShapes[force].m_t() != 0))
         shape = force;
@@ -228,6 +233,53 @@ int launch_conv(ConvParams p, hipStream_t s) {
         rc = launch_shape(li.shape, p, li.lds, li.grid_x, s);
     }
     profile_end(s, li.kind, li.flops, li.bytes);
+    return rc;
+}
+
+// The three last convs of an MRF stage summed in one accumulator (conv_sum3_kernel).
+int launch_conv_sum3(ConvParams* ps, hipStream_t s) {
+    int order[3] = {0, 1, 2};
+    for (int i = 0; i < 3; ++i)       // sort by taps, largest first
+        for (int j = i + 1; j < 3; ++j)
+            if (ps[order[j]].k > ps[order[i]].k) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+    Sum3Params sp;
+    LaunchInfo li[3];
+    const bool m16 = pad_rows(ps[0].M) == 16;
+    for (int i = 0; i < 3; ++i) {
+        ConvParams& q = ps[order[i]];
+        const ConvParams& a = ps[order[0]];
+        static const int want_k[3] = {11, 7, 3};
+        if (q.k != want_k[i] || q.dil != 1 || q.ups != 1 || q.pad != (q.k - 1) / 2 || q.pad_mode != FV_PAD_ZERO ||
+            q.pre_slope != 1.f || q.x2 || !q.res || q.Cin != a.Cin || q.M != a.M || q.Tin != a.Tin || q.B != a.B ||
+            q.M <= 4 || (!m16 && pad_rows(q.M) % 32 != 0))
+            return fail(FV_ERR_UNSUPPORTED, "conv_sum3: needs the 11/7/3-tap undilated same-shape trio with residuals "
+                        "(member %d: k=%d dil=%d pad=%d Cin=%d Cout=%d)", i, q.k, q.dil, q.pad, q.Cin, q.M);
+        const int want_shape = m16 ? 0 : 2;   // 16 x 128 / 32 x 128 (32 x 64 two-wave tiles were measured slower)
+        if (int rc = prepare_conv(q, li[i], 3, want_shape)) return rc;
+        if (li[i].narrow || li[i].shape != want_shape) return fail(FV_ERR_UNSUPPORTED, "conv_sum3: tile shape");
+        sp.p[i] = q;
+    }
+    {   // the summed bias rides on whichever member the caller attached it to: move it to p[0]
+        const float* bias = nullptr;
+        for (int i = 0; i < 3; ++i)
+            if (sp.p[i].bias) bias = sp.p[i].bias;
+        for (int i = 0; i < 3; ++i) sp.p[i].bias = i == 0 ? bias : nullptr;
+    }
+    sp.xbuf_max = sp.wbuf_max = 0;
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (sp.p[i].xbuf > sp.xbuf_max) sp.xbuf_max = sp.p[i].xbuf;
+        if (sp.p[i].wbuf > sp.wbuf_max) sp.wbuf_max = sp.p[i].wbuf;
+        flops += li[i].flops;
+        bytes += li[i].bytes;
+    }
+    // the three members stored no outputs of their own: only ONE output (+ twin) is written
+    bytes -= 2.0 * 4.0 * sp.p[0].B * (double)sp.p[0].Cout * sp.p[0].Tout * (sp.p[0].y_act ? 2 : 1);
+    const size_t lds = (size_t)2 * (sp.xbuf_max + sp.wbuf_max) * 4;
+    profile_begin(s);
+    const int rc = m16 ? launch_sum3_geom<16, 4, 2>(sp, lds, li[0].grid_x, s)
+                       : launch_sum3_geom<32, 4, 1>(sp, lds, li[0].grid_x, s);
+    profile_end(s, li[0].kind, flops, bytes);
     return rc;
 }
 

@@ -113,6 +113,14 @@ struct GroupParams {
     int grid_x[3];
 };
 
+// The last convs of the three ResBlocks of an MRF stage, summed in one accumulator
+// (conv_sum3_kernel): p sorted k = 11, 7, 3; p[0] carries the output side and the summed bias.
+struct Sum3Params {
+    ConvParams p[3];
+    int xbuf_max, wbuf_max;   // floats per LDS stage buffer (largest member)
+};
+int launch_conv_sum3(ConvParams* ps, hipStream_t stream);
+
 // Shared between the host launcher (conv_mfma.hip) and the kernels (conv_kernels.hpp):
 #ifndef FV_RING
 #define FV_RING 2          // stage buffers of the LDS-DMA ring in the plain (aligned, zero-padded) kernels.

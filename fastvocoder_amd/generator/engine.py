@@ -118,6 +118,24 @@ class PlanBuilder:
                              cin1=conv_a.in_channels, cin2=conv_b.in_channels, cout=conv_a.out_channels,
                              post=post))
 
+    def conv_sum3(self, convs, srcs, ress, tmps, dst, pre_slope=1.0, out_div=1.0, post=POST_NONE):
+        """dst = post((sum_j conv_j(act(src_j)) + bias_j + res_j) / out_div) for the three last
+        convs of an MRF stage in ONE launch (fv_plan_add_conv1d_sum3).  The kernel applies no
+        input activation: ``pre_slope`` must be absorbed by the producers (checked in finalize)."""
+        c0 = convs[0]
+        for c in convs:
+            if (c.stride[0] != 1 or c.groups != 1 or c.dilation[0] != 1 or c.in_channels != c0.in_channels
+                    or c.out_channels != c0.in_channels or c.padding[0] != (c.kernel_size[0] - 1) // 2):
+                raise _native.NativeError("conv_sum3: three undilated 'same' C->C convs are required")
+        biases = [self._bias(c) for c in convs]
+        bias = None if all(b is None for b in biases) else sum(b for b in biases if b is not None).contiguous()
+        self.ops.append(dict(kind="sum3", lane=self.lane, x=srcs[0], xb=srcs[1], xc=srcs[2], y=dst,
+                             res=ress[0], resb=ress[1], resc=ress[2], tmps=list(tmps), acc=SLOT_NONE,
+                             pre_slope=float(pre_slope),
+                             packed=[_native.pack_conv1d(effective_weight(c)) for c in convs], bias=bias,
+                             channels=c0.in_channels, ks=[c.kernel_size[0] for c in convs],
+                             out_div=float(out_div), post=post))
+
     def conv_transpose(self, convt, src, dst, pre_slope=1.0, post=POST_NONE):
         """Record a torch.nn.ConvTranspose1d container (polyphase form)."""
         if convt.groups != 1 or convt.dilation[0] != 1:
@@ -171,15 +189,16 @@ class PlanBuilder:
             act_uses, raw_needed = {}, y == SLOT_OUT
             for j in range(i + 1, len(ops)):
                 c = ops[j]
-                if c["x"] == y:
-                    if c["pre_slope"] != 1.0:
-                        act_uses.setdefault(c["pre_slope"], []).append(j)
-                    else:
-                        raw_needed = True
-                if c["res"] == y or c["acc"] == y or c.get("acc2", SLOT_NONE) == y or \
-                        c.get("x2", SLOT_NONE) == y:
+                for key in ("x", "xb", "xc"):           # activated inputs (sum3 has three)
+                    if c.get(key, SLOT_NONE) == y:
+                        if c["pre_slope"] != 1.0:
+                            act_uses.setdefault(c["pre_slope"], []).append((j, key))
+                        else:
+                            raw_needed = True
+                if y in (c["res"], c["acc"], c.get("acc2", SLOT_NONE), c.get("x2", SLOT_NONE),
+                         c.get("resb", SLOT_NONE), c.get("resc", SLOT_NONE)):
                     raw_needed = True
-                if c["y"] == y or c.get("y_act") == y:
+                if c["y"] == y or c.get("y_act") == y or y in c.get("tmps", ()):
                     break
             if not act_uses:
                 continue
@@ -192,8 +211,13 @@ class PlanBuilder:
                 op["y_act"], op["act_slope"], target = twin_of[y], slope, twin_of[y]
             else:
                 op["act_slope"], target = slope, y
-            for j in act_uses[slope]:
-                ops[j]["x"], ops[j]["pre_slope"] = target, 1.0
+            for j, key in act_uses[slope]:
+                ops[j][key] = target
+                ops[j].setdefault("_hoisted", set()).add(key)
+        for op in ops:      # an op's read-time activation is off once ALL its activated inputs are hoisted
+            keys = [k for k in ("x", "xb", "xc") if op.get(k, SLOT_NONE) != SLOT_NONE]
+            if op.get("_hoisted") and set(keys) <= op["_hoisted"]:
+                op["pre_slope"] = 1.0
 
     # -- receptive field (for time-chunked runs) -------------------------------
     def receptive_halo(self):
@@ -208,6 +232,8 @@ class PlanBuilder:
             if op["kind"] == "conv":
                 reach = op["dil"] * (op["k"] - 1)
                 own, rate = max(op["pad"], reach - op["pad"]), 1
+            elif op["kind"] == "sum3":
+                own, rate = max(op["ks"]) // 2, 1
             elif op["kind"] == "conv2":
                 own, rate = 0, 1
             elif op["kind"] == "convT":
@@ -218,7 +244,11 @@ class PlanBuilder:
                 S, ntaps = op["h"].shape
                 own, rate = -(-(ntaps // 2) // S) + 1, S
             need[op["x"]] = max(need.get(op["x"], 0), -(-h_out // rate) + own)
-            for aux in (op["res"], op["acc"], op.get("acc2", SLOT_NONE), op.get("x2", SLOT_NONE)):
+            for key in ("xb", "xc"):
+                if op.get(key, SLOT_NONE) != SLOT_NONE:
+                    need[op[key]] = max(need.get(op[key], 0), -(-h_out // rate) + own)
+            for aux in (op["res"], op["acc"], op.get("acc2", SLOT_NONE), op.get("x2", SLOT_NONE),
+                        op.get("resb", SLOT_NONE), op.get("resc", SLOT_NONE)):
                 if aux != SLOT_NONE:
                     need[aux] = max(need.get(aux, 0), h_out)
         return need.get(SLOT_IN, 0)
@@ -237,6 +267,13 @@ class PlanBuilder:
                                      pre_slope=op["pre_slope"], res=op["res"], acc=op["acc"],
                                      out_div=op["out_div"], post=op["post"], y_act=op["y_act"],
                                      act_slope=op["act_slope"], acc2=op.get("acc2", SLOT_NONE))
+            elif op["kind"] == "sum3":
+                if op["pre_slope"] != 1.0:
+                    raise _native.NativeError("conv_sum3: the activation of its inputs could not be hoisted")
+                self.plan.add_conv1d_sum3([op["x"], op["xb"], op["xc"]], [op["res"], op["resb"], op["resc"]],
+                                          op["tmps"], op["y"], op["packed"], op["bias"], op["channels"], op["ks"],
+                                          out_div=op["out_div"], post=op["post"], y_act=op["y_act"],
+                                          act_slope=op["act_slope"])
             elif op["kind"] == "conv2":
                 if op["pre_slope"] != 1.0:
                     raise _native.NativeError("conv_sum_1x1: the activation of the first input could not "

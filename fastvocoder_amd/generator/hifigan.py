@@ -92,6 +92,22 @@ class _HiFiGANBase(NativeModule):
                 states = [dict() for _ in range(nk)]
                 # which block's final conv carries the sum: the first (cheapest; the others' final
                 # convs then share a launch) or, FV_MRF_CARRIER=last, the last
+                # FV_MRF_FINAL=sum3 (default): the three last convs accumulate into one output tile in
+                # ONE launch (no r_1 / r_2 tensors; the sum is formed inside the fp32 accumulator);
+                # =carrier: the reference's association, bit for bit, in two launches (below)
+                sum3 = (os.environ.get("FV_MRF_FINAL", "sum3") == "sum3" and nk == 3 and mode == "group"
+                        and all(isinstance(b, ResBlock1) for b in blocks)
+                        and sorted(b.convs2[-1].kernel_size[0] for b in blocks) == [3, 7, 11])
+                if sum3:
+                    for st in range(steps - 1):
+                        pb.begin_group()
+                        for j in range(nk):
+                            blocks[j].emit_step(pb, st, states[j], up, x, scratch[j])
+                        pb.end_group()
+                    convs, srcs, ress = zip(*[blocks[j].last_conv_inputs(states[j], up, scratch[j])
+                                              for j in range(nk)])
+                    pb.conv_sum3(convs, srcs, ress, parts[:2], x, pre_slope=LRELU_SLOPE, out_div=float(nk))
+                    continue
                 carrier = nk - 1 if os.environ.get("FV_MRF_CARRIER", "first") == "last" else 0
                 others = [j for j in range(nk) if j != carrier]
                 for st in range(steps):

@@ -89,6 +89,12 @@ class ResBlock1(_Block):
                 out_div=out_div if last else 1.0, own_first=own_first and last)
         state["cur"] = nxt
 
+    def last_conv_inputs(self, state, src, scratch):
+        """(conv, input slot, residual slot) of the block's last conv, for a caller that merges
+        the last convs of several blocks itself (PlanBuilder.conv_sum3); valid after every
+        earlier step has been emitted."""
+        return self.convs2[-1], scratch[0], state.get("cur", src)
+
     def emit(self, pb, src, dst, scratch, acc=SLOT_NONE, out_div=1.0):
         """src -> dst through the pairs; the LAST conv's epilogue also carries the
         caller's running MRF sum (``acc``) and mean (``out_div``)."""

@@ -223,6 +223,23 @@ int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot, int y_
 int fv_plan_add_conv1d_2src(fv_plan_t* plan, int x_slot, int x2_slot, int y_slot, int y_act_slot,
                             int res_slot, const float* packed, const float* bias, int Cin1,
                             int Cin2, int Cout, int post, float act_slope);
+/*
+ * y = act( ( sum_{j<3} ( conv1d(x_j; w_j, k_j taps, 'same' zero padding) + res_j ) + bias_sum ) / out_div )
+ *
+ * The MRF merge of a HiFi-GAN stage (hifigan.py:97-103 with modules.py:226-229): the last convs of
+ * the three ResBlocks (taps 11 / 7 / 3 in any order, undilated, C -> C) accumulate into one
+ * output tile in ONE launch; bias_sum = b_0 + b_1 + b_2.  The three partial results are summed
+ * inside the fp32 accumulator rather than as ((r0 + r1) + r2): equal up to fp32 rounding of
+ * the additions (the conv1d ops with acc / acc2 keep the reference's association exactly).
+ * x_slots / res_slots / packed / k: arrays of 3.  When the layer has too few tiles for one launch
+ * to fill the GPU (utterance-length dependent, never batch dependent) the op runs as two launches
+ * instead -- members 1 and 2 into the two [B,C,T] scratch slots tmp_slots[0..1], then member 0
+ * with both as running-sum inputs; same sum.
+ */
+int fv_plan_add_conv1d_sum3(fv_plan_t* plan, const int* x_slots, const int* res_slots,
+                            const int* tmp_slots, int y_slot, int y_act_slot,
+                            const float* const* packed, const float* bias_sum, int C, const int* k,
+                            float out_div, int post, float act_slope);
 int fv_plan_add_upsample_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot,
                                 const float* packed, const float* bias, int Cin, int Cout,
                                 int k, int rate, int pad, float pre_slope, int post,

@@ -359,7 +359,23 @@ def test_concurrency_lanes_do_not_change_results(monkeypatch):
     assert torch.equal(a, b) and torch.equal(a, c)
 
 
-@pytest.mark.parametrize("mrf,carrier", [("group", "last"), ("lanes", "first"), ("chain", "first")])
+@pytest.mark.parametrize("tag", ["hifigan_s", "mb_s", "hifigan_up"])
+def test_mrf_sum3_kernel_forced_on_small_configs(monkeypatch, golden_dir, tag):
+    """fv_plan_add_conv1d_sum3 picks its one-launch kernel only for layers with >= 800 tiles; forcing
+    it (FV_SUM3_MIN=1) on the shrunken configs -- 64/32/16/8-channel stages, ragged row tiles,
+    unaligned lengths -- must still match the reference goldens; channel counts <= 4 keep the
+    two-launch form."""
+    monkeypatch.setenv("FV_SUM3_MIN", "1")
+    name, cfg = next((n, c) for t, n, c in cases.SMALL if t == tag)
+    g = np.load(os.path.join(golden_dir, f"small_{tag}.npz"))
+    m, sd = _model(name, cfg, seed=7)
+    y = m.inference(seeded_mel(cases.SMALL_T, seed=5))
+    assert _err(y, g["inference"]) <= TOL
+    f = m(torch.from_numpy(seeded_mel(cases.SMALL_T, seed=6, batch=cases.SMALL_B)).to(_dev()))
+    assert _err(f, g["forward"]) <= TOL
+
+
+@pytest.mark.parametrize("mrf,carrier", [("group", "last"), ("group", "first"), ("lanes", "first"), ("chain", "first")])
 def test_mrf_schedules_agree(monkeypatch, mrf, carrier):
     """The MRF stage can be scheduled as grouped launches with the first block's conv carrying
     the sum (default), with the last block's, on three streams, or as the plain sequential
@@ -372,6 +388,7 @@ def test_mrf_schedules_agree(monkeypatch, mrf, carrier):
         ref = ref_model(x).cpu().numpy()
     monkeypatch.setenv("FV_MRF", mrf)
     monkeypatch.setenv("FV_MRF_CARRIER", carrier)
+    monkeypatch.setenv("FV_MRF_FINAL", "carrier")       # the reference run above used the default (sum3)
     m, _ = _model("hifigan", cfg, seed=0)
     with torch.no_grad():
         got = m(x).cpu().numpy()
