@@ -214,9 +214,10 @@ def main():
             traffic_src = "profiles/" + cand
             break
         roofline = {
-            "kernel": "fv::conv_mfma_kernel / fv::conv_group3_kernel (fp32-MFMA implicit-GEMM conv1d body "
-                      "conv_body<...>: every Conv1d / ConvTranspose1d layer with Cout > 4 = 77 of the 78 "
-                      "convs of a forward; the 3 ResBlock convs of an MRF position share one launch)",
+            "kernel": "fv::conv_mfma_kernel / fv::conv_group3_kernel / fv::conv_sum3_kernel (fp32-MFMA "
+                      "implicit-GEMM conv1d, csrc/conv_kernels.hpp: every Conv1d / ConvTranspose1d layer with "
+                      "Cout > 4 = 77 of the 78 convs of a forward; the 3 ResBlock convs of an MRF position "
+                      "share one launch)",
             "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (PMC, offline pass)", "traffic_source": traffic_src,

@@ -35,7 +35,7 @@ def main():
         fb = 2.0 * fetch[k] / nf[k] * 1024
         wb = write[k] / nw[k] * 1024
         out["kernels"][k] = {"launches": nf[k], "fetch_bytes_corrected": fb, "write_bytes": wb, "hbm_bytes": fb + wb}
-        if "conv_mfma_kernel" in k or "conv_group3_kernel" in k:
+        if "conv_mfma_kernel" in k or "conv_group3_kernel" in k or "conv_sum3_kernel" in k:
             fam_bytes += (fb + wb) * nf[k]
             fam_n += nf[k]
     out["conv_mfma_family"] = {"launches": fam_n, "hbm_bytes_per_launch": fam_bytes / max(fam_n, 1)}

@@ -32,13 +32,13 @@ with open(f"{dst}/{tag}_mfma_counters.txt", "w") as f:
         f.write(k + "\n")
         for name in sorted(d):
             f.write(f"    {name:28s} {d[name] / c[name]:16.0f}   (n={c[name]})\n")
-        if ("conv_mfma_kernel" in k or "conv_group3_kernel" in k) and d.get("GRBM_GUI_ACTIVE"):
+        if ("conv_mfma_kernel" in k or "conv_group3_kernel" in k or "conv_sum3_kernel" in k) and d.get("GRBM_GUI_ACTIVE"):
             f.write(f"    MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs) = "
                     f"{d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f};  "
                     f"VALU instructions per MFMA = {d['SQ_INSTS_VALU'] / max(d['SQ_INSTS_MFMA'], 1):.2f}\n")
             for name in d:
                 fam[name] += d[name]
-    f.write("conv family (conv_mfma_kernel + conv_group3_kernel), all launches:\n")
+    f.write("conv family (conv_mfma_kernel + conv_group3_kernel + conv_sum3_kernel), all launches:\n")
     f.write(f"    MFMA-busy fraction of SIMD cycles = {fam['SQ_VALU_MFMA_BUSY_CYCLES'] / (fam['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f}\n")
     f.write(f"    VALU instructions per MFMA (incl. the MFMA itself) = {fam['SQ_INSTS_VALU'] / fam['SQ_INSTS_MFMA']:.2f}\n")
     f.write(f"    SQ_LDS_BANK_CONFLICT total = {fam['SQ_LDS_BANK_CONFLICT']:.0f}\n")
