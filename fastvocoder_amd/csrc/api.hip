@@ -982,7 +982,7 @@ int fv_plan_run(fv_plan_t* plan, int B, int T, const float* in, float* out, void
             const int64_t blocks = (int64_t)(Mp == 16 ? 1 : Mp / 32) * ((T3 + 127) / 128);
             const int min_blocks = getenv("FV_SUM3_MIN") ? atoi(getenv("FV_SUM3_MIN")) : 800;   // measured: HiFi-GAN light, B = 1
             int rc3;
-            if (blocks >= min_blocks && o.Cout > 4) {
+            if (blocks >= min_blocks && Mp == o.Cout) {   // (whole row tiles only: the kernel's epilogue is the affine one)
                 ConvParams ps[3] = {
                     make_params(o, base[o.x], base[o.y], y2s, base[o.res], nullptr, nullptr, B, T3),
                     make_params(mb, base[o.xb], base[o.y], y2s, base[o.resb], nullptr, nullptr, B, T3),

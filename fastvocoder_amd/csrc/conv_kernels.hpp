@@ -807,29 +807,18 @@ __global__ __launch_bounds__(64 * WN) FV_SUM3_WAVES void conv_sum3_kernel(Sum3Pa
     float* const xs0 = smem;
     float* const ws0 = smem + 2 * sp.xbuf_max;
 
-    // epilogue addressing (all three members write the same rows)
-    const bool affine = m0 + M_T <= p0.M;
+    // epilogue addressing: always the affine form (one vector offset per batch, the per-row part
+    // in the scalar offset operand) -- the host only selects this kernel when the row tiles lie
+    // entirely inside the output rows (Cout a multiple of the tile height)
     const int mlane = m0 + F::row(0, lane);
-    RowInfo<EN> ri[EH];
-    if (affine) {
+    float bias[EH][EN];
+    {
         const __amdgpu_buffer_rsrc_t rb = make_rsrc(p0.bias ? p0.bias : p0.wp, p0.bias ? (unsigned)p0.Cout * 4u : 0u);
 #pragma unroll
-        for (int h = 0; h < EH; ++h) {
-            ri[h].short_mask = 0u;
+        for (int h = 0; h < EH; ++h)
 #pragma unroll
-            for (int i = 0; i < EN; ++i) {
-                ri[h].off[i] = 0u;
-                ri[h].bias[i] = buffer_load1s(rb, (unsigned)mlane * 4u, (unsigned)F::row(h * EN + i, 0) * 4u);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int h = 0; h < EH; ++h) {
-            int mm[EN];
-#pragma unroll
-            for (int i = 0; i < EN; ++i) mm[i] = m0 + F::row(h * EN + i, lane);
-            row_info<EN>(p0, mm, ri[h]);
-        }
+            for (int i = 0; i < EN; ++i)
+                bias[h][i] = buffer_load1s(rb, (unsigned)mlane * 4u, (unsigned)F::row(h * EN + i, 0) * 4u);
     }
 
     const int total = sp.p[0].nchunks + sp.p[1].nchunks + sp.p[2].nchunks;   // stages per tile
@@ -903,7 +892,7 @@ __global__ __launch_bounds__(64 * WN) FV_SUM3_WAVES void conv_sum3_kernel(Sum3Pa
                 unsigned off[EN], so[EN];
 #pragma unroll
                 for (int i = 0; i < EN; ++i) vv[i] = acc[r][h * EN + i];
-                if (affine) {
+                {
                     const unsigned t4 = (unsigned)opaque_uniform(p0.Tout) * 4u;
                     const unsigned voff = q < p0.Tq ? (unsigned)(mlane * p0.Tout + q) * 4u : kOutOfRange;
 #pragma unroll
@@ -911,13 +900,6 @@ __global__ __launch_bounds__(64 * WN) FV_SUM3_WAVES void conv_sum3_kernel(Sum3Pa
                         off[i] = voff;
                         so[i] = (unsigned)F::row(h * EN + i, 0) * t4;
                     }
-                } else {
-                    int mm[EN];
-#pragma unroll
-                    for (int i = 0; i < EN; ++i) mm[i] = m0 + F::row(h * EN + i, lane);
-                    epilogue_offsets<EN>(p0, ri[h], mm, q, off);
-#pragma unroll
-                    for (int i = 0; i < EN; ++i) so[i] = 0u;
                 }
                 float e1[EN], e2[EN];
 #pragma unroll
@@ -926,7 +908,7 @@ __global__ __launch_bounds__(64 * WN) FV_SUM3_WAVES void conv_sum3_kernel(Sum3Pa
                 for (int i = 0; i < EN; ++i) e2[i] = buffer_load1s(r2, off[i], so[i]);
 #pragma unroll
                 for (int i = 0; i < EN; ++i) vv[i] += e1[i] + e2[i];
-                epilogue_finish<EN>(p0, ersrc, ri[h].bias, off, so, vv);
+                epilogue_finish<EN>(p0, ersrc, bias[h], off, so, vv);
             }
         }
     }
