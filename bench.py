@@ -208,6 +208,11 @@ def main():
         del os.environ["FV_SINGLE_LANE"]
         p32 = _native.profile_collect(_native.KERNEL_CONV_MFMA32)
         p16 = _native.profile_collect(_native.KERNEL_CONV_MFMA16)
+        q16 = _native.profile_collect(_native.KERNEL_PAIR16)
+        q32 = _native.profile_collect(_native.KERNEL_PAIR32)
+        for k in ("launches", "ms", "flops", "bytes"):
+            p16[k] += q16[k]
+            p32[k] += q32[k]
         pn = _native.profile_collect(_native.KERNEL_CONV_NARROW)
         mf_launch, mf_ms, mf_flops = (p32["launches"] + p16["launches"], p32["ms"] + p16["ms"],
                                       p32["flops"] + p16["flops"])
@@ -267,7 +272,7 @@ def main():
                                    f"{samples_per_utt} samples each; BASELINE.json configs[1]",
                        "global_batch": B * world, "frames": T_FRAMES,
                        "parallelism": f"utterance-sharded x{world}" if world > 1 else "single GPU",
-                       "convs_per_forward": model._plan("trunk", None, 80).num_ops()},
+                       "convs_per_forward": model._trunk_plan(T_FRAMES).num_ops()},
             "roofline": roofline,
             "roofline_hbm_stage": roofline_hbm,
         }

@@ -16,15 +16,16 @@ LIB_PATH = os.path.join(_HERE, "libfastvocoder_hip.so")
 _CSRC = os.path.join(_HERE, "csrc")
 # conv_inst_s*.hip instantiate the conv kernel templates (conv_kernels.hpp) one tile shape each,
 # so that the ~170 kernel variants compile in parallel
-SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip", "wav_sink.hip", "conv_inst_narrow.hip"] + \
+SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip", "wav_sink.hip", "conv_inst_narrow.hip",
+           "pair_launch.hip", "pair_inst_c16.hip", "pair_inst_c32.hip"] + \
           [f"conv_inst_s{i}.hip" for i in range(6)]
-HEADERS = ["fv_internal.h", "conv_kernels.hpp"]
+HEADERS = ["fv_internal.h", "conv_kernels.hpp", "pair_kernels.hpp", "pair_inst.hpp"]
 
 PAD_ZERO, PAD_REFLECT = 0, 1
 PAD_CAUSAL = 2      # flag: pad (k-1)*dil on both sides, keep the first Tin outputs (CausalConv1d)
 POST_NONE, POST_TANH, POST_RELU = 0, 1, 2
 SLOT_NONE, SLOT_IN, SLOT_OUT, SLOT_TMP0, MAX_SLOTS = -1, 0, 1, 2, 32
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class NativeError(RuntimeError):
@@ -45,7 +46,7 @@ def build(force=False, verbose=False):
              "-Wno-unused-value", "-Wno-comment", "-Wno-pass-failed",
              # MFMA results straight in VGPRs (unified register file on gfx950): no
              # v_accvgpr_read/write pairs around every stage -- VALU work costs MFMA time
-             "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+             "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + os.environ.get("FV_HIPCC_FLAGS", "").split()
     objdir = os.path.join(_HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     jobs = []
@@ -108,6 +109,14 @@ def lib():
     L.fv_pack_upsample_conv1d_weight.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.fv_upsample_conv1d_fused.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, i, f, vp]
     L.fv_plan_add_upsample_conv1d.argtypes = [vp, i, i, i, vp, vp, i, i, i, i, i, f, i, f]
+    pp = ctypes.POINTER(vp)
+    L.fv_packed_pair_floats.argtypes = [i, i]
+    L.fv_packed_pair_floats.restype = i64
+    L.fv_pack_pair_weight.argtypes = [vp, vp, i, i, vp]
+    L.fv_resblock1_fused.argtypes = [i, pp, pp, pp, pp, pp, pp, pp, ctypes.POINTER(i), i, i, i, i, f, f, vp]
+    L.fv_mrf_stage.argtypes = [pp, pp, pp, pp, pp, vp, vp, ctypes.POINTER(i), i, i, i, i, f, f, i, f, vp]
+    L.fv_plan_add_resblock_pair.argtypes = [vp, i, i, i, vp, vp, vp, vp, i, i, i, f, f]
+    L.fv_plan_add_mrf_sum.argtypes = [vp, ctypes.POINTER(i), i, i, pp, pp, pp, pp, i, ctypes.POINTER(i), i, f, f, i, f]
     L.fv_plan_create.argtypes = [i]
     L.fv_plan_create.restype = vp
     L.fv_plan_destroy.argtypes = [vp]
@@ -214,9 +223,58 @@ def pack_upsample_conv1d(w, rate, pad):
     return out
 
 
+def pack_pair(w):
+    """ResBlock Conv1d weight [C,C,k] -> A-fragment image of the fused pair kernels (flat tensor)."""
+    w = w.detach().contiguous().float()
+    c, c2, k = w.shape
+    if c != c2:
+        raise NativeError(f"pack_pair: square [C,C,k] weight expected, got {tuple(w.shape)}")
+    out = torch.empty(lib().fv_packed_pair_floats(c, k), dtype=torch.float32, device=w.device)
+    check(lib().fv_pack_pair_weight(_ptr(w, "w"), _ptr(out), c, k, _stream()))
+    return out
+
+
+def pair_supported(channels, k, dil):
+    """Shapes the fused ResBlock-pair kernels are built for (csrc/pair_launch.hip)."""
+    return channels in (16, 32) and k in (3, 7, 11) and dil in (1, 3, 5)
+
+
+def _vp_array(tensors, name, allow_none=False):
+    return (ctypes.c_void_p * len(tensors))(*[_ptr(t, name, allow_none) for t in tensors])
+
+
 # ---------------------------------------------------------------------------
 # single fused operators (used by tests and by modules outside a plan)
 # ---------------------------------------------------------------------------
+
+def resblock1_fused(xs, w1s, w2s, b1s, b2s, ks, dil, slope, act_slope=1.0, outs=None, outs_act=None):
+    """n = len(xs) independent fused ResBlock pairs in one launch (fv_resblock1_fused):
+    y_j = x_j + conv2_j(lrelu(conv1_j(lrelu(x_j)) + b1_j)) + b2_j; w1s / w2s from pack_pair."""
+    n = len(xs)
+    B, C, T = xs[0].shape
+    if outs is None:
+        outs = [torch.empty_like(x) for x in xs]
+    acts = list(outs_act) if outs_act is not None else [None] * n
+    check(lib().fv_resblock1_fused(n, _vp_array(xs, "x"), _vp_array(w1s, "w1"), _vp_array(w2s, "w2"),
+                                   _vp_array(b1s, "b1", True), _vp_array(b2s, "b2", True),
+                                   _vp_array(outs, "y"), _vp_array(acts, "y_act", True),
+                                   (ctypes.c_int * n)(*ks), B, C, T, dil, float(slope), float(act_slope),
+                                   _stream()))
+    return outs
+
+
+def mrf_stage(xs, w1s, w2s, b1s, b2s, ks, dil, slope, out_div=3.0, post=POST_NONE, act_slope=1.0, out=None,
+              out_act=None):
+    """y = post(sum_j pair_j(x_j) / out_div): the last pairs of three ResBlocks + the MRF mean (fv_mrf_stage)."""
+    B, C, T = xs[0].shape
+    if out is None:
+        out = torch.empty_like(xs[0])
+    check(lib().fv_mrf_stage(_vp_array(xs, "x"), _vp_array(w1s, "w1"), _vp_array(w2s, "w2"),
+                             _vp_array(b1s, "b1", True), _vp_array(b2s, "b2", True), _ptr(out, "y"),
+                             _ptr(out_act, "y_act", True), (ctypes.c_int * 3)(*ks), B, C, T, dil, float(slope),
+                             float(out_div), post, float(act_slope), _stream()))
+    return out
+
 
 def conv1d_fused(x, packed, bias, cout, k, dil=1, pad=0, pad_mode=PAD_ZERO, pre_slope=1.0,
                  res=None, acc_in=None, out_div=1.0, post=POST_NONE, out=None, out_act=None,
@@ -382,6 +440,28 @@ class Plan:
                                             _ptr(bias_sum, "bias_sum", True), channels, i3(*ks),
                                             float(out_div), post, float(act_slope)))
 
+    def add_resblock_pair(self, x, y, packed1, packed2, bias1, bias2, channels, k, dil, slope,
+                          y_act=SLOT_NONE, act_slope=1.0):
+        """One fused ResBlock pair (fv_plan_add_resblock_pair); group members share a launch."""
+        for t in (packed1, packed2, bias1, bias2):
+            if t is not None:
+                self.keep(t)
+        check(lib().fv_plan_add_resblock_pair(self._h, x, y, y_act, _ptr(packed1, "packed1"), _ptr(packed2, "packed2"),
+                                              _ptr(bias1, "bias1", True), _ptr(bias2, "bias2", True), channels, k,
+                                              dil, float(slope), float(act_slope)))
+
+    def add_mrf_sum(self, xs, y, packed1, packed2, bias1, bias2, channels, ks, dil, slope, out_div=3.0,
+                    post=POST_NONE, y_act=SLOT_NONE, act_slope=1.0):
+        """Last pairs of the three ResBlocks + the MRF mean in one launch (fv_plan_add_mrf_sum)."""
+        for t in list(packed1) + list(packed2) + list(bias1) + list(bias2):
+            if t is not None:
+                self.keep(t)
+        i3 = ctypes.c_int * 3
+        check(lib().fv_plan_add_mrf_sum(self._h, i3(*xs), y, y_act, _vp_array(packed1, "packed1"),
+                                        _vp_array(packed2, "packed2"), _vp_array(bias1, "bias1", True),
+                                        _vp_array(bias2, "bias2", True), channels, i3(*ks), dil, float(slope),
+                                        float(out_div), post, float(act_slope)))
+
     def set_sum_order(self, own_first):
         check(lib().fv_plan_set_sum_order(self._h, 1 if own_first else 0))
 
@@ -434,7 +514,7 @@ def profile_enable(on):
     check(lib().fv_profile_enable(1 if on else 0))
 
 
-KERNEL_CONV_MFMA32, KERNEL_CONV_MFMA16, KERNEL_CONV_NARROW = 0, 1, 2
+KERNEL_CONV_MFMA32, KERNEL_CONV_MFMA16, KERNEL_CONV_NARROW, KERNEL_PAIR16, KERNEL_PAIR32 = 0, 1, 2, 3, 4
 
 
 def profile_collect(kind=-1):

@@ -182,10 +182,28 @@ __global__ void pack_upconv_kernel(const float* __restrict__ w, float* __restric
     }
 }
 
+// Conv1d weight [C, C, k] -> the A-fragment image of the fused ResBlock pair kernels (pair_kernels.hpp):
+// Wl[row half h][step group g][lane][e], step s = 4g + e = (channel group cg = s / k, tap = s % k),
+// value w[co = 16h + (lane & 15)][ci = 4cg + (lane >> 4)][tap] -- what lane `lane` feeds to the s-th
+// v_mfma_f32_16x16x4_f32 of its row half, so a wave loads 4 steps with one 16-byte LDS read.
+__global__ void pack_pair_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, int k) {
+    const int64_t total = (int64_t)C * C * k;
+    const int groups = (C / 16) * k;            // step groups per row half: S / 4, S = C * k / 4
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
+        const int64_t hg = i >> 8;
+        const int g = (int)(hg % groups), h = (int)(hg / groups);
+        const int s = 4 * g + e, cg = s / k, tap = s - cg * k;
+        const int co = 16 * h + (lane & 15), ci = 4 * cg + (lane >> 4);
+        wp[i] = w[((size_t)co * C + ci) * k + tap];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------
-enum OpType { OP_CONV = 0, OP_CONVT = 1, OP_PQMF = 2, OP_UPCONV = 3 };
+enum OpType { OP_CONV = 0, OP_CONVT = 1, OP_PQMF = 2, OP_UPCONV = 3, OP_PAIR = 4, OP_MRFSUM = 5 };
 
 struct Op {
     int type;
@@ -214,6 +232,12 @@ struct Op {
     const float* wpb = nullptr;
     const float* wpc = nullptr;
     int kb = 0, kc = 0;
+    // fused ResBlock pairs (OP_PAIR: member 0 only; OP_MRFSUM: the three members, inputs x / xb / xc)
+    const float* pw1[3] = {nullptr, nullptr, nullptr};
+    const float* pw2[3] = {nullptr, nullptr, nullptr};
+    const float* pb1[3] = {nullptr, nullptr, nullptr};
+    const float* pb2[3] = {nullptr, nullptr, nullptr};
+    int pk[3] = {0, 0, 0};
 };
 
 constexpr int kMaxLanes = 4;
@@ -253,6 +277,7 @@ struct fv_plan {
 namespace fv {
 
 static int64_t conv_out_len(const Op& o, int64_t Tin) {
+    if (o.type == OP_PAIR || o.type == OP_MRFSUM) return Tin;
     if (o.type == OP_CONV)
         return (o.pad_mode & FV_PAD_CAUSAL) ? Tin : Tin + 2LL * o.pad - (int64_t)o.dil * (o.k - 1);
     if (o.type == OP_CONVT) return (Tin - 1) * o.stride - 2LL * o.pad + o.k + o.out_pad;
@@ -286,6 +311,14 @@ static int infer(const fv_plan* plan, int B, int T, Shape* sh, int64_t* slot_ele
             if (aux[a] == FV_SLOT_NONE) continue;
             if (!sh[aux[a]].set || sh[aux[a]].C != Cout || sh[aux[a]].T != Tout)
                 return fail(FV_ERR_INVALID_ARG, "op %zu: residual/accumulator slot %d shape mismatch", n, aux[a]);
+        }
+        if (o.type == OP_MRFSUM) {
+            const int extra[2] = {o.xb, o.xc};
+            for (int e = 0; e < 2; ++e)
+                if (!sh[extra[e]].set || sh[extra[e]].C != o.Cin || sh[extra[e]].T != sh[o.x].T || extra[e] == o.y ||
+                    extra[e] == o.y2)
+                    return fail(FV_ERR_INVALID_ARG, "op %zu: mrf member slot %d must be [%d, T] and not the output", n,
+                                extra[e], o.Cin);
         }
         if (o.sum3) {
             const int extra[4] = {o.xb, o.xc, o.resb, o.resc};
@@ -864,6 +897,162 @@ int fv_plan_add_pqmf_synthesis(fv_plan_t* plan, int x_slot, int y_slot, const fl
     return 0;
 }
 
+int64_t fv_packed_pair_floats(int C, int k) { return (int64_t)C * C * k; }
+
+int fv_pack_pair_weight(const float* w, float* packed, int C, int k, void* stream) {
+    if (!w || !packed) return fail(FV_ERR_INVALID_ARG, "pack_pair_weight: null tensor");
+    if (C <= 0 || C % 16 != 0 || k <= 0) return fail(FV_ERR_INVALID_ARG, "pack_pair_weight: C=%d (multiple of 16) k=%d", C, k);
+    const int64_t total = (int64_t)C * C * k;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_pair_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, C, k);
+    FV_HIP(hipGetLastError());
+    return 0;
+}
+
+static int check_pair_args(int n, int C, const int* k, int dil) {
+    if (n < 1 || n > 3) return fail(FV_ERR_INVALID_ARG, "resblock pair: %d members (1..3)", n);
+    if (C != 16 && C != 32) return fail(FV_ERR_UNSUPPORTED, "resblock pair: C = %d (16 or 32); use the conv1d ops", C);
+    if (dil != 1 && dil != 3 && dil != 5) return fail(FV_ERR_UNSUPPORTED, "resblock pair: dilation %d (1, 3 or 5)", dil);
+    for (int j = 0; j < n; ++j)
+        if (k[j] != 3 && k[j] != 7 && k[j] != 11) return fail(FV_ERR_UNSUPPORTED, "resblock pair: %d taps (3, 7 or 11)", k[j]);
+    return 0;
+}
+
+int fv_resblock1_fused(int n, const float* const* x, const float* const* w1, const float* const* w2,
+                       const float* const* b1, const float* const* b2, float* const* y, float* const* y_act,
+                       const int* k, int B, int C, int T, int dil, float slope, float act_slope, void* stream) {
+    if (!x || !w1 || !w2 || !y || !k) return fail(FV_ERR_INVALID_ARG, "resblock1_fused: null argument");
+    if (int rc = check_pair_args(n, C, k, dil)) return rc;
+    PairParams pp = {};
+    pp.n_members = n;
+    pp.B = B;
+    pp.T = T;
+    pp.slope = slope;
+    pp.act_slope = act_slope;
+    pp.out_div = 1.f;
+    pp.post = FV_POST_NONE;
+    for (int j = 0; j < n; ++j) {
+        if (!x[j] || !y[j] || x[j] == y[j] || (y_act && y_act[j] && (y_act[j] == y[j] || y_act[j] == x[j])))
+            return fail(FV_ERR_INVALID_ARG, "resblock1_fused: member %d: null tensor, or y / y_act aliases x or each other", j);
+        PairMember& mb = pp.m[j];
+        mb.x = x[j];
+        mb.w1 = w1[j];
+        mb.w2 = w2[j];
+        mb.b1 = b1 ? b1[j] : nullptr;
+        mb.b2 = b2 ? b2[j] : nullptr;
+        mb.y = y[j];
+        mb.y_act = y_act ? y_act[j] : nullptr;
+        mb.k = k[j];
+    }
+    return launch_pairs(pp, C, dil, (hipStream_t)stream);
+}
+
+int fv_mrf_stage(const float* const* x, const float* const* w1, const float* const* w2, const float* const* b1,
+                 const float* const* b2, float* y, float* y_act, const int* k, int B, int C, int T, int dil,
+                 float slope, float out_div, int post, float act_slope, void* stream) {
+    if (!x || !w1 || !w2 || !y || !k) return fail(FV_ERR_INVALID_ARG, "mrf_stage: null argument");
+    if (int rc = check_pair_args(3, C, k, dil)) return rc;
+    PairParams pp = {};
+    pp.n_members = 3;
+    pp.sum = 1;
+    pp.B = B;
+    pp.T = T;
+    pp.slope = slope;
+    pp.act_slope = act_slope;
+    pp.out_div = out_div;
+    pp.post = post;
+    for (int j = 0; j < 3; ++j) {
+        if (!x[j] || x[j] == y || x[j] == y_act || (y_act && y_act == y))
+            return fail(FV_ERR_INVALID_ARG, "mrf_stage: member %d: null input, or y / y_act aliases an input or each other", j);
+        PairMember& mb = pp.m[j];
+        mb.x = x[j];
+        mb.w1 = w1[j];
+        mb.w2 = w2[j];
+        mb.b1 = b1 ? b1[j] : nullptr;
+        mb.b2 = b2 ? b2[j] : nullptr;
+        mb.y = y;
+        mb.y_act = y_act;
+        mb.k = k[j];
+    }
+    return launch_pairs(pp, C, dil, (hipStream_t)stream);
+}
+
+int fv_plan_add_resblock_pair(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed1,
+                              const float* packed2, const float* bias1, const float* bias2, int C, int k, int dil,
+                              float slope, float act_slope) {
+    if (!plan || !packed1 || !packed2) return fail(FV_ERR_INVALID_ARG, "plan_add_resblock_pair: null");
+    if (int rc = check_pair_args(1, C, &k, dil)) return rc;
+    if (int rc = check_slot(x_slot, false)) return rc;
+    if (int rc = check_slot(y_slot, false)) return rc;
+    if (int rc = check_slot(y_act_slot, true)) return rc;
+    if (y_slot == FV_SLOT_IN || y_act_slot == FV_SLOT_IN) return fail(FV_ERR_INVALID_ARG, "plan: the input slot is read-only");
+    Op o = {};
+    o.type = OP_PAIR;
+    o.x = x_slot;
+    o.y = y_slot;
+    o.y2 = y_act_slot;
+    o.res = o.acc = o.acc2 = FV_SLOT_NONE;
+    o.group = plan->cur_group;
+    o.lane = plan->cur_lane;
+    o.Cin = o.Cout = C;
+    o.k = k;
+    o.dil = dil;
+    o.pre_slope = slope;
+    o.act_slope = act_slope;
+    o.out_div = 1.f;
+    o.post = FV_POST_NONE;
+    o.pw1[0] = packed1;
+    o.pw2[0] = packed2;
+    o.pb1[0] = bias1;
+    o.pb2[0] = bias2;
+    o.pk[0] = k;
+    plan->compiled = false;
+    plan->ops.push_back(o);
+    return 0;
+}
+
+int fv_plan_add_mrf_sum(fv_plan_t* plan, const int* x_slots, int y_slot, int y_act_slot,
+                        const float* const* packed1, const float* const* packed2, const float* const* bias1,
+                        const float* const* bias2, int C, const int* k, int dil, float slope, float out_div,
+                        int post, float act_slope) {
+    if (!plan || !x_slots || !packed1 || !packed2 || !k) return fail(FV_ERR_INVALID_ARG, "plan_add_mrf_sum: null");
+    if (int rc = check_pair_args(3, C, k, dil)) return rc;
+    if (C != 16) return fail(FV_ERR_UNSUPPORTED, "plan_add_mrf_sum: C = %d (16)", C);
+    for (int j = 0; j < 3; ++j) {
+        if (!packed1[j] || !packed2[j]) return fail(FV_ERR_INVALID_ARG, "plan_add_mrf_sum: member %d has no weights", j);
+        if (int rc = check_slot(x_slots[j], false)) return rc;
+    }
+    if (int rc = check_slot(y_slot, false)) return rc;
+    if (int rc = check_slot(y_act_slot, true)) return rc;
+    if (y_slot == FV_SLOT_IN || y_act_slot == FV_SLOT_IN) return fail(FV_ERR_INVALID_ARG, "plan: the input slot is read-only");
+    Op o = {};
+    o.type = OP_MRFSUM;
+    o.x = x_slots[0];
+    o.xb = x_slots[1];
+    o.xc = x_slots[2];
+    o.y = y_slot;
+    o.y2 = y_act_slot;
+    o.res = o.acc = o.acc2 = FV_SLOT_NONE;
+    o.lane = plan->cur_lane;
+    o.Cin = o.Cout = C;
+    o.k = k[0];
+    o.dil = dil;
+    o.pre_slope = slope;
+    o.act_slope = act_slope;
+    o.out_div = out_div;
+    o.post = post;
+    for (int j = 0; j < 3; ++j) {
+        o.pw1[j] = packed1[j];
+        o.pw2[j] = packed2[j];
+        o.pb1[j] = bias1 ? bias1[j] : nullptr;
+        o.pb2[j] = bias2 ? bias2[j] : nullptr;
+        o.pk[j] = k[j];
+    }
+    plan->compiled = false;
+    plan->ops.push_back(o);
+    return 0;
+}
+
 int fv_plan_set_group(fv_plan_t* plan, int group) {
     if (!plan || group < 0) return fail(FV_ERR_INVALID_ARG, "plan_set_group: group %d", group);
     plan->cur_group = group;
@@ -936,6 +1125,66 @@ int fv_plan_run(fv_plan_t* plan, int B, int T, const float* in, float* out, void
     sh[FV_SLOT_IN] = {plan->in_channels, T, true};
     for (size_t n = 0; n < plan->ops.size(); ++n) {
         const Op& o = plan->ops[n];
+        // ---- fused ResBlock pairs: the members of a group (the three ResBlocks of an MRF stage) in one launch ----
+        if (o.type == OP_PAIR || o.type == OP_MRFSUM) {
+            size_t m = n + 1;
+            if (o.type == OP_PAIR && o.group != 0)
+                while (m < plan->ops.size() && m - n < 3 && plan->ops[m].type == OP_PAIR && plan->ops[m].group == o.group &&
+                       plan->ops[m].lane == o.lane && plan->ops[m].Cin == o.Cin && plan->ops[m].dil == o.dil &&
+                       plan->ops[m].pre_slope == o.pre_slope && plan->ops[m].act_slope == o.act_slope)
+                    ++m;
+            hipStream_t s = lanes[o.lane];
+            if (multi)
+                for (size_t q = n; q < m; ++q)
+                    for (int d = 0; d < plan->ops[q].ndeps; ++d)
+                        FV_HIP(hipStreamWaitEvent(s, plan->op_event[plan->ops[q].deps[d]], 0));
+            PairParams pp = {};
+            pp.B = B;
+            pp.T = (int)sh[o.x].T;
+            pp.slope = o.pre_slope;
+            pp.act_slope = o.act_slope;
+            pp.out_div = o.out_div;
+            pp.post = o.post;
+            if (o.type == OP_MRFSUM) {
+                const int xs3[3] = {o.x, o.xb, o.xc};
+                pp.sum = 1;
+                pp.n_members = 3;
+                for (int j = 0; j < 3; ++j) {
+                    PairMember& mb = pp.m[j];
+                    mb.x = base[xs3[j]];
+                    mb.w1 = o.pw1[j];
+                    mb.w2 = o.pw2[j];
+                    mb.b1 = o.pb1[j];
+                    mb.b2 = o.pb2[j];
+                    mb.k = o.pk[j];
+                    mb.y = base[o.y];
+                    mb.y_act = o.y2 == FV_SLOT_NONE ? nullptr : base[o.y2];
+                }
+            } else {
+                pp.n_members = (int)(m - n);
+                for (size_t q = n; q < m; ++q) {
+                    const Op& qo = plan->ops[q];
+                    PairMember& mb = pp.m[q - n];
+                    mb.x = base[qo.x];
+                    mb.w1 = qo.pw1[0];
+                    mb.w2 = qo.pw2[0];
+                    mb.b1 = qo.pb1[0];
+                    mb.b2 = qo.pb2[0];
+                    mb.k = qo.pk[0];
+                    mb.y = base[qo.y];
+                    mb.y_act = qo.y2 == FV_SLOT_NONE ? nullptr : base[qo.y2];
+                }
+            }
+            if (int rc = launch_pairs(pp, o.Cin, o.dil, s)) return rc;
+            for (size_t q = n; q < m; ++q) {
+                const Op& qo = plan->ops[q];
+                if (multi && qo.signal) FV_HIP(hipEventRecord(plan->op_event[q], s));
+                sh[qo.y] = {qo.Cout, sh[qo.x].T, true};
+                if (qo.y2 != FV_SLOT_NONE) sh[qo.y2] = sh[qo.y];
+            }
+            n = m - 1;
+            continue;
+        }
         // ---- a group of mutually independent convs: one launch when possible ----
         if (o.group != 0 && o.type == OP_CONV) {
             size_t m = n;

@@ -121,6 +121,55 @@ struct Sum3Params {
 };
 int launch_conv_sum3(ConvParams* ps, hipStream_t stream);
 
+// ---- fused ResBlock1 pairs (pair_kernels.hpp / pair_launch.hip) ---------------------------------------
+// one ResBlock's pair (a "member" of the launch)
+struct PairMember {
+    const float* x;      // [B, C, T] raw input = residual
+    const float* w1;     // fv_pack_pair_weight image of conv1 / conv2
+    const float* w2;
+    const float* b1;     // [C] or null
+    const float* b2;
+    float* y;            // [B, C, T] raw output (sum mode: member 0's is THE output)
+    float* y_act;        // optional activated twin lrelu(y, act_slope), or null
+    int k;               // taps: 11, 7 or 3
+    int cost;            // relative cost of one tile of this member (partition weights): taps + per-tile overhead
+    int n_tiles;         // tiles per utterance
+    int w_off;           // float offset of this member's two weight images in dynamic LDS
+};
+
+struct PairParams {
+    PairMember m[3];
+    int n_members;
+    int sum;             // members accumulate into m[0].y ( / out_div, activation)
+    int B, T;
+    int n_out_sum;       // sum mode: output columns per tile (the largest member's NOUT)
+    float slope;         // leaky slope of the two in-block activations
+    float out_div;       // sum mode: divisor
+    float act_slope;     // y_act = lrelu(y, act_slope); without y_act and != 1: y itself is stored activated
+    int post;            // FV_POST_* applied to y (sum mode / single)
+    int nblk;            // persistent blocks in the grid
+    int x_off, mid_off;  // float offsets of the x image / intermediate in dynamic LDS
+    int bias_off;        // ... of the staged biases: per member [b1[C] | b2[C]]
+    unsigned long long* trace;   // tuning aid (FV_PAIR_TRACE_PTR): s_memtime stamps [block < 8][wave][tile < 8][16 events]
+    int dbg;             // ablation switches (FV_PAIR_DBG, timing experiments only -- results are wrong):
+                         // 1 no x DMA after a block's first tile, 2 no activation pass, 4 no MFMA,
+                         // 8 no stores, 16 no residual loads
+};
+
+// tile geometry of the pair kernels, the run-time mirror of PairGeom<> (pair_kernels.hpp)
+struct PairShape {
+    int MH, NF, NG;      // row halves, column fragments per wave, column groups
+    int NW, NM;          // waves per block, intermediate columns per tile
+    int XS, NXI, MS;     // x image: row stride (floats), DMA instructions; intermediate row stride
+    int WF;              // floats per packed conv weight
+    int NOUT;            // output columns per tile
+};
+PairShape pair_shape(int C, int k, int dil);
+// n (1..3) members, plain (sum = 0: one raw output each) or sum mode (one output: mean of the members)
+int launch_pairs(PairParams p, int C, int dil, hipStream_t stream);
+template <int MH, int NF, int NG>
+int launch_pair_geom(const PairParams& p, int dil, size_t lds, hipStream_t s);
+
 // Shared between the host launcher (conv_mfma.hip) and the kernels (conv_kernels.hpp):
 #ifndef FV_RING
 #define FV_RING 2          // stage buffers of the LDS-DMA ring in the plain (aligned, zero-padded) kernels.

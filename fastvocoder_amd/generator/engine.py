@@ -136,6 +136,41 @@ class PlanBuilder:
                              channels=c0.in_channels, ks=[c.kernel_size[0] for c in convs],
                              out_div=float(out_div), post=post))
 
+    @staticmethod
+    def pair_fusable(conv1, conv2):
+        """Can this (dilated conv, conv) pair of a ResBlock1 run on the fused pair kernels?"""
+        k, c = conv1.kernel_size[0], conv1.in_channels
+        return (all(cv.stride[0] == 1 and cv.groups == 1 and cv.in_channels == c and cv.out_channels == c
+                    and cv.kernel_size[0] == k and cv.padding[0] == cv.dilation[0] * (k - 1) // 2
+                    for cv in (conv1, conv2))
+                and conv2.dilation[0] == 1 and _native.pair_supported(c, k, conv1.dilation[0]))
+
+    def _pair_member(self, conv1, conv2):
+        if not self.pair_fusable(conv1, conv2):
+            raise _native.NativeError("resblock pair: shape not built into the fused kernels")
+        return dict(w1=_native.pack_pair(effective_weight(conv1)), w2=_native.pack_pair(effective_weight(conv2)),
+                    b1=self._bias(conv1), b2=self._bias(conv2), k=conv1.kernel_size[0])
+
+    def pair(self, conv1, conv2, src, dst, slope):
+        """dst = src + conv2(lrelu(conv1(lrelu(src)))) as ONE fused op (fv_plan_add_resblock_pair); it reads
+        ``src`` raw and applies both activations on chip.  Ops recorded inside one group share a launch."""
+        m = self._pair_member(conv1, conv2)
+        self.ops.append(dict(kind="pair", lane=self.lane, group=self.group, x=src, y=dst, res=SLOT_NONE,
+                             acc=SLOT_NONE, pre_slope=1.0, slope=float(slope), channels=conv1.in_channels,
+                             dil=conv1.dilation[0], **m))
+
+    def mrf_sum(self, pairs, srcs, dst, slope, out_div, post=POST_NONE):
+        """dst = post(sum_j pair_j(srcs[j]) / out_div): the last pairs of the three ResBlocks of an MRF stage
+        and the mean, one launch (fv_plan_add_mrf_sum)."""
+        ms = [self._pair_member(c1, c2) for c1, c2 in pairs]
+        c1 = pairs[0][0]
+        if any(p[0].dilation[0] != c1.dilation[0] or p[0].in_channels != c1.in_channels for p in pairs):
+            raise _native.NativeError("mrf_sum: the three pairs must share channels and dilation")
+        self.ops.append(dict(kind="mrfsum", lane=self.lane, x=srcs[0], xb=srcs[1], xc=srcs[2], y=dst,
+                             res=SLOT_NONE, acc=SLOT_NONE, pre_slope=1.0, slope=float(slope),
+                             channels=c1.in_channels, dil=c1.dilation[0], members=ms, out_div=float(out_div),
+                             post=post))
+
     def conv_transpose(self, convt, src, dst, pre_slope=1.0, post=POST_NONE):
         """Record a torch.nn.ConvTranspose1d container (polyphase form)."""
         if convt.groups != 1 or convt.dilation[0] != 1:
@@ -236,6 +271,10 @@ class PlanBuilder:
                 own, rate = max(op["ks"]) // 2, 1
             elif op["kind"] == "conv2":
                 own, rate = 0, 1
+            elif op["kind"] == "pair":
+                own, rate = (op["k"] - 1) // 2 * (op["dil"] + 1), 1
+            elif op["kind"] == "mrfsum":
+                own, rate = max((m["k"] - 1) // 2 * (op["dil"] + 1) for m in op["members"]), 1
             elif op["kind"] == "convT":
                 own, rate = -(-op["k"] // op["stride"]) + 1, op["stride"]
             elif op["kind"] == "upconv":
@@ -274,6 +313,17 @@ class PlanBuilder:
                                           op["tmps"], op["y"], op["packed"], op["bias"], op["channels"], op["ks"],
                                           out_div=op["out_div"], post=op["post"], y_act=op["y_act"],
                                           act_slope=op["act_slope"])
+            elif op["kind"] == "pair":
+                self.plan.add_resblock_pair(op["x"], op["y"], op["w1"], op["w2"], op["b1"], op["b2"],
+                                            op["channels"], op["k"], op["dil"], op["slope"],
+                                            y_act=op["y_act"], act_slope=op["act_slope"])
+            elif op["kind"] == "mrfsum":
+                ms = op["members"]
+                self.plan.add_mrf_sum([op["x"], op["xb"], op["xc"]], op["y"], [m["w1"] for m in ms],
+                                      [m["w2"] for m in ms], [m["b1"] for m in ms], [m["b2"] for m in ms],
+                                      op["channels"], [m["k"] for m in ms], op["dil"], op["slope"],
+                                      out_div=op["out_div"], post=op["post"], y_act=op["y_act"],
+                                      act_slope=op["act_slope"])
             elif op["kind"] == "conv2":
                 if op["pre_slope"] != 1.0:
                     raise _native.NativeError("conv_sum_1x1: the activation of the first input could not "
@@ -371,14 +421,17 @@ class NativeModule(torch.nn.Module):
 
     def _run_plan(self, plan, x, chunk_frames=None):
         """plan.run(x), time-chunked when x is longer than ``chunk_frames``
-        (default ``max_frames_per_run``)."""
+        (default ``max_frames_per_run``).  ``plan`` is a native plan or a callable ``T -> plan``
+        (variants of one graph whose fused ops depend on the length, all with the same
+        receptive field and output-length law)."""
+        plan_for = plan if callable(plan) else (lambda T: plan)
         chunk = self.max_frames_per_run if chunk_frames is None else int(chunk_frames)
         if chunk <= 0 or x.shape[2] <= chunk:
-            return plan.run(x)
-        return self._run_chunked(plan, x, chunk)
+            return plan_for(x.shape[2]).run(x)
+        return self._run_chunked(plan_for, x, chunk)
 
     @staticmethod
-    def _run_chunked(plan, x, chunk):
+    def _run_chunked(plan_for, x, chunk):
         """Exact chunked evaluation: each chunk of ``chunk`` frames is run with ``halo`` extra
         frames of real input on both sides (clipped at the utterance ends, where the layers'
         own zero / reflection padding applies as in a whole run) and only its interior is
@@ -386,6 +439,7 @@ class NativeModule(torch.nn.Module):
         crop (MB-large), c > 0 a tail (Basis overlap-add); either way a chunk that starts at
         frame ``lo`` produces final samples [lo*hop, lo*hop + len)."""
         B, _, T = x.shape
+        plan = plan_for(T)
         halo = plan.halo_frames
         (_, n1), (cout, n2) = plan.output_shape(halo + 64), plan.output_shape(halo + 65)
         hop = n2 - n1
@@ -394,7 +448,7 @@ class NativeModule(torch.nn.Module):
         for a in range(0, T, chunk):
             b = min(T, a + chunk)
             lo, hi = max(0, a - halo), min(T, b + halo)
-            y = plan.run(x[:, :, lo:hi].contiguous())
+            y = plan_for(hi - lo).run(x[:, :, lo:hi].contiguous())
             first = a * hop if a > 0 else 0
             last = b * hop if b < T else total
             out[:, :, first:last] = y[:, :, first - lo * hop: last - lo * hop]

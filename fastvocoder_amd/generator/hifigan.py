@@ -17,7 +17,7 @@ import os
 
 import torch
 
-from .engine import NativeModule, POST_TANH, SLOT_IN, SLOT_NONE, SLOT_OUT, weight_norm  # noqa: F401
+from .engine import NativeModule, PlanBuilder, POST_TANH, SLOT_IN, SLOT_NONE, SLOT_OUT, weight_norm  # noqa: F401
 from .modules import LRELU_SLOPE, ResBlock1, ResBlock2, UpsampleLayer
 from .pqmf import PQMF
 
@@ -62,9 +62,69 @@ class _HiFiGANBase(NativeModule):
         self.apply_weight_norm()
         self.reset_parameters()
 
+    # -- fused ResBlock pairs ------------------------------------------------
+    def _stage_fusable(self, i):
+        """Stage i can run on the fused ResBlock-pair kernels (csrc/pair_kernels.hpp): the classic
+        ResBlock1 trio (3 / 7 / 11 taps) with one dilation per pair position, 16 or 32 channels."""
+        nk = self.num_kernels
+        blocks = [self.resblocks[i * nk + j] for j in range(nk)]
+        if nk != 3 or not all(isinstance(b, ResBlock1) for b in blocks):
+            return False
+        if sorted(b.convs1[0].kernel_size[0] for b in blocks) != [3, 7, 11]:
+            return False
+        dils = [[c.dilation[0] for c in b.convs1] for b in blocks]
+        if any(d != dils[0] for d in dils):
+            return False
+        return all(PlanBuilder.pair_fusable(c1, c2) for b in blocks for c1, c2 in zip(b.convs1, b.convs2))
+
+    def _fused_flags(self, T):
+        """Per stage: run it fused for a mel of T frames?  The pair kernels need 16-byte aligned rows
+        (stage length % 4 == 0); FV_PAIR=0 keeps every stage on the conv-by-conv path (A/B runs)."""
+        if os.environ.get("FV_PAIR", "1") == "0" or os.environ.get("FV_MRF", "group") != "group":
+            return (False,) * self.num_upsamples
+        flags, t = [], int(T)
+        for i in range(self.num_upsamples):
+            up = self.ups[i]
+            if isinstance(up, UpsampleLayer):
+                t = t * up.upsample_rate + 2 * up.conv.padding[0] - (up.conv.kernel_size[0] - 1)
+            else:
+                t = (t - 1) * up.stride[0] - 2 * up.padding[0] + up.kernel_size[0] + up.output_padding[0]
+            flags.append(t > 0 and t % 4 == 0 and self._stage_fusable(i))
+        return tuple(flags)
+
+    def _emit_fused_stage(self, pb, blocks, up, x, scratch, parts):
+        """The three ResBlocks of a stage as fused pair launches: every pair position is ONE launch of
+        three members; the last position also forms the MRF mean when the three weight sets fit in
+        LDS (16 channels), otherwise it runs conv by conv (grouped first convs + the merged last convs)."""
+        nk = len(blocks)
+        npairs = len(blocks[0].convs1)
+        ch = blocks[0].channels
+        curs = [up] * nk
+        for pi in range(npairs - 1):
+            pb.begin_group()
+            nxt = []
+            for j in range(nk):
+                ping, pong = scratch[j][1], scratch[j][2]
+                d = ping if curs[j] != ping else pong
+                pb.pair(blocks[j].convs1[pi], blocks[j].convs2[pi], curs[j], d, LRELU_SLOPE)
+                nxt.append(d)
+            pb.end_group()
+            curs = nxt
+        if ch == 16:
+            pb.mrf_sum([(b.convs1[-1], b.convs2[-1]) for b in blocks], curs, x, LRELU_SLOPE, float(nk))
+            return
+        states = [dict(cur=c) for c in curs]
+        steps = blocks[0].num_steps()
+        pb.begin_group()
+        for j in range(nk):
+            blocks[j].emit_step(pb, steps - 2, states[j], up, x, scratch[j])
+        pb.end_group()
+        convs, srcs, ress = zip(*[blocks[j].last_conv_inputs(states[j], up, scratch[j]) for j in range(nk)])
+        pb.conv_sum3(convs, srcs, ress, parts[:2], x, pre_slope=LRELU_SLOPE, out_div=float(nk))
+
     # -- op emission ---------------------------------------------------------
-    def _emit_trunk(self, pb, dst):
-        """mel (SLOT_IN) -> tanh(conv_post(...)) in ``dst``."""
+    def _emit_trunk(self, pb, dst, fused=None):
+        """mel (SLOT_IN) -> tanh(conv_post(...)) in ``dst``; ``fused``: per-stage flags (_fused_flags)."""
         x, up = pb.tmp(), pb.tmp()
         nk = self.num_kernels
         # The nk ResBlocks of a stage are independent given the upsampled input, and at
@@ -87,6 +147,9 @@ class _HiFiGANBase(NativeModule):
             else:
                 pb.conv_transpose(self.ups[i], x, up, pre_slope=LRELU_SLOPE)
             blocks = [self.resblocks[i * nk + j] for j in range(nk)]
+            if fused is not None and fused[i]:
+                self._emit_fused_stage(pb, blocks, up, x, scratch, parts)
+                continue
             if nk <= 3 and mode != "chain":
                 steps = blocks[0].num_steps()
                 states = [dict() for _ in range(nk)]
@@ -139,8 +202,13 @@ class _HiFiGANBase(NativeModule):
                                    out_div=float(nk) if last else 1.0)
         pb.conv(self.conv_post, x, dst, pre_slope=DEFAULT_LRELU_SLOPE, post=POST_TANH)
 
+    def _trunk_plan(self, T):
+        fused = self._fused_flags(T)
+        return self._plan("trunk" + "".join("f" if f else "-" for f in fused),
+                          lambda pb: self._emit_trunk(pb, SLOT_OUT, fused), 80)
+
     def _trunk(self, x):
-        return self._run_plan(self._plan("trunk", lambda pb: self._emit_trunk(pb, SLOT_OUT), 80), x)
+        return self._run_plan(self._trunk_plan, x)
 
 
 class HiFiGANGenerator(_HiFiGANBase):
@@ -188,16 +256,21 @@ class MultiBandHiFiGANGenerator(_HiFiGANBase):
         reference bin/train.py:96)."""
         return self._trunk(self._prepare(x))
 
-    def _emit_full(self, pb):
+    def _emit_full(self, pb, fused=None):
         sub = pb.tmp()
-        self._emit_trunk(pb, sub)
+        self._emit_trunk(pb, sub, fused)
         pb.pqmf_synthesis(self.pqmf.synthesis_filter, sub, SLOT_OUT)
+
+    def _full_plan(self, T):
+        fused = self._fused_flags(T)
+        return self._plan("inference" + "".join("f" if f else "-" for f in fused),
+                          lambda pb: self._emit_full(pb, fused), 80)
 
     def inference(self, x):
         """x [T,80] -> 1-D full-band waveform (trunk + PQMF synthesis, one plan)."""
         x = self._prepare(x).transpose(1, 0).unsqueeze(0).contiguous()
-        return self._run_plan(self._plan("inference", self._emit_full, 80), x).squeeze()
+        return self._run_plan(self._full_plan, x).squeeze()
 
     def synthesize_batch(self, x):
         """x [B,80,T] -> full-band waveforms [B, 4*T'] (batched ``inference``)."""
-        return self._run_plan(self._plan("inference", self._emit_full, 80), self._prepare(x))[:, 0, :]
+        return self._run_plan(self._full_plan, self._prepare(x))[:, 0, :]

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FV_ABI_VERSION 6
+#define FV_ABI_VERSION 7
 
 #define FV_ERR_INVALID_ARG (-1)
 #define FV_ERR_UNSUPPORTED (-2)
@@ -119,6 +119,46 @@ int fv_conv1d_fused(const float* x, const float* packed, const float* bias,
                     float* y_act, int B, int Cin, int Cout, int Tin, int k, int dil, int pad,
                     int pad_mode, float pre_slope, float out_div, int post, float act_slope,
                     void* stream);
+
+/*
+ * Fused ResBlock1 pair (model/generator/modules.py:223-230, one iteration of the loop):
+ *
+ *     y_j = x_j + conv1d( lrelu( conv1d( lrelu(x_j, slope); w1_j, k_j taps, dilation dil ) + b1_j, slope ); w2_j, k_j taps ) + b2_j
+ *
+ * for n = 1..3 independent members j in ONE launch -- the pairs at the same position of the three
+ * ResBlocks of an MRF stage (hifigan.py:97-103; taps 11 / 7 / 3, same dilation).  Both convs use 'same'
+ * zero padding.  The intermediate tensor lives in LDS only; x_j is read raw (the activation is applied
+ * on chip) and y_j is written raw, so no activated twin tensors exist between the pairs of a block.
+ *   x_j, y_j [B,C,T]; w1_j, w2_j: fv_pack_pair_weight images of the [C,C,k_j] Conv1d weights;
+ *   b1_j, b2_j [C] or NULL (the arrays themselves may be NULL); y_act (array or its entries may be
+ *   NULL): optional second output lrelu(y_j, act_slope) for a conv1d consumer; with y_act[j] == NULL and
+ *   act_slope != 1 only the activated tensor is written, to y_j.
+ * Supported: C = 16 or 32, k_j in {3, 7, 11}, dil in {1, 3, 5}, T % 4 == 0 (rows 16-byte aligned);
+ * anything else returns FV_ERR_UNSUPPORTED (use two fv_conv1d_fused calls).  Persistent blocks, each
+ * with a contiguous cost-balanced share of the (member, utterance, tile) list; every output element is
+ * computed the same way whichever block owns its tile: results do not depend on B or on how a batch is
+ * split over calls.
+ */
+int64_t fv_packed_pair_floats(int C, int k);
+/* w [C, C, k] (torch.nn.Conv1d.weight of a ResBlock conv) -> the A-fragment image the pair kernels read */
+int fv_pack_pair_weight(const float* w, float* packed, int C, int k, void* stream);
+int fv_resblock1_fused(int n, const float* const* x, const float* const* w1, const float* const* w2,
+                       const float* const* b1, const float* const* b2, float* const* y, float* const* y_act,
+                       const int* k, int B, int C, int T, int dil, float slope, float act_slope, void* stream);
+
+/*
+ * End of an MRF stage (hifigan.py:97-103): the LAST pairs of the three ResBlocks and the mean, one launch:
+ *
+ *     y = post( ( sum_{j<3} pair_j(x_j) ) / out_div ),   y_act = lrelu(y, act_slope)   (as fv_conv1d_fused)
+ *
+ * pair_j as in fv_resblock1_fused (taps 11 / 7 / 3 in any order).  The three results are summed inside
+ * the fp32 accumulator rather than as ((r0 + r1) + r2): equal up to fp32 rounding of the additions.
+ * Supported: C = 16 (the three weight sets stay resident in LDS); otherwise FV_ERR_UNSUPPORTED --
+ * use fv_conv1d_fused for the first convs and the sum3 plan op / running-sum epilogues for the merge.
+ */
+int fv_mrf_stage(const float* const* x, const float* const* w1, const float* const* w2, const float* const* b1,
+                 const float* const* b2, float* y, float* y_act, const int* k, int B, int C, int T, int dil,
+                 float slope, float out_div, int post, float act_slope, void* stream);
 
 /*
  * y = post( W1 * x + W2 * x2 + bias + res )    (two 1-tap convs that are summed, as ONE GEMM)
@@ -240,6 +280,15 @@ int fv_plan_add_conv1d_sum3(fv_plan_t* plan, const int* x_slots, const int* res_
                             const int* tmp_slots, int y_slot, int y_act_slot,
                             const float* const* packed, const float* bias_sum, int C, const int* k,
                             float out_div, int post, float act_slope);
+/* fv_resblock1_fused / fv_mrf_stage as plan ops.  Consecutive resblock-pair ops appended under the same
+ * non-zero group id (fv_plan_set_group) with equal C, dilation and slopes run as ONE launch. */
+int fv_plan_add_resblock_pair(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed1,
+                              const float* packed2, const float* bias1, const float* bias2, int C, int k, int dil,
+                              float slope, float act_slope);
+int fv_plan_add_mrf_sum(fv_plan_t* plan, const int* x_slots, int y_slot, int y_act_slot,
+                        const float* const* packed1, const float* const* packed2, const float* const* bias1,
+                        const float* const* bias2, int C, const int* k, int dil, float slope, float out_div,
+                        int post, float act_slope);
 int fv_plan_add_upsample_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot,
                                 const float* packed, const float* bias, int Cin, int Cout,
                                 int k, int rate, int pad, float pre_slope, int post,
@@ -292,6 +341,8 @@ int fv_plan_num_ops(fv_plan_t* plan);
 #define FV_KERNEL_CONV_MFMA32 0 /* 32x32x2 fp32-MFMA implicit-GEMM conv (M > 16 rows) */
 #define FV_KERNEL_CONV_MFMA16 1 /* 16x16x4 fp32-MFMA implicit-GEMM conv (M <= 16 rows) */
 #define FV_KERNEL_CONV_NARROW 2 /* VALU conv for Cout <= 4 */
+#define FV_KERNEL_PAIR16 3      /* fused ResBlock pairs / MRF stage end, C = 16 (16x16x4 fp32 MFMA) */
+#define FV_KERNEL_PAIR32 4      /* fused ResBlock pairs, C = 32 */
 int fv_profile_enable(int on);
 int fv_profile_collect(int kind, int64_t* launches, double* ms, double* flops, double* bytes);
 

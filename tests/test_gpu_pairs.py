@@ -1,0 +1,152 @@
+"""GPU parity of the fused ResBlock-pair kernels (csrc/pair_kernels.hpp) through the C ABI
+(fv_resblock1_fused, fv_mrf_stage) against the C oracle's conv1d on the same seeded inputs.
+
+Tolerance: 2e-5 relative to the tensor's scale (the generator-level bound is the north star's 1e-4).
+"""
+import numpy as np
+import pytest
+import torch
+
+from fastvocoder_amd import _native
+from oracle import ops as oo
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a = a.detach().cpu().numpy().astype(np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max()))
+
+
+def _pair_ref(x, w1, b1, w2, b2, dil, slope):
+    """x + conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 (reference modules.py:223-230, one loop iteration)."""
+    k = w1.shape[2]
+    mid = oo.conv1d(x, w1, b1, dil=dil, pad=(k - 1) * dil // 2, pre_slope=slope)
+    return oo.conv1d(mid, w2, b2, dil=1, pad=(k - 1) // 2, pre_slope=slope) + x
+
+
+def _member(rng, B, C, T, k, bias=True):
+    x = rng.randn(B, C, T).astype(np.float32)
+    w1 = (rng.randn(C, C, k) / np.sqrt(C * k)).astype(np.float32)
+    w2 = (rng.randn(C, C, k) / np.sqrt(C * k)).astype(np.float32)
+    b1 = rng.randn(C).astype(np.float32) if bias else None
+    b2 = rng.randn(C).astype(np.float32) if bias else None
+    return x, w1, b1, w2, b2
+
+
+def _t(a):
+    return None if a is None else torch.from_numpy(a).to(_dev())
+
+
+PAIR_CASES = [
+    # B, C, T, dil, taps of the members, bias
+    (1, 16, 48, 1, (3,), True),            # one tile, both sequence ends inside it
+    (2, 16, 100, 3, (7,), True),
+    (1, 16, 1000, 5, (11,), True),         # several 244-column tiles
+    (2, 16, 740, 5, (11, 7, 3), True),     # the MRF trio in one launch, ragged last tiles
+    (1, 16, 2000, 1, (3, 7, 11), False),   # member order free, no bias
+    (1, 32, 64, 1, (11,), True),
+    (2, 32, 500, 3, (11, 7, 3), True),     # 116 / 120 / 124-column tiles
+    (1, 32, 1204, 5, (7, 3, 11), True),
+    (3, 32, 236, 5, (3,), False),
+    (1, 16, 4, 5, (11,), True),            # shorter than every halo
+]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_resblock_pair_vs_oracle(case):
+    B, C, T, dil, ks, bias = case
+    rng = np.random.RandomState(abs(hash(case)) % (2 ** 31))
+    ms = [_member(rng, B, C, T, k, bias) for k in ks]
+    refs = [_pair_ref(x, w1, b1, w2, b2, dil, 0.1) for x, w1, b1, w2, b2 in ms]
+    xs = [_t(m[0]) for m in ms]
+    w1s = [_native.pack_pair(_t(m[1])) for m in ms]
+    w2s = [_native.pack_pair(_t(m[3])) for m in ms]
+    ys = _native.resblock1_fused(xs, w1s, w2s, [_t(m[2]) for m in ms], [_t(m[4]) for m in ms], list(ks), dil, 0.1)
+    for y, ref in zip(ys, refs):
+        assert _rel(y, ref) <= 2e-5
+    # activated twin next to the raw output, and the in-place form
+    acts = [torch.empty_like(x) for x in xs]
+    ys2 = _native.resblock1_fused(xs, w1s, w2s, [_t(m[2]) for m in ms], [_t(m[4]) for m in ms], list(ks), dil, 0.1,
+                                  act_slope=0.2, outs_act=acts)
+    for y, a, ref in zip(ys2, acts, refs):
+        assert _rel(y, ref) <= 2e-5
+        assert _rel(a, oo.lrelu(ref, 0.2)) <= 2e-5
+    ys3 = _native.resblock1_fused(xs, w1s, w2s, [_t(m[2]) for m in ms], [_t(m[4]) for m in ms], list(ks), dil, 0.1,
+                                  act_slope=0.2)
+    for y, ref in zip(ys3, refs):
+        assert _rel(y, oo.lrelu(ref, 0.2)) <= 2e-5
+
+
+@pytest.mark.parametrize("case", [(1, 244, 5), (2, 1000, 5), (1, 100, 1), (3, 488, 3), (1, 8, 5), (1, 2444, 5)],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_mrf_stage_vs_oracle(case):
+    B, T, dil = case
+    C = 16
+    rng = np.random.RandomState(1000 * T + dil)
+    ks = (3, 11, 7)                                       # any member order
+    ms = [_member(rng, B, C, T, k, True) for k in ks]
+    total = sum(_pair_ref(x, w1, b1, w2, b2, dil, 0.1).astype(np.float64) for x, w1, b1, w2, b2 in ms)
+    ref = (total / 3.0).astype(np.float32)
+    xs = [_t(m[0]) for m in ms]
+    w1s = [_native.pack_pair(_t(m[1])) for m in ms]
+    w2s = [_native.pack_pair(_t(m[3])) for m in ms]
+    b1s, b2s = [_t(m[2]) for m in ms], [_t(m[4]) for m in ms]
+    y = _native.mrf_stage(xs, w1s, w2s, b1s, b2s, list(ks), dil, 0.1, out_div=3.0)
+    assert _rel(y, ref) <= 2e-5
+    act = torch.empty_like(y)
+    y2 = _native.mrf_stage(xs, w1s, w2s, b1s, b2s, list(ks), dil, 0.1, out_div=3.0, act_slope=0.01, out_act=act)
+    assert _rel(y2, ref) <= 2e-5 and _rel(act, oo.lrelu(ref, 0.01)) <= 2e-5
+    y3 = _native.mrf_stage(xs, w1s, w2s, b1s, b2s, list(ks), dil, 0.1, out_div=3.0, post=_native.POST_TANH)
+    assert _rel(y3, np.tanh(ref.astype(np.float64))) <= 2e-5
+
+
+def test_pair_results_do_not_depend_on_the_batch():
+    """Bit-identity: an utterance gives the same bits alone and inside a batch (what lets a batch be
+    sharded over GPUs), for the plain and the sum kernels, on both channel counts."""
+    rng = np.random.RandomState(7)
+    for C, T in ((16, 1500), (32, 700)):
+        ks = (11, 7, 3)
+        ms = [_member(rng, 3, C, T, k, True) for k in ks]
+        xs = [_t(m[0]) for m in ms]
+        w1s = [_native.pack_pair(_t(m[1])) for m in ms]
+        w2s = [_native.pack_pair(_t(m[3])) for m in ms]
+        b1s, b2s = [_t(m[2]) for m in ms], [_t(m[4]) for m in ms]
+        full = _native.resblock1_fused(xs, w1s, w2s, b1s, b2s, list(ks), 3, 0.1)
+        for b in range(3):
+            one = _native.resblock1_fused([x[b:b + 1].contiguous() for x in xs], w1s, w2s, b1s, b2s, list(ks), 3, 0.1)
+            for yf, yo in zip(full, one):
+                assert torch.equal(yf[b:b + 1], yo)
+        if C == 16:
+            fs = _native.mrf_stage(xs, w1s, w2s, b1s, b2s, list(ks), 5, 0.1)
+            for b in range(3):
+                os_ = _native.mrf_stage([x[b:b + 1].contiguous() for x in xs], w1s, w2s, b1s, b2s, list(ks), 5, 0.1)
+                assert torch.equal(fs[b:b + 1], os_)
+
+
+def test_pair_rejects_what_it_is_not_built_for():
+    dev = _dev()
+    x = torch.zeros((1, 16, 50), device=dev)              # T % 4 != 0
+    w = _native.pack_pair(torch.zeros((16, 16, 3), device=dev))
+    with pytest.raises(_native.NativeError, match="multiple of 4"):
+        _native.resblock1_fused([x], [w], [w], [None], [None], [3], 1, 0.1)
+    x64 = torch.zeros((1, 64, 64), device=dev)
+    w64 = _native.pack_pair(torch.zeros((64, 64, 3), device=dev))
+    with pytest.raises(_native.NativeError, match="C = 64"):
+        _native.resblock1_fused([x64], [w64], [w64], [None], [None], [3], 1, 0.1)
+    x16 = torch.zeros((1, 16, 64), device=dev)
+    with pytest.raises(_native.NativeError, match="taps"):
+        _native.resblock1_fused([x16], [w], [w], [None], [None], [5], 1, 0.1)
+    with pytest.raises(_native.NativeError, match="dilation"):
+        _native.resblock1_fused([x16], [w], [w], [None], [None], [3], 2, 0.1)
+    x32 = torch.zeros((1, 32, 64), device=dev)
+    w32 = _native.pack_pair(torch.zeros((32, 32, 3), device=dev))
+    with pytest.raises(_native.NativeError, match="mrf"):
+        _native.mrf_stage([x32] * 3, [w32] * 3, [w32] * 3, [None] * 3, [None] * 3, [3, 7, 11], 5, 0.1)

@@ -164,7 +164,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_native.LIB_PATH)
     for n in sorted(names):
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
-    assert _native.lib().fv_version() == 6
+    assert _native.lib().fv_version() == _native.ABI_VERSION
     # host-only entry points that need no device
     assert _native.lib().fv_packed_conv1d_floats(128, 128, 11) == 128 * 11 * 128
     # k = 2*stride, Cout % 32 == 0: phase-major form, 2 taps per phase (3 in the co-major form)

@@ -1,0 +1,52 @@
+"""Per-launch timing of the fused ResBlock-pair kernels at the HiFi-GAN light stage sizes
+(tuning aid; knobs: FV_PAIR_BLOCKS, FV_PAIR_DBG).  python tools/pair_bench.py [C] [T] [B]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fastvocoder_amd import _native  # noqa: E402
+
+
+def bench(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+
+
+def main():
+    C = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    T = int(sys.argv[2]) if len(sys.argv) > 2 else (240000 if C == 16 else 120000)
+    B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(0)
+    ks = [11, 7, 3]
+    xs = [torch.randn((B, C, T), generator=g).to(dev) for _ in ks]
+    w1 = [_native.pack_pair((torch.randn((C, C, k), generator=g) / (C * k) ** 0.5).to(dev)) for k in ks]
+    w2 = [_native.pack_pair((torch.randn((C, C, k), generator=g) / (C * k) ** 0.5).to(dev)) for k in ks]
+    bs = [torch.randn(C, generator=g).to(dev) for _ in ks]
+    ys = [torch.empty_like(x) for x in xs]
+    tag = f"C={C} T={T} B={B} blocks={os.environ.get('FV_PAIR_BLOCKS', '-')} dbg={os.environ.get('FV_PAIR_DBG', '0')}"
+    for dil in (1, 3, 5):
+        us = bench(lambda: _native.resblock1_fused(xs, w1, w2, bs, bs, ks, dil, 0.1, outs=ys))
+        fl = sum(2 * 2 * B * C * C * k * T for k in ks)
+        print(f"{tag} pairs dil={dil}: {us:8.1f} us  {fl / us / 1e6:6.1f} TFLOP/s")
+        for j, k in enumerate(ks):
+            us = bench(lambda: _native.resblock1_fused([xs[j]], [w1[j]], [w2[j]], [bs[j]], [bs[j]], [k], dil, 0.1,
+                                                       outs=[ys[j]]))
+            print(f"{tag}   member k={k:2d} alone: {us:8.1f} us  {2 * 2 * B * C * C * k * T / us / 1e6:6.1f} TFLOP/s")
+    if C == 16:
+        us = bench(lambda: _native.mrf_stage(xs, w1, w2, bs, bs, ks, 5, 0.1, out=ys[0]))
+        print(f"{tag} mrf_stage dil=5: {us:8.1f} us  {sum(2 * 2 * B * C * C * k * T for k in ks) / us / 1e6:6.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
