@@ -1,22 +1,30 @@
 """Headline benchmark: HiFi-GAN-light generator inference on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config light|large512]
 
-Workload (BASELINE.json configs[1]): conf/hifigan/light.yaml, batch = 1 utterance
-per GPU, mel 80 x 1000 frames of synthetic U[0,1) data already resident in HBM,
-seeded gain-calibrated random-init weights (no checkpoint exists offline),
-weight norm folded.  One "step" = one ``Generator.forward`` over the per-GPU
-batch -> 240 000 samples per utterance.  N > 1 (launched by torch.distributed.run,
-one rank per GPU): weights are built on rank 0 and broadcast over RCCL once,
-every rank then runs its own utterances (weak scaling: the path has no exchange
-step, so the timed steps contain no collective); one root gather after the timed
-region checks the RCCL data path, and ``--gather`` puts an asynchronous per-step
-gather inside the timed region instead.
+Default workload (BASELINE.json configs[1]): conf/hifigan/light.yaml, batch = 1 utterance per GPU,
+mel 80 x 1000 frames of synthetic U[0,1) data already resident in HBM, seeded gain-calibrated
+random-init weights (no checkpoint exists offline), weight norm folded.  One "step" = one
+``Generator.forward`` over the per-GPU batch -> 240 000 samples per utterance.  Utterance 0 is the
+mel the committed reference golden was made from, and the LAST timed output is checked against that
+golden (<= 1e-4, the north star's bound) before anything is printed: the timed forward is the
+parity-checked forward.
 
-Prints ONE JSON line: value = whole-job audio samples / second, plus RTF at
-22.05 kHz and 24 kHz, the roofline of the dominant kernel (fp32-MFMA implicit-GEMM
-conv, per-launch HIP-event timing on the launch stream), and the reference's CPU
-path (its ATen op sequence, oracle/torch_port.py) timed on this host's cores.
+N > 1 (launched by torch.distributed.run, one rank per GPU): weights are built on rank 0 and broadcast
+over RCCL once; every rank runs its own utterances (weak scaling: the path has no exchange step) and
+every step's waveforms are gathered to rank 0 INSIDE the timed region (asynchronously, overlapping the
+next step's forward); the same steps without the gather are timed too and reported beside it.
+
+``--config large512`` (BASELINE.json configs[4]): HiFi-GAN large, 512 utterances of 80 x 1000 per step --
+a fixed job (strong scaling): rank 0 holds the mels, scatters one block per rank, every rank synthesises
+its block and encodes it to int16 on the GPU (fv_encode_16bits), rank 0 gathers the int16 waveforms;
+scatter, forward, encode and gather are all inside the timed step, and rank 0 checks gathered rows
+against its own single-utterance runs bit for bit.
+
+Prints ONE JSON line: value = whole-job audio samples / second, plus RTF at 22.05 kHz and 24 kHz, the
+roofline of the dominant kernel family (fp32-MFMA convs, per-launch HIP events on the launch stream),
+the C = 16 stage against the memory roofline, and the reference's CPU path (its ATen op sequence,
+oracle/torch_port.py) timed on this host's cores.
 """
 import argparse
 import json
@@ -34,10 +42,13 @@ from fastvocoder_amd import _native  # noqa: E402
 from fastvocoder_amd.bin.synthesize import build_generator  # noqa: E402
 from fastvocoder_amd.synthetic import seeded_mel, seeded_state_dict  # noqa: E402
 
-MODEL, CONF = "hifigan", "conf/hifigan/light.yaml"
+MODEL = "hifigan"
+CONFS = {"light": "conf/hifigan/light.yaml", "large512": "conf/hifigan/large.yaml"}
 T_FRAMES = 1000
+JOB_UTTERANCES = int(os.environ.get("FV_BENCH_JOB", "512"))   # --config large512 (the env override is for tests)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0
+TOL = 1e-4                      # north star: outputs match the reference generator within 1e-4 fp32 max-abs
 
 
 def baseline_metric():
@@ -49,10 +60,27 @@ def baseline_metric():
         return "audio samples/sec + RTF @22.05kHz, HiFi-GAN-light, 1/2/4/8 MI355X"
 
 
-def load_conf():
+def load_conf(config):
     import yaml
-    with open(os.path.join(ROOT, CONF)) as f:
+    with open(os.path.join(ROOT, CONFS[config])) as f:
         return yaml.safe_load(f)
+
+
+def utterance_mels(first, count):
+    """[count, 80, T] forward-layout mels of the global utterances first .. first+count-1; utterance i is
+    ``seeded_mel(T, seed=1+i)``: utterance 0 is the mel of tests/golden/full_hifigan_light.npz (seed 1)."""
+    return np.stack([seeded_mel(T_FRAMES, seed=1 + first + i).T for i in range(count)]).astype(np.float32)
+
+
+def check_against_golden(wav_row):
+    """The generator output for utterance 0 against the reference's own output (strided samples of
+    tests/golden/full_hifigan_light.npz, written by tests/golden/make_golden.py from /root/reference)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "full_hifigan_light.npz"))
+    y = wav_row.double().cpu().numpy().reshape(-1)
+    assert y.size == int(g["T1000_n"]), (y.size, int(g["T1000_n"]))
+    err = float(np.abs(y[g["T1000_idx"]] - g["T1000_samples"]).max())
+    assert err <= TOL, f"timed output differs from the reference golden by {err:.3e} > {TOL}"
+    return err
 
 
 def cpu_baseline(cfg, sd, mel):
@@ -110,18 +138,120 @@ def timed_steps(step, steps, warmup, dist, dev, after=None):
     return elapsed, out
 
 
+def survey_bytes_c16_stage(model, B, T_stage):
+    """SURVEY.md section 8(d) bytes of the 16-channel stage: every conv's input and output tensor once, the
+    residual read of each second conv, the weights -- the layer-by-layer (unfused) accounting."""
+    total = 0.0
+    for rb in model.resblocks[-model.num_kernels:]:
+        for c1, c2 in zip(rb.convs1, rb.convs2):
+            act = 4.0 * B * c1.in_channels * T_stage
+            total += 2 * act + 4.0 * c1.weight.numel()            # conv1: in + out
+            total += 3 * act + 4.0 * c2.weight.numel()            # conv2: in + out + residual
+    return total
+
+
+def roofline_report(model, mel, ms_per_step, reps=5):
+    """Per-launch timing of the conv kernel families with HIP events on the launch stream (single-stream
+    replay of the same forward), event-bracket cost calibrated out."""
+    os.environ["FV_SINGLE_LANE"] = "1"
+    for _ in range(2):
+        with torch.no_grad():
+            model(mel)
+    torch.cuda.synchronize()
+    bracket_ms = _native.profile_bracket_cost(200)
+    _native.profile_enable(True)
+    for _ in range(reps):
+        with torch.no_grad():
+            model(mel)
+    torch.cuda.synchronize()
+    _native.profile_enable(False)
+    del os.environ["FV_SINGLE_LANE"]
+    kinds = {"conv32": _native.KERNEL_CONV_MFMA32, "conv16": _native.KERNEL_CONV_MFMA16,
+             "pair16": _native.KERNEL_PAIR16, "pair32": _native.KERNEL_PAIR32, "narrow": _native.KERNEL_CONV_NARROW}
+    rec = {k: _native.profile_collect(v) for k, v in kinds.items()}
+    for r in rec.values():
+        r["ms"] = max(r["ms"] - bracket_ms * r["launches"], 0.0)
+    mf = [rec[k] for k in ("conv32", "conv16", "pair16", "pair32")]
+    launches = sum(r["launches"] for r in mf)
+    ms = sum(r["ms"] for r in mf)
+    flops = sum(r["flops"] for r in mf)
+    nbytes = sum(r["bytes"] for r in mf)
+    all_ms = (ms + rec["narrow"]["ms"]) / reps
+    # Sum of kernel time must fit inside the step; if the calibration ever fails that test, fall back to
+    # the whole-step figure (launch gaps included: a lower bound of the kernels' rate)
+    consistent = all_ms <= ms_per_step * 1.001
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 and consistent else flops / reps / (ms_per_step * 1e-3) / 1e12
+    traffic, traffic_src = None, None
+    pdir = os.path.join(ROOT, "profiles")
+    for cand in sorted((f for f in os.listdir(pdir) if f.endswith("_hbm_traffic.json")), reverse=True) \
+            if os.path.isdir(pdir) else []:
+        with open(os.path.join(pdir, cand)) as f:
+            traffic = json.load(f)["conv_mfma_family"]["hbm_bytes_per_launch"]
+        traffic_src = "profiles/" + cand
+        break
+    roofline = {
+        "kernel": "fp32-MFMA conv family: fv::pair_kernel / fv::pair_sum_kernel (fused ResBlock pairs, 16x16x4, "
+                  "csrc/pair_kernels.hpp) + fv::conv_group3_kernel / conv_sum3_kernel / conv_mfma_kernel "
+                  "(implicit-GEMM conv1d, 32x32x2, csrc/conv_kernels.hpp): 77 of the 78 convs of a forward",
+        "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+        "traffic": traffic,
+        "traffic_unit": "HBM bytes per launch; committed OFFLINE rocprofv3 PMC pass of this command, not this run",
+        "traffic_source": traffic_src,
+        "algorithmic_bytes_per_launch": nbytes / max(launches, 1),
+        "measured": "per-launch HIP events on the launch stream, single-stream replay of the same forward, "
+                    f"event-bracket cost ({bracket_ms * 1e3:.2f} us per launch) subtracted"
+                    + ("" if consistent else "; INCONSISTENT with the step time -> whole-step figure used"),
+        "achieved_whole_step": flops / reps / (ms_per_step * 1e-3) / 1e12,
+        "frac_whole_step": flops / reps / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+        "launches_per_step": launches // reps,
+        "avg_launch_us": 1e3 * ms / max(launches, 1),
+        "algorithmic_gflop_per_step": flops / reps / 1e9,
+        "kernel_ms_per_step": ms / reps,
+        "narrow_conv_ms_per_step": rec["narrow"]["ms"] / reps,
+        "by_family_ms_per_step": {k: r["ms"] / reps for k, r in rec.items()},
+        "by_family_tflops": {k: (r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0) for k, r in rec.items()},
+    }
+    # The HBM-bound members (north star: "memory roofline on the dilated-conv kernels"): the 16-channel stage,
+    # 12-44 FLOP/B, with SURVEY.md section 8(d)'s layer-by-layer bytes over the time of its launches
+    stage = rec["pair16"] if rec["pair16"]["launches"] else rec["conv16"]
+    B = mel.shape[0]
+    t_stage = T_FRAMES
+    for up in model.ups:
+        t_stage *= up.stride[0]
+    survey = survey_bytes_c16_stage(model, B, t_stage) if model.resblocks[-1].channels == 16 else 0.0
+    st_ms = stage["ms"] / reps
+    hbm = {
+        "kernel": "the C = 16 stage of the generator (18 dilated / plain 16-channel convs on 240 000 samples): "
+                  + ("2 fused-pair launches + the fused MRF stage end (fv::pair_kernel, fv::pair_sum_kernel)"
+                     if rec["pair16"]["launches"] else "16x16x4-MFMA conv launches"),
+        "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
+        "achieved": survey / (st_ms * 1e-3) / 1e9 if st_ms > 0 else 0.0,
+        "frac": survey / (st_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if st_ms > 0 else 0.0,
+        "bytes": survey, "bytes_rule": "SURVEY.md section 8(d): every conv's input and output once + the residual "
+                                       "read + weights, layer by layer (unfused accounting)",
+        "fused_external_bytes": stage["bytes"] / reps,
+        "ms": st_ms, "launches_per_step": stage["launches"] // reps,
+        "tflops": stage["flops"] / (stage["ms"] * 1e-3) / 1e12 if stage["ms"] > 0 else 0.0,
+        "measured": "per-launch HIP events (bracket cost subtracted); HBM traffic by PMC: profiles/",
+    }
+    return roofline, hbm
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(CONFS), default="light")
+    ap.add_argument("--batch", type=int, default=1, help="light: utterances per GPU per step")
+    ap.add_argument("--sub", type=int, default=16, help="large512: utterances per forward call on a rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", action="store_true",
-                    help="N > 1: also gather every step's waveforms to rank 0 inside the timed region "
-                         "(asynchronously, overlapping the next step); default: utterances stay on "
-                         "the rank that made them and one gather after the timed region checks the path")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="light, N > 1: leave the waveforms on the ranks that made them (headline without the gather)")
     args = ap.parse_args()
+    steps = args.steps if args.steps is not None else (50 if args.config == "light" else 2)
+    warmup = args.warmup if args.warmup is not None else (5 if args.config == "light" else 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -133,7 +263,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    # FV_BENCH_FORCE_DIST=1: take the N > 1 code path (RCCL init, broadcast, gather, barrier,
+    # FV_BENCH_FORCE_DIST=1: take the N > 1 code path (RCCL init, broadcast, scatter, gather, barrier,
     # all-reduce) with a single rank too -- a self-test of that path on a 1-GPU box
     force_dist = os.environ.get("FV_BENCH_FORCE_DIST", "0") == "1"
     if world > 1 or force_dist:
@@ -141,7 +271,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    cfg = load_conf()
+    cfg = load_conf(args.config)
     from fastvocoder_amd import parallel
     model = build_generator(MODEL, cfg)
     sd = seeded_state_dict(MODEL, cfg, seed=0) if rank == 0 else None
@@ -152,149 +282,131 @@ def main():
         parallel.broadcast_weights(model, src=0)          # RCCL broadcast, once
     model.remove_weight_norm()
 
-    B = args.batch
-    mel = torch.from_numpy(seeded_mel(T_FRAMES, seed=100 + rank, batch=B)).to(dev)
-    gather = parallel.WaveformGather(world, rank, dev) if dist is not None else None
+    extra = {}
+    if args.config == "light":
+        B = args.batch
+        mel = torch.from_numpy(utterance_mels(rank * B, B)).to(dev)
+        gather = parallel.WaveformGather(world, rank, dev) if dist is not None else None
 
-    def step():
+        def make_step(with_gather):
+            def step():
+                with torch.no_grad():
+                    wav = model(mel)
+                if with_gather:
+                    gather(wav)           # asynchronous: overlaps the next step's forward
+                return wav
+
+            def done():
+                if with_gather:
+                    gather.flush()        # the last gather belongs to the timed region
+            return step, done
+
+        # model load, not a step: the first call folds weight norm and packs every layer's weights on the
+        # GPU (the plan), which later calls replay -- done here so that even --warmup 0 times steps only
         with torch.no_grad():
-            wav = model(mel)
-        if gather is not None and args.gather:
-            gather(wav)           # asynchronous: overlaps the next step's forward
-        return wav
+            model(mel)
+        torch.cuda.synchronize()
+        use_gather = gather is not None and not args.no_gather
+        step, done = make_step(use_gather)
+        elapsed, wav = timed_steps(step, steps, warmup, dist, dev, after=done)
+        if use_gather:
+            bufs = gather.flush()
+            if rank == 0:          # rank 0 holds every rank's last waveforms, its own block bit for bit
+                assert len(bufs) == world and all(tuple(b.shape) == tuple(wav.shape) for b in bufs)
+                assert torch.equal(bufs[0], wav)
+            step2, done2 = make_step(False)
+            e2, _ = timed_steps(step2, steps, warmup, dist, dev, after=done2)
+            extra["without_gather"] = {"ms_per_step": 1e3 * e2 / steps,
+                                       "what": "the same steps with the waveforms left on the ranks that made them"}
+        samples_per_utt = int(wav.shape[-1])
+        utt_per_step = B * world
+        golden_err = check_against_golden(wav[0]) if rank == 0 else None
+        workload = (f"HiFi-GAN light (conf/hifigan/light.yaml) generator forward, mel 80x{T_FRAMES}, batch {B} "
+                    f"utterance(s) per GPU, {samples_per_utt} samples each; BASELINE.json configs[1]"
+                    + ("; waveforms gathered to rank 0 inside the timed steps" if use_gather else ""))
+        scaling = "weak"
+    else:
+        # ---- the fixed 512-utterance job, BASELINE.json configs[4] ----
+        total_utt = JOB_UTTERANCES
+        mels = torch.from_numpy(utterance_mels(0, total_utt)).to(dev) if rank == 0 else None
+        from fastvocoder_amd import audio
 
-    def last_step_done():
-        if gather is not None and args.gather:
-            gather.flush()        # the last gather belongs to the timed region
+        def rank_block(block):
+            outs = []
+            with torch.no_grad():
+                for a in range(0, block.shape[0], args.sub):
+                    w = model(block[a:a + args.sub].contiguous())
+                    outs.append(audio.encode_16bits(w, 1.0))      # per-row peak normalise -> int16, on the GPU
+            return torch.cat(outs, dim=0)
 
-    # model load, not a step: the first call folds weight norm and packs every layer's weights on
-    # the GPU (the plan), which later calls replay -- done here so that even --warmup 0 times steps only
-    with torch.no_grad():
-        model(mel)
-    torch.cuda.synchronize()
-    elapsed, wav = timed_steps(step, args.steps, args.warmup, dist, dev, after=last_step_done)
+        def step():
+            if dist is None:
+                return rank_block(mels)
+            return parallel.synthesize_sharded(rank_block, mels, world, rank, scatter=True, device=dev)
 
-    if gather is not None and not args.gather:
-        # outside the timed region: one root gather, so that the RCCL data path is exercised and
-        # rank 0 ends up holding every rank's last waveforms, as a serving front-end would
-        gather(wav)
-        bufs = gather.flush()
+        rank_block(torch.from_numpy(utterance_mels(0, min(args.sub, 2))).to(dev))   # plan build, not a step
+        torch.cuda.synchronize()
+        elapsed, pcm = timed_steps(step, steps, warmup, dist, dev)
+        golden_err = None
         if rank == 0:
-            assert len(bufs) == world and all(tuple(b.shape) == tuple(wav.shape) for b in bufs)
-            assert torch.equal(bufs[0], wav)
-    samples_per_utt = int(wav.shape[-1])
-    total_samples = samples_per_utt * B * world * args.steps
-    value = total_samples / elapsed
-    ms_per_step = 1e3 * elapsed / args.steps
+            assert pcm.dtype == torch.int16 and pcm.shape[0] == total_utt
+            # gathered rows == this rank's own single-utterance runs of the same mels, bit for bit
+            per = (total_utt + world - 1) // world
+            for idx in sorted({0, 1, per - 1, per % total_utt, total_utt - 1}):
+                one = rank_block(mels[idx:idx + 1])
+                assert torch.equal(one[0], pcm[idx]), f"utterance {idx} differs between the sharded job and a solo run"
+        samples_per_utt = int(pcm.shape[-1]) if rank == 0 else 240 * T_FRAMES
+        utt_per_step = total_utt
+        workload = (f"HiFi-GAN large (conf/hifigan/large.yaml), {total_utt} utterances of mel 80x{T_FRAMES} per step "
+                    f"sharded over {world} GPU(s): scatter of mels from rank 0, forward in sub-batches of {args.sub}, "
+                    "int16 wav sink on the GPU, gather to rank 0 -- all inside the timed step; BASELINE.json configs[4]")
+        scaling = "strong"
+        mel = None
 
-    out = None
+    total_samples = samples_per_utt * utt_per_step * steps
+    value = total_samples / elapsed
+    ms_per_step = 1e3 * elapsed / steps
+
     if rank == 0:
-        # per-launch timing of the dominant kernel family with HIP events on the launch stream.
-        # A per-launch duration is only well defined without stream overlap, so this leg pins
-        # the replay of the same forward to ONE stream (FV_SINGLE_LANE, read by fv_plan_run at
-        # every call; the default grouped plan already is single-stream, FV_MRF=lanes is not).
-        os.environ["FV_SINGLE_LANE"] = "1"
-        for _ in range(2):
-            with torch.no_grad():
-                model(mel)
-        torch.cuda.synchronize()
-        _native.profile_enable(True)
-        reps = 5
-        for _ in range(reps):
-            with torch.no_grad():
-                model(mel)
-        torch.cuda.synchronize()
-        _native.profile_enable(False)
-        del os.environ["FV_SINGLE_LANE"]
-        p32 = _native.profile_collect(_native.KERNEL_CONV_MFMA32)
-        p16 = _native.profile_collect(_native.KERNEL_CONV_MFMA16)
-        q16 = _native.profile_collect(_native.KERNEL_PAIR16)
-        q32 = _native.profile_collect(_native.KERNEL_PAIR32)
-        for k in ("launches", "ms", "flops", "bytes"):
-            p16[k] += q16[k]
-            p32[k] += q32[k]
-        pn = _native.profile_collect(_native.KERNEL_CONV_NARROW)
-        mf_launch, mf_ms, mf_flops = (p32["launches"] + p16["launches"], p32["ms"] + p16["ms"],
-                                      p32["flops"] + p16["flops"])
-        achieved = mf_flops / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
-        # HBM bytes per launch of this kernel family from the committed rocprofv3 PMC
-        # passes of this same command (tools/pmc_traffic.py: (2*FETCH_SIZE + WRITE_SIZE)*1024)
-        traffic, traffic_src = None, None
-        for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles"))
-                            if f.endswith("_hbm_traffic.json")), reverse=True) \
-                if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-            with open(os.path.join(ROOT, "profiles", cand)) as f:
-                traffic = json.load(f)["conv_mfma_family"]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/" + cand
-            break
-        roofline = {
-            "kernel": "fv::conv_mfma_kernel / fv::conv_group3_kernel / fv::conv_sum3_kernel (fp32-MFMA "
-                      "implicit-GEMM conv1d, csrc/conv_kernels.hpp: every Conv1d / ConvTranspose1d layer with "
-                      "Cout > 4 = 77 of the 78 convs of a forward; the 3 ResBlock convs of an MRF position "
-                      "share one launch)",
-            "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (PMC, offline pass)", "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": (p32["bytes"] + p16["bytes"]) / max(mf_launch, 1),
-            "measured": "per-launch HIP events, single-stream replay of the same forward",
-            # the timed (multi-stream) step as a whole: algorithmic FLOP of one forward / step time
-            "achieved_whole_step": mf_flops / reps / (ms_per_step * 1e-3) / 1e12,
-            "frac_whole_step": mf_flops / reps / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-            "launches_per_step": mf_launch // reps,
-            "avg_launch_us": 1e3 * mf_ms / max(mf_launch, 1),
-            "algorithmic_gflop_per_step": mf_flops / reps / 1e9,
-            "kernel_ms_per_step": mf_ms / reps,
-            "hbm_GBps_algorithmic": (p32["bytes"] + p16["bytes"]) / (mf_ms * 1e-3) / 1e9 if mf_ms > 0 else 0.0,
-            "narrow_conv_ms_per_step": pn["ms"] / reps,
-        }
-        # The HBM-bound members of the same family, which the north star names ("memory roofline on
-        # the dilated-conv kernels"): the C = 16 stage (12-44 FLOP/B, below the 20 FLOP/B ridge for the
-        # 3-tap layers) runs in the 16x16x4-MFMA instantiations -- algorithmic bytes / their HIP-event time
-        roofline_hbm = {
-            "kernel": "the C = 16 stage of the generator (5 grouped + 1 merged launch of dilated / plain "
-                      "16-channel convs, 240 000 samples each): 16x16x4-MFMA instantiations of the same conv body",
-            "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
-            "achieved": p16["bytes"] / (p16["ms"] * 1e-3) / 1e9 if p16["ms"] > 0 else 0.0,
-            "frac": p16["bytes"] / (p16["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS if p16["ms"] > 0 else 0.0,
-            "launches_per_step": p16["launches"] // reps,
-            "tflops": p16["flops"] / (p16["ms"] * 1e-3) / 1e12 if p16["ms"] > 0 else 0.0,
-            "measured": "algorithmic bytes (each tensor once) / per-launch HIP events; traffic by PMC: profiles/",
-        }
         dur22, dur24 = total_samples / 22050.0, total_samples / 24000.0
         out = {
             "metric": baseline_metric(), "value": value, "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "rtf_22k05": elapsed / dur22, "rtf_24k": elapsed / dur24,
-            "config": {"workload": "HiFi-GAN light (conf/hifigan/light.yaml) generator forward, "
-                                   f"mel 80x{T_FRAMES}, batch {B} utterance(s) per GPU, "
-                                   f"{samples_per_utt} samples each; BASELINE.json configs[1]",
-                       "global_batch": B * world, "frames": T_FRAMES,
-                       "parallelism": f"utterance-sharded x{world}" if world > 1 else "single GPU",
-                       "convs_per_forward": model._trunk_plan(T_FRAMES).num_ops()},
-            "roofline": roofline,
-            "roofline_hbm_stage": roofline_hbm,
+            "config": {"workload": workload, "global_batch": utt_per_step, "frames": T_FRAMES,
+                       "parallelism": f"utterance-sharded x{world}" if world > 1 else "single GPU"},
         }
-        # PCIe-inclusive rate of the drop-in boundary (never `value`): Generator.inference takes a
-        # HOST mel [T,80] and the caller wants a HOST waveform -- pageable numpy in, numpy out,
-        # one utterance per call, fully synchronous (H2D + forward + D2H per call)
-        if world == 1:
-            mel_np = seeded_mel(T_FRAMES, seed=100)
-            for _ in range(3):
-                model.inference(mel_np).cpu()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            reps_io = 20
-            for _ in range(reps_io):
-                y_host = model.inference(mel_np).cpu().numpy()
-            dt = (time.perf_counter() - t0) / reps_io
-            out["host_to_host"] = {"ms_per_utterance": 1e3 * dt, "samples_per_s": y_host.size / dt,
-                                   "what": "Generator.inference(numpy mel) -> numpy waveform, per call: "
-                                           "H2D 320 KB + forward + D2H 960 KB, pageable memory, synchronous"}
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, seeded_mel(T_FRAMES, seed=100))
-            out["cpu_baseline"]["rtf_22k05"] = out["cpu_baseline"]["seconds"] / (samples_per_utt / 22050.0)
+        if golden_err is not None:
+            out["parity"] = {"max_abs_vs_reference_golden": golden_err, "tolerance": TOL,
+                             "what": "last timed output, utterance 0, vs tests/golden/full_hifigan_light.npz "
+                                     "(the reference's own output for this mel and these weights)"}
+        out.update(extra)
+        if args.config == "light":
+            out["config"]["plan_ops_per_forward"] = model._trunk_plan(T_FRAMES).num_ops()
+            roofline, hbm = roofline_report(model, mel, ms_per_step)
+            out["roofline"] = roofline
+            out["roofline_hbm_stage"] = hbm
+            # PCIe-inclusive rate of the drop-in boundary (never `value`): Generator.inference takes a
+            # HOST mel [T,80] and the caller wants a HOST waveform -- pageable numpy in, numpy out,
+            # one utterance per call, fully synchronous (H2D + forward + D2H per call)
+            if world == 1:
+                mel_np = seeded_mel(T_FRAMES, seed=1)
+                for _ in range(3):
+                    model.inference(mel_np).cpu()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                reps_io = 20
+                for _ in range(reps_io):
+                    y_host = model.inference(mel_np).cpu().numpy()
+                dt = (time.perf_counter() - t0) / reps_io
+                out["host_to_host"] = {"ms_per_utterance": 1e3 * dt, "samples_per_s": y_host.size / dt,
+                                       "what": "Generator.inference(numpy mel) -> numpy waveform, per call: "
+                                               "H2D 320 KB + forward + D2H 960 KB, pageable memory, synchronous"}
+            if not args.no_cpu_baseline and world == 1:
+                out["cpu_baseline"] = cpu_baseline(cfg, sd, seeded_mel(T_FRAMES, seed=1))
+                out["cpu_baseline"]["rtf_22k05"] = out["cpu_baseline"]["seconds"] / (samples_per_utt / 22050.0)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -32,17 +32,43 @@ class NativeError(RuntimeError):
     pass
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over every source of the library and the extra compiler flags: the
+    build id the .so carries (fv_build_id), so that a binary can be proven to be built from this tree."""
+    import hashlib
+    h = hashlib.sha256()
+    paths = [os.path.join(_CSRC, s) for s in SOURCES] + [os.path.join(_CSRC, x) for x in HEADERS] + \
+        [os.path.join(_HERE, "..", "include", "fastvocoder_hip.h")]
+    for path in paths:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(os.environ.get("FV_HIPCC_FLAGS", "").encode())
+    return h.hexdigest()[:16]
+
+
+def built_id():
+    """Build id of the .so on disk, or None when it is missing / predates build ids."""
+    if not os.path.exists(LIB_PATH):
+        return None
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+        L.fv_build_id.restype = ctypes.c_char_p
+        return L.fv_build_id().decode()
+    except (OSError, AttributeError):
+        return None
+
+
 def build(force=False, verbose=False):
     """hipcc the kernels for gfx950 into fastvocoder_amd/libfastvocoder_hip.so
-    (cross-compiles without a GPU): one object per source, compiled in parallel, then linked."""
+    (cross-compiles without a GPU): one object per source, compiled in parallel, then linked.
+    Up to date <=> the library's embedded build id equals the hash of the sources."""
     srcs = [os.path.join(_CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(_CSRC, h) for h in HEADERS] + \
-        [os.path.join(_HERE, "..", "include", "fastvocoder_hip.h")]
-    if (not force and os.path.exists(LIB_PATH)
-            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps)):
+    want = source_hash()
+    if not force and built_id() == want:
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f'-DFV_BUILD_ID="{want}"',
              "-Wno-unused-value", "-Wno-comment", "-Wno-pass-failed",
              # MFMA results straight in VGPRs (unified register file on gfx950): no
              # v_accvgpr_read/write pairs around every stage -- VALU work costs MFMA time
@@ -85,6 +111,7 @@ def lib():
     vp, i, f, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
     L.fv_version.restype = i
     L.fv_last_error.restype = ctypes.c_char_p
+    L.fv_build_id.restype = ctypes.c_char_p
     L.fv_fold_weight_norm.argtypes = [vp, vp, vp, i, i64, vp]
     L.fv_packed_conv1d_floats.argtypes = [i, i, i]
     L.fv_packed_conv1d_floats.restype = i64
@@ -132,6 +159,7 @@ def lib():
     L.fv_plan_run.argtypes = [vp, i, i, vp, vp, vp, i64, vp]
     L.fv_plan_num_ops.argtypes = [vp]
     L.fv_profile_enable.argtypes = [i]
+    L.fv_profile_bracket_cost.argtypes = [vp, i, ctypes.POINTER(ctypes.c_double)]
     L.fv_profile_collect.argtypes = [i, ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     if L.fv_version() != ABI_VERSION:
@@ -159,8 +187,27 @@ def _ptr(t, name="tensor", allow_none=False):
     return t.data_ptr()
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+class _on:
+    """Context for one native call: makes the operands' device current (the kernels launch on the
+    CURRENT device; after ``model.to('cuda:1')`` that need not be the tensors') and yields that
+    device's current stream.  All tensor operands must live on one device."""
+
+    def __init__(self, *tensors):
+        devs = {t.device for t in tensors if t is not None}
+        if len(devs) != 1:
+            raise NativeError(f"operands of a native call must share one ROCm device, got {sorted(map(str, devs))}")
+        self.dev = devs.pop()
+        if self.dev.type != "cuda":
+            raise NativeError(f"operands live on {self.dev}; the HIP kernels need a ROCm device tensor "
+                              "(there is no CPU path in fastvocoder_amd)")
+        self._guard = torch.cuda.device(self.dev)
+
+    def __enter__(self):
+        self._guard.__enter__()
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def __exit__(self, *exc):
+        return self._guard.__exit__(*exc)
 
 
 # ---------------------------------------------------------------------------
@@ -172,8 +219,8 @@ def fold_weight_norm(v, g):
     v = v.detach().contiguous().float()
     g = g.detach().contiguous().float()
     w = torch.empty_like(v)
-    check(lib().fv_fold_weight_norm(_ptr(v, "v"), _ptr(g, "g"), _ptr(w), v.shape[0],
-                                    v[0].numel(), _stream()))
+    with _on(v, g) as stream:
+        check(lib().fv_fold_weight_norm(_ptr(v, "v"), _ptr(g, "g"), _ptr(w), v.shape[0], v[0].numel(), stream))
     return w
 
 
@@ -182,7 +229,8 @@ def pack_conv1d(w):
     w = w.detach().contiguous().float()
     cout, cin, k = w.shape
     out = torch.empty(lib().fv_packed_conv1d_floats(cout, cin, k), dtype=torch.float32, device=w.device)
-    check(lib().fv_pack_conv1d_weight(_ptr(w, "w"), _ptr(out), cout, cin, k, _stream()))
+    with _on(w) as stream:
+        check(lib().fv_pack_conv1d_weight(_ptr(w, "w"), _ptr(out), cout, cin, k, stream))
     return out
 
 
@@ -192,8 +240,8 @@ def pack_conv_transpose1d(w, stride, pad):
     cin, cout, k = w.shape
     n = lib().fv_packed_conv_transpose1d_floats(cin, cout, k, stride, pad)
     out = torch.empty(n, dtype=torch.float32, device=w.device)
-    check(lib().fv_pack_conv_transpose1d_weight(_ptr(w, "w"), _ptr(out), cin, cout, k, stride, pad,
-                                                _stream()))
+    with _on(w) as stream:
+        check(lib().fv_pack_conv_transpose1d_weight(_ptr(w, "w"), _ptr(out), cin, cout, k, stride, pad, stream))
     return out
 
 
@@ -206,10 +254,11 @@ def fold_batchnorm_conv(w, b, bn):
     b_out = torch.empty(cout, dtype=torch.float32, device=w.device)
     t = lambda a: None if a is None else a.detach().contiguous().float()  # noqa: E731
     b, gamma, beta, mean, var = t(b), t(bn.weight), t(bn.bias), t(bn.running_mean), t(bn.running_var)
-    check(lib().fv_fold_batchnorm_conv(_ptr(w, "w"), _ptr(b, "b", True), _ptr(gamma, "gamma", True),
-                                       _ptr(beta, "beta", True), _ptr(mean, "running_mean"),
-                                       _ptr(var, "running_var"), float(bn.eps), _ptr(w_out), _ptr(b_out),
-                                       cout, cin, k, _stream()))
+    with _on(w, b, gamma, beta, mean, var) as stream:
+        check(lib().fv_fold_batchnorm_conv(_ptr(w, "w"), _ptr(b, "b", True), _ptr(gamma, "gamma", True),
+                                           _ptr(beta, "beta", True), _ptr(mean, "running_mean"),
+                                           _ptr(var, "running_var"), float(bn.eps), _ptr(w_out), _ptr(b_out),
+                                           cout, cin, k, stream))
     return w_out, b_out
 
 
@@ -219,7 +268,8 @@ def pack_upsample_conv1d(w, rate, pad):
     cout, cin, k = w.shape
     n = lib().fv_packed_upsample_conv1d_floats(cout, cin, k, rate, pad)
     out = torch.empty(n, dtype=torch.float32, device=w.device)
-    check(lib().fv_pack_upsample_conv1d_weight(_ptr(w, "w"), _ptr(out), cout, cin, k, rate, pad, _stream()))
+    with _on(w) as stream:
+        check(lib().fv_pack_upsample_conv1d_weight(_ptr(w, "w"), _ptr(out), cout, cin, k, rate, pad, stream))
     return out
 
 
@@ -230,7 +280,8 @@ def pack_pair(w):
     if c != c2:
         raise NativeError(f"pack_pair: square [C,C,k] weight expected, got {tuple(w.shape)}")
     out = torch.empty(lib().fv_packed_pair_floats(c, k), dtype=torch.float32, device=w.device)
-    check(lib().fv_pack_pair_weight(_ptr(w, "w"), _ptr(out), c, k, _stream()))
+    with _on(w) as stream:
+        check(lib().fv_pack_pair_weight(_ptr(w, "w"), _ptr(out), c, k, stream))
     return out
 
 
@@ -255,11 +306,12 @@ def resblock1_fused(xs, w1s, w2s, b1s, b2s, ks, dil, slope, act_slope=1.0, outs=
     if outs is None:
         outs = [torch.empty_like(x) for x in xs]
     acts = list(outs_act) if outs_act is not None else [None] * n
-    check(lib().fv_resblock1_fused(n, _vp_array(xs, "x"), _vp_array(w1s, "w1"), _vp_array(w2s, "w2"),
-                                   _vp_array(b1s, "b1", True), _vp_array(b2s, "b2", True),
-                                   _vp_array(outs, "y"), _vp_array(acts, "y_act", True),
-                                   (ctypes.c_int * n)(*ks), B, C, T, dil, float(slope), float(act_slope),
-                                   _stream()))
+    with _on(*xs, *w1s, *w2s, *b1s, *b2s, *outs, *acts) as stream:
+        check(lib().fv_resblock1_fused(n, _vp_array(xs, "x"), _vp_array(w1s, "w1"), _vp_array(w2s, "w2"),
+                                       _vp_array(b1s, "b1", True), _vp_array(b2s, "b2", True),
+                                       _vp_array(outs, "y"), _vp_array(acts, "y_act", True),
+                                       (ctypes.c_int * n)(*ks), B, C, T, dil, float(slope), float(act_slope),
+                                       stream))
     return outs
 
 
@@ -269,10 +321,11 @@ def mrf_stage(xs, w1s, w2s, b1s, b2s, ks, dil, slope, out_div=3.0, post=POST_NON
     B, C, T = xs[0].shape
     if out is None:
         out = torch.empty_like(xs[0])
-    check(lib().fv_mrf_stage(_vp_array(xs, "x"), _vp_array(w1s, "w1"), _vp_array(w2s, "w2"),
-                             _vp_array(b1s, "b1", True), _vp_array(b2s, "b2", True), _ptr(out, "y"),
-                             _ptr(out_act, "y_act", True), (ctypes.c_int * 3)(*ks), B, C, T, dil, float(slope),
-                             float(out_div), post, float(act_slope), _stream()))
+    with _on(*xs, *w1s, *w2s, *b1s, *b2s, out, out_act) as stream:
+        check(lib().fv_mrf_stage(_vp_array(xs, "x"), _vp_array(w1s, "w1"), _vp_array(w2s, "w2"),
+                                 _vp_array(b1s, "b1", True), _vp_array(b2s, "b2", True), _ptr(out, "y"),
+                                 _ptr(out_act, "y_act", True), (ctypes.c_int * 3)(*ks), B, C, T, dil, float(slope),
+                                 float(out_div), post, float(act_slope), stream))
     return out
 
 
@@ -284,11 +337,12 @@ def conv1d_fused(x, packed, bias, cout, k, dil=1, pad=0, pad_mode=PAD_ZERO, pre_
     tout = T if pad_mode & PAD_CAUSAL else T + 2 * pad - dil * (k - 1)
     if out is None:
         out = torch.empty((B, cout, tout), dtype=torch.float32, device=x.device)
-    check(lib().fv_conv1d_fused(_ptr(x, "x"), _ptr(packed, "packed"), _ptr(bias, "bias", True),
-                                _ptr(res, "res", True), _ptr(acc_in, "acc_in", True),
-                                _ptr(acc_in2, "acc_in2", True), _ptr(out, "out"),
-                                _ptr(out_act, "out_act", True), B, cin, cout, T, k, dil, pad, pad_mode,
-                                float(pre_slope), float(out_div), post, float(act_slope), _stream()))
+    with _on(x, packed, bias, res, acc_in, acc_in2, out, out_act) as stream:
+        check(lib().fv_conv1d_fused(_ptr(x, "x"), _ptr(packed, "packed"), _ptr(bias, "bias", True),
+                                    _ptr(res, "res", True), _ptr(acc_in, "acc_in", True),
+                                    _ptr(acc_in2, "acc_in2", True), _ptr(out, "out"),
+                                    _ptr(out_act, "out_act", True), B, cin, cout, T, k, dil, pad, pad_mode,
+                                    float(pre_slope), float(out_div), post, float(act_slope), stream))
     return out
 
 
@@ -299,10 +353,11 @@ def conv1d_2src_fused(x, x2, packed, bias, cout, res=None, post=POST_NONE, out=N
     c2 = x2.shape[1]
     if out is None:
         out = torch.empty((B, cout, T), dtype=torch.float32, device=x.device)
-    check(lib().fv_conv1d_2src_fused(_ptr(x, "x"), _ptr(x2, "x2"), _ptr(packed, "packed"),
-                                     _ptr(bias, "bias", True), _ptr(res, "res", True), _ptr(out, "out"),
-                                     _ptr(out_act, "out_act", True), B, c1, c2, cout, T, post,
-                                     float(act_slope), _stream()))
+    with _on(x, x2, packed, bias, res, out, out_act) as stream:
+        check(lib().fv_conv1d_2src_fused(_ptr(x, "x"), _ptr(x2, "x2"), _ptr(packed, "packed"),
+                                         _ptr(bias, "bias", True), _ptr(res, "res", True), _ptr(out, "out"),
+                                         _ptr(out_act, "out_act", True), B, c1, c2, cout, T, post,
+                                         float(act_slope), stream))
     return out
 
 
@@ -312,11 +367,12 @@ def conv_transpose1d_fused(x, packed, bias, cout, k, stride, pad, out_pad, pre_s
     tout = (T - 1) * stride - 2 * pad + k + out_pad
     if out is None:
         out = torch.empty((B, cout, tout), dtype=torch.float32, device=x.device)
-    check(lib().fv_conv_transpose1d_fused(_ptr(x, "x"), _ptr(packed, "packed"),
-                                          _ptr(bias, "bias", True), _ptr(out, "out"),
-                                          _ptr(out_act, "out_act", True), B, cin, cout, T, k, stride,
-                                          pad, out_pad, float(pre_slope), post, float(act_slope),
-                                          _stream()))
+    with _on(x, packed, bias, out, out_act) as stream:
+        check(lib().fv_conv_transpose1d_fused(_ptr(x, "x"), _ptr(packed, "packed"),
+                                              _ptr(bias, "bias", True), _ptr(out, "out"),
+                                              _ptr(out_act, "out_act", True), B, cin, cout, T, k, stride,
+                                              pad, out_pad, float(pre_slope), post, float(act_slope),
+                                              stream))
     return out
 
 
@@ -326,10 +382,11 @@ def upsample_conv1d_fused(x, packed, bias, cout, k, rate, pad, pre_slope=1.0, po
     tout = T * rate + 2 * pad - (k - 1)
     if out is None:
         out = torch.empty((B, cout, tout), dtype=torch.float32, device=x.device)
-    check(lib().fv_upsample_conv1d_fused(_ptr(x, "x"), _ptr(packed, "packed"), _ptr(bias, "bias", True),
-                                         _ptr(out, "out"), _ptr(out_act, "out_act", True), B, cin, cout,
-                                         T, k, rate, pad, float(pre_slope), post, float(act_slope),
-                                         _stream()))
+    with _on(x, packed, bias, out, out_act) as stream:
+        check(lib().fv_upsample_conv1d_fused(_ptr(x, "x"), _ptr(packed, "packed"), _ptr(bias, "bias", True),
+                                             _ptr(out, "out"), _ptr(out_act, "out_act", True), B, cin, cout,
+                                             T, k, rate, pad, float(pre_slope), post, float(act_slope),
+                                             stream))
     return out
 
 
@@ -341,8 +398,9 @@ def encode_16bits(x, rescale_out=1.0, scale_in_place=True):
     B, n = flat.shape
     out = torch.empty((B, n), dtype=torch.int16, device=x.device)
     peak = torch.empty(B, dtype=torch.float32, device=x.device)
-    check(lib().fv_encode_16bits(_ptr(flat, "x"), out.data_ptr(), _ptr(peak), B, n, float(rescale_out),
-                                 1 if scale_in_place else 0, _stream()))
+    with _on(flat, out, peak) as stream:
+        check(lib().fv_encode_16bits(_ptr(flat, "x"), out.data_ptr(), _ptr(peak), B, n, float(rescale_out),
+                                     1 if scale_in_place else 0, stream))
     return out.reshape(x.shape), peak
 
 
@@ -353,7 +411,8 @@ def pqmf_analysis(x, analysis_filter):
     B, T = x.shape
     h = analysis_filter.detach().reshape(S, ntaps).contiguous().float()
     y = torch.empty((B, S, (T - S) // S + 1), dtype=torch.float32, device=x.device)
-    check(lib().fv_pqmf_analysis(_ptr(x, "x"), _ptr(h, "analysis_filter"), _ptr(y), B, S, ntaps, T, _stream()))
+    with _on(x, h, y) as stream:
+        check(lib().fv_pqmf_analysis(_ptr(x, "x"), _ptr(h, "analysis_filter"), _ptr(y), B, S, ntaps, T, stream))
     return y
 
 
@@ -361,8 +420,9 @@ def pqmf_synthesis(x, synthesis_filter, y):
     """x [B,S,Tsub], synthesis_filter [1,S,ntaps] -> y [B,1,S*Tsub] (filled in place)."""
     B, S, Tsub = x.shape
     h = synthesis_filter.reshape(S, -1).contiguous().float()
-    check(lib().fv_pqmf_synthesis(_ptr(x, "x"), _ptr(h, "h"), _ptr(y, "y"), B, S, h.shape[1], Tsub,
-                                  _stream()))
+    with _on(x, h, y) as stream:
+        check(lib().fv_pqmf_synthesis(_ptr(x, "x"), _ptr(h, "h"), _ptr(y, "y"), B, S, h.shape[1], Tsub,
+                                      stream))
     return y
 
 
@@ -388,6 +448,13 @@ class Plan:
     def keep(self, t):
         self._keep.append(t)
         return t
+
+    # a plan is a raw native handle + device pointers into its owner's tensors: never copied or pickled
+    def __deepcopy__(self, memo):
+        raise NativeError("a native plan cannot be copied; the owning module rebuilds its plans on demand")
+
+    def __reduce__(self):
+        raise NativeError("a native plan cannot be pickled; the owning module rebuilds its plans on demand")
 
     def add_conv1d(self, x, y, packed, bias, cin, cout, k, dil=1, pad=0, pad_mode=PAD_ZERO,
                    pre_slope=1.0, res=SLOT_NONE, acc=SLOT_NONE, out_div=1.0, post=POST_NONE,
@@ -501,8 +568,9 @@ class Plan:
                 check(int(nbytes))
             self._ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=x.device)
             self._ws_key = key
-        check(lib().fv_plan_run(self._h, B, T, _ptr(x, "input"), _ptr(out, "out"),
-                                self._ws.data_ptr(), self._ws.numel(), _stream()))
+        with _on(x, out, self._ws, *self._keep[:1]) as stream:
+            check(lib().fv_plan_run(self._h, B, T, _ptr(x, "input"), _ptr(out, "out"),
+                                    self._ws.data_ptr(), self._ws.numel(), stream))
         return out
 
 
@@ -515,6 +583,13 @@ def profile_enable(on):
 
 
 KERNEL_CONV_MFMA32, KERNEL_CONV_MFMA16, KERNEL_CONV_NARROW, KERNEL_PAIR16, KERNEL_PAIR32 = 0, 1, 2, 3, 4
+
+
+def profile_bracket_cost(n=200):
+    """Milliseconds the (begin, end) event pair of the measurement hook adds per launch."""
+    ms = ctypes.c_double()
+    check(lib().fv_profile_bracket_cost(torch.cuda.current_stream().cuda_stream, n, ctypes.byref(ms)))
+    return ms.value
 
 
 def profile_collect(kind=-1):

@@ -401,6 +401,8 @@ static ConvParams make_params(const Op& o, const float* x, float* y, float* y2, 
         p.pad_mode = FV_PAD_ZERO;
         p.ups = o.stride;
         p.Tq = (p.Tout + o.stride - 1) / o.stride;
+        // MACs of a ConvTranspose1d = Tin * Cin * Cout * k, whatever the polyphase image pads
+        if (o.type == OP_CONVT) p.alg_flops = 2.0 * B * (double)Tin * o.Cin * o.Cout * o.k;
     }
     p.Mpad = pad_rows(p.M);
     return p;
@@ -505,6 +507,11 @@ using namespace fv;
 extern "C" {
 
 int fv_version(void) { return FV_ABI_VERSION; }
+
+#ifndef FV_BUILD_ID
+#define FV_BUILD_ID "unknown"
+#endif
+const char* fv_build_id(void) { return FV_BUILD_ID; }
 
 const char* fv_last_error(void) { return g_err.c_str(); }
 
@@ -1289,6 +1296,24 @@ int fv_plan_num_ops(fv_plan_t* plan) { return plan ? (int)plan->ops.size() : 0; 
 
 int fv_profile_enable(int on) {
     g_prof_on = on != 0;
+    return 0;
+}
+
+int fv_profile_bracket_cost(void* stream, int n, double* ms_per_bracket) {
+    if (n <= 0 || !ms_per_bracket) return fail(FV_ERR_INVALID_ARG, "profile_bracket_cost: n=%d", n);
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<hipEvent_t> ev(2 * (size_t)n);
+    for (hipEvent_t& e : ev) FV_HIP(hipEventCreate(&e));
+    for (hipEvent_t& e : ev) FV_HIP(hipEventRecord(e, s));      // n empty (begin, end) pairs back to back
+    FV_HIP(hipEventSynchronize(ev.back()));
+    double tot = 0;
+    for (int i = 0; i < n; ++i) {
+        float e = 0.f;
+        FV_HIP(hipEventElapsedTime(&e, ev[2 * i], ev[2 * i + 1]));
+        tot += e;
+    }
+    for (hipEvent_t& e : ev) (void)hipEventDestroy(e);
+    *ms_per_bracket = tot / n;
     return 0;
 }
 

@@ -73,6 +73,12 @@ constexpr unsigned kOutOfRange = 0x40000000u;
 // equal to x >= 0 ? x : slope*x, branch-free (slope is wave-uniform)
 __device__ __forceinline__ float act(float v, float slope) { return fmaxf(v, v * slope); }
 
+// Workgroup barrier for LDS hand-offs WITHOUT __syncthreads()'s fences: the release fence makes hipcc wait
+// for every global store in flight (vmcnt) before the barrier, so a block that walks several tiles pays
+// the ~2 us drain of the previous tile's stores at the next stage boundary.  LDS traffic only needs this
+// wave's LDS operations retired (lgkmcnt); LDS-DMA landing is ordered by the explicit vmcnt waits.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // A wave-uniform value the optimiser must treat as unknown at this point.  The DMA issue code
 // runs once per stage inside the tile/chunk loops; left alone, LLVM hoists every per-instruction
 // predicate (as a 64-bit lane mask) and LDS address out of those loops, runs out of SGPRs and
@@ -448,6 +454,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return base + within;
 }
 
+// an LDS address the optimiser must treat as a fresh value (a 32-bit address-space-3 pointer, so loads through
+// it stay ds_read with immediate offsets; laundering a generic pointer would turn them into flat loads)
+typedef __attribute__((address_space(3))) const float LdsCF;
+__device__ __forceinline__ LdsCF* lds_opaque(const float* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned v = __builtin_bit_cast(unsigned, (LdsCF*)p);
+    asm volatile("" : "+v"(v));
+    return __builtin_bit_cast(LdsCF*, v);
+#else
+    return (LdsCF*)p;   // host pass: never executed
+#endif
+}
+
 // MFMA shape traits: MF = 32 -> v_mfma_f32_32x32x2_f32 (K step 2, 16 acc regs),
 //                    MF = 16 -> v_mfma_f32_16x16x4_f32 (K step 4,  4 acc regs).
 template <int MF>
@@ -474,6 +493,72 @@ struct Frag<16> {
     // C/D map: col = lane & 15, row = 4*(lane >> 4) + reg
     static __device__ __forceinline__ int row(int reg, int lane) { return 4 * (lane >> 4) + reg; }
 };
+
+// Software-pipelined K loop of the conv kernels: n_it iterations of (one MFMA K step: KS channels x KT taps),
+// A operands at pa[tap * tap_a], B operands at pb[tap * tap_b + r * MF]; pa / pb advance by step_a / step_b.
+// An iteration is cut in two halves of taps; the operands of a half are read from LDS while the MFMAs of the
+// PREVIOUS half run -- the second half of this iteration behind its first, the first half of the next
+// iteration behind this second.  Left alone, hipcc issues all reads of an iteration at its top and the wave
+// exposes one LDS latency per iteration (every 3-11 MFMAs); sched_barrier pins the order, the waitcnt pass
+// still derives the exact lgkmcnt per use.  Same register count as the plain loop.  The running pointers are
+// opaque (one register each, one add per iteration): otherwise their lane part and running part are kept
+// apart and re-added in front of every group of reads.
+template <int MF, int KT, int NR>
+__device__ __forceinline__ void mma_pipelined(const float* pa0, const float* pb0, int tap_a, int tap_b, int step_a,
+                                              int step_b, int n_it, typename Frag<MF>::acc_t (&acc)[NR]) {
+    typedef Frag<MF> F;
+    constexpr int H1 = (KT + 1) / 2, H2 = KT - H1;
+    if (n_it <= 0) return;
+    LdsCF* pa = lds_opaque(pa0);
+    LdsCF* pb = lds_opaque(pb0);
+    float a1[H1], b1[H1][NR], a2[H2 > 0 ? H2 : 1], b2[H2 > 0 ? H2 : 1][NR];
+    auto load1 = [&]() {
+#pragma unroll
+        for (int t = 0; t < H1; ++t) {
+            a1[t] = pa[t * tap_a];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) b1[t][r] = pb[t * tap_b + r * MF];
+        }
+    };
+    auto load2 = [&]() {
+#pragma unroll
+        for (int t = 0; t < H2; ++t) {
+            a2[t] = pa[(H1 + t) * tap_a];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) b2[t][r] = pb[(H1 + t) * tap_b + r * MF];
+        }
+    };
+    auto mma1 = [&]() {
+#pragma unroll
+        for (int t = 0; t < H1; ++t)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc[r] = F::mfma(a1[t], b1[t][r], acc[r]);
+    };
+    auto mma2 = [&]() {
+#pragma unroll
+        for (int t = 0; t < H2; ++t)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc[r] = F::mfma(a2[t], b2[t][r], acc[r]);
+    };
+    load1();
+    for (int it = 0; it + 1 < n_it; ++it) {
+        __builtin_amdgcn_sched_barrier(0);
+        load2();
+        __builtin_amdgcn_sched_barrier(0);
+        mma1();
+        __builtin_amdgcn_sched_barrier(0);
+        pa += step_a;
+        pb += step_b;
+        load1();
+        __builtin_amdgcn_sched_barrier(0);
+        mma2();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    load2();
+    __builtin_amdgcn_sched_barrier(0);
+    mma1();
+    mma2();
+}
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate);
 // n <= 2 * (kMaxDmaX + kMaxDmaW).  Larger or unexpected values wait for everything.
@@ -624,7 +709,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
             else wait_vmcnt((issued - s - 1) * n_inst);
         }
         landed = false;
-        __syncthreads();
+        lds_barrier();
         if (issued < issue_limit) issue();
         const bool last_chunk = chunk == nchunks - 1;
         // ---- matrix work on buffer cur ----
@@ -672,7 +757,7 @@ __device__ __forceinline__ void conv_body(const ConvParams& p, const int block_x
 #pragma unroll
                         for (int i = 0; i < F::REGS; ++i) dst[(r * F::REGS + i) * 64] = acc[r][i];
                 }
-                __syncthreads();
+                lds_barrier();
                 if (wk == 0) {
 #pragma unroll
                     for (int g = 1; g < WK; ++g) {
@@ -773,16 +858,7 @@ __device__ __forceinline__ void sum3_mma(const float* wsA, const float* xsB, int
                                          typename Frag<MF>::acc_t (&acc)[NR]) {
     typedef Frag<MF> F;
     constexpr int M_T = MF;   // WM == 1 in the shapes this kernel is built for
-    for (int c = 0; c < cend; c += F::KS) {
-        const float* pa = wsA + c * (KT * M_T);
-        const float* pb = xsB + c * xw;
-#pragma unroll
-        for (int tap = 0; tap < KT; ++tap) {
-            const float a = pa[tap * M_T];
-#pragma unroll
-            for (int r = 0; r < NR; ++r) acc[r] = F::mfma(a, pb[tap + r * MF], acc[r]);
-        }
-    }
+    mma_pipelined<MF, KT, NR>(wsA, xsB, M_T, 1, F::KS * (KT * M_T), F::KS * xw, (cend + F::KS - 1) / F::KS, acc);
 }
 
 template <int MF, int WN, int NR>
@@ -858,7 +934,7 @@ __global__ __launch_bounds__(64 * WN) FV_SUM3_WAVES void conv_sum3_kernel(Sum3Pa
         for (int s = 0; s < total; ++s) {
             if (!landed) wait_vmcnt(0);   // stage s landed (own wave); the barrier: everyone's, and buffer cur^1 is free
             landed = false;
-            __syncthreads();
+            lds_barrier();
             const bool more = s + 1 < total || tile + 1 < tile_hi;
             if (more) issue(s + 1 < total ? tile : tile + 1);
             const ConvParams& q = sp.p[cm];

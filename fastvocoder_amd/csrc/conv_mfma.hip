@@ -147,7 +147,7 @@ int prepare_conv(ConvParams& p, LaunchInfo& li, int members = 1, int force_shape
                     p.Cout, p.Tout);
     p.vec_ok = (p.Tin % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) &&
                ((reinterpret_cast<uintptr_t>(p.x2) & 15) == 0);
-    li.flops = 2.0 * p.B * (double)p.M * p.Tq * p.Cin * p.k;
+    li.flops = p.alg_flops > 0 ? p.alg_flops : 2.0 * p.B * (double)p.M * p.Tq * p.Cin * p.k;
     li.bytes = 4.0 * ((double)p.B * p.Cin * p.Tin + (double)p.B * p.Cout * p.Tout *
                       (1 + (p.res != nullptr) + (p.acc_in != nullptr) + (p.acc_in2 != nullptr) +
                        (p.y_act != nullptr)) +

@@ -104,6 +104,8 @@ struct ConvParams {
     int red_off;    // float offset of the split-K reduction area in LDS
     int vec_ok;     // rows are 16-byte aligned: float4 global loads allowed
     int dbg;        // ablation switches (FV_DBG, tuning only): 1 no epilogue, 2 no restaging, 4 no MFMA
+    double alg_flops;   // > 0: algorithmic FLOPs of the layer for the measurement hook (a transposed conv in
+                        // polyphase form executes zero taps that the reference's MAC count does not contain)
 };
 
 // Three (or two: the third grid empty) mutually independent convs of one MRF position in

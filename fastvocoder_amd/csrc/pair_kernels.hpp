@@ -66,11 +66,7 @@ struct PairGeom {
 
 __device__ __forceinline__ void pair_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// Workgroup barrier for LDS hand-offs WITHOUT __syncthreads()'s fences: the release fence makes hipcc
-// wait for every global store in flight (vmcnt) before the barrier, i.e. each tile of a persistent block
-// would pay the ~2 us drain of the previous tile's stores.  LDS traffic only needs this wave's LDS
-// operations retired (lgkmcnt) before the barrier; LDS-DMA landing is ordered by explicit vmcnt waits.
-__device__ __forceinline__ void pair_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void pair_barrier() { lds_barrier(); }
 
 // s_waitcnt vmcnt(0) the compiler can see (simm16: vmcnt 0, expcnt 7, lgkmcnt 15): after it hipcc knows
 // that no global store is in flight and does not guard later register re-use with waits of its own --
@@ -139,19 +135,6 @@ __device__ __forceinline__ void pair_dma_x(const PairDma<G>& d, const float* xb,
             }
         }
     }
-}
-
-// an LDS address the optimiser must treat as a fresh value (a 32-bit address-space-3 pointer, so loads through
-// it stay ds_read with immediate offsets; laundering a generic pointer would turn them into flat loads)
-typedef __attribute__((address_space(3))) const float LdsCF;
-__device__ __forceinline__ LdsCF* lds_opaque(const float* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    unsigned v = __builtin_bit_cast(unsigned, (LdsCF*)p);
-    asm volatile("" : "+v"(v));
-    return __builtin_bit_cast(LdsCF*, v);
-#else
-    return (LdsCF*)p;   // host pass: never executed
-#endif
 }
 
 // ---- one conv phase: NF accumulators += W (registers) x image (LDS) ---------------------------------

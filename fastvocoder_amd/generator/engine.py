@@ -346,6 +346,21 @@ class PlanBuilder:
         return self.plan
 
 
+# Any parameter / buffer (re-)registration anywhere bumps this epoch: a replaced tensor
+# (``conv.weight = nn.Parameter(...)``, torch's remove_weight_norm on a submodule) is not in a
+# module's memoised tensor list, so in-place version counters alone would miss it.  Walking
+# the module tree on every call instead costs ~350 us for a HiFi-GAN (a quarter of a step).
+_registration_epoch = [0]
+
+
+def _bump_epoch(*_args):
+    _registration_epoch[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump_epoch)
+torch.nn.modules.module.register_module_buffer_registration_hook(_bump_epoch)
+
+
 class NativeModule(torch.nn.Module):
     """Base of every module on the path: caches native plans keyed by a name and
     rebuilds them when any parameter/buffer was modified, replaced or moved."""
@@ -354,12 +369,24 @@ class NativeModule(torch.nn.Module):
         super().__init__()
         self._fv_plans = {}
         self._fv_tensors = None
+        self._fv_epoch = -1
 
     # -- cache bookkeeping -------------------------------------------------
     def _fv_state(self):
-        if self._fv_tensors is None:
+        """(registration epoch, sum of in-place version counters) of the tensors the plans bake in."""
+        if self._fv_tensors is None or self._fv_epoch != _registration_epoch[0]:
             self._fv_tensors = list(self.parameters()) + list(self.buffers())
-        return sum(t._version for t in self._fv_tensors)
+            self._fv_epoch = _registration_epoch[0]
+        return self._fv_epoch, sum(t._version for t in self._fv_tensors)
+
+    # A native plan is a raw handle plus pointers into THIS module's packed weights: a copied or
+    # unpickled module must not share it (double free, stale device pointers) -- it rebuilds its own.
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_fv_plans"] = {}
+        state["_fv_tensors"] = None
+        state["_fv_epoch"] = -1
+        return state
 
     def invalidate_plans(self):
         """Drop cached native plans (packed weights).  Called automatically on

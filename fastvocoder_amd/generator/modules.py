@@ -102,6 +102,29 @@ class ResBlock1(_Block):
         for step in range(self.num_steps()):
             self.emit_step(pb, step, state, src, dst, scratch, acc=acc, out_div=out_div)
 
+    def pairs_fusable(self):
+        """Every (dilated conv, conv) pair has a shape the fused pair kernels are built for."""
+        from .engine import PlanBuilder
+        return all(PlanBuilder.pair_fusable(c1, c2) for c1, c2 in zip(self.convs1, self.convs2))
+
+    def emit_fused(self, pb, src, dst, scratch):
+        """src -> dst with every pair as ONE fused launch (csrc/pair_kernels.hpp); needs T % 4 == 0."""
+        _, ping, pong = scratch
+        cur = src
+        for i, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
+            nxt = dst if i == len(self.convs1) - 1 else (ping if cur != ping else pong)
+            pb.pair(c1, c2, cur, nxt, LRELU_SLOPE)
+            cur = nxt
+
+    def forward(self, x):
+        x = self._prepare(x)
+        if x.shape[2] % 4 != 0 or not self.pairs_fusable() or os.environ.get("FV_PAIR", "1") == "0":
+            return super().forward(x)
+
+        def build(pb):
+            self.emit_fused(pb, SLOT_IN, SLOT_OUT, [pb.tmp() for _ in range(3)])
+        return self._plan("forward_fused", build, self.channels).run(x)
+
 
 class ResBlock2(_Block):
     """Two single dilated convs with residual (reference modules.py:233-252)."""

@@ -73,27 +73,57 @@ class WaveformGather:
         return None
 
 
-def synthesize_sharded(forward_fn, mels, world_size=None, rank=None, dst=0, group=None):
-    """Run ``forward_fn(mels[lo:hi]) -> [hi-lo, n]`` on this rank's contiguous block
-    of ``mels [B, C, T]`` and gather all waveforms, in utterance order, on ``dst``.
-    Ragged blocks (B not divisible by the world size) are padded for the gather
-    and trimmed on the root.  Returns [B, n] on ``dst`` and None elsewhere."""
+def synthesize_sharded(forward_fn, mels, world_size=None, rank=None, dst=0, group=None, scatter=False,
+                       device=None):
+    """Run ``forward_fn(block) -> [rows, n]`` on this rank's contiguous block of the batch
+    ``mels [B, C, T]`` and gather all results, in utterance order, on ``dst``.
+
+    ``scatter=False``: every rank already holds ``mels`` (or makes its own) and slices its block.
+    ``scatter=True``: only ``dst`` holds ``mels`` (others pass None): its shape is broadcast and the
+    blocks are scattered from ``dst`` -- with the gather that is the whole traffic of a job (SURVEY.md
+    section 8e: scatter of mels, gather of waveforms, nothing in between).  ``device``: where the
+    received block lives (default: ``mels``' device on dst, required on the other ranks).
+    Ragged blocks (B not divisible by the world size) are padded and trimmed on the root.  The result
+    keeps ``forward_fn``'s dtype (fp32 waveforms, or int16 after a GPU wav sink).  Returns [B, n] on
+    ``dst`` and None elsewhere."""
     world_size = dist.get_world_size(group) if world_size is None else world_size
     rank = dist.get_rank(group) if rank is None else rank
-    B = mels.shape[0]
+    if scatter:
+        device = mels.device if mels is not None else device
+        shape = torch.tensor(list(mels.shape) if rank == dst else [0, 0, 0], dtype=torch.int64, device=device)
+        dist.broadcast(shape, src=dst, group=group)
+        B, C, T = (int(v) for v in shape.tolist())
+    else:
+        B = mels.shape[0]
     lo, hi = shard_range(B, world_size, rank)
     per = (B + world_size - 1) // world_size
-    block = mels[lo:hi]
-    if hi - lo < per:   # pad with a copy of the last row (or a zero row for an empty block)
-        filler = block[-1:] if hi > lo else torch.zeros_like(mels[:1])
-        block = torch.cat([block] + [filler] * (per - (hi - lo)), dim=0)
+    if scatter:
+        block = torch.empty((per, C, T), dtype=torch.float32, device=device)
+        parts = None
+        if rank == dst:
+            parts = []
+            for r in range(world_size):
+                a, b = shard_range(B, world_size, r)
+                part = mels[a:b]
+                if b - a < per:
+                    filler = part[-1:] if b > a else torch.zeros_like(mels[:1])
+                    part = torch.cat([part] + [filler] * (per - (b - a)), dim=0)
+                parts.append(part.contiguous())
+        dist.scatter(block, scatter_list=parts, src=dst, group=group)
+    else:
+        block = mels[lo:hi]
+        if hi - lo < per:   # pad with a copy of the last row (or a zero row for an empty block)
+            filler = block[-1:] if hi > lo else torch.zeros_like(mels[:1])
+            block = torch.cat([block] + [filler] * (per - (hi - lo)), dim=0)
     wav = forward_fn(block.contiguous()).contiguous()
-    bufs = [torch.empty_like(wav) for _ in range(world_size)] if rank == dst else None
-    dist.gather(wav, gather_list=bufs, dst=dst, group=group)
+    # RCCL / gloo have no 16-bit integer type: int16 PCM travels as its bytes
+    wire = wav.view(torch.uint8) if wav.dtype == torch.int16 else wav
+    bufs = [torch.empty_like(wire) for _ in range(world_size)] if rank == dst else None
+    dist.gather(wire, gather_list=bufs, dst=dst, group=group)
     if rank != dst:
         return None
     rows = []
     for r in range(world_size):
         a, b = shard_range(B, world_size, r)
-        rows.append(bufs[r][: b - a])
+        rows.append(bufs[r].view(wav.dtype)[: b - a])
     return torch.cat(rows, dim=0)

@@ -52,6 +52,9 @@ extern "C" {
 #define FV_POST_RELU 2 /* torch.nn.ReLU, basis_melgan.py:120-121 */
 
 int fv_version(void);
+/* hash of the sources this binary was built from (fastvocoder_amd/_native.py source_hash()): lets a
+ * test prove that the loaded library is the working tree's, not a stale prebuilt one */
+const char* fv_build_id(void);
 /* thread-local description of the last non-zero return on this thread */
 const char* fv_last_error(void);
 
@@ -344,6 +347,9 @@ int fv_plan_num_ops(fv_plan_t* plan);
 #define FV_KERNEL_PAIR16 3      /* fused ResBlock pairs / MRF stage end, C = 16 (16x16x4 fp32 MFMA) */
 #define FV_KERNEL_PAIR32 4      /* fused ResBlock pairs, C = 32 */
 int fv_profile_enable(int on);
+/* what the event bracket itself adds to a measured launch: the average elapsed time between the two events
+ * of n EMPTY brackets recorded back to back on `stream` (subtract it per launch) */
+int fv_profile_bracket_cost(void* stream, int n, double* ms_per_bracket);
 int fv_profile_collect(int kind, int64_t* launches, double* ms, double* flops, double* bytes);
 
 #ifdef __cplusplus

@@ -11,8 +11,10 @@ OUTPUTS (plus key/shape tables and the PQMF filters):
                                   strided samples + float64 sums, per-stage taps
   blocks.npz                      ResBlock1/2, ResidualStack, LastLayer, BasisSignalLayer, PQMF
   synthesize_melgan.npz           Synthesizer.synthesize triple, BASELINE config 1
+  audio.npz                       data/audio.py encode_16bits: int16 samples + the in-place scaled input
+  blocks_t52.npz                  ResBlock1 (16 and 32 channels) at T = 52: lengths the fused pair kernels take
 
-Usage:  python tests/golden/make_golden.py
+Usage:  python tests/golden/make_golden.py [extra]      (extra: only the last two files)
 """
 import json
 import os
@@ -232,5 +234,42 @@ def main():
     print("synthesize", tonp(est).shape, float(tonp(est).std()), float(tonp(bias).std()))
 
 
+def extra_fixtures(out):
+    """Fixtures added in round 2; kept apart so that the round-1 files need not be regenerated."""
+    import data.audio as refaudio            # reference data/audio.py (librosa / tensorflow stubbed above)
+    rng = np.random.RandomState(21)
+    rec = {}
+    cases_ = [("unit", rng.uniform(-1, 1, 5000), 1.0), ("quiet_floor", rng.uniform(-0.004, 0.004, 3000), 1.0),
+              ("rescale04", rng.randn(4801) * 0.3, 0.4), ("big", rng.randn(2000) * 7.0, 0.4),
+              ("zeros", np.zeros(64), 0.4)]
+    for tag, x, rescale in cases_:
+        x = x.astype(np.float32)
+        rec[f"{tag}_in"] = x.copy()
+        rec[f"{tag}_rescale"] = np.float32(rescale)
+        rec[f"{tag}_int16"] = refaudio.encode_16bits(x, rescale_out=rescale)      # mutates x (data/audio.py:13)
+        rec[f"{tag}_scaled"] = x
+    np.savez_compressed(os.path.join(out, "audio.npz"), **rec)
+
+    rng = np.random.RandomState(12)
+    rec = {}
+    with torch.no_grad():
+        for ch in (16, 32):
+            x = rng.randn(2, ch, 52).astype(np.float32)
+            rec[f"x{ch}"] = x
+            for k in (3, 7, 11):
+                rb = refmod.ResBlock1(ch, k, (1, 3, 5))
+                for p in rb.parameters():
+                    p.copy_(torch.from_numpy(rng.uniform(-0.3, 0.3, size=tuple(p.shape)).astype(np.float32)
+                                             / np.float32(np.sqrt(ch / 16.0))))
+                rec[f"rb1_c{ch}_k{k}_params"] = np.concatenate([tonp(p).reshape(-1) for p in rb.parameters()])
+                rec[f"rb1_c{ch}_k{k}_out"] = tonp(rb(torch.from_numpy(x)))
+    np.savez_compressed(os.path.join(out, "blocks_t52.npz"), **rec)
+    print("extra fixtures written")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":
+        extra_fixtures(HERE)
+    else:
+        main()
+        extra_fixtures(HERE)

@@ -51,6 +51,16 @@ def _worker(rank, world, port, B, out_path):
             np.save(out_path, out.numpy())
         else:
             assert out is None
+        # 2b) the job form (bench.py --config large512): only the root holds the mels, blocks are
+        #     scattered, results come back in the generator's dtype (int16 after a wav sink)
+        def _sink(block):
+            return (_fake_generator(block) * 100).to(torch.int16)
+        out = parallel.synthesize_sharded(_sink, mels if rank == 0 else None, scatter=True,
+                                          device=torch.device("cpu"))
+        if rank == 0:
+            assert out.dtype == torch.int16 and torch.equal(out, _sink(mels))
+        else:
+            assert out is None
         # 3) the fixed-shape gather used by bench.py
         gather = parallel.WaveformGather(world, rank, torch.device("cpu"))
         mine = torch.full((2, 6), float(rank))

@@ -1,0 +1,82 @@
+"""GPU tests of the N > 1 code path with the REAL HIP generator on one GPU: a 1-rank RCCL process group
+(FV_BENCH_FORCE_DIST=1) drives bench.py's broadcast / gather / scatter legs, and
+parallel.synthesize_sharded runs the real forward.  The 8-GPU curve itself is the driver's."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench(*args, **env):
+    e = dict(os.environ, FV_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
+             RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", **env)
+    r = subprocess.run([sys.executable, os.path.join(cases.ROOT, "bench.py"), *args], env=e, cwd=cases.ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, r.stdout[-2000:] + r.stderr[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_light_through_the_distributed_path():
+    """Default workload through RCCL init, weight broadcast, per-step gather inside the timed region,
+    barrier bracket and MAX all-reduce; the timed output is checked against the reference golden."""
+    out = _bench("--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    assert out["n_gpus"] == 1 and out["scaling"] == "weak" and out["unit"] == "samples/s"
+    assert "gathered to rank 0 inside the timed steps" in out["config"]["workload"]
+    assert out["parity"]["max_abs_vs_reference_golden"] <= 1e-4
+    assert out["without_gather"]["ms_per_step"] > 0
+    assert abs(out["value"] - 240000 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-6
+    r = out["roofline"]
+    assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and r["kernel_ms_per_step"] <= out["ms_per_step"] * 1.05
+    assert out["roofline_hbm_stage"]["bytes"] > 6.0e8      # 18 convs x (2 or 3) x 15.36 MB, SURVEY 8(d)
+
+
+def test_bench_large512_job_shape_on_one_rank():
+    """BASELINE configs[4] harness (scatter of mels, sub-batched forward, int16 sink, gather), shrunk to
+    6 utterances: rows equal solo runs bit for bit (asserted inside bench.py)."""
+    out = _bench("--config", "large512", "--steps", "1", "--warmup", "0", "--sub", "4", FV_BENCH_JOB="6")
+    assert out["scaling"] == "strong" and out["config"]["global_batch"] == 6
+    assert "int16 wav sink" in out["config"]["workload"]
+    assert abs(out["value"] - 6 * 240000 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-6
+
+
+def test_synthesize_sharded_with_the_hip_generator():
+    """parallel.synthesize_sharded (scatter from the root + gather) around the real generator forward in a
+    1-rank RCCL group: identical bits to the direct forward, fp32 and through the int16 sink."""
+    import torch.distributed as dist
+    from fastvocoder_amd import audio, parallel
+    from fastvocoder_amd.bin.synthesize import build_generator
+    from fastvocoder_amd.synthetic import seeded_mel, seeded_state_dict
+    dev = torch.device("cuda:0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        cfg = cases.load_conf("conf/hifigan/light.yaml")
+        m = build_generator("hifigan", cfg)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict("hifigan", cfg, seed=0).items()})
+        m = m.to(dev).eval()
+        parallel.broadcast_weights(m, src=0)
+        mels = torch.from_numpy(seeded_mel(64, seed=9, batch=3)).to(dev)
+        with torch.no_grad():
+            direct = m(mels)
+            got = parallel.synthesize_sharded(lambda b: m(b), mels, scatter=True, device=dev)
+            assert torch.equal(got, direct)
+            pcm = parallel.synthesize_sharded(lambda b: audio.encode_16bits(m(b), 0.4), mels, scatter=True, device=dev)
+        assert pcm.dtype == torch.int16 and pcm.shape == direct.shape
+        want = direct.cpu().numpy().copy()
+        for r in range(3):
+            row = want[r]
+            row *= 32767 / max(0.01, np.max(np.abs(row))) * 0.4
+            assert np.array_equal(pcm[r].cpu().numpy(), row.astype(np.int16))
+    finally:
+        dist.destroy_process_group()

@@ -150,3 +150,24 @@ def test_pair_rejects_what_it_is_not_built_for():
     w32 = _native.pack_pair(torch.zeros((32, 32, 3), device=dev))
     with pytest.raises(_native.NativeError, match="mrf"):
         _native.mrf_stage([x32] * 3, [w32] * 3, [w32] * 3, [None] * 3, [None] * 3, [3, 7, 11], 5, 0.1)
+
+
+def test_resblock1_on_the_fused_path_vs_reference_goldens():
+    """ResBlock1(x) at a length the fused pair kernels take (T = 52), 16 and 32 channels, 3 / 7 / 11 taps,
+    against the REFERENCE module's outputs (tests/golden/blocks_t52.npz, made by make_golden.py)."""
+    import os
+    from fastvocoder_amd.generator import modules as M
+    from tests import cases
+    g = np.load(os.path.join(cases.ROOT, "tests", "golden", "blocks_t52.npz"))
+    for ch in (16, 32):
+        x = torch.from_numpy(g[f"x{ch}"]).to(_dev())
+        for k in (3, 7, 11):
+            rb = M.ResBlock1(ch, k, (1, 3, 5)).to(_dev())
+            flat, off = g[f"rb1_c{ch}_k{k}_params"], 0
+            with torch.no_grad():
+                for p in rb.parameters():
+                    p.copy_(torch.from_numpy(flat[off:off + p.numel()].reshape(tuple(p.shape))))
+                    off += p.numel()
+            y = rb(x)
+            assert "forward_fused" in rb._fv_plans and rb._fv_plans["forward_fused"][1].num_ops() == 3
+            assert _rel(y, g[f"rb1_c{ch}_k{k}_out"]) <= 2e-5

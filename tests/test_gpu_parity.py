@@ -53,6 +53,8 @@ def _model(name, cfg, seed):
 def test_native_library_is_loaded():
     L = _native.lib()
     assert L.fv_version() == _native.ABI_VERSION
+    # the binary is THIS tree's: its embedded build id is the hash of the sources next to it
+    assert L.fv_build_id().decode() == _native.source_hash()
     with open("/proc/self/maps") as f:
         assert "libfastvocoder_hip.so" in f.read()
 
@@ -629,6 +631,19 @@ def test_synthesize_triple_config1(golden_dir, tmp_path):
     assert _err(est, g["est"]) <= TOL
     assert _err(bias, g["bias"]) <= TOL
     assert _err(rem, g["remove"]) <= TOL
+
+
+def test_encode_16bits_vs_reference_fixture(golden_dir):
+    """fv_encode_16bits against what the REFERENCE's data/audio.py:12-14 produced (tests/golden/audio.npz,
+    made by make_golden.py): the int16 samples AND the in-place scaled argument, bit for bit -- including
+    the max(0.01, .) floor case, an all-zero waveform and rescale_out = 0.4 (hparams.rescale_out)."""
+    from fastvocoder_amd import audio
+    g = np.load(os.path.join(golden_dir, "audio.npz"))
+    for tag in ("unit", "quiet_floor", "rescale04", "big", "zeros"):
+        x = torch.from_numpy(g[f"{tag}_in"].copy()).to(_dev())
+        q = audio.encode_16bits(x, float(g[f"{tag}_rescale"]))
+        assert np.array_equal(q if isinstance(q, np.ndarray) else q.cpu().numpy(), g[f"{tag}_int16"]), tag
+        assert np.array_equal(x.cpu().numpy(), g[f"{tag}_scaled"]), tag
 
 
 @pytest.mark.parametrize("n,peak,rescale", [(48000, 0.7, 1.0), (240015, 0.93, 0.4), (1001, 0.004, 1.0),

@@ -165,6 +165,9 @@ def test_c_abi_library_exports_every_declared_symbol():
     for n in sorted(names):
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
     assert _native.lib().fv_version() == _native.ABI_VERSION
+    # build provenance: the binary carries the hash of the sources it was built from
+    assert _native.lib().fv_build_id().decode() == _native.source_hash() == _native.built_id()
+    assert _native.lib().fv_packed_pair_floats(32, 11) == 32 * 32 * 11
     # host-only entry points that need no device
     assert _native.lib().fv_packed_conv1d_floats(128, 128, 11) == 128 * 11 * 128
     # k = 2*stride, Cout % 32 == 0: phase-major form, 2 taps per phase (3 in the co-major form)
