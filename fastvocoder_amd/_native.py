@@ -25,6 +25,7 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 PAD_CAUSAL = 2      # flag: pad (k-1)*dil on both sides, keep the first Tin outputs (CausalConv1d)
 POST_NONE, POST_TANH, POST_RELU = 0, 1, 2
 SLOT_NONE, SLOT_IN, SLOT_OUT, SLOT_TMP0, MAX_SLOTS = -1, 0, 1, 2, 32
+SLOT_AUX_IN0, SLOT_AUX_IN1, SLOT_OUT2 = 28, 29, 30    # caller-provided tensors of Plan.run(aux=..., out2=...)
 ABI_VERSION = 7
 
 
@@ -157,6 +158,9 @@ def lib():
     L.fv_plan_workspace_bytes.argtypes = [vp, i, i]
     L.fv_plan_workspace_bytes.restype = i64
     L.fv_plan_run.argtypes = [vp, i, i, vp, vp, vp, i64, vp]
+    L.fv_plan_run_aux.argtypes = [vp, i, i, vp, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(i), vp, i64, vp]
+    L.fv_plan_set_output_offset.argtypes = [vp, i, i]
+    L.fv_plan_slot_shape.argtypes = [vp, i, i, ctypes.POINTER(i), ctypes.POINTER(i64)]
     L.fv_plan_num_ops.argtypes = [vp]
     L.fv_profile_enable.argtypes = [i]
     L.fv_profile_bracket_cost.argtypes = [vp, i, ctypes.POINTER(ctypes.c_double)]
@@ -543,16 +547,25 @@ class Plan:
         self.keep(h)
         check(lib().fv_plan_add_pqmf_synthesis(self._h, x, y, _ptr(h, "h"), h.shape[0], h.shape[1]))
 
-    def output_shape(self, T):
+    def set_output_offset(self, aux_slot, y2_slot=SLOT_NONE):
+        """The op added last subtracts auxiliary input ``aux_slot`` in its epilogue (fv_plan_set_output_offset)."""
+        check(lib().fv_plan_set_output_offset(self._h, aux_slot, y2_slot))
+
+    def slot_shape(self, T, slot):
         c, n = ctypes.c_int(), ctypes.c_int64()
-        check(lib().fv_plan_output_shape(self._h, T, ctypes.byref(c), ctypes.byref(n)))
+        check(lib().fv_plan_slot_shape(self._h, T, slot, ctypes.byref(c), ctypes.byref(n)))
         return c.value, n.value
+
+    def output_shape(self, T):
+        return self.slot_shape(T, SLOT_OUT)
 
     def num_ops(self):
         return lib().fv_plan_num_ops(self._h)
 
-    def run(self, x, out=None):
-        """x [B,Cin,T] contiguous fp32 on a ROCm device -> [B,Cout,Tout]."""
+    def run(self, x, out=None, aux=(), out2=False):
+        """x [B,Cin,T] contiguous fp32 on a ROCm device -> [B,Cout,Tout].  ``aux``: up to two tensors for the
+        plan's auxiliary inputs (output offsets: [C,T'], [1,C,T'] or, per utterance, [B,C,T']); ``out2``: also
+        return the plan's second output (SLOT_OUT2) -> (out, out2)."""
         if x.dim() != 3 or x.shape[1] != self.in_channels:
             raise NativeError(f"plan input must be [B, {self.in_channels}, T], got {tuple(x.shape)}")
         B, _, T = x.shape
@@ -568,10 +581,18 @@ class Plan:
                 check(int(nbytes))
             self._ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=x.device)
             self._ws_key = key
-        with _on(x, out, self._ws, *self._keep[:1]) as stream:
-            check(lib().fv_plan_run(self._h, B, T, _ptr(x, "input"), _ptr(out, "out"),
-                                    self._ws.data_ptr(), self._ws.numel(), stream))
-        return out
+        second = None
+        if out2:
+            c2, n2 = self.slot_shape(T, SLOT_OUT2)
+            second = torch.empty((B, c2, n2), dtype=torch.float32, device=x.device)
+        aux = list(aux) + [None] * (2 - len(aux))
+        ptrs = (ctypes.c_void_p * 2)(*[_ptr(a, "aux", True) for a in aux])
+        batched = (ctypes.c_int * 2)(*[1 if (a is not None and a.dim() == 3 and a.shape[0] == B and B > 1) else 0
+                                       for a in aux])
+        with _on(x, out, self._ws, second, *aux, *self._keep[:1]) as stream:
+            check(lib().fv_plan_run_aux(self._h, B, T, _ptr(x, "input"), _ptr(out, "out"), _ptr(second, "out2", True),
+                                        ptrs, batched, self._ws.data_ptr(), self._ws.numel(), stream))
+        return (out, second) if out2 else out
 
 
 # ---------------------------------------------------------------------------

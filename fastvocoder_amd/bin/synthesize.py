@@ -46,6 +46,16 @@ def build_generator(model_name, config):
     raise Exception("no model find!")
 
 
+def load_checkpoint(path, device):
+    """torch.load restricted to tensors and plain containers when possible; published checkpoints carry a
+    numpy ``'pattern'`` entry (bin/publish.py:71-75), which needs the unrestricted unpickler -- only then,
+    and only for a file the caller chose, is it used."""
+    try:
+        return torch.load(path, map_location=device, weights_only=True)
+    except Exception:   # noqa: BLE001 - numpy arrays / legacy pickles
+        return torch.load(path, map_location=device, weights_only=False)
+
+
 def default_device():
     if not torch.cuda.is_available():
         raise RuntimeError("fastvocoder_amd needs a ROCm GPU (MI355X); no CPU inference path exists")
@@ -62,7 +72,7 @@ class Synthesizer:
             config = yaml.load(f, Loader=yaml.Loader)
         print(f"Loading Model of {model_name}...")
         model = build_generator(model_name, config).to(self.device)
-        ckpt = torch.load(os.path.join(checkpoint_path), map_location=self.device, weights_only=False)
+        ckpt = load_checkpoint(checkpoint_path, self.device)
         model.load_state_dict(ckpt["model"])
         model.eval()
         model.remove_weight_norm()
@@ -70,24 +80,31 @@ class Synthesizer:
         self.config = config
         return model
 
+    _ZERO_CACHE_ENTRIES = 8     # ~1 MB of device memory per 1000 frames each
+
     def zero_mel_response(self, frames):
-        """The generator's output for an all-zero mel of ``frames`` frames.  It depends
-        only on (weights, frames), so it is computed once per length and cached
+        """The generator's output for an all-zero mel of ``frames`` frames.  It depends only on
+        (weights, frames): computed once per (weights version, length) and kept in a small LRU
         (the reference recomputes it for every utterance, bin/synthesize.py:76-77)."""
         cache = self.__dict__.setdefault("_zero_cache", {})
-        if frames not in cache:
+        key = (self.model._fv_state(), int(frames))
+        if key in cache:
+            cache[key] = cache.pop(key)                      # most recently used last
+        else:
+            while len(cache) >= self._ZERO_CACHE_ENTRIES:
+                cache.pop(next(iter(cache)))
             with torch.no_grad():
-                cache[frames] = self.model.inference(
+                cache[key] = self.model.inference(
                     torch.zeros(frames, self.config.get("in_channels", 80))).clone()
-        return cache[frames]
+        return cache[key]
 
     def synthesize(self, mel):
-        """mel [T,80] ndarray -> (est_source, est_source - bias, bias), each 1-D fp32
-        on the device; ``bias`` is the generator's response to an all-zero mel."""
+        """mel [T,80] ndarray -> (est_source, est_source - bias, bias), each 1-D fp32 on the device;
+        ``bias`` is the generator's response to an all-zero mel (cached) and the difference is formed in
+        the last kernel's epilogue: one generator pass per utterance instead of the reference's two."""
         with torch.no_grad():
             bias = self.zero_mel_response(int(np.asarray(mel).shape[0]))
-            est_source = self.model.inference(mel)
-            est_source_remove_bias = est_source - bias
+            est_source, est_source_remove_bias = self.model.inference_minus(mel, bias)
         return est_source, est_source_remove_bias, bias
 
     def test_rtf(self, mel):

@@ -35,13 +35,17 @@ class Synthesizer(_BaseSynthesizer):
         """Basis-MelGAN only (like the reference): drop the trailing L/2 samples
         and subtract the stored zero-mel pattern (or a fresh zero-mel pass)."""
         with torch.no_grad():
-            est_source = self.model.inference(mel)[:-(self.L // 2)]
+            frames = int(np.asarray(mel).shape[0])
+            n = self.model._minus_plan(frames).output_shape(frames)[1]      # (F-1)*L/2 + L samples
+            keep = n - self.L // 2
             if getattr(self, "pattern", None) is not None:
-                est_source = est_source - self.pattern[:est_source.size(0)]
+                # the stored zero-mel pattern, padded to the generator's output length (the tail is dropped)
+                bias = torch.zeros(n, dtype=torch.float32, device=self.pattern.device)
+                bias[:keep] = self.pattern[:keep]
             else:
-                zero = torch.zeros_like(torch.from_numpy(np.asarray(mel))).float()
-                est_source = est_source - self.model.inference(zero)[:-(self.L // 2)]
-        return est_source
+                bias = self.model.inference(torch.zeros(frames, np.asarray(mel).shape[1]))
+            _, removed = self.model.inference_minus(mel, bias)              # one pass; difference in the epilogue
+        return removed[:keep]
 
 
 def run_test():

@@ -238,6 +238,7 @@ struct Op {
     const float* pb1[3] = {nullptr, nullptr, nullptr};
     const float* pb2[3] = {nullptr, nullptr, nullptr};
     int pk[3] = {0, 0, 0};
+    int sub = FV_SLOT_NONE;   // fv_plan_set_output_offset: auxiliary input subtracted in this op's epilogue
 };
 
 constexpr int kMaxLanes = 4;
@@ -294,6 +295,9 @@ static int infer(const fv_plan* plan, int B, int T, Shape* sh, int64_t* slot_ele
     sh[FV_SLOT_IN] = {plan->in_channels, T, true};
     for (size_t n = 0; n < plan->ops.size(); ++n) {
         const Op& o = plan->ops[n];
+        if (o.x == FV_SLOT_AUX_IN0 || o.x == FV_SLOT_AUX_IN1 || o.y == FV_SLOT_AUX_IN0 || o.y == FV_SLOT_AUX_IN1 ||
+            o.y2 == FV_SLOT_AUX_IN0 || o.y2 == FV_SLOT_AUX_IN1)
+            return fail(FV_ERR_INVALID_ARG, "op %zu: the auxiliary input slots can only be output offsets", n);
         if (!sh[o.x].set) return fail(FV_ERR_INVALID_ARG, "op %zu reads unset slot %d", n, o.x);
         const int cin_x = o.x2 == FV_SLOT_NONE ? o.Cin : o.Cin1;
         if (sh[o.x].C != cin_x)
@@ -355,8 +359,10 @@ static int infer(const fv_plan* plan, int B, int T, Shape* sh, int64_t* slot_ele
 
 static ConvParams make_params(const Op& o, const float* x, float* y, float* y2, const float* res,
                               const float* acc, const float* acc2, int B, int64_t Tin,
-                              const float* x2 = nullptr) {
+                              const float* x2 = nullptr, const float* sub = nullptr, int sub_batched = 0) {
     ConvParams p = {};
+    p.sub = sub;
+    p.sub_batched = sub_batched;
     p.x = x;
     p.x2 = x2;
     p.Cin1 = x2 ? o.Cin1 : o.Cin;
@@ -409,9 +415,10 @@ static ConvParams make_params(const Op& o, const float* x, float* y, float* y2, 
 }
 
 static int run_op(const Op& o, const float* x, float* y, float* y2, const float* res, const float* acc,
-                  const float* acc2, int B, int64_t Tin, hipStream_t s, const float* x2 = nullptr) {
-    if (o.type == OP_PQMF) return launch_pqmf(x, o.wp, y, B, o.Cin, o.k, (int)Tin, s);
-    return launch_conv(make_params(o, x, y, y2, res, acc, acc2, B, Tin, x2), s);
+                  const float* acc2, int B, int64_t Tin, hipStream_t s, const float* x2 = nullptr,
+                  const float* sub = nullptr, int sub_batched = 0) {
+    if (o.type == OP_PQMF) return launch_pqmf(x, o.wp, y, y2, sub, sub_batched, B, o.Cin, o.k, (int)Tin, s);
+    return launch_conv(make_params(o, x, y, y2, res, acc, acc2, B, Tin, x2, sub, sub_batched), s);
 }
 
 // Cross-lane dependencies from the slots each op reads and writes (RAW, WAR, WAW):
@@ -692,7 +699,7 @@ int fv_pqmf_synthesis(const float* x, const float* h, float* y, int B, int S, in
                       void* stream) {
     if (!x || !h || !y || B < 0 || S <= 0 || ntaps <= 0 || ntaps % 2 == 0 || Tsub < 0)
         return fail(FV_ERR_INVALID_ARG, "pqmf: B=%d S=%d ntaps=%d Tsub=%d", B, S, ntaps, Tsub);
-    return launch_pqmf(x, h, y, B, S, ntaps, Tsub, (hipStream_t)stream);
+    return launch_pqmf(x, h, y, nullptr, nullptr, 0, B, S, ntaps, Tsub, (hipStream_t)stream);
 }
 
 int fv_pqmf_analysis(const float* x, const float* h, float* y, int B, int S, int ntaps, int64_t T,
@@ -1060,6 +1067,25 @@ int fv_plan_add_mrf_sum(fv_plan_t* plan, const int* x_slots, int y_slot, int y_a
     return 0;
 }
 
+int fv_plan_set_output_offset(fv_plan_t* plan, int aux_slot, int y2_slot) {
+    if (!plan || plan->ops.empty()) return fail(FV_ERR_INVALID_ARG, "plan_set_output_offset: no op to attach to");
+    if (aux_slot != FV_SLOT_AUX_IN0 && aux_slot != FV_SLOT_AUX_IN1)
+        return fail(FV_ERR_INVALID_ARG, "plan_set_output_offset: slot %d is not an auxiliary input", aux_slot);
+    if (int rc = check_slot(y2_slot, true)) return rc;
+    Op& o = plan->ops.back();
+    if (o.type == OP_PAIR || o.type == OP_MRFSUM || o.sum3 || o.group != 0)
+        return fail(FV_ERR_UNSUPPORTED, "plan_set_output_offset: only plain conv / transposed conv / pqmf ops carry an offset");
+    if (y2_slot != FV_SLOT_NONE) {
+        if (o.y2 != FV_SLOT_NONE) return fail(FV_ERR_INVALID_ARG, "plan_set_output_offset: the op already has a second output");
+        if (y2_slot == o.y || y2_slot == o.x || y2_slot == FV_SLOT_IN) return fail(FV_ERR_INVALID_ARG, "plan_set_output_offset: y2 aliases");
+        o.y2 = y2_slot;
+        if (o.type != OP_PQMF) o.act_slope = 1.f;
+    }
+    o.sub = aux_slot;
+    plan->compiled = false;
+    return 0;
+}
+
 int fv_plan_set_group(fv_plan_t* plan, int group) {
     if (!plan || group < 0) return fail(FV_ERR_INVALID_ARG, "plan_set_group: group %d", group);
     plan->cur_group = group;
@@ -1078,15 +1104,20 @@ int fv_plan_set_lane(fv_plan_t* plan, int lane) {
     return 0;
 }
 
-int fv_plan_output_shape(fv_plan_t* plan, int T, int* out_channels, int64_t* out_len) {
+int fv_plan_slot_shape(fv_plan_t* plan, int T, int slot, int* channels, int64_t* len) {
     if (!plan) return fail(FV_ERR_INVALID_ARG, "null plan");
+    if (int rc = check_slot(slot, false)) return rc;
     Shape sh[FV_MAX_SLOTS];
     int64_t elems[FV_MAX_SLOTS];
     if (int rc = infer(plan, 1, T, sh, elems)) return rc;
-    if (!sh[FV_SLOT_OUT].set) return fail(FV_ERR_INVALID_ARG, "plan never writes the output slot");
-    if (out_channels) *out_channels = sh[FV_SLOT_OUT].C;
-    if (out_len) *out_len = sh[FV_SLOT_OUT].T;
+    if (!sh[slot].set) return fail(FV_ERR_INVALID_ARG, "plan never writes slot %d", slot);
+    if (channels) *channels = sh[slot].C;
+    if (len) *len = sh[slot].T;
     return 0;
+}
+
+int fv_plan_output_shape(fv_plan_t* plan, int T, int* out_channels, int64_t* out_len) {
+    return fv_plan_slot_shape(plan, T, FV_SLOT_OUT, out_channels, out_len);
 }
 
 int64_t fv_plan_workspace_bytes(fv_plan_t* plan, int B, int T) {
@@ -1095,12 +1126,18 @@ int64_t fv_plan_workspace_bytes(fv_plan_t* plan, int B, int T) {
     int64_t elems[FV_MAX_SLOTS];
     if (int rc = infer(plan, B, T, sh, elems)) return rc < 0 ? rc : -rc;
     int64_t bytes = 0;
-    for (int i = FV_SLOT_TMP0; i < FV_MAX_SLOTS; ++i) bytes += (elems[i] * 4 + 255) / 256 * 256;
+    for (int i = FV_SLOT_TMP0; i < FV_SLOT_AUX_IN0; ++i) bytes += (elems[i] * 4 + 255) / 256 * 256;
     return bytes;
 }
 
 int fv_plan_run(fv_plan_t* plan, int B, int T, const float* in, float* out, void* workspace,
                 int64_t workspace_bytes, void* stream) {
+    return fv_plan_run_aux(plan, B, T, in, out, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, float* out2,
+                    const float* const* aux_in, const int* aux_batched, void* workspace,
+                    int64_t workspace_bytes, void* stream) {
     if (!plan || !in || !out) return fail(FV_ERR_INVALID_ARG, "plan_run: null argument");
     if (B <= 0 || T <= 0) return fail(FV_ERR_INVALID_ARG, "plan_run: B=%d T=%d", B, T);
     Shape sh[FV_MAX_SLOTS];
@@ -1108,9 +1145,17 @@ int fv_plan_run(fv_plan_t* plan, int B, int T, const float* in, float* out, void
     if (int rc = infer(plan, B, T, sh, elems)) return rc;
     float* base[FV_MAX_SLOTS] = {};
     int64_t off = 0;
-    for (int i = FV_SLOT_TMP0; i < FV_MAX_SLOTS; ++i) {
+    for (int i = FV_SLOT_TMP0; i < FV_SLOT_AUX_IN0; ++i) {
         base[i] = reinterpret_cast<float*>(static_cast<char*>(workspace) + off);
         off += (elems[i] * 4 + 255) / 256 * 256;
+    }
+    base[FV_SLOT_AUX_IN0] = aux_in ? const_cast<float*>(aux_in[0]) : nullptr;
+    base[FV_SLOT_AUX_IN1] = aux_in ? const_cast<float*>(aux_in[1]) : nullptr;
+    base[FV_SLOT_OUT2] = out2;
+    const int aux_b[2] = {aux_batched ? aux_batched[0] : 0, aux_batched ? aux_batched[1] : 0};
+    for (const Op& o : plan->ops) {
+        if (o.sub != FV_SLOT_NONE && !base[o.sub]) return fail(FV_ERR_INVALID_ARG, "plan_run: the plan subtracts auxiliary input %d, which was not given", o.sub - FV_SLOT_AUX_IN0);
+        if ((o.y == FV_SLOT_OUT2 || o.y2 == FV_SLOT_OUT2) && !out2) return fail(FV_ERR_INVALID_ARG, "plan_run: the plan writes a second output, which was not given");
     }
     if (off > workspace_bytes || (off > 0 && !workspace))
         return fail(FV_ERR_WORKSPACE, "plan needs %lld workspace bytes, got %lld", (long long)off,
@@ -1276,7 +1321,8 @@ int fv_plan_run(fv_plan_t* plan, int B, int T, const float* in, float* out, void
         if (multi)
             for (int d = 0; d < o.ndeps; ++d) FV_HIP(hipStreamWaitEvent(s, plan->op_event[o.deps[d]], 0));
         if (int rc = run_op(o, base[o.x], base[o.y], y2, res, acc, acc2, B, Tin, s,
-                            o.x2 == FV_SLOT_NONE ? nullptr : base[o.x2]))
+                            o.x2 == FV_SLOT_NONE ? nullptr : base[o.x2], o.sub == FV_SLOT_NONE ? nullptr : base[o.sub],
+                            o.sub == FV_SLOT_NONE ? 0 : aux_b[o.sub - FV_SLOT_AUX_IN0]))
             return rc;
         if (multi && o.signal) FV_HIP(hipEventRecord(plan->op_event[n], s));
         sh[o.y] = {o.type == OP_PQMF ? 1 : o.Cout, Tout, true};

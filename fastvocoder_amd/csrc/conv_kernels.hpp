@@ -267,7 +267,7 @@ __device__ __forceinline__ void stage_x(const ConvParams& p, const DmaPlan& d, _
 // gets an out-of-range offset (loads 0, store dropped), so the loads of a tile
 // issue back to back instead of one s_waitcnt vmcnt(0) per element.
 struct EpilogueRsrc {
-    __amdgpu_buffer_rsrc_t y, y2, res, acc, acc2;
+    __amdgpu_buffer_rsrc_t y, y2, res, acc, acc2, sub;
 };
 
 __device__ __forceinline__ EpilogueRsrc epilogue_rsrc(const ConvParams& p, int b) {
@@ -279,6 +279,7 @@ __device__ __forceinline__ EpilogueRsrc epilogue_rsrc(const ConvParams& p, int b
     e.res = make_rsrc(p.res ? p.res + boff : p.y + boff, bytes);
     e.acc = make_rsrc(p.acc_in ? p.acc_in + boff : p.y + boff, bytes);
     e.acc2 = make_rsrc(p.acc_in2 ? p.acc_in2 + boff : p.y + boff, bytes);
+    e.sub = make_rsrc(p.sub ? p.sub + (p.sub_batched ? boff : 0) : p.y + boff, bytes);
     return e;
 }
 
@@ -395,7 +396,21 @@ __device__ __forceinline__ void epilogue_finish(const ConvParams& p, const Epilo
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = fmaxf(v[i], 0.f);
     }
-    if (p.y_act) {
+    if (p.sub) {
+        // bias-removal flows (last op of a graph only): y raw, y2 = act(y) - sub; or y = act(y) - sub
+        float sv[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) sv[i] = buffer_load1s(e.sub, off[i], so[i]);
+        if (p.y_act) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) buffer_store1s(e.y, off[i], so[i], v[i]);
+#pragma unroll
+            for (int i = 0; i < N; ++i) buffer_store1s(e.y2, off[i], so[i], act(v[i], p.act_slope) - sv[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) buffer_store1s(e.y, off[i], so[i], act(v[i], p.act_slope) - sv[i]);
+        }
+    } else if (p.y_act) {
         // raw tensor for residual consumers + activated twin for conv consumers
 #pragma unroll
         for (int i = 0; i < N; ++i) buffer_store1s(e.y, off[i], so[i], v[i]);

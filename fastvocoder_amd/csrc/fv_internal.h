@@ -80,6 +80,9 @@ struct ConvParams {
     const float* acc_in2; // second running-sum input (added to acc_in first) or null
     float* y;             // [B,Cout,Tout]
     float* y_act;         // optional activated twin of y: act(y, act_slope), or null
+    const float* sub;     // optional offset subtracted AFTER post / activation from the stored value -- from the
+                          // twin when there is one (y stays raw), else from y: [Cout,Tout], or [B,Cout,Tout]
+    int sub_batched;      //   (sub_batched).  The bias-removal flows: y - generator(0) (bin/synthesize.py:74-80)
     int B, Cin, M, Mpad, Cout;
     int Tin, Tq, Tout;
     int k, dil, pad, pad_mode;
@@ -185,8 +188,8 @@ constexpr int kMaxDmaX = 6, kMaxDmaW = 8;   // LDS-DMA instructions per wave per
 int launch_conv(ConvParams p, hipStream_t stream);
 // n mutually independent convs; one grouped launch when they form an MRF position
 int launch_conv_group(ConvParams* ps, int n, hipStream_t stream);
-int launch_pqmf(const float* x, const float* h, float* y, int B, int S, int ntaps, int Tsub,
-                hipStream_t stream);
+int launch_pqmf(const float* x, const float* h, float* y, float* y2, const float* sub, int sub_batched, int B, int S,
+                int ntaps, int Tsub, hipStream_t stream);
 int launch_encode16(float* x, int B, int64_t n, float rescale, short* out, unsigned* peak_bits,
                     int scale_in_place, hipStream_t s);
 int launch_pqmf_analysis(const float* xin, const float* ha, float* x, int B, int S, int ntaps,

@@ -14,10 +14,13 @@
 
 namespace fv {
 
+// y2 / sub (optional): the bias-removal flows -- y2 = y - sub when y2 is given (y stays the plain synthesis),
+// else y = y - sub; sub is [T] or, sub_batched, [B, T].
 __global__ __launch_bounds__(256) void pqmf_synthesis_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ h,
-                                                             float* __restrict__ y, int S,
-                                                             int ntaps, int Tsub) {
+                                                             float* __restrict__ y, float* __restrict__ y2,
+                                                             const float* __restrict__ sub, int sub_batched,
+                                                             int S, int ntaps, int Tsub) {
     extern __shared__ float hs[];  // [S][ntaps], scaled by S
     for (int i = threadIdx.x; i < S * ntaps; i += 256) hs[i] = h[i] * (float)S;
     __syncthreads();
@@ -37,7 +40,17 @@ __global__ __launch_bounds__(256) void pqmf_synthesis_kernel(const float* __rest
                 if (m >= 0 && m < Tsub) acc = fmaf(hr[j], xr[m], acc);
             }
         }
-        y[(size_t)b * T + n] = acc;
+        if (sub) {
+            const float d = acc - sub[(sub_batched ? (size_t)b * T : 0) + n];
+            if (y2) {
+                y[(size_t)b * T + n] = acc;
+                y2[(size_t)b * T + n] = d;
+            } else {
+                y[(size_t)b * T + n] = d;
+            }
+        } else {
+            y[(size_t)b * T + n] = acc;
+        }
     }
 }
 
@@ -83,14 +96,14 @@ int launch_pqmf_analysis(const float* xin, const float* ha, float* x, int B, int
     return 0;
 }
 
-int launch_pqmf(const float* x, const float* h, float* y, int B, int S, int ntaps, int Tsub,
-                hipStream_t s) {
+int launch_pqmf(const float* x, const float* h, float* y, float* y2, const float* sub, int sub_batched, int B, int S,
+                int ntaps, int Tsub, hipStream_t s) {
     if (B <= 0 || Tsub <= 0) return 0;
     const int64_t T = (int64_t)S * Tsub;
     int64_t blocks = (T + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(pqmf_synthesis_kernel, dim3((unsigned)blocks, B), dim3(256),
-                       (size_t)S * ntaps * sizeof(float), s, x, h, y, S, ntaps, Tsub);
+                       (size_t)S * ntaps * sizeof(float), s, x, h, y, y2, sub, sub_batched, S, ntaps, Tsub);
     FV_HIP(hipGetLastError());
     return 0;
 }

@@ -15,7 +15,7 @@ import torch
 
 from .. import _native
 from .._native import (PAD_CAUSAL, PAD_REFLECT, PAD_ZERO, POST_NONE, POST_RELU, POST_TANH,  # noqa: F401
-                       SLOT_IN, SLOT_NONE, SLOT_OUT)
+                       SLOT_AUX_IN0, SLOT_AUX_IN1, SLOT_IN, SLOT_NONE, SLOT_OUT, SLOT_OUT2)
 
 
 def weight_norm(module):
@@ -58,8 +58,8 @@ class PlanBuilder:
 
     def tmp(self):
         s = self._next
-        if s >= _native.MAX_SLOTS:
-            raise _native.NativeError("plan needs more than %d tensor slots" % _native.MAX_SLOTS)
+        if s >= SLOT_AUX_IN0:
+            raise _native.NativeError("plan needs more than %d tensor slots" % (SLOT_AUX_IN0 - _native.SLOT_TMP0))
         self._next += 1
         return s
 
@@ -204,6 +204,18 @@ class PlanBuilder:
                              pre_slope=float(pre_slope), packed=_native.pack_conv_transpose1d(w, hop, 0),
                              bias=None, cin=C, cout=1, k=L, stride=hop, pad=0, out_pad=0, post=POST_NONE))
 
+    def subtract_output(self, aux=0, second=True):
+        """The op recorded last also subtracts the plan's auxiliary input ``aux`` (0 or 1; a cached
+        zero-input response given to ``Plan.run(aux=...)``) after its post op: with ``second`` it keeps its
+        own output and writes the difference to SLOT_OUT2, otherwise its output becomes the difference.
+        Bias removal without a separate elementwise pass (reference bin/synthesize.py:74-80,
+        basis_melgan.py:147-159, bin/test.py:82-91)."""
+        op = self.ops[-1]
+        if op["kind"] not in ("conv", "conv2", "convT", "upconv", "pqmf") or op.get("group", 0):
+            raise _native.NativeError("subtract_output: the last op must be a plain conv / transposed conv / pqmf")
+        op["sub"] = SLOT_AUX_IN0 + int(aux)
+        op["sub_y2"] = SLOT_OUT2 if second else SLOT_NONE
+
     def pqmf_synthesis(self, synthesis_filter, src, dst):
         S = synthesis_filter.shape[1]
         h = synthesis_filter.detach().reshape(S, -1).contiguous().float()
@@ -343,6 +355,8 @@ class PlanBuilder:
                                               y_act=op["y_act"], act_slope=op["act_slope"])
             else:
                 self.plan.add_pqmf_synthesis(op["x"], op["y"], op["h"])
+            if "sub" in op:
+                self.plan.set_output_offset(op["sub"], op["sub_y2"])
         return self.plan
 
 
@@ -480,6 +494,22 @@ class NativeModule(torch.nn.Module):
             last = b * hop if b < T else total
             out[:, :, first:last] = y[:, :, first - lo * hop: last - lo * hop]
         return out
+
+    def _run_minus(self, plan_for, x, bias):
+        """Run ``plan_for(T)`` -- a graph whose last op carries ``PlanBuilder.subtract_output(0, True)`` --
+        on x [B,C,T] with ``bias`` (any shape with the output's element count per utterance, or one row
+        per utterance) as the offset: returns (out, out - bias), both [B,Cout,Tout], from ONE pass; the
+        subtraction happens in the last kernel's epilogue.  Inputs longer than ``max_frames_per_run`` take
+        the chunked route and one elementwise subtraction."""
+        bias = bias.detach().to(device=x.device, dtype=torch.float32)
+        if x.shape[2] > self.max_frames_per_run:
+            out = self._run_plan(plan_for, x)
+            return out, out - bias.reshape((-1,) + tuple(out.shape[1:]))
+        plan = plan_for(x.shape[2])
+        c, n = plan.output_shape(x.shape[2])
+        if bias.numel() not in (c * n, x.shape[0] * c * n):
+            raise _native.NativeError(f"bias has {bias.numel()} elements, the output {c} x {n} per utterance")
+        return plan.run(x, aux=(bias.reshape(-1, c, n).contiguous(),), out2=True)
 
     def _prepare(self, x):
         """Any array-like -> contiguous fp32 tensor on this module's device."""

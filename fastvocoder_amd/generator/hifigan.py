@@ -207,6 +207,25 @@ class _HiFiGANBase(NativeModule):
         return self._plan("trunk" + "".join("f" if f else "-" for f in fused),
                           lambda pb: self._emit_trunk(pb, SLOT_OUT, fused), 80)
 
+    def _emit_inference(self, pb, fused):
+        self._emit_trunk(pb, SLOT_OUT, fused)
+
+    def _minus_plan(self, T):
+        """The inference graph whose last op also writes (output - auxiliary input) to the second output."""
+        fused = self._fused_flags(T)
+
+        def emit(pb):
+            self._emit_inference(pb, fused)
+            pb.subtract_output(0, second=True)
+        return self._plan("minus" + "".join("f" if f else "-" for f in fused), emit, 80)
+
+    def inference_minus(self, x, bias):
+        """x [T,80], bias [n] (e.g. the response to an all-zero mel) -> (waveform, waveform - bias), both 1-D,
+        from one generator pass: what bin/synthesize.py:74-80 forms with a second pass and a subtraction."""
+        x = self._prepare(x).transpose(1, 0).unsqueeze(0).contiguous()
+        est, rem = self._run_minus(self._minus_plan, x, bias)
+        return est.squeeze(), rem.squeeze()
+
     def _trunk(self, x):
         return self._run_plan(self._trunk_plan, x)
 
@@ -260,6 +279,9 @@ class MultiBandHiFiGANGenerator(_HiFiGANBase):
         sub = pb.tmp()
         self._emit_trunk(pb, sub, fused)
         pb.pqmf_synthesis(self.pqmf.synthesis_filter, sub, SLOT_OUT)
+
+    def _emit_inference(self, pb, fused):
+        self._emit_full(pb, fused)
 
     def _full_plan(self, T):
         fused = self._fused_flags(T)

@@ -10,7 +10,8 @@ it is a parameter container only -- calls go through native plans.
 """
 import torch
 
-from .engine import NativeModule, POST_NONE, POST_RELU, POST_TANH, SLOT_IN, SLOT_OUT
+from .. import _native
+from .engine import NativeModule, POST_NONE, POST_RELU, POST_TANH, SLOT_IN, SLOT_OUT, SLOT_OUT2  # noqa: F401
 from .modules import (BasisSignalLayer, LastLayer, LastLinear, ResidualStack, UpsampleLayer,
                       _activation_slope, _pad_mode)
 
@@ -118,6 +119,18 @@ class MelGANGenerator(_MelGANTrunk):
         """c [B,in_channels,T] -> [B, T*prod(upsample_scales)] (channel 0)."""
         return self._run(self._prepare(c))[:, 0, :]
 
+    def _minus_plan(self, T):
+        def emit(pb):
+            self._emit_layers(pb, SLOT_OUT, self._final_post)
+            pb.subtract_output(0, second=True)
+        return self._plan("minus", emit, self._in_channels)
+
+    def inference_minus(self, c, bias):
+        """c [T,in_channels], bias [n] -> (waveform, waveform - bias) from one pass (bin/synthesize.py:74-80)."""
+        c = self._prepare(c).transpose(1, 0).unsqueeze(0).contiguous()
+        est, rem = self._run_minus(self._minus_plan, c, bias)
+        return est.squeeze(), rem.squeeze()
+
     def inference(self, c):
         """c [T,in_channels] -> squeezed waveform."""
         c = self._prepare(c)
@@ -169,20 +182,63 @@ class BasisMelGANGenerator(_MelGANTrunk):
         scratch, no [B,F,L] frame tensor)."""
         return self._run_plan(self._plan("full", self._emit_full, self._in_channels), x)[:, 0, :]
 
+    def _zero_response(self, T):
+        """(zero_weight [1,C,F], zero_est [1,1,n]): the generator's response to an all-zero mel of T frames.
+        It depends only on (weights, T) and not on the batch -- the reference recomputes it in every
+        ``forward`` (basis_melgan.py:147-152); here it is computed once per (weights, T) and kept."""
+        def emit(pb):
+            self._emit_layers(pb, SLOT_OUT2, self._final_post)
+            self.basis_signal.emit(pb, SLOT_OUT2, SLOT_OUT)
+        key = (self._fv_state(), int(T))
+        cache = self.__dict__.setdefault("_fv_zero", {})
+        if key not in cache:
+            if len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+            dev = self._device()
+            zero = torch.zeros((1, self._in_channels, int(T)), dtype=torch.float32, device=dev)
+            est, w = self._plan("zero", emit, self._in_channels).run(zero, out2=True)
+            cache[key] = (w, est)
+        return cache[key]
+
     def forward(self, c):
-        """Reference semantics (basis_melgan.py:140-162): runs the zero-mel pass
-        too and returns (est - zero_est [B, F*L/2], weight - zero_weight [B,F,C])."""
+        """Reference semantics (basis_melgan.py:140-162): (est - zero_est [B, F*L/2], weight - zero_weight
+        [B,F,C]).  One generator pass: both differences are formed in the epilogues of the trunk's last conv
+        and of the overlap-add, against the cached zero-mel response."""
         c = self._prepare(c)
-        zero = torch.zeros_like(c)
         hop = self.L // 2
-        outs = []
-        for inp in (zero, c):
-            w = self._weights(inp)                                   # [B,C,F]
-            src = self._plan("ola", lambda pb: self.basis_signal.emit(pb, SLOT_IN, SLOT_OUT),
-                             w.shape[1]).run(w)[:, 0, :]
-            outs.append((src[:, : w.shape[2] * hop], w.transpose(1, 2)))
-        (zs, zw), (s, w) = outs
-        return s - zs, w - zw
+        if c.shape[2] > self.max_frames_per_run:
+            # longer than one run: time-chunked passes (mel and zero mel), then the overlap-add and the
+            # differences on the whole tensors -- the two-pass form of the reference
+            outs = []
+            for inp in (torch.zeros_like(c[:1]), c):
+                w = self._weights(inp)                                   # [B,C,F]
+                src = self._plan("ola", lambda pb: self.basis_signal.emit(pb, SLOT_IN, SLOT_OUT),
+                                 w.shape[1]).run(w)[:, 0, :]
+                outs.append((src[:, : w.shape[2] * hop], w.transpose(1, 2)))
+            (zs, zw), (s, w) = outs
+            return s - zs, w - zw
+        zw, zs = self._zero_response(c.shape[2])
+
+        def emit(pb):
+            w = pb.tmp()
+            self._emit_layers(pb, w, self._final_post)
+            pb.subtract_output(0, second=True)                       # SLOT_OUT2 = weight - zero_weight
+            self.basis_signal.emit(pb, w, SLOT_OUT)
+            pb.subtract_output(1, second=False)                      # SLOT_OUT  = est - zero_est
+        s, w = self._plan("forward", emit, self._in_channels).run(c, aux=(zw, zs), out2=True)
+        return s[:, 0, : w.shape[2] * hop], w.transpose(1, 2)
+
+    def _minus_plan(self, T):
+        def emit(pb):
+            self._emit_full(pb)
+            pb.subtract_output(0, second=True)
+        return self._plan("minus", emit, self._in_channels)
+
+    def inference_minus(self, c, bias):
+        """c [T,in_channels], bias [n] -> (waveform, waveform - bias) from one pass (bin/test.py:82-91)."""
+        c = self._prepare(c).transpose(1, 0).unsqueeze(0).contiguous()
+        est, rem = self._run_minus(self._minus_plan, c, bias)
+        return est.squeeze(), rem.squeeze()
 
     def inference(self, c):
         """c [T,in_channels] -> squeezed waveform of (F-1)*L/2 + L samples."""

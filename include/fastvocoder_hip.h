@@ -248,6 +248,11 @@ typedef struct fv_plan fv_plan_t;
 #define FV_SLOT_OUT 1
 #define FV_SLOT_TMP0 2
 #define FV_MAX_SLOTS 32
+/* caller-provided auxiliary tensors of fv_plan_run_aux: two read-only inputs (output offsets) and a second
+ * output; temporaries live in [FV_SLOT_TMP0, FV_SLOT_AUX_IN0) */
+#define FV_SLOT_AUX_IN0 28
+#define FV_SLOT_AUX_IN1 29
+#define FV_SLOT_OUT2 30
 
 fv_plan_t* fv_plan_create(int in_channels);
 void fv_plan_destroy(fv_plan_t* plan);
@@ -299,6 +304,16 @@ int fv_plan_add_upsample_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int y_a
 int fv_plan_add_pqmf_synthesis(fv_plan_t* plan, int x_slot, int y_slot, const float* h,
                                int S, int ntaps);
 
+/*
+ * Bias removal in the epilogue (bin/synthesize.py:74-80 est - generator(0); basis_melgan.py:147-159
+ * (est - zero_est, weight - zero_weight); bin/test.py:82-91 est - pattern): the op appended LAST (a conv1d,
+ * conv_transpose1d / upsample conv or the pqmf synthesis) subtracts the auxiliary input `aux_slot`
+ * (FV_SLOT_AUX_IN0/1, given to fv_plan_run_aux: the cached zero-input response, [C,T'] or [B,C,T']) after its
+ * post op / activation.  With y2_slot != FV_SLOT_NONE the op keeps y raw and writes y2 = y - aux (y2 may be
+ * FV_SLOT_OUT2 or a temporary); otherwise y itself becomes y - aux.
+ */
+int fv_plan_set_output_offset(fv_plan_t* plan, int aux_slot, int y2_slot);
+
 /* Concurrency lanes (0..3): ops appended after this call belong to `lane`.  Lane 0
  * runs on the caller's stream, other lanes on plan-owned streams; cross-lane
  * ordering is derived from the slots each op reads and writes (events), with a
@@ -324,11 +339,18 @@ int fv_plan_set_group(fv_plan_t* plan, int group);
 /* shape inference for a (B, T) call: channels / length of the output tensor
  * and the workspace the plan needs (bytes) */
 int fv_plan_output_shape(fv_plan_t* plan, int T, int* out_channels, int64_t* out_len);
+int fv_plan_slot_shape(fv_plan_t* plan, int T, int slot, int* channels, int64_t* len);
 int64_t fv_plan_workspace_bytes(fv_plan_t* plan, int B, int T);
 
 /* enqueue the whole op list: in [B,Cin0,T] -> out [B,Cout,Tout] */
 int fv_plan_run(fv_plan_t* plan, int B, int T, const float* in, float* out,
                 void* workspace, int64_t workspace_bytes, void* stream);
+
+/* fv_plan_run with the auxiliary tensors: out2 (FV_SLOT_OUT2; NULL if the plan writes none), aux_in[2]
+ * (FV_SLOT_AUX_IN0/1; entries NULL when unused) and aux_batched[2] (non-zero: that input has a batch dimension) */
+int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, float* out2,
+                    const float* const* aux_in, const int* aux_batched, void* workspace,
+                    int64_t workspace_bytes, void* stream);
 
 /* number of kernel launches one fv_plan_run enqueues */
 int fv_plan_num_ops(fv_plan_t* plan);

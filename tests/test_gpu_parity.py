@@ -743,3 +743,40 @@ def test_edge_inputs_match_the_reference_behaviour():
     for x, y in zip(mels, outs):
         again = m(torch.from_numpy(x.T[None].copy()).to(_dev()))[0]
         assert torch.equal(again, y)
+
+
+@pytest.mark.parametrize("tag,name,path", cases.SHIPPED, ids=[c[0] for c in cases.SHIPPED])
+def test_inference_minus_is_one_pass_of_the_two_pass_flow(tag, name, path):
+    """Bias removal in the epilogue: inference_minus(mel, bias) returns the plain inference
+    output and output - bias, both bit-identical to the two-pass form (inference, then a subtraction) -- for
+    every generator: conv_post / LastLayer epilogue, PQMF synthesis, Basis overlap-add."""
+    cfg = cases.load_conf(path)
+    m, _ = _model(name, cfg, seed=0)
+    mel = seeded_mel(48, seed=5)
+    with torch.no_grad():
+        bias = m.inference(np.zeros_like(mel)).clone()
+        est = m.inference(mel).clone()
+        e2, rem = m.inference_minus(mel, bias)
+    assert torch.equal(e2, est)
+    assert torch.equal(rem, est - bias)
+    assert float((est - bias).abs().max()) > 1e-3          # not vacuous
+
+
+def test_basis_forward_caches_the_zero_pass():
+    cfg = cases.load_conf("conf/basis-melgan/light.yaml")
+    m, _ = _model("basis-melgan", cfg, seed=0)
+    x = torch.from_numpy(seeded_mel(16, seed=3, batch=2)).to(_dev())
+    with torch.no_grad():
+        a = m(x)
+        zw = m._zero_response(16)[0]
+        b = m(x)
+        assert m._zero_response(16)[0].data_ptr() == zw.data_ptr()      # served from the cache
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        # the two-pass form of the reference (basis_melgan.py:147-159), for the same weights
+        w = m._weights(x)
+        z = m._weights(torch.zeros_like(x))
+        assert torch.equal(a[1], (w - z).transpose(1, 2))
+        m.melgan[1].weight.data.mul_(1.0)                                # same values, but "modified": rebuilds
+        m.invalidate_plans()
+        c = m(x)
+        assert torch.equal(a[0], c[0])
