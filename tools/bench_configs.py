@@ -27,9 +27,12 @@ CONFIGS = [
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--only", type=int, default=None, help="index into CONFIGS (0-based): run just that one")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    for label, name, path, B, T in CONFIGS:
+    for idx, (label, name, path, B, T) in enumerate(CONFIGS):
+        if args.only is not None and idx != args.only:
+            continue
         cfg = yaml.safe_load(open(path))
         m = build_generator(name, cfg)
         m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(name, cfg).items()})

@@ -35,7 +35,8 @@ def main():
         fb = 2.0 * fetch[k] / nf[k] * 1024
         wb = write[k] / nw[k] * 1024
         out["kernels"][k] = {"launches": nf[k], "fetch_bytes_corrected": fb, "write_bytes": wb, "hbm_bytes": fb + wb}
-        if "conv_mfma_kernel" in k or "conv_group3_kernel" in k or "conv_sum3_kernel" in k:
+        if any(t in k for t in ("conv_mfma_kernel", "conv_group3_kernel", "conv_sum3_kernel", "pair_kernel",
+                                "pair_sum_kernel")):
             fam_bytes += (fb + wb) * nf[k]
             fam_n += nf[k]
     out["conv_mfma_family"] = {"launches": fam_n, "hbm_bytes_per_launch": fam_bytes / max(fam_n, 1)}

@@ -6,7 +6,7 @@ import subprocess
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src, dst = f"gpurun_out/{tag}", "profiles"
 os.makedirs(dst, exist_ok=True)
 shutil.copy(f"{src}/stats/bench_kernel_stats.csv", f"{dst}/{tag}_bench_kernel_stats.csv")
@@ -32,14 +32,38 @@ with open(f"{dst}/{tag}_mfma_counters.txt", "w") as f:
         f.write(k + "\n")
         for name in sorted(d):
             f.write(f"    {name:28s} {d[name] / c[name]:16.0f}   (n={c[name]})\n")
-        if ("conv_mfma_kernel" in k or "conv_group3_kernel" in k or "conv_sum3_kernel" in k) and d.get("GRBM_GUI_ACTIVE"):
+        if any(t in k for t in ("conv_mfma_kernel", "conv_group3_kernel", "conv_sum3_kernel", "pair_kernel",
+                                "pair_sum_kernel")) and d.get("GRBM_GUI_ACTIVE"):
             f.write(f"    MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs) = "
                     f"{d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f};  "
                     f"VALU instructions per MFMA = {d['SQ_INSTS_VALU'] / max(d['SQ_INSTS_MFMA'], 1):.2f}\n")
             for name in d:
                 fam[name] += d[name]
-    f.write("conv family (conv_mfma_kernel + conv_group3_kernel + conv_sum3_kernel), all launches:\n")
+    f.write("conv family (conv_mfma_kernel + conv_group3_kernel + conv_sum3_kernel + pair_kernel + pair_sum_kernel), all launches:\n")
     f.write(f"    MFMA-busy fraction of SIMD cycles = {fam['SQ_VALU_MFMA_BUSY_CYCLES'] / (fam['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f}\n")
     f.write(f"    VALU instructions per MFMA (incl. the MFMA itself) = {fam['SQ_INSTS_VALU'] / fam['SQ_INSTS_MFMA']:.2f}\n")
     f.write(f"    SQ_LDS_BANK_CONFLICT total = {fam['SQ_LDS_BANK_CONFLICT']:.0f}\n")
 print(open(f"{dst}/{tag}_mfma_counters.txt").read()[-700:])
+
+# ---- the other BASELINE configs: kernel-time shares from rocprofv3 --stats ----
+names = {0: "config 1: MelGAN original, T=200, B=1", 2: "config 3: MB-HiFi-GAN light + PQMF, T=1000, B=32",
+         3: "config 4: Basis-MelGAN light, T=1000, B=64", 4: "config 5 (one GPU's share): HiFi-GAN large, T=1000, B=64"}
+with open(f"{dst}/{tag}_configs.md", "w") as f:
+    f.write(f"# {tag}: the other BASELINE configs on one MI355X (tools/collect_profiles.sh)\n\n")
+    if os.path.exists(f"{src}/configs.log"):
+        f.write("Throughput (tools/bench_configs.py, un-profiled):\n\n```\n" + open(f"{src}/configs.log").read() + "```\n\n")
+    for i, title in names.items():
+        path = f"{src}/cfg{i}/cfg_kernel_stats.csv"
+        if not os.path.exists(path):
+            continue
+        shutil.copy(path, f"{dst}/{tag}_cfg{i}_kernel_stats.csv")
+        rows = [r for r in csv.DictReader(open(path)) if "fv::" in r["Name"] and "pack" not in r["Name"]
+                and "fold" not in r["Name"]]
+        total = sum(float(r["TotalDurationNs"]) for r in rows)
+        f.write(f"## {title}\n\nrocprofv3 --kernel-trace --stats, fv:: kernels of the forward passes "
+                f"(profiles/{tag}_cfg{i}_kernel_stats.csv):\n\n| kernel | calls | avg us | share |\n|---|---|---|---|\n")
+        for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:8]:
+            f.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | "
+                    f"{100 * float(r['TotalDurationNs']) / total:.1f} % |\n")
+        f.write("\n")
+print(open(f"{dst}/{tag}_configs.md").read()[:1500])
