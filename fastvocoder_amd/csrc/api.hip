@@ -200,6 +200,26 @@ __global__ void pack_pair_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
+// Conv1d weight [C, C, k] -> the split-f16 A operands of pairh_kernels.hpp:
+// Wh[(K step s * MH + row half h) * 2 + split half][lane][8 halves]; lane = (row m = lane & 15, K block g = lane >> 4),
+// C = 16: tap = 2s + (g >> 1), channels 8 (g & 1) .. + 7 (an odd tap count is padded with a zero tap);
+// C = 32: tap = s, channels 8g .. 8g + 7.  Split: h1 = f16(w), h2 = f16((w - h1) * 2048), round to nearest.
+__global__ void pack_pairh_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int C, int k) {
+    const int MH = C / 16, tps = 32 / C, KS = (k + tps - 1) / tps;
+    const int64_t total = (int64_t)KS * MH * 2 * 64 * 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63), half = (int)((i >> 9) & 1);
+        const int sh = (int)(i >> 10), h = sh % MH, s = sh / MH;
+        const int g = lane >> 4, co = 16 * h + (lane & 15);
+        const int tap = tps == 2 ? 2 * s + (g >> 1) : s;
+        const int ci = tps == 2 ? 8 * (g & 1) + j : 8 * g + j;
+        const float v = tap < k ? w[((size_t)co * C + ci) * k + tap] : 0.f;
+        const _Float16 h1 = (_Float16)v;
+        wp[i] = half == 0 ? h1 : (_Float16)((v - (float)h1) * 2048.f);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------
@@ -238,6 +258,7 @@ struct Op {
     const float* pb1[3] = {nullptr, nullptr, nullptr};
     const float* pb2[3] = {nullptr, nullptr, nullptr};
     int pk[3] = {0, 0, 0};
+    int prec = 0;             // FV_PAIR_F32 / FV_PAIR_SPLIT_F16
     int sub = FV_SLOT_NONE;   // fv_plan_set_output_offset: auxiliary input subtracted in this op's epilogue
 };
 
@@ -923,6 +944,25 @@ int fv_pack_pair_weight(const float* w, float* packed, int C, int k, void* strea
     return 0;
 }
 
+int64_t fv_packed_pair_floats_ex(int C, int k, int prec) {
+    if (prec != FV_PAIR_SPLIT_F16) return fv_packed_pair_floats(C, k);
+    if (C != 16 && C != 32) return 0;
+    const int tps = 32 / C;
+    return (int64_t)((k + tps - 1) / tps) * (C / 16) * 512;   // K steps x row halves x 2 split halves x 64 lanes x 16 bytes
+}
+
+int fv_pack_pair_weight_ex(const float* w, float* packed, int C, int k, int prec, void* stream) {
+    if (prec == FV_PAIR_F32) return fv_pack_pair_weight(w, packed, C, k, stream);
+    if (prec != FV_PAIR_SPLIT_F16) return fail(FV_ERR_INVALID_ARG, "pack_pair_weight: unknown arithmetic %d", prec);
+    if (!w || !packed) return fail(FV_ERR_INVALID_ARG, "pack_pair_weight: null tensor");
+    if ((C != 16 && C != 32) || k <= 0) return fail(FV_ERR_INVALID_ARG, "pack_pair_weight: C=%d (16 or 32) k=%d", C, k);
+    const int64_t total = fv_packed_pair_floats_ex(C, k, prec) * 2;
+    hipLaunchKernelGGL(pack_pairh_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       reinterpret_cast<_Float16*>(packed), C, k);
+    FV_HIP(hipGetLastError());
+    return 0;
+}
+
 static int check_pair_args(int n, int C, const int* k, int dil) {
     if (n < 1 || n > 3) return fail(FV_ERR_INVALID_ARG, "resblock pair: %d members (1..3)", n);
     if (C != 16 && C != 32) return fail(FV_ERR_UNSUPPORTED, "resblock pair: C = %d (16 or 32); use the conv1d ops", C);
@@ -935,6 +975,14 @@ static int check_pair_args(int n, int C, const int* k, int dil) {
 int fv_resblock1_fused(int n, const float* const* x, const float* const* w1, const float* const* w2,
                        const float* const* b1, const float* const* b2, float* const* y, float* const* y_act,
                        const int* k, int B, int C, int T, int dil, float slope, float act_slope, void* stream) {
+    return fv_resblock1_fused_ex(n, x, w1, w2, b1, b2, y, y_act, nullptr, nullptr, k, B, C, T, dil, slope, 1.f,
+                                 FV_POST_NONE, act_slope, FV_PAIR_F32, stream);
+}
+
+int fv_resblock1_fused_ex(int n, const float* const* x, const float* const* w1, const float* const* w2,
+                          const float* const* b1, const float* const* b2, float* const* y, float* const* y_act,
+                          const float* const* add1, const float* const* add2, const int* k, int B, int C, int T,
+                          int dil, float slope, float out_div, int post, float act_slope, int prec, void* stream) {
     if (!x || !w1 || !w2 || !y || !k) return fail(FV_ERR_INVALID_ARG, "resblock1_fused: null argument");
     if (int rc = check_pair_args(n, C, k, dil)) return rc;
     PairParams pp = {};
@@ -943,12 +991,18 @@ int fv_resblock1_fused(int n, const float* const* x, const float* const* w1, con
     pp.T = T;
     pp.slope = slope;
     pp.act_slope = act_slope;
-    pp.out_div = 1.f;
-    pp.post = FV_POST_NONE;
+    pp.out_div = out_div;
+    pp.post = post;
+    pp.prec = prec;
     for (int j = 0; j < n; ++j) {
         if (!x[j] || !y[j] || x[j] == y[j] || (y_act && y_act[j] && (y_act[j] == y[j] || y_act[j] == x[j])))
             return fail(FV_ERR_INVALID_ARG, "resblock1_fused: member %d: null tensor, or y / y_act aliases x or each other", j);
         PairMember& mb = pp.m[j];
+        mb.add1 = add1 ? add1[j] : nullptr;
+        mb.add2 = add2 ? add2[j] : nullptr;
+        if ((mb.add1 && (mb.add1 == y[j] || (y_act && mb.add1 == y_act[j]))) ||
+            (mb.add2 && (mb.add2 == y[j] || (y_act && mb.add2 == y_act[j]))))
+            return fail(FV_ERR_INVALID_ARG, "resblock1_fused: member %d: add1 / add2 alias an output", j);
         mb.x = x[j];
         mb.w1 = w1[j];
         mb.w2 = w2[j];
@@ -994,18 +1048,35 @@ int fv_mrf_stage(const float* const* x, const float* const* w1, const float* con
 int fv_plan_add_resblock_pair(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed1,
                               const float* packed2, const float* bias1, const float* bias2, int C, int k, int dil,
                               float slope, float act_slope) {
+    return fv_plan_add_resblock_pair_ex(plan, x_slot, y_slot, y_act_slot, FV_SLOT_NONE, FV_SLOT_NONE, packed1, packed2,
+                                        bias1, bias2, C, k, dil, slope, 1.f, FV_POST_NONE, act_slope, FV_PAIR_F32);
+}
+
+int fv_plan_add_resblock_pair_ex(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, int add1_slot,
+                                 int add2_slot, const float* packed1, const float* packed2, const float* bias1,
+                                 const float* bias2, int C, int k, int dil, float slope, float out_div, int post,
+                                 float act_slope, int prec) {
     if (!plan || !packed1 || !packed2) return fail(FV_ERR_INVALID_ARG, "plan_add_resblock_pair: null");
     if (int rc = check_pair_args(1, C, &k, dil)) return rc;
+    if (prec != FV_PAIR_F32 && prec != FV_PAIR_SPLIT_F16)
+        return fail(FV_ERR_INVALID_ARG, "plan_add_resblock_pair: unknown arithmetic %d", prec);
+    if (prec == FV_PAIR_F32 && (add1_slot != FV_SLOT_NONE || add2_slot != FV_SLOT_NONE || out_div != 1.f || post != FV_POST_NONE))
+        return fail(FV_ERR_UNSUPPORTED, "plan_add_resblock_pair: add1 / add2 / out_div / post exist with FV_PAIR_SPLIT_F16 only");
+    if (add2_slot != FV_SLOT_NONE && add1_slot == FV_SLOT_NONE) return fail(FV_ERR_INVALID_ARG, "plan_add_resblock_pair: add2 without add1");
     if (int rc = check_slot(x_slot, false)) return rc;
     if (int rc = check_slot(y_slot, false)) return rc;
     if (int rc = check_slot(y_act_slot, true)) return rc;
+    if (int rc = check_slot(add1_slot, true)) return rc;
+    if (int rc = check_slot(add2_slot, true)) return rc;
     if (y_slot == FV_SLOT_IN || y_act_slot == FV_SLOT_IN) return fail(FV_ERR_INVALID_ARG, "plan: the input slot is read-only");
     Op o = {};
     o.type = OP_PAIR;
     o.x = x_slot;
     o.y = y_slot;
     o.y2 = y_act_slot;
-    o.res = o.acc = o.acc2 = FV_SLOT_NONE;
+    o.res = FV_SLOT_NONE;
+    o.acc = add1_slot;      // the MRF addends travel in the running-sum fields (dependencies, shape checks)
+    o.acc2 = add2_slot;
     o.group = plan->cur_group;
     o.lane = plan->cur_lane;
     o.Cin = o.Cout = C;
@@ -1013,8 +1084,9 @@ int fv_plan_add_resblock_pair(fv_plan_t* plan, int x_slot, int y_slot, int y_act
     o.dil = dil;
     o.pre_slope = slope;
     o.act_slope = act_slope;
-    o.out_div = 1.f;
-    o.post = FV_POST_NONE;
+    o.out_div = out_div;
+    o.post = post;
+    o.prec = prec;
     o.pw1[0] = packed1;
     o.pw2[0] = packed2;
     o.pb1[0] = bias1;
@@ -1183,7 +1255,8 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             if (o.type == OP_PAIR && o.group != 0)
                 while (m < plan->ops.size() && m - n < 3 && plan->ops[m].type == OP_PAIR && plan->ops[m].group == o.group &&
                        plan->ops[m].lane == o.lane && plan->ops[m].Cin == o.Cin && plan->ops[m].dil == o.dil &&
-                       plan->ops[m].pre_slope == o.pre_slope && plan->ops[m].act_slope == o.act_slope)
+                       plan->ops[m].pre_slope == o.pre_slope && plan->ops[m].act_slope == o.act_slope &&
+                       plan->ops[m].prec == o.prec && plan->ops[m].out_div == o.out_div && plan->ops[m].post == o.post)
                     ++m;
             hipStream_t s = lanes[o.lane];
             if (multi)
@@ -1197,6 +1270,7 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             pp.act_slope = o.act_slope;
             pp.out_div = o.out_div;
             pp.post = o.post;
+            pp.prec = o.prec;
             if (o.type == OP_MRFSUM) {
                 const int xs3[3] = {o.x, o.xb, o.xc};
                 pp.sum = 1;
@@ -1225,6 +1299,8 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
                     mb.k = qo.pk[0];
                     mb.y = base[qo.y];
                     mb.y_act = qo.y2 == FV_SLOT_NONE ? nullptr : base[qo.y2];
+                    mb.add1 = qo.acc == FV_SLOT_NONE ? nullptr : base[qo.acc];
+                    mb.add2 = qo.acc2 == FV_SLOT_NONE ? nullptr : base[qo.acc2];
                 }
             }
             if (int rc = launch_pairs(pp, o.Cin, o.dil, s)) return rc;

@@ -136,6 +136,8 @@ struct PairMember {
     const float* b2;
     float* y;            // [B, C, T] raw output (sum mode: member 0's is THE output)
     float* y_act;        // optional activated twin lrelu(y, act_slope), or null
+    const float* add1;   // split-f16 kernels, last launch of an MRF stage: y = post(((x' + add1) + add2) / out_div)
+    const float* add2;   //   (the other two ResBlocks' outputs, hifigan.py:99-103), or null
     int k;               // taps: 11, 7 or 3
     int cost;            // relative cost of one tile of this member (partition weights): taps + per-tile overhead
     int n_tiles;         // tiles per utterance
@@ -153,7 +155,9 @@ struct PairParams {
     float act_slope;     // y_act = lrelu(y, act_slope); without y_act and != 1: y itself is stored activated
     int post;            // FV_POST_* applied to y (sum mode / single)
     int nblk;            // persistent blocks in the grid
+    int prec;            // FV_PAIR_F32: fp32 MFMA (pair_kernels.hpp); FV_PAIR_SPLIT_F16: pairh_kernels.hpp
     int x_off, mid_off;  // float offsets of the x image / intermediate in dynamic LDS
+    int img_off;         // split-f16 kernels: float offset of the x image (x_off: the member's packed weights)
     int bias_off;        // ... of the staged biases: per member [b1[C] | b2[C]]
     unsigned long long* trace;   // tuning aid (FV_PAIR_TRACE_PTR): s_memtime stamps [block < 8][wave][tile < 8][16 events]
     int dbg;             // ablation switches (FV_PAIR_DBG, timing experiments only -- results are wrong):
@@ -170,10 +174,21 @@ struct PairShape {
     int NOUT;            // output columns per tile
 };
 PairShape pair_shape(int C, int k, int dil);
+// ... of the split-f16 pair kernels, the run-time mirror of PairHGeom<> (pairh_kernels.hpp)
+struct PairHShape {
+    int MH, NF, NG, NM;
+    int KS;              // K steps per conv (32 K values each)
+    int XROWS, WB;       // x image rows; bytes of one conv's packed weights
+    int RB, MROWS;       // bytes per image row; rows of the intermediate image
+    int NOUT;
+};
+PairHShape pairh_shape(int C, int k, int dil);
 // n (1..3) members, plain (sum = 0: one raw output each) or sum mode (one output: mean of the members)
 int launch_pairs(PairParams p, int C, int dil, hipStream_t stream);
 template <int MH, int NF, int NG>
 int launch_pair_geom(const PairParams& p, int dil, size_t lds, hipStream_t s);
+template <int MH, int NF, int NG>
+int launch_pairh_geom(const PairParams& p, int dil, size_t lds, hipStream_t s);
 
 // Shared between the host launcher (conv_mfma.hip) and the kernels (conv_kernels.hpp):
 #ifndef FV_RING

@@ -9,6 +9,8 @@ namespace fv {
 
 extern template int launch_pair_geom<1, 2, 8>(const PairParams&, int, size_t, hipStream_t);
 extern template int launch_pair_geom<2, 1, 8>(const PairParams&, int, size_t, hipStream_t);
+extern template int launch_pairh_geom<1, 4, 4>(const PairParams&, int, size_t, hipStream_t);
+extern template int launch_pairh_geom<2, 1, 8>(const PairParams&, int, size_t, hipStream_t);
 
 namespace {
 
@@ -55,6 +57,77 @@ PairShape pair_shape(int C, int k, int dil) {
     return g;
 }
 
+// ---- split-f16 pairs (pairh_kernels.hpp): run-time mirror of PairHGeom<> ----------------------------------
+PairHShape pairh_shape(int C, int k, int dil) {
+    PairHShape g = {};
+    // C = 16: 4 waves x four fragments (256-column tiles, two blocks per CU);
+    // C = 32: 8 waves x one fragment, both row halves in the wave (128-column tiles, one block per CU)
+    g.MH = C / 16;
+    g.NF = C == 16 ? 4 : 1;
+    g.NG = C == 16 ? 4 : 8;
+    g.NM = 16 * g.NF * g.NG;
+    const int tps = 32 / C;
+    g.KS = (k + tps - 1) / tps;
+    const int ktp = g.KS * tps;
+    const int p1 = (k - 1) * dil / 2, p2 = (k - 1) / 2;
+    const int aoff = (4 - (p1 + p2) % 4) % 4;
+    const int xwin = g.NM + (ktp - 1) * dil + aoff;
+    g.XROWS = (xwin + 3) / 4 * 4;
+    g.WB = g.KS * g.MH * 2 * 1024;
+    g.RB = 4 * C + 16;
+    g.MROWS = g.NM + 16;
+    g.NOUT = (g.NM - (k - 1)) / 4 * 4;
+    return g;
+}
+
+static int launch_pairs_split(PairParams p, int C, int dil, hipStream_t s) {
+    if (p.sum) return fail(FV_ERR_UNSUPPORTED, "mrf sum: fp32 kernels only (split-f16 stages end in a pair with add1 / add2)");
+    int w_bytes = 0, img_bytes = 0, mid_bytes = 0;
+    double flops = 0, bytes = 0;
+    long long items = 0;
+    for (int i = 0; i < p.n_members; ++i) {
+        PairMember& mb = p.m[i];
+        if (mb.k != 11 && mb.k != 7 && mb.k != 3) return fail(FV_ERR_UNSUPPORTED, "resblock pair: %d taps (3, 7 or 11)", mb.k);
+        if (!mb.x || !mb.w1 || !mb.w2 || !mb.y) return fail(FV_ERR_INVALID_ARG, "resblock pair: null tensor (member %d)", i);
+        if (mb.add2 && !mb.add1) return fail(FV_ERR_INVALID_ARG, "resblock pair: add2 without add1 (member %d)", i);
+        if ((reinterpret_cast<uintptr_t>(mb.x) | reinterpret_cast<uintptr_t>(mb.w1) | reinterpret_cast<uintptr_t>(mb.w2)) & 15)
+            return fail(FV_ERR_UNSUPPORTED, "resblock pair: x / packed weights must be 16-byte aligned");
+        const PairHShape g = pairh_shape(C, mb.k, dil);
+        mb.n_tiles = (p.T + g.NOUT - 1) / g.NOUT;
+        // LDS-bandwidth bound: a tile costs its K steps (two convs) plus the convert pass / epilogues / barriers
+        mb.cost = g.KS + (getenv("FV_PAIRH_SKEL") ? atoi(getenv("FV_PAIRH_SKEL")) : 3);
+        mb.w_off = 0;
+        if (2 * g.WB > w_bytes) w_bytes = 2 * g.WB;
+        if (g.XROWS * g.RB > img_bytes) img_bytes = g.XROWS * g.RB;
+        if (g.MROWS * g.RB > mid_bytes) mid_bytes = g.MROWS * g.RB;
+        items += (long long)mb.n_tiles * p.B;
+        flops += 2.0 * 2.0 * p.B * (double)C * C * mb.k * p.T;
+        bytes += 4.0 * (2.0 * C * C * mb.k + (double)p.B * C * p.T * ((mb.y_act ? 3 : 2) + (mb.add1 ? 1 : 0) + (mb.add2 ? 1 : 0)));
+    }
+    size_t floats = 0;
+    p.x_off = 0;                       // [conv1 | conv2] packed weights of the member a block is working on
+    floats += (size_t)w_bytes / 4;
+    p.img_off = (int)floats;
+    floats += (size_t)img_bytes / 4;
+    p.mid_off = (int)floats;
+    floats += (size_t)mid_bytes / 4;
+    p.bias_off = (int)floats;
+    floats += 2 * (size_t)C;
+    const size_t lds = floats * 4;
+    if (lds > (C == 16 ? 80 : 160) * 1024) return fail(FV_ERR_UNSUPPORTED, "resblock pair, split-f16: %zu bytes of LDS", lds);
+    const char* force = getenv("FV_PAIR_BLOCKS");
+    // 8 waves per CU (2 per SIMD): two 4-wave blocks at C = 16, one 8-wave block at C = 32
+    long long nblk = force && atoi(force) > 0 ? atoi(force) : (C == 16 ? 2LL : 1LL) * num_cus();
+    if (nblk > items) nblk = items;
+    p.nblk = (int)nblk;
+    p.dbg = getenv("FV_PAIR_DBG") ? atoi(getenv("FV_PAIR_DBG")) : 0;
+    p.trace = nullptr;
+    profile_begin(s);
+    const int rc = C == 16 ? launch_pairh_geom<1, 4, 4>(p, dil, lds, s) : launch_pairh_geom<2, 1, 8>(p, dil, lds, s);
+    profile_end(s, C == 16 ? FV_KERNEL_PAIRH16 : FV_KERNEL_PAIRH32, flops, bytes);
+    return rc;
+}
+
 int launch_pairs(PairParams p, int C, int dil, hipStream_t s) {
     if (p.B <= 0 || p.T <= 0) return 0;
     if (C != 16 && C != 32) return fail(FV_ERR_UNSUPPORTED, "resblock pair: C = %d (16 or 32)", C);
@@ -68,6 +141,11 @@ int launch_pairs(PairParams p, int C, int dil, hipStream_t s) {
                     "buffer-descriptor range; split the utterance", C, p.T);
     if (p.slope < 0.f || p.slope > 1.f || p.act_slope < 0.f || p.act_slope > 1.f)
         return fail(FV_ERR_INVALID_ARG, "resblock pair: activation slope outside [0, 1]");
+    if (p.prec == FV_PAIR_SPLIT_F16) return launch_pairs_split(p, C, dil, s);
+    if (p.prec != FV_PAIR_F32) return fail(FV_ERR_INVALID_ARG, "resblock pair: unknown arithmetic %d", p.prec);
+    for (int i = 0; i < p.n_members; ++i)
+        if (p.m[i].add1 || p.m[i].add2)
+            return fail(FV_ERR_UNSUPPORTED, "resblock pair: add1 / add2 exist with FV_PAIR_SPLIT_F16 only (fp32: fv_mrf_stage)");
     if (p.sum) {
         if (p.n_members != 3) return fail(FV_ERR_UNSUPPORTED, "mrf sum: needs the three members");
         for (int i = 0; i < 3; ++i)          // sort by taps, largest first: the kernel's member order

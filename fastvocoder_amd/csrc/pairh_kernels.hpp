@@ -1,0 +1,403 @@
+// Fused ResBlock1 pair with SPLIT-F16 operands on the gfx950 matrix cores:
+//
+//     x' = x + conv2( lrelu( conv1( lrelu(x) ) + b1 ) ) + b2          (reference model/generator/modules.py:223-230)
+//
+// Same operator, tiling and persistent-block structure as pair_kernels.hpp; what changes is the arithmetic of
+// the two convolutions.  Every fp32 operand v (activation or weight) is written as
+//         v  =  h1 + h2 / 2048 + e,     h1 = f16(v),  h2 = f16((v - h1) * 2048),  |e| <= 2^-22 |v|
+// (v - h1 is exact in fp32; the 2^11 scale keeps h2 a normal f16 number whenever h1 is one), and a product
+// becomes three v_mfma_f32_16x16x32_f16 terms accumulated in fp32:
+//         a * b  ~  a1 b1  +  (a1 b2 + a2 b1) / 2048                    (dropped: a2 b2 / 2^22 and the e terms)
+// f16 x f16 products are exact in the fp32 accumulator, so the only new error is the dropped 2^-22 terms: per
+// layer the result is as close to the exact sum as the fp32 FMA chain is (tests/test_split_precision.py,
+// DESIGN.md section 3.7).  Three f16 MFMAs cover 32 K values in 3 x 16 cycles where the fp32 MFMA needs
+// 8 x 32: at 16-32 channels the fp32 pair kernel is matrix-core bound, this one is bound by LDS bandwidth
+// and by the HBM traffic of x and x' -- which is where SURVEY section 8(d) puts these layers.
+//
+// Layout: the activated, split input lives in LDS CHANNELS-LAST: one row per time sample,
+// [C halves of h1 | C halves of h2 | 16 bytes of padding]; the B operand of a K step (lane = column n,
+// K block = 8 consecutive channels of one tap) is then ONE ds_read_b128 per half, and the 80 / 144-byte row
+// stride puts 16 consecutive rows on disjoint banks.  The D fragment (lane = column, 4 consecutive channels)
+// is exactly what a row of the intermediate wants: conv1's epilogue splits and stores with ds_write_b64.
+// K order: step s covers 32 / C taps (C = 16: taps 2s, 2s+1 x 16 channels; an odd tap count is padded with a
+// zero tap), channels inside a tap.  The packed weights of a member's two convs sit in LDS; a wave loads the A
+// operands of a phase with KS x 2 ds_read_b128 (4-wave blocks, two per CU, 2 waves per SIMD => 256 VGPRs each).
+//
+// Per tile: the NEXT tile's raw fp32 x window is loaded global -> registers at the top of the tile (in flight for
+// the whole tile, no LDS landing buffer); conv1 -> + b1, lrelu, zero outside [0, T), split -> intermediate image;
+// barrier; conv2 -> + b2 + residual (fp32, from global memory); convert pass for the next tile (lrelu, split,
+// transpose registers -> x image); stores -> HBM; barrier.  Two barriers per tile.
+// Limits: |activation| and |weight| < 65504 (f16 range); beyond that use the fp32 kernels (FV_PAIR_PREC=f32).
+#pragma once
+#include "pair_kernels.hpp"
+
+namespace fv {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kSplitScale = 2048.f, kSplitInv = 1.f / 2048.f;
+
+template <int MH_, int NF_, int NG_, int KT_, int DIL_>
+struct PairHGeom {
+    static constexpr int MH = MH_, NF = NF_, NG = NG_, KT = KT_, DIL = DIL_;
+    static constexpr int C = 16 * MH;
+    static constexpr int NW = NG, NT = 64 * NW;
+    static constexpr int NM = 16 * NF * NG;             // intermediate columns per tile
+    static constexpr int TPS = 32 / C;                  // taps per K step
+    static constexpr int KS = (KT + TPS - 1) / TPS;     // K steps per conv
+    static constexpr int KTP = KS * TPS;                // taps incl. the zero tap that pads an odd count
+    static constexpr int P1 = (KT - 1) * DIL / 2, P2 = (KT - 1) / 2;
+    static constexpr int AOFF = (4 - (P1 + P2) % 4) % 4;
+    static constexpr int XWIN = NM + (KTP - 1) * DIL + AOFF;   // columns of x a tile reads (pad tap included)
+    static constexpr int NCOL4 = (XWIN + 3) / 4;
+    static constexpr int XROWS = 4 * NCOL4;             // rows of the x image
+    static constexpr int WB = KS * MH * 2 * 1024;       // bytes of one conv's packed weights
+    static constexpr bool AREG = MH == 1;               // a phase's A operands fit in registers
+    static constexpr int RB = 4 * C + 16;               // bytes per image row: h1[C] | h2[C] | pad
+    static constexpr int MROWS = NM + 16;               // rows of the intermediate image (>= NM + KTP - 1)
+    static constexpr int NOUT = (NM - (KT - 1)) / 4 * 4;
+    static_assert(C == 16 || C == 32, "16 or 32 channels");
+    static_assert(KT % 2 == 1 && KTP - 1 <= 16, "odd tap counts up to 15");
+    static_assert(((KS - 1) * TPS * DIL + 16 * (NF - 1)) * RB + 2 * C + 16 < 65536, "ds_read immediate range");
+    static_assert(AREG || KS * MH * 2 * 1024 < 65536, "ds_read immediate range (weights)");
+};
+
+// ---- raw x window: global -> registers (a whole tile ahead) -> image [XROWS][h1 | h2], activated -------------
+// task = (row t of the window, block of 8 channels); a thread owns XR tasks, lanes along t (coalesced rows)
+template <class G>
+struct PairHRaw {
+    static constexpr int CB = G::C / 8;
+    static constexpr int XR = (G::XROWS * CB + G::NT - 1) / G::NT;
+    float v[XR][8];
+};
+
+// tA: time of window row 0; rows outside [0, T) read as zero (per-lane offset: the descriptor only bounds the tensor)
+template <class G>
+__device__ __forceinline__ void pairh_load_raw(PairHRaw<G>& r, const float* xb, int T, int tA, int tid) {
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)G::C * (unsigned)T * 4u);
+    const unsigned t4 = (unsigned)T * 4u;
+#pragma unroll
+    for (int q = 0; q < PairHRaw<G>::XR; ++q) {
+        const int idx = tid + q * G::NT;
+        const int cb = idx / G::XROWS, row = idx - cb * G::XROWS;
+        const int t = tA + row;
+        const bool ok = idx < G::XROWS * PairHRaw<G>::CB && t >= 0 && t < T;
+        const unsigned voff = ok ? (unsigned)(cb * 8 * T + t) * 4u : kOutOfRange;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.v[q][j] = buffer_load1s(rx, voff, (unsigned)j * t4);
+    }
+}
+
+template <class G>
+__device__ __forceinline__ void pairh_convert(const PairHRaw<G>& r, char* ximg, float slope, int tid) {
+#pragma unroll
+    for (int q = 0; q < PairHRaw<G>::XR; ++q) {
+        const int idx = tid + q * G::NT;
+        const int cb = idx / G::XROWS, row = idx - cb * G::XROWS;
+        f16x8 h1, h2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = act(r.v[q][j], slope);
+            const _Float16 a = (_Float16)v;
+            h1[j] = a;
+            h2[j] = (_Float16)((v - (float)a) * kSplitScale);
+        }
+        if (idx < G::XROWS * PairHRaw<G>::CB) {
+            *reinterpret_cast<f16x8*>(ximg + row * G::RB + cb * 16) = h1;
+            *reinterpret_cast<f16x8*>(ximg + row * G::RB + 2 * G::C + cb * 16) = h2;
+        }
+    }
+}
+
+// the two weight images of a member: global -> LDS by LDS-DMA ([conv1 | conv2], G::WB bytes each)
+template <class G>
+__device__ __forceinline__ void pairh_stage_weights(const PairMember& mb, float* wl, int wave, int lane) {
+    constexpr int NI = G::WB / 1024;   // 64-lane x 16-byte instructions per conv
+    const __amdgpu_buffer_rsrc_t r1 = make_rsrc(mb.w1, (unsigned)G::WB);
+    const __amdgpu_buffer_rsrc_t r2 = make_rsrc(mb.w2, (unsigned)G::WB);
+    for (int j = wave; j < NI; j += G::NW) {
+        dma16(r1, wl + j * 256, (unsigned)(j * 1024 + lane * 16));
+        dma16(r2, wl + G::WB / 4 + j * 256, (unsigned)(j * 1024 + lane * 16));
+    }
+}
+
+// A operands of one conv, LDS -> registers (per phase): packed by fv_pack_pair_weight_ex as
+// [(step * MH + row half) * 2 + split half][lane][8 halves]
+template <class G>
+__device__ __forceinline__ void pairh_load_a(const float* wl, f16x8 (&A)[G::KS][G::MH][2], int lane) {
+    typedef __attribute__((address_space(3))) const f16x8 LdsH8;
+    LdsCF* base = lds_opaque(wl + 4 * lane);
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s)
+#pragma unroll
+        for (int h = 0; h < G::MH; ++h) {
+            A[s][h][0] = *reinterpret_cast<LdsH8*>(base + ((s * G::MH + h) * 2 + 0) * 256);
+            A[s][h][1] = *reinterpret_cast<LdsH8*>(base + ((s * G::MH + h) * 2 + 1) * 256);
+        }
+}
+
+// ---- one conv phase: hi += a1 b1, lo += a1 b2 + a2 b1 over the KS steps --------------------------------
+// img: the lane's image base (row = its column of fragment 0 at the lane group's first tap, byte offset of
+// its channel block); TAPB: bytes between consecutive K steps of the image.  B operands are read one step
+// ahead of the MFMAs that use them (sched_barrier pins the order; the waitcnt pass derives the counts).
+template <class G, int TAPB>
+__device__ __forceinline__ void pairh_mma(const float* wl, const char* img, f32x4 (&hi)[G::MH][G::NF],
+                                          f32x4 (&lo)[G::MH][G::NF], int lane) {
+    typedef __attribute__((address_space(3))) const f16x8 LdsH8;
+    LdsCF* base = lds_opaque(reinterpret_cast<const float*>(img));
+    f16x8 bq[2][G::NF][2];
+    auto fetch = [&](int s, f16x8 (&dst)[G::NF][2]) {
+#pragma unroll
+        for (int f = 0; f < G::NF; ++f) {
+            dst[f][0] = *reinterpret_cast<LdsH8*>(base + (s * TAPB + f * 16 * G::RB) / 4);
+            dst[f][1] = *reinterpret_cast<LdsH8*>(base + (s * TAPB + f * 16 * G::RB + 2 * G::C) / 4);
+        }
+    };
+    auto mma = [&](const f16x8 (&a)[G::MH][2], const f16x8 (&bv)[G::NF][2]) {
+#pragma unroll
+        for (int h = 0; h < G::MH; ++h)
+#pragma unroll
+            for (int f = 0; f < G::NF; ++f)
+                hi[h][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[h][0], bv[f][0], hi[h][f], 0, 0, 0);
+#pragma unroll
+        for (int h = 0; h < G::MH; ++h)
+#pragma unroll
+            for (int f = 0; f < G::NF; ++f)
+                lo[h][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[h][0], bv[f][1], lo[h][f], 0, 0, 0);
+#pragma unroll
+        for (int h = 0; h < G::MH; ++h)
+#pragma unroll
+            for (int f = 0; f < G::NF; ++f)
+                lo[h][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[h][1], bv[f][0], lo[h][f], 0, 0, 0);
+    };
+    if constexpr (G::AREG) {
+        // the phase's A operands up front (C = 16: 48 registers at 11 taps)
+        f16x8 A[G::KS][G::MH][2];
+        pairh_load_a<G>(wl, A, lane);
+        fetch(0, bq[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < G::KS; ++s) {
+            if (s + 1 < G::KS) fetch(s + 1, bq[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(A[s], bq[s & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        // C = 32: a phase's A operands are 176 registers at 11 taps -- they stream through a two-step queue like B
+        LdsCF* wb = lds_opaque(wl + 4 * lane);
+        f16x8 aq[2][G::MH][2];
+        auto fetch_a = [&](int s, f16x8 (&dst)[G::MH][2]) {
+#pragma unroll
+            for (int h = 0; h < G::MH; ++h) {
+                dst[h][0] = *reinterpret_cast<LdsH8*>(wb + ((s * G::MH + h) * 2 + 0) * 256);
+                dst[h][1] = *reinterpret_cast<LdsH8*>(wb + ((s * G::MH + h) * 2 + 1) * 256);
+            }
+        };
+        fetch_a(0, aq[0]);
+        fetch(0, bq[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < G::KS; ++s) {
+            if (s + 1 < G::KS) {
+                fetch_a(s + 1, aq[(s + 1) & 1]);
+                fetch(s + 1, bq[(s + 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma(aq[s & 1], bq[s & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// items [item0, hi) of ONE member, in order (item = utterance * n_tiles + tile).
+// Per tile: [loads of the NEXT tile's raw window and of this tile's residual are issued] conv1 -> intermediate,
+// barrier, conv2, convert the next window into the x image (free since the barrier), stores, barrier.
+template <class G>
+__device__ __forceinline__ void pairh_run_member(const PairParams& p, const PairMember& mb, int item0, int hi_item,
+                                                 float* smem, int wave, int lane_in, bool first) {
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int tid = wave * 64 + lane;
+    float* const wl = smem + p.x_off;                  // [conv1 | conv2] packed weights
+    char* const ximg = reinterpret_cast<char*>(smem + p.img_off);
+    char* const mimg = reinterpret_cast<char*>(smem + p.mid_off);
+    float* const bl = smem + p.bias_off;
+    const int n = lane & 15, g = lane >> 4;
+    const int col0 = wave * (16 * G::NF) + n;          // the lane's column in the wave's fragment 0
+    const int tapg = G::TPS == 2 ? (g >> 1) : 0;       // the lane group's tap inside a K step
+    const int cb = G::TPS == 2 ? (g & 1) : g;          // ... and its block of 8 channels
+    const char* const xb = ximg + (col0 + G::AOFF + tapg * G::DIL) * G::RB + cb * 16;
+    const char* const mbase = mimg + (col0 + tapg) * G::RB + cb * 16;
+    char* const mw = mimg + col0 * G::RB + 8 * g;      // D fragment: rows (channels) 4g .. 4g+3 of column n
+    const int row0 = 4 * g;
+
+    const size_t ustride = (size_t)G::C * (size_t)p.T;
+    constexpr int HEAD = G::P1 + G::P2 + G::AOFF;
+    int item = item0;
+    int b = item / mb.n_tiles, tile = item - b * mb.n_tiles;
+    if (!first) pair_barrier();                         // everybody is done with the previous member's LDS
+    PairHRaw<G> raw;
+    pairh_load_raw<G>(raw, mb.x + b * ustride, p.T, tile * G::NOUT - HEAD, tid);
+    pairh_stage_weights<G>(mb, wl, wave, lane);
+    pair_stage_bias<G>(mb, bl, tid);
+    // rows [NM, MROWS) of the intermediate feed only discarded columns / the zero tap: finite values once
+    for (int idx = tid; idx < (G::MROWS - G::NM) * G::RB / 4; idx += G::NT)
+        reinterpret_cast<float*>(mimg + G::NM * G::RB)[idx] = 0.f;
+    pair_wait_vm0();
+    pairh_convert<G>(raw, ximg, p.slope, tid);
+    pair_barrier();
+    for (;;) {
+        const int t0 = tile * G::NOUT;
+        const int nitem = item + 1;
+        const bool more = nitem < hi_item;
+        int nb = b, ntile = tile + 1;
+        if (ntile == mb.n_tiles) {
+            ntile = 0;
+            ++nb;
+        }
+        // the next tile's raw window: in flight for the whole tile; then this tile's residual (fp32, L2 hits)
+        if (more && !(p.dbg & 1)) pairh_load_raw<G>(raw, mb.x + nb * ustride, p.T, ntile * G::NOUT - HEAD, tid);
+        float res[G::MH][G::NF][4];
+        const unsigned ubytes = (unsigned)G::C * (unsigned)p.T * 4u;
+        const unsigned t4 = (unsigned)p.T * 4u;
+        unsigned voff[G::MH][G::NF];
+        {
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc(mb.x + b * ustride, ubytes);
+#pragma unroll
+            for (int h = 0; h < G::MH; ++h)
+#pragma unroll
+                for (int f = 0; f < G::NF; ++f) {
+                    const int col = col0 + f * 16, t = t0 + col;
+                    const bool ok = col < G::NOUT && t < p.T && !(p.dbg & 16);
+                    voff[h][f] = ok ? (unsigned)((16 * h + row0) * p.T + t) * 4u : kOutOfRange;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) res[h][f][i] = buffer_load1s(rx, voff[h][f], (unsigned)i * t4);
+                }
+        }
+        f32x4 hi[G::MH][G::NF], lo[G::MH][G::NF];
+#pragma unroll
+        for (int h = 0; h < G::MH; ++h)
+#pragma unroll
+            for (int f = 0; f < G::NF; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(p.dbg & 4)) pairh_mma<G, G::TPS * G::DIL * G::RB>(wl, xb, hi, lo, lane);
+        {
+            // intermediate column u of the tile is time t0 - P2 + u; conv2's zero padding applies to the
+            // intermediate: columns outside [0, T) are zero, not conv1 of the padded input
+            const int tm = t0 - G::P2;
+#pragma unroll
+            for (int h = 0; h < G::MH; ++h) {
+                float bv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[i] = bl[16 * h + row0 + i];
+#pragma unroll
+                for (int f = 0; f < G::NF; ++f) {
+                    const int t = tm + col0 + f * 16;
+                    const bool ok = t >= 0 && t < p.T;
+                    f16x4 h1, h2;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = act(fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[i], p.slope);
+                        v = ok ? v : 0.f;
+                        const _Float16 a = (_Float16)v;
+                        h1[i] = a;
+                        h2[i] = (_Float16)((v - (float)a) * kSplitScale);
+                    }
+                    *reinterpret_cast<f16x4*>(mw + f * 16 * G::RB + 32 * h) = h1;
+                    *reinterpret_cast<f16x4*>(mw + f * 16 * G::RB + 32 * h + 2 * G::C) = h2;
+                }
+            }
+        }
+        pair_barrier();                                  // (C) intermediate complete, x image free
+#pragma unroll
+        for (int h = 0; h < G::MH; ++h)
+#pragma unroll
+            for (int f = 0; f < G::NF; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(p.dbg & 4)) pairh_mma<G, G::TPS * G::RB>(wl + G::WB / 4, mbase, hi, lo, lane);
+        // raw window and residual have been in flight for two conv phases; no store is outstanding here
+        // (the previous tile's were issued a tile ago and are drained with the same wait)
+        pair_wait_vm0();
+        if (more && !(p.dbg & 2)) pairh_convert<G>(raw, ximg, p.slope, tid);
+        const bool fin = mb.add1 != nullptr;
+#pragma unroll
+        for (int h = 0; h < G::MH; ++h) {
+            float bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bv[i] = bl[G::C + 16 * h + row0 + i];
+#pragma unroll
+            for (int f = 0; f < G::NF; ++f)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hi[h][f][i] = (fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[i]) + res[h][f][i];
+        }
+        if (fin) {
+            // last launch of an MRF stage: (r0 + r1) + r2 in the reference's order (hifigan.py:99-103)
+            const __amdgpu_buffer_rsrc_t r1 = make_rsrc(mb.add1 + b * ustride, ubytes);
+            const __amdgpu_buffer_rsrc_t r2 = make_rsrc(mb.add2 ? mb.add2 + b * ustride : mb.add1, mb.add2 ? ubytes : 0u);
+#pragma unroll
+            for (int h = 0; h < G::MH; ++h)
+#pragma unroll
+                for (int f = 0; f < G::NF; ++f)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        lo[h][f][i] = buffer_load1s(r1, voff[h][f], (unsigned)i * t4);
+                        res[h][f][i] = buffer_load1s(r2, voff[h][f], (unsigned)i * t4);
+                    }
+            pair_wait_vm0();
+#pragma unroll
+            for (int h = 0; h < G::MH; ++h)
+#pragma unroll
+                for (int f = 0; f < G::NF; ++f)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hi[h][f][i] = (hi[h][f][i] + lo[h][f][i]) + res[h][f][i];
+        }
+#pragma unroll
+        for (int h = 0; h < G::MH; ++h)
+#pragma unroll
+            for (int f = 0; f < G::NF; ++f) {
+                const int col = col0 + f * 16;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = hi[h][f][i];
+                pair_store(p, mb.y, mb.y_act, G::C, b, 16 * h + row0, t0 + col,
+                           col < G::NOUT && t0 + col < p.T && !(p.dbg & 8), v, fin);
+            }
+        if (!more) break;
+        pair_barrier();                                  // (A) the next x image is complete; the intermediate is free
+        item = nitem;
+        b = nb;
+        tile = ntile;
+    }
+}
+
+template <int MH, int NF, int NG, int DIL>
+__device__ __forceinline__ void pairh_run_any(const PairParams& p, int m, int item0, int hi, float* smem, int wave,
+                                              int lane, bool first) {
+    const PairMember& mb = p.m[m];
+    if (mb.k == 11) pairh_run_member<PairHGeom<MH, NF, NG, 11, DIL>>(p, mb, item0, hi, smem, wave, lane, first);
+    else if (mb.k == 7) pairh_run_member<PairHGeom<MH, NF, NG, 7, DIL>>(p, mb, item0, hi, smem, wave, lane, first);
+    else pairh_run_member<PairHGeom<MH, NF, NG, 3, DIL>>(p, mb, item0, hi, smem, wave, lane, first);
+}
+
+// 2 waves per SIMD: 256 VGPRs (both convs' weights stay in registers)
+template <int MH, int NF, int NG, int DIL>
+__global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu(2, 2))) void pairh_kernel(PairParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    long long total = 0;
+    for (int m = 0; m < p.n_members; ++m) total += (long long)p.m[m].n_tiles * p.B * p.m[m].cost;
+    long long base = 0;
+    bool first = true;
+    for (int m = 0; m < p.n_members; ++m) {
+        const int n = p.m[m].n_tiles * p.B;
+        const int lo = pair_share(blockIdx.x, total, base, p.m[m].cost, n, p.nblk);
+        const int hi = pair_share(blockIdx.x + 1, total, base, p.m[m].cost, n, p.nblk);
+        base += (long long)n * p.m[m].cost;
+        if (lo >= hi) continue;
+        pairh_run_any<MH, NF, NG, DIL>(p, m, lo, hi, smem, wave, lane, first);
+        first = false;
+    }
+}
+
+}  // namespace fv

@@ -9,6 +9,7 @@ into a :class:`PlanBuilder`, which folds weight norm and packs every weight on
 the GPU once, and the resulting native plan is replayed for every call until a
 parameter changes.
 """
+import os
 import warnings
 
 import torch
@@ -137,27 +138,48 @@ class PlanBuilder:
                              out_div=float(out_div), post=post))
 
     @staticmethod
-    def pair_fusable(conv1, conv2):
+    def pair_precision(channels):
+        """Arithmetic of the fused pair kernels for a stage of ``channels`` channels: split-f16 operands
+        (csrc/pairh_kernels.hpp; fp32-class accuracy) where that kernel exists, the fp32
+        MFMA kernels otherwise.  FV_PAIR_PREC=f32 forces the fp32 kernels (activations beyond the f16 range)."""
+        if os.environ.get("FV_PAIR_PREC", "split") == "f32":
+            return _native.PAIR_F32
+        return _native.PAIR_SPLIT_F16 if _native.pair_supported(channels, 3, 1, _native.PAIR_SPLIT_F16) \
+            else _native.PAIR_F32
+
+    @staticmethod
+    def pair_mode_tag():
+        """Part of a plan's cache key: the arithmetic policy in force (FV_PAIR_PREC)."""
+        return "s" if os.environ.get("FV_PAIR_PREC", "split") == "f32" else "h"
+
+    @staticmethod
+    def pair_fusable(conv1, conv2, prec=None):
         """Can this (dilated conv, conv) pair of a ResBlock1 run on the fused pair kernels?"""
         k, c = conv1.kernel_size[0], conv1.in_channels
+        prec = _native.PAIR_F32 if prec is None else prec
         return (all(cv.stride[0] == 1 and cv.groups == 1 and cv.in_channels == c and cv.out_channels == c
                     and cv.kernel_size[0] == k and cv.padding[0] == cv.dilation[0] * (k - 1) // 2
                     for cv in (conv1, conv2))
-                and conv2.dilation[0] == 1 and _native.pair_supported(c, k, conv1.dilation[0]))
+                and conv2.dilation[0] == 1 and _native.pair_supported(c, k, conv1.dilation[0], prec))
 
-    def _pair_member(self, conv1, conv2):
-        if not self.pair_fusable(conv1, conv2):
+    def _pair_member(self, conv1, conv2, prec=_native.PAIR_F32):
+        if not self.pair_fusable(conv1, conv2, prec):
             raise _native.NativeError("resblock pair: shape not built into the fused kernels")
-        return dict(w1=_native.pack_pair(effective_weight(conv1)), w2=_native.pack_pair(effective_weight(conv2)),
+        return dict(w1=_native.pack_pair(effective_weight(conv1), prec),
+                    w2=_native.pack_pair(effective_weight(conv2), prec),
                     b1=self._bias(conv1), b2=self._bias(conv2), k=conv1.kernel_size[0])
 
-    def pair(self, conv1, conv2, src, dst, slope):
-        """dst = src + conv2(lrelu(conv1(lrelu(src)))) as ONE fused op (fv_plan_add_resblock_pair); it reads
-        ``src`` raw and applies both activations on chip.  Ops recorded inside one group share a launch."""
-        m = self._pair_member(conv1, conv2)
+    def pair(self, conv1, conv2, src, dst, slope, prec=_native.PAIR_F32, add1=SLOT_NONE, add2=SLOT_NONE,
+             out_div=1.0, post=POST_NONE):
+        """dst = src + conv2(lrelu(conv1(lrelu(src)))) as ONE fused op (fv_plan_add_resblock_pair_ex); it reads
+        ``src`` raw and applies both activations on chip.  Ops recorded inside one group share a launch.
+        With ``add1`` / ``add2`` (split-f16 arithmetic): dst = post(((pair + add1) + add2) / out_div), the MRF
+        merge of hifigan.py:99-103 in the reference's association."""
+        m = self._pair_member(conv1, conv2, prec)
         self.ops.append(dict(kind="pair", lane=self.lane, group=self.group, x=src, y=dst, res=SLOT_NONE,
-                             acc=SLOT_NONE, pre_slope=1.0, slope=float(slope), channels=conv1.in_channels,
-                             dil=conv1.dilation[0], **m))
+                             acc=add1, acc2=add2, pre_slope=1.0, slope=float(slope),
+                             channels=conv1.in_channels, dil=conv1.dilation[0], prec=prec,
+                             out_div=float(out_div), post=post, **m))
 
     def mrf_sum(self, pairs, srcs, dst, slope, out_div, post=POST_NONE):
         """dst = post(sum_j pair_j(srcs[j]) / out_div): the last pairs of the three ResBlocks of an MRF stage
@@ -328,7 +350,9 @@ class PlanBuilder:
             elif op["kind"] == "pair":
                 self.plan.add_resblock_pair(op["x"], op["y"], op["w1"], op["w2"], op["b1"], op["b2"],
                                             op["channels"], op["k"], op["dil"], op["slope"],
-                                            y_act=op["y_act"], act_slope=op["act_slope"])
+                                            y_act=op["y_act"], act_slope=op["act_slope"], prec=op["prec"],
+                                            add1=op["acc"], add2=op["acc2"], out_div=op["out_div"],
+                                            post=op["post"])
             elif op["kind"] == "mrfsum":
                 ms = op["members"]
                 self.plan.add_mrf_sum([op["x"], op["xb"], op["xc"]], op["y"], [m["w1"] for m in ms],

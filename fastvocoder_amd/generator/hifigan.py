@@ -17,6 +17,7 @@ import os
 
 import torch
 
+from .._native import PAIR_SPLIT_F16
 from .engine import NativeModule, PlanBuilder, POST_TANH, SLOT_IN, SLOT_NONE, SLOT_OUT, weight_norm  # noqa: F401
 from .modules import LRELU_SLOPE, ResBlock1, ResBlock2, UpsampleLayer
 from .pqmf import PQMF
@@ -100,16 +101,27 @@ class _HiFiGANBase(NativeModule):
         npairs = len(blocks[0].convs1)
         ch = blocks[0].channels
         curs = [up] * nk
+        prec = pb.pair_precision(ch)
         for pi in range(npairs - 1):
             pb.begin_group()
             nxt = []
             for j in range(nk):
                 ping, pong = scratch[j][1], scratch[j][2]
                 d = ping if curs[j] != ping else pong
-                pb.pair(blocks[j].convs1[pi], blocks[j].convs2[pi], curs[j], d, LRELU_SLOPE)
+                pb.pair(blocks[j].convs1[pi], blocks[j].convs2[pi], curs[j], d, LRELU_SLOPE, prec)
                 nxt.append(d)
             pb.end_group()
             curs = nxt
+        if prec == PAIR_SPLIT_F16:
+            # the 7- and 11-tap blocks' last pairs share a launch and store r_1, r_2; the first block's last pair
+            # runs after them and forms ((r_0 + r_1) + r_2) / nk in its epilogue: the reference's order, bit for bit
+            pb.begin_group()
+            for j in range(1, nk):
+                pb.pair(blocks[j].convs1[-1], blocks[j].convs2[-1], curs[j], parts[j - 1], LRELU_SLOPE, prec)
+            pb.end_group()
+            pb.pair(blocks[0].convs1[-1], blocks[0].convs2[-1], curs[0], x, LRELU_SLOPE, prec,
+                    add1=parts[0], add2=parts[1], out_div=float(nk))
+            return
         if ch == 16:
             pb.mrf_sum([(b.convs1[-1], b.convs2[-1]) for b in blocks], curs, x, LRELU_SLOPE, float(nk))
             return
@@ -204,7 +216,7 @@ class _HiFiGANBase(NativeModule):
 
     def _trunk_plan(self, T):
         fused = self._fused_flags(T)
-        return self._plan("trunk" + "".join("f" if f else "-" for f in fused),
+        return self._plan("trunk" + PlanBuilder.pair_mode_tag() + "".join("f" if f else "-" for f in fused),
                           lambda pb: self._emit_trunk(pb, SLOT_OUT, fused), 80)
 
     def _emit_inference(self, pb, fused):
@@ -217,7 +229,7 @@ class _HiFiGANBase(NativeModule):
         def emit(pb):
             self._emit_inference(pb, fused)
             pb.subtract_output(0, second=True)
-        return self._plan("minus" + "".join("f" if f else "-" for f in fused), emit, 80)
+        return self._plan("minus" + PlanBuilder.pair_mode_tag() + "".join("f" if f else "-" for f in fused), emit, 80)
 
     def inference_minus(self, x, bias):
         """x [T,80], bias [n] (e.g. the response to an all-zero mel) -> (waveform, waveform - bias), both 1-D,
@@ -285,7 +297,7 @@ class MultiBandHiFiGANGenerator(_HiFiGANBase):
 
     def _full_plan(self, T):
         fused = self._fused_flags(T)
-        return self._plan("inference" + "".join("f" if f else "-" for f in fused),
+        return self._plan("inference" + PlanBuilder.pair_mode_tag() + "".join("f" if f else "-" for f in fused),
                           lambda pb: self._emit_full(pb, fused), 80)
 
     def inference(self, x):

@@ -113,7 +113,7 @@ class ResBlock1(_Block):
         cur = src
         for i, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
             nxt = dst if i == len(self.convs1) - 1 else (ping if cur != ping else pong)
-            pb.pair(c1, c2, cur, nxt, LRELU_SLOPE)
+            pb.pair(c1, c2, cur, nxt, LRELU_SLOPE, pb.pair_precision(self.channels))
             cur = nxt
 
     def forward(self, x):
@@ -123,7 +123,8 @@ class ResBlock1(_Block):
 
         def build(pb):
             self.emit_fused(pb, SLOT_IN, SLOT_OUT, [pb.tmp() for _ in range(3)])
-        return self._plan("forward_fused", build, self.channels).run(x)
+        from .engine import PlanBuilder
+        return self._plan("forward_fused" + PlanBuilder.pair_mode_tag(), build, self.channels).run(x)
 
 
 class ResBlock2(_Block):

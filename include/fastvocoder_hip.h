@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FV_ABI_VERSION 7
+#define FV_ABI_VERSION 8
 
 #define FV_ERR_INVALID_ARG (-1)
 #define FV_ERR_UNSUPPORTED (-2)
@@ -148,6 +148,30 @@ int fv_pack_pair_weight(const float* w, float* packed, int C, int k, void* strea
 int fv_resblock1_fused(int n, const float* const* x, const float* const* w1, const float* const* w2,
                        const float* const* b1, const float* const* b2, float* const* y, float* const* y_act,
                        const int* k, int B, int C, int T, int dil, float slope, float act_slope, void* stream);
+
+/*
+ * The same operator with a choice of arithmetic, and -- for the last launch of an MRF stage -- the merge
+ * of hifigan.py:99-103 in the epilogue.
+ *   prec = FV_PAIR_F32:       v_mfma_f32_16x16x4_f32, exact fp32 products (the functions above).
+ *   prec = FV_PAIR_SPLIT_F16: every fp32 operand v is split as v = h1 + h2/2048 (+ <= 2^-22 |v|), h1, h2 f16,
+ *       and a product is three v_mfma_f32_16x16x32_f16 terms a1 b1 + (a1 b2 + a2 b1)/2048 accumulated in
+ *       fp32.  Per layer the result is as close to the exact sum as an fp32 FMA chain (measured: DESIGN.md
+ *       section 3.7, tests/test_split_precision.py); 5.3x fewer matrix-core cycles, which turns the C = 16
+ *       layers from matrix-bound into HBM / LDS-bound.  Needs |v| < 65504 for activations and weights.
+ *       Weights: fv_pack_pair_weight_ex(prec) images ([K step][row half][split half][lane][8 f16]).
+ *   add1 / add2 (arrays or entries may be NULL; FV_PAIR_SPLIT_F16 only): member j stores
+ *       y_j = post( ((x'_j + add1_j) + add2_j) / out_div )  -- with x'_j the first ResBlock's result and
+ *       add1 / add2 the second and third this is xs = r0; xs += r1; xs += r2; x = xs / 3 in the
+ *       reference's association.  Members without add1 ignore out_div / post.
+ */
+#define FV_PAIR_F32 0
+#define FV_PAIR_SPLIT_F16 1
+int64_t fv_packed_pair_floats_ex(int C, int k, int prec);
+int fv_pack_pair_weight_ex(const float* w, float* packed, int C, int k, int prec, void* stream);
+int fv_resblock1_fused_ex(int n, const float* const* x, const float* const* w1, const float* const* w2,
+                          const float* const* b1, const float* const* b2, float* const* y, float* const* y_act,
+                          const float* const* add1, const float* const* add2, const int* k, int B, int C, int T,
+                          int dil, float slope, float out_div, int post, float act_slope, int prec, void* stream);
 
 /*
  * End of an MRF stage (hifigan.py:97-103): the LAST pairs of the three ResBlocks and the mean, one launch:
@@ -293,6 +317,11 @@ int fv_plan_add_conv1d_sum3(fv_plan_t* plan, const int* x_slots, const int* res_
 int fv_plan_add_resblock_pair(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed1,
                               const float* packed2, const float* bias1, const float* bias2, int C, int k, int dil,
                               float slope, float act_slope);
+/* fv_resblock1_fused_ex as a plan op (add1_slot / add2_slot: FV_SLOT_NONE or [B,C,T] slots) */
+int fv_plan_add_resblock_pair_ex(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, int add1_slot,
+                                 int add2_slot, const float* packed1, const float* packed2, const float* bias1,
+                                 const float* bias2, int C, int k, int dil, float slope, float out_div, int post,
+                                 float act_slope, int prec);
 int fv_plan_add_mrf_sum(fv_plan_t* plan, const int* x_slots, int y_slot, int y_act_slot,
                         const float* const* packed1, const float* const* packed2, const float* const* bias1,
                         const float* const* bias2, int C, const int* k, int dil, float slope, float out_div,
@@ -368,6 +397,8 @@ int fv_plan_num_ops(fv_plan_t* plan);
 #define FV_KERNEL_CONV_NARROW 2 /* VALU conv for Cout <= 4 */
 #define FV_KERNEL_PAIR16 3      /* fused ResBlock pairs / MRF stage end, C = 16 (16x16x4 fp32 MFMA) */
 #define FV_KERNEL_PAIR32 4      /* fused ResBlock pairs, C = 32 */
+#define FV_KERNEL_PAIRH16 5     /* fused ResBlock pairs, C = 16, split-f16 operands (16x16x32 f16 MFMA) */
+#define FV_KERNEL_PAIRH32 6     /* ... C = 32 */
 int fv_profile_enable(int on);
 /* what the event bracket itself adds to a measured launch: the average elapsed time between the two events
  * of n EMPTY brackets recorded back to back on `stream` (subtract it per launch) */

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from fastvocoder_amd import _native
+from fastvocoder_amd.generator.engine import PlanBuilder
 from oracle import ops as oo
 
 pytestmark = pytest.mark.gpu
@@ -108,6 +109,94 @@ def test_mrf_stage_vs_oracle(case):
     assert _rel(y3, np.tanh(ref.astype(np.float64))) <= 2e-5
 
 
+SPLIT = _native.PAIR_SPLIT_F16
+
+
+@pytest.mark.parametrize("case", PAIR_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_resblock_pair_split_f16_vs_oracle(case):
+    """The split-f16 kernel (csrc/pairh_kernels.hpp) against the double-accumulating oracle: per layer it must be
+    as close as the fp32-MFMA kernel is (within 3x of its error + 1e-7), and inside 4e-6 of the tensor's scale."""
+    B, C, T, dil, ks, bias = case
+    rng = np.random.RandomState(abs(hash(case)) % (2 ** 31))
+    ms = [_member(rng, B, C, T, k, bias) for k in ks]
+    refs = [_pair_ref(x, w1, b1, w2, b2, dil, 0.1) for x, w1, b1, w2, b2 in ms]
+    xs = [_t(m[0]) for m in ms]
+    b1s, b2s = [_t(m[2]) for m in ms], [_t(m[4]) for m in ms]
+    f1, f2 = [_native.pack_pair(_t(m[1])) for m in ms], [_native.pack_pair(_t(m[3])) for m in ms]
+    h1, h2 = [_native.pack_pair(_t(m[1]), SPLIT) for m in ms], [_native.pack_pair(_t(m[3]), SPLIT) for m in ms]
+    y32 = _native.resblock1_fused(xs, f1, f2, b1s, b2s, list(ks), dil, 0.1)
+    ys = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, prec=SPLIT)
+    for y, yf, ref in zip(ys, y32, refs):
+        e, ef = _rel(y, ref), _rel(yf, ref)
+        assert e <= 4e-6 and e <= 3 * ef + 1e-7, (e, ef)
+    acts = [torch.empty_like(x) for x in xs]
+    ys2 = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, act_slope=0.2, outs_act=acts, prec=SPLIT)
+    for y, a, ref in zip(ys2, acts, refs):
+        assert _rel(y, ref) <= 4e-6 and _rel(a, oo.lrelu(ref, 0.2)) <= 4e-6
+    ys3 = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, act_slope=0.2, prec=SPLIT)
+    for y, ref in zip(ys3, refs):
+        assert _rel(y, oo.lrelu(ref, 0.2)) <= 4e-6
+
+
+@pytest.mark.parametrize("case", [(1, 16, 244, 5), (2, 16, 1000, 5), (1, 16, 100, 1), (3, 16, 488, 3), (1, 16, 8, 5),
+                                  (1, 16, 2444, 5), (2, 32, 500, 5), (1, 32, 1204, 3), (1, 32, 12, 1)],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_split_f16_stage_end_vs_oracle(case):
+    """End of an MRF stage on the split-f16 kernels: the 7- and 11-tap pairs in one launch (r1, r2), then the
+    3-tap pair with ((r0 + r1) + r2) / 3 in its epilogue -- the reference's association (hifigan.py:99-103)."""
+    B, C, T, dil = case
+    rng = np.random.RandomState(2000 * T + dil + C)
+    ks = (3, 7, 11)
+    ms = [_member(rng, B, C, T, k, True) for k in ks]
+    r = [_pair_ref(x, w1, b1, w2, b2, dil, 0.1) for x, w1, b1, w2, b2 in ms]
+    ref = ((r[0] + r[1]) + r[2]) / np.float32(3.0)
+    xs = [_t(m[0]) for m in ms]
+    h1, h2 = [_native.pack_pair(_t(m[1]), SPLIT) for m in ms], [_native.pack_pair(_t(m[3]), SPLIT) for m in ms]
+    b1s, b2s = [_t(m[2]) for m in ms], [_t(m[4]) for m in ms]
+    r12 = _native.resblock1_fused(xs[1:], h1[1:], h2[1:], b1s[1:], b2s[1:], [7, 11], dil, 0.1, prec=SPLIT)
+    args = ([xs[0]], [h1[0]], [h2[0]], [b1s[0]], [b2s[0]], [3], dil, 0.1)
+    y, = _native.resblock1_fused(*args, prec=SPLIT, add1=[r12[0]], add2=[r12[1]], out_div=3.0)
+    assert _rel(y, ref) <= 4e-6
+    act = [torch.empty_like(y)]
+    y2, = _native.resblock1_fused(*args, prec=SPLIT, add1=[r12[0]], add2=[r12[1]], out_div=3.0, act_slope=0.01,
+                                  outs_act=act)
+    assert _rel(y2, ref) <= 4e-6 and _rel(act[0], oo.lrelu(ref, 0.01)) <= 4e-6
+    y3, = _native.resblock1_fused(*args, prec=SPLIT, add1=[r12[0]], add2=[r12[1]], out_div=3.0, post=_native.POST_TANH)
+    assert _rel(y3, np.tanh(ref.astype(np.float64))) <= 4e-6
+    y4, = _native.resblock1_fused(*args, prec=SPLIT, add1=[r12[0]], out_div=2.0)        # one addend only
+    assert _rel(y4, (r[0] + r[1]) / np.float32(2.0)) <= 4e-6
+
+
+def test_split_f16_results_do_not_depend_on_the_batch():
+    rng = np.random.RandomState(11)
+    ks = (11, 7, 3)
+    for C, T in ((16, 1500), (32, 700)):
+        ms = [_member(rng, 3, C, T, k, True) for k in ks]
+        xs = [_t(m[0]) for m in ms]
+        h1, h2 = [_native.pack_pair(_t(m[1]), SPLIT) for m in ms], [_native.pack_pair(_t(m[3]), SPLIT) for m in ms]
+        b1s, b2s = [_t(m[2]) for m in ms], [_t(m[4]) for m in ms]
+        full = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), 3, 0.1, prec=SPLIT)
+        for b in range(3):
+            one = _native.resblock1_fused([x[b:b + 1].contiguous() for x in xs], h1, h2, b1s, b2s, list(ks), 3, 0.1,
+                                          prec=SPLIT)
+            for yf, yo in zip(full, one):
+                assert torch.equal(yf[b:b + 1], yo)
+
+
+def test_split_f16_rejects_what_it_is_not_built_for():
+    dev = _dev()
+    with pytest.raises(_native.NativeError):
+        _native.pack_pair(torch.zeros((64, 64, 3), device=dev), SPLIT)
+    x = torch.zeros((1, 16, 50), device=dev)               # T % 4 != 0
+    w = _native.pack_pair(torch.zeros((16, 16, 3), device=dev), SPLIT)
+    with pytest.raises(_native.NativeError, match="multiple of 4"):
+        _native.resblock1_fused([x], [w], [w], [None], [None], [3], 1, 0.1, prec=SPLIT)
+    x16 = torch.zeros((1, 16, 64), device=dev)
+    w16 = _native.pack_pair(torch.zeros((16, 16, 3), device=dev))
+    with pytest.raises(_native.NativeError, match="SPLIT_F16 only"):
+        _native.resblock1_fused([x16], [w16], [w16], [None], [None], [3], 1, 0.1, add1=[x16.clone()])
+
+
 def test_pair_results_do_not_depend_on_the_batch():
     """Bit-identity: an utterance gives the same bits alone and inside a batch (what lets a batch be
     sharded over GPUs), for the plain and the sum kernels, on both channel counts."""
@@ -169,5 +258,6 @@ def test_resblock1_on_the_fused_path_vs_reference_goldens():
                     p.copy_(torch.from_numpy(flat[off:off + p.numel()].reshape(tuple(p.shape))))
                     off += p.numel()
             y = rb(x)
-            assert "forward_fused" in rb._fv_plans and rb._fv_plans["forward_fused"][1].num_ops() == 3
+            name = "forward_fused" + PlanBuilder.pair_mode_tag()
+            assert name in rb._fv_plans and rb._fv_plans[name][1].num_ops() == 3
             assert _rel(y, g[f"rb1_c{ch}_k{k}_out"]) <= 2e-5
