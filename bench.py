@@ -167,16 +167,23 @@ def roofline_report(model, mel, ms_per_step, reps=5):
     _native.profile_enable(False)
     del os.environ["FV_SINGLE_LANE"]
     kinds = {"conv32": _native.KERNEL_CONV_MFMA32, "conv16": _native.KERNEL_CONV_MFMA16,
-             "pair16": _native.KERNEL_PAIR16, "pair32": _native.KERNEL_PAIR32, "narrow": _native.KERNEL_CONV_NARROW}
+             "pair16": _native.KERNEL_PAIR16, "pair32": _native.KERNEL_PAIR32,
+             "pairh16": _native.KERNEL_PAIRH16, "pairh32": _native.KERNEL_PAIRH32,
+             "narrow": _native.KERNEL_CONV_NARROW}
     rec = {k: _native.profile_collect(v) for k, v in kinds.items()}
     for r in rec.values():
         r["ms"] = max(r["ms"] - bracket_ms * r["launches"], 0.0)
+    # the dominant kernel family: everything that runs on the fp32 matrix cores (the split-f16 fused pairs of the
+    # 16- and 32-channel stages are HBM / LDS-bound and are reported against the memory roofline below)
     mf = [rec[k] for k in ("conv32", "conv16", "pair16", "pair32")]
     launches = sum(r["launches"] for r in mf)
     ms = sum(r["ms"] for r in mf)
     flops = sum(r["flops"] for r in mf)
     nbytes = sum(r["bytes"] for r in mf)
-    all_ms = (ms + rec["narrow"]["ms"]) / reps
+    split = [rec[k] for k in ("pairh16", "pairh32")]
+    split_ms = sum(r["ms"] for r in split)
+    split_flops = sum(r["flops"] for r in split)
+    all_ms = (ms + split_ms + rec["narrow"]["ms"]) / reps
     # Sum of kernel time must fit inside the step; if the calibration ever fails that test, fall back to
     # the whole-step figure (launch gaps included: a lower bound of the kernels' rate)
     consistent = all_ms <= ms_per_step * 1.001
@@ -189,10 +196,16 @@ def roofline_report(model, mel, ms_per_step, reps=5):
             traffic = json.load(f)["conv_mfma_family"]["hbm_bytes_per_launch"]
         traffic_src = "profiles/" + cand
         break
+    split_on = split_ms > 0
     roofline = {
-        "kernel": "fp32-MFMA conv family: fv::pair_kernel / fv::pair_sum_kernel (fused ResBlock pairs, 16x16x4, "
-                  "csrc/pair_kernels.hpp) + fv::conv_group3_kernel / conv_sum3_kernel / conv_mfma_kernel "
-                  "(implicit-GEMM conv1d, 32x32x2, csrc/conv_kernels.hpp): 77 of the 78 convs of a forward",
+        "kernel": ("fp32-MFMA implicit-GEMM conv family, fv::conv_group3_kernel / conv_mfma_kernel / conv_sum3_kernel "
+                   "(32x32x2 fp32 MFMA, csrc/conv_kernels.hpp): conv_pre, the four upsamplers and the 128- and "
+                   "64-channel MRF stages -- %.0f %% of the step's kernel time; the 32- and 16-channel stages run as "
+                   "split-f16 fused ResBlock pairs (csrc/pairh_kernels.hpp), see roofline_hbm_stage / split_f16"
+                   % (100.0 * ms / max(ms + split_ms + rec["narrow"]["ms"], 1e-9))) if split_on else
+                  ("fp32-MFMA conv family: fv::pair_kernel / fv::pair_sum_kernel (fused ResBlock pairs, 16x16x4, "
+                   "csrc/pair_kernels.hpp) + fv::conv_group3_kernel / conv_sum3_kernel / conv_mfma_kernel "
+                   "(implicit-GEMM conv1d, 32x32x2, csrc/conv_kernels.hpp): 77 of the 78 convs of a forward"),
         "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
         "traffic": traffic,
@@ -202,19 +215,31 @@ def roofline_report(model, mel, ms_per_step, reps=5):
         "measured": "per-launch HIP events on the launch stream, single-stream replay of the same forward, "
                     f"event-bracket cost ({bracket_ms * 1e3:.2f} us per launch) subtracted"
                     + ("" if consistent else "; INCONSISTENT with the step time -> whole-step figure used"),
-        "achieved_whole_step": flops / reps / (ms_per_step * 1e-3) / 1e12,
-        "frac_whole_step": flops / reps / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+        "achieved_whole_step": (flops + split_flops) / reps / (ms_per_step * 1e-3) / 1e12,
+        "frac_whole_step": (flops + split_flops) / reps / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+        "whole_step_note": "all algorithmic conv FLOP of the forward / step time, against the fp32-MFMA peak"
+                           + (" (fp32-equivalent: the split-f16 stages spend 3 f16 MFMAs per 32 fp32 products)"
+                              if split_on else ""),
         "launches_per_step": launches // reps,
         "avg_launch_us": 1e3 * ms / max(launches, 1),
         "algorithmic_gflop_per_step": flops / reps / 1e9,
+        "algorithmic_gflop_per_step_all_kernels": (flops + split_flops) / reps / 1e9,
         "kernel_ms_per_step": ms / reps,
+        "split_f16": {
+            "kernel": "fv::pairh_kernel (fused ResBlock1 pairs, operands split into two f16 halves, "
+                      "v_mfma_f32_16x16x32_f16 x 3 per product, fp32 accumulate; csrc/pairh_kernels.hpp)",
+            "ms_per_step": split_ms / reps, "launches_per_step": sum(r["launches"] for r in split) // reps,
+            "fp32_equivalent_tflops": split_flops / (split_ms * 1e-3) / 1e12 if split_ms > 0 else 0.0,
+            "external_gbs": sum(r["bytes"] for r in split) / (split_ms * 1e-3) / 1e9 if split_ms > 0 else 0.0,
+            "bound": "hbm / lds (DESIGN.md section 3.7)",
+        },
         "narrow_conv_ms_per_step": rec["narrow"]["ms"] / reps,
         "by_family_ms_per_step": {k: r["ms"] / reps for k, r in rec.items()},
         "by_family_tflops": {k: (r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0) for k, r in rec.items()},
     }
     # The HBM-bound members (north star: "memory roofline on the dilated-conv kernels"): the 16-channel stage,
     # 12-44 FLOP/B, with SURVEY.md section 8(d)'s layer-by-layer bytes over the time of its launches
-    stage = rec["pair16"] if rec["pair16"]["launches"] else rec["conv16"]
+    stage = rec["pairh16"] if rec["pairh16"]["launches"] else rec["pair16"] if rec["pair16"]["launches"] else rec["conv16"]
     B = mel.shape[0]
     t_stage = T_FRAMES
     for up in model.ups:
@@ -223,7 +248,9 @@ def roofline_report(model, mel, ms_per_step, reps=5):
     st_ms = stage["ms"] / reps
     hbm = {
         "kernel": "the C = 16 stage of the generator (18 dilated / plain 16-channel convs on 240 000 samples): "
-                  + ("2 fused-pair launches + the fused MRF stage end (fv::pair_kernel, fv::pair_sum_kernel)"
+                  + ("3 fused-pair launches (two of three members, the stage end of two) + the first block's last "
+                     "pair with the MRF merge (fv::pairh_kernel, split-f16 operands)" if rec["pairh16"]["launches"]
+                     else "2 fused-pair launches + the fused MRF stage end (fv::pair_kernel, fv::pair_sum_kernel)"
                      if rec["pair16"]["launches"] else "16x16x4-MFMA conv launches"),
         "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
         "achieved": survey / (st_ms * 1e-3) / 1e9 if st_ms > 0 else 0.0,

@@ -94,8 +94,10 @@ static int launch_pairs_split(PairParams p, int C, int dil, hipStream_t s) {
             return fail(FV_ERR_UNSUPPORTED, "resblock pair: x / packed weights must be 16-byte aligned");
         const PairHShape g = pairh_shape(C, mb.k, dil);
         mb.n_tiles = (p.T + g.NOUT - 1) / g.NOUT;
-        // LDS-bandwidth bound: a tile costs its K steps (two convs) plus the convert pass / epilogues / barriers
-        mb.cost = g.KS + (getenv("FV_PAIRH_SKEL") ? atoi(getenv("FV_PAIRH_SKEL")) : 3);
+        // a tile costs its K steps (two convs, LDS-bandwidth bound) plus a part that does not depend on the taps
+        // (loads, convert pass, epilogues, stores, barriers): measured per member alone (tools/pair_bench.py)
+        // 0.8 us per step + 8 steps' worth at C = 16, 1.6 us per step + 4 steps' worth at C = 32
+        mb.cost = g.KS + (getenv("FV_PAIRH_SKEL") ? atoi(getenv("FV_PAIRH_SKEL")) : (C == 16 ? 8 : 4));
         mb.w_off = 0;
         if (2 * g.WB > w_bytes) w_bytes = 2 * g.WB;
         if (g.XROWS * g.RB > img_bytes) img_bytes = g.XROWS * g.RB;

@@ -29,17 +29,26 @@ def main():
     write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {"unit": "bytes per launch", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": {}}
     fam_bytes, fam_n = 0.0, 0
+    split = {"16": [0.0, 0], "32": [0.0, 0]}          # fv::pairh_kernel<MH = 1 | 2, ...>: C = 16 | 32
     for k in sorted(fetch, key=lambda k: -fetch[k]):
         if k not in write or "fv::" not in k:
             continue
         fb = 2.0 * fetch[k] / nf[k] * 1024
         wb = write[k] / nw[k] * 1024
         out["kernels"][k] = {"launches": nf[k], "fetch_bytes_corrected": fb, "write_bytes": wb, "hbm_bytes": fb + wb}
-        if any(t in k for t in ("conv_mfma_kernel", "conv_group3_kernel", "conv_sum3_kernel", "pair_kernel",
+        if any(t in k for t in ("conv_mfma_kernel", "conv_group3_kernel", "conv_sum3_kernel", "fv::pair_kernel",
                                 "pair_sum_kernel")):
             fam_bytes += (fb + wb) * nf[k]
             fam_n += nf[k]
+        if "pairh_kernel<" in k:
+            c = "16" if "pairh_kernel<1," in k else "32"
+            split[c][0] += (fb + wb) * nf[k]
+            split[c][1] += nf[k]
+    # the fp32-MFMA family bench.py's `roofline` is about; the split-f16 fused pairs per channel count
     out["conv_mfma_family"] = {"launches": fam_n, "hbm_bytes_per_launch": fam_bytes / max(fam_n, 1)}
+    for c, (b, n) in split.items():
+        if n:
+            out["split_f16_pairs_c" + c] = {"launches": n, "hbm_bytes_per_launch": b / n}
     js = json.dumps(out, indent=1)
     if len(sys.argv) > 3:
         open(sys.argv[3], "w").write(js)
