@@ -17,10 +17,11 @@ _CSRC = os.path.join(_HERE, "csrc")
 # conv_inst_s*.hip instantiate the conv kernel templates (conv_kernels.hpp) one tile shape each,
 # so that the ~170 kernel variants compile in parallel
 SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip", "wav_sink.hip", "conv_inst_narrow.hip",
-           "pair_launch.hip", "pair_inst_c16.hip", "pair_inst_c32.hip", "pairh_inst_c16.hip", "pairh_inst_c32.hip"] + \
+           "pair_launch.hip", "pair_inst_c16.hip", "pair_inst_c32.hip", "pairh_inst_c16.hip", "pairh_inst_c32.hip",
+           "convh_launch.hip", "convh_inst_c64.hip", "convh_inst_c128.hip"] + \
           [f"conv_inst_s{i}.hip" for i in range(6)]
 HEADERS = ["fv_internal.h", "conv_kernels.hpp", "pair_kernels.hpp", "pair_inst.hpp", "pairh_kernels.hpp",
-           "pairh_inst.hpp"]
+           "pairh_inst.hpp", "convh_kernels.hpp", "convh_inst.hpp"]
 
 PAD_ZERO, PAD_REFLECT = 0, 1
 PAD_CAUSAL = 2      # flag: pad (k-1)*dil on both sides, keep the first Tin outputs (CausalConv1d)
@@ -149,9 +150,9 @@ def lib():
     L.fv_packed_pair_floats_ex.argtypes = [i, i, i]
     L.fv_packed_pair_floats_ex.restype = i64
     L.fv_pack_pair_weight_ex.argtypes = [vp, vp, i, i, i, vp]
-    L.fv_resblock1_fused_ex.argtypes = [i, pp, pp, pp, pp, pp, pp, pp, pp, pp, ctypes.POINTER(i), i, i, i, i, f, f, i, f,
-                                        i, vp]
-    L.fv_plan_add_resblock_pair_ex.argtypes = [vp, i, i, i, i, i, vp, vp, vp, vp, i, i, i, f, f, i, f, i]
+    L.fv_resblock1_fused_ex.argtypes = [i, pp, pp, pp, pp, pp, pp, pp, pp, pp, pp, ctypes.POINTER(i), i, i, i, i, f, f,
+                                        i, f, i, vp]
+    L.fv_plan_add_resblock_pair_ex.argtypes = [vp, i, i, i, i, i, i, vp, vp, vp, vp, i, i, i, f, f, i, f, i]
     L.fv_plan_add_mrf_sum.argtypes = [vp, ctypes.POINTER(i), i, i, pp, pp, pp, pp, i, ctypes.POINTER(i), i, f, f, i, f]
     L.fv_plan_create.argtypes = [i]
     L.fv_plan_create.restype = vp
@@ -303,7 +304,8 @@ def pack_pair(w, prec=PAIR_F32):
 
 def pair_supported(channels, k, dil, prec=PAIR_F32):
     """Shapes the fused ResBlock-pair kernels are built for (csrc/pair_launch.hip)."""
-    return channels in (16, 32) and k in (3, 7, 11) and dil in (1, 3, 5) and prec in (PAIR_F32, PAIR_SPLIT_F16)
+    chans = (16, 32) if prec == PAIR_F32 else (16, 32, 64, 128)
+    return channels in chans and k in (3, 7, 11) and dil in (1, 3, 5) and prec in (PAIR_F32, PAIR_SPLIT_F16)
 
 
 def _vp_array(tensors, name, allow_none=False):
@@ -315,7 +317,7 @@ def _vp_array(tensors, name, allow_none=False):
 # ---------------------------------------------------------------------------
 
 def resblock1_fused(xs, w1s, w2s, b1s, b2s, ks, dil, slope, act_slope=1.0, outs=None, outs_act=None,
-                    prec=PAIR_F32, add1=None, add2=None, out_div=1.0, post=POST_NONE):
+                    prec=PAIR_F32, add1=None, add2=None, out_div=1.0, post=POST_NONE, mids=None):
     """n = len(xs) independent fused ResBlock pairs in one launch (fv_resblock1_fused_ex):
     y_j = x_j + conv2_j(lrelu(conv1_j(lrelu(x_j)) + b1_j)) + b2_j; w1s / w2s from pack_pair(w, prec).
     With add1 / add2 (split-f16 arithmetic): y_j = post(((y_j + add1_j) + add2_j) / out_div)."""
@@ -326,10 +328,13 @@ def resblock1_fused(xs, w1s, w2s, b1s, b2s, ks, dil, slope, act_slope=1.0, outs=
     acts = list(outs_act) if outs_act is not None else [None] * n
     a1 = list(add1) if add1 is not None else [None] * n
     a2 = list(add2) if add2 is not None else [None] * n
-    with _on(*xs, *w1s, *w2s, *b1s, *b2s, *outs, *acts, *a1, *a2) as stream:
+    # C >= 64 (split-f16): the pair runs as two conv launches through a scratch tensor per member
+    mids = [torch.empty_like(x) if C >= 64 else None for x in xs] if mids is None else list(mids)
+    with _on(*xs, *w1s, *w2s, *b1s, *b2s, *outs, *acts, *a1, *a2, *mids) as stream:
         check(lib().fv_resblock1_fused_ex(n, _vp_array(xs, "x"), _vp_array(w1s, "w1"), _vp_array(w2s, "w2"),
                                           _vp_array(b1s, "b1", True), _vp_array(b2s, "b2", True),
                                           _vp_array(outs, "y"), _vp_array(acts, "y_act", True),
+                                          _vp_array(mids, "mid", True),
                                           _vp_array(a1, "add1", True), _vp_array(a2, "add2", True),
                                           (ctypes.c_int * n)(*ks), B, C, T, dil, float(slope), float(out_div), post,
                                           float(act_slope), prec, stream))
@@ -530,12 +535,12 @@ class Plan:
 
     def add_resblock_pair(self, x, y, packed1, packed2, bias1, bias2, channels, k, dil, slope,
                           y_act=SLOT_NONE, act_slope=1.0, prec=PAIR_F32, add1=SLOT_NONE, add2=SLOT_NONE,
-                          out_div=1.0, post=POST_NONE):
+                          out_div=1.0, post=POST_NONE, mid=SLOT_NONE):
         """One fused ResBlock pair (fv_plan_add_resblock_pair_ex); group members share a launch."""
         for t in (packed1, packed2, bias1, bias2):
             if t is not None:
                 self.keep(t)
-        check(lib().fv_plan_add_resblock_pair_ex(self._h, x, y, y_act, add1, add2, _ptr(packed1, "packed1"),
+        check(lib().fv_plan_add_resblock_pair_ex(self._h, x, y, y_act, mid, add1, add2, _ptr(packed1, "packed1"),
                                                  _ptr(packed2, "packed2"), _ptr(bias1, "bias1", True),
                                                  _ptr(bias2, "bias2", True), channels, k, dil, float(slope),
                                                  float(out_div), post, float(act_slope), prec))
@@ -623,7 +628,7 @@ def profile_enable(on):
 
 
 KERNEL_CONV_MFMA32, KERNEL_CONV_MFMA16, KERNEL_CONV_NARROW, KERNEL_PAIR16, KERNEL_PAIR32 = 0, 1, 2, 3, 4
-KERNEL_PAIRH16, KERNEL_PAIRH32 = 5, 6
+KERNEL_PAIRH16, KERNEL_PAIRH32, KERNEL_CONVH64, KERNEL_CONVH128 = 5, 6, 7, 8
 
 
 def profile_bracket_cost(n=200):

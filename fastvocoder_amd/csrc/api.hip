@@ -220,6 +220,24 @@ __global__ void pack_pairh_kernel(const float* __restrict__ w, _Float16* __restr
     }
 }
 
+// Conv1d weight [C, C, k], C = 64 / 128 -> the streamed split-f16 A operands of convh_kernels.hpp:
+// Wh[row tile mt][K step s = tap * C/32 + cg][row sixteenth mh][split half][lane][8 halves];
+// lane = (row = lane & 15, K block kb = lane >> 4): co = 64 mt + 16 mh + row, ci = 32 cg + 8 kb + j.
+__global__ void pack_convh_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int C, int k) {
+    const int CG = C / 32, NSTEP = k * CG;
+    const int64_t total = (int64_t)(C / 64) * NSTEP * 4 * 2 * 64 * 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63), half = (int)((i >> 9) & 1), mh = (int)((i >> 10) & 3);
+        const int ms = (int)(i >> 12), s = ms % NSTEP, mt = ms / NSTEP;
+        const int tap = s / CG, cg = s % CG;
+        const int co = 64 * mt + 16 * mh + (lane & 15), ci = 32 * cg + 8 * (lane >> 4) + j;
+        const float v = w[((size_t)co * C + ci) * k + tap];
+        const _Float16 h1 = (_Float16)v;
+        wp[i] = half == 0 ? h1 : (_Float16)((v - (float)h1) * 2048.f);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------
@@ -363,6 +381,13 @@ static int infer(const fv_plan* plan, int B, int T, Shape* sh, int64_t* slot_ele
                 const int64_t es = (int64_t)B * o.Cout * sh[o.x].T;
                 if (es > slot_elems[t2[e]]) slot_elems[t2[e]] = es;
             }
+        }
+        if (o.type == OP_PAIR && o.tmpb != FV_SLOT_NONE) {   // intermediate of a two-launch (C >= 64) pair
+            if (o.tmpb == o.x || o.tmpb == o.y || o.tmpb == o.y2 || o.tmpb == o.acc || o.tmpb == o.acc2 || o.tmpb == FV_SLOT_IN)
+                return fail(FV_ERR_INVALID_ARG, "op %zu: pair scratch slot %d aliases an operand", n, o.tmpb);
+            sh[o.tmpb] = {o.Cout, sh[o.x].T, true};
+            const int64_t es = (int64_t)B * o.Cout * sh[o.x].T;
+            if (es > slot_elems[o.tmpb]) slot_elems[o.tmpb] = es;
         }
         if (o.y == o.x || o.y == o.x2) return fail(FV_ERR_INVALID_ARG, "op %zu: output aliases input", n);
         sh[o.y] = {Cout, Tout, true};
@@ -946,6 +971,7 @@ int fv_pack_pair_weight(const float* w, float* packed, int C, int k, void* strea
 
 int64_t fv_packed_pair_floats_ex(int C, int k, int prec) {
     if (prec != FV_PAIR_SPLIT_F16) return fv_packed_pair_floats(C, k);
+    if (C == 64 || C == 128) return (int64_t)(C / 64) * k * (C / 32) * 2048;   // row tiles x K steps x 8 KB
     if (C != 16 && C != 32) return 0;
     const int tps = 32 / C;
     return (int64_t)((k + tps - 1) / tps) * (C / 16) * 512;   // K steps x row halves x 2 split halves x 64 lanes x 16 bytes
@@ -955,17 +981,49 @@ int fv_pack_pair_weight_ex(const float* w, float* packed, int C, int k, int prec
     if (prec == FV_PAIR_F32) return fv_pack_pair_weight(w, packed, C, k, stream);
     if (prec != FV_PAIR_SPLIT_F16) return fail(FV_ERR_INVALID_ARG, "pack_pair_weight: unknown arithmetic %d", prec);
     if (!w || !packed) return fail(FV_ERR_INVALID_ARG, "pack_pair_weight: null tensor");
-    if ((C != 16 && C != 32) || k <= 0) return fail(FV_ERR_INVALID_ARG, "pack_pair_weight: C=%d (16 or 32) k=%d", C, k);
+    if ((C != 16 && C != 32 && C != 64 && C != 128) || k <= 0)
+        return fail(FV_ERR_INVALID_ARG, "pack_pair_weight: C=%d (16, 32, 64 or 128) k=%d", C, k);
     const int64_t total = fv_packed_pair_floats_ex(C, k, prec) * 2;
-    hipLaunchKernelGGL(pack_pairh_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       reinterpret_cast<_Float16*>(packed), C, k);
+    if (C >= 64)
+        hipLaunchKernelGGL(pack_convh_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           w, reinterpret_cast<_Float16*>(packed), C, k);
+    else
+        hipLaunchKernelGGL(pack_pairh_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           w, reinterpret_cast<_Float16*>(packed), C, k);
     FV_HIP(hipGetLastError());
     return 0;
 }
 
-static int check_pair_args(int n, int C, const int* k, int dil) {
+// A pair at C >= 64 (split-f16 arithmetic only): conv1 of every member in one launch, then conv2 + residual
+// (+ the MRF addends); the members' intermediates go through mid[j]
+static int launch_wide_pairs(const PairParams& pp, float* const* mid, int C, int dil, hipStream_t s) {
+    PairParams c1 = pp, c2 = pp;
+    c1.act_slope = 1.f;
+    c1.out_div = 1.f;
+    c1.post = FV_POST_NONE;
+    for (int j = 0; j < pp.n_members; ++j) {
+        if (!mid || !mid[j]) return fail(FV_ERR_INVALID_ARG, "resblock pair: C = %d needs a scratch tensor per member (mid)", C);
+        if (mid[j] == pp.m[j].x || mid[j] == pp.m[j].y || mid[j] == pp.m[j].y_act || mid[j] == pp.m[j].add1 ||
+            mid[j] == pp.m[j].add2)
+            return fail(FV_ERR_INVALID_ARG, "resblock pair: mid aliases another tensor of member %d", j);
+        PairMember& a = c1.m[j];
+        a.y = mid[j];
+        a.y_act = nullptr;
+        a.res = a.add1 = a.add2 = nullptr;
+        PairMember& b = c2.m[j];
+        b.x = mid[j];
+        b.w1 = pp.m[j].w2;
+        b.b1 = pp.m[j].b2;
+        b.res = pp.m[j].x;
+    }
+    if (int rc = launch_convh(c1, C, dil, s)) return rc;
+    return launch_convh(c2, C, 1, s);
+}
+
+static int check_pair_args(int n, int C, const int* k, int dil, int prec = FV_PAIR_F32) {
     if (n < 1 || n > 3) return fail(FV_ERR_INVALID_ARG, "resblock pair: %d members (1..3)", n);
-    if (C != 16 && C != 32) return fail(FV_ERR_UNSUPPORTED, "resblock pair: C = %d (16 or 32); use the conv1d ops", C);
+    if (C != 16 && C != 32 && !(prec == FV_PAIR_SPLIT_F16 && (C == 64 || C == 128)))
+        return fail(FV_ERR_UNSUPPORTED, "resblock pair: C = %d (16 or 32; 64 or 128 with split-f16 operands); use the conv1d ops", C);
     if (dil != 1 && dil != 3 && dil != 5) return fail(FV_ERR_UNSUPPORTED, "resblock pair: dilation %d (1, 3 or 5)", dil);
     for (int j = 0; j < n; ++j)
         if (k[j] != 3 && k[j] != 7 && k[j] != 11) return fail(FV_ERR_UNSUPPORTED, "resblock pair: %d taps (3, 7 or 11)", k[j]);
@@ -975,16 +1033,17 @@ static int check_pair_args(int n, int C, const int* k, int dil) {
 int fv_resblock1_fused(int n, const float* const* x, const float* const* w1, const float* const* w2,
                        const float* const* b1, const float* const* b2, float* const* y, float* const* y_act,
                        const int* k, int B, int C, int T, int dil, float slope, float act_slope, void* stream) {
-    return fv_resblock1_fused_ex(n, x, w1, w2, b1, b2, y, y_act, nullptr, nullptr, k, B, C, T, dil, slope, 1.f,
-                                 FV_POST_NONE, act_slope, FV_PAIR_F32, stream);
+    return fv_resblock1_fused_ex(n, x, w1, w2, b1, b2, y, y_act, nullptr, nullptr, nullptr, k, B, C, T, dil, slope,
+                                 1.f, FV_POST_NONE, act_slope, FV_PAIR_F32, stream);
 }
 
 int fv_resblock1_fused_ex(int n, const float* const* x, const float* const* w1, const float* const* w2,
                           const float* const* b1, const float* const* b2, float* const* y, float* const* y_act,
-                          const float* const* add1, const float* const* add2, const int* k, int B, int C, int T,
-                          int dil, float slope, float out_div, int post, float act_slope, int prec, void* stream) {
+                          float* const* mid, const float* const* add1, const float* const* add2, const int* k, int B,
+                          int C, int T, int dil, float slope, float out_div, int post, float act_slope, int prec,
+                          void* stream) {
     if (!x || !w1 || !w2 || !y || !k) return fail(FV_ERR_INVALID_ARG, "resblock1_fused: null argument");
-    if (int rc = check_pair_args(n, C, k, dil)) return rc;
+    if (int rc = check_pair_args(n, C, k, dil, prec)) return rc;
     PairParams pp = {};
     pp.n_members = n;
     pp.B = B;
@@ -1012,6 +1071,7 @@ int fv_resblock1_fused_ex(int n, const float* const* x, const float* const* w1, 
         mb.y_act = y_act ? y_act[j] : nullptr;
         mb.k = k[j];
     }
+    if (C >= 64) return launch_wide_pairs(pp, mid, C, dil, (hipStream_t)stream);
     return launch_pairs(pp, C, dil, (hipStream_t)stream);
 }
 
@@ -1048,16 +1108,20 @@ int fv_mrf_stage(const float* const* x, const float* const* w1, const float* con
 int fv_plan_add_resblock_pair(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed1,
                               const float* packed2, const float* bias1, const float* bias2, int C, int k, int dil,
                               float slope, float act_slope) {
-    return fv_plan_add_resblock_pair_ex(plan, x_slot, y_slot, y_act_slot, FV_SLOT_NONE, FV_SLOT_NONE, packed1, packed2,
-                                        bias1, bias2, C, k, dil, slope, 1.f, FV_POST_NONE, act_slope, FV_PAIR_F32);
+    return fv_plan_add_resblock_pair_ex(plan, x_slot, y_slot, y_act_slot, FV_SLOT_NONE, FV_SLOT_NONE, FV_SLOT_NONE,
+                                        packed1, packed2, bias1, bias2, C, k, dil, slope, 1.f, FV_POST_NONE, act_slope,
+                                        FV_PAIR_F32);
 }
 
-int fv_plan_add_resblock_pair_ex(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, int add1_slot,
+int fv_plan_add_resblock_pair_ex(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, int mid_slot, int add1_slot,
                                  int add2_slot, const float* packed1, const float* packed2, const float* bias1,
                                  const float* bias2, int C, int k, int dil, float slope, float out_div, int post,
                                  float act_slope, int prec) {
     if (!plan || !packed1 || !packed2) return fail(FV_ERR_INVALID_ARG, "plan_add_resblock_pair: null");
-    if (int rc = check_pair_args(1, C, &k, dil)) return rc;
+    if (int rc = check_pair_args(1, C, &k, dil, prec)) return rc;
+    if ((C >= 64) != (mid_slot != FV_SLOT_NONE))
+        return fail(FV_ERR_INVALID_ARG, "plan_add_resblock_pair: a scratch slot is needed at C >= 64 and only there");
+    if (int rc = check_slot(mid_slot, true)) return rc;
     if (prec != FV_PAIR_F32 && prec != FV_PAIR_SPLIT_F16)
         return fail(FV_ERR_INVALID_ARG, "plan_add_resblock_pair: unknown arithmetic %d", prec);
     if (prec == FV_PAIR_F32 && (add1_slot != FV_SLOT_NONE || add2_slot != FV_SLOT_NONE || out_div != 1.f || post != FV_POST_NONE))
@@ -1077,6 +1141,7 @@ int fv_plan_add_resblock_pair_ex(fv_plan_t* plan, int x_slot, int y_slot, int y_
     o.res = FV_SLOT_NONE;
     o.acc = add1_slot;      // the MRF addends travel in the running-sum fields (dependencies, shape checks)
     o.acc2 = add2_slot;
+    o.tmpb = mid_slot;
     o.group = plan->cur_group;
     o.lane = plan->cur_lane;
     o.Cin = o.Cout = C;
@@ -1303,7 +1368,11 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
                     mb.add2 = qo.acc2 == FV_SLOT_NONE ? nullptr : base[qo.acc2];
                 }
             }
-            if (int rc = launch_pairs(pp, o.Cin, o.dil, s)) return rc;
+            if (o.Cin >= 64) {
+                float* mids[3] = {nullptr, nullptr, nullptr};
+                for (size_t q = n; q < m; ++q) mids[q - n] = base[plan->ops[q].tmpb];
+                if (int rc = launch_wide_pairs(pp, mids, o.Cin, o.dil, s)) return rc;
+            } else if (int rc = launch_pairs(pp, o.Cin, o.dil, s)) return rc;
             for (size_t q = n; q < m; ++q) {
                 const Op& qo = plan->ops[q];
                 if (multi && qo.signal) FV_HIP(hipEventRecord(plan->op_event[q], s));

@@ -1,0 +1,26 @@
+// launch of one split-f16 wide-channel conv geometry: picks the dilation instantiation
+#pragma once
+#include "convh_kernels.hpp"
+
+namespace fv {
+
+template <int CG, int NFW>
+int launch_convh_geom(const PairParams& p, int dil, size_t lds, hipStream_t s) {
+#define FV_CONVH(DIL)                                                                          \
+    do {                                                                                       \
+        auto kern = convh_kernel<CG, NFW, DIL>;                                                \
+        FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                        \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
+        hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(512), lds, s, p);                          \
+    } while (0)
+    switch (dil) {
+        case 1: FV_CONVH(1); break;
+        case 3: FV_CONVH(3); break;
+        default: FV_CONVH(5); break;
+    }
+#undef FV_CONVH
+    FV_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace fv

@@ -1,0 +1,360 @@
+// Conv1d with SPLIT-F16 operands for the wide ResBlock convs (C = 64, 128; 'same' zero padding):
+//
+//     y = post( ( conv1d( lrelu(x, slope); w, KT taps, dilation DIL ) + bias + res + add1 + add2 ) / out_div )
+//
+// Same arithmetic as pairh_kernels.hpp (every fp32 operand v = h1 + h2/2048, h1 / h2 f16; a product is three
+// v_mfma_f32_16x16x32_f16 terms a1 b1 + (a1 b2 + a2 b1)/2048 accumulated in fp32: fp32-class accuracy at 3/16 of
+// the fp32-MFMA cycles), same channels-last split image of the activated input in LDS (built in the kernel
+// from the raw fp32 tensor, which is prefetched global -> registers half a tile ahead).  What is new is that
+// the weights no longer fit on chip: C x C x KT x 4 bytes is 180 KB at C = 64 and 720 KB at C = 128.
+//
+//   * a block (8 waves = 2 row groups x 4 column groups) owns a 64-row x NTC-column output tile and walks the
+//     K range (tap-major: step = 32 input channels of one tap) in STAGES of two steps;
+//   * the packed weights of a stage (16 KB: [step][row sixteenth][split half][lane][8 f16], fv_pack_convh)
+//     stream global(L2) -> LDS by LDS-DMA through a ring of 4 stage slots, three stages ahead of their use,
+//     across tile boundaries (a block's tiles of one member form ONE linear stage sequence);
+//   * one barrier per stage (it proves the stage's DMA parts of all waves have landed and frees the slot of
+//     the stage before); the barrier of stage g+1 is taken one MFMA group early so that the operand prefetch
+//     never drains at a stage boundary;
+//   * a wave owns 2 row sixteenths x NFW column fragments: per step 4 A reads + 2 NFW B reads (ds_read_b128)
+//     feed 6 NFW MFMAs; operands are fetched one group (two fragments) ahead, order pinned by sched_barrier;
+//   * vmcnt bookkeeping is static: every tile issues the same loads in the same order (out-of-range offsets
+//     where there is nothing to load), so each stage waits with the exact count of younger loads.
+//
+// Tiles of one member are ordered (utterance, column tile, row tile): the two row tiles of a C = 128 layer share
+// the column tile's image, which is converted once.
+#pragma once
+#include "pairh_kernels.hpp"
+
+namespace fv {
+
+template <int I>
+struct IntC {
+    static constexpr int value = I;
+};
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(IntC<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    constexpr int n = N > 63 ? 63 : N;
+    __builtin_amdgcn_s_waitcnt((n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14));
+}
+
+template <int CG_, int NFW_, int KT_, int DIL_>
+struct ConvHGeom {
+    static constexpr int CG = CG_, NFW = NFW_, KT = KT_, DIL = DIL_;
+    static constexpr int C = 32 * CG;
+    static constexpr int WM = 2, WN = 4, NW = 8, NT = 512;
+    static constexpr int NTC = 16 * NFW * WN;            // output columns per tile
+    static constexpr int NSTEP = KT * CG;                // K steps of 32
+    static constexpr int NST = NSTEP / 2;                // stages of two steps
+    static constexpr int NP = NFW / 2;                   // MFMA groups (two fragments) per step
+    static constexpr int NUNIT = NSTEP * NP;
+    static constexpr int P = (KT - 1) * DIL / 2;
+    static constexpr int XROWS = (NTC + (KT - 1) * DIL + 3) / 4 * 4;
+    static constexpr int RB = 4 * C + 16;                // bytes per image row: h1[C] | h2[C] | pad
+    static constexpr int CB = C / 8;
+    static constexpr int XR = (XROWS * CB + NT - 1) / NT;   // (row, 8-channel block) conversion tasks per thread
+    static constexpr int STAGE_BYTES = 16384, RING = 4;
+    static constexpr int WTILE = NSTEP * 8192;           // packed bytes of one 64-row tile
+    static constexpr int NMT = C / 64;
+    static constexpr int RAWST = NST >= 4 ? NST - 4 : 0; // stage at which the next tile's raw window is requested
+    static constexpr int NRAW = XR * 8;
+    static_assert(NSTEP % 2 == 0 && NST >= 3 && NFW % 2 == 0, "stages of two steps, at least three");
+    static_assert(((KT - 1) * DIL + 16 * (NFW - 1)) * RB + 4 * C < 65536, "ds_read immediate range");
+};
+
+template <class G>
+struct ConvHRaw {
+    float v[G::XR][8];
+};
+
+// raw window rows [tA, tA + XROWS) of all C channels -> registers; rows outside [0, T) (or `live` false) read as zero
+template <class G>
+__device__ __forceinline__ void convh_load_raw(ConvHRaw<G>& r, const float* xb, int T, int tA, int tid, bool live) {
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)G::C * (unsigned)T * 4u);
+    const unsigned t4 = (unsigned)T * 4u;
+#pragma unroll
+    for (int q = 0; q < G::XR; ++q) {
+        const int idx = tid + q * G::NT;
+        const int cb = idx / G::XROWS, row = idx - cb * G::XROWS;
+        const int t = tA + row;
+        const bool ok = live && idx < G::XROWS * G::CB && t >= 0 && t < T;
+        const unsigned voff = ok ? (unsigned)(cb * 8 * T + t) * 4u : kOutOfRange;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.v[q][j] = buffer_load1s(rx, voff, (unsigned)j * t4);
+    }
+}
+
+template <class G>
+__device__ __forceinline__ void convh_convert(const ConvHRaw<G>& r, char* ximg, float slope, int tid) {
+#pragma unroll
+    for (int q = 0; q < G::XR; ++q) {
+        const int idx = tid + q * G::NT;
+        const int cb = idx / G::XROWS, row = idx - cb * G::XROWS;
+        f16x8 h1, h2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = act(r.v[q][j], slope);
+            const _Float16 a = (_Float16)v;
+            h1[j] = a;
+            h2[j] = (_Float16)((v - (float)a) * kSplitScale);
+        }
+        if (idx < G::XROWS * G::CB) {
+            *reinterpret_cast<f16x8*>(ximg + row * G::RB + cb * 16) = h1;
+            *reinterpret_cast<f16x8*>(ximg + row * G::RB + 2 * G::C + cb * 16) = h2;
+        }
+    }
+}
+
+// one stage of packed weights -> ring slot (2 DMA instructions per wave); byte_off: offset of the stage inside the
+// member's packed image, or kOutOfRange (nothing to load: the slot is written with zeros and never read)
+template <class G>
+__device__ __forceinline__ void convh_dma_stage(__amdgpu_buffer_rsrc_t rw, float* ring, int slot, unsigned byte_off,
+                                                int wave, int lane) {
+    float* dst = ring + slot * (G::STAGE_BYTES / 4) + wave * 512;
+    const unsigned o = byte_off + (unsigned)(wave * 2048 + lane * 16);
+    dma16(rw, dst, o);
+    dma16(rw, dst + 256, o + 1024u);
+}
+
+// items [item0, hi_item) of ONE member; item = (utterance * n_tiles + column tile) * NMT + row tile
+template <class G>
+__device__ __forceinline__ void convh_run_member(const PairParams& p, const PairMember& mb, int item0, int hi_item,
+                                                 float* smem, int wave, int lane_in, bool first) {
+    typedef __attribute__((address_space(3))) const f16x8 LdsH8;
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int tid = wave * 64 + lane;
+    float* const ring = smem + p.x_off;
+    char* const ximg = reinterpret_cast<char*>(smem + p.img_off);
+    float* const bl = smem + p.bias_off;
+    const int n = lane & 15, kb = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int col0 = wn * (16 * G::NFW) + n;
+    const char* const bptr = ximg + col0 * G::RB + kb * 16;                 // B: + (tap*DIL + 16 f) RB + half*2C + 64 cg
+    const float* const aptr = ring + (wm * 2) * 512 + lane * 4;             // A: + slot*4096 + (i*4 + h)*512 + half*256
+    const int row0 = 16 * (2 * wm) + 4 * kb;                                // + 16 h + i: row inside the 64-row tile
+
+    const size_t ustride = (size_t)G::C * (size_t)p.T;
+    const unsigned ubytes = (unsigned)G::C * (unsigned)p.T * 4u;
+    const unsigned t4 = (unsigned)p.T * 4u;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(mb.w1, (unsigned)(G::NMT * G::WTILE));
+    int item = item0;
+    int g0 = 0;                                                             // stage counter of the run (ring slot = g & 3)
+    auto decode = [&](int it, int& b, int& nt, int& mt) {
+        mt = it % G::NMT;
+        const int q = it / G::NMT;
+        b = q / mb.n_tiles;
+        nt = q - b * mb.n_tiles;
+    };
+    int b, ntile, mtile;
+    decode(item, b, ntile, mtile);
+    if (!first) pair_barrier();                         // everybody is done with the previous member's LDS
+    ConvHRaw<G> raw;
+    convh_load_raw<G>(raw, mb.x + b * ustride, p.T, ntile * G::NTC - G::P, tid, true);
+#pragma unroll
+    for (int st = 0; st < 3; ++st)
+        convh_dma_stage<G>(rw, ring, st, (unsigned)(mtile * G::WTILE + st * G::STAGE_BYTES), wave, lane);
+    if (tid < G::C) bl[tid] = mb.b1 ? mb.b1[tid] : 0.f;
+    pair_wait_vm0();
+    if (!(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid);
+    for (;;) {
+        const int t0 = ntile * G::NTC;
+        const int nitem = item + 1;
+        const bool more = nitem < hi_item;
+        int nb = b, nnt = ntile, nmt = mtile;
+        if (more) decode(nitem, nb, nnt, nmt);
+        const bool new_win = more && (nb != b || nnt != ntile);
+        f32x4 hi[2][G::NFW], lo[2][G::NFW];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int f = 0; f < G::NFW; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float res[2][G::NFW][4];
+        unsigned voff[G::NFW];
+        f16x8 abuf[2][2][2], bbuf[2][2][2];
+
+        // ---- stage entry: the stage's weights are in its ring slot for every wave; the slot of the stage
+        // before is free: request the stage three ahead into it (this tile's, or the next item's first stages)
+        auto entry = [&](auto GC) {
+            constexpr int GS = decltype(GC)::value;
+            if constexpr (GS >= 3) {
+                // younger loads than this stage's DMA: the DMAs of the two stages after it (+ the raw window
+                // if it was requested at one of the three entries in between)
+                constexpr bool raw_between = G::RAWST >= GS - 3 && G::RAWST <= GS - 1;
+                wait_vm<4 + (raw_between ? G::NRAW : 0)>();
+            }
+            pair_barrier();
+            constexpr int NS = GS + 3;
+            unsigned off;
+            if constexpr (NS < G::NST) off = (unsigned)(mtile * G::WTILE + NS * G::STAGE_BYTES);
+            else off = more ? (unsigned)(nmt * G::WTILE + (NS - G::NST) * G::STAGE_BYTES) : kOutOfRange;
+            convh_dma_stage<G>(rw, ring, (g0 + NS) & 3, off, wave, lane);
+            if constexpr (GS == G::RAWST)
+                convh_load_raw<G>(raw, mb.x + nb * ustride, p.T, nnt * G::NTC - G::P, tid, new_win && !(p.dbg & 1));
+        };
+        auto fetch_a = [&](auto SC, f16x8 (&dst)[2][2]) {
+            constexpr int S = decltype(SC)::value;
+            LdsCF* a = lds_opaque(aptr + ((g0 + S / 2) & 3) * (G::STAGE_BYTES / 4));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                dst[h][0] = *reinterpret_cast<LdsH8*>(a + ((S % 2) * 4 + h) * 512);
+                dst[h][1] = *reinterpret_cast<LdsH8*>(a + ((S % 2) * 4 + h) * 512 + 256);
+            }
+        };
+        LdsCF* const bb = lds_opaque(reinterpret_cast<const float*>(bptr));
+        auto fetch_b = [&](auto SC, auto PC, f16x8 (&dst)[2][2]) {
+            constexpr int S = decltype(SC)::value, PP = decltype(PC)::value;
+            constexpr int tap = S / G::CG, cg = S % G::CG;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                constexpr int base = tap * G::DIL * G::RB + 64 * cg;
+                dst[e][0] = *reinterpret_cast<LdsH8*>(bb + (base + (2 * PP) * 16 * G::RB) / 4 + e * (16 * G::RB / 4));
+                dst[e][1] = *reinterpret_cast<LdsH8*>(bb + (base + (2 * PP) * 16 * G::RB + 2 * G::C) / 4 + e * (16 * G::RB / 4));
+            }
+        };
+
+        entry(IntC<0>{});
+        fetch_a(IntC<0>{}, abuf[0]);
+        fetch_b(IntC<0>{}, IntC<0>{}, bbuf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, G::NUNIT>([&](auto UC) {
+            constexpr int U = decltype(UC)::value;
+            constexpr int S = U / G::NP, PP = U % G::NP;
+            constexpr int UN = U + 1, SN = UN / G::NP, PN = UN % G::NP;
+            if constexpr (UN < G::NUNIT) {
+                // the next group starts a new stage: take its barrier now, then prefetch from its slot
+                if constexpr (PN == 0 && SN % 2 == 0) entry(IntC<SN / 2>{});
+                if constexpr (PN == 0) fetch_a(IntC<SN>{}, abuf[SN & 1]);
+                fetch_b(IntC<SN>{}, IntC<PN>{}, bbuf[UN & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        hi[h][2 * PP + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[S & 1][h][0], bbuf[U & 1][e][0],
+                                                                                   hi[h][2 * PP + e], 0, 0, 0);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        lo[h][2 * PP + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[S & 1][h][0], bbuf[U & 1][e][1],
+                                                                                   lo[h][2 * PP + e], 0, 0, 0);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        lo[h][2 * PP + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[S & 1][h][1], bbuf[U & 1][e][0],
+                                                                                   lo[h][2 * PP + e], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // ---- epilogue: residual, image of the next window, stores -------------------------------------------
+        {
+            const __amdgpu_buffer_rsrc_t rr = make_rsrc(mb.res ? mb.res + b * ustride : mb.w1, mb.res ? ubytes : 0u);
+#pragma unroll
+            for (int f = 0; f < G::NFW; ++f) {
+                const int t = t0 + col0 + f * 16;
+                voff[f] = t < p.T ? (unsigned)((64 * mtile + row0) * p.T + t) * 4u : kOutOfRange;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) res[h][f][i] = buffer_load1s(rr, voff[f], (unsigned)(16 * h + i) * t4);
+            }
+        }
+        pair_barrier();                                  // every wave is done with the image (and with the last ring reads)
+        pair_wait_vm0();                                 // raw window, residual; the next stages' DMAs
+        if (new_win && !(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid);
+        const bool fin = mb.add1 != nullptr;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bv[i] = bl[64 * mtile + row0 + 16 * h + i];
+#pragma unroll
+            for (int f = 0; f < G::NFW; ++f)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hi[h][f][i] = (fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[i]) + res[h][f][i];
+        }
+        if (fin) {
+            const __amdgpu_buffer_rsrc_t r1 = make_rsrc(mb.add1 + b * ustride, ubytes);
+            const __amdgpu_buffer_rsrc_t r2 = make_rsrc(mb.add2 ? mb.add2 + b * ustride : mb.add1, mb.add2 ? ubytes : 0u);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int f = 0; f < G::NFW; ++f)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        lo[h][f][i] = buffer_load1s(r1, voff[f], (unsigned)(16 * h + i) * t4);
+                        res[h][f][i] = buffer_load1s(r2, voff[f], (unsigned)(16 * h + i) * t4);
+                    }
+            pair_wait_vm0();
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int f = 0; f < G::NFW; ++f)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hi[h][f][i] = (hi[h][f][i] + lo[h][f][i]) + res[h][f][i];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int f = 0; f < G::NFW; ++f) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = hi[h][f][i];
+                const int t = t0 + col0 + f * 16;
+                pair_store(p, mb.y, mb.y_act, G::C, b, 64 * mtile + row0 + 16 * h, t, t < p.T && !(p.dbg & 8), v, fin);
+            }
+        if (!more) break;
+        g0 += G::NST;
+        item = nitem;
+        b = nb;
+        ntile = nnt;
+        mtile = nmt;
+    }
+    // the DMAs requested for a next item that does not exist wrote zeros; nothing is in flight past this point
+    pair_wait_vm0();
+}
+
+template <int CG, int NFW, int DIL>
+__device__ __forceinline__ void convh_run_any(const PairParams& p, int m, int item0, int hi, float* smem, int wave,
+                                              int lane, bool first) {
+    const PairMember& mb = p.m[m];
+    if (mb.k == 11) convh_run_member<ConvHGeom<CG, NFW, 11, DIL>>(p, mb, item0, hi, smem, wave, lane, first);
+    else if (mb.k == 7) convh_run_member<ConvHGeom<CG, NFW, 7, DIL>>(p, mb, item0, hi, smem, wave, lane, first);
+    else convh_run_member<ConvHGeom<CG, NFW, 3, DIL>>(p, mb, item0, hi, smem, wave, lane, first);
+}
+
+// 8 waves per block, one block per CU (150-160 KB of LDS): 2 waves per SIMD, 256 VGPRs
+template <int CG, int NFW, int DIL>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void convh_kernel(PairParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    long long total = 0;
+    for (int m = 0; m < p.n_members; ++m) total += (long long)p.m[m].n_items * p.m[m].cost;
+    long long base = 0;
+    bool first = true;
+    for (int m = 0; m < p.n_members; ++m) {
+        const int n = p.m[m].n_items;
+        const int lo = pair_share(blockIdx.x, total, base, p.m[m].cost, n, p.nblk);
+        const int hi = pair_share(blockIdx.x + 1, total, base, p.m[m].cost, n, p.nblk);
+        base += (long long)n * p.m[m].cost;
+        if (lo >= hi) continue;
+        convh_run_any<CG, NFW, DIL>(p, m, lo, hi, smem, wave, lane, first);
+        first = false;
+    }
+}
+
+}  // namespace fv

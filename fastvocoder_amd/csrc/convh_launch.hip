@@ -1,0 +1,82 @@
+// Host side of the split-f16 wide-channel conv kernels (convh_kernels.hpp): validation, tile geometry, LDS layout,
+// persistent grid, launch.  Device code: convh_inst_c64.hip / convh_inst_c128.hip.
+#include <stdlib.h>
+
+#include "fv_internal.h"
+
+namespace fv {
+
+extern template int launch_convh_geom<2, 4>(const PairParams&, int, size_t, hipStream_t);
+extern template int launch_convh_geom<4, 2>(const PairParams&, int, size_t, hipStream_t);
+
+// run-time mirror of ConvHGeom<>
+ConvHShape convh_shape(int C, int k, int dil) {
+    ConvHShape g = {};
+    g.CG = C / 32;
+    g.NFW = C == 64 ? 4 : 2;
+    g.NTC = 16 * g.NFW * 4;
+    g.NSTEP = k * g.CG;
+    g.NST = g.NSTEP / 2;
+    g.XROWS = (g.NTC + (k - 1) * dil + 3) / 4 * 4;
+    g.RB = 4 * C + 16;
+    g.NMT = C / 64;
+    return g;
+}
+
+int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
+    if (p.B <= 0 || p.T <= 0) return 0;
+    if (C != 64 && C != 128) return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: C = %d (64 or 128)", C);
+    if (dil != 1 && dil != 3 && dil != 5) return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: dilation %d (1, 3 or 5)", dil);
+    if (p.n_members < 1 || p.n_members > 3) return fail(FV_ERR_INVALID_ARG, "split-f16 conv: %d members", p.n_members);
+    if ((double)C * p.T * 4.0 >= 1073741824.0)
+        return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: one utterance's tensor (%d x %d floats) exceeds the 1 GiB "
+                    "buffer-descriptor range; split the utterance", C, p.T);
+    if (p.slope < 0.f || p.slope > 1.f || p.act_slope < 0.f || p.act_slope > 1.f)
+        return fail(FV_ERR_INVALID_ARG, "split-f16 conv: activation slope outside [0, 1]");
+    int img_bytes = 0;
+    double flops = 0, bytes = 0;
+    long long items = 0;
+    for (int i = 0; i < p.n_members; ++i) {
+        PairMember& mb = p.m[i];
+        if (mb.k != 11 && mb.k != 7 && mb.k != 3) return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: %d taps (3, 7 or 11)", mb.k);
+        if (!mb.x || !mb.w1 || !mb.y) return fail(FV_ERR_INVALID_ARG, "split-f16 conv: null tensor (member %d)", i);
+        if (mb.add2 && !mb.add1) return fail(FV_ERR_INVALID_ARG, "split-f16 conv: add2 without add1 (member %d)", i);
+        if (reinterpret_cast<uintptr_t>(mb.w1) & 15)
+            return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: packed weights must be 16-byte aligned");
+        const ConvHShape g = convh_shape(C, mb.k, dil);
+        mb.n_tiles = (p.T + g.NTC - 1) / g.NTC;
+        mb.n_items = mb.n_tiles * p.B * g.NMT;
+        // a tile costs its stages (LDS / matrix time) plus loads, conversion, epilogue
+        mb.cost = g.NST + (getenv("FV_CONVH_SKEL") ? atoi(getenv("FV_CONVH_SKEL")) : 2);
+        if (g.XROWS * g.RB > img_bytes) img_bytes = g.XROWS * g.RB;
+        items += mb.n_items;
+        flops += 2.0 * p.B * (double)C * C * mb.k * p.T;
+        bytes += 4.0 * ((double)C * C * mb.k + (double)p.B * C * p.T *
+                        (2 + (mb.res ? 1 : 0) + (mb.add1 ? 1 : 0) + (mb.add2 ? 1 : 0) + (mb.y_act ? 1 : 0)));
+    }
+    size_t floats = 0;
+    p.x_off = 0;                       // ring of 4 weight stages
+    floats += 4 * 16384 / 4;
+    p.img_off = (int)floats;
+    floats += (size_t)img_bytes / 4;
+    p.bias_off = (int)floats;
+    floats += (size_t)C;
+    const size_t lds = floats * 4;
+    if (lds > 160 * 1024) return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: %zu bytes of LDS", lds);
+    int cus = 256, dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+        cus = v;
+    const char* force = getenv("FV_CONVH_BLOCKS");
+    long long nblk = force && atoi(force) > 0 ? atoi(force) : cus;     // one 8-wave block per CU
+    if (nblk > items) nblk = items;
+    p.nblk = (int)nblk;
+    p.dbg = getenv("FV_PAIR_DBG") ? atoi(getenv("FV_PAIR_DBG")) : 0;
+    p.trace = nullptr;
+    profile_begin(s);
+    const int rc = C == 64 ? launch_convh_geom<2, 4>(p, dil, lds, s) : launch_convh_geom<4, 2>(p, dil, lds, s);
+    profile_end(s, C == 64 ? FV_KERNEL_CONVH64 : FV_KERNEL_CONVH128, flops, bytes);
+    return rc;
+}
+
+}  // namespace fv

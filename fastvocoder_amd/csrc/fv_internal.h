@@ -136,6 +136,8 @@ struct PairMember {
     const float* b2;
     float* y;            // [B, C, T] raw output (sum mode: member 0's is THE output)
     float* y_act;        // optional activated twin lrelu(y, act_slope), or null
+    const float* res;    // conv launches of the split-f16 wide-channel kernels (convh_kernels.hpp): residual, or null
+    int n_items;         // ... (utterance, column tile, row tile) items of the member
     const float* add1;   // split-f16 kernels, last launch of an MRF stage: y = post(((x' + add1) + add2) / out_div)
     const float* add2;   //   (the other two ResBlocks' outputs, hifigan.py:99-103), or null
     int k;               // taps: 11, 7 or 3
@@ -183,6 +185,17 @@ struct PairHShape {
     int NOUT;
 };
 PairHShape pairh_shape(int C, int k, int dil);
+// Conv1d with split-f16 operands, C = 64 / 128 (convh_kernels.hpp): members use x, w1 (fv_pack_convh_weight image),
+// b1 (bias), res, add1 / add2, y, y_act, k; 'same' zero padding
+struct ConvHShape {
+    int CG, NFW, NTC;    // 32-channel groups, fragments per wave, output columns per tile
+    int NSTEP, NST;      // K steps of 32, stages of two steps
+    int XROWS, RB, NMT;  // image rows / bytes per row, 64-row tiles
+};
+ConvHShape convh_shape(int C, int k, int dil);
+int launch_convh(PairParams p, int C, int dil, hipStream_t stream);
+template <int CG, int NFW>
+int launch_convh_geom(const PairParams& p, int dil, size_t lds, hipStream_t s);
 // n (1..3) members, plain (sum = 0: one raw output each) or sum mode (one output: mean of the members)
 int launch_pairs(PairParams p, int C, int dil, hipStream_t stream);
 template <int MH, int NF, int NG>

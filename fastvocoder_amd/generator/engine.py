@@ -170,16 +170,20 @@ class PlanBuilder:
                     b1=self._bias(conv1), b2=self._bias(conv2), k=conv1.kernel_size[0])
 
     def pair(self, conv1, conv2, src, dst, slope, prec=_native.PAIR_F32, add1=SLOT_NONE, add2=SLOT_NONE,
-             out_div=1.0, post=POST_NONE):
+             out_div=1.0, post=POST_NONE, mid=SLOT_NONE):
         """dst = src + conv2(lrelu(conv1(lrelu(src)))) as ONE fused op (fv_plan_add_resblock_pair_ex); it reads
         ``src`` raw and applies both activations on chip.  Ops recorded inside one group share a launch.
         With ``add1`` / ``add2`` (split-f16 arithmetic): dst = post(((pair + add1) + add2) / out_div), the MRF
         merge of hifigan.py:99-103 in the reference's association."""
         m = self._pair_member(conv1, conv2, prec)
+        wide = conv1.in_channels >= 64      # two conv launches through the scratch slot ``mid`` (csrc/convh_kernels.hpp)
+        if wide and mid == SLOT_NONE:
+            raise _native.NativeError("resblock pair: a scratch slot (mid) is needed at 64 channels and above")
         self.ops.append(dict(kind="pair", lane=self.lane, group=self.group, x=src, y=dst, res=SLOT_NONE,
                              acc=add1, acc2=add2, pre_slope=1.0, slope=float(slope),
                              channels=conv1.in_channels, dil=conv1.dilation[0], prec=prec,
-                             out_div=float(out_div), post=post, **m))
+                             out_div=float(out_div), post=post, mid=mid if wide else SLOT_NONE,
+                             tmps=[mid] if wide else [], **m))
 
     def mrf_sum(self, pairs, srcs, dst, slope, out_div, post=POST_NONE):
         """dst = post(sum_j pair_j(srcs[j]) / out_div): the last pairs of the three ResBlocks of an MRF stage
@@ -352,7 +356,7 @@ class PlanBuilder:
                                             op["channels"], op["k"], op["dil"], op["slope"],
                                             y_act=op["y_act"], act_slope=op["act_slope"], prec=op["prec"],
                                             add1=op["acc"], add2=op["acc2"], out_div=op["out_div"],
-                                            post=op["post"])
+                                            post=op["post"], mid=op["mid"])
             elif op["kind"] == "mrfsum":
                 ms = op["members"]
                 self.plan.add_mrf_sum([op["x"], op["xb"], op["xc"]], op["y"], [m["w1"] for m in ms],

@@ -76,7 +76,8 @@ class _HiFiGANBase(NativeModule):
         dils = [[c.dilation[0] for c in b.convs1] for b in blocks]
         if any(d != dils[0] for d in dils):
             return False
-        return all(PlanBuilder.pair_fusable(c1, c2) for b in blocks for c1, c2 in zip(b.convs1, b.convs2))
+        prec = PlanBuilder.pair_precision(blocks[0].channels)
+        return all(PlanBuilder.pair_fusable(c1, c2, prec) for b in blocks for c1, c2 in zip(b.convs1, b.convs2))
 
     def _fused_flags(self, T):
         """Per stage: run it fused for a mel of T frames?  The pair kernels need 16-byte aligned rows
@@ -108,7 +109,7 @@ class _HiFiGANBase(NativeModule):
             for j in range(nk):
                 ping, pong = scratch[j][1], scratch[j][2]
                 d = ping if curs[j] != ping else pong
-                pb.pair(blocks[j].convs1[pi], blocks[j].convs2[pi], curs[j], d, LRELU_SLOPE, prec)
+                pb.pair(blocks[j].convs1[pi], blocks[j].convs2[pi], curs[j], d, LRELU_SLOPE, prec, mid=scratch[j][0])
                 nxt.append(d)
             pb.end_group()
             curs = nxt
@@ -117,10 +118,11 @@ class _HiFiGANBase(NativeModule):
             # runs after them and forms ((r_0 + r_1) + r_2) / nk in its epilogue: the reference's order, bit for bit
             pb.begin_group()
             for j in range(1, nk):
-                pb.pair(blocks[j].convs1[-1], blocks[j].convs2[-1], curs[j], parts[j - 1], LRELU_SLOPE, prec)
+                pb.pair(blocks[j].convs1[-1], blocks[j].convs2[-1], curs[j], parts[j - 1], LRELU_SLOPE, prec,
+                        mid=scratch[j][0])
             pb.end_group()
             pb.pair(blocks[0].convs1[-1], blocks[0].convs2[-1], curs[0], x, LRELU_SLOPE, prec,
-                    add1=parts[0], add2=parts[1], out_div=float(nk))
+                    add1=parts[0], add2=parts[1], out_div=float(nk), mid=scratch[0][0])
             return
         if ch == 16:
             pb.mrf_sum([(b.convs1[-1], b.convs2[-1]) for b in blocks], curs, x, LRELU_SLOPE, float(nk))

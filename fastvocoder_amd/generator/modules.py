@@ -105,15 +105,16 @@ class ResBlock1(_Block):
     def pairs_fusable(self):
         """Every (dilated conv, conv) pair has a shape the fused pair kernels are built for."""
         from .engine import PlanBuilder
-        return all(PlanBuilder.pair_fusable(c1, c2) for c1, c2 in zip(self.convs1, self.convs2))
+        prec = PlanBuilder.pair_precision(self.channels)
+        return all(PlanBuilder.pair_fusable(c1, c2, prec) for c1, c2 in zip(self.convs1, self.convs2))
 
     def emit_fused(self, pb, src, dst, scratch):
         """src -> dst with every pair as ONE fused launch (csrc/pair_kernels.hpp); needs T % 4 == 0."""
-        _, ping, pong = scratch
+        mid, ping, pong = scratch
         cur = src
         for i, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
             nxt = dst if i == len(self.convs1) - 1 else (ping if cur != ping else pong)
-            pb.pair(c1, c2, cur, nxt, LRELU_SLOPE, pb.pair_precision(self.channels))
+            pb.pair(c1, c2, cur, nxt, LRELU_SLOPE, pb.pair_precision(self.channels), mid=mid)
             cur = nxt
 
     def forward(self, x):

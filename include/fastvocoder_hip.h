@@ -159,6 +159,9 @@ int fv_resblock1_fused(int n, const float* const* x, const float* const* w1, con
  *       section 3.7, tests/test_split_precision.py); 5.3x fewer matrix-core cycles, which turns the C = 16
  *       layers from matrix-bound into HBM / LDS-bound.  Needs |v| < 65504 for activations and weights.
  *       Weights: fv_pack_pair_weight_ex(prec) images ([K step][row half][split half][lane][8 f16]).
+ *       C = 16 / 32: one fused launch (the intermediate stays in LDS).  C = 64 / 128: the weights do not fit on
+ *       chip; the pair runs as two launches of a split-f16 conv kernel that streams them through LDS
+ *       (csrc/convh_kernels.hpp) and needs mid[j], a [B,C,T] scratch tensor per member (NULL otherwise).
  *   add1 / add2 (arrays or entries may be NULL; FV_PAIR_SPLIT_F16 only): member j stores
  *       y_j = post( ((x'_j + add1_j) + add2_j) / out_div )  -- with x'_j the first ResBlock's result and
  *       add1 / add2 the second and third this is xs = r0; xs += r1; xs += r2; x = xs / 3 in the
@@ -170,8 +173,9 @@ int64_t fv_packed_pair_floats_ex(int C, int k, int prec);
 int fv_pack_pair_weight_ex(const float* w, float* packed, int C, int k, int prec, void* stream);
 int fv_resblock1_fused_ex(int n, const float* const* x, const float* const* w1, const float* const* w2,
                           const float* const* b1, const float* const* b2, float* const* y, float* const* y_act,
-                          const float* const* add1, const float* const* add2, const int* k, int B, int C, int T,
-                          int dil, float slope, float out_div, int post, float act_slope, int prec, void* stream);
+                          float* const* mid, const float* const* add1, const float* const* add2, const int* k, int B,
+                          int C, int T, int dil, float slope, float out_div, int post, float act_slope, int prec,
+                          void* stream);
 
 /*
  * End of an MRF stage (hifigan.py:97-103): the LAST pairs of the three ResBlocks and the mean, one launch:
@@ -317,8 +321,9 @@ int fv_plan_add_conv1d_sum3(fv_plan_t* plan, const int* x_slots, const int* res_
 int fv_plan_add_resblock_pair(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed1,
                               const float* packed2, const float* bias1, const float* bias2, int C, int k, int dil,
                               float slope, float act_slope);
-/* fv_resblock1_fused_ex as a plan op (add1_slot / add2_slot: FV_SLOT_NONE or [B,C,T] slots) */
-int fv_plan_add_resblock_pair_ex(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, int add1_slot,
+/* fv_resblock1_fused_ex as a plan op (add1_slot / add2_slot: FV_SLOT_NONE or [B,C,T] slots; mid_slot: a scratch
+ * slot, needed at C >= 64 with FV_PAIR_SPLIT_F16, FV_SLOT_NONE otherwise) */
+int fv_plan_add_resblock_pair_ex(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, int mid_slot, int add1_slot,
                                  int add2_slot, const float* packed1, const float* packed2, const float* bias1,
                                  const float* bias2, int C, int k, int dil, float slope, float out_div, int post,
                                  float act_slope, int prec);
@@ -399,6 +404,8 @@ int fv_plan_num_ops(fv_plan_t* plan);
 #define FV_KERNEL_PAIR32 4      /* fused ResBlock pairs, C = 32 */
 #define FV_KERNEL_PAIRH16 5     /* fused ResBlock pairs, C = 16, split-f16 operands (16x16x32 f16 MFMA) */
 #define FV_KERNEL_PAIRH32 6     /* ... C = 32 */
+#define FV_KERNEL_CONVH64 7     /* conv1d with split-f16 operands, C = 64 (ResBlock pairs of the wide stages) */
+#define FV_KERNEL_CONVH128 8    /* ... C = 128 */
 int fv_profile_enable(int on);
 /* what the event bracket itself adds to a measured launch: the average elapsed time between the two events
  * of n EMPTY brackets recorded back to back on `stream` (subtract it per launch) */

@@ -197,6 +197,49 @@ def test_split_f16_rejects_what_it_is_not_built_for():
         _native.resblock1_fused([x16], [w16], [w16], [None], [None], [3], 1, 0.1, add1=[x16.clone()])
 
 
+WIDE_CASES = [
+    # B, C, T, dil, taps, bias -- ResBlock pairs of the 64- / 128-channel stages: two launches of the split-f16 conv
+    # kernel with streamed weights (csrc/convh_kernels.hpp)
+    (1, 64, 300, 1, (3,), True),             # two 256-column tiles, ragged
+    (2, 64, 700, 5, (11, 7, 3), True),
+    (1, 64, 1030, 3, (7, 11), False),
+    (1, 64, 7, 5, (11,), True),              # shorter than every halo, T % 4 != 0
+    (1, 128, 200, 3, (7,), True),            # two row tiles share a column tile's image
+    (1, 128, 520, 5, (11, 7, 3), True),
+    (2, 128, 130, 1, (3, 11), True),
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_wide_resblock_pair_split_f16_vs_oracle(case):
+    B, C, T, dil, ks, bias = case
+    rng = np.random.RandomState(abs(hash(case)) % (2 ** 31))
+    ms = [_member(rng, B, C, T, k, bias) for k in ks]
+    refs = [_pair_ref(x, w1, b1, w2, b2, dil, 0.1) for x, w1, b1, w2, b2 in ms]
+    xs = [_t(m[0]) for m in ms]
+    b1s, b2s = [_t(m[2]) for m in ms], [_t(m[4]) for m in ms]
+    h1, h2 = [_native.pack_pair(_t(m[1]), SPLIT) for m in ms], [_native.pack_pair(_t(m[3]), SPLIT) for m in ms]
+    ys = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, prec=SPLIT)
+    for y, ref in zip(ys, refs):
+        assert _rel(y, ref) <= 4e-6
+    acts = [torch.empty_like(x) for x in xs]
+    ys2 = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, act_slope=0.2, outs_act=acts, prec=SPLIT)
+    for y, a, ref in zip(ys2, acts, refs):
+        assert _rel(y, ref) <= 4e-6 and _rel(a, oo.lrelu(ref, 0.2)) <= 4e-6
+    if len(ks) == 3:                          # the stage end: members 1, 2 first, member 0 carries the merge
+        r12 = _native.resblock1_fused(xs[1:], h1[1:], h2[1:], b1s[1:], b2s[1:], list(ks[1:]), dil, 0.1, prec=SPLIT)
+        y, = _native.resblock1_fused([xs[0]], [h1[0]], [h2[0]], [b1s[0]], [b2s[0]], [ks[0]], dil, 0.1, prec=SPLIT,
+                                     add1=[r12[0]], add2=[r12[1]], out_div=3.0, act_slope=0.1)
+        ref = oo.lrelu(((refs[0] + refs[1]) + refs[2]) / np.float32(3.0), 0.1)
+        assert _rel(y, ref) <= 4e-6
+        # bit-identity of an utterance alone and inside the batch
+        if B > 1:
+            one = _native.resblock1_fused([x[1:2].contiguous() for x in xs], h1, h2, b1s, b2s, list(ks), dil, 0.1,
+                                          prec=SPLIT)
+            for yf, yo in zip(ys, one):
+                assert torch.equal(yf[1:2], yo)
+
+
 def test_pair_results_do_not_depend_on_the_batch():
     """Bit-identity: an utterance gives the same bits alone and inside a batch (what lets a batch be
     sharded over GPUs), for the plain and the sum kernels, on both channel counts."""
