@@ -241,7 +241,7 @@ __global__ void pack_convh_kernel(const float* __restrict__ w, _Float16* __restr
 // ---------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------
-enum OpType { OP_CONV = 0, OP_CONVT = 1, OP_PQMF = 2, OP_UPCONV = 3, OP_PAIR = 4, OP_MRFSUM = 5 };
+enum OpType { OP_CONV = 0, OP_CONVT = 1, OP_PQMF = 2, OP_UPCONV = 3, OP_PAIR = 4, OP_MRFSUM = 5, OP_CONVH = 6 };
 
 struct Op {
     int type;
@@ -317,7 +317,7 @@ struct fv_plan {
 namespace fv {
 
 static int64_t conv_out_len(const Op& o, int64_t Tin) {
-    if (o.type == OP_PAIR || o.type == OP_MRFSUM) return Tin;
+    if (o.type == OP_PAIR || o.type == OP_MRFSUM || o.type == OP_CONVH) return Tin;
     if (o.type == OP_CONV)
         return (o.pad_mode & FV_PAD_CAUSAL) ? Tin : Tin + 2LL * o.pad - (int64_t)o.dil * (o.k - 1);
     if (o.type == OP_CONVT) return (Tin - 1) * o.stride - 2LL * o.pad + o.k + o.out_pad;
@@ -1162,6 +1162,89 @@ int fv_plan_add_resblock_pair_ex(fv_plan_t* plan, int x_slot, int y_slot, int y_
     return 0;
 }
 
+static int check_convh_args(int n, int C, const int* k, int dil) {
+    if (n < 1 || n > 3) return fail(FV_ERR_INVALID_ARG, "conv1d_split_f16: %d members (1..3)", n);
+    if (C != 64 && C != 128) return fail(FV_ERR_UNSUPPORTED, "conv1d_split_f16: C = %d (64 or 128)", C);
+    if (dil != 1 && dil != 3 && dil != 5) return fail(FV_ERR_UNSUPPORTED, "conv1d_split_f16: dilation %d (1, 3 or 5)", dil);
+    for (int j = 0; j < n; ++j)
+        if (k[j] != 3 && k[j] != 7 && k[j] != 11) return fail(FV_ERR_UNSUPPORTED, "conv1d_split_f16: %d taps (3, 7 or 11)", k[j]);
+    return 0;
+}
+
+int fv_conv1d_split_f16(int n, const float* const* x, const float* const* packed, const float* const* bias,
+                        const float* const* res, const float* const* add1, const float* const* add2, float* const* y,
+                        float* const* y_act, const int* k, int B, int C, int T, int dil, float pre_slope, float out_div,
+                        int post, float act_slope, void* stream) {
+    if (!x || !packed || !y || !k) return fail(FV_ERR_INVALID_ARG, "conv1d_split_f16: null argument");
+    if (int rc = check_convh_args(n, C, k, dil)) return rc;
+    PairParams pp = {};
+    pp.n_members = n;
+    pp.B = B;
+    pp.T = T;
+    pp.slope = pre_slope;
+    pp.act_slope = act_slope;
+    pp.out_div = out_div;
+    pp.post = post;
+    pp.prec = FV_PAIR_SPLIT_F16;
+    for (int j = 0; j < n; ++j) {
+        PairMember& mb = pp.m[j];
+        mb.x = x[j];
+        mb.w1 = packed[j];
+        mb.b1 = bias ? bias[j] : nullptr;
+        mb.res = res ? res[j] : nullptr;
+        mb.add1 = add1 ? add1[j] : nullptr;
+        mb.add2 = add2 ? add2[j] : nullptr;
+        mb.y = y[j];
+        mb.y_act = y_act ? y_act[j] : nullptr;
+        mb.k = k[j];
+        if (!mb.x || !mb.y || mb.x == mb.y || mb.y == mb.res || mb.y == mb.add1 || mb.y == mb.add2 ||
+            (mb.y_act && (mb.y_act == mb.y || mb.y_act == mb.x || mb.y_act == mb.res)))
+            return fail(FV_ERR_INVALID_ARG, "conv1d_split_f16: member %d: null tensor or an output aliases an input", j);
+    }
+    return launch_convh(pp, C, dil, (hipStream_t)stream);
+}
+
+int fv_plan_add_conv1d_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, int res_slot, int add1_slot,
+                                 int add2_slot, const float* packed, const float* bias, int C, int k, int dil,
+                                 float pre_slope, float out_div, int post, float act_slope) {
+    if (!plan || !packed) return fail(FV_ERR_INVALID_ARG, "plan_add_conv1d_split_f16: null");
+    if (int rc = check_convh_args(1, C, &k, dil)) return rc;
+    if (add2_slot != FV_SLOT_NONE && add1_slot == FV_SLOT_NONE) return fail(FV_ERR_INVALID_ARG, "plan_add_conv1d_split_f16: add2 without add1");
+    if (int rc = check_slot(x_slot, false)) return rc;
+    if (int rc = check_slot(y_slot, false)) return rc;
+    if (int rc = check_slot(y_act_slot, true)) return rc;
+    if (int rc = check_slot(res_slot, true)) return rc;
+    if (int rc = check_slot(add1_slot, true)) return rc;
+    if (int rc = check_slot(add2_slot, true)) return rc;
+    if (y_slot == FV_SLOT_IN || y_act_slot == FV_SLOT_IN) return fail(FV_ERR_INVALID_ARG, "plan: the input slot is read-only");
+    if (y_slot == res_slot || y_slot == add1_slot || y_slot == add2_slot)
+        return fail(FV_ERR_INVALID_ARG, "plan_add_conv1d_split_f16: the output aliases an addend");
+    Op o = {};
+    o.type = OP_CONVH;
+    o.x = x_slot;
+    o.y = y_slot;
+    o.y2 = y_act_slot;
+    o.res = res_slot;
+    o.acc = add1_slot;
+    o.acc2 = add2_slot;
+    o.group = plan->cur_group;
+    o.lane = plan->cur_lane;
+    o.Cin = o.Cout = C;
+    o.k = k;
+    o.dil = dil;
+    o.pre_slope = pre_slope;
+    o.act_slope = act_slope;
+    o.out_div = out_div;
+    o.post = post;
+    o.prec = FV_PAIR_SPLIT_F16;
+    o.pw1[0] = packed;
+    o.pb1[0] = bias;
+    o.pk[0] = k;
+    plan->compiled = false;
+    plan->ops.push_back(o);
+    return 0;
+}
+
 int fv_plan_add_mrf_sum(fv_plan_t* plan, const int* x_slots, int y_slot, int y_act_slot,
                         const float* const* packed1, const float* const* packed2, const float* const* bias1,
                         const float* const* bias2, int C, const int* k, int dil, float slope, float out_div,
@@ -1210,7 +1293,7 @@ int fv_plan_set_output_offset(fv_plan_t* plan, int aux_slot, int y2_slot) {
         return fail(FV_ERR_INVALID_ARG, "plan_set_output_offset: slot %d is not an auxiliary input", aux_slot);
     if (int rc = check_slot(y2_slot, true)) return rc;
     Op& o = plan->ops.back();
-    if (o.type == OP_PAIR || o.type == OP_MRFSUM || o.sum3 || o.group != 0)
+    if (o.type == OP_PAIR || o.type == OP_MRFSUM || o.type == OP_CONVH || o.sum3 || o.group != 0)
         return fail(FV_ERR_UNSUPPORTED, "plan_set_output_offset: only plain conv / transposed conv / pqmf ops carry an offset");
     if (y2_slot != FV_SLOT_NONE) {
         if (o.y2 != FV_SLOT_NONE) return fail(FV_ERR_INVALID_ARG, "plan_set_output_offset: the op already has a second output");
@@ -1314,6 +1397,52 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
     sh[FV_SLOT_IN] = {plan->in_channels, T, true};
     for (size_t n = 0; n < plan->ops.size(); ++n) {
         const Op& o = plan->ops[n];
+        // ---- split-f16 convs of the wide stages: the members of a group in one launch ----
+        if (o.type == OP_CONVH) {
+            size_t m = n + 1;
+            if (o.group != 0)
+                while (m < plan->ops.size() && m - n < 3 && plan->ops[m].type == OP_CONVH && plan->ops[m].group == o.group &&
+                       plan->ops[m].lane == o.lane && plan->ops[m].Cin == o.Cin && plan->ops[m].dil == o.dil &&
+                       plan->ops[m].pre_slope == o.pre_slope && plan->ops[m].act_slope == o.act_slope &&
+                       plan->ops[m].out_div == o.out_div && plan->ops[m].post == o.post)
+                    ++m;
+            hipStream_t s = lanes[o.lane];
+            if (multi)
+                for (size_t q = n; q < m; ++q)
+                    for (int d = 0; d < plan->ops[q].ndeps; ++d)
+                        FV_HIP(hipStreamWaitEvent(s, plan->op_event[plan->ops[q].deps[d]], 0));
+            PairParams pp = {};
+            pp.B = B;
+            pp.T = (int)sh[o.x].T;
+            pp.slope = o.pre_slope;
+            pp.act_slope = o.act_slope;
+            pp.out_div = o.out_div;
+            pp.post = o.post;
+            pp.prec = FV_PAIR_SPLIT_F16;
+            pp.n_members = (int)(m - n);
+            for (size_t q = n; q < m; ++q) {
+                const Op& qo = plan->ops[q];
+                PairMember& mb = pp.m[q - n];
+                mb.x = base[qo.x];
+                mb.w1 = qo.pw1[0];
+                mb.b1 = qo.pb1[0];
+                mb.k = qo.pk[0];
+                mb.y = base[qo.y];
+                mb.y_act = qo.y2 == FV_SLOT_NONE ? nullptr : base[qo.y2];
+                mb.res = qo.res == FV_SLOT_NONE ? nullptr : base[qo.res];
+                mb.add1 = qo.acc == FV_SLOT_NONE ? nullptr : base[qo.acc];
+                mb.add2 = qo.acc2 == FV_SLOT_NONE ? nullptr : base[qo.acc2];
+            }
+            if (int rc = launch_convh(pp, o.Cin, o.dil, s)) return rc;
+            for (size_t q = n; q < m; ++q) {
+                const Op& qo = plan->ops[q];
+                if (multi && qo.signal) FV_HIP(hipEventRecord(plan->op_event[q], s));
+                sh[qo.y] = {qo.Cout, sh[qo.x].T, true};
+                if (qo.y2 != FV_SLOT_NONE) sh[qo.y2] = sh[qo.y];
+            }
+            n = m - 1;
+            continue;
+        }
         // ---- fused ResBlock pairs: the members of a group (the three ResBlocks of an MRF stage) in one launch ----
         if (o.type == OP_PAIR || o.type == OP_MRFSUM) {
             size_t m = n + 1;

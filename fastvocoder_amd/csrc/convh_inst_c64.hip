@@ -2,4 +2,5 @@
 #include "convh_inst.hpp"
 namespace fv {
 template int launch_convh_geom<2, 4>(const PairParams&, int, size_t, hipStream_t);
+template int launch_convh_geom<2, 2>(const PairParams&, int, size_t, hipStream_t);   // 128-column tiles (A/B: FV_CONVH_NFW=2)
 }

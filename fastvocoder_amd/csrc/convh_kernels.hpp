@@ -59,8 +59,9 @@ struct ConvHGeom {
     static constexpr int NUNIT = NSTEP * NP;
     static constexpr int P = (KT - 1) * DIL / 2;
     static constexpr int XROWS = (NTC + (KT - 1) * DIL + 3) / 4 * 4;
-    static constexpr int RB = 4 * C + 16;                // bytes per image row: h1[C] | h2[C] | pad
     static constexpr int CB = C / 8;
+    static constexpr int XRP = (XROWS + 15) / 16 * 16;   // image: [split half][8-channel block][XRP rows][8 halves]
+    static constexpr int XHALF = CB * XRP * 16;          // (layout and why: PairHGeom)
     static constexpr int XR = (XROWS * CB + NT - 1) / NT;   // (row, 8-channel block) conversion tasks per thread
     static constexpr int STAGE_BYTES = 16384, RING = 4;
     static constexpr int WTILE = NSTEP * 8192;           // packed bytes of one 64-row tile
@@ -68,7 +69,7 @@ struct ConvHGeom {
     static constexpr int RAWST = NST >= 4 ? NST - 4 : 0; // stage at which the next tile's raw window is requested
     static constexpr int NRAW = XR * 8;
     static_assert(NSTEP % 2 == 0 && NST >= 3 && NFW % 2 == 0, "stages of two steps, at least three");
-    static_assert(((KT - 1) * DIL + 16 * (NFW - 1)) * RB + 4 * C < 65536, "ds_read immediate range");
+    static_assert(((CG - 1) * 4 * XRP + (KT - 1) * DIL + 16 * (NFW - 1)) * 16 + 16 < 65536, "ds_read immediate range");
 };
 
 template <class G>
@@ -108,8 +109,8 @@ __device__ __forceinline__ void convh_convert(const ConvHRaw<G>& r, char* ximg, 
             h2[j] = (_Float16)((v - (float)a) * kSplitScale);
         }
         if (idx < G::XROWS * G::CB) {
-            *reinterpret_cast<f16x8*>(ximg + row * G::RB + cb * 16) = h1;
-            *reinterpret_cast<f16x8*>(ximg + row * G::RB + 2 * G::C + cb * 16) = h2;
+            *reinterpret_cast<f16x8*>(ximg + (cb * G::XRP + row) * 16) = h1;
+            *reinterpret_cast<f16x8*>(ximg + (cb * G::XRP + row) * 16 + G::XHALF) = h2;
         }
     }
 }
@@ -135,11 +136,10 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
     const int tid = wave * 64 + lane;
     float* const ring = smem + p.x_off;
     char* const ximg = reinterpret_cast<char*>(smem + p.img_off);
-    float* const bl = smem + p.bias_off;
     const int n = lane & 15, kb = lane >> 4;
     const int wm = wave >> 2, wn = wave & 3;
     const int col0 = wn * (16 * G::NFW) + n;
-    const char* const bptr = ximg + col0 * G::RB + kb * 16;                 // B: + (tap*DIL + 16 f) RB + half*2C + 64 cg
+    const char* const bptr = ximg + (kb * G::XRP + col0) * 16;              // B: + (4 cg XRP + tap DIL + 16 f) 16 (+ XHALF)
     const float* const aptr = ring + (wm * 2) * 512 + lane * 4;             // A: + slot*4096 + (i*4 + h)*512 + half*256
     const int row0 = 16 * (2 * wm) + 4 * kb;                                // + 16 h + i: row inside the 64-row tile
 
@@ -163,7 +163,6 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
 #pragma unroll
     for (int st = 0; st < 3; ++st)
         convh_dma_stage<G>(rw, ring, st, (unsigned)(mtile * G::WTILE + st * G::STAGE_BYTES), wave, lane);
-    if (tid < G::C) bl[tid] = mb.b1 ? mb.b1[tid] : 0.f;
     pair_wait_vm0();
     if (!(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid);
     for (;;) {
@@ -178,7 +177,7 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int f = 0; f < G::NFW; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float res[2][G::NFW][4];
+        float res[2][G::NFW][4], bv[2][4];
         unsigned voff[G::NFW];
         f16x8 abuf[2][2][2], bbuf[2][2][2];
 
@@ -211,14 +210,15 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
             }
         };
         LdsCF* const bb = lds_opaque(reinterpret_cast<const float*>(bptr));
+        LdsCF* const bb2 = lds_opaque(reinterpret_cast<const float*>(bptr + G::XHALF));
         auto fetch_b = [&](auto SC, auto PC, f16x8 (&dst)[2][2]) {
             constexpr int S = decltype(SC)::value, PP = decltype(PC)::value;
             constexpr int tap = S / G::CG, cg = S % G::CG;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                constexpr int base = tap * G::DIL * G::RB + 64 * cg;
-                dst[e][0] = *reinterpret_cast<LdsH8*>(bb + (base + (2 * PP) * 16 * G::RB) / 4 + e * (16 * G::RB / 4));
-                dst[e][1] = *reinterpret_cast<LdsH8*>(bb + (base + (2 * PP) * 16 * G::RB + 2 * G::C) / 4 + e * (16 * G::RB / 4));
+                constexpr int off = (cg * 4 * G::XRP + tap * G::DIL + (2 * PP) * 16) * 4;   // in floats
+                dst[e][0] = *reinterpret_cast<LdsH8*>(bb + off + e * 64);
+                dst[e][1] = *reinterpret_cast<LdsH8*>(bb2 + off + e * 64);
             }
         };
 
@@ -261,6 +261,11 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
         });
         // ---- epilogue: residual, image of the next window, stores -------------------------------------------
         {
+            const __amdgpu_buffer_rsrc_t rb = make_rsrc(mb.b1 ? mb.b1 : mb.w1, mb.b1 ? (unsigned)G::C * 4u : 0u);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[h][i] = buffer_load1(rb, (unsigned)(64 * mtile + row0 + 16 * h + i) * 4u);
             const __amdgpu_buffer_rsrc_t rr = make_rsrc(mb.res ? mb.res + b * ustride : mb.w1, mb.res ? ubytes : 0u);
 #pragma unroll
             for (int f = 0; f < G::NFW; ++f) {
@@ -277,15 +282,11 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
         if (new_win && !(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid);
         const bool fin = mb.add1 != nullptr;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float bv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bv[i] = bl[64 * mtile + row0 + 16 * h + i];
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int f = 0; f < G::NFW; ++f)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) hi[h][f][i] = (fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[i]) + res[h][f][i];
-        }
+                for (int i = 0; i < 4; ++i) hi[h][f][i] = (fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[h][i]) + res[h][f][i];
         if (fin) {
             const __amdgpu_buffer_rsrc_t r1 = make_rsrc(mb.add1 + b * ustride, ubytes);
             const __amdgpu_buffer_rsrc_t r2 = make_rsrc(mb.add2 ? mb.add2 + b * ustride : mb.add1, mb.add2 ? ubytes : 0u);

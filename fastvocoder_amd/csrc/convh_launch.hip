@@ -8,17 +8,23 @@ namespace fv {
 
 extern template int launch_convh_geom<2, 4>(const PairParams&, int, size_t, hipStream_t);
 extern template int launch_convh_geom<4, 2>(const PairParams&, int, size_t, hipStream_t);
+extern template int launch_convh_geom<2, 2>(const PairParams&, int, size_t, hipStream_t);
+
+static int convh_nfw(int C) {
+    const char* e = getenv("FV_CONVH_NFW");
+    return C == 64 ? (e && atoi(e) == 4 ? 4 : 2) : 2;     // measured at T = 40 000, B = 1: 128-column tiles 65 us per pair, 256: 72
+}
 
 // run-time mirror of ConvHGeom<>
 ConvHShape convh_shape(int C, int k, int dil) {
     ConvHShape g = {};
     g.CG = C / 32;
-    g.NFW = C == 64 ? 4 : 2;
+    g.NFW = convh_nfw(C);
     g.NTC = 16 * g.NFW * 4;
     g.NSTEP = k * g.CG;
     g.NST = g.NSTEP / 2;
     g.XROWS = (g.NTC + (k - 1) * dil + 3) / 4 * 4;
-    g.RB = 4 * C + 16;
+    g.XIMG = 4 * C * ((g.XROWS + 15) / 16 * 16);
     g.NMT = C / 64;
     return g;
 }
@@ -47,8 +53,8 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
         mb.n_tiles = (p.T + g.NTC - 1) / g.NTC;
         mb.n_items = mb.n_tiles * p.B * g.NMT;
         // a tile costs its stages (LDS / matrix time) plus loads, conversion, epilogue
-        mb.cost = g.NST + (getenv("FV_CONVH_SKEL") ? atoi(getenv("FV_CONVH_SKEL")) : 2);
-        if (g.XROWS * g.RB > img_bytes) img_bytes = g.XROWS * g.RB;
+        mb.cost = g.NST + (getenv("FV_CONVH_SKEL") ? atoi(getenv("FV_CONVH_SKEL")) : (C == 64 ? 5 : 2));
+        if (g.XIMG > img_bytes) img_bytes = g.XIMG;
         items += mb.n_items;
         flops += 2.0 * p.B * (double)C * C * mb.k * p.T;
         bytes += 4.0 * ((double)C * C * mb.k + (double)p.B * C * p.T *
@@ -59,8 +65,7 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     floats += 4 * 16384 / 4;
     p.img_off = (int)floats;
     floats += (size_t)img_bytes / 4;
-    p.bias_off = (int)floats;
-    floats += (size_t)C;
+    p.bias_off = 0;                    // (biases are read from global memory in the epilogue)
     const size_t lds = floats * 4;
     if (lds > 160 * 1024) return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: %zu bytes of LDS", lds);
     int cus = 256, dev = 0, v = 0;
@@ -74,7 +79,8 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     p.dbg = getenv("FV_PAIR_DBG") ? atoi(getenv("FV_PAIR_DBG")) : 0;
     p.trace = nullptr;
     profile_begin(s);
-    const int rc = C == 64 ? launch_convh_geom<2, 4>(p, dil, lds, s) : launch_convh_geom<4, 2>(p, dil, lds, s);
+    const int rc = C == 128 ? launch_convh_geom<4, 2>(p, dil, lds, s)
+                   : convh_nfw(C) == 4 ? launch_convh_geom<2, 4>(p, dil, lds, s) : launch_convh_geom<2, 2>(p, dil, lds, s);
     profile_end(s, C == 64 ? FV_KERNEL_CONVH64 : FV_KERNEL_CONVH128, flops, bytes);
     return rc;
 }

@@ -181,7 +181,8 @@ struct PairHShape {
     int MH, NF, NG, NM;
     int KS;              // K steps per conv (32 K values each)
     int XROWS, WB;       // x image rows; bytes of one conv's packed weights
-    int RB, MROWS;       // bytes per image row; rows of the intermediate image
+    int MROWS;           // rows of the intermediate image
+    int XIMG, MIMG;      // bytes of the x image / the intermediate image
     int NOUT;
 };
 PairHShape pairh_shape(int C, int k, int dil);
@@ -190,7 +191,7 @@ PairHShape pairh_shape(int C, int k, int dil);
 struct ConvHShape {
     int CG, NFW, NTC;    // 32-channel groups, fragments per wave, output columns per tile
     int NSTEP, NST;      // K steps of 32, stages of two steps
-    int XROWS, RB, NMT;  // image rows / bytes per row, 64-row tiles
+    int XROWS, XIMG, NMT;   // image rows / bytes, 64-row tiles
 };
 ConvHShape convh_shape(int C, int k, int dil);
 int launch_convh(PairParams p, int C, int dil, hipStream_t stream);

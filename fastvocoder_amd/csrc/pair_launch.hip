@@ -74,8 +74,9 @@ PairHShape pairh_shape(int C, int k, int dil) {
     const int xwin = g.NM + (ktp - 1) * dil + aoff;
     g.XROWS = (xwin + 3) / 4 * 4;
     g.WB = g.KS * g.MH * 2 * 1024;
-    g.RB = 4 * C + 16;
     g.MROWS = g.NM + 16;
+    g.XIMG = 4 * C * ((g.XROWS + 15) / 16 * 16);
+    g.MIMG = 4 * C * g.MROWS;
     g.NOUT = (g.NM - (k - 1)) / 4 * 4;
     return g;
 }
@@ -100,8 +101,8 @@ static int launch_pairs_split(PairParams p, int C, int dil, hipStream_t s) {
         mb.cost = g.KS + (getenv("FV_PAIRH_SKEL") ? atoi(getenv("FV_PAIRH_SKEL")) : (C == 16 ? 8 : 4));
         mb.w_off = 0;
         if (2 * g.WB > w_bytes) w_bytes = 2 * g.WB;
-        if (g.XROWS * g.RB > img_bytes) img_bytes = g.XROWS * g.RB;
-        if (g.MROWS * g.RB > mid_bytes) mid_bytes = g.MROWS * g.RB;
+        if (g.XIMG > img_bytes) img_bytes = g.XIMG;
+        if (g.MIMG > mid_bytes) mid_bytes = g.MIMG;
         items += (long long)mb.n_tiles * p.B;
         flops += 2.0 * 2.0 * p.B * (double)C * C * mb.k * p.T;
         bytes += 4.0 * (2.0 * C * C * mb.k + (double)p.B * C * p.T * ((mb.y_act ? 3 : 2) + (mb.add1 ? 1 : 0) + (mb.add2 ? 1 : 0)));

@@ -14,11 +14,11 @@
 // 8 x 32: at 16-32 channels the fp32 pair kernel is matrix-core bound, this one is bound by LDS bandwidth
 // and by the HBM traffic of x and x' -- which is where SURVEY section 8(d) puts these layers.
 //
-// Layout: the activated, split input lives in LDS CHANNELS-LAST: one row per time sample,
-// [C halves of h1 | C halves of h2 | 16 bytes of padding]; the B operand of a K step (lane = column n,
-// K block = 8 consecutive channels of one tap) is then ONE ds_read_b128 per half, and the 80 / 144-byte row
-// stride puts 16 consecutive rows on disjoint banks.  The D fragment (lane = column, 4 consecutive channels)
-// is exactly what a row of the intermediate wants: conv1's epilogue splits and stores with ds_write_b64.
+// Layout: the activated, split input lives in LDS as [split half][block of 8 channels][time row][8 halves]:
+// the B operand of a K step (lane = column n, K block = 8 consecutive channels of one tap) is ONE ds_read_b128
+// per half, and consecutive columns sit in consecutive 16-byte slots, which is conflict-free for the lane
+// groups ds_read_b128 is serviced in (PairHGeom).  The D fragment (lane = column, 4 consecutive channels) is
+// half a block entry: conv1's epilogue splits and stores the intermediate with ds_write_b64.
 // K order: step s covers 32 / C taps (C = 16: taps 2s, 2s+1 x 16 channels; an odd tap count is padded with a
 // zero tap), channels inside a tap.  The packed weights of a member's two convs sit in LDS; a wave loads the A
 // operands of a phase with KS x 2 ds_read_b128 (4-wave blocks, two per CU, 2 waves per SIMD => 256 VGPRs each).
@@ -54,12 +54,18 @@ struct PairHGeom {
     static constexpr int XROWS = 4 * NCOL4;             // rows of the x image
     static constexpr int WB = KS * MH * 2 * 1024;       // bytes of one conv's packed weights
     static constexpr bool AREG = MH == 1;               // a phase's A operands fit in registers
-    static constexpr int RB = 4 * C + 16;               // bytes per image row: h1[C] | h2[C] | pad
     static constexpr int MROWS = NM + 16;               // rows of the intermediate image (>= NM + KTP - 1)
+    // image layout [split half][8-channel block][row][8 halves]: a block is RP rows of 16 bytes, RP a multiple of
+    // 16, so the sixteen lanes of a ds_read_b128 lane group (all sixteen columns, two channel blocks) fall on the
+    // sixteen 16-byte slots of the 256-byte bank row whatever the tap offset (no conflicts; a row-major
+    // [row][channels] image with a padded stride measured 37 % conflict cycles)
+    static constexpr int XRP = (XROWS + 15) / 16 * 16, MRP = MROWS;
+    static constexpr int XHALF = (C / 8) * XRP * 16, MHALF = (C / 8) * MRP * 16;   // bytes of one split half
     static constexpr int NOUT = (NM - (KT - 1)) / 4 * 4;
     static_assert(C == 16 || C == 32, "16 or 32 channels");
     static_assert(KT % 2 == 1 && KTP - 1 <= 16, "odd tap counts up to 15");
-    static_assert(((KS - 1) * TPS * DIL + 16 * (NF - 1)) * RB + 2 * C + 16 < 65536, "ds_read immediate range");
+    static_assert(MROWS % 16 == 0, "whole bank rows");
+    static_assert(XHALF + ((KS - 1) * TPS * DIL + 16 * (NF - 1)) * 16 + 16 < 65536, "ds_read immediate range");
     static_assert(AREG || KS * MH * 2 * 1024 < 65536, "ds_read immediate range (weights)");
 };
 
@@ -104,8 +110,8 @@ __device__ __forceinline__ void pairh_convert(const PairHRaw<G>& r, char* ximg, 
             h2[j] = (_Float16)((v - (float)a) * kSplitScale);
         }
         if (idx < G::XROWS * PairHRaw<G>::CB) {
-            *reinterpret_cast<f16x8*>(ximg + row * G::RB + cb * 16) = h1;
-            *reinterpret_cast<f16x8*>(ximg + row * G::RB + 2 * G::C + cb * 16) = h2;
+            *reinterpret_cast<f16x8*>(ximg + (cb * G::XRP + row) * 16) = h1;
+            *reinterpret_cast<f16x8*>(ximg + (cb * G::XRP + row) * 16 + G::XHALF) = h2;
         }
     }
 }
@@ -141,7 +147,7 @@ __device__ __forceinline__ void pairh_load_a(const float* wl, f16x8 (&A)[G::KS][
 // img: the lane's image base (row = its column of fragment 0 at the lane group's first tap, byte offset of
 // its channel block); TAPB: bytes between consecutive K steps of the image.  B operands are read one step
 // ahead of the MFMAs that use them (sched_barrier pins the order; the waitcnt pass derives the counts).
-template <class G, int TAPB>
+template <class G, int TAPB, int HALF>
 __device__ __forceinline__ void pairh_mma(const float* wl, const char* img, f32x4 (&hi)[G::MH][G::NF],
                                           f32x4 (&lo)[G::MH][G::NF], int lane) {
     typedef __attribute__((address_space(3))) const f16x8 LdsH8;
@@ -150,8 +156,8 @@ __device__ __forceinline__ void pairh_mma(const float* wl, const char* img, f32x
     auto fetch = [&](int s, f16x8 (&dst)[G::NF][2]) {
 #pragma unroll
         for (int f = 0; f < G::NF; ++f) {
-            dst[f][0] = *reinterpret_cast<LdsH8*>(base + (s * TAPB + f * 16 * G::RB) / 4);
-            dst[f][1] = *reinterpret_cast<LdsH8*>(base + (s * TAPB + f * 16 * G::RB + 2 * G::C) / 4);
+            dst[f][0] = *reinterpret_cast<LdsH8*>(base + (s * TAPB + f * 256) / 4);
+            dst[f][1] = *reinterpret_cast<LdsH8*>(base + (s * TAPB + f * 256 + HALF) / 4);
         }
     };
     auto mma = [&](const f16x8 (&a)[G::MH][2], const f16x8 (&bv)[G::NF][2]) {
@@ -228,9 +234,10 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
     const int col0 = wave * (16 * G::NF) + n;          // the lane's column in the wave's fragment 0
     const int tapg = G::TPS == 2 ? (g >> 1) : 0;       // the lane group's tap inside a K step
     const int cb = G::TPS == 2 ? (g & 1) : g;          // ... and its block of 8 channels
-    const char* const xb = ximg + (col0 + G::AOFF + tapg * G::DIL) * G::RB + cb * 16;
-    const char* const mbase = mimg + (col0 + tapg) * G::RB + cb * 16;
-    char* const mw = mimg + col0 * G::RB + 8 * g;      // D fragment: rows (channels) 4g .. 4g+3 of column n
+    const char* const xb = ximg + (cb * G::XRP + col0 + G::AOFF + tapg * G::DIL) * 16;
+    const char* const mbase = mimg + (cb * G::MRP + col0 + tapg) * 16;
+    // D fragment: channels 4g .. 4g+3 (+ 16 per row half) of column n = half of the 8-channel block g >> 1
+    char* const mw = mimg + ((g >> 1) * G::MRP + col0) * 16 + 8 * (g & 1);
     const int row0 = 4 * g;
 
     const size_t ustride = (size_t)G::C * (size_t)p.T;
@@ -243,8 +250,8 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
     pairh_stage_weights<G>(mb, wl, wave, lane);
     pair_stage_bias<G>(mb, bl, tid);
     // rows [NM, MROWS) of the intermediate feed only discarded columns / the zero tap: finite values once
-    for (int idx = tid; idx < (G::MROWS - G::NM) * G::RB / 4; idx += G::NT)
-        reinterpret_cast<float*>(mimg + G::NM * G::RB)[idx] = 0.f;
+    for (int idx = tid; idx < 2 * (G::C / 8) * 64; idx += G::NT)
+        reinterpret_cast<float*>(mimg + ((idx >> 6) * G::MRP + G::NM) * 16)[idx & 63] = 0.f;
     pair_wait_vm0();
     pairh_convert<G>(raw, ximg, p.slope, tid);
     pair_barrier();
@@ -281,7 +288,7 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
         for (int h = 0; h < G::MH; ++h)
 #pragma unroll
             for (int f = 0; f < G::NF; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!(p.dbg & 4)) pairh_mma<G, G::TPS * G::DIL * G::RB>(wl, xb, hi, lo, lane);
+        if (!(p.dbg & 4)) pairh_mma<G, G::TPS * G::DIL * 16, G::XHALF>(wl, xb, hi, lo, lane);
         {
             // intermediate column u of the tile is time t0 - P2 + u; conv2's zero padding applies to the
             // intermediate: columns outside [0, T) are zero, not conv1 of the padded input
@@ -304,8 +311,8 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
                         h1[i] = a;
                         h2[i] = (_Float16)((v - (float)a) * kSplitScale);
                     }
-                    *reinterpret_cast<f16x4*>(mw + f * 16 * G::RB + 32 * h) = h1;
-                    *reinterpret_cast<f16x4*>(mw + f * 16 * G::RB + 32 * h + 2 * G::C) = h2;
+                    *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16)) = h1;
+                    *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16) + G::MHALF) = h2;
                 }
             }
         }
@@ -314,7 +321,7 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
         for (int h = 0; h < G::MH; ++h)
 #pragma unroll
             for (int f = 0; f < G::NF; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!(p.dbg & 4)) pairh_mma<G, G::TPS * G::RB>(wl + G::WB / 4, mbase, hi, lo, lane);
+        if (!(p.dbg & 4)) pairh_mma<G, G::TPS * 16, G::MHALF>(wl + G::WB / 4, mbase, hi, lo, lane);
         // raw window and residual have been in flight for two conv phases; no store is outstanding here
         // (the previous tile's were issued a tile ago and are drained with the same wait)
         pair_wait_vm0();

@@ -185,6 +185,21 @@ class PlanBuilder:
                              out_div=float(out_div), post=post, mid=mid if wide else SLOT_NONE,
                              tmps=[mid] if wide else [], **m))
 
+    def conv_split(self, conv, src, dst, slope, res=SLOT_NONE, add1=SLOT_NONE, add2=SLOT_NONE, out_div=1.0,
+                   post=POST_NONE):
+        """dst = post((conv(lrelu(src, slope)) + bias + res + add1 + add2) / out_div): a 'same' conv of a 64- or
+        128-channel ResBlock with split-f16 operands (fv_plan_add_conv1d_split_f16).  ``src`` is read raw -- the
+        activation is applied on chip -- so nothing is hoisted into its producer.  Ops recorded inside one group
+        share a launch."""
+        c, k, d = conv.in_channels, conv.kernel_size[0], conv.dilation[0]
+        if not (conv.stride[0] == 1 and conv.groups == 1 and conv.out_channels == c and conv.padding[0] == d * (k - 1) // 2
+                and c in (64, 128) and _native.pair_supported(c, k, d, _native.PAIR_SPLIT_F16)):
+            raise _native.NativeError("conv_split: shape not built into the split-f16 conv kernels")
+        self.ops.append(dict(kind="convh", lane=self.lane, group=self.group, x=src, y=dst, res=res, acc=add1, acc2=add2,
+                             pre_slope=1.0, slope=float(slope), channels=c, k=k, dil=d,
+                             packed=_native.pack_pair(effective_weight(conv), _native.PAIR_SPLIT_F16),
+                             bias=self._bias(conv), out_div=float(out_div), post=post))
+
     def mrf_sum(self, pairs, srcs, dst, slope, out_div, post=POST_NONE):
         """dst = post(sum_j pair_j(srcs[j]) / out_div): the last pairs of the three ResBlocks of an MRF stage
         and the mean, one launch (fv_plan_add_mrf_sum)."""
@@ -309,6 +324,8 @@ class PlanBuilder:
                 own, rate = max(op["ks"]) // 2, 1
             elif op["kind"] == "conv2":
                 own, rate = 0, 1
+            elif op["kind"] == "convh":
+                own, rate = (op["k"] - 1) // 2 * op["dil"], 1
             elif op["kind"] == "pair":
                 own, rate = (op["k"] - 1) // 2 * (op["dil"] + 1), 1
             elif op["kind"] == "mrfsum":
@@ -357,6 +374,11 @@ class PlanBuilder:
                                             y_act=op["y_act"], act_slope=op["act_slope"], prec=op["prec"],
                                             add1=op["acc"], add2=op["acc2"], out_div=op["out_div"],
                                             post=op["post"], mid=op["mid"])
+            elif op["kind"] == "convh":
+                self.plan.add_conv1d_split_f16(op["x"], op["y"], op["packed"], op["bias"], op["channels"], op["k"],
+                                               op["dil"], pre_slope=op["slope"], res=op["res"], add1=op["acc"],
+                                               add2=op["acc2"], out_div=op["out_div"], post=op["post"],
+                                               y_act=op["y_act"], act_slope=op["act_slope"])
             elif op["kind"] == "mrfsum":
                 ms = op["members"]
                 self.plan.add_mrf_sum([op["x"], op["xb"], op["xc"]], op["y"], [m["w1"] for m in ms],

@@ -103,6 +103,30 @@ class _HiFiGANBase(NativeModule):
         ch = blocks[0].channels
         curs = [up] * nk
         prec = pb.pair_precision(ch)
+        if prec == PAIR_SPLIT_F16 and ch >= 64:
+            # 64 / 128 channels: the weights do not fit on chip, a pair is two launches of the split-f16 conv kernel
+            # (csrc/convh_kernels.hpp).  Per pair position: the three blocks' first convs, then their second convs
+            # (+ residual); at the last position the second convs of blocks 1.. store r_1.., and the first block's
+            # runs after them with ((r_0 + r_1) + r_2) / nk in its epilogue -- the reference's order, bit for bit.
+            for pi in range(npairs):
+                last = pi == npairs - 1
+                pb.begin_group()
+                for j in range(nk):
+                    pb.conv_split(blocks[j].convs1[pi], curs[j], scratch[j][0], LRELU_SLOPE)
+                pb.end_group()
+                nxt = []
+                pb.begin_group()
+                for j in range(1 if last else 0, nk):
+                    ping, pong = scratch[j][1], scratch[j][2]
+                    d = parts[j - 1] if last else (ping if curs[j] != ping else pong)
+                    pb.conv_split(blocks[j].convs2[pi], scratch[j][0], d, LRELU_SLOPE, res=curs[j])
+                    nxt.append(d)
+                pb.end_group()
+                if last:
+                    pb.conv_split(blocks[0].convs2[pi], scratch[0][0], x, LRELU_SLOPE, res=curs[0],
+                                  add1=parts[0], add2=parts[1] if nk > 2 else SLOT_NONE, out_div=float(nk))
+                curs = nxt
+            return
         for pi in range(npairs - 1):
             pb.begin_group()
             nxt = []

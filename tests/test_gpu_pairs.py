@@ -186,7 +186,7 @@ def test_split_f16_results_do_not_depend_on_the_batch():
 def test_split_f16_rejects_what_it_is_not_built_for():
     dev = _dev()
     with pytest.raises(_native.NativeError):
-        _native.pack_pair(torch.zeros((64, 64, 3), device=dev), SPLIT)
+        _native.pack_pair(torch.zeros((48, 48, 3), device=dev), SPLIT)
     x = torch.zeros((1, 16, 50), device=dev)               # T % 4 != 0
     w = _native.pack_pair(torch.zeros((16, 16, 3), device=dev), SPLIT)
     with pytest.raises(_native.NativeError, match="multiple of 4"):
@@ -238,6 +238,41 @@ def test_wide_resblock_pair_split_f16_vs_oracle(case):
                                           prec=SPLIT)
             for yf, yo in zip(ys, one):
                 assert torch.equal(yf[1:2], yo)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 300, 3, (7, 3)), (1, 128, 260, 5, (11, 7, 3)), (1, 64, 5, 1, (3,)),
+                                  (3, 128, 129, 1, (11,))], ids=lambda c: "x".join(str(v) for v in c))
+def test_conv1d_split_f16_vs_oracle(case):
+    """fv_conv1d_split_f16: every epilogue form against the oracle's conv1d."""
+    B, C, T, dil, ks = case
+    rng = np.random.RandomState(31 * T + C + dil)
+    n = len(ks)
+    xs = [rng.randn(B, C, T).astype(np.float32) for _ in ks]
+    ws = [(rng.randn(C, C, k) / np.sqrt(C * k)).astype(np.float32) for k in ks]
+    bs = [rng.randn(C).astype(np.float32) for _ in ks]
+    rs = [rng.randn(B, C, T).astype(np.float32) for _ in ks]
+    a1 = [rng.randn(B, C, T).astype(np.float32) for _ in ks]
+    a2 = [rng.randn(B, C, T).astype(np.float32) for _ in ks]
+    conv = [oo.conv1d(x, w, b, dil=dil, pad=(k - 1) * dil // 2, pre_slope=0.1) for x, w, b, k in zip(xs, ws, bs, ks)]
+    X, P, Bi = [_t(x) for x in xs], [_native.pack_pair(_t(w), SPLIT) for w in ws], [_t(b) for b in bs]
+    R, A1, A2 = [_t(r) for r in rs], [_t(a) for a in a1], [_t(a) for a in a2]
+    ys = _native.conv1d_split_f16(X, P, Bi, list(ks), dil, pre_slope=0.1)
+    for y, c in zip(ys, conv):
+        assert _rel(y, c) <= 4e-6
+    ys = _native.conv1d_split_f16(X, P, [None] * n, list(ks), dil, pre_slope=0.1, res=R)
+    for y, c, b, r in zip(ys, conv, bs, rs):
+        assert _rel(y, c - b[None, :, None] + r) <= 4e-6
+    acts = [torch.empty_like(x) for x in X]
+    ys = _native.conv1d_split_f16(X, P, Bi, list(ks), dil, pre_slope=0.1, res=R, add1=A1, add2=A2, out_div=3.0,
+                                  act_slope=0.01, outs_act=acts)
+    for y, a, c, r, p1, p2 in zip(ys, acts, conv, rs, a1, a2):
+        ref = (((c + r) + p1) + p2) / np.float32(3.0)
+        assert _rel(y, ref) <= 4e-6 and _rel(a, oo.lrelu(ref, 0.01)) <= 4e-6
+    ys = _native.conv1d_split_f16(X, P, Bi, list(ks), dil, pre_slope=0.1, add1=A1, out_div=2.0, post=_native.POST_TANH)
+    for y, c, p1 in zip(ys, conv, a1):
+        assert _rel(y, np.tanh(((c + p1) / np.float32(2.0)).astype(np.float64))) <= 4e-6
+    with pytest.raises(_native.NativeError, match="64 or 128"):
+        _native.conv1d_split_f16([torch.zeros((1, 32, 16), device=_dev())], P[:1], [None], [ks[0]], dil)
 
 
 def test_pair_results_do_not_depend_on_the_batch():

@@ -24,7 +24,7 @@ def bench(fn, reps=20):
 
 def main():
     C = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-    T = int(sys.argv[2]) if len(sys.argv) > 2 else {16: 240000, 32: 120000, 64: 40000, 128: 8000}[C]
+    T = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else {16: 240000, 32: 120000, 64: 40000, 128: 8000}[C]
     B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     prec = _native.PAIR_SPLIT_F16 if len(sys.argv) > 4 and sys.argv[4] == "split" else _native.PAIR_F32
     dev = torch.device("cuda:0")
