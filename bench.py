@@ -46,7 +46,11 @@ MODEL = "hifigan"
 CONFS = {"light": "conf/hifigan/light.yaml", "large512": "conf/hifigan/large.yaml"}
 T_FRAMES = 1000
 JOB_UTTERANCES = int(os.environ.get("FV_BENCH_JOB", "512"))   # --config large512 (the env override is for tests)
+# the arithmetic the path computes in: fp32 tensors, fp32 accumulation; on the ResBlock stages every fp32 product is
+# formed from split-f16 operand pairs on the f16 matrix cores (fp32-class accuracy)
+DTYPE = "f32" if os.environ.get("FV_PAIR_PREC", "split") == "f32" else "f32 (products as split-f16 pairs, fp32 accumulate)"
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
+PEAK_F16_MFMA_TFLOPS = 2500.0   # dense f16 matrix peak (same guide; the sparse headline figure is twice that)
 PEAK_HBM_GBS = 8000.0
 TOL = 1e-4                      # north star: outputs match the reference generator within 1e-4 fp32 max-abs
 
@@ -151,8 +155,8 @@ def survey_bytes_c16_stage(model, B, T_stage):
 
 
 def roofline_report(model, mel, ms_per_step, reps=5):
-    """Per-launch timing of the conv kernel families with HIP events on the launch stream (single-stream
-    replay of the same forward), event-bracket cost calibrated out."""
+    """Per-launch timing of the kernel families with HIP events on the launch stream (single-stream replay of the
+    same forward), event-bracket cost calibrated out.  `roofline` is about the family that takes most of the step."""
     os.environ["FV_SINGLE_LANE"] = "1"
     for _ in range(2):
         with torch.no_grad():
@@ -169,74 +173,104 @@ def roofline_report(model, mel, ms_per_step, reps=5):
     kinds = {"conv32": _native.KERNEL_CONV_MFMA32, "conv16": _native.KERNEL_CONV_MFMA16,
              "pair16": _native.KERNEL_PAIR16, "pair32": _native.KERNEL_PAIR32,
              "pairh16": _native.KERNEL_PAIRH16, "pairh32": _native.KERNEL_PAIRH32,
+             "convh64": _native.KERNEL_CONVH64, "convh128": _native.KERNEL_CONVH128,
              "narrow": _native.KERNEL_CONV_NARROW}
     rec = {k: _native.profile_collect(v) for k, v in kinds.items()}
     for r in rec.values():
         r["ms"] = max(r["ms"] - bracket_ms * r["launches"], 0.0)
-    # the dominant kernel family: everything that runs on the fp32 matrix cores (the split-f16 fused pairs of the
-    # 16- and 32-channel stages are HBM / LDS-bound and are reported against the memory roofline below)
-    mf = [rec[k] for k in ("conv32", "conv16", "pair16", "pair32")]
-    launches = sum(r["launches"] for r in mf)
-    ms = sum(r["ms"] for r in mf)
-    flops = sum(r["flops"] for r in mf)
-    nbytes = sum(r["bytes"] for r in mf)
-    split = [rec[k] for k in ("pairh16", "pairh32")]
-    split_ms = sum(r["ms"] for r in split)
-    split_flops = sum(r["flops"] for r in split)
-    all_ms = (ms + split_ms + rec["narrow"]["ms"]) / reps
+
+    def fam(*names):
+        rs = [rec[n] for n in names]
+        return {"ms": sum(r["ms"] for r in rs), "flops": sum(r["flops"] for r in rs),
+                "bytes": sum(r["bytes"] for r in rs), "launches": sum(r["launches"] for r in rs)}
+
+    fp32 = fam("conv32", "conv16", "pair16", "pair32")       # fp32 matrix cores (csrc/conv_kernels.hpp, pair_kernels.hpp)
+    wide = fam("convh64", "convh128")                        # split-f16 convs with streamed weights (convh_kernels.hpp)
+    pairs = fam("pairh16", "pairh32")                        # split-f16 fused pairs (pairh_kernels.hpp)
+    all_ms = (fp32["ms"] + wide["ms"] + pairs["ms"] + rec["narrow"]["ms"]) / reps
+    all_flops = fp32["flops"] + wide["flops"] + pairs["flops"]
     # Sum of kernel time must fit inside the step; if the calibration ever fails that test, fall back to
     # the whole-step figure (launch gaps included: a lower bound of the kernels' rate)
     consistent = all_ms <= ms_per_step * 1.001
-    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 and consistent else flops / reps / (ms_per_step * 1e-3) / 1e12
-    traffic, traffic_src = None, None
+    note = "" if consistent else "; INCONSISTENT with the step time -> whole-step figure used"
+
+    def rate(f):
+        if f["ms"] <= 0:
+            return 0.0
+        return f["flops"] / (f["ms"] * 1e-3) / 1e12 if consistent else f["flops"] / reps / (ms_per_step * 1e-3) / 1e12
+
+    traffic, traffic_src, tkey = None, None, "split_f16_convs" if wide["ms"] >= fp32["ms"] else "conv_mfma_family"
     pdir = os.path.join(ROOT, "profiles")
     for cand in sorted((f for f in os.listdir(pdir) if f.endswith("_hbm_traffic.json")), reverse=True) \
             if os.path.isdir(pdir) else []:
         with open(os.path.join(pdir, cand)) as f:
-            traffic = json.load(f)["conv_mfma_family"]["hbm_bytes_per_launch"]
-        traffic_src = "profiles/" + cand
-        break
-    split_on = split_ms > 0
-    roofline = {
-        "kernel": ("fp32-MFMA implicit-GEMM conv family, fv::conv_group3_kernel / conv_mfma_kernel / conv_sum3_kernel "
-                   "(32x32x2 fp32 MFMA, csrc/conv_kernels.hpp): conv_pre, the four upsamplers and the 128- and "
-                   "64-channel MRF stages -- %.0f %% of the step's kernel time; the 32- and 16-channel stages run as "
-                   "split-f16 fused ResBlock pairs (csrc/pairh_kernels.hpp), see roofline_hbm_stage / split_f16"
-                   % (100.0 * ms / max(ms + split_ms + rec["narrow"]["ms"], 1e-9))) if split_on else
-                  ("fp32-MFMA conv family: fv::pair_kernel / fv::pair_sum_kernel (fused ResBlock pairs, 16x16x4, "
-                   "csrc/pair_kernels.hpp) + fv::conv_group3_kernel / conv_sum3_kernel / conv_mfma_kernel "
-                   "(implicit-GEMM conv1d, 32x32x2, csrc/conv_kernels.hpp): 77 of the 78 convs of a forward"),
-        "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+            js = json.load(f)
+        if tkey in js:
+            traffic = js[tkey]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/" + cand
+            break
+    measured = ("per-launch HIP events on the launch stream, single-stream replay of the same forward, "
+                f"event-bracket cost ({bracket_ms * 1e3:.2f} us per launch) subtracted" + note)
+    if wide["ms"] >= fp32["ms"]:
+        dom, peak = wide, PEAK_F16_MFMA_TFLOPS / 3.0
+        roofline = {
+            "kernel": "fv::convh_kernel (csrc/convh_kernels.hpp): conv1d of the 128- and 64-channel MRF stages (36 of the "
+                      "78 convs, %.0f %% of the step's kernel time) with split-f16 operands -- every fp32 product is three "
+                      "v_mfma_f32_16x16x32_f16 terms (a1 b1 + (a1 b2 + a2 b1) / 2048, fp32 accumulate), weights streamed "
+                      "L2 -> LDS" % (100.0 * wide["ms"] / max(all_ms * reps, 1e-9)),
+            "bound": "mfma", "achieved": rate(dom), "peak": peak, "unit": "TFLOP/s",
+            "frac": rate(dom) / peak,
+            "flop_rule": "achieved counts ALGORITHMIC conv FLOP (2 B Cout Cin k T per conv, SURVEY 8(d)); the matrix cores "
+                         "execute three f16 FLOP per algorithmic FLOP, so the peak is the dense f16 MFMA peak "
+                         f"({PEAK_F16_MFMA_TFLOPS:.0f} TFLOP/s, MI355X_MICROARCH.md) / 3",
+            "executed_f16_tflops": 3.0 * rate(dom),
+            "vs_fp32_mfma_peak": rate(dom) / PEAK_FP32_MFMA_TFLOPS,
+        }
+    else:
+        dom, peak = fp32, PEAK_FP32_MFMA_TFLOPS
+        roofline = {
+            "kernel": "fp32-MFMA conv family: fv::pair_kernel / fv::pair_sum_kernel (fused ResBlock pairs, 16x16x4, "
+                      "csrc/pair_kernels.hpp) + fv::conv_group3_kernel / conv_sum3_kernel / conv_mfma_kernel "
+                      "(implicit-GEMM conv1d, 32x32x2, csrc/conv_kernels.hpp)",
+            "bound": "mfma", "achieved": rate(dom), "peak": peak, "unit": "TFLOP/s", "frac": rate(dom) / peak,
+        }
+    roofline.update({
         "traffic": traffic,
         "traffic_unit": "HBM bytes per launch; committed OFFLINE rocprofv3 PMC pass of this command, not this run",
         "traffic_source": traffic_src,
-        "algorithmic_bytes_per_launch": nbytes / max(launches, 1),
-        "measured": "per-launch HIP events on the launch stream, single-stream replay of the same forward, "
-                    f"event-bracket cost ({bracket_ms * 1e3:.2f} us per launch) subtracted"
-                    + ("" if consistent else "; INCONSISTENT with the step time -> whole-step figure used"),
-        "achieved_whole_step": (flops + split_flops) / reps / (ms_per_step * 1e-3) / 1e12,
-        "frac_whole_step": (flops + split_flops) / reps / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-        "whole_step_note": "all algorithmic conv FLOP of the forward / step time, against the fp32-MFMA peak"
-                           + (" (fp32-equivalent: the split-f16 stages spend 3 f16 MFMAs per 32 fp32 products)"
-                              if split_on else ""),
-        "launches_per_step": launches // reps,
-        "avg_launch_us": 1e3 * ms / max(launches, 1),
-        "algorithmic_gflop_per_step": flops / reps / 1e9,
-        "algorithmic_gflop_per_step_all_kernels": (flops + split_flops) / reps / 1e9,
-        "kernel_ms_per_step": ms / reps,
-        "split_f16": {
-            "kernel": "fv::pairh_kernel (fused ResBlock1 pairs, operands split into two f16 halves, "
-                      "v_mfma_f32_16x16x32_f16 x 3 per product, fp32 accumulate; csrc/pairh_kernels.hpp)",
-            "ms_per_step": split_ms / reps, "launches_per_step": sum(r["launches"] for r in split) // reps,
-            "fp32_equivalent_tflops": split_flops / (split_ms * 1e-3) / 1e12 if split_ms > 0 else 0.0,
-            "external_gbs": sum(r["bytes"] for r in split) / (split_ms * 1e-3) / 1e9 if split_ms > 0 else 0.0,
+        "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
+        "measured": measured,
+        "launches_per_step": dom["launches"] // reps,
+        "avg_launch_us": 1e3 * dom["ms"] / max(dom["launches"], 1),
+        "algorithmic_gflop_per_step": dom["flops"] / reps / 1e9,
+        "kernel_ms_per_step": dom["ms"] / reps,
+        "whole_step": {
+            "algorithmic_gflop": all_flops / reps / 1e9,
+            "tflops": all_flops / reps / (ms_per_step * 1e-3) / 1e12,
+            "vs_fp32_mfma_peak": all_flops / reps / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "note": "all algorithmic conv FLOP of the forward / step time; the fp32-MFMA peak (157.3 TFLOP/s) is what an "
+                    "exact-fp32 matrix path is limited to -- the split-f16 path is not",
+            "kernel_ms": all_ms, "launch_gaps_ms": max(ms_per_step - all_ms, 0.0),
+        },
+        "fp32_mfma_family": {
+            "kernel": "fv::conv_mfma_kernel / conv_group3_kernel / conv_sum3_kernel (32x32x2 fp32 MFMA, csrc/conv_kernels.hpp): "
+                      "conv_pre, the transposed-conv upsamplers"
+                      + ("" if wide["ms"] > 0 else ", the 128- and 64-channel stages"),
+            "ms_per_step": fp32["ms"] / reps, "launches_per_step": fp32["launches"] // reps,
+            "tflops": rate(fp32), "frac_of_fp32_mfma_peak": rate(fp32) / PEAK_FP32_MFMA_TFLOPS,
+        },
+        "split_f16_pairs": {
+            "kernel": "fv::pairh_kernel (fused ResBlock1 pairs of the 32- and 16-channel stages, split-f16 operands, "
+                      "intermediate in LDS; csrc/pairh_kernels.hpp)",
+            "ms_per_step": pairs["ms"] / reps, "launches_per_step": pairs["launches"] // reps,
+            "fp32_equivalent_tflops": rate(pairs),
+            "external_gbs": pairs["bytes"] / (pairs["ms"] * 1e-3) / 1e9 if pairs["ms"] > 0 else 0.0,
             "bound": "hbm / lds (DESIGN.md section 3.7)",
         },
         "narrow_conv_ms_per_step": rec["narrow"]["ms"] / reps,
         "by_family_ms_per_step": {k: r["ms"] / reps for k, r in rec.items()},
         "by_family_tflops": {k: (r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0) for k, r in rec.items()},
-    }
+    })
     # The HBM-bound members (north star: "memory roofline on the dilated-conv kernels"): the 16-channel stage,
     # 12-44 FLOP/B, with SURVEY.md section 8(d)'s layer-by-layer bytes over the time of its launches
     stage = rec["pairh16"] if rec["pairh16"]["launches"] else rec["pair16"] if rec["pair16"]["launches"] else rec["conv16"]
@@ -258,6 +292,7 @@ def roofline_report(model, mel, ms_per_step, reps=5):
         "bytes": survey, "bytes_rule": "SURVEY.md section 8(d): every conv's input and output once + the residual "
                                        "read + weights, layer by layer (unfused accounting)",
         "fused_external_bytes": stage["bytes"] / reps,
+        "fused_external_gbs": stage["bytes"] / reps / (st_ms * 1e-3) / 1e9 if st_ms > 0 else 0.0,
         "ms": st_ms, "launches_per_step": stage["launches"] // reps,
         "tflops": stage["flops"] / (stage["ms"] * 1e-3) / 1e12 if stage["ms"] > 0 else 0.0,
         "measured": "per-launch HIP events (bracket cost subtracted); HBM traffic by PMC: profiles/",
@@ -400,7 +435,7 @@ def main():
             "metric": baseline_metric(), "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": DTYPE, "data": "synthetic",
             "rtf_22k05": elapsed / dur22, "rtf_24k": elapsed / dur24,
             "config": {"workload": workload, "global_batch": utt_per_step, "frames": T_FRAMES,
                        "parallelism": f"utterance-sharded x{world}" if world > 1 else "single GPU"},

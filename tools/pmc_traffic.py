@@ -30,6 +30,7 @@ def main():
     out = {"unit": "bytes per launch", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": {}}
     fam_bytes, fam_n = 0.0, 0
     split = {"16": [0.0, 0], "32": [0.0, 0]}          # fv::pairh_kernel<MH = 1 | 2, ...>: C = 16 | 32
+    wide = [0.0, 0]                                   # fv::convh_kernel: the 64- / 128-channel convs
     for k in sorted(fetch, key=lambda k: -fetch[k]):
         if k not in write or "fv::" not in k:
             continue
@@ -40,12 +41,17 @@ def main():
                                 "pair_sum_kernel")):
             fam_bytes += (fb + wb) * nf[k]
             fam_n += nf[k]
+        if "convh_kernel<" in k:
+            wide[0] += (fb + wb) * nf[k]
+            wide[1] += nf[k]
         if "pairh_kernel<" in k:
             c = "16" if "pairh_kernel<1," in k else "32"
             split[c][0] += (fb + wb) * nf[k]
             split[c][1] += nf[k]
     # the fp32-MFMA family bench.py's `roofline` is about; the split-f16 fused pairs per channel count
     out["conv_mfma_family"] = {"launches": fam_n, "hbm_bytes_per_launch": fam_bytes / max(fam_n, 1)}
+    if wide[1]:
+        out["split_f16_convs"] = {"launches": wide[1], "hbm_bytes_per_launch": wide[0] / wide[1]}
     for c, (b, n) in split.items():
         if n:
             out["split_f16_pairs_c" + c] = {"launches": n, "hbm_bytes_per_launch": b / n}

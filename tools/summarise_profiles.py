@@ -26,24 +26,31 @@ with open(f"{dst}/{tag}_mfma_counters.txt", "w") as f:
     f.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY\n"
             "#   SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace -- python bench.py --steps 5 --warmup 2\n"
             "# MI355X, HiFi-GAN light B=1 T=1000; per-dispatch averages; GRBM_GUI_ACTIVE is summed over the 8 XCDs\n")
-    fam = defaultdict(float)
-    for k in sorted(tot, key=lambda k: -tot[k].get("GRBM_GUI_ACTIVE", 0)):
+    fams = {"split-f16 convs (convh_kernel)": ("convh_kernel",), "split-f16 fused pairs (pairh_kernel)": ("pairh_kernel",),
+            "fp32-MFMA convs (conv_mfma_kernel + conv_group3_kernel + conv_sum3_kernel + pair_kernel + pair_sum_kernel)":
+                ("conv_mfma_kernel", "conv_group3_kernel", "conv_sum3_kernel", "fv::pair_kernel", "pair_sum_kernel")}
+    fam = {name: defaultdict(float) for name in fams}
+    for k in sorted(tot, key=lambda k: -tot[k].get("GRBM_GUI_ACTIVE", 0) * n[k].get("GRBM_GUI_ACTIVE", 0)):
         d, c = tot[k], n[k]
         f.write(k + "\n")
         for name in sorted(d):
             f.write(f"    {name:28s} {d[name] / c[name]:16.0f}   (n={c[name]})\n")
-        if any(t in k for t in ("conv_mfma_kernel", "conv_group3_kernel", "conv_sum3_kernel", "pair_kernel",
-                                "pair_sum_kernel")) and d.get("GRBM_GUI_ACTIVE"):
+        if d.get("GRBM_GUI_ACTIVE") and d.get("SQ_INSTS_MFMA"):
             f.write(f"    MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs) = "
                     f"{d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f};  "
                     f"VALU instructions per MFMA = {d['SQ_INSTS_VALU'] / max(d['SQ_INSTS_MFMA'], 1):.2f}\n")
-            for name in d:
-                fam[name] += d[name]
-    f.write("conv family (conv_mfma_kernel + conv_group3_kernel + conv_sum3_kernel + pair_kernel + pair_sum_kernel), all launches:\n")
-    f.write(f"    MFMA-busy fraction of SIMD cycles = {fam['SQ_VALU_MFMA_BUSY_CYCLES'] / (fam['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f}\n")
-    f.write(f"    VALU instructions per MFMA (incl. the MFMA itself) = {fam['SQ_INSTS_VALU'] / fam['SQ_INSTS_MFMA']:.2f}\n")
-    f.write(f"    SQ_LDS_BANK_CONFLICT total = {fam['SQ_LDS_BANK_CONFLICT']:.0f}\n")
-print(open(f"{dst}/{tag}_mfma_counters.txt").read()[-700:])
+        for name, pats in fams.items():
+            if any(t in k for t in pats):
+                for cn in d:
+                    fam[name][cn] += d[cn]
+    for name, d in fam.items():
+        if not d.get("GRBM_GUI_ACTIVE"):
+            continue
+        f.write(f"{name}, all launches:\n")
+        f.write(f"    MFMA-busy fraction of SIMD cycles = {d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f}\n")
+        f.write(f"    VALU instructions per MFMA (incl. the MFMA itself) = {d['SQ_INSTS_VALU'] / max(d['SQ_INSTS_MFMA'], 1):.2f}\n")
+        f.write(f"    SQ_LDS_BANK_CONFLICT total = {d['SQ_LDS_BANK_CONFLICT']:.0f}\n")
+print(open(f"{dst}/{tag}_mfma_counters.txt").read()[-1200:])
 
 # ---- the other BASELINE configs: kernel-time shares from rocprofv3 --stats ----
 names = {0: "config 1: MelGAN original, T=200, B=1", 2: "config 3: MB-HiFi-GAN light + PQMF, T=1000, B=32",
