@@ -315,6 +315,8 @@ def main():
     steps = args.steps if args.steps is not None else (50 if args.config == "light" else 2)
     warmup = args.warmup if args.warmup is not None else (5 if args.config == "light" else 1)
 
+    if _native.built_id() != _native.source_hash():
+        sys.exit("libfastvocoder_hip.so was not built from this tree (python -c 'import __graft_entry__ as g; g.build()')")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -450,6 +452,15 @@ def main():
             roofline, hbm = roofline_report(model, mel, ms_per_step)
             out["roofline"] = roofline
             out["roofline_hbm_stage"] = hbm
+            # host time to enqueue one forward (plan replay: ~28 launches), no synchronisation inside
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                with torch.no_grad():
+                    model(mel)
+            enq = (time.perf_counter() - t0) / 10
+            torch.cuda.synchronize()
+            out["host_enqueue_ms_per_forward"] = 1e3 * enq
             # PCIe-inclusive rate of the drop-in boundary (never `value`): Generator.inference takes a
             # HOST mel [T,80] and the caller wants a HOST waveform -- pageable numpy in, numpy out,
             # one utterance per call, fully synchronous (H2D + forward + D2H per call)

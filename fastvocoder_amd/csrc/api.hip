@@ -6,6 +6,8 @@
 #include <stdlib.h>
 
 #include <string>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "fv_internal.h"
@@ -557,9 +559,43 @@ static int check_conv_args(int Cin, int Cout, int k, int dil) {
 
 using namespace fv;
 
+namespace fv {
+int allow_dynamic_lds(const void* kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return 0;
+    struct Grant { const void* kernel; int device; size_t bytes; };
+    static std::mutex mu;
+    static std::vector<Grant> granted;                               // a few dozen kernels per device at most
+    int dev = 0;
+    FV_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    for (Grant& g : granted)
+        if (g.kernel == kernel && g.device == dev) {
+            if (g.bytes >= bytes) return 0;
+            FV_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            g.bytes = bytes;
+            return 0;
+        }
+    FV_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    granted.push_back({kernel, dev, bytes});
+    return 0;
+}
+
+int device_cu_count() {
+    static int cus = 0;   // one device model per process (the boxes hold eight identical GPUs)
+    if (!cus) {
+        int dev = 0, v = 0;
+        cus = hipGetDevice(&dev) == hipSuccess &&
+                      hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0
+                  ? v : 256;
+    }
+    return cus;
+}
+}  // namespace fv
+
 extern "C" {
 
 int fv_version(void) { return FV_ABI_VERSION; }
+
 
 #ifndef FV_BUILD_ID
 #define FV_BUILD_ID "unknown"

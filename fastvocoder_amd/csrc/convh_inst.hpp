@@ -9,8 +9,7 @@ int launch_convh_geom(const PairParams& p, int dil, size_t lds, hipStream_t s) {
 #define FV_CONVH(DIL)                                                                          \
     do {                                                                                       \
         auto kern = convh_kernel<CG, NFW, DIL>;                                                \
-        FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                        \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
+        if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc; \
         hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(512), lds, s, p);                          \
     } while (0)
     switch (dil) {

@@ -68,6 +68,8 @@ struct ConvHGeom {
     static constexpr int NMT = C / 64;
     static constexpr int RAWST = NST >= 4 ? NST - 4 : 0; // stage at which the next tile's raw window is requested
     static constexpr int NRAW = XR * 8;
+    static constexpr int RESST = NST - 2;                // ... this tile's bias and residual
+    static constexpr int NRES = 8 + 8 * NFW;
     static_assert(NSTEP % 2 == 0 && NST >= 3 && NFW % 2 == 0, "stages of two steps, at least three");
     static_assert(((CG - 1) * 4 * XRP + (KT - 1) * DIL + 16 * (NFW - 1)) * 16 + 16 < 65536, "ds_read immediate range");
 };
@@ -185,12 +187,19 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
         // before is free: request the stage three ahead into it (this tile's, or the next item's first stages)
         auto entry = [&](auto GC) {
             constexpr int GS = decltype(GC)::value;
-            if constexpr (GS >= 3) {
-                // younger loads than this stage's DMA: the DMAs of the two stages after it (+ the raw window
-                // if it was requested at one of the three entries in between)
-                constexpr bool raw_between = G::RAWST >= GS - 3 && G::RAWST <= GS - 1;
-                wait_vm<4 + (raw_between ? G::NRAW : 0)>();
+            {
+                // This stage's DMA was issued three entries ago (for the first three stages: in the previous tile, or
+                // the run's prologue).  Loads return in order, so it has landed once at most as many loads are
+                // outstanding as were issued AFTER it: the DMAs of the two entries in between (4), plus the raw
+                // window / the residual if they were requested at one of the three entries in between.  (Stores in
+                // flight only make the count larger: conservative.)
+                constexpr bool raw_between = GS >= 3 && G::RAWST >= GS - 3 && G::RAWST <= GS - 1;
+                constexpr bool res_between = GS >= 3 && G::RESST >= GS - 3 && G::RESST <= GS - 1;
+                wait_vm<4 + (raw_between ? G::NRAW : 0) + (res_between ? G::NRES : 0)>();
             }
+#ifdef FV_CONVH_EXP
+            if (!(p.dbg & 32))
+#endif
             pair_barrier();
             constexpr int NS = GS + 3;
             unsigned off;
@@ -199,6 +208,24 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
             convh_dma_stage<G>(rw, ring, (g0 + NS) & 3, off, wave, lane);
             if constexpr (GS == G::RAWST)
                 convh_load_raw<G>(raw, mb.x + nb * ustride, p.T, nnt * G::NTC - G::P, tid, new_win && !(p.dbg & 1));
+            if constexpr (GS == G::RESST) {
+                // bias and residual of THIS tile: in flight during the last two stages
+                const __amdgpu_buffer_rsrc_t rb = make_rsrc(mb.b1 ? mb.b1 : mb.w1, mb.b1 ? (unsigned)G::C * 4u : 0u);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bv[h][i] = buffer_load1(rb, (unsigned)(64 * mtile + row0 + 16 * h + i) * 4u);
+                const __amdgpu_buffer_rsrc_t rr = make_rsrc(mb.res ? mb.res + b * ustride : mb.w1, mb.res ? ubytes : 0u);
+#pragma unroll
+                for (int f = 0; f < G::NFW; ++f) {
+                    const int t = t0 + col0 + f * 16;
+                    voff[f] = t < p.T ? (unsigned)((64 * mtile + row0) * p.T + t) * 4u : kOutOfRange;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) res[h][f][i] = buffer_load1s(rr, voff[f], (unsigned)(16 * h + i) * t4);
+                }
+            }
         };
         auto fetch_a = [&](auto SC, f16x8 (&dst)[2][2]) {
             constexpr int S = decltype(SC)::value;
@@ -237,6 +264,9 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
                 fetch_b(IntC<SN>{}, IntC<PN>{}, bbuf[UN & 1]);
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifdef FV_CONVH_EXP
+            if (!(p.dbg & 4))
+#endif
             {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
@@ -259,26 +289,9 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        // ---- epilogue: residual, image of the next window, stores -------------------------------------------
-        {
-            const __amdgpu_buffer_rsrc_t rb = make_rsrc(mb.b1 ? mb.b1 : mb.w1, mb.b1 ? (unsigned)G::C * 4u : 0u);
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) bv[h][i] = buffer_load1(rb, (unsigned)(64 * mtile + row0 + 16 * h + i) * 4u);
-            const __amdgpu_buffer_rsrc_t rr = make_rsrc(mb.res ? mb.res + b * ustride : mb.w1, mb.res ? ubytes : 0u);
-#pragma unroll
-            for (int f = 0; f < G::NFW; ++f) {
-                const int t = t0 + col0 + f * 16;
-                voff[f] = t < p.T ? (unsigned)((64 * mtile + row0) * p.T + t) * 4u : kOutOfRange;
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) res[h][f][i] = buffer_load1s(rr, voff[f], (unsigned)(16 * h + i) * t4);
-            }
-        }
+        // ---- epilogue: image of the next window, stores ------------------------------------------------------
         pair_barrier();                                  // every wave is done with the image (and with the last ring reads)
-        pair_wait_vm0();                                 // raw window, residual; the next stages' DMAs
+        wait_vm<2>();                                    // raw window, residual: everything but the DMA of the last entry
         if (new_win && !(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid);
         const bool fin = mb.add1 != nullptr;
 #pragma unroll

@@ -6,20 +6,15 @@
 
 namespace fv {
 
-extern template int launch_convh_geom<2, 4>(const PairParams&, int, size_t, hipStream_t);
 extern template int launch_convh_geom<4, 2>(const PairParams&, int, size_t, hipStream_t);
 extern template int launch_convh_geom<2, 2>(const PairParams&, int, size_t, hipStream_t);
 
-static int convh_nfw(int C) {
-    const char* e = getenv("FV_CONVH_NFW");
-    return C == 64 ? (e && atoi(e) == 4 ? 4 : 2) : 2;     // measured at T = 40 000, B = 1: 128-column tiles 65 us per pair, 256: 72
-}
 
 // run-time mirror of ConvHGeom<>
 ConvHShape convh_shape(int C, int k, int dil) {
     ConvHShape g = {};
     g.CG = C / 32;
-    g.NFW = convh_nfw(C);
+    g.NFW = 2;
     g.NTC = 16 * g.NFW * 4;
     g.NSTEP = k * g.CG;
     g.NST = g.NSTEP / 2;
@@ -68,10 +63,7 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     p.bias_off = 0;                    // (biases are read from global memory in the epilogue)
     const size_t lds = floats * 4;
     if (lds > 160 * 1024) return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: %zu bytes of LDS", lds);
-    int cus = 256, dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-        cus = v;
+    const int cus = device_cu_count();
     const char* force = getenv("FV_CONVH_BLOCKS");
     long long nblk = force && atoi(force) > 0 ? atoi(force) : cus;     // one 8-wave block per CU
     if (nblk > items) nblk = items;
@@ -79,8 +71,7 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     p.dbg = getenv("FV_PAIR_DBG") ? atoi(getenv("FV_PAIR_DBG")) : 0;
     p.trace = nullptr;
     profile_begin(s);
-    const int rc = C == 128 ? launch_convh_geom<4, 2>(p, dil, lds, s)
-                   : convh_nfw(C) == 4 ? launch_convh_geom<2, 4>(p, dil, lds, s) : launch_convh_geom<2, 2>(p, dil, lds, s);
+    const int rc = C == 128 ? launch_convh_geom<4, 2>(p, dil, lds, s) : launch_convh_geom<2, 2>(p, dil, lds, s);
     profile_end(s, C == 64 ? FV_KERNEL_CONVH64 : FV_KERNEL_CONVH128, flops, bytes);
     return rc;
 }

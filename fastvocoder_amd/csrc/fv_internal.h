@@ -126,6 +126,11 @@ struct Sum3Params {
 };
 int launch_conv_sum3(ConvParams* ps, hipStream_t stream);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and size (a driver call per launch otherwise:
+// tens of microseconds of host time on a path whose whole forward is under a millisecond); api.hip
+int allow_dynamic_lds(const void* kernel, size_t bytes);
+int device_cu_count();
+
 // ---- fused ResBlock1 pairs (pair_kernels.hpp / pair_launch.hip) ---------------------------------------
 // one ResBlock's pair (a "member" of the launch)
 struct PairMember {

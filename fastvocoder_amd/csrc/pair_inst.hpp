@@ -10,15 +10,11 @@ int launch_pair_geom(const PairParams& p, int dil, size_t lds, hipStream_t s) {
     do {                                                                                        \
         if (p.sum) {                                                                            \
             auto kern = pair_sum_kernel<MH, NF, NG, DIL>;                                       \
-            if (lds > 64 * 1024)                                                                \
-                FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                 \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc; \
             hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(64 * MH * NG), lds, s, p);              \
         } else {                                                                                \
             auto kern = pair_kernel<MH, NF, NG, DIL>;                                           \
-            if (lds > 64 * 1024)                                                                \
-                FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                 \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc; \
             hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(64 * MH * NG), lds, s, p);              \
         }                                                                                       \
     } while (0)

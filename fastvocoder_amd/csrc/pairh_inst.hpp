@@ -9,9 +9,7 @@ int launch_pairh_geom(const PairParams& p, int dil, size_t lds, hipStream_t s) {
 #define FV_PAIRH(DIL)                                                                          \
     do {                                                                                       \
         auto kern = pairh_kernel<MH, NF, NG, DIL>;                                             \
-        if (lds > 64 * 1024)                                                                   \
-            FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                    \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc; \
         hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(64 * NG), lds, s, p);                      \
     } while (0)
     switch (dil) {
