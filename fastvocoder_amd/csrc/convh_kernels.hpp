@@ -167,8 +167,10 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
         convh_dma_stage<G>(rw, ring, st, (unsigned)(mtile * G::WTILE + st * G::STAGE_BYTES), wave, lane);
     pair_wait_vm0();
     if (!(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid);
-    for (;;) {
+    pair_stamp(p, 8, wave, lane, 7, 13);                 // (tuning aid, -DFV_PAIR_TRACE) prologue done
+    for (int it = 0;; ++it) {
         const int t0 = ntile * G::NTC;
+        pair_stamp(p, 8, wave, lane, it, 0);
         const int nitem = item + 1;
         const bool more = nitem < hi_item;
         int nb = b, nnt = ntile, nmt = mtile;
@@ -250,6 +252,7 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
         };
 
         entry(IntC<0>{});
+        pair_stamp(p, 8, wave, lane, it, 1);
         fetch_a(IntC<0>{}, abuf[0]);
         fetch_b(IntC<0>{}, IntC<0>{}, bbuf[0]);
         __builtin_amdgcn_sched_barrier(0);
@@ -290,9 +293,13 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
             __builtin_amdgcn_sched_barrier(0);
         });
         // ---- epilogue: image of the next window, stores ------------------------------------------------------
+        pair_stamp(p, 8, wave, lane, it, 2);
         pair_barrier();                                  // every wave is done with the image (and with the last ring reads)
+        pair_stamp(p, 8, wave, lane, it, 3);
         wait_vm<2>();                                    // raw window, residual: everything but the DMA of the last entry
+        pair_stamp(p, 8, wave, lane, it, 4);
         if (new_win && !(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid);
+        pair_stamp(p, 8, wave, lane, it, 5);
         const bool fin = mb.add1 != nullptr;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -330,6 +337,7 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
                 const int t = t0 + col0 + f * 16;
                 pair_store(p, mb.y, mb.y_act, G::C, b, 64 * mtile + row0 + 16 * h, t, t < p.T && !(p.dbg & 8), v, fin);
             }
+        pair_stamp(p, 8, wave, lane, it, 6);
         if (!more) break;
         g0 += G::NST;
         item = nitem;
@@ -356,6 +364,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    pair_stamp(p, 8, wave, lane, 7, 15);
     long long total = 0;
     for (int m = 0; m < p.n_members; ++m) total += (long long)p.m[m].n_items * p.m[m].cost;
     long long base = 0;
@@ -369,6 +378,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         convh_run_any<CG, NFW, DIL>(p, m, lo, hi, smem, wave, lane, first);
         first = false;
     }
+    pair_stamp(p, 8, wave, lane, 7, 14);
 }
 
 }  // namespace fv

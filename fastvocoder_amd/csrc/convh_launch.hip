@@ -69,7 +69,7 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
     p.dbg = getenv("FV_PAIR_DBG") ? atoi(getenv("FV_PAIR_DBG")) : 0;
-    p.trace = nullptr;
+    p.trace = getenv("FV_PAIR_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("FV_PAIR_TRACE_PTR"), nullptr, 0)) : nullptr;
     profile_begin(s);
     const int rc = C == 128 ? launch_convh_geom<4, 2>(p, dil, lds, s) : launch_convh_geom<2, 2>(p, dil, lds, s);
     profile_end(s, C == 64 ? FV_KERNEL_CONVH64 : FV_KERNEL_CONVH128, flops, bytes);

@@ -397,6 +397,23 @@ def test_mrf_schedules_agree(monkeypatch, mrf, carrier):
     assert np.abs(got - ref).max() <= 2e-6
 
 
+@pytest.mark.parametrize("prec,pair", [("f32", "1"), ("f32", "0"), ("split", "0")])
+def test_arithmetic_switches_agree(monkeypatch, prec, pair):
+    """FV_PAIR_PREC=f32 (exact-fp32 MFMA on every stage) and FV_PAIR=0 (no fused ResBlock pairs: round-1 conv-by-conv
+    path) give the default path's result up to fp32 summation noise."""
+    cfg = cases.load_conf("conf/hifigan/light.yaml")
+    x = torch.from_numpy(seeded_mel(200, seed=23, batch=2)).to(_dev())
+    ref_model, _ = _model("hifigan", cfg, seed=0)
+    with torch.no_grad():
+        ref = ref_model(x).cpu().numpy()
+    monkeypatch.setenv("FV_PAIR_PREC", prec)
+    monkeypatch.setenv("FV_PAIR", pair)
+    m, _ = _model("hifigan", cfg, seed=0)
+    with torch.no_grad():
+        got = m(x).cpu().numpy()
+    assert np.abs(got - ref).max() <= 4e-6
+
+
 def test_conv_transpose_no_padding_is_overlap_add():
     """ConvTranspose1d(Cout=1, k=L, stride=L/2, pad=0) == linear + overlap_and_add."""
     rng = np.random.RandomState(5)

@@ -168,6 +168,14 @@ def test_c_abi_library_exports_every_declared_symbol():
     # build provenance: the binary carries the hash of the sources it was built from
     assert _native.lib().fv_build_id().decode() == _native.source_hash() == _native.built_id()
     assert _native.lib().fv_packed_pair_floats(32, 11) == 32 * 32 * 11
+    # split-f16 images: C = 16: (k+1)/2 K steps x 2 KB; C = 32: k steps x 2 row halves; C = 64 / 128: row tiles x k C/32 steps x 8 KB
+    L = _native.lib()
+    assert L.fv_packed_pair_floats_ex(16, 11, _native.PAIR_SPLIT_F16) == 6 * 512
+    assert L.fv_packed_pair_floats_ex(32, 7, _native.PAIR_SPLIT_F16) == 7 * 2 * 512
+    assert L.fv_packed_pair_floats_ex(64, 11, _native.PAIR_SPLIT_F16) == 22 * 2048
+    assert L.fv_packed_pair_floats_ex(128, 3, _native.PAIR_SPLIT_F16) == 2 * 12 * 2048
+    assert L.fv_packed_pair_floats_ex(48, 3, _native.PAIR_SPLIT_F16) == 0
+    assert L.fv_packed_pair_floats_ex(32, 11, _native.PAIR_F32) == 32 * 32 * 11
     # host-only entry points that need no device
     assert _native.lib().fv_packed_conv1d_floats(128, 128, 11) == 128 * 11 * 128
     # k = 2*stride, Cout % 32 == 0: phase-major form, 2 taps per phase (3 in the co-major form)
@@ -237,6 +245,20 @@ def test_plan_shape_inference_without_gpu():
     assert L.fv_plan_output_shape(h, 100, ctypes.byref(c), ctypes.byref(n)) != 0
     assert b"channels" in L.fv_last_error()
     L.fv_plan_destroy(h)
+    # ResBlock pairs / split-f16 convs keep the length; a wide pair needs its scratch slot, and only a wide one
+    S = _native.PAIR_SPLIT_F16
+    w = L.fv_plan_create(64)
+    assert L.fv_plan_add_conv1d_split_f16(w, 0, 2, -1, -1, -1, -1, dummy, None, 64, 11, 5, 0.1, 1.0, 0, 1.0) == 0
+    assert L.fv_plan_add_conv1d_split_f16(w, 2, 3, -1, 0, -1, -1, dummy, None, 64, 11, 1, 0.1, 1.0, 0, 1.0) == 0
+    assert L.fv_plan_add_resblock_pair_ex(w, 3, 1, -1, 4, 0, 2, dummy, dummy, None, None, 64, 3, 3, 0.1, 3.0, 0, 0.1, S) == 0
+    assert L.fv_plan_output_shape(w, 333, ctypes.byref(c), ctypes.byref(n)) == 0
+    assert (c.value, n.value) == (64, 333)
+    assert L.fv_plan_add_resblock_pair_ex(w, 3, 1, -1, -1, -1, -1, dummy, dummy, None, None, 64, 3, 3, 0.1, 1.0, 0, 1.0, S) != 0
+    assert b"scratch" in L.fv_last_error()
+    assert L.fv_plan_add_resblock_pair_ex(w, 3, 1, -1, 4, -1, -1, dummy, dummy, None, None, 16, 3, 3, 0.1, 1.0, 0, 1.0, S) != 0
+    assert L.fv_plan_add_conv1d_split_f16(w, 0, 2, -1, -1, -1, -1, dummy, None, 32, 11, 5, 0.1, 1.0, 0, 1.0) != 0
+    assert b"64 or 128" in L.fv_last_error()
+    L.fv_plan_destroy(w)
 
 
 def test_encode_16bits_matches_reference_semantics():
