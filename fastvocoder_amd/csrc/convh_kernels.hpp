@@ -292,14 +292,12 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        // ---- epilogue: image of the next window, stores ------------------------------------------------------
+        // ---- epilogue: outputs, then the image of the next window ------------------------------------------------------
         pair_stamp(p, 8, wave, lane, it, 2);
         pair_barrier();                                  // every wave is done with the image (and with the last ring reads)
         pair_stamp(p, 8, wave, lane, it, 3);
         wait_vm<2>();                                    // raw window, residual: everything but the DMA of the last entry
         pair_stamp(p, 8, wave, lane, it, 4);
-        if (new_win && !(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid);
-        pair_stamp(p, 8, wave, lane, it, 5);
         const bool fin = mb.add1 != nullptr;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -337,6 +335,10 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
                 const int t = t0 + col0 + f * 16;
                 pair_store(p, mb.y, mb.y_act, G::C, b, 64 * mtile + row0 + 16 * h, t, t < p.T && !(p.dbg & 8), v, fin);
             }
+        pair_stamp(p, 8, wave, lane, it, 5);
+        // the stores first, the conversion of the next window after them: a vmcnt wait cannot tell stores from loads,
+        // the next tile's first stage waits would otherwise sit behind the stores' round trip
+        if (new_win && !(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid);
         pair_stamp(p, 8, wave, lane, it, 6);
         if (!more) break;
         g0 += G::NST;

@@ -275,6 +275,36 @@ def test_conv1d_split_f16_vs_oracle(case):
         _native.conv1d_split_f16([torch.zeros((1, 32, 16), device=_dev())], P[:1], [None], [ks[0]], dil)
 
 
+@pytest.mark.parametrize("blocks", [1, 3, 7])
+def test_persistent_blocks_walk_many_tiles_and_cross_members(monkeypatch, blocks):
+    """With few persistent blocks every block walks several tiles and crosses from one member to the next (the small
+    cases above give each block one tile): forced grid sizes, same results bit for bit as the full grid."""
+    rng = np.random.RandomState(77)
+    ks = (7, 11, 3)
+    for C, T, dil in ((16, 1500, 3), (32, 900, 5), (64, 1030, 3), (128, 520, 1)):
+        ms = [_member(rng, 2, C, T, k, True) for k in ks]
+        xs = [_t(m[0]) for m in ms]
+        h1, h2 = [_native.pack_pair(_t(m[1]), SPLIT) for m in ms], [_native.pack_pair(_t(m[3]), SPLIT) for m in ms]
+        b1s, b2s = [_t(m[2]) for m in ms], [_t(m[4]) for m in ms]
+        full = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, prec=SPLIT)
+        refs = [_pair_ref(x, w1, b1, w2, b2, dil, 0.1) for x, w1, b1, w2, b2 in ms]
+        monkeypatch.setenv("FV_PAIR_BLOCKS", str(blocks))
+        monkeypatch.setenv("FV_CONVH_BLOCKS", str(blocks))
+        few = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, prec=SPLIT)
+        monkeypatch.delenv("FV_PAIR_BLOCKS")
+        monkeypatch.delenv("FV_CONVH_BLOCKS")
+        for yf, yw, ref in zip(full, few, refs):
+            assert _rel(yw, ref) <= 4e-6
+            assert torch.equal(yf, yw)
+        if C <= 32:                                  # the fp32 kernels share the partition code
+            f1, f2 = [_native.pack_pair(_t(m[1])) for m in ms], [_native.pack_pair(_t(m[3])) for m in ms]
+            monkeypatch.setenv("FV_PAIR_BLOCKS", str(blocks))
+            y32 = _native.resblock1_fused(xs, f1, f2, b1s, b2s, list(ks), dil, 0.1)
+            monkeypatch.delenv("FV_PAIR_BLOCKS")
+            for y, ref in zip(y32, refs):
+                assert _rel(y, ref) <= 2e-5
+
+
 def test_pair_results_do_not_depend_on_the_batch():
     """Bit-identity: an utterance gives the same bits alone and inside a batch (what lets a batch be
     sharded over GPUs), for the plain and the sum kernels, on both channel counts."""
