@@ -580,6 +580,12 @@ int allow_dynamic_lds(const void* kernel, size_t bytes) {
     return 0;
 }
 
+int tuning_dbg_flags() {
+    const char* on = getenv("FV_TUNING");
+    const char* d = getenv("FV_PAIR_DBG");
+    return on && atoi(on) == 1 && d ? atoi(d) : 0;
+}
+
 int device_cu_count() {
     static int cus = 0;   // one device model per process (the boxes hold eight identical GPUs)
     if (!cus) {

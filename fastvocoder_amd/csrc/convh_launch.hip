@@ -68,7 +68,7 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     long long nblk = force && atoi(force) > 0 ? atoi(force) : cus;     // one 8-wave block per CU
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
-    p.dbg = getenv("FV_PAIR_DBG") ? atoi(getenv("FV_PAIR_DBG")) : 0;
+    p.dbg = tuning_dbg_flags();
     p.trace = getenv("FV_PAIR_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("FV_PAIR_TRACE_PTR"), nullptr, 0)) : nullptr;
     profile_begin(s);
     const int rc = C == 128 ? launch_convh_geom<4, 2>(p, dil, lds, s) : launch_convh_geom<2, 2>(p, dil, lds, s);

@@ -130,6 +130,9 @@ int launch_conv_sum3(ConvParams* ps, hipStream_t stream);
 // tens of microseconds of host time on a path whose whole forward is under a millisecond); api.hip
 int allow_dynamic_lds(const void* kernel, size_t bytes);
 int device_cu_count();
+// FV_PAIR_DBG: ablation switches of the persistent kernels (timing experiments; the results are WRONG).  Honoured only
+// together with FV_TUNING=1 so that a stray environment variable cannot corrupt a product run.
+int tuning_dbg_flags();
 
 // ---- fused ResBlock1 pairs (pair_kernels.hpp / pair_launch.hip) ---------------------------------------
 // one ResBlock's pair (a "member" of the launch)

@@ -123,7 +123,7 @@ static int launch_pairs_split(PairParams p, int C, int dil, hipStream_t s) {
     long long nblk = force && atoi(force) > 0 ? atoi(force) : (C == 16 ? 2LL : 1LL) * num_cus();
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
-    p.dbg = getenv("FV_PAIR_DBG") ? atoi(getenv("FV_PAIR_DBG")) : 0;
+    p.dbg = tuning_dbg_flags();
     p.trace = nullptr;
     profile_begin(s);
     const int rc = C == 16 ? launch_pairh_geom<1, 4, 4>(p, dil, lds, s) : launch_pairh_geom<2, 1, 8>(p, dil, lds, s);
@@ -216,7 +216,7 @@ int launch_pairs(PairParams p, int C, int dil, hipStream_t s) {
     long long nblk = force && atoi(force) > 0 ? atoi(force) : (long long)per_cu * num_cus();
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
-    p.dbg = getenv("FV_PAIR_DBG") ? atoi(getenv("FV_PAIR_DBG")) : 0;
+    p.dbg = tuning_dbg_flags();
     p.trace = getenv("FV_PAIR_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("FV_PAIR_TRACE_PTR"), nullptr, 0)) : nullptr;
 
     profile_begin(s);

@@ -6,7 +6,7 @@ timeout 300 python tools/pair_bench.py 16 240000 1 split 2>&1 | grep -v amdgpu.i
 timeout 300 python tools/pair_bench.py 16 240000 1 f32 2>&1 | grep -v amdgpu.ids | grep -v member >> gpurun_out/split_bench.log
 timeout 300 python tools/pair_bench.py 32 120000 1 split 2>&1 | grep -v amdgpu.ids >> gpurun_out/split_bench.log
 timeout 300 python tools/pair_bench.py 32 120000 1 f32 2>&1 | grep -v amdgpu.ids | grep -v member >> gpurun_out/split_bench.log
-for d in 2 4 6 8; do FV_PAIR_DBG=$d timeout 300 python tools/pair_bench.py 32 120000 1 split 2>&1 | grep "pairs dil=5" >> gpurun_out/split_bench.log; done
+for d in 2 4 6 8; do FV_TUNING=1 FV_PAIR_DBG=$d timeout 300 python tools/pair_bench.py 32 120000 1 split 2>&1 | grep "pairs dil=5" >> gpurun_out/split_bench.log; done
 for sk in 5 8; do FV_PAIRH_SKEL=$sk timeout 300 python tools/pair_bench.py 16 240000 1 split 2>&1 | grep "pairs dil" | sed "s/^/skel=$sk /" >> gpurun_out/split_bench.log; done
 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/split_bench_line.json 2> gpurun_out/split_bench_line.err
 FV_PAIR_PREC=f32 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/f32_bench_line.json 2>/dev/null
