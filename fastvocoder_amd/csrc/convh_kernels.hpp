@@ -183,7 +183,7 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
             for (int f = 0; f < G::NFW; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
         float res[2][G::NFW][4], bv[2][4];
         unsigned voff[G::NFW];
-        f16x8 abuf[2][2][2], bbuf[2][2][2];
+        f16x8 abuf[2][2][2], bbuf[3][2][2];         // A one group ahead, B two (from the image: no ring slot involved)
 
         // ---- stage entry: the stage's weights are in its ring slot for every wave; the slot of the stage
         // before is free: request the stage three ahead into it (this tile's, or the next item's first stages)
@@ -255,6 +255,7 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
         pair_stamp(p, 8, wave, lane, it, 1);
         fetch_a(IntC<0>{}, abuf[0]);
         fetch_b(IntC<0>{}, IntC<0>{}, bbuf[0]);
+        fetch_b(IntC<1 / G::NP>{}, IntC<1 % G::NP>{}, bbuf[1]);
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, G::NUNIT>([&](auto UC) {
             constexpr int U = decltype(UC)::value;
@@ -264,8 +265,8 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
                 // the next group starts a new stage: take its barrier now, then prefetch from its slot
                 if constexpr (PN == 0 && SN % 2 == 0) entry(IntC<SN / 2>{});
                 if constexpr (PN == 0) fetch_a(IntC<SN>{}, abuf[SN & 1]);
-                fetch_b(IntC<SN>{}, IntC<PN>{}, bbuf[UN & 1]);
             }
+            if constexpr (U + 2 < G::NUNIT) fetch_b(IntC<(U + 2) / G::NP>{}, IntC<(U + 2) % G::NP>{}, bbuf[(U + 2) % 3]);
             __builtin_amdgcn_sched_barrier(0);
 #ifdef FV_CONVH_EXP
             if (!(p.dbg & 4))
@@ -275,19 +276,19 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int e = 0; e < 2; ++e)
-                        hi[h][2 * PP + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[S & 1][h][0], bbuf[U & 1][e][0],
+                        hi[h][2 * PP + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[S & 1][h][0], bbuf[U % 3][e][0],
                                                                                    hi[h][2 * PP + e], 0, 0, 0);
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int e = 0; e < 2; ++e)
-                        lo[h][2 * PP + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[S & 1][h][0], bbuf[U & 1][e][1],
+                        lo[h][2 * PP + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[S & 1][h][0], bbuf[U % 3][e][1],
                                                                                    lo[h][2 * PP + e], 0, 0, 0);
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int e = 0; e < 2; ++e)
-                        lo[h][2 * PP + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[S & 1][h][1], bbuf[U & 1][e][0],
+                        lo[h][2 * PP + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[S & 1][h][1], bbuf[U % 3][e][0],
                                                                                    lo[h][2 * PP + e], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
