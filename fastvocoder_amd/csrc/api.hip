@@ -761,7 +761,8 @@ int fv_conv_transpose1d_fused(const float* x, const float* packed, const float* 
                               void* stream) {
     if (int rc = check_conv_args(Cin, Cout, k, 1)) return rc;
     if (!x || !packed || !y) return fail(FV_ERR_INVALID_ARG, "conv_transpose1d: null tensor");
-    if (stride <= 0 || pad < 0 || out_pad < 0 || out_pad >= stride + (stride == 1))
+    // out_pad in [-stride, stride): negative values trim the tail (CausalConvTranspose1d, modules.py:297-317: -stride)
+    if (stride <= 0 || pad < 0 || out_pad < -stride || out_pad >= stride + (stride == 1))
         return fail(FV_ERR_INVALID_ARG, "conv_transpose1d: stride=%d pad=%d out_pad=%d", stride, pad, out_pad);
     if (x == y || x == y_act || (y_act && y_act == y))
         return fail(FV_ERR_INVALID_ARG, "conv_transpose1d: y / y_act must not alias x or each other");
@@ -942,7 +943,7 @@ int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot, int y_
                                  float act_slope) {
     if (!plan || !packed) return fail(FV_ERR_INVALID_ARG, "plan_add_conv_transpose1d: null");
     if (int rc = check_conv_args(Cin, Cout, k, 1)) return rc;
-    if (stride <= 0 || pad < 0 || out_pad < 0)
+    if (stride <= 0 || pad < 0 || out_pad < -stride)
         return fail(FV_ERR_INVALID_ARG, "convT stride=%d pad=%d out_pad=%d", stride, pad, out_pad);
     if (int rc = check_slot(x_slot, false)) return rc;
     if (int rc = check_slot(y_slot, false)) return rc;

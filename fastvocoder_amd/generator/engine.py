@@ -212,8 +212,9 @@ class PlanBuilder:
                              channels=c1.in_channels, dil=c1.dilation[0], members=ms, out_div=float(out_div),
                              post=post))
 
-    def conv_transpose(self, convt, src, dst, pre_slope=1.0, post=POST_NONE):
-        """Record a torch.nn.ConvTranspose1d container (polyphase form)."""
+    def conv_transpose(self, convt, src, dst, pre_slope=1.0, post=POST_NONE, trim=0):
+        """Record a torch.nn.ConvTranspose1d container (polyphase form); ``trim``: samples dropped from the end of
+        the output (CausalConvTranspose1d: its stride)."""
         if convt.groups != 1 or convt.dilation[0] != 1:
             raise _native.NativeError("only dense, undilated ConvTranspose1d layers exist on this path")
         k, s = convt.kernel_size[0], convt.stride[0]
@@ -222,7 +223,7 @@ class PlanBuilder:
                              pre_slope=float(pre_slope),
                              packed=_native.pack_conv_transpose1d(effective_weight(convt), s, p),
                              bias=self._bias(convt), cin=convt.in_channels, cout=convt.out_channels,
-                             k=k, stride=s, pad=p, out_pad=op, post=post))
+                             k=k, stride=s, pad=p, out_pad=op - int(trim), post=post))
 
     def upsample_conv(self, layer, src, dst, pre_slope=1.0, post=POST_NONE):
         """Record an UpsampleLayer container (nearest-repeat x rate, then its Conv1d)."""

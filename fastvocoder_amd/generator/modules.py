@@ -335,6 +335,24 @@ class BasisSignalLayer(NativeModule):
         return out[:, 0, :]
 
 
+class CausalConvTranspose1d(NativeModule):
+    """Drop-in for the reference ``CausalConvTranspose1d`` (modules.py:297-317): ``ConvTranspose1d(kernel_size, stride)``
+    without its last ``stride`` output samples.  None of the reference's generators instantiates it; it exists
+    here for completeness of the module surface (same ``deconv.weight`` / ``deconv.bias`` keys).  The tail is
+    never computed: the transposed conv runs with ``out_pad = -stride`` (include/fastvocoder_hip.h)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, bias=True):
+        super().__init__()
+        self.deconv = torch.nn.ConvTranspose1d(in_channels, out_channels, kernel_size, stride, bias=bias)
+        self.stride = stride
+        self.in_channels = in_channels
+
+    def forward(self, x):
+        x = self._prepare(x)
+        return self._plan("forward", lambda pb: pb.conv_transpose(self.deconv, SLOT_IN, SLOT_OUT, trim=self.stride),
+                          self.in_channels).run(x)
+
+
 class UpsampleLayer(NativeModule):
     """Nearest-repeat + Conv1d upsampler (reference modules.py:135-177: ``Stretch2d`` then
     ``conv``), chosen by ``transposedconv: False``.  The repeated signal is never built:

@@ -232,7 +232,8 @@ int fv_conv1d_2src_fused(const float* x, const float* x2, const float* packed, c
  * with Cout = 1, k = L, stride = L/2, pad = 0, packed from W^T -- the
  * F.linear + overlap_and_add pair of BasisSignalLayer (modules.py:264-267,
  * :34-73).  x [B,Cin,Tin] -> y [B,Cout,Tout],
- * Tout = (Tin-1)*stride - 2*pad + k + out_pad.
+ * Tout = (Tin-1)*stride - 2*pad + k + out_pad; -stride <= out_pad < stride: a negative out_pad drops
+ * the tail of the output -- CausalConvTranspose1d (modules.py:297-317) is pad = 0, out_pad = -stride.
  */
 int fv_conv_transpose1d_fused(const float* x, const float* packed, const float* bias,
                               float* y, float* y_act, int B, int Cin, int Cout, int Tin,

@@ -264,6 +264,22 @@ def extra_fixtures(out):
                 rec[f"rb1_c{ch}_k{k}_params"] = np.concatenate([tonp(p).reshape(-1) for p in rb.parameters()])
                 rec[f"rb1_c{ch}_k{k}_out"] = tonp(rb(torch.from_numpy(x)))
     np.savez_compressed(os.path.join(out, "blocks_t52.npz"), **rec)
+
+    # CausalConvTranspose1d (reference modules.py:297-317): ConvTranspose1d(k, stride, pad 0) minus its last `stride` samples
+    rng = np.random.RandomState(13)
+    rec = {}
+    with torch.no_grad():
+        for tag, cin, cout, k, s, T in (("a", 24, 12, 16, 8, 37), ("b", 64, 32, 6, 3, 50), ("c", 8, 4, 4, 2, 9)):
+            m = refmod.CausalConvTranspose1d(cin, cout, k, s)
+            for p in m.parameters():
+                p.copy_(torch.from_numpy(rng.uniform(-0.2, 0.2, size=tuple(p.shape)).astype(np.float32)))
+            x = rng.randn(2, cin, T).astype(np.float32)
+            rec[f"{tag}_shape"] = np.array([cin, cout, k, s], dtype=np.int64)
+            rec[f"{tag}_x"] = x
+            rec[f"{tag}_weight"] = tonp(m.deconv.weight)
+            rec[f"{tag}_bias"] = tonp(m.deconv.bias)
+            rec[f"{tag}_out"] = tonp(m(torch.from_numpy(x)))
+    np.savez_compressed(os.path.join(out, "causal_convt.npz"), **rec)
     print("extra fixtures written")
 
 

@@ -414,6 +414,22 @@ def test_arithmetic_switches_agree(monkeypatch, prec, pair):
     assert np.abs(got - ref).max() <= 4e-6
 
 
+def test_causal_conv_transpose_vs_reference_fixture(golden_dir):
+    """CausalConvTranspose1d (reference modules.py:297-317) against outputs of the reference module itself."""
+    from fastvocoder_amd.generator import modules as M
+    g = np.load(os.path.join(golden_dir, "causal_convt.npz"))
+    for tag in "abc":
+        cin, cout, k, s = (int(v) for v in g[f"{tag}_shape"])
+        m = M.CausalConvTranspose1d(cin, cout, k, s).to(_dev())
+        with torch.no_grad():
+            m.deconv.weight.copy_(torch.from_numpy(g[f"{tag}_weight"]))
+            m.deconv.bias.copy_(torch.from_numpy(g[f"{tag}_bias"]))
+        y = m(torch.from_numpy(g[f"{tag}_x"]).to(_dev()))
+        ref = g[f"{tag}_out"]
+        assert tuple(y.shape) == ref.shape and _rel(y, ref) <= 2e-5
+        assert sorted(m.state_dict()) == ["deconv.bias", "deconv.weight"]
+
+
 def test_conv_transpose_no_padding_is_overlap_add():
     """ConvTranspose1d(Cout=1, k=L, stride=L/2, pad=0) == linear + overlap_and_add."""
     rng = np.random.RandomState(5)
