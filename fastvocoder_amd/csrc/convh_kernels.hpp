@@ -105,10 +105,10 @@ __device__ __forceinline__ void convh_convert(const ConvHRaw<G>& r, char* ximg, 
         f16x8 h1, h2;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float v = act(r.v[q][j], slope);
+            const float v = split_act(r.v[q][j], slope);
             const _Float16 a = (_Float16)v;
             h1[j] = a;
-            h2[j] = (_Float16)((v - (float)a) * kSplitScale);
+            h2[j] = split_rem(v, a);
         }
         if (idx < G::XROWS * G::CB) {
             *reinterpret_cast<f16x8*>(ximg + (cb * G::XRP + row) * 16) = h1;

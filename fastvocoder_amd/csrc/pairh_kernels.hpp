@@ -38,6 +38,20 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr float kSplitScale = 2048.f, kSplitInv = 1.f / 2048.f;
 
+// The split runs once per operand element per tile and its VALU instructions cost matrix time, so:
+// leaky ReLU as mul + max without the canonicalising v_max hipcc puts in front of fmaxf, and the scaled remainder
+// (v - h1) * 2048 as ONE fused multiply-add on the f16 value (v_fma_mix_f32: the f16 -> f32 conversion is part of
+// the instruction).  Both are exact rewrites: v - h1 and the power-of-two scalings are exact in fp32.
+__device__ __forceinline__ float split_act(float v, float slope) {
+    const float t = v * slope;
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(t));
+    return r;
+}
+__device__ __forceinline__ _Float16 split_rem(float v, _Float16 h1) {
+    return (_Float16)fmaf((float)h1, -kSplitScale, v * kSplitScale);
+}
+
 template <int MH_, int NF_, int NG_, int KT_, int DIL_>
 struct PairHGeom {
     static constexpr int MH = MH_, NF = NF_, NG = NG_, KT = KT_, DIL = DIL_;
@@ -104,10 +118,10 @@ __device__ __forceinline__ void pairh_convert(const PairHRaw<G>& r, char* ximg, 
         f16x8 h1, h2;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float v = act(r.v[q][j], slope);
+            const float v = split_act(r.v[q][j], slope);
             const _Float16 a = (_Float16)v;
             h1[j] = a;
-            h2[j] = (_Float16)((v - (float)a) * kSplitScale);
+            h2[j] = split_rem(v, a);
         }
         if (idx < G::XROWS * PairHRaw<G>::CB) {
             *reinterpret_cast<f16x8*>(ximg + (cb * G::XRP + row) * 16) = h1;
@@ -305,11 +319,11 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
                     f16x4 h1, h2;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float v = act(fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[i], p.slope);
+                        float v = split_act(fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[i], p.slope);
                         v = ok ? v : 0.f;
                         const _Float16 a = (_Float16)v;
                         h1[i] = a;
-                        h2[i] = (_Float16)((v - (float)a) * kSplitScale);
+                        h2[i] = split_rem(v, a);
                     }
                     *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16)) = h1;
                     *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16) + G::MHALF) = h2;
