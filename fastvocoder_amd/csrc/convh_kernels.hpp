@@ -160,12 +160,15 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
     int b, ntile, mtile;
     decode(item, b, ntile, mtile);
     if (!first) pair_barrier();                         // everybody is done with the previous member's LDS
+    pair_stamp(p, 8, wave, lane, 7, 12);
     ConvHRaw<G> raw;
     convh_load_raw<G>(raw, mb.x + b * ustride, p.T, ntile * G::NTC - G::P, tid, true);
 #pragma unroll
     for (int st = 0; st < 3; ++st)
         convh_dma_stage<G>(rw, ring, st, (unsigned)(mtile * G::WTILE + st * G::STAGE_BYTES), wave, lane);
+    pair_stamp(p, 8, wave, lane, 7, 11);
     pair_wait_vm0();
+    pair_stamp(p, 8, wave, lane, 7, 10);
     if (!(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid);
     pair_stamp(p, 8, wave, lane, 7, 13);                 // (tuning aid, -DFV_PAIR_TRACE) prologue done
     for (int it = 0;; ++it) {
@@ -352,15 +355,6 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
     pair_wait_vm0();
 }
 
-template <int CG, int NFW, int DIL>
-__device__ __forceinline__ void convh_run_any(const PairParams& p, int m, int item0, int hi, float* smem, int wave,
-                                              int lane, bool first) {
-    const PairMember& mb = p.m[m];
-    if (mb.k == 11) convh_run_member<ConvHGeom<CG, NFW, 11, DIL>>(p, mb, item0, hi, smem, wave, lane, first);
-    else if (mb.k == 7) convh_run_member<ConvHGeom<CG, NFW, 7, DIL>>(p, mb, item0, hi, smem, wave, lane, first);
-    else convh_run_member<ConvHGeom<CG, NFW, 3, DIL>>(p, mb, item0, hi, smem, wave, lane, first);
-}
-
 // 8 waves per block, one block per CU (150-160 KB of LDS): 2 waves per SIMD, 256 VGPRs
 template <int CG, int NFW, int DIL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void convh_kernel(PairParams p) {
@@ -368,20 +362,42 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     pair_stamp(p, 8, wave, lane, 7, 15);
+    // Every scalar of the launch in ONE batch of kernarg loads.  Left to itself hipcc loads each field right before its
+    // first use: nine dependent s_load round trips (~500 cycles each) stood between kernel entry and the first tile
+    // (tools/convh_trace.py: 4.4-6.3k of a launch's ~60k cycles).
+    PairParams q;
+    q.n_members = p.n_members; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = p.out_div;
+    q.act_slope = p.act_slope; q.post = p.post; q.x_off = p.x_off; q.img_off = p.img_off; q.dbg = p.dbg; q.trace = p.trace;
+    int n_items[3], cost[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { n_items[m] = p.m[m].n_items; cost[m] = p.m[m].cost; }
+    asm volatile("" ::"s"(q.n_members), "s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.out_div), "s"(q.act_slope),
+                 "s"(q.post), "s"(q.x_off), "s"(q.img_off), "s"(q.dbg), "s"(q.trace), "s"(n_items[0]), "s"(n_items[1]),
+                 "s"(n_items[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]));
     long long total = 0;
-    for (int m = 0; m < p.n_members; ++m) total += (long long)p.m[m].n_items * p.m[m].cost;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_items[m] * cost[m] : 0;
     long long base = 0;
     bool first = true;
-    for (int m = 0; m < p.n_members; ++m) {
-        const int n = p.m[m].n_items;
-        const int lo = pair_share(blockIdx.x, total, base, p.m[m].cost, n, p.nblk);
-        const int hi = pair_share(blockIdx.x + 1, total, base, p.m[m].cost, n, p.nblk);
-        base += (long long)n * p.m[m].cost;
+    for (int m = 0; m < q.n_members; ++m) {
+        const int n = m == 0 ? n_items[0] : m == 1 ? n_items[1] : n_items[2];
+        const int cm = m == 0 ? cost[0] : m == 1 ? cost[1] : cost[2];
+        const int lo = pair_share(blockIdx.x, total, base, cm, n, q.nblk);
+        const int hi = pair_share(blockIdx.x + 1, total, base, cm, n, q.nblk);
+        base += (long long)n * cm;
         if (lo >= hi) continue;
-        convh_run_any<CG, NFW, DIL>(p, m, lo, hi, smem, wave, lane, first);
+        // ... and this member's pointers and sizes in one more
+        PairMember mb;
+        mb.x = p.m[m].x; mb.w1 = p.m[m].w1; mb.b1 = p.m[m].b1; mb.res = p.m[m].res; mb.add1 = p.m[m].add1;
+        mb.add2 = p.m[m].add2; mb.y = p.m[m].y; mb.y_act = p.m[m].y_act; mb.k = p.m[m].k; mb.n_tiles = p.m[m].n_tiles;
+        asm volatile("" ::"s"(mb.x), "s"(mb.w1), "s"(mb.b1), "s"(mb.res), "s"(mb.add1), "s"(mb.add2), "s"(mb.y), "s"(mb.y_act),
+                     "s"(mb.k), "s"(mb.n_tiles));
+        if (mb.k == 11) convh_run_member<ConvHGeom<CG, NFW, 11, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
+        else if (mb.k == 7) convh_run_member<ConvHGeom<CG, NFW, 7, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
+        else convh_run_member<ConvHGeom<CG, NFW, 3, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
         first = false;
     }
-    pair_stamp(p, 8, wave, lane, 7, 14);
+    pair_stamp(q, 8, wave, lane, 7, 14);
 }
 
 }  // namespace fv

@@ -39,7 +39,9 @@ for blk in range(8):
     ent, stg, ext = tr[blk, 0, 7, 15], tr[blk, 0, 7, 13], tr[blk, 0, 7, 14]
     if ent == 0:
         continue
-    print(f"block {64 * blk}: entry->prologue done {stg - ent}, prologue->exit {ext - stg}, total {ext - ent} ticks")
+    t12, t11, t10 = tr[blk, 0, 7, 12], tr[blk, 0, 7, 11], tr[blk, 0, 7, 10]
+    print(f"block {64 * blk}: entry->member start {t12 - ent}, loads issued {t11 - t12}, loads landed {t10 - t11}, "
+          f"converted {stg - t10}; prologue->exit {ext - stg}, total {ext - ent} ticks")
     for it in range(7):
         e = tr[blk, 0, it]
         if e[0] == 0:
