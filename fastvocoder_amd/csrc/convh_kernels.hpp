@@ -10,14 +10,15 @@
 //
 //   * a block (8 waves = 2 row groups x 4 column groups) owns a 64-row x NTC-column output tile and walks the
 //     K range (tap-major: step = 32 input channels of one tap) in STAGES of two steps;
-//   * the packed weights of a stage (16 KB: [step][row sixteenth][split half][lane][8 f16], fv_pack_convh)
+//   * the packed weights of a stage (16 KB: [step][row sixteenth][split half][lane][8 f16], fv_pack_pair_weight_ex)
 //     stream global(L2) -> LDS by LDS-DMA through a ring of 4 stage slots, three stages ahead of their use,
 //     across tile boundaries (a block's tiles of one member form ONE linear stage sequence);
 //   * one barrier per stage (it proves the stage's DMA parts of all waves have landed and frees the slot of
 //     the stage before); the barrier of stage g+1 is taken one MFMA group early so that the operand prefetch
 //     never drains at a stage boundary;
 //   * a wave owns 2 row sixteenths x NFW column fragments: per step 4 A reads + 2 NFW B reads (ds_read_b128)
-//     feed 6 NFW MFMAs; operands are fetched one group (two fragments) ahead, order pinned by sched_barrier;
+//     feed 6 NFW MFMAs; A operands are fetched one group (two fragments) ahead, B operands two, order pinned by
+//     sched_barrier;
 //   * vmcnt bookkeeping is static: every tile issues the same loads in the same order (out-of-range offsets
 //     where there is nothing to load), so each stage waits with the exact count of younger loads.
 //

@@ -11,8 +11,9 @@
 // f16 x f16 products are exact in the fp32 accumulator, so the only new error is the dropped 2^-22 terms: per
 // layer the result is as close to the exact sum as the fp32 FMA chain is (tests/test_split_precision.py,
 // DESIGN.md section 3.7).  Three f16 MFMAs cover 32 K values in 3 x 16 cycles where the fp32 MFMA needs
-// 8 x 32: at 16-32 channels the fp32 pair kernel is matrix-core bound, this one is bound by LDS bandwidth
-// and by the HBM traffic of x and x' -- which is where SURVEY section 8(d) puts these layers.
+// 8 x 32: at 16-32 channels the fp32 pair kernel is matrix-core bound; this one is not -- what is left is the HBM
+// traffic of x and x' (where SURVEY section 8(d) puts these layers), LDS operand traffic and, at batch 1, the
+// per-tile conversion / epilogue work and latency (profiles/r02_*: 0.12-0.22 MFMA-busy).
 //
 // Layout: the activated, split input lives in LDS as [split half][block of 8 channels][time row][8 halves]:
 // the B operand of a K step (lane = column n, K block = 8 consecutive channels of one tap) is ONE ds_read_b128
@@ -20,8 +21,10 @@
 // groups ds_read_b128 is serviced in (PairHGeom).  The D fragment (lane = column, 4 consecutive channels) is
 // half a block entry: conv1's epilogue splits and stores the intermediate with ds_write_b64.
 // K order: step s covers 32 / C taps (C = 16: taps 2s, 2s+1 x 16 channels; an odd tap count is padded with a
-// zero tap), channels inside a tap.  The packed weights of a member's two convs sit in LDS; a wave loads the A
-// operands of a phase with KS x 2 ds_read_b128 (4-wave blocks, two per CU, 2 waves per SIMD => 256 VGPRs each).
+// zero tap), channels inside a tap.  The packed weights of a member's two convs sit in LDS.  C = 16: a wave loads the
+// A operands of a phase up front (KS x 2 ds_read_b128, 48 registers at 11 taps; 4-wave blocks, two per CU).  C = 32:
+// both row halves per wave, a phase's A operands are 176 registers -- they stream through a two-step queue like the
+// B operands (one 8-wave block per CU: the two 11-tap weight images are 88 KB).  2 waves per SIMD => 256 VGPRs.
 //
 // Per tile: the NEXT tile's raw fp32 x window is loaded global -> registers at the top of the tile (in flight for
 // the whole tile, no LDS landing buffer); conv1 -> + b1, lrelu, zero outside [0, T), split -> intermediate image;
