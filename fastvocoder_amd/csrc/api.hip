@@ -1114,6 +1114,7 @@ int fv_resblock1_fused_ex(int n, const float* const* x, const float* const* w1, 
         mb.y_act = y_act ? y_act[j] : nullptr;
         mb.k = k[j];
     }
+    if (C == 64 && !getenv("FV_PAIR64_UNFUSED")) return launch_convp(pp, dil, (hipStream_t)stream);
     if (C >= 64) return launch_wide_pairs(pp, mid, C, dil, (hipStream_t)stream);
     return launch_pairs(pp, C, dil, (hipStream_t)stream);
 }
@@ -1540,7 +1541,9 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
                     mb.add2 = qo.acc2 == FV_SLOT_NONE ? nullptr : base[qo.acc2];
                 }
             }
-            if (o.Cin >= 64) {
+            if (o.Cin == 64 && !getenv("FV_PAIR64_UNFUSED")) {
+                if (int rc = launch_convp(pp, o.dil, s)) return rc;
+            } else if (o.Cin >= 64) {
                 float* mids[3] = {nullptr, nullptr, nullptr};
                 for (size_t q = n; q < m; ++q) mids[q - n] = base[plan->ops[q].tmpb];
                 if (int rc = launch_wide_pairs(pp, mids, o.Cin, o.dil, s)) return rc;

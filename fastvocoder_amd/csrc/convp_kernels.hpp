@@ -1,0 +1,321 @@
+// Fused ResBlock1 pair at 64 channels, split-f16 operands, streamed weights:
+//
+//     x' = x + conv2( lrelu( conv1( lrelu(x) ) + b1 ) ) + b2          (reference model/generator/modules.py:223-230)
+//
+// convh_kernels.hpp run twice without leaving the CU: a tile walks ONE linear sequence of 2 KT weight stages (conv1's,
+// then conv2's) through the same 4-slot LDS ring; after conv1's last stage the accumulators become the split image of
+// the intermediate (+ b1, lrelu, zero outside [0, T)) in LDS, conv2 reads its B operands from there.  Against two
+// convh launches per pair: one prologue / pipeline fill / tail instead of two, the intermediate never touches HBM,
+// the x window is converted once; price: KT - 1 of the tile's 128 intermediate columns are recomputed by the
+// neighbouring tile (8 % at 11 taps).  LDS: ring 64 KB + x image 48 KB + intermediate image 36 KB.  At 128 channels
+// the two images alone would be 172 KB: those pairs stay two launches.
+#pragma once
+#include "convh_kernels.hpp"
+
+namespace fv {
+
+template <int KT_, int DIL_>
+struct ConvPGeom {
+    typedef ConvHGeom<2, 2, KT_, DIL_> H;                // the conv1 side: same image, ring, wave layout
+    static constexpr int KT = KT_, DIL = DIL_, C = 64, NFW = 2;
+    static constexpr int NM = H::NTC;                    // 128 intermediate columns per tile
+    static constexpr int NOUT = NM - (KT - 1);           // output columns per tile
+    static constexpr int P1 = (KT - 1) * DIL / 2, P2 = (KT - 1) / 2;
+    static constexpr int NST1 = H::NST, NST = 2 * NST1;  // weight stages per tile: conv1's, then conv2's
+    static constexpr int NUNIT1 = H::NUNIT;              // MFMA groups per conv
+    static constexpr int MRP = NM + 16;                  // rows of the intermediate image (>= NM + KT - 1, multiple of 16)
+    static constexpr int MHALF = (C / 8) * MRP * 16;
+    static constexpr int RAWST = NST - 4, RESST = NST - 2;
+    static constexpr int NRAW = H::NRAW, NRES = 8 * NFW;
+    static_assert(KT - 1 <= 16 && NST1 >= 3, "taps");
+};
+
+template <class G>
+__device__ __forceinline__ void convp_run_member(const PairParams& p, const PairMember& mb, int item0, int hi_item,
+                                                 float* smem, int wave, int lane_in, bool first) {
+    typedef typename G::H H;
+    typedef __attribute__((address_space(3))) const f16x8 LdsH8;
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int tid = wave * 64 + lane;
+    float* const ring = smem + p.x_off;
+    char* const ximg = reinterpret_cast<char*>(smem + p.img_off);
+    char* const mimg = reinterpret_cast<char*>(smem + p.mid_off);
+    float* const bl = smem + p.bias_off;                 // [b1[64] | b2[64]]
+    const int n = lane & 15, kb = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int col0 = wn * (16 * G::NFW) + n;
+    const char* const bptr = ximg + (kb * H::XRP + col0) * 16;
+    const char* const mptr = mimg + (kb * G::MRP + col0) * 16;
+    const float* const aptr = ring + (wm * 2) * 512 + lane * 4;
+    const int row0 = 16 * (2 * wm) + 4 * kb;             // + 16 h + i
+    // D fragment -> intermediate image: channels row0 + 16 h + i = half of the 8-channel block 2 (2 wm + h) + (kb >> 1)
+    char* const mw = mimg + ((2 * (2 * wm) + (kb >> 1)) * G::MRP + col0) * 16 + 8 * (kb & 1);
+
+    const size_t ustride = (size_t)G::C * (size_t)p.T;
+    const unsigned ubytes = (unsigned)G::C * (unsigned)p.T * 4u;
+    const unsigned t4 = (unsigned)p.T * 4u;
+    const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(mb.w1, (unsigned)H::WTILE);
+    const __amdgpu_buffer_rsrc_t rw2 = make_rsrc(mb.w2, (unsigned)H::WTILE);
+    int item = item0;
+    int g0 = 0;
+    int b = item / mb.n_tiles, tile = item - b * mb.n_tiles;
+    if (!first) pair_barrier();
+    ConvHRaw<H> raw;
+    convh_load_raw<H>(raw, mb.x + b * ustride, p.T, tile * G::NOUT - G::P1 - G::P2, tid, true);
+#pragma unroll
+    for (int st = 0; st < 3; ++st) convh_dma_stage<H>(rw1, ring, st, (unsigned)(st * H::STAGE_BYTES), wave, lane);
+    if (tid < G::C) {
+        bl[tid] = mb.b1 ? mb.b1[tid] : 0.f;
+        bl[G::C + tid] = mb.b2 ? mb.b2[tid] : 0.f;
+    }
+    // rows [NM, MRP) of the intermediate feed only discarded columns: finite values once
+    for (int idx = tid; idx < 2 * (G::C / 8) * 64; idx += 512)
+        reinterpret_cast<float*>(mimg + ((idx >> 6) * G::MRP + G::NM) * 16)[idx & 63] = 0.f;
+    pair_wait_vm0();
+    if (!(p.dbg & 2)) convh_convert<H>(raw, ximg, p.slope, tid);
+    for (;;) {
+        const int t0 = tile * G::NOUT;
+        const int nitem = item + 1;
+        const bool more = nitem < hi_item;
+        int nb = b, ntile = tile + 1;
+        if (ntile == mb.n_tiles) {
+            ntile = 0;
+            ++nb;
+        }
+        f32x4 hi[2][G::NFW], lo[2][G::NFW];
+        float res[2][G::NFW][4];
+        unsigned voff[G::NFW];
+        f16x8 abuf[2][2][2], bbuf[3][2][2];
+
+        auto entry = [&](auto GC) {
+            constexpr int GS = decltype(GC)::value;
+            {
+                constexpr bool raw_between = GS >= 3 && G::RAWST >= GS - 3 && G::RAWST <= GS - 1;
+                constexpr bool res_between = GS >= 3 && G::RESST >= GS - 3 && G::RESST <= GS - 1;
+                wait_vm<4 + (raw_between ? G::NRAW : 0) + (res_between ? G::NRES : 0)>();
+            }
+            pair_barrier();
+            constexpr int NS = GS + 3;                   // this tile's stage NS, or the next tile's NS - NST
+            if constexpr (NS < G::NST1)
+                convh_dma_stage<H>(rw1, ring, (g0 + NS) & 3, (unsigned)(NS * H::STAGE_BYTES), wave, lane);
+            else if constexpr (NS < G::NST)
+                convh_dma_stage<H>(rw2, ring, (g0 + NS) & 3, (unsigned)((NS - G::NST1) * H::STAGE_BYTES), wave, lane);
+            else
+                convh_dma_stage<H>(rw1, ring, (g0 + NS) & 3,
+                                   more ? (unsigned)((NS - G::NST) * H::STAGE_BYTES) : kOutOfRange, wave, lane);
+            if constexpr (GS == G::RAWST)
+                convh_load_raw<H>(raw, mb.x + nb * ustride, p.T, ntile * G::NOUT - G::P1 - G::P2, tid, more && !(p.dbg & 1));
+            if constexpr (GS == G::RESST) {
+                const __amdgpu_buffer_rsrc_t rr = make_rsrc(mb.x + b * ustride, ubytes);     // the residual is x itself
+#pragma unroll
+                for (int f = 0; f < G::NFW; ++f) {
+                    const int col = col0 + f * 16, t = t0 + col;
+                    voff[f] = col < G::NOUT && t < p.T ? (unsigned)(row0 * p.T + t) * 4u : kOutOfRange;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) res[h][f][i] = buffer_load1s(rr, voff[f], (unsigned)(16 * h + i) * t4);
+                }
+            }
+        };
+        auto fetch_a = [&](auto SC, f16x8 (&dst)[2][2]) {        // SC: step of the tile's 2 x NSTEP sequence
+            constexpr int S = decltype(SC)::value;
+            LdsCF* a = lds_opaque(aptr + ((g0 + S / 2) & 3) * (H::STAGE_BYTES / 4));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                dst[h][0] = *reinterpret_cast<LdsH8*>(a + ((S % 2) * 4 + h) * 512);
+                dst[h][1] = *reinterpret_cast<LdsH8*>(a + ((S % 2) * 4 + h) * 512 + 256);
+            }
+        };
+        LdsCF* const bb = lds_opaque(reinterpret_cast<const float*>(bptr));
+        LdsCF* const bb2 = lds_opaque(reinterpret_cast<const float*>(bptr + H::XHALF));
+        LdsCF* const mb1 = lds_opaque(reinterpret_cast<const float*>(mptr));
+        LdsCF* const mb2 = lds_opaque(reinterpret_cast<const float*>(mptr + G::MHALF));
+        // B operands of step S of conv CV (0: from the x image, tap stride DIL; 1: from the intermediate, stride 1)
+        auto fetch_b = [&](auto CVC, auto SC, f16x8 (&dst)[2][2]) {
+            constexpr int CV = decltype(CVC)::value, S = decltype(SC)::value;
+            constexpr int tap = S / 2, cg = S % 2;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if constexpr (CV == 0) {
+                    constexpr int off = (cg * 4 * H::XRP + tap * G::DIL) * 4;
+                    dst[e][0] = *reinterpret_cast<LdsH8*>(bb + off + e * 64);
+                    dst[e][1] = *reinterpret_cast<LdsH8*>(bb2 + off + e * 64);
+                } else {
+                    constexpr int off = (cg * 4 * G::MRP + tap) * 4;
+                    dst[e][0] = *reinterpret_cast<LdsH8*>(mb1 + off + e * 64);
+                    dst[e][1] = *reinterpret_cast<LdsH8*>(mb2 + off + e * 64);
+                }
+            }
+        };
+        // one conv: NUNIT1 groups (NP = 1: group = step); CV selects the B image, the stage numbers continue
+        auto conv = [&](auto CVC) {
+            constexpr int CV = decltype(CVC)::value;
+            constexpr int S0 = CV * H::NSTEP;                // first step of this conv in the tile's sequence
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int f = 0; f < G::NFW; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (CV == 0) entry(IntC<0>{});         // conv2's first stage was entered during conv1's last group
+            fetch_a(IntC<S0>{}, abuf[S0 & 1]);
+            fetch_b(CVC, IntC<0>{}, bbuf[0]);
+            fetch_b(CVC, IntC<1>{}, bbuf[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, G::NUNIT1>([&](auto UC) {
+                constexpr int U = decltype(UC)::value;       // group = step inside this conv
+                constexpr int S = S0 + U, SN = S + 1;
+                if constexpr (SN < 2 * H::NSTEP) {
+                    // the next step starts a new stage (also across the conv1 -> conv2 boundary: the ring does not care)
+                    if constexpr (SN % 2 == 0) entry(IntC<SN / 2>{});
+                    if constexpr (U + 1 < G::NUNIT1) fetch_a(IntC<SN>{}, abuf[SN & 1]);
+                }
+                if constexpr (U + 2 < G::NUNIT1) fetch_b(CVC, IntC<U + 2>{}, bbuf[(U + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        hi[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[S & 1][h][0], bbuf[U % 3][e][0], hi[h][e], 0, 0, 0);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        lo[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[S & 1][h][0], bbuf[U % 3][e][1], lo[h][e], 0, 0, 0);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        lo[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[S & 1][h][1], bbuf[U % 3][e][0], lo[h][e], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+
+        conv(IntC<0>{});
+        {
+            // conv1 -> intermediate image: column u of the tile is time t0 - P2 + u; conv2's zero padding applies to
+            // the intermediate: columns outside [0, T) are zero, not conv1 of the padded input
+            const int tm = t0 - G::P2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float bv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[i] = bl[row0 + 16 * h + i];
+#pragma unroll
+                for (int f = 0; f < G::NFW; ++f) {
+                    const int t = tm + col0 + f * 16;
+                    const bool ok = t >= 0 && t < p.T;
+                    f16x4 h1, h2;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = split_act(fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[i], p.slope);
+                        v = ok ? v : 0.f;
+                        const _Float16 a = (_Float16)v;
+                        h1[i] = a;
+                        h2[i] = split_rem(v, a);
+                    }
+                    *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16)) = h1;
+                    *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16) + G::MHALF) = h2;
+                }
+            }
+        }
+        pair_barrier();                                  // the intermediate is complete (and nobody reads the x image any more)
+        // fetch_a of conv2's first step: its stage was entered (barrier, DMA landed) during conv1's last group
+        conv(IntC<1>{});
+        // ---- epilogue: outputs, then the image of the next window ----------------------------------------------
+        pair_barrier();                                  // every wave is done with the intermediate
+        wait_vm<2>();                                    // raw window, residual: everything but the DMA of the last entry
+        const bool fin = mb.add1 != nullptr;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bv[i] = bl[G::C + row0 + 16 * h + i];
+#pragma unroll
+            for (int f = 0; f < G::NFW; ++f)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hi[h][f][i] = (fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[i]) + res[h][f][i];
+        }
+        if (fin) {
+            const __amdgpu_buffer_rsrc_t r1 = make_rsrc(mb.add1 + b * ustride, ubytes);
+            const __amdgpu_buffer_rsrc_t r2 = make_rsrc(mb.add2 ? mb.add2 + b * ustride : mb.add1, mb.add2 ? ubytes : 0u);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int f = 0; f < G::NFW; ++f)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        lo[h][f][i] = buffer_load1s(r1, voff[f], (unsigned)(16 * h + i) * t4);
+                        res[h][f][i] = buffer_load1s(r2, voff[f], (unsigned)(16 * h + i) * t4);
+                    }
+            pair_wait_vm0();
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int f = 0; f < G::NFW; ++f)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hi[h][f][i] = (hi[h][f][i] + lo[h][f][i]) + res[h][f][i];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int f = 0; f < G::NFW; ++f) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = hi[h][f][i];
+                const int col = col0 + f * 16;
+                pair_store(p, mb.y, mb.y_act, G::C, b, row0 + 16 * h, t0 + col,
+                           col < G::NOUT && t0 + col < p.T && !(p.dbg & 8), v, fin);
+            }
+        if (more && !(p.dbg & 2)) convh_convert<H>(raw, ximg, p.slope, tid);
+        if (!more) break;
+        g0 += G::NST;
+        item = nitem;
+        b = nb;
+        tile = ntile;
+    }
+    pair_wait_vm0();
+}
+
+// one 8-wave block per CU (150 KB of LDS), 2 waves per SIMD
+template <int DIL>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void convp_kernel(PairParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the launch's scalars in one batch of kernarg loads (see convh_kernel)
+    PairParams q;
+    q.n_members = p.n_members; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = p.out_div;
+    q.act_slope = p.act_slope; q.post = p.post; q.x_off = p.x_off; q.img_off = p.img_off; q.mid_off = p.mid_off;
+    q.bias_off = p.bias_off; q.dbg = p.dbg; q.trace = p.trace;
+    int n_items[3], cost[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { n_items[m] = p.m[m].n_items; cost[m] = p.m[m].cost; }
+    asm volatile("" ::"s"(q.n_members), "s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.out_div), "s"(q.act_slope),
+                 "s"(q.post), "s"(q.x_off), "s"(q.img_off), "s"(q.mid_off), "s"(q.bias_off), "s"(q.dbg), "s"(q.trace),
+                 "s"(n_items[0]), "s"(n_items[1]), "s"(n_items[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]));
+    long long total = 0;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_items[m] * cost[m] : 0;
+    long long base = 0;
+    bool first = true;
+    for (int m = 0; m < q.n_members; ++m) {
+        const int n = m == 0 ? n_items[0] : m == 1 ? n_items[1] : n_items[2];
+        const int cm = m == 0 ? cost[0] : m == 1 ? cost[1] : cost[2];
+        const int lo = pair_share(blockIdx.x, total, base, cm, n, q.nblk);
+        const int hi = pair_share(blockIdx.x + 1, total, base, cm, n, q.nblk);
+        base += (long long)n * cm;
+        if (lo >= hi) continue;
+        PairMember mb;
+        mb.x = p.m[m].x; mb.w1 = p.m[m].w1; mb.w2 = p.m[m].w2; mb.b1 = p.m[m].b1; mb.b2 = p.m[m].b2; mb.add1 = p.m[m].add1;
+        mb.add2 = p.m[m].add2; mb.y = p.m[m].y; mb.y_act = p.m[m].y_act; mb.k = p.m[m].k; mb.n_tiles = p.m[m].n_tiles;
+        asm volatile("" ::"s"(mb.x), "s"(mb.w1), "s"(mb.w2), "s"(mb.b1), "s"(mb.b2), "s"(mb.add1), "s"(mb.add2), "s"(mb.y),
+                     "s"(mb.y_act), "s"(mb.k), "s"(mb.n_tiles));
+        if (mb.k == 11) convp_run_member<ConvPGeom<11, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
+        else if (mb.k == 7) convp_run_member<ConvPGeom<7, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
+        else convp_run_member<ConvPGeom<3, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
+        first = false;
+    }
+}
+
+}  // namespace fv

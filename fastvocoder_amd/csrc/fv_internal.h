@@ -203,6 +203,11 @@ struct ConvHShape {
 };
 ConvHShape convh_shape(int C, int k, int dil);
 int launch_convh(PairParams p, int C, int dil, hipStream_t stream);
+// fused ResBlock pair at C = 64 with split-f16 operands and streamed weights (convp_kernels.hpp): members use x, w1, w2
+// (fv_pack_pair_weight_ex images), b1, b2, add1 / add2, y, y_act, k
+int launch_convp(PairParams p, int dil, hipStream_t stream);
+template <int DIL>
+int launch_convp_dil(const PairParams& p, size_t lds, hipStream_t s);
 template <int CG, int NFW>
 int launch_convh_geom(const PairParams& p, int dil, size_t lds, hipStream_t s);
 // n (1..3) members, plain (sum = 0: one raw output each) or sum mode (one output: mean of the members)

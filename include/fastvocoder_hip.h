@@ -159,9 +159,10 @@ int fv_resblock1_fused(int n, const float* const* x, const float* const* w1, con
  *       section 3.7, tests/test_split_precision.py); 5.3x fewer matrix-core cycles, which turns the C = 16
  *       layers from matrix-bound into HBM / LDS-bound.  Needs |v| < 65504 for activations and weights.
  *       Weights: fv_pack_pair_weight_ex(prec) images ([K step][row half][split half][lane][8 f16]).
- *       C = 16 / 32: one fused launch (the intermediate stays in LDS).  C = 64 / 128: the weights do not fit on
- *       chip; the pair runs as two launches of a split-f16 conv kernel that streams them through LDS
- *       (csrc/convh_kernels.hpp) and needs mid[j], a [B,C,T] scratch tensor per member (NULL otherwise).
+ *       C = 16 / 32: one fused launch (intermediate and weights in LDS).  C = 64: one fused launch, the weights of
+ *       both convs stream through an LDS ring (csrc/convp_kernels.hpp).  C = 128: the pair's two LDS images do not
+ *       fit next to the ring; it runs as two launches of the split-f16 conv kernel (csrc/convh_kernels.hpp) and
+ *       needs mid[j], a [B,C,T] scratch tensor per member (ignored at C = 64, NULL below).
  *   add1 / add2 (arrays or entries may be NULL; FV_PAIR_SPLIT_F16 only): member j stores
  *       y_j = post( ((x'_j + add1_j) + add2_j) / out_div )  -- with x'_j the first ResBlock's result and
  *       add1 / add2 the second and third this is xs = r0; xs += r1; xs += r2; x = xs / 3 in the

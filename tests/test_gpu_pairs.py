@@ -296,6 +296,12 @@ def test_persistent_blocks_walk_many_tiles_and_cross_members(monkeypatch, blocks
         for yf, yw, ref in zip(full, few, refs):
             assert _rel(yw, ref) <= 4e-6
             assert torch.equal(yf, yw)
+        if C == 64:                                  # fused (convp_kernels.hpp) == two conv launches (convh), bit for bit
+            monkeypatch.setenv("FV_PAIR64_UNFUSED", "1")
+            two = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, prec=SPLIT)
+            monkeypatch.delenv("FV_PAIR64_UNFUSED")
+            for yf, yt in zip(full, two):
+                assert torch.equal(yf, yt)
         if C <= 32:                                  # the fp32 kernels share the partition code
             f1, f2 = [_native.pack_pair(_t(m[1])) for m in ms], [_native.pack_pair(_t(m[3])) for m in ms]
             monkeypatch.setenv("FV_PAIR_BLOCKS", str(blocks))
