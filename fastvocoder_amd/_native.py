@@ -306,7 +306,7 @@ def pack_pair(w, prec=PAIR_F32):
 
 def pair_supported(channels, k, dil, prec=PAIR_F32):
     """Shapes the fused ResBlock-pair kernels are built for (csrc/pair_launch.hip)."""
-    chans = (16, 32) if prec == PAIR_F32 else (16, 32, 64, 128)
+    chans = (16, 32) if prec == PAIR_F32 else (16, 32, 64, 128, 256, 512)
     return channels in chans and k in (3, 7, 11) and dil in (1, 3, 5) and prec in (PAIR_F32, PAIR_SPLIT_F16)
 
 

@@ -226,14 +226,15 @@ __global__ void pack_pairh_kernel(const float* __restrict__ w, _Float16* __restr
 // Wh[row tile mt][K step s = tap * C/32 + cg][row sixteenth mh][split half][lane][8 halves];
 // lane = (row = lane & 15, K block kb = lane >> 4): co = 64 mt + 16 mh + row, ci = 32 cg + 8 kb + j.
 __global__ void pack_convh_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int C, int k) {
-    const int CG = C / 32, NSTEP = k * CG;
-    const int64_t total = (int64_t)(C / 64) * NSTEP * 4 * 2 * 64 * 8;
+    // above 128 channels the input channels come in chunks of 128: [row tile][chunk][step inside the chunk]...
+    const int NCH = C > 128 ? C / 128 : 1, CC = C / NCH, CG = CC / 32, NSTEP = k * CG;
+    const int64_t total = (int64_t)(C / 64) * NCH * NSTEP * 4 * 2 * 64 * 8;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)(i & 7), lane = (int)((i >> 3) & 63), half = (int)((i >> 9) & 1), mh = (int)((i >> 10) & 3);
-        const int ms = (int)(i >> 12), s = ms % NSTEP, mt = ms / NSTEP;
+        const int ms = (int)(i >> 12), s = ms % NSTEP, mc = ms / NSTEP, chunk = mc % NCH, mt = mc / NCH;
         const int tap = s / CG, cg = s % CG;
-        const int co = 64 * mt + 16 * mh + (lane & 15), ci = 32 * cg + 8 * (lane >> 4) + j;
+        const int co = 64 * mt + 16 * mh + (lane & 15), ci = CC * chunk + 32 * cg + 8 * (lane >> 4) + j;
         const float v = w[((size_t)co * C + ci) * k + tap];
         const _Float16 h1 = (_Float16)v;
         wp[i] = half == 0 ? h1 : (_Float16)((v - (float)h1) * 2048.f);
@@ -1014,7 +1015,8 @@ int fv_pack_pair_weight(const float* w, float* packed, int C, int k, void* strea
 
 int64_t fv_packed_pair_floats_ex(int C, int k, int prec) {
     if (prec != FV_PAIR_SPLIT_F16) return fv_packed_pair_floats(C, k);
-    if (C == 64 || C == 128) return (int64_t)(C / 64) * k * (C / 32) * 2048;   // row tiles x K steps x 8 KB
+    if (C == 64 || C == 128 || C == 256 || C == 512)
+        return (int64_t)(C / 64) * k * (C / 32) * 2048;                       // row tiles x (chunks x) K steps x 8 KB
     if (C != 16 && C != 32) return 0;
     const int tps = 32 / C;
     return (int64_t)((k + tps - 1) / tps) * (C / 16) * 512;   // K steps x row halves x 2 split halves x 64 lanes x 16 bytes
@@ -1024,8 +1026,8 @@ int fv_pack_pair_weight_ex(const float* w, float* packed, int C, int k, int prec
     if (prec == FV_PAIR_F32) return fv_pack_pair_weight(w, packed, C, k, stream);
     if (prec != FV_PAIR_SPLIT_F16) return fail(FV_ERR_INVALID_ARG, "pack_pair_weight: unknown arithmetic %d", prec);
     if (!w || !packed) return fail(FV_ERR_INVALID_ARG, "pack_pair_weight: null tensor");
-    if ((C != 16 && C != 32 && C != 64 && C != 128) || k <= 0)
-        return fail(FV_ERR_INVALID_ARG, "pack_pair_weight: C=%d (16, 32, 64 or 128) k=%d", C, k);
+    if ((C != 16 && C != 32 && C != 64 && C != 128 && C != 256 && C != 512) || k <= 0)
+        return fail(FV_ERR_INVALID_ARG, "pack_pair_weight: C=%d (16 ... 512, a power of two) k=%d", C, k);
     const int64_t total = fv_packed_pair_floats_ex(C, k, prec) * 2;
     if (C >= 64)
         hipLaunchKernelGGL(pack_convh_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -1065,8 +1067,8 @@ static int launch_wide_pairs(const PairParams& pp, float* const* mid, int C, int
 
 static int check_pair_args(int n, int C, const int* k, int dil, int prec = FV_PAIR_F32) {
     if (n < 1 || n > 3) return fail(FV_ERR_INVALID_ARG, "resblock pair: %d members (1..3)", n);
-    if (C != 16 && C != 32 && !(prec == FV_PAIR_SPLIT_F16 && (C == 64 || C == 128)))
-        return fail(FV_ERR_UNSUPPORTED, "resblock pair: C = %d (16 or 32; 64 or 128 with split-f16 operands); use the conv1d ops", C);
+    if (C != 16 && C != 32 && !(prec == FV_PAIR_SPLIT_F16 && (C == 64 || C == 128 || C == 256 || C == 512)))
+        return fail(FV_ERR_UNSUPPORTED, "resblock pair: C = %d (16 or 32; 64 ... 512 with split-f16 operands); use the conv1d ops", C);
     if (dil != 1 && dil != 3 && dil != 5) return fail(FV_ERR_UNSUPPORTED, "resblock pair: dilation %d (1, 3 or 5)", dil);
     for (int j = 0; j < n; ++j)
         if (k[j] != 3 && k[j] != 7 && k[j] != 11) return fail(FV_ERR_UNSUPPORTED, "resblock pair: %d taps (3, 7 or 11)", k[j]);
@@ -1208,7 +1210,8 @@ int fv_plan_add_resblock_pair_ex(fv_plan_t* plan, int x_slot, int y_slot, int y_
 
 static int check_convh_args(int n, int C, const int* k, int dil) {
     if (n < 1 || n > 3) return fail(FV_ERR_INVALID_ARG, "conv1d_split_f16: %d members (1..3)", n);
-    if (C != 64 && C != 128) return fail(FV_ERR_UNSUPPORTED, "conv1d_split_f16: C = %d (64 or 128)", C);
+    if (C != 64 && C != 128 && C != 256 && C != 512)
+        return fail(FV_ERR_UNSUPPORTED, "conv1d_split_f16: C = %d (64, 128, 256 or 512)", C);
     if (dil != 1 && dil != 3 && dil != 5) return fail(FV_ERR_UNSUPPORTED, "conv1d_split_f16: dilation %d (1, 3 or 5)", dil);
     for (int j = 0; j < n; ++j)
         if (k[j] != 3 && k[j] != 7 && k[j] != 11) return fail(FV_ERR_UNSUPPORTED, "conv1d_split_f16: %d taps (3, 7 or 11)", k[j]);

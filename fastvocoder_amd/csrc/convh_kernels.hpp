@@ -23,7 +23,9 @@
 //     where there is nothing to load), so each stage waits with the exact count of younger loads.
 //
 // Tiles of one member are ordered (utterance, column tile, row tile): the two row tiles of a C = 128 layer share
-// the column tile's image, which is converted once.
+// the column tile's image, which is converted once.  256 / 512 channels (HiFi-GAN large): the image holds 128 input
+// channels at a time; an output tile walks its 2 / 4 channel chunks one after the other (convert chunk, K loop over
+// the chunk's stages) and keeps its accumulators in registers across them.
 #pragma once
 #include "pairh_kernels.hpp"
 
@@ -129,7 +131,7 @@ __device__ __forceinline__ void convh_dma_stage(__amdgpu_buffer_rsrc_t rw, float
     dma16(rw, dst + 256, o + 1024u);
 }
 
-// items [item0, hi_item) of ONE member; item = (utterance * n_tiles + column tile) * NMT + row tile
+// items [item0, hi_item) of ONE member; item = (utterance * n_tiles + column tile) * p.nmt + row tile
 template <class G>
 __device__ __forceinline__ void convh_run_member(const PairParams& p, const PairMember& mb, int item0, int hi_item,
                                                  float* smem, int wave, int lane_in, bool first) {
@@ -146,15 +148,18 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
     const float* const aptr = ring + (wm * 2) * 512 + lane * 4;             // A: + slot*4096 + (i*4 + h)*512 + half*256
     const int row0 = 16 * (2 * wm) + 4 * kb;                                // + 16 h + i: row inside the 64-row tile
 
-    const size_t ustride = (size_t)G::C * (size_t)p.T;
-    const unsigned ubytes = (unsigned)G::C * (unsigned)p.T * 4u;
+    // p.ctot channels in and out = p.nch chunks of G::C input channels, p.nmt row tiles of 64 (one chunk up to 128 channels)
+    const int nch = p.nch, nmt = p.nmt;
+    const size_t ustride = (size_t)p.ctot * (size_t)p.T;
+    const size_t cstride = (size_t)G::C * (size_t)p.T;                      // one chunk of input channels
+    const unsigned ubytes = (unsigned)p.ctot * (unsigned)p.T * 4u;
     const unsigned t4 = (unsigned)p.T * 4u;
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc(mb.w1, (unsigned)(G::NMT * G::WTILE));
-    int item = item0;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(mb.w1, (unsigned)(nmt * nch * G::WTILE));
+    int item = item0, chunk = 0;
     int g0 = 0;                                                             // stage counter of the run (ring slot = g & 3)
     auto decode = [&](int it, int& b, int& nt, int& mt) {
-        mt = it % G::NMT;
-        const int q = it / G::NMT;
+        mt = it % nmt;
+        const int q = it / nmt;
         b = q / mb.n_tiles;
         nt = q - b * mb.n_tiles;
     };
@@ -166,25 +171,34 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
     convh_load_raw<G>(raw, mb.x + b * ustride, p.T, ntile * G::NTC - G::P, tid, true);
 #pragma unroll
     for (int st = 0; st < 3; ++st)
-        convh_dma_stage<G>(rw, ring, st, (unsigned)(mtile * G::WTILE + st * G::STAGE_BYTES), wave, lane);
+        convh_dma_stage<G>(rw, ring, st, (unsigned)(mtile * nch * G::WTILE + st * G::STAGE_BYTES), wave, lane);
     pair_stamp(p, 8, wave, lane, 7, 11);
     pair_wait_vm0();
     pair_stamp(p, 8, wave, lane, 7, 10);
     if (!(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid);
     pair_stamp(p, 8, wave, lane, 7, 13);                 // (tuning aid, -DFV_PAIR_TRACE) prologue done
+    f32x4 hi[2][G::NFW], lo[2][G::NFW];                // live across the channel chunks of an item
     for (int it = 0;; ++it) {
         const int t0 = ntile * G::NTC;
         pair_stamp(p, 8, wave, lane, it, 0);
-        const int nitem = item + 1;
+        // the next (item, chunk): the next chunk of this output tile, or chunk 0 of the next item
+        int nchunk = chunk + 1, nitem = item;
+        if (nchunk == nch) {
+            nchunk = 0;
+            nitem = item + 1;
+        }
+        const bool last = nchunk == 0;                   // this is the tile's last chunk: the epilogue runs
         const bool more = nitem < hi_item;
-        int nb = b, nnt = ntile, nmt = mtile;
-        if (more) decode(nitem, nb, nnt, nmt);
-        const bool new_win = more && (nb != b || nnt != ntile);
-        f32x4 hi[2][G::NFW], lo[2][G::NFW];
+        int nb = b, nnt = ntile, nmt_ = mtile;
+        if (more && last) decode(nitem, nb, nnt, nmt_);
+        const bool new_win = more && (nb != b || nnt != ntile || nchunk != chunk);
+        const unsigned wnext = (unsigned)((nmt_ * nch + nchunk) * G::WTILE), wcur = (unsigned)((mtile * nch + chunk) * G::WTILE);
+        if (chunk == 0) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int f = 0; f < G::NFW; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int f = 0; f < G::NFW; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         float res[2][G::NFW][4], bv[2][4];
         unsigned voff[G::NFW];
         f16x8 abuf[2][2][2], bbuf[3][2][2];         // A one group ahead, B two (from the image: no ring slot involved)
@@ -209,14 +223,16 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
             pair_barrier();
             constexpr int NS = GS + 3;
             unsigned off;
-            if constexpr (NS < G::NST) off = (unsigned)(mtile * G::WTILE + NS * G::STAGE_BYTES);
-            else off = more ? (unsigned)(nmt * G::WTILE + (NS - G::NST) * G::STAGE_BYTES) : kOutOfRange;
+            if constexpr (NS < G::NST) off = wcur + (unsigned)(NS * G::STAGE_BYTES);
+            else off = more ? wnext + (unsigned)((NS - G::NST) * G::STAGE_BYTES) : kOutOfRange;
             convh_dma_stage<G>(rw, ring, (g0 + NS) & 3, off, wave, lane);
             if constexpr (GS == G::RAWST)
-                convh_load_raw<G>(raw, mb.x + nb * ustride, p.T, nnt * G::NTC - G::P, tid, new_win && !(p.dbg & 1));
+                convh_load_raw<G>(raw, mb.x + nb * ustride + nchunk * cstride, p.T, nnt * G::NTC - G::P, tid,
+                                  new_win && !(p.dbg & 1));
             if constexpr (GS == G::RESST) {
                 // bias and residual of THIS tile: in flight during the last two stages
-                const __amdgpu_buffer_rsrc_t rb = make_rsrc(mb.b1 ? mb.b1 : mb.w1, mb.b1 ? (unsigned)G::C * 4u : 0u);
+                // (before the tile's last chunk the same loads are issued out of range: the wait counts stay static)
+                const __amdgpu_buffer_rsrc_t rb = make_rsrc(mb.b1 ? mb.b1 : mb.w1, mb.b1 && last ? (unsigned)p.ctot * 4u : 0u);
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -225,7 +241,7 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
 #pragma unroll
                 for (int f = 0; f < G::NFW; ++f) {
                     const int t = t0 + col0 + f * 16;
-                    voff[f] = t < p.T ? (unsigned)((64 * mtile + row0) * p.T + t) * 4u : kOutOfRange;
+                    voff[f] = t < p.T && last ? (unsigned)((64 * mtile + row0) * p.T + t) * 4u : kOutOfRange;
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -303,43 +319,45 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
         pair_stamp(p, 8, wave, lane, it, 3);
         wait_vm<2>();                                    // raw window, residual: everything but the DMA of the last entry
         pair_stamp(p, 8, wave, lane, it, 4);
-        const bool fin = mb.add1 != nullptr;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int f = 0; f < G::NFW; ++f)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) hi[h][f][i] = (fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[h][i]) + res[h][f][i];
-        if (fin) {
-            const __amdgpu_buffer_rsrc_t r1 = make_rsrc(mb.add1 + b * ustride, ubytes);
-            const __amdgpu_buffer_rsrc_t r2 = make_rsrc(mb.add2 ? mb.add2 + b * ustride : mb.add1, mb.add2 ? ubytes : 0u);
+        if (last) {
+            const bool fin = mb.add1 != nullptr;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int f = 0; f < G::NFW; ++f)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        lo[h][f][i] = buffer_load1s(r1, voff[f], (unsigned)(16 * h + i) * t4);
-                        res[h][f][i] = buffer_load1s(r2, voff[f], (unsigned)(16 * h + i) * t4);
-                    }
-            pair_wait_vm0();
+                    for (int i = 0; i < 4; ++i) hi[h][f][i] = (fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[h][i]) + res[h][f][i];
+            if (fin) {
+                const __amdgpu_buffer_rsrc_t r1 = make_rsrc(mb.add1 + b * ustride, ubytes);
+                const __amdgpu_buffer_rsrc_t r2 = make_rsrc(mb.add2 ? mb.add2 + b * ustride : mb.add1, mb.add2 ? ubytes : 0u);
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int f = 0; f < G::NFW; ++f)
+                    for (int f = 0; f < G::NFW; ++f)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) hi[h][f][i] = (hi[h][f][i] + lo[h][f][i]) + res[h][f][i];
-        }
+                        for (int i = 0; i < 4; ++i) {
+                            lo[h][f][i] = buffer_load1s(r1, voff[f], (unsigned)(16 * h + i) * t4);
+                            res[h][f][i] = buffer_load1s(r2, voff[f], (unsigned)(16 * h + i) * t4);
+                        }
+                pair_wait_vm0();
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int f = 0; f < G::NFW; ++f) {
-                float v[4];
+                    for (int f = 0; f < G::NFW; ++f)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = hi[h][f][i];
-                const int t = t0 + col0 + f * 16;
-                pair_store(p, mb.y, mb.y_act, G::C, b, 64 * mtile + row0 + 16 * h, t, t < p.T && !(p.dbg & 8), v, fin);
+                        for (int i = 0; i < 4; ++i) hi[h][f][i] = (hi[h][f][i] + lo[h][f][i]) + res[h][f][i];
             }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int f = 0; f < G::NFW; ++f) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = hi[h][f][i];
+                    const int t = t0 + col0 + f * 16;
+                    pair_store(p, mb.y, mb.y_act, p.ctot, b, 64 * mtile + row0 + 16 * h, t, t < p.T && !(p.dbg & 8), v, fin);
+                }
+        }
         pair_stamp(p, 8, wave, lane, it, 5);
         // the stores first, the conversion of the next window after them: a vmcnt wait cannot tell stores from loads,
         // the next tile's first stage waits would otherwise sit behind the stores' round trip
@@ -348,9 +366,10 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
         if (!more) break;
         g0 += G::NST;
         item = nitem;
+        chunk = nchunk;
         b = nb;
         ntile = nnt;
-        mtile = nmt;
+        mtile = nmt_;
     }
     // the DMAs requested for a next item that does not exist wrote zeros; nothing is in flight past this point
     pair_wait_vm0();
@@ -369,12 +388,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     PairParams q;
     q.n_members = p.n_members; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = p.out_div;
     q.act_slope = p.act_slope; q.post = p.post; q.x_off = p.x_off; q.img_off = p.img_off; q.dbg = p.dbg; q.trace = p.trace;
+    q.ctot = p.ctot; q.nch = p.nch; q.nmt = p.nmt;
     int n_items[3], cost[3];
 #pragma unroll
     for (int m = 0; m < 3; ++m) { n_items[m] = p.m[m].n_items; cost[m] = p.m[m].cost; }
     asm volatile("" ::"s"(q.n_members), "s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.out_div), "s"(q.act_slope),
                  "s"(q.post), "s"(q.x_off), "s"(q.img_off), "s"(q.dbg), "s"(q.trace), "s"(n_items[0]), "s"(n_items[1]),
-                 "s"(n_items[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]));
+                 "s"(n_items[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]), "s"(q.ctot), "s"(q.nch), "s"(q.nmt));
     long long total = 0;
 #pragma unroll
     for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_items[m] * cost[m] : 0;

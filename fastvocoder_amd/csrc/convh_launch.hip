@@ -13,6 +13,9 @@ extern template int launch_convh_geom<2, 2>(const PairParams&, int, size_t, hipS
 // run-time mirror of ConvHGeom<>
 ConvHShape convh_shape(int C, int k, int dil) {
     ConvHShape g = {};
+    g.NCH = C > 128 ? C / 128 : 1;     // the image holds at most 128 input channels at a time
+    g.NMT = C / 64;
+    C = C > 128 ? 128 : C;             // ... everything below is per chunk
     g.CG = C / 32;
     g.NFW = 2;
     g.NTC = 16 * g.NFW * 4;
@@ -20,13 +23,13 @@ ConvHShape convh_shape(int C, int k, int dil) {
     g.NST = g.NSTEP / 2;
     g.XROWS = (g.NTC + (k - 1) * dil + 3) / 4 * 4;
     g.XIMG = 4 * C * ((g.XROWS + 15) / 16 * 16);
-    g.NMT = C / 64;
     return g;
 }
 
 int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     if (p.B <= 0 || p.T <= 0) return 0;
-    if (C != 64 && C != 128) return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: C = %d (64 or 128)", C);
+    if (C != 64 && C != 128 && C != 256 && C != 512)
+        return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: C = %d (64, 128, 256 or 512)", C);
     if (dil != 1 && dil != 3 && dil != 5) return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: dilation %d (1, 3 or 5)", dil);
     if (p.n_members < 1 || p.n_members > 3) return fail(FV_ERR_INVALID_ARG, "split-f16 conv: %d members", p.n_members);
     if ((double)C * p.T * 4.0 >= 1073741824.0)
@@ -47,8 +50,11 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
         const ConvHShape g = convh_shape(C, mb.k, dil);
         mb.n_tiles = (p.T + g.NTC - 1) / g.NTC;
         mb.n_items = mb.n_tiles * p.B * g.NMT;
+        p.ctot = C;
+        p.nch = g.NCH;
+        p.nmt = g.NMT;
         // a tile costs its stages (LDS / matrix time) plus loads, conversion, epilogue
-        mb.cost = g.NST + (getenv("FV_CONVH_SKEL") ? atoi(getenv("FV_CONVH_SKEL")) : (C == 64 ? 5 : 2));
+        mb.cost = g.NST * g.NCH + (getenv("FV_CONVH_SKEL") ? atoi(getenv("FV_CONVH_SKEL")) : (C == 64 ? 5 : 2));
         if (g.XIMG > img_bytes) img_bytes = g.XIMG;
         items += mb.n_items;
         flops += 2.0 * p.B * (double)C * C * mb.k * p.T;
@@ -71,7 +77,7 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     p.dbg = tuning_dbg_flags();
     p.trace = getenv("FV_PAIR_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("FV_PAIR_TRACE_PTR"), nullptr, 0)) : nullptr;
     profile_begin(s);
-    const int rc = C == 128 ? launch_convh_geom<4, 2>(p, dil, lds, s) : launch_convh_geom<2, 2>(p, dil, lds, s);
+    const int rc = C >= 128 ? launch_convh_geom<4, 2>(p, dil, lds, s) : launch_convh_geom<2, 2>(p, dil, lds, s);
     profile_end(s, C == 64 ? FV_KERNEL_CONVH64 : FV_KERNEL_CONVH128, flops, bytes);
     return rc;
 }

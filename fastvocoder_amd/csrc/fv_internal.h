@@ -165,6 +165,7 @@ struct PairParams {
     float act_slope;     // y_act = lrelu(y, act_slope); without y_act and != 1: y itself is stored activated
     int post;            // FV_POST_* applied to y (sum mode / single)
     int nblk;            // persistent blocks in the grid
+    int ctot, nch, nmt;  // convh: channels in and out, chunks of <= 128 input channels, row tiles of 64
     int prec;            // FV_PAIR_F32: fp32 MFMA (pair_kernels.hpp); FV_PAIR_SPLIT_F16: pairh_kernels.hpp
     int x_off, mid_off;  // float offsets of the x image / intermediate in dynamic LDS
     int img_off;         // split-f16 kernels: float offset of the x image (x_off: the member's packed weights)
@@ -200,6 +201,7 @@ struct ConvHShape {
     int CG, NFW, NTC;    // 32-channel groups, fragments per wave, output columns per tile
     int NSTEP, NST;      // K steps of 32, stages of two steps
     int XROWS, XIMG, NMT;   // image rows / bytes, 64-row tiles
+    int NCH;                // chunks of input channels (128 each above 128 channels)
 };
 ConvHShape convh_shape(int C, int k, int dil);
 int launch_convh(PairParams p, int C, int dil, hipStream_t stream);

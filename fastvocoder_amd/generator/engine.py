@@ -193,7 +193,7 @@ class PlanBuilder:
         share a launch."""
         c, k, d = conv.in_channels, conv.kernel_size[0], conv.dilation[0]
         if not (conv.stride[0] == 1 and conv.groups == 1 and conv.out_channels == c and conv.padding[0] == d * (k - 1) // 2
-                and c in (64, 128) and _native.pair_supported(c, k, d, _native.PAIR_SPLIT_F16)):
+                and c in (64, 128, 256, 512) and _native.pair_supported(c, k, d, _native.PAIR_SPLIT_F16)):
             raise _native.NativeError("conv_split: shape not built into the split-f16 conv kernels")
         self.ops.append(dict(kind="convh", lane=self.lane, group=self.group, x=src, y=dst, res=res, acc=add1, acc2=add2,
                              pre_slope=1.0, slope=float(slope), channels=c, k=k, dil=d,

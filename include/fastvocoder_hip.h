@@ -160,7 +160,7 @@ int fv_resblock1_fused(int n, const float* const* x, const float* const* w1, con
  *       layers from matrix-bound into HBM / LDS-bound.  Needs |v| < 65504 for activations and weights.
  *       Weights: fv_pack_pair_weight_ex(prec) images ([K step][row half][split half][lane][8 f16]).
  *       C = 16 / 32: one fused launch (intermediate and weights in LDS).  C = 64: one fused launch, the weights of
- *       both convs stream through an LDS ring (csrc/convp_kernels.hpp).  C = 128: the pair's two LDS images do not
+ *       both convs stream through an LDS ring (csrc/convp_kernels.hpp).  C = 128 / 256 / 512: the pair's two LDS images do not
  *       fit next to the ring; it runs as two launches of the split-f16 conv kernel (csrc/convh_kernels.hpp) and
  *       needs mid[j], a [B,C,T] scratch tensor per member (ignored at C = 64, NULL below).
  *   add1 / add2 (arrays or entries may be NULL; FV_PAIR_SPLIT_F16 only): member j stores
@@ -187,7 +187,7 @@ int fv_resblock1_fused_ex(int n, const float* const* x, const float* const* w1, 
  *
  * (modules.py:223-230: conv1 of a pair is res = add = NULL; conv2 is res = the pair's input; the last conv of a
  * stage's first block carries the MRF merge, hifigan.py:99-103, with add1 / add2 = the other blocks' results.)
- * C = Cin = Cout = 64 or 128, k_j in {3, 7, 11}, dil in {1, 3, 5}; x_j is read RAW (the activation is applied on
+ * C = Cin = Cout = 64, 128, 256 or 512, k_j in {3, 7, 11}, dil in {1, 3, 5}; x_j is read RAW (the activation is applied on
  * chip while the operand is split); packed_j: fv_pack_pair_weight_ex(C, k_j, FV_PAIR_SPLIT_F16) -- the packed
  * weights stream L2 -> LDS through a 4-stage ring (csrc/convh_kernels.hpp).  out_div / post apply to members with
  * add1 only.  Any T.

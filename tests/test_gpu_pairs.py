@@ -207,6 +207,8 @@ WIDE_CASES = [
     (1, 128, 200, 3, (7,), True),            # two row tiles share a column tile's image
     (1, 128, 520, 5, (11, 7, 3), True),
     (2, 128, 130, 1, (3, 11), True),
+    (1, 256, 150, 3, (7, 3), True),          # two chunks of 128 input channels, four row tiles
+    (1, 512, 70, 1, (3,), True),             # four chunks, eight row tiles
 ]
 
 
@@ -241,7 +243,8 @@ def test_wide_resblock_pair_split_f16_vs_oracle(case):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 300, 3, (7, 3)), (1, 128, 260, 5, (11, 7, 3)), (1, 64, 5, 1, (3,)),
-                                  (3, 128, 129, 1, (11,))], ids=lambda c: "x".join(str(v) for v in c))
+                                  (3, 128, 129, 1, (11,)), (1, 256, 300, 5, (11, 3)), (2, 512, 40, 3, (7,))],
+                         ids=lambda c: "x".join(str(v) for v in c))
 def test_conv1d_split_f16_vs_oracle(case):
     """fv_conv1d_split_f16: every epilogue form against the oracle's conv1d."""
     B, C, T, dil, ks = case
@@ -271,7 +274,7 @@ def test_conv1d_split_f16_vs_oracle(case):
     ys = _native.conv1d_split_f16(X, P, Bi, list(ks), dil, pre_slope=0.1, add1=A1, out_div=2.0, post=_native.POST_TANH)
     for y, c, p1 in zip(ys, conv, a1):
         assert _rel(y, np.tanh(((c + p1) / np.float32(2.0)).astype(np.float64))) <= 4e-6
-    with pytest.raises(_native.NativeError, match="64 or 128"):
+    with pytest.raises(_native.NativeError, match="64, 128, 256 or 512"):
         _native.conv1d_split_f16([torch.zeros((1, 32, 16), device=_dev())], P[:1], [None], [ks[0]], dil)
 
 
@@ -281,7 +284,7 @@ def test_persistent_blocks_walk_many_tiles_and_cross_members(monkeypatch, blocks
     cases above give each block one tile): forced grid sizes, same results bit for bit as the full grid."""
     rng = np.random.RandomState(77)
     ks = (7, 11, 3)
-    for C, T, dil in ((16, 1500, 3), (32, 900, 5), (64, 1030, 3), (128, 520, 1)):
+    for C, T, dil in ((16, 1500, 3), (32, 900, 5), (64, 1030, 3), (128, 520, 1), (256, 260, 5)):
         ms = [_member(rng, 2, C, T, k, True) for k in ks]
         xs = [_t(m[0]) for m in ms]
         h1, h2 = [_native.pack_pair(_t(m[1]), SPLIT) for m in ms], [_native.pack_pair(_t(m[3]), SPLIT) for m in ms]

@@ -174,6 +174,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert L.fv_packed_pair_floats_ex(32, 7, _native.PAIR_SPLIT_F16) == 7 * 2 * 512
     assert L.fv_packed_pair_floats_ex(64, 11, _native.PAIR_SPLIT_F16) == 22 * 2048
     assert L.fv_packed_pair_floats_ex(128, 3, _native.PAIR_SPLIT_F16) == 2 * 12 * 2048
+    assert L.fv_packed_pair_floats_ex(512, 7, _native.PAIR_SPLIT_F16) == 8 * 4 * 28 * 2048      # row tiles x chunks x steps
     assert L.fv_packed_pair_floats_ex(48, 3, _native.PAIR_SPLIT_F16) == 0
     assert L.fv_packed_pair_floats_ex(32, 11, _native.PAIR_F32) == 32 * 32 * 11
     # host-only entry points that need no device
@@ -257,7 +258,7 @@ def test_plan_shape_inference_without_gpu():
     assert b"scratch" in L.fv_last_error()
     assert L.fv_plan_add_resblock_pair_ex(w, 3, 1, -1, 4, -1, -1, dummy, dummy, None, None, 16, 3, 3, 0.1, 1.0, 0, 1.0, S) != 0
     assert L.fv_plan_add_conv1d_split_f16(w, 0, 2, -1, -1, -1, -1, dummy, None, 32, 11, 5, 0.1, 1.0, 0, 1.0) != 0
-    assert b"64 or 128" in L.fv_last_error()
+    assert b"64, 128, 256 or 512" in L.fv_last_error()
     L.fv_plan_destroy(w)
 
 
