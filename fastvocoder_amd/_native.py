@@ -153,8 +153,8 @@ def lib():
     L.fv_resblock1_fused_ex.argtypes = [i, pp, pp, pp, pp, pp, pp, pp, pp, pp, pp, ctypes.POINTER(i), i, i, i, i, f, f,
                                         i, f, i, vp]
     L.fv_plan_add_resblock_pair_ex.argtypes = [vp, i, i, i, i, i, i, vp, vp, vp, vp, i, i, i, f, f, i, f, i]
-    L.fv_conv1d_split_f16.argtypes = [i, pp, pp, pp, pp, pp, pp, pp, pp, ctypes.POINTER(i), i, i, i, i, f, f, i, f, vp]
-    L.fv_plan_add_conv1d_split_f16.argtypes = [vp, i, i, i, i, i, i, vp, vp, i, i, i, f, f, i, f]
+    L.fv_conv1d_split_f16.argtypes = [i, pp, pp, pp, pp, pp, pp, pp, pp, ctypes.POINTER(i), i, i, i, i, i, f, f, i, f, vp]
+    L.fv_plan_add_conv1d_split_f16.argtypes = [vp, i, i, i, i, i, i, vp, vp, i, i, i, i, f, f, i, f]
     L.fv_plan_add_mrf_sum.argtypes = [vp, ctypes.POINTER(i), i, i, pp, pp, pp, pp, i, ctypes.POINTER(i), i, f, f, i, f]
     L.fv_plan_create.argtypes = [i]
     L.fv_plan_create.restype = vp
@@ -310,6 +310,11 @@ def pair_supported(channels, k, dil, prec=PAIR_F32):
     return channels in chans and k in (3, 7, 11) and dil in (1, 3, 5) and prec in (PAIR_F32, PAIR_SPLIT_F16)
 
 
+def conv_split_supported(channels, k, dil):
+    """Shapes of the conv-level split-f16 op (csrc/convh_launch.hip): the ResBlock shapes plus MelGAN's dilation 9."""
+    return channels in (64, 128, 256, 512) and ((k in (3, 7, 11) and dil in (1, 3, 5)) or (k == 3 and dil == 9))
+
+
 def _vp_array(tensors, name, allow_none=False):
     return (ctypes.c_void_p * len(tensors))(*[_ptr(t, name, allow_none) for t in tensors])
 
@@ -344,10 +349,10 @@ def resblock1_fused(xs, w1s, w2s, b1s, b2s, ks, dil, slope, act_slope=1.0, outs=
 
 
 def conv1d_split_f16(xs, packed, biases, ks, dil, pre_slope=1.0, res=None, add1=None, add2=None, out_div=1.0,
-                     post=POST_NONE, act_slope=1.0, outs=None, outs_act=None):
-    """n = len(xs) independent 'same' convs with split-f16 operands in one launch (fv_conv1d_split_f16), C = 64 / 128:
-    y_j = post((conv(lrelu(x_j, pre_slope)) + bias_j + res_j + add1_j + add2_j) / out_div);
-    packed from pack_pair(w, PAIR_SPLIT_F16)."""
+                     post=POST_NONE, act_slope=1.0, outs=None, outs_act=None, pad_mode=PAD_ZERO):
+    """n = len(xs) independent 'same' convs with split-f16 operands in one launch (fv_conv1d_split_f16), C = 64 ... 512:
+    y_j = post((conv(pad(lrelu(x_j, pre_slope))) + bias_j + res_j + add1_j + add2_j) / out_div), zero or reflection
+    padding; packed from pack_pair(w, PAIR_SPLIT_F16)."""
     n = len(xs)
     B, C, T = xs[0].shape
     if outs is None:
@@ -360,7 +365,7 @@ def conv1d_split_f16(xs, packed, biases, ks, dil, pre_slope=1.0, res=None, add1=
                                         _vp_array(biases, "bias", True), _vp_array(rs, "res", True),
                                         _vp_array(a1, "add1", True), _vp_array(a2, "add2", True), _vp_array(outs, "y"),
                                         _vp_array(acts, "y_act", True), (ctypes.c_int * n)(*ks), B, C, T, dil,
-                                        float(pre_slope), float(out_div), post, float(act_slope), stream))
+                                        pad_mode, float(pre_slope), float(out_div), post, float(act_slope), stream))
     return outs
 
 
@@ -569,14 +574,15 @@ class Plan:
                                                  float(out_div), post, float(act_slope), prec))
 
     def add_conv1d_split_f16(self, x, y, packed, bias, channels, k, dil, pre_slope=1.0, res=SLOT_NONE, add1=SLOT_NONE,
-                             add2=SLOT_NONE, out_div=1.0, post=POST_NONE, y_act=SLOT_NONE, act_slope=1.0):
+                             add2=SLOT_NONE, out_div=1.0, post=POST_NONE, y_act=SLOT_NONE, act_slope=1.0,
+                             pad_mode=PAD_ZERO):
         """One 'same' conv with split-f16 operands (fv_plan_add_conv1d_split_f16); group members share a launch."""
         for t in (packed, bias):
             if t is not None:
                 self.keep(t)
         check(lib().fv_plan_add_conv1d_split_f16(self._h, x, y, y_act, res, add1, add2, _ptr(packed, "packed"),
-                                                 _ptr(bias, "bias", True), channels, k, dil, float(pre_slope),
-                                                 float(out_div), post, float(act_slope)))
+                                                 _ptr(bias, "bias", True), channels, k, dil, pad_mode,
+                                                 float(pre_slope), float(out_div), post, float(act_slope)))
 
     def add_mrf_sum(self, xs, y, packed1, packed2, bias1, bias2, channels, ks, dil, slope, out_div=3.0,
                     post=POST_NONE, y_act=SLOT_NONE, act_slope=1.0):

@@ -1208,22 +1208,26 @@ int fv_plan_add_resblock_pair_ex(fv_plan_t* plan, int x_slot, int y_slot, int y_
     return 0;
 }
 
-static int check_convh_args(int n, int C, const int* k, int dil) {
+static int check_convh_args(int n, int C, const int* k, int dil, int pad_mode) {
+    if (pad_mode != FV_PAD_ZERO && pad_mode != FV_PAD_REFLECT)
+        return fail(FV_ERR_UNSUPPORTED, "conv1d_split_f16: pad_mode %d (FV_PAD_ZERO or FV_PAD_REFLECT)", pad_mode);
     if (n < 1 || n > 3) return fail(FV_ERR_INVALID_ARG, "conv1d_split_f16: %d members (1..3)", n);
     if (C != 64 && C != 128 && C != 256 && C != 512)
         return fail(FV_ERR_UNSUPPORTED, "conv1d_split_f16: C = %d (64, 128, 256 or 512)", C);
-    if (dil != 1 && dil != 3 && dil != 5) return fail(FV_ERR_UNSUPPORTED, "conv1d_split_f16: dilation %d (1, 3 or 5)", dil);
+    if (dil != 1 && dil != 3 && dil != 5 && dil != 9)
+        return fail(FV_ERR_UNSUPPORTED, "conv1d_split_f16: dilation %d (1, 3, 5; 9 with 3 taps)", dil);
     for (int j = 0; j < n; ++j)
-        if (k[j] != 3 && k[j] != 7 && k[j] != 11) return fail(FV_ERR_UNSUPPORTED, "conv1d_split_f16: %d taps (3, 7 or 11)", k[j]);
+        if ((k[j] != 3 && k[j] != 7 && k[j] != 11) || (dil == 9 && k[j] != 3))
+            return fail(FV_ERR_UNSUPPORTED, "conv1d_split_f16: %d taps at dilation %d (3, 7 or 11; 3 at dilation 9)", k[j], dil);
     return 0;
 }
 
 int fv_conv1d_split_f16(int n, const float* const* x, const float* const* packed, const float* const* bias,
                         const float* const* res, const float* const* add1, const float* const* add2, float* const* y,
-                        float* const* y_act, const int* k, int B, int C, int T, int dil, float pre_slope, float out_div,
-                        int post, float act_slope, void* stream) {
+                        float* const* y_act, const int* k, int B, int C, int T, int dil, int pad_mode, float pre_slope,
+                        float out_div, int post, float act_slope, void* stream) {
     if (!x || !packed || !y || !k) return fail(FV_ERR_INVALID_ARG, "conv1d_split_f16: null argument");
-    if (int rc = check_convh_args(n, C, k, dil)) return rc;
+    if (int rc = check_convh_args(n, C, k, dil, pad_mode)) return rc;
     PairParams pp = {};
     pp.n_members = n;
     pp.B = B;
@@ -1233,6 +1237,7 @@ int fv_conv1d_split_f16(int n, const float* const* x, const float* const* packed
     pp.out_div = out_div;
     pp.post = post;
     pp.prec = FV_PAIR_SPLIT_F16;
+    pp.reflect = pad_mode == FV_PAD_REFLECT;
     for (int j = 0; j < n; ++j) {
         PairMember& mb = pp.m[j];
         mb.x = x[j];
@@ -1253,9 +1258,9 @@ int fv_conv1d_split_f16(int n, const float* const* x, const float* const* packed
 
 int fv_plan_add_conv1d_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, int res_slot, int add1_slot,
                                  int add2_slot, const float* packed, const float* bias, int C, int k, int dil,
-                                 float pre_slope, float out_div, int post, float act_slope) {
+                                 int pad_mode, float pre_slope, float out_div, int post, float act_slope) {
     if (!plan || !packed) return fail(FV_ERR_INVALID_ARG, "plan_add_conv1d_split_f16: null");
-    if (int rc = check_convh_args(1, C, &k, dil)) return rc;
+    if (int rc = check_convh_args(1, C, &k, dil, pad_mode)) return rc;
     if (add2_slot != FV_SLOT_NONE && add1_slot == FV_SLOT_NONE) return fail(FV_ERR_INVALID_ARG, "plan_add_conv1d_split_f16: add2 without add1");
     if (int rc = check_slot(x_slot, false)) return rc;
     if (int rc = check_slot(y_slot, false)) return rc;
@@ -1279,6 +1284,7 @@ int fv_plan_add_conv1d_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_
     o.Cin = o.Cout = C;
     o.k = k;
     o.dil = dil;
+    o.pad_mode = pad_mode;
     o.pre_slope = pre_slope;
     o.act_slope = act_slope;
     o.out_div = out_div;
@@ -1450,6 +1456,7 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             if (o.group != 0)
                 while (m < plan->ops.size() && m - n < 3 && plan->ops[m].type == OP_CONVH && plan->ops[m].group == o.group &&
                        plan->ops[m].lane == o.lane && plan->ops[m].Cin == o.Cin && plan->ops[m].dil == o.dil &&
+                       plan->ops[m].pad_mode == o.pad_mode &&
                        plan->ops[m].pre_slope == o.pre_slope && plan->ops[m].act_slope == o.act_slope &&
                        plan->ops[m].out_div == o.out_div && plan->ops[m].post == o.post)
                     ++m;
@@ -1466,6 +1473,7 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             pp.out_div = o.out_div;
             pp.post = o.post;
             pp.prec = FV_PAIR_SPLIT_F16;
+            pp.reflect = o.pad_mode == FV_PAD_REFLECT;
             pp.n_members = (int)(m - n);
             for (size_t q = n; q < m; ++q) {
                 const Op& qo = plan->ops[q];

@@ -15,7 +15,8 @@ int launch_convh_geom(const PairParams& p, int dil, size_t lds, hipStream_t s) {
     switch (dil) {
         case 1: FV_CONVH(1); break;
         case 3: FV_CONVH(3); break;
-        default: FV_CONVH(5); break;
+        case 5: FV_CONVH(5); break;
+        default: FV_CONVH(9); break;
     }
 #undef FV_CONVH
     FV_HIP(hipGetLastError());

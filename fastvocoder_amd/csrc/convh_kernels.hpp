@@ -82,16 +82,22 @@ struct ConvHRaw {
     float v[G::XR][8];
 };
 
-// raw window rows [tA, tA + XROWS) of all C channels -> registers; rows outside [0, T) (or `live` false) read as zero
+// raw window rows [tA, tA + XROWS) of all C channels -> registers; rows outside [0, T) (or `live` false) read as zero,
+// or (reflect: MelGAN's ReflectionPad1d, pad < T) as the row mirrored at the first / last sample
 template <class G>
-__device__ __forceinline__ void convh_load_raw(ConvHRaw<G>& r, const float* xb, int T, int tA, int tid, bool live) {
+__device__ __forceinline__ void convh_load_raw(ConvHRaw<G>& r, const float* xb, int T, int tA, int tid, bool live,
+                                               bool reflect = false) {
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)G::C * (unsigned)T * 4u);
     const unsigned t4 = (unsigned)T * 4u;
 #pragma unroll
     for (int q = 0; q < G::XR; ++q) {
         const int idx = tid + q * G::NT;
         const int cb = idx / G::XROWS, row = idx - cb * G::XROWS;
-        const int t = tA + row;
+        int t = tA + row;
+        if (reflect) {
+            t = t < 0 ? -t : t;
+            t = t >= T ? 2 * (T - 1) - t : t;
+        }
         const bool ok = live && idx < G::XROWS * G::CB && t >= 0 && t < T;
         const unsigned voff = ok ? (unsigned)(cb * 8 * T + t) * 4u : kOutOfRange;
 #pragma unroll
@@ -168,7 +174,7 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
     if (!first) pair_barrier();                         // everybody is done with the previous member's LDS
     pair_stamp(p, 8, wave, lane, 7, 12);
     ConvHRaw<G> raw;
-    convh_load_raw<G>(raw, mb.x + b * ustride, p.T, ntile * G::NTC - G::P, tid, true);
+    convh_load_raw<G>(raw, mb.x + b * ustride, p.T, ntile * G::NTC - G::P, tid, true, p.reflect != 0);
 #pragma unroll
     for (int st = 0; st < 3; ++st)
         convh_dma_stage<G>(rw, ring, st, (unsigned)(mtile * nch * G::WTILE + st * G::STAGE_BYTES), wave, lane);
@@ -228,7 +234,7 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
             convh_dma_stage<G>(rw, ring, (g0 + NS) & 3, off, wave, lane);
             if constexpr (GS == G::RAWST)
                 convh_load_raw<G>(raw, mb.x + nb * ustride + nchunk * cstride, p.T, nnt * G::NTC - G::P, tid,
-                                  new_win && !(p.dbg & 1));
+                                  new_win && !(p.dbg & 1), p.reflect != 0);
             if constexpr (GS == G::RESST) {
                 // bias and residual of THIS tile: in flight during the last two stages
                 // (before the tile's last chunk the same loads are issued out of range: the wait counts stay static)
@@ -388,13 +394,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     PairParams q;
     q.n_members = p.n_members; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = p.out_div;
     q.act_slope = p.act_slope; q.post = p.post; q.x_off = p.x_off; q.img_off = p.img_off; q.dbg = p.dbg; q.trace = p.trace;
-    q.ctot = p.ctot; q.nch = p.nch; q.nmt = p.nmt;
+    q.ctot = p.ctot; q.nch = p.nch; q.nmt = p.nmt; q.reflect = p.reflect;
     int n_items[3], cost[3];
 #pragma unroll
     for (int m = 0; m < 3; ++m) { n_items[m] = p.m[m].n_items; cost[m] = p.m[m].cost; }
     asm volatile("" ::"s"(q.n_members), "s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.out_div), "s"(q.act_slope),
                  "s"(q.post), "s"(q.x_off), "s"(q.img_off), "s"(q.dbg), "s"(q.trace), "s"(n_items[0]), "s"(n_items[1]),
-                 "s"(n_items[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]), "s"(q.ctot), "s"(q.nch), "s"(q.nmt));
+                 "s"(n_items[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.reflect));
     long long total = 0;
 #pragma unroll
     for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_items[m] * cost[m] : 0;
@@ -413,7 +419,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         mb.add2 = p.m[m].add2; mb.y = p.m[m].y; mb.y_act = p.m[m].y_act; mb.k = p.m[m].k; mb.n_tiles = p.m[m].n_tiles;
         asm volatile("" ::"s"(mb.x), "s"(mb.w1), "s"(mb.b1), "s"(mb.res), "s"(mb.add1), "s"(mb.add2), "s"(mb.y), "s"(mb.y_act),
                      "s"(mb.k), "s"(mb.n_tiles));
-        if (mb.k == 11) convh_run_member<ConvHGeom<CG, NFW, 11, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
+        if constexpr (DIL > 5)                            // (dilation 9 is MelGAN's third ResidualStack layer: 3 taps only)
+            convh_run_member<ConvHGeom<CG, NFW, 3, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
+        else if (mb.k == 11) convh_run_member<ConvHGeom<CG, NFW, 11, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
         else if (mb.k == 7) convh_run_member<ConvHGeom<CG, NFW, 7, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
         else convh_run_member<ConvHGeom<CG, NFW, 3, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
         first = false;

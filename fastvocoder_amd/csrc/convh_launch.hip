@@ -30,7 +30,8 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     if (p.B <= 0 || p.T <= 0) return 0;
     if (C != 64 && C != 128 && C != 256 && C != 512)
         return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: C = %d (64, 128, 256 or 512)", C);
-    if (dil != 1 && dil != 3 && dil != 5) return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: dilation %d (1, 3 or 5)", dil);
+    if (dil != 1 && dil != 3 && dil != 5 && dil != 9)
+        return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: dilation %d (1, 3, 5; 9 with 3 taps)", dil);
     if (p.n_members < 1 || p.n_members > 3) return fail(FV_ERR_INVALID_ARG, "split-f16 conv: %d members", p.n_members);
     if ((double)C * p.T * 4.0 >= 1073741824.0)
         return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: one utterance's tensor (%d x %d floats) exceeds the 1 GiB "
@@ -43,6 +44,9 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     for (int i = 0; i < p.n_members; ++i) {
         PairMember& mb = p.m[i];
         if (mb.k != 11 && mb.k != 7 && mb.k != 3) return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: %d taps (3, 7 or 11)", mb.k);
+        if (dil == 9 && mb.k != 3) return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: dilation 9 with %d taps (3 only)", mb.k);
+        if (p.reflect && (mb.k - 1) / 2 * dil >= p.T)
+            return fail(FV_ERR_INVALID_ARG, "split-f16 conv: reflection padding %d needs more than %d samples", (mb.k - 1) / 2 * dil, p.T);
         if (!mb.x || !mb.w1 || !mb.y) return fail(FV_ERR_INVALID_ARG, "split-f16 conv: null tensor (member %d)", i);
         if (mb.add2 && !mb.add1) return fail(FV_ERR_INVALID_ARG, "split-f16 conv: add2 without add1 (member %d)", i);
         if (reinterpret_cast<uintptr_t>(mb.w1) & 15)

@@ -166,6 +166,7 @@ struct PairParams {
     int post;            // FV_POST_* applied to y (sum mode / single)
     int nblk;            // persistent blocks in the grid
     int ctot, nch, nmt;  // convh: channels in and out, chunks of <= 128 input channels, row tiles of 64
+    int reflect;         // convh: rows outside [0, T) are the mirrored samples (ReflectionPad1d) instead of zeros
     int prec;            // FV_PAIR_F32: fp32 MFMA (pair_kernels.hpp); FV_PAIR_SPLIT_F16: pairh_kernels.hpp
     int x_off, mid_off;  // float offsets of the x image / intermediate in dynamic LDS
     int img_off;         // split-f16 kernels: float offset of the x image (x_off: the member's packed weights)

@@ -185,18 +185,31 @@ class PlanBuilder:
                              out_div=float(out_div), post=post, mid=mid if wide else SLOT_NONE,
                              tmps=[mid] if wide else [], **m))
 
+    @staticmethod
+    def conv_split_supported(conv, pad, pad_mode=PAD_ZERO):
+        """Is this a 'same' conv (zero or reflection padding ``pad`` applied in front of it) the split-f16 conv kernels
+        are built for, and is that arithmetic in force?"""
+        c, k, d = conv.in_channels, conv.kernel_size[0], conv.dilation[0]
+        return (conv.stride[0] == 1 and conv.groups == 1 and conv.out_channels == c and pad == d * (k - 1) // 2
+                and pad_mode in (PAD_ZERO, PAD_REFLECT) and c in (64, 128, 256, 512)
+                and PlanBuilder.pair_precision(c) == _native.PAIR_SPLIT_F16
+                and _native.conv_split_supported(c, k, d))
+
     def conv_split(self, conv, src, dst, slope, res=SLOT_NONE, add1=SLOT_NONE, add2=SLOT_NONE, out_div=1.0,
-                   post=POST_NONE):
-        """dst = post((conv(lrelu(src, slope)) + bias + res + add1 + add2) / out_div): a 'same' conv of a 64- or
-        128-channel ResBlock with split-f16 operands (fv_plan_add_conv1d_split_f16).  ``src`` is read raw -- the
-        activation is applied on chip -- so nothing is hoisted into its producer.  Ops recorded inside one group
+                   post=POST_NONE, pad=None, pad_mode=PAD_ZERO):
+        """dst = post((conv(pad(lrelu(src, slope))) + bias + res + add1 + add2) / out_div): a 'same' conv of a 64- ...
+        512-channel ResBlock (zero padding, the conv's own) or MelGAN ResidualStack (``pad`` reflected samples in
+        front of an unpadded conv) with split-f16 operands (fv_plan_add_conv1d_split_f16).  ``src`` is read raw --
+        the activation is applied on chip -- so nothing is hoisted into its producer.  Ops recorded inside one group
         share a launch."""
         c, k, d = conv.in_channels, conv.kernel_size[0], conv.dilation[0]
-        if not (conv.stride[0] == 1 and conv.groups == 1 and conv.out_channels == c and conv.padding[0] == d * (k - 1) // 2
-                and c in (64, 128, 256, 512) and _native.pair_supported(c, k, d, _native.PAIR_SPLIT_F16)):
+        pad = conv.padding[0] if pad is None else pad + conv.padding[0]
+        if not (conv.stride[0] == 1 and conv.groups == 1 and conv.out_channels == c and pad == d * (k - 1) // 2
+                and pad_mode in (PAD_ZERO, PAD_REFLECT) and (pad_mode == PAD_ZERO or conv.padding[0] == 0)
+                and c in (64, 128, 256, 512) and _native.conv_split_supported(c, k, d)):
             raise _native.NativeError("conv_split: shape not built into the split-f16 conv kernels")
         self.ops.append(dict(kind="convh", lane=self.lane, group=self.group, x=src, y=dst, res=res, acc=add1, acc2=add2,
-                             pre_slope=1.0, slope=float(slope), channels=c, k=k, dil=d,
+                             pre_slope=1.0, slope=float(slope), channels=c, k=k, dil=d, pad_mode=pad_mode,
                              packed=_native.pack_pair(effective_weight(conv), _native.PAIR_SPLIT_F16),
                              bias=self._bias(conv), out_div=float(out_div), post=post))
 
@@ -379,7 +392,7 @@ class PlanBuilder:
                 self.plan.add_conv1d_split_f16(op["x"], op["y"], op["packed"], op["bias"], op["channels"], op["k"],
                                                op["dil"], pre_slope=op["slope"], res=op["res"], add1=op["acc"],
                                                add2=op["acc2"], out_div=op["out_div"], post=op["post"],
-                                               y_act=op["y_act"], act_slope=op["act_slope"])
+                                               y_act=op["y_act"], act_slope=op["act_slope"], pad_mode=op["pad_mode"])
             elif op["kind"] == "mrfsum":
                 ms = op["members"]
                 self.plan.add_mrf_sum([op["x"], op["xb"], op["xc"]], op["y"], [m["w1"] for m in ms],
@@ -438,11 +451,12 @@ class NativeModule(torch.nn.Module):
 
     # -- cache bookkeeping -------------------------------------------------
     def _fv_state(self):
-        """(registration epoch, sum of in-place version counters) of the tensors the plans bake in."""
+        """(registration epoch, sum of in-place version counters of the tensors the plans bake in, arithmetic policy
+        in force -- FV_PAIR_PREC decides which kernels a plan records)."""
         if self._fv_tensors is None or self._fv_epoch != _registration_epoch[0]:
             self._fv_tensors = list(self.parameters()) + list(self.buffers())
             self._fv_epoch = _registration_epoch[0]
-        return self._fv_epoch, sum(t._version for t in self._fv_tensors)
+        return self._fv_epoch, sum(t._version for t in self._fv_tensors), PlanBuilder.pair_mode_tag()
 
     # A native plan is a raw handle plus pointers into THIS module's packed weights: a copied or
     # unpickled module must not share it (double free, stale device pointers) -- it rebuilds its own.

@@ -16,6 +16,7 @@ from .. import _native
 
 LRELU_SLOPE = 0.1  # reference modules.py:9
 _FUSE_SKIP = os.environ.get("FV_FUSE_SKIP", "1") != "0"   # ResidualStack: 1x1 + skip 1x1 as one launch
+_SPLIT_STACK = os.environ.get("FV_SPLIT_STACK", "1") != "0"   # ... its dilated conv on the split-f16 conv kernels
 
 
 def get_padding(kernel_size, dilation=1):
@@ -242,7 +243,12 @@ class ResidualStack(_Block):
         hidden, skip = scratch[:2]
         dilated, pointwise = (self.stack[i] for i in self._conv_at)
         dilated = getattr(dilated, "conv", dilated)               # CausalConv1d wraps its conv
-        pb.conv(dilated, src, hidden, pad=self._pad, pad_mode=self._pad_mode, pre_slope=self._slope)
+        if _SPLIT_STACK and pb.conv_split_supported(dilated, self._pad, self._pad_mode):
+            # 64 ... 512 channels: the dilated conv with split-f16 operands (csrc/convh_kernels.hpp), the
+            # reflected samples are mirrored addresses of its window loader
+            pb.conv_split(dilated, src, hidden, self._slope, pad=self._pad, pad_mode=self._pad_mode)
+        else:
+            pb.conv(dilated, src, hidden, pad=self._pad, pad_mode=self._pad_mode, pre_slope=self._slope)
         if _FUSE_SKIP and self.channels > 4:
             # stack[4](act(hidden)) + skip_layer(src): one GEMM over the concatenated K range;
             # the skip branch costs no launch and no [B,C,T] round trip (src is read raw)

@@ -182,20 +182,22 @@ int fv_resblock1_fused_ex(int n, const float* const* x, const float* const* w1, 
  * Conv1d of the wide ResBlock stages with split-f16 operands (arithmetic: FV_PAIR_SPLIT_F16 above), n = 1..3
  * independent members in one launch -- the convs at the same position of the three ResBlocks of an MRF stage:
  *
- *     y_j = post( ( conv1d( lrelu(x_j, pre_slope); w_j, k_j taps, dilation dil, 'same' zero padding ) + bias_j
+ *     y_j = post( ( conv1d( lrelu(x_j, pre_slope); w_j, k_j taps, dilation dil, 'same' padding ) + bias_j
  *                   + res_j + add1_j + add2_j ) / out_div ),      y_act_j = lrelu(y_j, act_slope)
  *
+ * pad_mode: FV_PAD_ZERO (the HiFi-GAN ResBlock convs) or FV_PAD_REFLECT (the dilated convs of MelGAN's
+ * ResidualStack, modules.py:351-359: ReflectionPad1d((k-1)/2*dil) in front of a 3-tap conv; needs (k-1)/2*dil < T).
  * (modules.py:223-230: conv1 of a pair is res = add = NULL; conv2 is res = the pair's input; the last conv of a
  * stage's first block carries the MRF merge, hifigan.py:99-103, with add1 / add2 = the other blocks' results.)
- * C = Cin = Cout = 64, 128, 256 or 512, k_j in {3, 7, 11}, dil in {1, 3, 5}; x_j is read RAW (the activation is applied on
+ * C = Cin = Cout = 64, 128, 256 or 512, k_j in {3, 7, 11}, dil in {1, 3, 5} (and 9 with k_j = 3); x_j is read RAW (the activation is applied on
  * chip while the operand is split); packed_j: fv_pack_pair_weight_ex(C, k_j, FV_PAIR_SPLIT_F16) -- the packed
  * weights stream L2 -> LDS through a 4-stage ring (csrc/convh_kernels.hpp).  out_div / post apply to members with
  * add1 only.  Any T.
  */
 int fv_conv1d_split_f16(int n, const float* const* x, const float* const* packed, const float* const* bias,
                         const float* const* res, const float* const* add1, const float* const* add2, float* const* y,
-                        float* const* y_act, const int* k, int B, int C, int T, int dil, float pre_slope, float out_div,
-                        int post, float act_slope, void* stream);
+                        float* const* y_act, const int* k, int B, int C, int T, int dil, int pad_mode, float pre_slope,
+                        float out_div, int post, float act_slope, void* stream);
 
 /*
  * End of an MRF stage (hifigan.py:97-103): the LAST pairs of the three ResBlocks and the mean, one launch:
@@ -348,11 +350,11 @@ int fv_plan_add_resblock_pair_ex(fv_plan_t* plan, int x_slot, int y_slot, int y_
                                  int add2_slot, const float* packed1, const float* packed2, const float* bias1,
                                  const float* bias2, int C, int k, int dil, float slope, float out_div, int post,
                                  float act_slope, int prec);
-/* fv_conv1d_split_f16 as a plan op; consecutive ops under one non-zero group id with equal C, dilation, slopes,
- * out_div and post run as ONE launch */
+/* fv_conv1d_split_f16 as a plan op; consecutive ops under one non-zero group id with equal C, dilation, padding
+ * mode, slopes, out_div and post run as ONE launch */
 int fv_plan_add_conv1d_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, int res_slot, int add1_slot,
                                  int add2_slot, const float* packed, const float* bias, int C, int k, int dil,
-                                 float pre_slope, float out_div, int post, float act_slope);
+                                 int pad_mode, float pre_slope, float out_div, int post, float act_slope);
 int fv_plan_add_mrf_sum(fv_plan_t* plan, const int* x_slots, int y_slot, int y_act_slot,
                         const float* const* packed1, const float* const* packed2, const float* const* bias1,
                         const float* const* bias2, int C, const int* k, int dil, float slope, float out_div,

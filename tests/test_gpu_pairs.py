@@ -278,6 +278,45 @@ def test_conv1d_split_f16_vs_oracle(case):
         _native.conv1d_split_f16([torch.zeros((1, 32, 16), device=_dev())], P[:1], [None], [ks[0]], dil)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 300, 9, (3,)), (1, 128, 130, 9, (3,)), (2, 256, 257, 3, (3,)), (1, 64, 12, 1, (3, 7)),
+                                  (1, 512, 50, 9, (3,)), (3, 128, 10, 9, (3,)), (1, 64, 128, 5, (11, 3))],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_conv1d_split_f16_reflection_padding_vs_oracle(case):
+    """MelGAN's ResidualStack conv (reference modules.py:351-359): ReflectionPad1d((k-1)/2 dil) in front of the conv,
+    as mirrored rows of the window loader; dilation 9 exists with 3 taps."""
+    B, C, T, dil, ks = case
+    rng = np.random.RandomState(17 * T + C + dil)
+    xs = [rng.randn(B, C, T).astype(np.float32) for _ in ks]
+    ws = [(rng.randn(C, C, k) / np.sqrt(C * k)).astype(np.float32) for k in ks]
+    bs = [rng.randn(C).astype(np.float32) for _ in ks]
+    conv = [oo.conv1d(x, w, b, dil=dil, pad=(k - 1) * dil // 2, pad_mode=oo.PAD_REFLECT, pre_slope=0.2)
+            for x, w, b, k in zip(xs, ws, bs, ks)]
+    X, P, Bi = [_t(x) for x in xs], [_native.pack_pair(_t(w), SPLIT) for w in ws], [_t(b) for b in bs]
+    ys = _native.conv1d_split_f16(X, P, Bi, list(ks), dil, pre_slope=0.2, pad_mode=_native.PAD_REFLECT)
+    for y, c in zip(ys, conv):
+        assert _rel(y, c) <= 4e-6
+    # the hidden tensor stored activated for the 1x1 behind it (act_slope without a twin)
+    ys = _native.conv1d_split_f16(X, P, Bi, list(ks), dil, pre_slope=0.2, pad_mode=_native.PAD_REFLECT, act_slope=0.2)
+    for y, c in zip(ys, conv):
+        assert _rel(y, oo.lrelu(c, 0.2)) <= 4e-6
+    # zero padding with dilation 9 too
+    zc = [oo.conv1d(x, w, b, dil=dil, pad=(k - 1) * dil // 2, pre_slope=0.2) for x, w, b, k in zip(xs, ws, bs, ks)]
+    for y, c in zip(_native.conv1d_split_f16(X, P, Bi, list(ks), dil, pre_slope=0.2), zc):
+        assert _rel(y, c) <= 4e-6
+
+
+def test_conv1d_split_f16_reflection_rejects():
+    x = [torch.zeros((1, 64, 9), device=_dev())]
+    w = [_native.pack_pair(torch.zeros((64, 64, 3), device=_dev()), SPLIT)]
+    with pytest.raises(_native.NativeError, match="reflection padding 9 needs more than 9"):
+        _native.conv1d_split_f16(x, w, [None], [3], 9, pad_mode=_native.PAD_REFLECT)
+    w7 = [_native.pack_pair(torch.zeros((64, 64, 7), device=_dev()), SPLIT)]
+    with pytest.raises(_native.NativeError, match="dilation 9"):
+        _native.conv1d_split_f16(x, w7, [None], [7], 9)
+    with pytest.raises(_native.NativeError, match="pad_mode"):
+        _native.conv1d_split_f16(x, w, [None], [3], 1, pad_mode=_native.PAD_CAUSAL)
+
+
 @pytest.mark.parametrize("blocks", [1, 3, 7])
 def test_persistent_blocks_walk_many_tiles_and_cross_members(monkeypatch, blocks):
     """With few persistent blocks every block walks several tiles and crosses from one member to the next (the small

@@ -249,16 +249,22 @@ def test_plan_shape_inference_without_gpu():
     # ResBlock pairs / split-f16 convs keep the length; a wide pair needs its scratch slot, and only a wide one
     S = _native.PAIR_SPLIT_F16
     w = L.fv_plan_create(64)
-    assert L.fv_plan_add_conv1d_split_f16(w, 0, 2, -1, -1, -1, -1, dummy, None, 64, 11, 5, 0.1, 1.0, 0, 1.0) == 0
-    assert L.fv_plan_add_conv1d_split_f16(w, 2, 3, -1, 0, -1, -1, dummy, None, 64, 11, 1, 0.1, 1.0, 0, 1.0) == 0
+    assert L.fv_plan_add_conv1d_split_f16(w, 0, 2, -1, -1, -1, -1, dummy, None, 64, 11, 5, 0, 0.1, 1.0, 0, 1.0) == 0
+    assert L.fv_plan_add_conv1d_split_f16(w, 2, 3, -1, 0, -1, -1, dummy, None, 64, 11, 1, 0, 0.1, 1.0, 0, 1.0) == 0
     assert L.fv_plan_add_resblock_pair_ex(w, 3, 1, -1, 4, 0, 2, dummy, dummy, None, None, 64, 3, 3, 0.1, 3.0, 0, 0.1, S) == 0
     assert L.fv_plan_output_shape(w, 333, ctypes.byref(c), ctypes.byref(n)) == 0
     assert (c.value, n.value) == (64, 333)
     assert L.fv_plan_add_resblock_pair_ex(w, 3, 1, -1, -1, -1, -1, dummy, dummy, None, None, 64, 3, 3, 0.1, 1.0, 0, 1.0, S) != 0
     assert b"scratch" in L.fv_last_error()
     assert L.fv_plan_add_resblock_pair_ex(w, 3, 1, -1, 4, -1, -1, dummy, dummy, None, None, 16, 3, 3, 0.1, 1.0, 0, 1.0, S) != 0
-    assert L.fv_plan_add_conv1d_split_f16(w, 0, 2, -1, -1, -1, -1, dummy, None, 32, 11, 5, 0.1, 1.0, 0, 1.0) != 0
+    assert L.fv_plan_add_conv1d_split_f16(w, 0, 2, -1, -1, -1, -1, dummy, None, 32, 11, 5, 0, 0.1, 1.0, 0, 1.0) != 0
     assert b"64, 128, 256 or 512" in L.fv_last_error()
+    # MelGAN's ResidualStack convs: reflection padding, dilation 9 with 3 taps only; no causal form
+    assert L.fv_plan_add_conv1d_split_f16(w, 0, 2, -1, -1, -1, -1, dummy, None, 64, 3, 9, _native.PAD_REFLECT, 0.2, 1.0, 0, 1.0) == 0
+    assert L.fv_plan_add_conv1d_split_f16(w, 0, 2, -1, -1, -1, -1, dummy, None, 64, 7, 9, 0, 0.2, 1.0, 0, 1.0) != 0
+    assert b"dilation 9" in L.fv_last_error()
+    assert L.fv_plan_add_conv1d_split_f16(w, 0, 2, -1, -1, -1, -1, dummy, None, 64, 3, 1, _native.PAD_CAUSAL, 0.2, 1.0, 0, 1.0) != 0
+    assert b"pad_mode" in L.fv_last_error()
     L.fv_plan_destroy(w)
 
 
