@@ -174,7 +174,7 @@ def roofline_report(model, mel, ms_per_step, reps=5):
              "pair16": _native.KERNEL_PAIR16, "pair32": _native.KERNEL_PAIR32,
              "pairh16": _native.KERNEL_PAIRH16, "pairh32": _native.KERNEL_PAIRH32,
              "convh64": _native.KERNEL_CONVH64, "convh128": _native.KERNEL_CONVH128,
-             "narrow": _native.KERNEL_CONV_NARROW}
+             "convt": _native.KERNEL_CONVT, "narrow": _native.KERNEL_CONV_NARROW}
     rec = {k: _native.profile_collect(v) for k, v in kinds.items()}
     for r in rec.values():
         r["ms"] = max(r["ms"] - bracket_ms * r["launches"], 0.0)
@@ -187,8 +187,9 @@ def roofline_report(model, mel, ms_per_step, reps=5):
     fp32 = fam("conv32", "conv16", "pair16", "pair32")       # fp32 matrix cores (csrc/conv_kernels.hpp, pair_kernels.hpp)
     wide = fam("convh64", "convh128")                        # split-f16 convs with streamed weights (convh_kernels.hpp)
     pairs = fam("pairh16", "pairh32")                        # split-f16 fused pairs (pairh_kernels.hpp)
-    all_ms = (fp32["ms"] + wide["ms"] + pairs["ms"] + rec["narrow"]["ms"]) / reps
-    all_flops = fp32["flops"] + wide["flops"] + pairs["flops"]
+    ups = fam("convt")                                       # split-f16 transposed convs (convt_kernel)
+    all_ms = (fp32["ms"] + wide["ms"] + pairs["ms"] + ups["ms"] + rec["narrow"]["ms"]) / reps
+    all_flops = fp32["flops"] + wide["flops"] + pairs["flops"] + ups["flops"]
     # Sum of kernel time must fit inside the step; if the calibration ever fails that test, fall back to
     # the whole-step figure (launch gaps included: a lower bound of the kernels' rate)
     consistent = all_ms <= ms_per_step * 1.001
@@ -255,7 +256,7 @@ def roofline_report(model, mel, ms_per_step, reps=5):
         },
         "fp32_mfma_family": {
             "kernel": "fv::conv_mfma_kernel / conv_group3_kernel / conv_sum3_kernel (32x32x2 fp32 MFMA, csrc/conv_kernels.hpp): "
-                      "conv_pre, the transposed-conv upsamplers"
+                      "conv_pre, the transposed-conv upsamplers below 128 input channels"
                       + ("" if wide["ms"] > 0 else ", the 128- and 64-channel stages"),
             "ms_per_step": fp32["ms"] / reps, "launches_per_step": fp32["launches"] // reps,
             "tflops": rate(fp32), "frac_of_fp32_mfma_peak": rate(fp32) / PEAK_FP32_MFMA_TFLOPS,
@@ -267,6 +268,13 @@ def roofline_report(model, mel, ms_per_step, reps=5):
             "fp32_equivalent_tflops": rate(pairs),
             "external_gbs": pairs["bytes"] / (pairs["ms"] * 1e-3) / 1e9 if pairs["ms"] > 0 else 0.0,
             "bound": "hbm / lds (DESIGN.md section 3.7)",
+        },
+        "split_f16_transposed_convs": {
+            "kernel": "fv::convt_kernel (the upsamplers with 128+ input channels: kernel = 2 strides as one GEMM with rows "
+                      "(output channel, phase), split-f16 operands, weights streamed; csrc/convh_kernels.hpp)",
+            "ms_per_step": ups["ms"] / reps, "launches_per_step": ups["launches"] // reps,
+            "fp32_equivalent_tflops": rate(ups),
+            "external_gbs": ups["bytes"] / (ups["ms"] * 1e-3) / 1e9 if ups["ms"] > 0 else 0.0,
         },
         "narrow_conv_ms_per_step": rec["narrow"]["ms"] / reps,
         "by_family_ms_per_step": {k: r["ms"] / reps for k, r in rec.items()},

@@ -18,7 +18,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 # so that the ~170 kernel variants compile in parallel
 SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip", "wav_sink.hip", "conv_inst_narrow.hip",
            "pair_launch.hip", "pair_inst_c16.hip", "pair_inst_c32.hip", "pairh_inst_c16.hip", "pairh_inst_c32.hip",
-           "convh_launch.hip", "convh_inst_c64.hip", "convh_inst_c128.hip", "convp_inst.hip"] + \
+           "convh_launch.hip", "convh_inst_c64.hip", "convh_inst_c128.hip", "convp_inst.hip", "convt_inst.hip"] + \
           [f"conv_inst_s{i}.hip" for i in range(6)]
 HEADERS = ["fv_internal.h", "conv_kernels.hpp", "pair_kernels.hpp", "pair_inst.hpp", "pairh_kernels.hpp",
            "pairh_inst.hpp", "convh_kernels.hpp", "convh_inst.hpp", "convp_kernels.hpp"]
@@ -125,6 +125,11 @@ def lib():
     L.fv_pack_conv_transpose1d_weight.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.fv_conv1d_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, f, i, f, vp]
     L.fv_conv_transpose1d_fused.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, i, f, vp]
+    L.fv_packed_conv_transpose1d_split_floats.argtypes = [i, i, i, i]
+    L.fv_packed_conv_transpose1d_split_floats.restype = i64
+    L.fv_pack_conv_transpose1d_split_f16.argtypes = [vp, vp, i, i, i, i, vp]
+    L.fv_conv_transpose1d_split_f16.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, f, vp]
+    L.fv_plan_add_conv_transpose1d_split_f16.argtypes = [vp, i, i, i, vp, vp, i, i, i, i, i, i, f, f]
     L.fv_pqmf_synthesis.argtypes = [vp, vp, vp, i, i, i, i, vp]
     L.fv_conv1d_2src_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, f, vp]
     L.fv_plan_add_conv1d_2src.argtypes = [vp, i, i, i, i, i, vp, vp, i, i, i, i, f]
@@ -257,6 +262,25 @@ def pack_conv_transpose1d(w, stride, pad):
     out = torch.empty(n, dtype=torch.float32, device=w.device)
     with _on(w) as stream:
         check(lib().fv_pack_conv_transpose1d_weight(_ptr(w, "w"), _ptr(out), cin, cout, k, stride, pad, stream))
+    return out
+
+
+def conv_transpose_split_supported(cin, cout, k, stride, pad, out_pad):
+    """Shapes of the split-f16 transposed conv (csrc/convh_launch.hip launch_convt)."""
+    return (cin in (128, 256, 512) and 2 <= stride <= 16 and k == 2 * stride and (cout * stride) % 64 == 0
+            and 0 <= pad <= stride and -stride <= out_pad < stride)
+
+
+def pack_conv_transpose1d_split(w, stride):
+    """ConvTranspose1d weight [Cin,Cout,2*stride] -> split-f16 stage image of convt_kernel (flat fp32-typed tensor)."""
+    w = w.detach().contiguous().float()
+    cin, cout, k = w.shape
+    n = lib().fv_packed_conv_transpose1d_split_floats(cin, cout, k, stride)
+    if n <= 0:
+        raise NativeError(f"pack_conv_transpose1d_split: Cin={cin} Cout={cout} k={k} stride={stride} is not built")
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    with _on(w) as stream:
+        check(lib().fv_pack_conv_transpose1d_split_f16(_ptr(w, "w"), _ptr(out), cin, cout, k, stride, stream))
     return out
 
 
@@ -430,6 +454,20 @@ def conv_transpose1d_fused(x, packed, bias, cout, k, stride, pad, out_pad, pre_s
     return out
 
 
+def conv_transpose1d_split_f16(x, packed, bias, cout, k, stride, pad, out_pad, pre_slope=1.0, out=None, out_act=None,
+                               act_slope=1.0):
+    """ConvTranspose1d (kernel = 2 stride) with split-f16 operands (fv_conv_transpose1d_split_f16)."""
+    B, cin, T = x.shape
+    tout = (T - 1) * stride - 2 * pad + k + out_pad
+    if out is None:
+        out = torch.empty((B, cout, tout), dtype=torch.float32, device=x.device)
+    with _on(x, packed, bias, out, out_act) as stream:
+        check(lib().fv_conv_transpose1d_split_f16(_ptr(x, "x"), _ptr(packed, "packed"), _ptr(bias, "bias", True),
+                                                  _ptr(out, "out"), _ptr(out_act, "out_act", True), B, cin, cout, T, k,
+                                                  stride, pad, out_pad, float(pre_slope), float(act_slope), stream))
+    return out
+
+
 def upsample_conv1d_fused(x, packed, bias, cout, k, rate, pad, pre_slope=1.0, post=POST_NONE,
                           out=None, out_act=None, act_slope=1.0):
     B, cin, T = x.shape
@@ -529,6 +567,15 @@ class Plan:
                                                  _ptr(bias, "bias", True), cin, cout, k, stride,
                                                  pad, out_pad, float(pre_slope), post,
                                                  float(act_slope)))
+
+    def add_conv_transpose1d_split_f16(self, x, y, packed, bias, cin, cout, k, stride, pad, out_pad, pre_slope=1.0,
+                                       y_act=SLOT_NONE, act_slope=1.0):
+        self.keep(packed)
+        if bias is not None:
+            self.keep(bias)
+        check(lib().fv_plan_add_conv_transpose1d_split_f16(self._h, x, y, y_act, _ptr(packed, "packed"),
+                                                           _ptr(bias, "bias", True), cin, cout, k, stride, pad, out_pad,
+                                                           float(pre_slope), float(act_slope)))
 
     def add_conv1d_2src(self, x, x2, y, packed, bias, cin1, cin2, cout, res=SLOT_NONE, post=POST_NONE,
                         y_act=SLOT_NONE, act_slope=1.0):
@@ -667,7 +714,7 @@ def profile_enable(on):
 
 
 KERNEL_CONV_MFMA32, KERNEL_CONV_MFMA16, KERNEL_CONV_NARROW, KERNEL_PAIR16, KERNEL_PAIR32 = 0, 1, 2, 3, 4
-KERNEL_PAIRH16, KERNEL_PAIRH32, KERNEL_CONVH64, KERNEL_CONVH128 = 5, 6, 7, 8
+KERNEL_PAIRH16, KERNEL_PAIRH32, KERNEL_CONVH64, KERNEL_CONVH128, KERNEL_CONVT = 5, 6, 7, 8, 9
 
 
 def profile_bracket_cost(n=200):

@@ -241,6 +241,24 @@ __global__ void pack_convh_kernel(const float* __restrict__ w, _Float16* __restr
     }
 }
 
+// ConvTranspose1d weights w[Cin][Cout][2 s] for convt_kernel (convh_kernels.hpp): the same stage layout, rows
+// m = co * s + phase, K = (tap, ci): tap 0 multiplies x[u - 1] (kernel index s + phase), tap 1 x[u] (kernel index phase)
+__global__ void pack_convth_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int Cin, int Cout, int s_) {
+    const int NCH = Cin / 128, CG = 4, NSTEP = 2 * CG, k = 2 * s_;
+    const int64_t total = (int64_t)(Cout * s_ / 64) * NCH * NSTEP * 4 * 2 * 64 * 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63), half = (int)((i >> 9) & 1), mh = (int)((i >> 10) & 3);
+        const int ms = (int)(i >> 12), st = ms % NSTEP, mc = ms / NSTEP, chunk = mc % NCH, mt = mc / NCH;
+        const int tap = st / CG, cg = st % CG;
+        const int m = 64 * mt + 16 * mh + (lane & 15), co = m / s_, ph = m - co * s_;
+        const int ci = 128 * chunk + 32 * cg + 8 * (lane >> 4) + j;
+        const float v = w[((size_t)ci * Cout + co) * k + (tap == 0 ? s_ + ph : ph)];
+        const _Float16 h1 = (_Float16)v;
+        wp[i] = half == 0 ? h1 : (_Float16)((v - (float)h1) * 2048.f);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------
@@ -467,6 +485,20 @@ static int run_op(const Op& o, const float* x, float* y, float* y2, const float*
                   const float* acc2, int B, int64_t Tin, hipStream_t s, const float* x2 = nullptr,
                   const float* sub = nullptr, int sub_batched = 0) {
     if (o.type == OP_PQMF) return launch_pqmf(x, o.wp, y, y2, sub, sub_batched, B, o.Cin, o.k, (int)Tin, s);
+    if (o.type == OP_CONVT && o.prec == FV_PAIR_SPLIT_F16) {
+        PairParams pp = {};
+        pp.B = B;
+        pp.T = (int)Tin;
+        pp.slope = o.pre_slope;
+        pp.act_slope = o.act_slope;
+        pp.prec = FV_PAIR_SPLIT_F16;
+        pp.m[0].x = x;
+        pp.m[0].w1 = o.wp;
+        pp.m[0].b1 = o.bias;
+        pp.m[0].y = y;
+        pp.m[0].y_act = y2;
+        return launch_convt(pp, o.Cin, o.Cout, o.stride, o.pad, (int)conv_out_len(o, Tin), s);
+    }
     return launch_conv(make_params(o, x, y, y2, res, acc, acc2, B, Tin, x2, sub, sub_batched), s);
 }
 
@@ -785,6 +817,63 @@ int fv_conv_transpose1d_fused(const float* x, const float* packed, const float* 
     return run_op(o, x, y, y_act, nullptr, nullptr, nullptr, B, Tin, (hipStream_t)stream);
 }
 
+// ---- ConvTranspose1d with split-f16 operands (convt_kernel) ----
+static int check_convt_split_args(int Cin, int Cout, int k, int stride, int pad, int out_pad) {
+    if (Cin != 128 && Cin != 256 && Cin != 512)
+        return fail(FV_ERR_UNSUPPORTED, "conv_transpose1d_split_f16: Cin = %d (128, 256 or 512)", Cin);
+    if (stride < 2 || stride > 16 || k != 2 * stride)
+        return fail(FV_ERR_UNSUPPORTED, "conv_transpose1d_split_f16: kernel %d, stride %d (kernel = 2 x stride, stride 2..16)", k, stride);
+    if (Cout <= 0 || (Cout * stride) % 64 != 0)
+        return fail(FV_ERR_UNSUPPORTED, "conv_transpose1d_split_f16: Cout * stride = %d (a multiple of 64)", Cout * stride);
+    if (pad < 0 || pad > stride || out_pad < -stride || out_pad >= stride)
+        return fail(FV_ERR_INVALID_ARG, "conv_transpose1d_split_f16: pad=%d (0..stride) out_pad=%d", pad, out_pad);
+    return 0;
+}
+
+int64_t fv_packed_conv_transpose1d_split_floats(int Cin, int Cout, int k, int stride) {
+    if ((Cin != 128 && Cin != 256 && Cin != 512) || stride < 2 || stride > 16 || k != 2 * stride || Cout <= 0 ||
+        (Cout * stride) % 64 != 0)
+        return 0;
+    return (int64_t)(Cout * stride / 64) * (Cin / 128) * 8 * 2048;          // row tiles x chunks x 8 K steps x 8 KB
+}
+
+int fv_pack_conv_transpose1d_split_f16(const float* w, float* packed, int Cin, int Cout, int k, int stride, void* stream) {
+    if (!w || !packed) return fail(FV_ERR_INVALID_ARG, "pack_conv_transpose1d_split_f16: null tensor");
+    if (int rc = check_convt_split_args(Cin, Cout, k, stride, 0, 0)) return rc;
+    const int64_t total = fv_packed_conv_transpose1d_split_floats(Cin, Cout, k, stride) * 2;
+    hipLaunchKernelGGL(pack_convth_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       reinterpret_cast<_Float16*>(packed), Cin, Cout, stride);
+    FV_HIP(hipGetLastError());
+    return 0;
+}
+
+int fv_conv_transpose1d_split_f16(const float* x, const float* packed, const float* bias, float* y, float* y_act, int B,
+                                  int Cin, int Cout, int Tin, int k, int stride, int pad, int out_pad, float pre_slope,
+                                  float act_slope, void* stream) {
+    if (!x || !packed || !y) return fail(FV_ERR_INVALID_ARG, "conv_transpose1d_split_f16: null tensor");
+    if (int rc = check_convt_split_args(Cin, Cout, k, stride, pad, out_pad)) return rc;
+    if (x == y || x == y_act || (y_act && y_act == y))
+        return fail(FV_ERR_INVALID_ARG, "conv_transpose1d_split_f16: y / y_act must not alias x or each other");
+    Op o = {};
+    o.type = OP_CONVT;
+    o.prec = FV_PAIR_SPLIT_F16;
+    o.wp = packed;
+    o.bias = bias;
+    o.Cin = Cin;
+    o.Cout = Cout;
+    o.k = k;
+    o.stride = stride;
+    o.pad = pad;
+    o.out_pad = out_pad;
+    o.pre_slope = pre_slope;
+    o.out_div = 1.f;
+    o.act_slope = act_slope;
+    if (B < 0 || Tin < 0) return fail(FV_ERR_INVALID_ARG, "conv_transpose1d_split_f16: B=%d Tin=%d", B, Tin);
+    if (B == 0 || Tin == 0) return 0;
+    if (conv_out_len(o, Tin) <= 0) return fail(FV_ERR_INVALID_ARG, "conv_transpose1d_split_f16: empty output");
+    return run_op(o, x, y, y_act, nullptr, nullptr, nullptr, B, Tin, (hipStream_t)stream);
+}
+
 int fv_pqmf_synthesis(const float* x, const float* h, float* y, int B, int S, int ntaps, int Tsub,
                       void* stream) {
     if (!x || !h || !y || B < 0 || S <= 0 || ntaps <= 0 || ntaps % 2 == 0 || Tsub < 0)
@@ -974,6 +1063,17 @@ int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot, int y_
     o.lane = plan->cur_lane;
     plan->compiled = false;
     plan->ops.push_back(o);
+    return 0;
+}
+
+int fv_plan_add_conv_transpose1d_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed,
+                                           const float* bias, int Cin, int Cout, int k, int stride, int pad,
+                                           int out_pad, float pre_slope, float act_slope) {
+    if (int rc = check_convt_split_args(Cin, Cout, k, stride, pad, out_pad)) return rc;
+    if (int rc = fv_plan_add_conv_transpose1d(plan, x_slot, y_slot, y_act_slot, packed, bias, Cin, Cout, k, stride, pad,
+                                              out_pad, pre_slope, FV_POST_NONE, act_slope))
+        return rc;
+    plan->ops.back().prec = FV_PAIR_SPLIT_F16;
     return 0;
 }
 
@@ -1346,7 +1446,8 @@ int fv_plan_set_output_offset(fv_plan_t* plan, int aux_slot, int y2_slot) {
         return fail(FV_ERR_INVALID_ARG, "plan_set_output_offset: slot %d is not an auxiliary input", aux_slot);
     if (int rc = check_slot(y2_slot, true)) return rc;
     Op& o = plan->ops.back();
-    if (o.type == OP_PAIR || o.type == OP_MRFSUM || o.type == OP_CONVH || o.sum3 || o.group != 0)
+    if (o.type == OP_PAIR || o.type == OP_MRFSUM || o.type == OP_CONVH || o.sum3 || o.group != 0 ||
+        (o.type == OP_CONVT && o.prec == FV_PAIR_SPLIT_F16))
         return fail(FV_ERR_UNSUPPORTED, "plan_set_output_offset: only plain conv / transposed conv / pqmf ops carry an offset");
     if (y2_slot != FV_SLOT_NONE) {
         if (o.y2 != FV_SLOT_NONE) return fail(FV_ERR_INVALID_ARG, "plan_set_output_offset: the op already has a second output");

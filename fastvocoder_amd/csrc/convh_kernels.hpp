@@ -50,9 +50,11 @@ __device__ __forceinline__ void wait_vm() {
     __builtin_amdgcn_s_waitcnt((n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14));
 }
 
-template <int CG_, int NFW_, int KT_, int DIL_>
+// TR: the transposed conv of convt_kernel below (KT = 2 taps x[u-1], x[u]; rows are (output channel, phase))
+template <int CG_, int NFW_, int KT_, int DIL_, bool TR_ = false>
 struct ConvHGeom {
     static constexpr int CG = CG_, NFW = NFW_, KT = KT_, DIL = DIL_;
+    static constexpr bool TR = TR_;
     static constexpr int C = 32 * CG;
     static constexpr int WM = 2, WN = 4, NW = 8, NT = 512;
     static constexpr int NTC = 16 * NFW * WN;            // output columns per tile
@@ -60,7 +62,7 @@ struct ConvHGeom {
     static constexpr int NST = NSTEP / 2;                // stages of two steps
     static constexpr int NP = NFW / 2;                   // MFMA groups (two fragments) per step
     static constexpr int NUNIT = NSTEP * NP;
-    static constexpr int P = (KT - 1) * DIL / 2;
+    static constexpr int P = TR ? 1 : (KT - 1) * DIL / 2;
     static constexpr int XROWS = (NTC + (KT - 1) * DIL + 3) / 4 * 4;
     static constexpr int CB = C / 8;
     static constexpr int XRP = (XROWS + 15) / 16 * 16;   // image: [split half][8-channel block][XRP rows][8 halves]
@@ -72,7 +74,7 @@ struct ConvHGeom {
     static constexpr int RAWST = NST >= 4 ? NST - 4 : 0; // stage at which the next tile's raw window is requested
     static constexpr int NRAW = XR * 8;
     static constexpr int RESST = NST - 2;                // ... this tile's bias and residual
-    static constexpr int NRES = 8 + 8 * NFW;
+    static constexpr int NRES = TR ? 8 : 8 + 8 * NFW;
     static_assert(NSTEP % 2 == 0 && NST >= 3 && NFW % 2 == 0, "stages of two steps, at least three");
     static_assert(((CG - 1) * 4 * XRP + (KT - 1) * DIL + 16 * (NFW - 1)) * 16 + 16 < 65536, "ds_read immediate range");
 };
@@ -161,6 +163,12 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
     const unsigned ubytes = (unsigned)p.ctot * (unsigned)p.T * 4u;
     const unsigned t4 = (unsigned)p.T * 4u;
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(mb.w1, (unsigned)(nmt * nch * G::WTILE));
+    // transposed conv: rows are (output channel, phase): m = co * ups + phase; cout = nmt * 64 / ups channels
+    const int cout = G::TR ? nmt * 64 / p.ups : 0;
+    auto row_phase = [&](int m, int& co, int& ph) {
+        co = (int)((unsigned)m / (unsigned)p.ups);
+        ph = m - co * p.ups;
+    };
     int item = item0, chunk = 0;
     int g0 = 0;                                                             // stage counter of the run (ring slot = g & 3)
     auto decode = [&](int it, int& b, int& nt, int& mt) {
@@ -238,6 +246,19 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
             if constexpr (GS == G::RESST) {
                 // bias and residual of THIS tile: in flight during the last two stages
                 // (before the tile's last chunk the same loads are issued out of range: the wait counts stay static)
+                if constexpr (G::TR) {
+                    const __amdgpu_buffer_rsrc_t rb = make_rsrc(mb.b1 ? mb.b1 : mb.w1, mb.b1 && last ? (unsigned)cout * 4u : 0u);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        int co, ph;
+                        row_phase(64 * mtile + row0 + 16 * h, co, ph);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            bv[h][i] = buffer_load1(rb, (unsigned)co * 4u);
+                            if (++ph == p.ups) { ph = 0; ++co; }
+                        }
+                    }
+                } else {
                 const __amdgpu_buffer_rsrc_t rb = make_rsrc(mb.b1 ? mb.b1 : mb.w1, mb.b1 && last ? (unsigned)p.ctot * 4u : 0u);
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
@@ -252,6 +273,7 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
                     for (int h = 0; h < 2; ++h)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) res[h][f][i] = buffer_load1s(rr, voff[f], (unsigned)(16 * h + i) * t4);
+                }
                 }
             }
         };
@@ -325,6 +347,52 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
         pair_stamp(p, 8, wave, lane, it, 3);
         wait_vm<2>();                                    // raw window, residual: everything but the DMA of the last entry
         pair_stamp(p, 8, wave, lane, it, 4);
+        if constexpr (G::TR) {
+            if (last) {
+                // y[co][ups u + phase - pad]: a lane's four rows are four consecutive phases -- inside one output channel
+                // four consecutive samples, one 16-byte store (8-phase upsamplers: always)
+                const size_t yoff = (size_t)b * (size_t)cout * (size_t)p.Tout;
+                const unsigned ybytes = (unsigned)cout * (unsigned)p.Tout * 4u;
+                const __amdgpu_buffer_rsrc_t ry = make_rsrc(mb.y + yoff, ybytes);
+                const __amdgpu_buffer_rsrc_t ra = make_rsrc(mb.y_act ? mb.y_act + yoff : mb.y, mb.y_act ? ybytes : 0u);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    int co0, ph0;
+                    row_phase(64 * mtile + row0 + 16 * h, co0, ph0);
+                    const bool one_row = ph0 + 3 < p.ups;
+#pragma unroll
+                    for (int f = 0; f < G::NFW; ++f) {
+                        const int n0 = (t0 + col0 + f * 16) * p.ups - p.pad_t;
+                        float v[4], a[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            v[i] = fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[h][i];
+                            a[i] = act(v[i], p.act_slope);
+                            if (!mb.y_act) v[i] = a[i];              // no twin: y itself is stored activated
+                        }
+                        if (one_row && n0 + ph0 >= 0 && n0 + ph0 + 3 < p.Tout && !(p.dbg & 8)) {
+                            const unsigned off = (unsigned)(co0 * p.Tout + n0 + ph0) * 4u;
+                            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                                                                         __float_as_uint(v[3])}, ry, (int)off, 0, 0);
+                            if (mb.y_act)
+                                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(a[0]), __float_as_uint(a[1]),
+                                                                             __float_as_uint(a[2]), __float_as_uint(a[3])}, ra, (int)off, 0, 0);
+                        } else {
+                            int co = co0, ph = ph0;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int n = n0 + ph;
+                                const unsigned off = n >= 0 && n < p.Tout && !(p.dbg & 8) ? (unsigned)(co * p.Tout + n) * 4u : kOutOfRange;
+                                buffer_store1(ry, off, v[i]);
+                                if (mb.y_act) buffer_store1(ra, off, a[i]);
+                                if (++ph == p.ups) { ph = 0; ++co; }
+                            }
+                        }
+                    }
+                }
+            }
+        } else
         if (last) {
             const bool fin = mb.add1 != nullptr;
 #pragma unroll
@@ -427,6 +495,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         first = false;
     }
     pair_stamp(q, 8, wave, lane, 7, 14);
+}
+
+// ConvTranspose1d, kernel = 2 x stride (every shipped upsampler: hifigan.py:45-46, melgan.py:37-39), as the same
+// streamed-weight GEMM: with n' = n + pad = ups u + phase every output sample has exactly the two taps x[u] (kernel index
+// phase) and x[u - 1] (kernel index ups + phase), so all phases share ONE window and the rows of the GEMM are
+// (output channel, phase) -- M = Cout ups rows, K = 2 taps x Cin (chunks of 128 channels), N = Tin + 1 columns u.
+// Rows are channel-major (m = co ups + phase): the four rows a lane holds are consecutive output samples.
+template <int CG>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void convt_kernel(PairParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    PairParams q;
+    q.n_members = 1; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = 1.f;
+    q.act_slope = p.act_slope; q.post = 0; q.x_off = p.x_off; q.img_off = p.img_off; q.dbg = p.dbg; q.trace = p.trace;
+    q.ctot = p.ctot; q.nch = p.nch; q.nmt = p.nmt; q.reflect = 0; q.ups = p.ups; q.pad_t = p.pad_t; q.Tout = p.Tout;
+    PairMember mb;
+    mb.x = p.m[0].x; mb.w1 = p.m[0].w1; mb.b1 = p.m[0].b1; mb.res = nullptr; mb.add1 = nullptr; mb.add2 = nullptr;
+    mb.y = p.m[0].y; mb.y_act = p.m[0].y_act; mb.k = 2; mb.n_tiles = p.m[0].n_tiles;
+    const int n_items = p.m[0].n_items;
+    asm volatile("" ::"s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.act_slope), "s"(q.x_off), "s"(q.img_off), "s"(q.dbg),
+                 "s"(q.trace), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.ups), "s"(q.pad_t), "s"(q.Tout), "s"(mb.x), "s"(mb.w1),
+                 "s"(mb.b1), "s"(mb.y), "s"(mb.y_act), "s"(mb.n_tiles), "s"(n_items));
+    // equal items: block b takes [b n / nblk, (b + 1) n / nblk)
+    const int lo = (int)((long long)blockIdx.x * n_items / q.nblk), hi = (int)((long long)(blockIdx.x + 1) * n_items / q.nblk);
+    if (lo < hi) convh_run_member<ConvHGeom<CG, 2, 2, 1, true>>(q, mb, lo, hi, smem, wave, lane, true);
 }
 
 }  // namespace fv

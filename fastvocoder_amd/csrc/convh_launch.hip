@@ -86,6 +86,57 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     return rc;
 }
 
+// ---- ConvTranspose1d, kernel = 2 x stride (convt_kernel) -----------------------------------------------------------
+int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout, hipStream_t s) {
+    if (p.B <= 0 || p.T <= 0 || Tout <= 0) return 0;
+    if (Cin != 128 && Cin != 256 && Cin != 512)
+        return fail(FV_ERR_UNSUPPORTED, "split-f16 transposed conv: Cin = %d (128, 256 or 512)", Cin);
+    if (stride < 2 || stride > 16 || Cout <= 0 || (Cout * stride) % 64 != 0)
+        return fail(FV_ERR_UNSUPPORTED, "split-f16 transposed conv: stride %d (2..16), Cout * stride = %d (a multiple of 64)",
+                    stride, Cout * stride);
+    if (pad < 0 || pad > stride) return fail(FV_ERR_UNSUPPORTED, "split-f16 transposed conv: padding %d (0..stride)", pad);
+    if ((double)Cin * p.T * 4.0 >= 1073741824.0 || (double)Cout * Tout * 4.0 >= 1073741824.0)
+        return fail(FV_ERR_UNSUPPORTED, "split-f16 transposed conv: one utterance's tensor exceeds the 1 GiB "
+                    "buffer-descriptor range; split the utterance");
+    if (p.slope < 0.f || p.slope > 1.f || p.act_slope < 0.f || p.act_slope > 1.f)
+        return fail(FV_ERR_INVALID_ARG, "split-f16 transposed conv: activation slope outside [0, 1]");
+    PairMember& mb = p.m[0];
+    if (!mb.x || !mb.w1 || !mb.y) return fail(FV_ERR_INVALID_ARG, "split-f16 transposed conv: null tensor");
+    if (reinterpret_cast<uintptr_t>(mb.w1) & 15)
+        return fail(FV_ERR_UNSUPPORTED, "split-f16 transposed conv: packed weights must be 16-byte aligned");
+    p.n_members = 1;
+    p.ctot = Cin;
+    p.nch = Cin / 128;
+    p.nmt = Cout * stride / 64;
+    p.ups = stride;
+    p.pad_t = pad;
+    p.Tout = Tout;
+    p.reflect = 0;
+    const int NTC = 128;
+    const int ncols = (Tout + pad + stride - 1) / stride;          // u = (n + pad) / stride of the last sample, + 1
+    mb.k = 2;
+    mb.n_tiles = (ncols + NTC - 1) / NTC;
+    mb.n_items = mb.n_tiles * p.B * p.nmt;
+    mb.cost = 1;
+    const int xrows = (NTC + 1 + 3) / 4 * 4;
+    const int img_bytes = 4 * 128 * ((xrows + 15) / 16 * 16);
+    p.x_off = 0;                       // ring of 4 weight stages
+    p.img_off = 4 * 16384 / 4;
+    const size_t lds = 4 * 16384 + (size_t)img_bytes;
+    const char* force = getenv("FV_CONVH_BLOCKS");
+    long long nblk = force && atoi(force) > 0 ? atoi(force) : device_cu_count();
+    if (nblk > mb.n_items) nblk = mb.n_items;
+    p.nblk = (int)nblk;
+    p.dbg = tuning_dbg_flags();
+    p.trace = nullptr;
+    profile_begin(s);
+    const int rc = launch_convt_geom(p, lds, s);
+    // MACs of a ConvTranspose1d = Tin * Cin * Cout * k
+    profile_end(s, FV_KERNEL_CONVT, 2.0 * p.B * (double)p.T * Cin * Cout * 2 * stride,
+                4.0 * ((double)Cin * Cout * 2 * stride + (double)p.B * ((double)Cin * p.T + (double)Cout * Tout * (mb.y_act ? 2 : 1))));
+    return rc;
+}
+
 // ---- fused pair at C = 64 (convp_kernels.hpp) --------------------------------------------------------------------
 extern template int launch_convp_dil<1>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convp_dil<3>(const PairParams&, size_t, hipStream_t);

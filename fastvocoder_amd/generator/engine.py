@@ -35,6 +35,9 @@ def effective_weight(conv):
     return conv.weight.detach().contiguous().float()
 
 
+_SPLIT_CONVT = os.environ.get("FV_SPLIT_CONVT", "1") != "0"   # upsamplers with 128+ input channels on convt_kernel
+
+
 class PlanBuilder:
     """Accumulates ops, runs the activation-hoisting pass, then emits a native
     plan.  Slots are small integers naming tensors (SLOT_IN / SLOT_OUT /
@@ -232,10 +235,21 @@ class PlanBuilder:
             raise _native.NativeError("only dense, undilated ConvTranspose1d layers exist on this path")
         k, s = convt.kernel_size[0], convt.stride[0]
         p, op = convt.padding[0], convt.output_padding[0]
+        cin, cout = convt.in_channels, convt.out_channels
+        if (_SPLIT_CONVT and post == POST_NONE and self.pair_precision(cin) == _native.PAIR_SPLIT_F16
+                and _native.conv_transpose_split_supported(cin, cout, k, s, p, op - int(trim))):
+            # kernel = 2 strides, 128+ input channels: split-f16 operands (csrc/convh_kernels.hpp convt_kernel)
+            # (src is read raw, the activation is applied on chip: nothing is hoisted into its producer)
+            self.ops.append(dict(kind="convT", split=True, lane=self.lane, x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE,
+                                 pre_slope=1.0, slope=float(pre_slope),
+                                 packed=_native.pack_conv_transpose1d_split(effective_weight(convt), s),
+                                 bias=self._bias(convt), cin=cin, cout=cout, k=k, stride=s, pad=p,
+                                 out_pad=op - int(trim), post=post))
+            return
         self.ops.append(dict(kind="convT", lane=self.lane, x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE,
                              pre_slope=float(pre_slope),
                              packed=_native.pack_conv_transpose1d(effective_weight(convt), s, p),
-                             bias=self._bias(convt), cin=convt.in_channels, cout=convt.out_channels,
+                             bias=self._bias(convt), cin=cin, cout=cout,
                              k=k, stride=s, pad=p, out_pad=op - int(trim), post=post))
 
     def upsample_conv(self, layer, src, dst, pre_slope=1.0, post=POST_NONE):
@@ -266,7 +280,7 @@ class PlanBuilder:
         Bias removal without a separate elementwise pass (reference bin/synthesize.py:74-80,
         basis_melgan.py:147-159, bin/test.py:82-91)."""
         op = self.ops[-1]
-        if op["kind"] not in ("conv", "conv2", "convT", "upconv", "pqmf") or op.get("group", 0):
+        if op["kind"] not in ("conv", "conv2", "convT", "upconv", "pqmf") or op.get("group", 0) or op.get("split"):
             raise _native.NativeError("subtract_output: the last op must be a plain conv / transposed conv / pqmf")
         op["sub"] = SLOT_AUX_IN0 + int(aux)
         op["sub_y2"] = SLOT_OUT2 if second else SLOT_NONE
@@ -407,6 +421,11 @@ class PlanBuilder:
                 self.plan.add_conv1d_2src(op["x"], op["x2"], op["y"], op["packed"], op["bias"], op["cin1"],
                                           op["cin2"], op["cout"], res=op["res"], post=op["post"],
                                           y_act=op["y_act"], act_slope=op["act_slope"])
+            elif op["kind"] == "convT" and op.get("split"):
+                self.plan.add_conv_transpose1d_split_f16(op["x"], op["y"], op["packed"], op["bias"], op["cin"],
+                                                         op["cout"], op["k"], op["stride"], op["pad"], op["out_pad"],
+                                                         pre_slope=op["slope"], y_act=op["y_act"],
+                                                         act_slope=op["act_slope"])
             elif op["kind"] == "convT":
                 self.plan.add_conv_transpose1d(op["x"], op["y"], op["packed"], op["bias"], op["cin"],
                                                op["cout"], op["k"], op["stride"], op["pad"],

@@ -200,6 +200,26 @@ int fv_conv1d_split_f16(int n, const float* const* x, const float* const* packed
                         float out_div, int post, float act_slope, void* stream);
 
 /*
+ * ConvTranspose1d with split-f16 operands (arithmetic: FV_PAIR_SPLIT_F16 above) for the upsamplers whose kernel is two
+ * strides long -- every one the reference builds (hifigan.py:45-46, melgan.py:37-39: kernel 2 s, padding s/2 + s%2,
+ * output_padding s%2):
+ *
+ *     y = conv_transpose1d( lrelu(x, pre_slope); w [Cin, Cout, k], stride, pad, out_pad ) + bias,  y_act = lrelu(y, act_slope)
+ *
+ * (without y_act and act_slope != 1, y itself is stored activated).  Cin = 128, 256 or 512; k = 2 stride, stride 2..16;
+ * Cout * stride a multiple of 64; 0 <= pad <= stride; out_pad in [-stride, stride) (negative: CausalConvTranspose1d's
+ * trim, modules.py:297-317).  Tout = (Tin-1)*stride - 2*pad + k + out_pad.  With n + pad = stride u + phase every
+ * output sample has the two taps x[u], x[u-1]: one GEMM with rows (output channel, phase), weights streamed as in
+ * fv_conv1d_split_f16 (csrc/convh_kernels.hpp, convt_kernel).  packed: fv_pack_conv_transpose1d_split_f16
+ * (fv_packed_conv_transpose1d_split_floats floats; 0 = shape not supported).
+ */
+int64_t fv_packed_conv_transpose1d_split_floats(int Cin, int Cout, int k, int stride);
+int fv_pack_conv_transpose1d_split_f16(const float* w, float* packed, int Cin, int Cout, int k, int stride, void* stream);
+int fv_conv_transpose1d_split_f16(const float* x, const float* packed, const float* bias, float* y, float* y_act, int B,
+                                  int Cin, int Cout, int Tin, int k, int stride, int pad, int out_pad, float pre_slope,
+                                  float act_slope, void* stream);
+
+/*
  * End of an MRF stage (hifigan.py:97-103): the LAST pairs of the three ResBlocks and the mean, one launch:
  *
  *     y = post( ( sum_{j<3} pair_j(x_j) ) / out_div ),   y_act = lrelu(y, act_slope)   (as fv_conv1d_fused)
@@ -355,6 +375,10 @@ int fv_plan_add_resblock_pair_ex(fv_plan_t* plan, int x_slot, int y_slot, int y_
 int fv_plan_add_conv1d_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, int res_slot, int add1_slot,
                                  int add2_slot, const float* packed, const float* bias, int C, int k, int dil,
                                  int pad_mode, float pre_slope, float out_div, int post, float act_slope);
+/* fv_conv_transpose1d_split_f16 as a plan op */
+int fv_plan_add_conv_transpose1d_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed,
+                                           const float* bias, int Cin, int Cout, int k, int stride, int pad,
+                                           int out_pad, float pre_slope, float act_slope);
 int fv_plan_add_mrf_sum(fv_plan_t* plan, const int* x_slots, int y_slot, int y_act_slot,
                         const float* const* packed1, const float* const* packed2, const float* const* bias1,
                         const float* const* bias2, int C, const int* k, int dil, float slope, float out_div,
@@ -434,6 +458,7 @@ int fv_plan_num_ops(fv_plan_t* plan);
 #define FV_KERNEL_PAIRH32 6     /* ... C = 32 */
 #define FV_KERNEL_CONVH64 7     /* conv1d with split-f16 operands, C = 64 (ResBlock pairs of the wide stages) */
 #define FV_KERNEL_CONVH128 8    /* ... C = 128 */
+#define FV_KERNEL_CONVT 9       /* transposed conv (kernel = 2 strides) with split-f16 operands (convt_kernel) */
 int fv_profile_enable(int on);
 /* what the event bracket itself adds to a measured launch: the average elapsed time between the two events
  * of n EMPTY brackets recorded back to back on `stream` (subtract it per launch) */

@@ -317,6 +317,58 @@ def test_conv1d_split_f16_reflection_rejects():
         _native.conv1d_split_f16(x, w, [None], [3], 1, pad_mode=_native.PAD_CAUSAL)
 
 
+CONVT_CASES = [  # B, Cin, Cout, Tin, stride, pad, out_pad
+    (1, 256, 128, 300, 8, 4, 0), (2, 128, 64, 257, 5, 3, 1), (1, 128, 32, 129, 2, 1, 0), (1, 512, 256, 40, 8, 4, 0),
+    (3, 128, 64, 1, 10, 5, 0), (2, 256, 64, 127, 6, 3, 0), (1, 128, 64, 128, 3, 2, 1), (1, 256, 256, 200, 4, 2, 0),
+    (2, 128, 16, 50, 4, 0, 0), (1, 128, 64, 33, 8, 8, -8), (1, 128, 64, 260, 16, 8, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_transpose1d_split_f16_vs_oracle(case, monkeypatch):
+    """fv_conv_transpose1d_split_f16 (kernel = 2 strides; reference hifigan.py:45-46, melgan.py:37-39) against the
+    oracle's transposed conv: every stride the shipped configs use, ragged ends, trimmed tail, activated twin."""
+    B, cin, cout, T, s, pad, op = case
+    k = 2 * s
+    rng = np.random.RandomState(cin + 7 * T + s)
+    x = rng.randn(B, cin, T).astype(np.float32)
+    w = (rng.randn(cin, cout, k) / np.sqrt(cin * 2)).astype(np.float32)
+    b = rng.randn(cout).astype(np.float32)
+    ref = oo.conv_transpose1d(x, w, b, s, pad, max(op, 0), pre_slope=0.1)
+    if op < 0:
+        ref = ref[:, :, :ref.shape[2] + op]
+    X, Bi = _t(x), _t(b)
+    P = _native.pack_conv_transpose1d_split(_t(w), s)
+    y = _native.conv_transpose1d_split_f16(X, P, Bi, cout, k, s, pad, op, pre_slope=0.1)
+    assert tuple(y.shape) == ref.shape and _rel(y, ref) <= 4e-6
+    twin = torch.empty_like(y)
+    y2 = _native.conv_transpose1d_split_f16(X, P, None, cout, k, s, pad, op, pre_slope=0.1, out_act=twin, act_slope=0.2)
+    assert _rel(y2, ref - b[None, :, None]) <= 4e-6 and _rel(twin, oo.lrelu(ref - b[None, :, None], 0.2)) <= 4e-6
+    y3 = _native.conv_transpose1d_split_f16(X, P, Bi, cout, k, s, pad, op, pre_slope=0.1, act_slope=0.2)
+    assert _rel(y3, oo.lrelu(ref, 0.2)) <= 4e-6
+    # a few persistent blocks walking many tiles (and row tiles of one column tile): same bits
+    monkeypatch.setenv("FV_CONVH_BLOCKS", "3")
+    few = _native.conv_transpose1d_split_f16(X, P, Bi, cout, k, s, pad, op, pre_slope=0.1)
+    monkeypatch.delenv("FV_CONVH_BLOCKS")
+    assert torch.equal(few, y)
+    if B > 1:                                      # an utterance alone and inside the batch: same bits
+        one = _native.conv_transpose1d_split_f16(X[1:2].contiguous(), P, Bi, cout, k, s, pad, op, pre_slope=0.1)
+        assert torch.equal(one, y[1:2])
+
+
+def test_conv_transpose1d_split_f16_rejects():
+    with pytest.raises(_native.NativeError, match="not built"):
+        _native.pack_conv_transpose1d_split(torch.zeros((64, 32, 16), device=_dev()), 8)       # Cin = 64
+    with pytest.raises(_native.NativeError, match="not built"):
+        _native.pack_conv_transpose1d_split(torch.zeros((128, 32, 17), device=_dev()), 8)      # k != 2 s
+    P = _native.pack_conv_transpose1d_split(torch.zeros((128, 32, 16), device=_dev()), 8)
+    x = torch.zeros((1, 128, 10), device=_dev())
+    with pytest.raises(_native.NativeError, match="pad="):
+        _native.conv_transpose1d_split_f16(x, P, None, 32, 16, 8, 9, 0)
+    with pytest.raises(_native.NativeError, match="alias"):
+        _native.conv_transpose1d_split_f16(x, P, None, 32, 16, 8, 4, 0, out=x)
+
+
 @pytest.mark.parametrize("blocks", [1, 3, 7])
 def test_persistent_blocks_walk_many_tiles_and_cross_members(monkeypatch, blocks):
     """With few persistent blocks every block walks several tiles and crosses from one member to the next (the small
