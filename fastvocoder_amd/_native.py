@@ -52,15 +52,18 @@ def source_hash():
 
 
 def built_id():
-    """Build id of the .so on disk, or None when it is missing / predates build ids."""
+    """Build id of the .so on disk, or None when it is missing / predates build ids.  Read from the file's bytes
+    (the "fv-build-id:" tag in front of the string fv_build_id() returns), not through dlopen: a library this
+    process has already loaded would answer for the OLD image after a rebuild."""
     if not os.path.exists(LIB_PATH):
         return None
-    try:
-        L = ctypes.CDLL(LIB_PATH)
-        L.fv_build_id.restype = ctypes.c_char_p
-        return L.fv_build_id().decode()
-    except (OSError, AttributeError):
+    with open(LIB_PATH, "rb") as f:
+        data = f.read()
+    at = data.find(b"fv-build-id:")
+    if at < 0:
         return None
+    end = data.find(b"\0", at)
+    return data[at + 12:end].decode(errors="replace") if 0 < end - at - 12 <= 64 else None
 
 
 def build(force=False, verbose=False):
@@ -267,7 +270,7 @@ def pack_conv_transpose1d(w, stride, pad):
 
 def conv_transpose_split_supported(cin, cout, k, stride, pad, out_pad):
     """Shapes of the split-f16 transposed conv (csrc/convh_launch.hip launch_convt)."""
-    return (cin in (128, 256, 512) and 2 <= stride <= 16 and k == 2 * stride and (cout * stride) % 64 == 0
+    return (cin in (64, 128, 256, 512) and 2 <= stride <= 16 and k == 2 * stride and cout * stride >= 64
             and 0 <= pad <= stride and -stride <= out_pad < stride)
 
 

@@ -244,8 +244,8 @@ __global__ void pack_convh_kernel(const float* __restrict__ w, _Float16* __restr
 // ConvTranspose1d weights w[Cin][Cout][2 s] for convt_kernel (convh_kernels.hpp): the same stage layout, rows
 // m = co * s + phase, K = (tap, ci): tap 0 multiplies x[u - 1] (kernel index s + phase), tap 1 x[u] (kernel index phase)
 __global__ void pack_convth_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int Cin, int Cout, int s_) {
-    const int NCH = Cin / 128, CG = 4, NSTEP = 2 * CG, k = 2 * s_;
-    const int64_t total = (int64_t)(Cout * s_ / 64) * NCH * NSTEP * 4 * 2 * 64 * 8;
+    const int NCH = (Cin + 127) / 128, CG = 4, NSTEP = 2 * CG, k = 2 * s_;
+    const int64_t total = (int64_t)((Cout * s_ + 63) / 64) * NCH * NSTEP * 4 * 2 * 64 * 8;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)(i & 7), lane = (int)((i >> 3) & 63), half = (int)((i >> 9) & 1), mh = (int)((i >> 10) & 3);
@@ -253,7 +253,7 @@ __global__ void pack_convth_kernel(const float* __restrict__ w, _Float16* __rest
         const int tap = st / CG, cg = st % CG;
         const int m = 64 * mt + 16 * mh + (lane & 15), co = m / s_, ph = m - co * s_;
         const int ci = 128 * chunk + 32 * cg + 8 * (lane >> 4) + j;
-        const float v = w[((size_t)ci * Cout + co) * k + (tap == 0 ? s_ + ph : ph)];
+        const float v = ci < Cin && co < Cout ? w[((size_t)ci * Cout + co) * k + (tap == 0 ? s_ + ph : ph)] : 0.f;
         const _Float16 h1 = (_Float16)v;
         wp[i] = half == 0 ? h1 : (_Float16)((v - (float)h1) * 2048.f);
     }
@@ -639,7 +639,8 @@ int fv_version(void) { return FV_ABI_VERSION; }
 #ifndef FV_BUILD_ID
 #define FV_BUILD_ID "unknown"
 #endif
-const char* fv_build_id(void) { return FV_BUILD_ID; }
+// (the "fv-build-id:" tag lets the id be read from the file without loading it: _native.built_id)
+const char* fv_build_id(void) { return "fv-build-id:" FV_BUILD_ID + 12; }
 
 const char* fv_last_error(void) { return g_err.c_str(); }
 
@@ -819,22 +820,22 @@ int fv_conv_transpose1d_fused(const float* x, const float* packed, const float* 
 
 // ---- ConvTranspose1d with split-f16 operands (convt_kernel) ----
 static int check_convt_split_args(int Cin, int Cout, int k, int stride, int pad, int out_pad) {
-    if (Cin != 128 && Cin != 256 && Cin != 512)
-        return fail(FV_ERR_UNSUPPORTED, "conv_transpose1d_split_f16: Cin = %d (128, 256 or 512)", Cin);
+    if (Cin != 64 && Cin != 128 && Cin != 256 && Cin != 512)
+        return fail(FV_ERR_UNSUPPORTED, "conv_transpose1d_split_f16: Cin = %d (64, 128, 256 or 512)", Cin);
     if (stride < 2 || stride > 16 || k != 2 * stride)
         return fail(FV_ERR_UNSUPPORTED, "conv_transpose1d_split_f16: kernel %d, stride %d (kernel = 2 x stride, stride 2..16)", k, stride);
-    if (Cout <= 0 || (Cout * stride) % 64 != 0)
-        return fail(FV_ERR_UNSUPPORTED, "conv_transpose1d_split_f16: Cout * stride = %d (a multiple of 64)", Cout * stride);
+    if (Cout <= 0 || Cout * stride < 64)
+        return fail(FV_ERR_UNSUPPORTED, "conv_transpose1d_split_f16: Cout * stride = %d (64 or more)", Cout * stride);
     if (pad < 0 || pad > stride || out_pad < -stride || out_pad >= stride)
         return fail(FV_ERR_INVALID_ARG, "conv_transpose1d_split_f16: pad=%d (0..stride) out_pad=%d", pad, out_pad);
     return 0;
 }
 
 int64_t fv_packed_conv_transpose1d_split_floats(int Cin, int Cout, int k, int stride) {
-    if ((Cin != 128 && Cin != 256 && Cin != 512) || stride < 2 || stride > 16 || k != 2 * stride || Cout <= 0 ||
-        (Cout * stride) % 64 != 0)
+    if ((Cin != 64 && Cin != 128 && Cin != 256 && Cin != 512) || stride < 2 || stride > 16 || k != 2 * stride ||
+        Cout <= 0 || Cout * stride < 64)
         return 0;
-    return (int64_t)(Cout * stride / 64) * (Cin / 128) * 8 * 2048;          // row tiles x chunks x 8 K steps x 8 KB
+    return (int64_t)((Cout * stride + 63) / 64) * ((Cin + 127) / 128) * 8 * 2048;   // row tiles x chunks x 8 K steps x 8 KB
 }
 
 int fv_pack_conv_transpose1d_split_f16(const float* w, float* packed, int Cin, int Cout, int k, int stride, void* stream) {

@@ -88,8 +88,9 @@ struct ConvHRaw {
 // or (reflect: MelGAN's ReflectionPad1d, pad < T) as the row mirrored at the first / last sample
 template <class G>
 __device__ __forceinline__ void convh_load_raw(ConvHRaw<G>& r, const float* xb, int T, int tA, int tid, bool live,
-                                               bool reflect = false) {
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)G::C * (unsigned)T * 4u);
+                                               bool reflect = false, int cvalid = G::C) {
+    // (cvalid < G::C: the transposed conv of a 64-channel input -- the missing channels read as zero)
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)cvalid * (unsigned)T * 4u);
     const unsigned t4 = (unsigned)T * 4u;
 #pragma unroll
     for (int q = 0; q < G::XR; ++q) {
@@ -163,8 +164,9 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
     const unsigned ubytes = (unsigned)p.ctot * (unsigned)p.T * 4u;
     const unsigned t4 = (unsigned)p.T * 4u;
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(mb.w1, (unsigned)(nmt * nch * G::WTILE));
-    // transposed conv: rows are (output channel, phase): m = co * ups + phase; cout = nmt * 64 / ups channels
-    const int cout = G::TR ? nmt * 64 / p.ups : 0;
+    // transposed conv: rows are (output channel, phase): m = co * ups + phase, p.cout channels (rows beyond them, in
+    // the last row tile, fall outside the output's buffer descriptor: their stores are dropped)
+    const int cout = G::TR ? p.cout : 0;
     auto row_phase = [&](int m, int& co, int& ph) {
         co = (int)((unsigned)m / (unsigned)p.ups);
         ph = m - co * p.ups;
@@ -182,7 +184,8 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
     if (!first) pair_barrier();                         // everybody is done with the previous member's LDS
     pair_stamp(p, 8, wave, lane, 7, 12);
     ConvHRaw<G> raw;
-    convh_load_raw<G>(raw, mb.x + b * ustride, p.T, ntile * G::NTC - G::P, tid, true, p.reflect != 0);
+    auto chunk_channels = [&](int c) { return G::TR ? min(G::C, p.ctot - c * G::C) : G::C; };
+    convh_load_raw<G>(raw, mb.x + b * ustride, p.T, ntile * G::NTC - G::P, tid, true, p.reflect != 0, chunk_channels(0));
 #pragma unroll
     for (int st = 0; st < 3; ++st)
         convh_dma_stage<G>(rw, ring, st, (unsigned)(mtile * nch * G::WTILE + st * G::STAGE_BYTES), wave, lane);
@@ -227,8 +230,10 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
                 // outstanding as were issued AFTER it: the DMAs of the two entries in between (4), plus the raw
                 // window / the residual if they were requested at one of the three entries in between.  (Stores in
                 // flight only make the count larger: conservative.)
-                constexpr bool raw_between = GS >= 3 && G::RAWST >= GS - 3 && G::RAWST <= GS - 1;
-                constexpr bool res_between = GS >= 3 && G::RESST >= GS - 3 && G::RESST <= GS - 1;
+                // (for GS < 3 the DMA was issued in the previous tile, whose raw / residual requests were waited
+                // for in its epilogue: only this tile's entries 0 .. GS - 1 count)
+                constexpr bool raw_between = G::RAWST >= GS - 3 && G::RAWST <= GS - 1;
+                constexpr bool res_between = G::RESST >= GS - 3 && G::RESST <= GS - 1;
                 wait_vm<4 + (raw_between ? G::NRAW : 0) + (res_between ? G::NRES : 0)>();
             }
 #ifdef FV_CONVH_EXP
@@ -242,7 +247,7 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
             convh_dma_stage<G>(rw, ring, (g0 + NS) & 3, off, wave, lane);
             if constexpr (GS == G::RAWST)
                 convh_load_raw<G>(raw, mb.x + nb * ustride + nchunk * cstride, p.T, nnt * G::NTC - G::P, tid,
-                                  new_win && !(p.dbg & 1), p.reflect != 0);
+                                  new_win && !(p.dbg & 1), p.reflect != 0, chunk_channels(nchunk));
             if constexpr (GS == G::RESST) {
                 // bias and residual of THIS tile: in flight during the last two stages
                 // (before the tile's last chunk the same loads are issued out of range: the wait counts stay static)
@@ -510,13 +515,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     PairParams q;
     q.n_members = 1; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = 1.f;
     q.act_slope = p.act_slope; q.post = 0; q.x_off = p.x_off; q.img_off = p.img_off; q.dbg = p.dbg; q.trace = p.trace;
-    q.ctot = p.ctot; q.nch = p.nch; q.nmt = p.nmt; q.reflect = 0; q.ups = p.ups; q.pad_t = p.pad_t; q.Tout = p.Tout;
+    q.ctot = p.ctot; q.nch = p.nch; q.nmt = p.nmt; q.reflect = 0; q.ups = p.ups; q.pad_t = p.pad_t; q.Tout = p.Tout; q.cout = p.cout;
     PairMember mb;
     mb.x = p.m[0].x; mb.w1 = p.m[0].w1; mb.b1 = p.m[0].b1; mb.res = nullptr; mb.add1 = nullptr; mb.add2 = nullptr;
     mb.y = p.m[0].y; mb.y_act = p.m[0].y_act; mb.k = 2; mb.n_tiles = p.m[0].n_tiles;
     const int n_items = p.m[0].n_items;
     asm volatile("" ::"s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.act_slope), "s"(q.x_off), "s"(q.img_off), "s"(q.dbg),
-                 "s"(q.trace), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.ups), "s"(q.pad_t), "s"(q.Tout), "s"(mb.x), "s"(mb.w1),
+                 "s"(q.trace), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.ups), "s"(q.pad_t), "s"(q.Tout), "s"(q.cout), "s"(mb.x), "s"(mb.w1),
                  "s"(mb.b1), "s"(mb.y), "s"(mb.y_act), "s"(mb.n_tiles), "s"(n_items));
     // equal items: block b takes [b n / nblk, (b + 1) n / nblk)
     const int lo = (int)((long long)blockIdx.x * n_items / q.nblk), hi = (int)((long long)(blockIdx.x + 1) * n_items / q.nblk);

@@ -89,10 +89,10 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
 // ---- ConvTranspose1d, kernel = 2 x stride (convt_kernel) -----------------------------------------------------------
 int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout, hipStream_t s) {
     if (p.B <= 0 || p.T <= 0 || Tout <= 0) return 0;
-    if (Cin != 128 && Cin != 256 && Cin != 512)
-        return fail(FV_ERR_UNSUPPORTED, "split-f16 transposed conv: Cin = %d (128, 256 or 512)", Cin);
-    if (stride < 2 || stride > 16 || Cout <= 0 || (Cout * stride) % 64 != 0)
-        return fail(FV_ERR_UNSUPPORTED, "split-f16 transposed conv: stride %d (2..16), Cout * stride = %d (a multiple of 64)",
+    if (Cin != 64 && Cin != 128 && Cin != 256 && Cin != 512)
+        return fail(FV_ERR_UNSUPPORTED, "split-f16 transposed conv: Cin = %d (64, 128, 256 or 512)", Cin);
+    if (stride < 2 || stride > 16 || Cout <= 0 || Cout * stride < 64)
+        return fail(FV_ERR_UNSUPPORTED, "split-f16 transposed conv: stride %d (2..16), Cout * stride = %d (64 or more)",
                     stride, Cout * stride);
     if (pad < 0 || pad > stride) return fail(FV_ERR_UNSUPPORTED, "split-f16 transposed conv: padding %d (0..stride)", pad);
     if ((double)Cin * p.T * 4.0 >= 1073741824.0 || (double)Cout * Tout * 4.0 >= 1073741824.0)
@@ -106,8 +106,9 @@ int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout,
         return fail(FV_ERR_UNSUPPORTED, "split-f16 transposed conv: packed weights must be 16-byte aligned");
     p.n_members = 1;
     p.ctot = Cin;
-    p.nch = Cin / 128;
-    p.nmt = Cout * stride / 64;
+    p.nch = (Cin + 127) / 128;                // 64 input channels: half a chunk, the other half multiplies zeros
+    p.nmt = (Cout * stride + 63) / 64;        // rows beyond Cout * stride: zero weights, stores dropped
+    p.cout = Cout;
     p.ups = stride;
     p.pad_t = pad;
     p.Tout = Tout;

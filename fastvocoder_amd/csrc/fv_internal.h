@@ -167,8 +167,9 @@ struct PairParams {
     int nblk;            // persistent blocks in the grid
     int ctot, nch, nmt;  // convh: channels in and out, chunks of <= 128 input channels, row tiles of 64
     int reflect;         // convh: rows outside [0, T) are the mirrored samples (ReflectionPad1d) instead of zeros
-    int ups, pad_t, Tout;   // transposed conv (convt_kernel): stride, padding, output samples; T = input samples,
-                            // ctot = input channels, rows m = co * ups + phase (nmt * 64 of them)
+    int ups, pad_t, Tout, cout;   // transposed conv (convt_kernel): stride, padding, output samples, output channels;
+                                  // T = input samples, ctot = input channels (64: half a chunk), rows m = co * ups +
+                                  // phase in nmt tiles of 64
     int prec;            // FV_PAIR_F32: fp32 MFMA (pair_kernels.hpp); FV_PAIR_SPLIT_F16: pairh_kernels.hpp
     int x_off, mid_off;  // float offsets of the x image / intermediate in dynamic LDS
     int img_off;         // split-f16 kernels: float offset of the x image (x_off: the member's packed weights)
@@ -215,7 +216,7 @@ template <int DIL>
 int launch_convp_dil(const PairParams& p, size_t lds, hipStream_t s);
 template <int CG, int NFW>
 int launch_convh_geom(const PairParams& p, int dil, size_t lds, hipStream_t s);
-// ConvTranspose1d with split-f16 operands, k = 2 stride, Cin a multiple of 128, Cout * stride of 64 (convt_kernel in
+// ConvTranspose1d with split-f16 operands, k = 2 stride, Cin = 64 or a multiple of 128 (convt_kernel in
 // convh_kernels.hpp): member 0 uses x, w1 (fv_pack_conv_transpose1d_split_f16 image), b1, y, y_act
 int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout, hipStream_t stream);
 int launch_convt_geom(const PairParams& p, size_t lds, hipStream_t s);

@@ -206,8 +206,8 @@ int fv_conv1d_split_f16(int n, const float* const* x, const float* const* packed
  *
  *     y = conv_transpose1d( lrelu(x, pre_slope); w [Cin, Cout, k], stride, pad, out_pad ) + bias,  y_act = lrelu(y, act_slope)
  *
- * (without y_act and act_slope != 1, y itself is stored activated).  Cin = 128, 256 or 512; k = 2 stride, stride 2..16;
- * Cout * stride a multiple of 64; 0 <= pad <= stride; out_pad in [-stride, stride) (negative: CausalConvTranspose1d's
+ * (without y_act and act_slope != 1, y itself is stored activated).  Cin = 64, 128, 256 or 512; k = 2 stride, stride 2..16;
+ * Cout * stride >= 64 (rows are padded to a multiple of 64, 64 input channels to 128); 0 <= pad <= stride; out_pad in [-stride, stride) (negative: CausalConvTranspose1d's
  * trim, modules.py:297-317).  Tout = (Tin-1)*stride - 2*pad + k + out_pad.  With n + pad = stride u + phase every
  * output sample has the two taps x[u], x[u-1]: one GEMM with rows (output channel, phase), weights streamed as in
  * fv_conv1d_split_f16 (csrc/convh_kernels.hpp, convt_kernel).  packed: fv_pack_conv_transpose1d_split_f16

@@ -321,6 +321,8 @@ CONVT_CASES = [  # B, Cin, Cout, Tin, stride, pad, out_pad
     (1, 256, 128, 300, 8, 4, 0), (2, 128, 64, 257, 5, 3, 1), (1, 128, 32, 129, 2, 1, 0), (1, 512, 256, 40, 8, 4, 0),
     (3, 128, 64, 1, 10, 5, 0), (2, 256, 64, 127, 6, 3, 0), (1, 128, 64, 128, 3, 2, 1), (1, 256, 256, 200, 4, 2, 0),
     (2, 128, 16, 50, 4, 0, 0), (1, 128, 64, 33, 8, 8, -8), (1, 128, 64, 260, 16, 8, 0),
+    # 64 input channels (half a chunk) and row counts that are not a multiple of the 64-row tile
+    (1, 64, 32, 300, 3, 2, 1), (2, 64, 32, 129, 2, 1, 0), (1, 64, 40, 100, 5, 3, 1), (1, 128, 20, 64, 4, 2, 0),
 ]
 
 
@@ -358,7 +360,7 @@ def test_conv_transpose1d_split_f16_vs_oracle(case, monkeypatch):
 
 def test_conv_transpose1d_split_f16_rejects():
     with pytest.raises(_native.NativeError, match="not built"):
-        _native.pack_conv_transpose1d_split(torch.zeros((64, 32, 16), device=_dev()), 8)       # Cin = 64
+        _native.pack_conv_transpose1d_split(torch.zeros((32, 32, 16), device=_dev()), 8)       # Cin = 32
     with pytest.raises(_native.NativeError, match="not built"):
         _native.pack_conv_transpose1d_split(torch.zeros((128, 32, 17), device=_dev()), 8)      # k != 2 s
     P = _native.pack_conv_transpose1d_split(torch.zeros((128, 32, 16), device=_dev()), 8)
