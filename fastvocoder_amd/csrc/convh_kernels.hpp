@@ -474,6 +474,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("" ::"s"(q.n_members), "s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.out_div), "s"(q.act_slope),
                  "s"(q.post), "s"(q.x_off), "s"(q.img_off), "s"(q.dbg), "s"(q.trace), "s"(n_items[0]), "s"(n_items[1]),
                  "s"(n_items[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.reflect));
+    // this block's items of each member: from the host's schedule (pair_schedule: few, unequal items per block), or its
+    // contiguous share of the cost-weighted item sequence
+    const int* const sched = p.sched;
+    int slo[3] = {0, 0, 0}, shi[3] = {0, 0, 0};
+    if (sched) {
+        const int* e = sched + blockIdx.x * 6;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { slo[m] = e[2 * m]; shi[m] = e[2 * m + 1]; }
+        asm volatile("" ::"s"(slo[0]), "s"(shi[0]), "s"(slo[1]), "s"(shi[1]), "s"(slo[2]), "s"(shi[2]));
+    }
     long long total = 0;
 #pragma unroll
     for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_items[m] * cost[m] : 0;
@@ -482,8 +492,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int m = 0; m < q.n_members; ++m) {
         const int n = m == 0 ? n_items[0] : m == 1 ? n_items[1] : n_items[2];
         const int cm = m == 0 ? cost[0] : m == 1 ? cost[1] : cost[2];
-        const int lo = pair_share(blockIdx.x, total, base, cm, n, q.nblk);
-        const int hi = pair_share(blockIdx.x + 1, total, base, cm, n, q.nblk);
+        int lo, hi;
+        if (sched) {
+            lo = m == 0 ? slo[0] : m == 1 ? slo[1] : slo[2];
+            hi = m == 0 ? shi[0] : m == 1 ? shi[1] : shi[2];
+        } else {
+            lo = pair_share(blockIdx.x, total, base, cm, n, q.nblk);
+            hi = pair_share(blockIdx.x + 1, total, base, cm, n, q.nblk);
+        }
         base += (long long)n * cm;
         if (lo >= hi) continue;
         // ... and this member's pointers and sizes in one more

@@ -2,6 +2,11 @@
 // persistent grid, launch.  Device code: convh_inst_c64.hip / convh_inst_c128.hip.
 #include <stdlib.h>
 
+#include <array>
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "fv_internal.h"
 
 namespace fv {
@@ -9,6 +14,79 @@ namespace fv {
 extern template int launch_convh_geom<4, 2>(const PairParams&, int, size_t, hipStream_t);
 extern template int launch_convh_geom<2, 2>(const PairParams&, int, size_t, hipStream_t);
 
+
+// ---- block schedule for launches with few items per block ----------------------------------------------------
+// The kernels' own partition cuts the cost-weighted item sequence into nblk contiguous shares: with 1-3 items per
+// block and items of three different costs, a share ends up anywhere between one cheap item and two expensive ones
+// (HiFi-GAN light at batch 1, 128 channels: 126 items each of cost 24 / 16 / 8 on 256 blocks -- makespan 32 against a
+// mean of 23.6).  Items of one member are interchangeable, so a greedy longest-processing-time-first assignment
+// (most expensive member first, every item to the block that finishes it earliest; taking up a second member costs
+// a pipeline refill) is computed once per shape on the host and handed to the kernel as per-block item ranges.
+// [measured, MI355X, B = 1] the two-member launches at the end of a stage (11 + 7 taps: every block ends up with ONE
+// member) 56.7 -> 47.7 us at 128 channels, 49.7 -> 47.0 at 64; three-member launches gain nothing (128 channels:
+// a 7-tap + 3-tap block pays a member switch, a pipeline drain and refill, for what it saves) or lose (64 channels,
+// 58 vs 55 us: more switches than the contiguous cut has), so they keep the contiguous cut (FV_SCHED=2: all).
+const int* pair_schedule(const PairParams& p, int nblk) {
+    static std::mutex mu;
+    static std::map<std::array<int, 10>, const int*> cache;
+    const char* off = getenv("FV_SCHED");
+    if (off && atoi(off) == 0) return nullptr;
+    long long items = 0;
+    for (int m = 0; m < p.n_members; ++m) items += p.m[m].n_items;
+    if (p.n_members < 2 || nblk < 2 || items > 6LL * nblk) return nullptr;
+    if (p.n_members != 2 && !(off && atoi(off) == 2)) return nullptr;
+    const int sw = getenv("FV_SCHED_SWITCH") ? atoi(getenv("FV_SCHED_SWITCH")) : 4;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::array<int, 10> key = {dev, nblk, p.n_members, sw, 0, 0, 0, 0, 0, 0};
+    for (int m = 0; m < p.n_members; ++m) {
+        key[4 + 2 * m] = p.m[m].n_items;
+        key[5 + 2 * m] = p.m[m].cost;
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    if (cache.size() >= 256) return nullptr;                     // (a process sees a handful of shapes)
+    int order[3] = {0, 1, 2};
+    for (int i = 0; i < p.n_members; ++i)
+        for (int j = i + 1; j < p.n_members; ++j)
+            if (p.m[order[j]].cost > p.m[order[i]].cost) std::swap(order[i], order[j]);
+    std::vector<long long> load(nblk, 0);
+    std::vector<int> cnt((size_t)nblk * 3, 0);
+    for (int oi = 0; oi < p.n_members; ++oi) {
+        const int m = order[oi], c = p.m[m].cost;
+        for (int i = 0; i < p.m[m].n_items; ++i) {
+            int best = 0;
+            long long best_end = -1;
+            for (int b = 0; b < nblk; ++b) {
+                const long long end = load[b] + c + (cnt[(size_t)b * 3 + m] == 0 && load[b] > 0 ? sw : 0);
+                if (best_end < 0 || end < best_end) {
+                    best_end = end;
+                    best = b;
+                }
+            }
+            load[best] = best_end;
+            ++cnt[(size_t)best * 3 + m];
+        }
+    }
+    std::vector<int> table((size_t)nblk * 6, 0);
+    for (int m = 0; m < p.n_members; ++m) {
+        int at = 0;
+        for (int b = 0; b < nblk; ++b) {
+            table[(size_t)b * 6 + 2 * m] = at;
+            at += cnt[(size_t)b * 3 + m];
+            table[(size_t)b * 6 + 2 * m + 1] = at;
+        }
+    }
+    int* dptr = nullptr;
+    if (hipMalloc(&dptr, table.size() * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemcpy(dptr, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(dptr);
+        return nullptr;
+    }
+    cache[key] = dptr;
+    return dptr;
+}
 
 // run-time mirror of ConvHGeom<>
 ConvHShape convh_shape(int C, int k, int dil) {
@@ -78,6 +156,7 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     long long nblk = force && atoi(force) > 0 ? atoi(force) : cus;     // one 8-wave block per CU
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
+    p.sched = pair_schedule(p, p.nblk);
     p.dbg = tuning_dbg_flags();
     p.trace = getenv("FV_PAIR_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("FV_PAIR_TRACE_PTR"), nullptr, 0)) : nullptr;
     profile_begin(s);
@@ -191,6 +270,7 @@ int launch_convp(PairParams p, int dil, hipStream_t s) {
     long long nblk = force && atoi(force) > 0 ? atoi(force) : device_cu_count();
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
+    p.sched = pair_schedule(p, p.nblk);
     p.dbg = tuning_dbg_flags();
     p.trace = nullptr;
     profile_begin(s);

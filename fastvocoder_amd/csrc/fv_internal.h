@@ -166,6 +166,8 @@ struct PairParams {
     int post;            // FV_POST_* applied to y (sum mode / single)
     int nblk;            // persistent blocks in the grid
     int ctot, nch, nmt;  // convh: channels in and out, chunks of <= 128 input channels, row tiles of 64
+    const int* sched;    // convh / convp: per block [member][lo, hi) item ranges (pair_schedule), or null: the kernel
+                         // cuts the cost-weighted item sequence into nblk contiguous shares itself (pair_share)
     int reflect;         // convh: rows outside [0, T) are the mirrored samples (ReflectionPad1d) instead of zeros
     int ups, pad_t, Tout, cout;   // transposed conv (convt_kernel): stride, padding, output samples, output channels;
                                   // T = input samples, ctot = input channels (64: half a chunk), rows m = co * ups +
@@ -209,6 +211,10 @@ struct ConvHShape {
 };
 ConvHShape convh_shape(int C, int k, int dil);
 int launch_convh(PairParams p, int C, int dil, hipStream_t stream);
+// Few, unequal items per block (batch 1: 378 items of three costs on 256 blocks): a longest-processing-time-first
+// assignment instead of the contiguous cut -- device table [nblk][3][2] (cached per shape), or null when every block
+// has many items anyway
+const int* pair_schedule(const PairParams& p, int nblk);
 // fused ResBlock pair at C = 64 with split-f16 operands and streamed weights (convp_kernels.hpp): members use x, w1, w2
 // (fv_pack_pair_weight_ex images), b1, b2, add1 / add2, y, y_act, k
 int launch_convp(PairParams p, int dil, hipStream_t stream);

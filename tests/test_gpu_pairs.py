@@ -317,6 +317,31 @@ def test_conv1d_split_f16_reflection_rejects():
         _native.conv1d_split_f16(x, w, [None], [3], 1, pad_mode=_native.PAD_CAUSAL)
 
 
+def test_block_schedule_gives_the_same_bits(monkeypatch):
+    """Few, unequal items per block (batch 1): the host's longest-processing-time-first block schedule
+    (csrc/convh_launch.hip pair_schedule) against the kernels' own contiguous partition (FV_SCHED=0) -- every item is
+    computed exactly once either way, so the results are bit-identical; also with a switch cost that makes blocks
+    take up two and three members."""
+    rng = np.random.RandomState(78)
+    monkeypatch.setenv("FV_SCHED", "2")            # (by default only two-member launches are scheduled)
+    for C, T, dil, ks in ((128, 8000, 3, (11, 7, 3)), (64, 9000, 5, (11, 7, 3)), (256, 700, 1, (7, 11, 3)), (128, 5000, 5, (11, 7))):
+        ms = [_member(rng, 1, C, T, k, True) for k in ks]
+        xs = [_t(m[0]) for m in ms]
+        h1, h2 = [_native.pack_pair(_t(m[1]), SPLIT) for m in ms], [_native.pack_pair(_t(m[3]), SPLIT) for m in ms]
+        b1s, b2s = [_t(m[2]) for m in ms], [_t(m[4]) for m in ms]
+        sched = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, prec=SPLIT)
+        monkeypatch.setenv("FV_SCHED_SWITCH", "0")
+        sched0 = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, prec=SPLIT)
+        monkeypatch.delenv("FV_SCHED_SWITCH")
+        monkeypatch.setenv("FV_SCHED", "0")
+        plain = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, prec=SPLIT)
+        monkeypatch.setenv("FV_SCHED", "2")
+        for a, b, c in zip(sched, sched0, plain):
+            assert torch.equal(a, c) and torch.equal(b, c)
+        ref = _pair_ref(*ms[0], dil, 0.1)
+        assert _rel(sched[0], ref) <= 4e-6
+
+
 CONVT_CASES = [  # B, Cin, Cout, Tin, stride, pad, out_pad
     (1, 256, 128, 300, 8, 4, 0), (2, 128, 64, 257, 5, 3, 1), (1, 128, 32, 129, 2, 1, 0), (1, 512, 256, 40, 8, 4, 0),
     (3, 128, 64, 1, 10, 5, 0), (2, 256, 64, 127, 6, 3, 0), (1, 128, 64, 128, 3, 2, 1), (1, 256, 256, 200, 4, 2, 0),
