@@ -1,6 +1,7 @@
 // What does a kernel boundary cost against a device-wide barrier inside one persistent kernel?
 //   hipcc --offload-arch=gfx950 -O3 tools/gridsync_probe.hip -o tools/gridsync_probe.bin && tools/gridsync_probe.bin
 // (a) N dependent launches of a 256-block x 512-thread kernel with 148 KB of dynamic LDS that touches a little memory;
+// (c) the same launches replayed from a hipGraph;
 // (b) ONE launch of the same grid doing the same work N times with a sense-free counter barrier + agent-scope fences
 //     (release: L2 write-back, acquire: L1 / L2 invalidate) between the rounds.
 #include <hip/hip_runtime.h>
@@ -61,6 +62,25 @@ int main() {
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
         printf("%d dependent launches: %.2f us each\n", rounds, ms * 1e3 / rounds);
+        // (c) the same N dependent launches captured once into a hipGraph and replayed
+        static hipGraphExec_t exec = nullptr;
+        static hipStream_t cs = nullptr;
+        if (!exec) {
+            hipStreamCreate(&cs);
+            hipGraph_t g;
+            hipStreamBeginCapture(cs, hipStreamCaptureModeGlobal);
+            for (int r = 0; r < rounds; ++r) hipLaunchKernelGGL(one_round, dim3(blocks), dim3(threads), lds, cs, buf, r, n);
+            hipStreamEndCapture(cs, &g);
+            hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+            hipGraphLaunch(exec, cs);
+            hipStreamSynchronize(cs);
+        }
+        hipEventRecord(e0, cs);
+        hipGraphLaunch(exec, cs);
+        hipEventRecord(e1, cs);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("%d dependent launches replayed from a hipGraph: %.2f us each\n", rounds, ms * 1e3 / rounds);
         hipMemset(ctr, 0, 4);
         hipEventRecord(e0);
         hipLaunchKernelGGL(persistent, dim3(blocks), dim3(threads), lds, 0, buf, rounds, n, ctr);
