@@ -270,7 +270,7 @@ def roofline_report(model, mel, ms_per_step, reps=5):
             "bound": "hbm / lds (DESIGN.md section 3.7)",
         },
         "split_f16_transposed_convs": {
-            "kernel": "fv::convt_kernel (the upsamplers with 128+ input channels: kernel = 2 strides as one GEMM with rows "
+            "kernel": "fv::convt_kernel (the upsamplers with 64+ input channels: kernel = 2 strides as one GEMM with rows "
                       "(output channel, phase), split-f16 operands, weights streamed; csrc/convh_kernels.hpp)",
             "ms_per_step": ups["ms"] / reps, "launches_per_step": ups["launches"] // reps,
             "fp32_equivalent_tflops": rate(ups),
