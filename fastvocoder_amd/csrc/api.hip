@@ -29,31 +29,64 @@ int fail(int code, const char* fmt, ...) {
 // ---------------------------------------------------------------------------
 // measurement hook
 // ---------------------------------------------------------------------------
+// A launch's duration is completion-to-completion on its stream: from the end of the launch before it (or, for the
+// first one, from an event recorded in front of it) to its own end -- its dispatch latency is part of it, as it is in
+// rocprofv3's dispatch durations, and the durations of a run add up to the run.  One event per launch.
 struct ProfRec {
-    hipEvent_t a, b;
+    hipEvent_t a, b;        // a: only where there is no previous launch to measure from
+    hipStream_t s;
+    double ms;              // < 0: not read back yet
     double flops, bytes;
     int kind;
 };
 static bool g_prof_on = false;
+static bool g_prof_need_start = true;
 static std::vector<ProfRec> g_prof;
 static hipEvent_t g_prof_start;
 
 void profile_begin(hipStream_t s) {
     if (!g_prof_on) return;
-    (void)hipEventCreate(&g_prof_start);
-    (void)hipEventRecord(g_prof_start, s);
+    g_prof_start = nullptr;
+    if (g_prof_need_start || g_prof.empty() || g_prof.back().s != s || !g_prof.back().b) {
+        (void)hipEventCreate(&g_prof_start);
+        (void)hipEventRecord(g_prof_start, s);
+        g_prof_need_start = false;
+    }
 }
 
 void profile_end(hipStream_t s, int kind, double flops, double bytes) {
     if (!g_prof_on) return;
     ProfRec r;
     r.a = g_prof_start;
+    g_prof_start = nullptr;
     (void)hipEventCreate(&r.b);
     (void)hipEventRecord(r.b, s);
+    r.s = s;
+    r.ms = -1.0;
     r.flops = flops;
     r.bytes = bytes;
     r.kind = kind;
     g_prof.push_back(r);
+}
+
+// read every pending record back (in order: a record without its own start event is measured from its predecessor's
+// end), then drop the events
+static int profile_resolve() {
+    for (size_t i = 0; i < g_prof.size(); ++i) {
+        ProfRec& r = g_prof[i];
+        if (r.ms >= 0) continue;
+        FV_HIP(hipEventSynchronize(r.b));
+        float e = 0.f;
+        FV_HIP(hipEventElapsedTime(&e, r.a ? r.a : g_prof[i - 1].b, r.b));
+        r.ms = e;
+    }
+    for (ProfRec& r : g_prof) {
+        if (r.a) (void)hipEventDestroy(r.a);
+        if (r.b) (void)hipEventDestroy(r.b);
+        r.a = r.b = nullptr;
+    }
+    g_prof_need_start = true;
+    return 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -1775,28 +1808,40 @@ int fv_plan_num_ops(fv_plan_t* plan) { return plan ? (int)plan->ops.size() : 0; 
 
 int fv_profile_enable(int on) {
     g_prof_on = on != 0;
+    g_prof_need_start = true;
     return 0;
 }
+
+// What the measurement adds to a launch: the end-of-launch event record is one more packet on the stream.  A chain
+// of n (null kernel, event record) pairs against a chain of n null kernels, per launch.
+__global__ void profile_null_kernel() {}
 
 int fv_profile_bracket_cost(void* stream, int n, double* ms_per_bracket) {
     if (n <= 0 || !ms_per_bracket) return fail(FV_ERR_INVALID_ARG, "profile_bracket_cost: n=%d", n);
     hipStream_t s = (hipStream_t)stream;
-    std::vector<hipEvent_t> ev(2 * (size_t)n);
+    std::vector<hipEvent_t> ev((size_t)n + 4);
     for (hipEvent_t& e : ev) FV_HIP(hipEventCreate(&e));
-    for (hipEvent_t& e : ev) FV_HIP(hipEventRecord(e, s));      // n empty (begin, end) pairs back to back
-    FV_HIP(hipEventSynchronize(ev.back()));
-    double tot = 0;
+    for (int i = 0; i < 8; ++i) hipLaunchKernelGGL(profile_null_kernel, dim3(1), dim3(64), 0, s);
+    FV_HIP(hipEventRecord(ev[n], s));
     for (int i = 0; i < n; ++i) {
-        float e = 0.f;
-        FV_HIP(hipEventElapsedTime(&e, ev[2 * i], ev[2 * i + 1]));
-        tot += e;
+        hipLaunchKernelGGL(profile_null_kernel, dim3(1), dim3(64), 0, s);
+        FV_HIP(hipEventRecord(ev[i], s));
     }
+    FV_HIP(hipEventRecord(ev[n + 1], s));
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(profile_null_kernel, dim3(1), dim3(64), 0, s);
+    FV_HIP(hipEventRecord(ev[n + 2], s));
+    FV_HIP(hipEventSynchronize(ev[n + 2]));
+    float with = 0.f, without = 0.f;
+    FV_HIP(hipEventElapsedTime(&with, ev[n], ev[n - 1]));
+    FV_HIP(hipEventElapsedTime(&without, ev[n + 1], ev[n + 2]));
     for (hipEvent_t& e : ev) (void)hipEventDestroy(e);
-    *ms_per_bracket = tot / n;
+    const double cost = ((double)with - (double)without) / n;
+    *ms_per_bracket = cost > 0 ? cost : 0;
     return 0;
 }
 
 int fv_profile_collect(int kind, int64_t* launches, double* ms, double* flops, double* bytes) {
+    if (int rc = profile_resolve()) return rc;
     double tms = 0, tf = 0, tb = 0;
     int64_t n = 0;
     std::vector<ProfRec> rest;
@@ -1805,15 +1850,10 @@ int fv_profile_collect(int kind, int64_t* launches, double* ms, double* flops, d
             rest.push_back(r);
             continue;
         }
-        FV_HIP(hipEventSynchronize(r.b));
-        float e = 0.f;
-        FV_HIP(hipEventElapsedTime(&e, r.a, r.b));
-        tms += e;
+        tms += r.ms;
         tf += r.flops;
         tb += r.bytes;
         ++n;
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
     }
     if (launches) *launches = n;
     if (ms) *ms = tms;

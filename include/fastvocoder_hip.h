@@ -445,10 +445,12 @@ int fv_plan_num_ops(fv_plan_t* plan);
  * measurement hook (bench.py): per-launch timing of the dominant kernel
  * with HIP events recorded on the caller's stream
  * ------------------------------------------------------------------ */
-/* When enabled, every conv kernel launch is bracketed by hipEvents on its
- * stream; fv_profile_collect() synchronises and returns the accumulated
- * (launches, milliseconds, algorithmic flops, algorithmic bytes) of one kernel
- * family and removes those records.  kind: FV_KERNEL_* or -1 for all. */
+/* When enabled, every conv kernel launch is followed by a hipEvent on its
+ * stream (and the first one preceded by one); a launch's time runs from the
+ * end of the launch before it to its own end.  fv_profile_collect()
+ * synchronises and returns the accumulated (launches, milliseconds,
+ * algorithmic flops, algorithmic bytes) of one kernel family and removes
+ * those records.  kind: FV_KERNEL_* or -1 for all. */
 #define FV_KERNEL_CONV_MFMA32 0 /* 32x32x2 fp32-MFMA implicit-GEMM conv (M > 16 rows) */
 #define FV_KERNEL_CONV_MFMA16 1 /* 16x16x4 fp32-MFMA implicit-GEMM conv (M <= 16 rows) */
 #define FV_KERNEL_CONV_NARROW 2 /* VALU conv for Cout <= 4 */
@@ -460,8 +462,10 @@ int fv_plan_num_ops(fv_plan_t* plan);
 #define FV_KERNEL_CONVH128 8    /* ... C = 128 */
 #define FV_KERNEL_CONVT 9       /* transposed conv (kernel = 2 strides) with split-f16 operands (convt_kernel) */
 int fv_profile_enable(int on);
-/* what the event bracket itself adds to a measured launch: the average elapsed time between the two events
- * of n EMPTY brackets recorded back to back on `stream` (subtract it per launch) */
+/* what the measurement adds to a launch (subtract it per launch): a launch's duration is measured completion to
+ * completion on its stream, from the end event of the launch before it to its own (its dispatch latency included, as
+ * in rocprofv3's dispatch durations); the end-event record is one more packet -- a chain of n (null kernel, event)
+ * pairs against a chain of n null kernels */
 int fv_profile_bracket_cost(void* stream, int n, double* ms_per_bracket);
 int fv_profile_collect(int kind, int64_t* launches, double* ms, double* flops, double* bytes);
 
