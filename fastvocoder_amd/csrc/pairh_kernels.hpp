@@ -395,9 +395,8 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
 }
 
 template <int MH, int NF, int NG, int DIL>
-__device__ __forceinline__ void pairh_run_any(const PairParams& p, int m, int item0, int hi, float* smem, int wave,
-                                              int lane, bool first) {
-    const PairMember& mb = p.m[m];
+__device__ __forceinline__ void pairh_run_any(const PairParams& p, const PairMember& mb, int item0, int hi, float* smem,
+                                              int wave, int lane, bool first) {
     if (mb.k == 11) pairh_run_member<PairHGeom<MH, NF, NG, 11, DIL>>(p, mb, item0, hi, smem, wave, lane, first);
     else if (mb.k == 7) pairh_run_member<PairHGeom<MH, NF, NG, 7, DIL>>(p, mb, item0, hi, smem, wave, lane, first);
     else pairh_run_member<PairHGeom<MH, NF, NG, 3, DIL>>(p, mb, item0, hi, smem, wave, lane, first);
@@ -409,17 +408,38 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the launch's scalars in one batch of kernarg loads (see convh_kernel: left to itself hipcc loads every field
+    // right before its first use, a chain of dependent s_load round trips between kernel entry and the first tile)
+    PairParams q;
+    q.n_members = p.n_members; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = p.out_div;
+    q.act_slope = p.act_slope; q.post = p.post; q.x_off = p.x_off; q.img_off = p.img_off; q.mid_off = p.mid_off;
+    q.bias_off = p.bias_off; q.dbg = p.dbg; q.trace = p.trace;
+    int n_tiles[3], cost[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { n_tiles[m] = p.m[m].n_tiles; cost[m] = p.m[m].cost; }
+    asm volatile("" ::"s"(q.n_members), "s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.out_div), "s"(q.act_slope),
+                 "s"(q.post), "s"(q.x_off), "s"(q.img_off), "s"(q.mid_off), "s"(q.bias_off), "s"(q.dbg), "s"(q.trace),
+                 "s"(n_tiles[0]), "s"(n_tiles[1]), "s"(n_tiles[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]));
     long long total = 0;
-    for (int m = 0; m < p.n_members; ++m) total += (long long)p.m[m].n_tiles * p.B * p.m[m].cost;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_tiles[m] * q.B * cost[m] : 0;
     long long base = 0;
     bool first = true;
-    for (int m = 0; m < p.n_members; ++m) {
-        const int n = p.m[m].n_tiles * p.B;
-        const int lo = pair_share(blockIdx.x, total, base, p.m[m].cost, n, p.nblk);
-        const int hi = pair_share(blockIdx.x + 1, total, base, p.m[m].cost, n, p.nblk);
-        base += (long long)n * p.m[m].cost;
+    for (int m = 0; m < q.n_members; ++m) {
+        const int nt = m == 0 ? n_tiles[0] : m == 1 ? n_tiles[1] : n_tiles[2];
+        const int cm = m == 0 ? cost[0] : m == 1 ? cost[1] : cost[2];
+        const int n = nt * q.B;
+        const int lo = pair_share(blockIdx.x, total, base, cm, n, q.nblk);
+        const int hi = pair_share(blockIdx.x + 1, total, base, cm, n, q.nblk);
+        base += (long long)n * cm;
         if (lo >= hi) continue;
-        pairh_run_any<MH, NF, NG, DIL>(p, m, lo, hi, smem, wave, lane, first);
+        // ... and this member's pointers and sizes in one more
+        PairMember mb;
+        mb.x = p.m[m].x; mb.w1 = p.m[m].w1; mb.w2 = p.m[m].w2; mb.b1 = p.m[m].b1; mb.b2 = p.m[m].b2; mb.add1 = p.m[m].add1;
+        mb.add2 = p.m[m].add2; mb.y = p.m[m].y; mb.y_act = p.m[m].y_act; mb.k = p.m[m].k; mb.n_tiles = nt;
+        asm volatile("" ::"s"(mb.x), "s"(mb.w1), "s"(mb.w2), "s"(mb.b1), "s"(mb.b2), "s"(mb.add1), "s"(mb.add2), "s"(mb.y),
+                     "s"(mb.y_act), "s"(mb.k));
+        pairh_run_any<MH, NF, NG, DIL>(q, mb, lo, hi, smem, wave, lane, first);
         first = false;
     }
 }
