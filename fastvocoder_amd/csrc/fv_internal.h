@@ -192,6 +192,18 @@ struct PairShape {
 };
 PairShape pair_shape(int C, int k, int dil);
 // ... of the split-f16 pair kernels, the run-time mirror of PairHGeom<> (pairh_kernels.hpp)
+// Block shapes of the split-f16 pair kernels (tools/pair_bench.py, HiFi-GAN light stage sizes, B = 1):
+// C = 32, one block per CU -- column groups (= waves): 8 (128-column tiles, 2 waves per SIMD) 59 us per three-member
+// launch, 12 (192 columns, 3 per SIMD) 53 us, 15 (240 columns, 4 per SIMD; 16 would need 162 KB of LDS) 49 us;
+// C = 16, two blocks per CU, 256-column tiles -- 4 waves x 4 fragments with the A operands in registers (2 waves per
+// SIMD), or 8 waves x 2 fragments with streamed A operands (116 VGPRs: 4 per SIMD)
+#ifndef FV_PAIRH32_NG
+#define FV_PAIRH32_NG 15
+#endif
+#ifndef FV_PAIRH16_NF
+#define FV_PAIRH16_NF 2
+#define FV_PAIRH16_NG 8
+#endif
 struct PairHShape {
     int MH, NF, NG, NM;
     int KS;              // K steps per conv (32 K values each)

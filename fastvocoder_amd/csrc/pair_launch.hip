@@ -9,8 +9,8 @@ namespace fv {
 
 extern template int launch_pair_geom<1, 2, 8>(const PairParams&, int, size_t, hipStream_t);
 extern template int launch_pair_geom<2, 1, 8>(const PairParams&, int, size_t, hipStream_t);
-extern template int launch_pairh_geom<1, 4, 4>(const PairParams&, int, size_t, hipStream_t);
-extern template int launch_pairh_geom<2, 1, 8>(const PairParams&, int, size_t, hipStream_t);
+extern template int launch_pairh_geom<1, FV_PAIRH16_NF, FV_PAIRH16_NG>(const PairParams&, int, size_t, hipStream_t);
+extern template int launch_pairh_geom<2, 1, FV_PAIRH32_NG>(const PairParams&, int, size_t, hipStream_t);
 
 namespace {
 
@@ -60,11 +60,12 @@ PairShape pair_shape(int C, int k, int dil) {
 // ---- split-f16 pairs (pairh_kernels.hpp): run-time mirror of PairHGeom<> ----------------------------------
 PairHShape pairh_shape(int C, int k, int dil) {
     PairHShape g = {};
-    // C = 16: 4 waves x four fragments (256-column tiles, two blocks per CU);
-    // C = 32: 8 waves x one fragment, both row halves in the wave (128-column tiles, one block per CU)
+    // C = 16: 8 waves x two fragments (256-column tiles, two blocks per CU: 4 waves per SIMD);
+    // C = 32: 15 waves x one fragment, both row halves in the wave (240-column tiles, one block per CU: the two
+    // 11-tap weight images are 88 KB; 16 waves would need 162 KB of LDS) -- fv_internal.h FV_PAIRH32_NG / FV_PAIRH16_*
     g.MH = C / 16;
-    g.NF = C == 16 ? 4 : 1;
-    g.NG = C == 16 ? 4 : 8;
+    g.NF = C == 16 ? FV_PAIRH16_NF : 1;
+    g.NG = C == 16 ? FV_PAIRH16_NG : FV_PAIRH32_NG;
     g.NM = 16 * g.NF * g.NG;
     const int tps = 32 / C;
     g.KS = (k + tps - 1) / tps;
@@ -97,8 +98,8 @@ static int launch_pairs_split(PairParams p, int C, int dil, hipStream_t s) {
         mb.n_tiles = (p.T + g.NOUT - 1) / g.NOUT;
         // a tile costs its K steps (two convs, LDS-bandwidth bound) plus a part that does not depend on the taps
         // (loads, convert pass, epilogues, stores, barriers): measured per member alone (tools/pair_bench.py)
-        // 0.8 us per step + 8 steps' worth at C = 16, 1.6 us per step + 4 steps' worth at C = 32
-        mb.cost = g.KS + (getenv("FV_PAIRH_SKEL") ? atoi(getenv("FV_PAIRH_SKEL")) : (C == 16 ? 8 : 4));
+        // 0.8 us per step + 8 steps' worth at C = 16, 1.6 us per step + 6 steps' worth at C = 32 (240-column tiles)
+        mb.cost = g.KS + (getenv("FV_PAIRH_SKEL") ? atoi(getenv("FV_PAIRH_SKEL")) : (C == 16 ? 8 : 6));
         mb.w_off = 0;
         if (2 * g.WB > w_bytes) w_bytes = 2 * g.WB;
         if (g.XIMG > img_bytes) img_bytes = g.XIMG;
@@ -119,14 +120,14 @@ static int launch_pairs_split(PairParams p, int C, int dil, hipStream_t s) {
     const size_t lds = floats * 4;
     if (lds > (C == 16 ? 80 : 160) * 1024) return fail(FV_ERR_UNSUPPORTED, "resblock pair, split-f16: %zu bytes of LDS", lds);
     const char* force = getenv("FV_PAIR_BLOCKS");
-    // 8 waves per CU (2 per SIMD): two 4-wave blocks at C = 16, one 8-wave block at C = 32
+    // 15-16 waves per CU (4 per SIMD): two 8-wave blocks at C = 16, one 15-wave block at C = 32
     long long nblk = force && atoi(force) > 0 ? atoi(force) : (C == 16 ? 2LL : 1LL) * num_cus();
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
     p.dbg = tuning_dbg_flags();
     p.trace = nullptr;
     profile_begin(s);
-    const int rc = C == 16 ? launch_pairh_geom<1, 4, 4>(p, dil, lds, s) : launch_pairh_geom<2, 1, 8>(p, dil, lds, s);
+    const int rc = C == 16 ? launch_pairh_geom<1, FV_PAIRH16_NF, FV_PAIRH16_NG>(p, dil, lds, s) : launch_pairh_geom<2, 1, FV_PAIRH32_NG>(p, dil, lds, s);
     profile_end(s, C == 16 ? FV_KERNEL_PAIRH16 : FV_KERNEL_PAIRH32, flops, bytes);
     return rc;
 }

@@ -21,10 +21,14 @@
 // groups ds_read_b128 is serviced in (PairHGeom).  The D fragment (lane = column, 4 consecutive channels) is
 // half a block entry: conv1's epilogue splits and stores the intermediate with ds_write_b64.
 // K order: step s covers 32 / C taps (C = 16: taps 2s, 2s+1 x 16 channels; an odd tap count is padded with a
-// zero tap), channels inside a tap.  The packed weights of a member's two convs sit in LDS.  C = 16: a wave loads the
-// A operands of a phase up front (KS x 2 ds_read_b128, 48 registers at 11 taps; 4-wave blocks, two per CU).  C = 32:
-// both row halves per wave, a phase's A operands are 176 registers -- they stream through a two-step queue like the
-// B operands (one 8-wave block per CU: the two 11-tap weight images are 88 KB).  2 waves per SIMD => 256 VGPRs.
+// zero tap), channels inside a tap.  The packed weights of a member's two convs sit in LDS and stream through a
+// two-step register queue like the B operands (AREG: with four fragments per wave at C = 16 a phase's A operands are
+// loaded up front instead, 48 registers at 11 taps -- the 2-waves-per-SIMD shape).
+// Occupancy is what these kernels live on at batch 1 (a tile is a chain of short phases: loads, conv1, barrier, conv2,
+// epilogue, convert, barrier; there is no matrix work to hide the latencies behind): 116-119 VGPRs, 4 waves per SIMD.
+// C = 32: ONE block of 15 waves per CU (240-column tiles; the two 11-tap weight images are 88 KB, a 16th wave's columns
+// would need 162 KB of LDS): 49 us per three-member launch at T = 120 000 against 59 us with 8 waves (128-column
+// tiles) and 53 with 12.  C = 16: two 8-wave blocks per CU, two fragments per wave (256-column tiles).
 //
 // Per tile: the NEXT tile's raw fp32 x window is loaded global -> registers at the top of the tile (in flight for
 // the whole tile, no LDS landing buffer); conv1 -> + b1, lrelu, zero outside [0, T), split -> intermediate image;
@@ -70,7 +74,7 @@ struct PairHGeom {
     static constexpr int NCOL4 = (XWIN + 3) / 4;
     static constexpr int XROWS = 4 * NCOL4;             // rows of the x image
     static constexpr int WB = KS * MH * 2 * 1024;       // bytes of one conv's packed weights
-    static constexpr bool AREG = MH == 1;               // a phase's A operands fit in registers
+    static constexpr bool AREG = MH == 1 && NF >= 4;    // a phase's A operands fit in registers (next to four fragments' accumulators: 2 waves per SIMD)
     static constexpr int MROWS = NM + 16;               // rows of the intermediate image (>= NM + KTP - 1)
     // image layout [split half][8-channel block][row][8 halves]: a block is RP rows of 16 bytes, RP a multiple of
     // 16, so the sixteen lanes of a ds_read_b128 lane group (all sixteen columns, two channel blocks) fall on the
@@ -402,9 +406,14 @@ __device__ __forceinline__ void pairh_run_any(const PairParams& p, const PairMem
     else pairh_run_member<PairHGeom<MH, NF, NG, 3, DIL>>(p, mb, item0, hi, smem, wave, lane, first);
 }
 
-// 2 waves per SIMD: 256 VGPRs (both convs' weights stay in registers)
+// waves per SIMD the register budget is cut for: C = 32 -- one block of NG waves per CU (8: 2, 12: 3, 13-16: 4);
+// C = 16 -- two blocks per CU: 4-wave blocks with four fragments per wave: 2 (256 VGPRs), 8-wave blocks with two: 4
+constexpr int pairh_waves_per_simd(int MH, int NF, int NG) {
+    return MH == 1 ? (NG >= 8 ? 4 : 2) : (NG > 12 ? 4 : NG > 8 ? 3 : 2);
+}
+
 template <int MH, int NF, int NG, int DIL>
-__global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu(2, 2))) void pairh_kernel(PairParams p) {
+__global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu(pairh_waves_per_simd(MH, NF, NG), pairh_waves_per_simd(MH, NF, NG)))) void pairh_kernel(PairParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
