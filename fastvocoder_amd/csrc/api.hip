@@ -10,6 +10,9 @@
 #include <utility>
 #include <vector>
 
+#include <string.h>
+#include <unistd.h>
+
 #include "fv_internal.h"
 
 namespace fv {
@@ -593,7 +596,7 @@ static int compile_lanes(fv_plan* plan) {
                 // the critical chain of an MRF stage) gets the greatest stream priority
                 int lo = 0, hi = 0;
                 (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-                const bool prio = getenv("FV_LANE_PRIO") && atoi(getenv("FV_LANE_PRIO")) != 0;
+                const bool prio = fv_getenv("FV_LANE_PRIO") && atoi(fv_getenv("FV_LANE_PRIO")) != 0;
                 const int pr = (prio && l == plan->n_lanes - 1) ? hi : lo;
                 FV_HIP(hipStreamCreateWithPriority(&plan->lane_stream[l], hipStreamNonBlocking, pr));
             }
@@ -646,9 +649,31 @@ int allow_dynamic_lds(const void* kernel, size_t bytes) {
     return 0;
 }
 
+const char* fv_getenv(const char* name) {
+    struct Entry {
+        const char* name;
+        const char* value;
+    };
+    thread_local uintptr_t gen = 0;
+    thread_local Entry cache[48];
+    thread_local int n = 0;
+    uintptr_t h = 0x9e3779b97f4a7c15ull;
+    if (environ)
+        for (char** e = environ; *e; ++e) h = (h ^ reinterpret_cast<uintptr_t>(*e)) * 0x100000001b3ull;
+    if (h != gen) {
+        gen = h;
+        n = 0;
+    }
+    for (int i = 0; i < n; ++i)
+        if (cache[i].name == name || strcmp(cache[i].name, name) == 0) return cache[i].value;
+    const char* v = getenv(name);
+    if (n < 48) cache[n++] = {name, v};
+    return v;
+}
+
 int tuning_dbg_flags() {
-    const char* on = getenv("FV_TUNING");
-    const char* d = getenv("FV_PAIR_DBG");
+    const char* on = fv_getenv("FV_TUNING");
+    const char* d = fv_getenv("FV_PAIR_DBG");
     return on && atoi(on) == 1 && d ? atoi(d) : 0;
 }
 
@@ -1250,7 +1275,7 @@ int fv_resblock1_fused_ex(int n, const float* const* x, const float* const* w1, 
         mb.y_act = y_act ? y_act[j] : nullptr;
         mb.k = k[j];
     }
-    if (C == 64 && !getenv("FV_PAIR64_UNFUSED")) return launch_convp(pp, dil, (hipStream_t)stream);
+    if (C == 64 && !fv_getenv("FV_PAIR64_UNFUSED")) return launch_convp(pp, dil, (hipStream_t)stream);
     if (C >= 64) return launch_wide_pairs(pp, mid, C, dil, (hipStream_t)stream);
     return launch_pairs(pp, C, dil, (hipStream_t)stream);
 }
@@ -1573,7 +1598,7 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
     if (int rc = compile_lanes(plan)) return rc;
     hipStream_t lanes[kMaxLanes];
     lanes[0] = (hipStream_t)stream;
-    const bool multi = plan->n_lanes > 1 && !getenv("FV_SINGLE_LANE");
+    const bool multi = plan->n_lanes > 1 && !fv_getenv("FV_SINGLE_LANE");
     for (int l = 1; l < kMaxLanes; ++l) lanes[l] = multi && l < plan->n_lanes ? plan->lane_stream[l] : lanes[0];
     if (multi) {
         // fork: the side lanes start after everything already queued on the caller's stream
@@ -1687,7 +1712,7 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
                     mb.add2 = qo.acc2 == FV_SLOT_NONE ? nullptr : base[qo.acc2];
                 }
             }
-            if (o.Cin == 64 && !getenv("FV_PAIR64_UNFUSED")) {
+            if (o.Cin == 64 && !fv_getenv("FV_PAIR64_UNFUSED")) {
                 if (int rc = launch_convp(pp, o.dil, s)) return rc;
             } else if (o.Cin >= 64) {
                 float* mids[3] = {nullptr, nullptr, nullptr};
@@ -1747,7 +1772,7 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             const int64_t T3 = sh[o.x].T;
             const int Mp = pad_rows(o.Cout);
             const int64_t blocks = (int64_t)(Mp == 16 ? 1 : Mp / 32) * ((T3 + 127) / 128);
-            const int min_blocks = getenv("FV_SUM3_MIN") ? atoi(getenv("FV_SUM3_MIN")) : 800;   // measured: HiFi-GAN light, B = 1
+            const int min_blocks = fv_getenv("FV_SUM3_MIN") ? atoi(fv_getenv("FV_SUM3_MIN")) : 800;   // measured: HiFi-GAN light, B = 1
             int rc3;
             if (blocks >= min_blocks && Mp == o.Cout) {   // (whole row tiles only: the kernel's epilogue is the affine one)
                 ConvParams ps[3] = {

@@ -40,7 +40,7 @@ struct Geometry {
 };
 
 int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
+    const char* v = fv_getenv(name);
     return v && *v ? atoi(v) : dflt;
 }
 

@@ -29,13 +29,13 @@ extern template int launch_convh_geom<2, 2>(const PairParams&, int, size_t, hipS
 const int* pair_schedule(const PairParams& p, int nblk) {
     static std::mutex mu;
     static std::map<std::array<int, 10>, const int*> cache;
-    const char* off = getenv("FV_SCHED");
+    const char* off = fv_getenv("FV_SCHED");
     if (off && atoi(off) == 0) return nullptr;
     long long items = 0;
     for (int m = 0; m < p.n_members; ++m) items += p.m[m].n_items;
     if (p.n_members < 2 || nblk < 2 || items > 6LL * nblk) return nullptr;
     if (p.n_members != 2 && !(off && atoi(off) == 2)) return nullptr;
-    const int sw = getenv("FV_SCHED_SWITCH") ? atoi(getenv("FV_SCHED_SWITCH")) : 4;
+    const int sw = fv_getenv("FV_SCHED_SWITCH") ? atoi(fv_getenv("FV_SCHED_SWITCH")) : 4;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::array<int, 10> key = {dev, nblk, p.n_members, sw, 0, 0, 0, 0, 0, 0};
@@ -136,7 +136,7 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
         p.nch = g.NCH;
         p.nmt = g.NMT;
         // a tile costs its stages (LDS / matrix time) plus loads, conversion, epilogue
-        mb.cost = g.NST * g.NCH + (getenv("FV_CONVH_SKEL") ? atoi(getenv("FV_CONVH_SKEL")) : (C == 64 ? 5 : 2));
+        mb.cost = g.NST * g.NCH + (fv_getenv("FV_CONVH_SKEL") ? atoi(fv_getenv("FV_CONVH_SKEL")) : (C == 64 ? 5 : 2));
         if (g.XIMG > img_bytes) img_bytes = g.XIMG;
         items += mb.n_items;
         flops += 2.0 * p.B * (double)C * C * mb.k * p.T;
@@ -152,13 +152,13 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     const size_t lds = floats * 4;
     if (lds > 160 * 1024) return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: %zu bytes of LDS", lds);
     const int cus = device_cu_count();
-    const char* force = getenv("FV_CONVH_BLOCKS");
+    const char* force = fv_getenv("FV_CONVH_BLOCKS");
     long long nblk = force && atoi(force) > 0 ? atoi(force) : cus;     // one 8-wave block per CU
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
     p.sched = pair_schedule(p, p.nblk);
     p.dbg = tuning_dbg_flags();
-    p.trace = getenv("FV_PAIR_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("FV_PAIR_TRACE_PTR"), nullptr, 0)) : nullptr;
+    p.trace = fv_getenv("FV_PAIR_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(fv_getenv("FV_PAIR_TRACE_PTR"), nullptr, 0)) : nullptr;
     profile_begin(s);
     const int rc = C >= 128 ? launch_convh_geom<4, 2>(p, dil, lds, s) : launch_convh_geom<2, 2>(p, dil, lds, s);
     profile_end(s, C == 64 ? FV_KERNEL_CONVH64 : FV_KERNEL_CONVH128, flops, bytes);
@@ -203,7 +203,7 @@ int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout,
     p.x_off = 0;                       // ring of 4 weight stages
     p.img_off = 4 * 16384 / 4;
     const size_t lds = 4 * 16384 + (size_t)img_bytes;
-    const char* force = getenv("FV_CONVH_BLOCKS");
+    const char* force = fv_getenv("FV_CONVH_BLOCKS");
     long long nblk = force && atoi(force) > 0 ? atoi(force) : device_cu_count();
     if (nblk > mb.n_items) nblk = mb.n_items;
     p.nblk = (int)nblk;
@@ -249,7 +249,7 @@ int launch_convp(PairParams p, int dil, hipStream_t s) {
         const int nout = g.NTC - (mb.k - 1);
         mb.n_tiles = (p.T + nout - 1) / nout;
         mb.n_items = mb.n_tiles * p.B;
-        mb.cost = 2 * g.NST + (getenv("FV_CONVP_SKEL") ? atoi(getenv("FV_CONVP_SKEL")) : 5);
+        mb.cost = 2 * g.NST + (fv_getenv("FV_CONVP_SKEL") ? atoi(fv_getenv("FV_CONVP_SKEL")) : 5);
         if (g.XIMG > img_bytes) img_bytes = g.XIMG;
         items += mb.n_items;
         flops += 2.0 * 2.0 * p.B * (double)C * C * mb.k * p.T;
@@ -266,7 +266,7 @@ int launch_convp(PairParams p, int dil, hipStream_t s) {
     floats += 2 * (size_t)C;
     const size_t lds = floats * 4;
     if (lds > 160 * 1024) return fail(FV_ERR_UNSUPPORTED, "resblock pair: %zu bytes of LDS", lds);
-    const char* force = getenv("FV_CONVH_BLOCKS");
+    const char* force = fv_getenv("FV_CONVH_BLOCKS");
     long long nblk = force && atoi(force) > 0 ? atoi(force) : device_cu_count();
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;

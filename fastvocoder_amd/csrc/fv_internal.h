@@ -133,6 +133,11 @@ int device_cu_count();
 // FV_PAIR_DBG: ablation switches of the persistent kernels (timing experiments; the results are WRONG).  Honoured only
 // together with FV_TUNING=1 so that a stray environment variable cannot corrupt a product run.
 int tuning_dbg_flags();
+// getenv for the launch path: a launch reads eight to ten tuning variables and glibc's getenv walks the whole
+// environment for each (~0.3 us; 45 launches make a MelGAN forward at batch 1, which is host-bound).  Values are cached
+// per thread until the environment changes (detected by a hash of the environ entries' addresses: setenv / putenv /
+// unsetenv replace or move entries).
+const char* fv_getenv(const char* name);
 
 // ---- fused ResBlock1 pairs (pair_kernels.hpp / pair_launch.hip) ---------------------------------------
 // one ResBlock's pair (a "member" of the launch)

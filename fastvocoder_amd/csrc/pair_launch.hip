@@ -99,7 +99,7 @@ static int launch_pairs_split(PairParams p, int C, int dil, hipStream_t s) {
         // a tile costs its K steps (two convs, LDS-bandwidth bound) plus a part that does not depend on the taps
         // (loads, convert pass, epilogues, stores, barriers): measured per member alone (tools/pair_bench.py)
         // 0.8 us per step + 8 steps' worth at C = 16, 1.6 us per step + 6 steps' worth at C = 32 (240-column tiles)
-        mb.cost = g.KS + (getenv("FV_PAIRH_SKEL") ? atoi(getenv("FV_PAIRH_SKEL")) : (C == 16 ? 8 : 6));
+        mb.cost = g.KS + (fv_getenv("FV_PAIRH_SKEL") ? atoi(fv_getenv("FV_PAIRH_SKEL")) : (C == 16 ? 8 : 6));
         mb.w_off = 0;
         if (2 * g.WB > w_bytes) w_bytes = 2 * g.WB;
         if (g.XIMG > img_bytes) img_bytes = g.XIMG;
@@ -119,7 +119,7 @@ static int launch_pairs_split(PairParams p, int C, int dil, hipStream_t s) {
     floats += 2 * (size_t)C;
     const size_t lds = floats * 4;
     if (lds > (C == 16 ? 80 : 160) * 1024) return fail(FV_ERR_UNSUPPORTED, "resblock pair, split-f16: %zu bytes of LDS", lds);
-    const char* force = getenv("FV_PAIR_BLOCKS");
+    const char* force = fv_getenv("FV_PAIR_BLOCKS");
     // 15-16 waves per CU (4 per SIMD): two 8-wave blocks at C = 16, one 15-wave block at C = 32
     long long nblk = force && atoi(force) > 0 ? atoi(force) : (C == 16 ? 2LL : 1LL) * num_cus();
     if (nblk > items) nblk = items;
@@ -179,7 +179,7 @@ int launch_pairs(PairParams p, int C, int dil, hipStream_t s) {
         // a tile costs its MFMA time (proportional to the taps) plus a per-tile part that does not depend on
         // them (staging, activation pass, barriers, epilogue): measured 4.2k + 1.1k * taps cycles at C = 16,
         // 6k + 2.0k * taps at C = 32 (tools/pair_trace.py) -- in units of one tap's time
-        mb.cost = mb.k + (getenv("FV_PAIR_SKEL") ? atoi(getenv("FV_PAIR_SKEL")) : (C == 16 ? 4 : 3));
+        mb.cost = mb.k + (fv_getenv("FV_PAIR_SKEL") ? atoi(fv_getenv("FV_PAIR_SKEL")) : (C == 16 ? 4 : 3));
         if (p.sum) {
             mb.w_off = (int)floats;
             floats += 2 * (size_t)g.WF;
@@ -213,12 +213,12 @@ int launch_pairs(PairParams p, int C, int dil, hipStream_t s) {
     int per_cu = (int)(160 * 1024 / lds);
     if (per_cu * g0.NW > 16) per_cu = 16 / g0.NW;      // <= 128 VGPRs: 4 waves per SIMD
     if (per_cu < 1) per_cu = 1;
-    const char* force = getenv("FV_PAIR_BLOCKS");
+    const char* force = fv_getenv("FV_PAIR_BLOCKS");
     long long nblk = force && atoi(force) > 0 ? atoi(force) : (long long)per_cu * num_cus();
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
     p.dbg = tuning_dbg_flags();
-    p.trace = getenv("FV_PAIR_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("FV_PAIR_TRACE_PTR"), nullptr, 0)) : nullptr;
+    p.trace = fv_getenv("FV_PAIR_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(fv_getenv("FV_PAIR_TRACE_PTR"), nullptr, 0)) : nullptr;
 
     profile_begin(s);
     int rc;
