@@ -162,6 +162,7 @@ def lib():
                                         i, f, i, vp]
     L.fv_plan_add_resblock_pair_ex.argtypes = [vp, i, i, i, i, i, i, vp, vp, vp, vp, i, i, i, f, f, i, f, i]
     L.fv_conv1d_split_f16.argtypes = [i, pp, pp, pp, pp, pp, pp, pp, pp, ctypes.POINTER(i), i, i, i, i, i, f, f, i, f, vp]
+    L.fv_plan_set_pair_output_conv.argtypes = [vp, vp, vp, i, f, i]
     L.fv_plan_add_conv1d_split_f16.argtypes = [vp, i, i, i, i, i, i, vp, vp, i, i, i, i, f, f, i, f]
     L.fv_plan_add_mrf_sum.argtypes = [vp, ctypes.POINTER(i), i, i, pp, pp, pp, pp, i, ctypes.POINTER(i), i, f, f, i, f]
     L.fv_plan_create.argtypes = [i]
@@ -622,6 +623,14 @@ class Plan:
                                                  _ptr(packed2, "packed2"), _ptr(bias1, "bias1", True),
                                                  _ptr(bias2, "bias2", True), channels, k, dil, float(slope),
                                                  float(out_div), post, float(act_slope), prec))
+
+    def set_pair_output_conv(self, w, bias, y, act_slope, post=POST_NONE):
+        """Fold a 16 -> 1 channel, 7-tap conv into the resblock pair appended last (fv_plan_set_pair_output_conv):
+        ``y`` becomes post(conv(lrelu(pair result, act_slope)) + bias), [B, 1, T]."""
+        self.keep(w)
+        if bias is not None:
+            self.keep(bias)
+        check(lib().fv_plan_set_pair_output_conv(self._h, _ptr(w, "w"), _ptr(bias, "bias", True), y, float(act_slope), post))
 
     def add_conv1d_split_f16(self, x, y, packed, bias, channels, k, dil, pre_slope=1.0, res=SLOT_NONE, add1=SLOT_NONE,
                              add2=SLOT_NONE, out_div=1.0, post=POST_NONE, y_act=SLOT_NONE, act_slope=1.0,

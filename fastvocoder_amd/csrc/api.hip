@@ -334,6 +334,9 @@ struct Op {
     const float* pb2[3] = {nullptr, nullptr, nullptr};
     int pk[3] = {0, 0, 0};
     int prec = 0;             // FV_PAIR_F32 / FV_PAIR_SPLIT_F16
+    // fv_plan_set_pair_output_conv: a 16 -> 1 channel, 7-tap conv folded into the pair; y is ITS output [B, 1, T]
+    const float* fold_w = nullptr;
+    const float* fold_b = nullptr;
     int sub = FV_SLOT_NONE;   // fv_plan_set_output_offset: auxiliary input subtracted in this op's epilogue
 };
 
@@ -447,8 +450,9 @@ static int infer(const fv_plan* plan, int B, int T, Shape* sh, int64_t* slot_ele
             if (es > slot_elems[o.tmpb]) slot_elems[o.tmpb] = es;
         }
         if (o.y == o.x || o.y == o.x2) return fail(FV_ERR_INVALID_ARG, "op %zu: output aliases input", n);
-        sh[o.y] = {Cout, Tout, true};
-        const int64_t e = (int64_t)B * Cout * Tout;
+        const int Cy = o.fold_w ? 1 : Cout;
+        sh[o.y] = {Cy, Tout, true};
+        const int64_t e = (int64_t)B * Cy * Tout;
         if (e > slot_elems[o.y]) slot_elems[o.y] = e;
         if (o.y2 != FV_SLOT_NONE) {
             if (o.y2 == o.x || o.y2 == o.y || o.y2 == o.x2)
@@ -1506,7 +1510,7 @@ int fv_plan_set_output_offset(fv_plan_t* plan, int aux_slot, int y2_slot) {
     if (int rc = check_slot(y2_slot, true)) return rc;
     Op& o = plan->ops.back();
     if (o.type == OP_PAIR || o.type == OP_MRFSUM || o.type == OP_CONVH || o.sum3 || o.group != 0 ||
-        (o.type == OP_CONVT && o.prec == FV_PAIR_SPLIT_F16))
+        (o.type == OP_CONVT && o.prec == FV_PAIR_SPLIT_F16))   // (a pair with a folded output conv included)
         return fail(FV_ERR_UNSUPPORTED, "plan_set_output_offset: only plain conv / transposed conv / pqmf ops carry an offset");
     if (y2_slot != FV_SLOT_NONE) {
         if (o.y2 != FV_SLOT_NONE) return fail(FV_ERR_INVALID_ARG, "plan_set_output_offset: the op already has a second output");
@@ -1515,6 +1519,26 @@ int fv_plan_set_output_offset(fv_plan_t* plan, int aux_slot, int y2_slot) {
         if (o.type != OP_PQMF) o.act_slope = 1.f;
     }
     o.sub = aux_slot;
+    plan->compiled = false;
+    return 0;
+}
+
+int fv_plan_set_pair_output_conv(fv_plan_t* plan, const float* w, const float* bias, int y_slot, float act_slope, int post) {
+    if (!plan || plan->ops.empty() || !w) return fail(FV_ERR_INVALID_ARG, "plan_set_pair_output_conv: no op / null weights");
+    if (int rc = check_slot(y_slot, false)) return rc;
+    Op& o = plan->ops.back();
+    if (o.type != OP_PAIR || o.prec != FV_PAIR_SPLIT_F16 || o.Cin != 16 || o.group != 0 || o.y2 != FV_SLOT_NONE ||
+        o.post != FV_POST_NONE || o.fold_w)
+        return fail(FV_ERR_UNSUPPORTED, "plan_set_pair_output_conv: the last op must be an ungrouped 16-channel split-f16 "
+                    "resblock pair without an activated twin or a post op of its own");
+    if (y_slot == FV_SLOT_IN || y_slot == o.x || y_slot == o.acc || y_slot == o.acc2 || y_slot == o.tmpb)
+        return fail(FV_ERR_INVALID_ARG, "plan_set_pair_output_conv: the output slot aliases an operand");
+    if (act_slope < 0.f || act_slope > 1.f) return fail(FV_ERR_INVALID_ARG, "plan_set_pair_output_conv: slope outside [0, 1]");
+    o.fold_w = w;
+    o.fold_b = bias;
+    o.y = y_slot;
+    o.act_slope = act_slope;
+    o.post = post;
     plan->compiled = false;
     return 0;
 }
@@ -1664,7 +1688,8 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             if (o.type == OP_PAIR && o.group != 0)
                 while (m < plan->ops.size() && m - n < 3 && plan->ops[m].type == OP_PAIR && plan->ops[m].group == o.group &&
                        plan->ops[m].lane == o.lane && plan->ops[m].Cin == o.Cin && plan->ops[m].dil == o.dil &&
-                       plan->ops[m].pre_slope == o.pre_slope && plan->ops[m].act_slope == o.act_slope &&
+                       plan->ops[m].pre_slope == o.pre_slope && plan->ops[m].act_slope == o.act_slope && !o.fold_w &&
+                       !plan->ops[m].fold_w &&
                        plan->ops[m].prec == o.prec && plan->ops[m].out_div == o.out_div && plan->ops[m].post == o.post)
                     ++m;
             hipStream_t s = lanes[o.lane];
@@ -1710,6 +1735,12 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
                     mb.y_act = qo.y2 == FV_SLOT_NONE ? nullptr : base[qo.y2];
                     mb.add1 = qo.acc == FV_SLOT_NONE ? nullptr : base[qo.acc];
                     mb.add2 = qo.acc2 == FV_SLOT_NONE ? nullptr : base[qo.acc2];
+                    if (qo.fold_w) {            // (never grouped: one member)
+                        pp.fold_w = qo.fold_w;
+                        pp.fold_b = qo.fold_b;
+                        pp.fold_y = base[qo.y];
+                        mb.y = nullptr;
+                    }
                 }
             }
             if (o.Cin == 64 && !fv_getenv("FV_PAIR64_UNFUSED")) {
@@ -1722,7 +1753,7 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             for (size_t q = n; q < m; ++q) {
                 const Op& qo = plan->ops[q];
                 if (multi && qo.signal) FV_HIP(hipEventRecord(plan->op_event[q], s));
-                sh[qo.y] = {qo.Cout, sh[qo.x].T, true};
+                sh[qo.y] = {qo.fold_w ? 1 : qo.Cout, sh[qo.x].T, true};
                 if (qo.y2 != FV_SLOT_NONE) sh[qo.y2] = sh[qo.y];
             }
             n = m - 1;

@@ -171,6 +171,9 @@ struct PairParams {
     int post;            // FV_POST_* applied to y (sum mode / single)
     int nblk;            // persistent blocks in the grid
     int ctot, nch, nmt;  // convh: channels in and out, chunks of <= 128 input channels, row tiles of 64
+    const float* fold_w; // pairh, C = 16, one member (pairh_run_member<G, true>): conv_post folded into the pair -- its
+    const float* fold_b; //   weights [C][7], bias [1] or null, output [B, 1, T]; `post` is applied to that output,
+    float* fold_y;       //   act_slope to the pair's own (never stored) output in front of it
     const int* sched;    // convh / convp: per block [member][lo, hi) item ranges (pair_schedule), or null: the kernel
                          // cuts the cost-weighted item sequence into nblk contiguous shares itself (pair_share)
     int reflect;         // convh: rows outside [0, T) are the mirrored samples (ReflectionPad1d) instead of zeros

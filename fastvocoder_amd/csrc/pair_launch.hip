@@ -84,18 +84,21 @@ PairHShape pairh_shape(int C, int k, int dil) {
 
 static int launch_pairs_split(PairParams p, int C, int dil, hipStream_t s) {
     if (p.sum) return fail(FV_ERR_UNSUPPORTED, "mrf sum: fp32 kernels only (split-f16 stages end in a pair with add1 / add2)");
+    if (p.fold_w && (C != 16 || p.n_members != 1 || !p.fold_y || p.m[0].y_act))
+        return fail(FV_ERR_UNSUPPORTED, "resblock pair with a folded output conv: one 16-channel member, no activated twin");
     int w_bytes = 0, img_bytes = 0, mid_bytes = 0;
     double flops = 0, bytes = 0;
     long long items = 0;
     for (int i = 0; i < p.n_members; ++i) {
         PairMember& mb = p.m[i];
         if (mb.k != 11 && mb.k != 7 && mb.k != 3) return fail(FV_ERR_UNSUPPORTED, "resblock pair: %d taps (3, 7 or 11)", mb.k);
-        if (!mb.x || !mb.w1 || !mb.w2 || !mb.y) return fail(FV_ERR_INVALID_ARG, "resblock pair: null tensor (member %d)", i);
+        if (!mb.x || !mb.w1 || !mb.w2 || (!mb.y && !p.fold_w)) return fail(FV_ERR_INVALID_ARG, "resblock pair: null tensor (member %d)", i);
         if (mb.add2 && !mb.add1) return fail(FV_ERR_INVALID_ARG, "resblock pair: add2 without add1 (member %d)", i);
         if ((reinterpret_cast<uintptr_t>(mb.x) | reinterpret_cast<uintptr_t>(mb.w1) | reinterpret_cast<uintptr_t>(mb.w2)) & 15)
             return fail(FV_ERR_UNSUPPORTED, "resblock pair: x / packed weights must be 16-byte aligned");
         const PairHShape g = pairh_shape(C, mb.k, dil);
-        mb.n_tiles = (p.T + g.NOUT - 1) / g.NOUT;
+        const int tstride = p.fold_w ? g.NOUT - 6 : g.NOUT;      // folded 7-tap output conv: 3 samples of halo either side
+        mb.n_tiles = (p.T + tstride - 1) / tstride;
         // a tile costs its K steps (two convs, LDS-bandwidth bound) plus a part that does not depend on the taps
         // (loads, convert pass, epilogues, stores, barriers): measured per member alone (tools/pair_bench.py)
         // 0.8 us per step + 8 steps' worth at C = 16, 1.6 us per step + 6 steps' worth at C = 32 (240-column tiles)
@@ -107,6 +110,10 @@ static int launch_pairs_split(PairParams p, int C, int dil, hipStream_t s) {
         items += (long long)mb.n_tiles * p.B;
         flops += 2.0 * 2.0 * p.B * (double)C * C * mb.k * p.T;
         bytes += 4.0 * (2.0 * C * C * mb.k + (double)p.B * C * p.T * ((mb.y_act ? 3 : 2) + (mb.add1 ? 1 : 0) + (mb.add2 ? 1 : 0)));
+        if (p.fold_w) {                // + the 16 -> 1, 7-tap conv; its output instead of the pair's
+            flops += 2.0 * p.B * (double)C * 7 * p.T;
+            bytes += 4.0 * ((double)p.B * p.T - (double)p.B * C * p.T);
+        }
     }
     size_t floats = 0;
     p.x_off = 0;                       // [conv1 | conv2] packed weights of the member a block is working on
@@ -147,6 +154,7 @@ int launch_pairs(PairParams p, int C, int dil, hipStream_t s) {
         return fail(FV_ERR_INVALID_ARG, "resblock pair: activation slope outside [0, 1]");
     if (p.prec == FV_PAIR_SPLIT_F16) return launch_pairs_split(p, C, dil, s);
     if (p.prec != FV_PAIR_F32) return fail(FV_ERR_INVALID_ARG, "resblock pair: unknown arithmetic %d", p.prec);
+    if (p.fold_w) return fail(FV_ERR_UNSUPPORTED, "resblock pair: a folded output conv exists with FV_PAIR_SPLIT_F16 only");
     for (int i = 0; i < p.n_members; ++i)
         if (p.m[i].add1 || p.m[i].add2)
             return fail(FV_ERR_UNSUPPORTED, "resblock pair: add1 / add2 exist with FV_PAIR_SPLIT_F16 only (fp32: fv_mrf_stage)");

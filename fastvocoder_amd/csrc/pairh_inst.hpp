@@ -8,7 +8,7 @@ template <int MH, int NF, int NG>
 int launch_pairh_geom(const PairParams& p, int dil, size_t lds, hipStream_t s) {
 #define FV_PAIRH(DIL)                                                                          \
     do {                                                                                       \
-        auto kern = pairh_kernel<MH, NF, NG, DIL>;                                             \
+        auto kern = p.fold_w && MH == 1 ? pairh_kernel<MH, NF, NG, DIL, MH == 1> : pairh_kernel<MH, NF, NG, DIL, false>; \
         if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc; \
         hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(64 * NG), lds, s, p);                      \
     } while (0)

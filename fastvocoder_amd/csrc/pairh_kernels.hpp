@@ -241,9 +241,13 @@ __device__ __forceinline__ void pairh_mma(const float* wl, const char* img, f32x
 // items [item0, hi) of ONE member, in order (item = utterance * n_tiles + tile).
 // Per tile: [loads of the NEXT tile's raw window and of this tile's residual are issued] conv1 -> intermediate,
 // barrier, conv2, convert the next window into the x image (free since the barrier), stores, barrier.
-template <class G>
+// FOLD (the last pair of a HiFi-GAN, C = 16): the pair's output never goes to memory -- conv_post (16 -> 1 channels, 7
+// taps, hifigan.py:104-106) runs on the activated tile in LDS: y_out = post( conv7( lrelu(x', act_slope) ) + b ).  Tiles
+// then advance by NOUT - 6 samples and start 3 early (the 3-sample halo either side is recomputed).
+template <class G, bool FOLD = false>
 __device__ __forceinline__ void pairh_run_member(const PairParams& p, const PairMember& mb, int item0, int hi_item,
                                                  float* smem, int wave, int lane_in, bool first) {
+    constexpr int TSTRIDE = FOLD ? G::NOUT - 6 : G::NOUT, TSHIFT = FOLD ? 3 : 0;
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
     const int tid = wave * 64 + lane;
@@ -267,7 +271,7 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
     int b = item / mb.n_tiles, tile = item - b * mb.n_tiles;
     if (!first) pair_barrier();                         // everybody is done with the previous member's LDS
     PairHRaw<G> raw;
-    pairh_load_raw<G>(raw, mb.x + b * ustride, p.T, tile * G::NOUT - HEAD, tid);
+    pairh_load_raw<G>(raw, mb.x + b * ustride, p.T, tile * TSTRIDE - TSHIFT - HEAD, tid);
     pairh_stage_weights<G>(mb, wl, wave, lane);
     pair_stage_bias<G>(mb, bl, tid);
     // rows [NM, MROWS) of the intermediate feed only discarded columns / the zero tap: finite values once
@@ -277,7 +281,7 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
     pairh_convert<G>(raw, ximg, p.slope, tid);
     pair_barrier();
     for (;;) {
-        const int t0 = tile * G::NOUT;
+        const int t0 = tile * TSTRIDE - TSHIFT;
         const int nitem = item + 1;
         const bool more = nitem < hi_item;
         int nb = b, ntile = tile + 1;
@@ -286,7 +290,7 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
             ++nb;
         }
         // the next tile's raw window: in flight for the whole tile; then this tile's residual (fp32, L2 hits)
-        if (more && !(p.dbg & 1)) pairh_load_raw<G>(raw, mb.x + nb * ustride, p.T, ntile * G::NOUT - HEAD, tid);
+        if (more && !(p.dbg & 1)) pairh_load_raw<G>(raw, mb.x + nb * ustride, p.T, ntile * TSTRIDE - TSHIFT - HEAD, tid);
         float res[G::MH][G::NF][4];
         const unsigned ubytes = (unsigned)G::C * (unsigned)p.T * 4u;
         const unsigned t4 = (unsigned)p.T * 4u;
@@ -298,7 +302,7 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
 #pragma unroll
                 for (int f = 0; f < G::NF; ++f) {
                     const int col = col0 + f * 16, t = t0 + col;
-                    const bool ok = col < G::NOUT && t < p.T && !(p.dbg & 16);
+                    const bool ok = col < G::NOUT && t >= 0 && t < p.T && !(p.dbg & 16);
                     voff[h][f] = ok ? (unsigned)((16 * h + row0) * p.T + t) * 4u : kOutOfRange;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) res[h][f][i] = buffer_load1s(rx, voff[h][f], (unsigned)i * t4);
@@ -379,6 +383,40 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
 #pragma unroll
                     for (int i = 0; i < 4; ++i) hi[h][f][i] = (hi[h][f][i] + lo[h][f][i]) + res[h][f][i];
         }
+        if constexpr (FOLD) {
+            // the activated tile -> LDS (the intermediate image's space: every wave is past its conv2 reads after the
+            // barrier), zero outside [0, T) and beyond the tile's valid columns; then one output sample per thread
+            float* const sb = reinterpret_cast<float*>(mimg);          // [C][NM]
+            pair_barrier();
+#pragma unroll
+            for (int h = 0; h < G::MH; ++h)
+#pragma unroll
+                for (int f = 0; f < G::NF; ++f) {
+                    const int col = col0 + f * 16, t = t0 + col;
+                    const bool ok = col < G::NOUT && t >= 0 && t < p.T;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = hi[h][f][i];
+                        if (fin) v = v / p.out_div;
+                        sb[(16 * h + row0 + i) * G::NM + col] = ok ? act(v, p.act_slope) : 0.f;
+                    }
+                }
+            pair_barrier();
+            if (tid < TSTRIDE) {
+                const int t = t0 + 3 + tid;
+                // (channel-major FMA chain from zero, bias last: conv_narrow_kernel's arithmetic -- the plans that keep
+                // conv_post as a launch of its own, e.g. inference_minus, give the same bits)
+                float o = 0.f;
+#pragma unroll 2
+                for (int c = 0; c < G::C; ++c)
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) o = fmaf(p.fold_w[c * 7 + j], sb[c * G::NM + tid + j], o);
+                o = o + (p.fold_b ? p.fold_b[0] : 0.f);
+                if (p.post == FV_POST_TANH) o = tanhf(o);
+                else if (p.post == FV_POST_RELU) o = fmaxf(o, 0.f);
+                if (t < p.T && !(p.dbg & 8)) p.fold_y[(size_t)b * p.T + t] = o;
+            }
+        } else {
 #pragma unroll
         for (int h = 0; h < G::MH; ++h)
 #pragma unroll
@@ -390,6 +428,7 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
                 pair_store(p, mb.y, mb.y_act, G::C, b, 16 * h + row0, t0 + col,
                            col < G::NOUT && t0 + col < p.T && !(p.dbg & 8), v, fin);
             }
+        }
         if (!more) break;
         pair_barrier();                                  // (A) the next x image is complete; the intermediate is free
         item = nitem;
@@ -398,12 +437,12 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
     }
 }
 
-template <int MH, int NF, int NG, int DIL>
+template <int MH, int NF, int NG, int DIL, bool FOLD>
 __device__ __forceinline__ void pairh_run_any(const PairParams& p, const PairMember& mb, int item0, int hi, float* smem,
                                               int wave, int lane, bool first) {
-    if (mb.k == 11) pairh_run_member<PairHGeom<MH, NF, NG, 11, DIL>>(p, mb, item0, hi, smem, wave, lane, first);
-    else if (mb.k == 7) pairh_run_member<PairHGeom<MH, NF, NG, 7, DIL>>(p, mb, item0, hi, smem, wave, lane, first);
-    else pairh_run_member<PairHGeom<MH, NF, NG, 3, DIL>>(p, mb, item0, hi, smem, wave, lane, first);
+    if (mb.k == 11) pairh_run_member<PairHGeom<MH, NF, NG, 11, DIL>, FOLD>(p, mb, item0, hi, smem, wave, lane, first);
+    else if (mb.k == 7) pairh_run_member<PairHGeom<MH, NF, NG, 7, DIL>, FOLD>(p, mb, item0, hi, smem, wave, lane, first);
+    else pairh_run_member<PairHGeom<MH, NF, NG, 3, DIL>, FOLD>(p, mb, item0, hi, smem, wave, lane, first);
 }
 
 // waves per SIMD the register budget is cut for: C = 32 -- one block of NG waves per CU (8: 2, 12: 3, 13-16: 4);
@@ -412,7 +451,7 @@ constexpr int pairh_waves_per_simd(int MH, int NF, int NG) {
     return MH == 1 ? (NG >= 8 ? 4 : 2) : (NG > 12 ? 4 : NG > 8 ? 3 : 2);
 }
 
-template <int MH, int NF, int NG, int DIL>
+template <int MH, int NF, int NG, int DIL, bool FOLD = false>
 __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu(pairh_waves_per_simd(MH, NF, NG), pairh_waves_per_simd(MH, NF, NG)))) void pairh_kernel(PairParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -423,12 +462,14 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu(pairh_w
     q.n_members = p.n_members; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = p.out_div;
     q.act_slope = p.act_slope; q.post = p.post; q.x_off = p.x_off; q.img_off = p.img_off; q.mid_off = p.mid_off;
     q.bias_off = p.bias_off; q.dbg = p.dbg; q.trace = p.trace;
+    q.fold_w = p.fold_w; q.fold_b = p.fold_b; q.fold_y = p.fold_y;
     int n_tiles[3], cost[3];
 #pragma unroll
     for (int m = 0; m < 3; ++m) { n_tiles[m] = p.m[m].n_tiles; cost[m] = p.m[m].cost; }
     asm volatile("" ::"s"(q.n_members), "s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.out_div), "s"(q.act_slope),
                  "s"(q.post), "s"(q.x_off), "s"(q.img_off), "s"(q.mid_off), "s"(q.bias_off), "s"(q.dbg), "s"(q.trace),
-                 "s"(n_tiles[0]), "s"(n_tiles[1]), "s"(n_tiles[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]));
+                 "s"(n_tiles[0]), "s"(n_tiles[1]), "s"(n_tiles[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]), "s"(q.fold_w),
+                 "s"(q.fold_b), "s"(q.fold_y));
     long long total = 0;
 #pragma unroll
     for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_tiles[m] * q.B * cost[m] : 0;
@@ -448,7 +489,7 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu(pairh_w
         mb.add2 = p.m[m].add2; mb.y = p.m[m].y; mb.y_act = p.m[m].y_act; mb.k = p.m[m].k; mb.n_tiles = nt;
         asm volatile("" ::"s"(mb.x), "s"(mb.w1), "s"(mb.w2), "s"(mb.b1), "s"(mb.b2), "s"(mb.add1), "s"(mb.add2), "s"(mb.y),
                      "s"(mb.y_act), "s"(mb.k));
-        pairh_run_any<MH, NF, NG, DIL>(q, mb, lo, hi, smem, wave, lane, first);
+        pairh_run_any<MH, NF, NG, DIL, FOLD>(q, mb, lo, hi, smem, wave, lane, first);
         first = false;
     }
 }

@@ -35,7 +35,7 @@ def effective_weight(conv):
     return conv.weight.detach().contiguous().float()
 
 
-_SPLIT_CONVT = os.environ.get("FV_SPLIT_CONVT", "1") != "0"   # upsamplers with 128+ input channels on convt_kernel
+_SPLIT_CONVT = os.environ.get("FV_SPLIT_CONVT", "1") != "0"   # upsamplers with 64+ input channels on convt_kernel
 
 
 class PlanBuilder:
@@ -152,8 +152,10 @@ class PlanBuilder:
 
     @staticmethod
     def pair_mode_tag():
-        """Part of a plan's cache key: the arithmetic policy in force (FV_PAIR_PREC)."""
-        return "s" if os.environ.get("FV_PAIR_PREC", "split") == "f32" else "h"
+        """Part of a plan's cache key: the arithmetic policy in force (FV_PAIR_PREC; FV_FOLD_POST=0: conv_post as a
+        launch of its own)."""
+        return ("s" if os.environ.get("FV_PAIR_PREC", "split") == "f32" else "h") + \
+            ("n" if os.environ.get("FV_FOLD_POST", "1") == "0" else "")
 
     @staticmethod
     def pair_fusable(conv1, conv2, prec=None):
@@ -172,13 +174,29 @@ class PlanBuilder:
                     w2=_native.pack_pair(effective_weight(conv2), prec),
                     b1=self._bias(conv1), b2=self._bias(conv2), k=conv1.kernel_size[0])
 
+    @staticmethod
+    def pair_fold_supported(conv1, out_conv, prec):
+        """Can ``out_conv`` (HiFi-GAN's conv_post: 16 -> 1 channels, 7 taps, 'same' zero padding) be folded into the
+        fused pair in front of it (fv_plan_set_pair_output_conv)?"""
+        return (os.environ.get("FV_FOLD_POST", "1") != "0" and prec == _native.PAIR_SPLIT_F16 and conv1.in_channels == 16
+                and isinstance(out_conv, torch.nn.Conv1d) and out_conv.in_channels == 16 and out_conv.out_channels == 1
+                and out_conv.kernel_size[0] == 7 and out_conv.stride[0] == 1 and out_conv.dilation[0] == 1
+                and out_conv.padding[0] == 3 and out_conv.groups == 1)
+
     def pair(self, conv1, conv2, src, dst, slope, prec=_native.PAIR_F32, add1=SLOT_NONE, add2=SLOT_NONE,
-             out_div=1.0, post=POST_NONE, mid=SLOT_NONE):
+             out_div=1.0, post=POST_NONE, mid=SLOT_NONE, fold=None):
         """dst = src + conv2(lrelu(conv1(lrelu(src)))) as ONE fused op (fv_plan_add_resblock_pair_ex); it reads
         ``src`` raw and applies both activations on chip.  Ops recorded inside one group share a launch.
         With ``add1`` / ``add2`` (split-f16 arithmetic): dst = post(((pair + add1) + add2) / out_div), the MRF
-        merge of hifigan.py:99-103 in the reference's association."""
+        merge of hifigan.py:99-103 in the reference's association.  ``fold`` = (out_conv, slope, post): the pair's
+        result is not stored; dst = post(out_conv(lrelu(result, slope))), a [B, 1, T] tensor (pair_fold_supported)."""
         m = self._pair_member(conv1, conv2, prec)
+        if fold is not None:
+            out_conv, fslope, fpost = fold
+            if not self.pair_fold_supported(conv1, out_conv, prec) or post != POST_NONE or self.group:
+                raise _native.NativeError("resblock pair: this output conv cannot be folded into the pair")
+            m = dict(m, fold_w=effective_weight(out_conv).detach().float().reshape(16, 7).contiguous(),
+                     fold_b=self._bias(out_conv), fold_post=fpost, act_slope=float(fslope))
         wide = conv1.in_channels >= 64      # two conv launches through the scratch slot ``mid`` (csrc/convh_kernels.hpp)
         if wide and mid == SLOT_NONE:
             raise _native.NativeError("resblock pair: a scratch slot (mid) is needed at 64 channels and above")
@@ -355,7 +373,7 @@ class PlanBuilder:
             elif op["kind"] == "convh":
                 own, rate = (op["k"] - 1) // 2 * op["dil"], 1
             elif op["kind"] == "pair":
-                own, rate = (op["k"] - 1) // 2 * (op["dil"] + 1), 1
+                own, rate = (op["k"] - 1) // 2 * (op["dil"] + 1) + (3 if "fold_w" in op else 0), 1
             elif op["kind"] == "mrfsum":
                 own, rate = max((m["k"] - 1) // 2 * (op["dil"] + 1) for m in op["members"]), 1
             elif op["kind"] == "convT":
@@ -402,6 +420,8 @@ class PlanBuilder:
                                             y_act=op["y_act"], act_slope=op["act_slope"], prec=op["prec"],
                                             add1=op["acc"], add2=op["acc2"], out_div=op["out_div"],
                                             post=op["post"], mid=op["mid"])
+                if "fold_w" in op:
+                    self.plan.set_pair_output_conv(op["fold_w"], op["fold_b"], op["y"], op["act_slope"], op["fold_post"])
             elif op["kind"] == "convh":
                 self.plan.add_conv1d_split_f16(op["x"], op["y"], op["packed"], op["bias"], op["channels"], op["k"],
                                                op["dil"], pre_slope=op["slope"], res=op["res"], add1=op["acc"],

@@ -94,7 +94,7 @@ class _HiFiGANBase(NativeModule):
             flags.append(t > 0 and t % 4 == 0 and self._stage_fusable(i))
         return tuple(flags)
 
-    def _emit_fused_stage(self, pb, blocks, up, x, scratch, parts):
+    def _emit_fused_stage(self, pb, blocks, up, x, scratch, parts, fold=None):
         """The three ResBlocks of a stage as fused pair launches: every pair position is ONE launch of
         three members; the last position also forms the MRF mean when the three weight sets fit in
         LDS (16 channels), otherwise it runs conv by conv (grouped first convs + the merged last convs)."""
@@ -145,6 +145,10 @@ class _HiFiGANBase(NativeModule):
                 pb.pair(blocks[j].convs1[-1], blocks[j].convs2[-1], curs[j], parts[j - 1], LRELU_SLOPE, prec,
                         mid=scratch[j][0])
             pb.end_group()
+            if fold is not None:        # conv_post inside the stage's last launch: its output goes to fold[3]
+                pb.pair(blocks[0].convs1[-1], blocks[0].convs2[-1], curs[0], fold[3], LRELU_SLOPE, prec,
+                        add1=parts[0], add2=parts[1], out_div=float(nk), mid=scratch[0][0], fold=fold[:3])
+                return
             pb.pair(blocks[0].convs1[-1], blocks[0].convs2[-1], curs[0], x, LRELU_SLOPE, prec,
                     add1=parts[0], add2=parts[1], out_div=float(nk), mid=scratch[0][0])
             return
@@ -161,8 +165,19 @@ class _HiFiGANBase(NativeModule):
         pb.conv_sum3(convs, srcs, ress, parts[:2], x, pre_slope=LRELU_SLOPE, out_div=float(nk))
 
     # -- op emission ---------------------------------------------------------
-    def _emit_trunk(self, pb, dst, fused=None):
-        """mel (SLOT_IN) -> tanh(conv_post(...)) in ``dst``; ``fused``: per-stage flags (_fused_flags)."""
+    def _fold_post(self, fused):
+        """conv_post can run inside the last stage's last launch (PlanBuilder.pair_fold_supported): the classic trio
+        of 16-channel ResBlock1s as split-f16 fused pairs, one output channel."""
+        if not fused or not fused[-1] or self.num_kernels != 3:
+            return False
+        blocks = self.resblocks[-3:]
+        return PlanBuilder.pair_fold_supported(blocks[0].convs1[-1], self.conv_post,
+                                               PlanBuilder.pair_precision(blocks[0].channels))
+
+    def _emit_trunk(self, pb, dst, fused=None, fold_post=False):
+        """mel (SLOT_IN) -> tanh(conv_post(...)) in ``dst``; ``fused``: per-stage flags (_fused_flags); ``fold_post``:
+        conv_post inside the last pair's launch (not for the plans whose LAST op subtracts an output offset)."""
+        fold_post = fold_post and self._fold_post(fused)
         x, up = pb.tmp(), pb.tmp()
         nk = self.num_kernels
         # The nk ResBlocks of a stage are independent given the upsampled input, and at
@@ -186,6 +201,10 @@ class _HiFiGANBase(NativeModule):
                 pb.conv_transpose(self.ups[i], x, up, pre_slope=LRELU_SLOPE)
             blocks = [self.resblocks[i * nk + j] for j in range(nk)]
             if fused is not None and fused[i]:
+                if fold_post and i == self.num_upsamples - 1:
+                    self._emit_fused_stage(pb, blocks, up, x, scratch, parts,
+                                           fold=(self.conv_post, DEFAULT_LRELU_SLOPE, POST_TANH, dst))
+                    return
                 self._emit_fused_stage(pb, blocks, up, x, scratch, parts)
                 continue
             if nk <= 3 and mode != "chain":
@@ -243,7 +262,7 @@ class _HiFiGANBase(NativeModule):
     def _trunk_plan(self, T):
         fused = self._fused_flags(T)
         return self._plan("trunk" + PlanBuilder.pair_mode_tag() + "".join("f" if f else "-" for f in fused),
-                          lambda pb: self._emit_trunk(pb, SLOT_OUT, fused), 80)
+                          lambda pb: self._emit_trunk(pb, SLOT_OUT, fused, fold_post=True), 80)
 
     def _emit_inference(self, pb, fused):
         self._emit_trunk(pb, SLOT_OUT, fused)

@@ -370,6 +370,13 @@ int fv_plan_add_resblock_pair_ex(fv_plan_t* plan, int x_slot, int y_slot, int y_
                                  int add2_slot, const float* packed1, const float* packed2, const float* bias1,
                                  const float* bias2, int C, int k, int dil, float slope, float out_div, int post,
                                  float act_slope, int prec);
+/* The last pair of a HiFi-GAN with conv_post folded in (hifigan.py:97-106): applies to the op appended last, which must
+ * be an ungrouped 16-channel FV_PAIR_SPLIT_F16 pair (with or without add1 / add2).  The pair's own output x' is never
+ * stored; the op's output becomes
+ *     y[B, 1, T] = post( conv1d( lrelu( x' / out_div, act_slope ); w [1, 16, 7], zero padding 3 ) + bias ),
+ * computed on the activated tile in LDS (tiles overlap by the conv's 3-sample halo).  One launch and a [B,16,T]
+ * round trip less than the pair followed by fv_conv1d_fused. */
+int fv_plan_set_pair_output_conv(fv_plan_t* plan, const float* w, const float* bias, int y_slot, float act_slope, int post);
 /* fv_conv1d_split_f16 as a plan op; consecutive ops under one non-zero group id with equal C, dilation, padding
  * mode, slopes, out_div and post run as ONE launch */
 int fv_plan_add_conv1d_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, int res_slot, int add1_slot,

@@ -342,6 +342,37 @@ def test_block_schedule_gives_the_same_bits(monkeypatch):
         assert _rel(sched[0], ref) <= 4e-6
 
 
+@pytest.mark.parametrize("case", [(1, 1000, 3, 5, True), (2, 484, 3, 5, True), (1, 244, 11, 1, False), (3, 8, 7, 3, True),
+                                  (1, 2468, 3, 1, False)], ids=lambda c: "x".join(str(v) for v in c))
+def test_pair_with_folded_output_conv_vs_oracle(case):
+    """fv_plan_set_pair_output_conv (HiFi-GAN's last launch, hifigan.py:97-106): the carrier pair with the MRF merge,
+    lrelu(0.01), conv_post (16 -> 1, 7 taps) and tanh in ONE launch, against the oracle's pair + merge + conv1d."""
+    B, T, k, dil, merge = case
+    rng = np.random.RandomState(13 * T + k)
+    C = 16
+    x, w1, b1, w2, b2 = _member(rng, B, C, T, k, True)
+    r1, r2 = rng.randn(B, C, T).astype(np.float32), rng.randn(B, C, T).astype(np.float32)
+    wp = (rng.randn(1, C, 7) / np.sqrt(C * 7)).astype(np.float32)
+    bp = rng.randn(1).astype(np.float32)
+    pair = _pair_ref(x, w1, b1, w2, b2, dil, 0.1)
+    merged = ((pair + r1) + r2) / np.float32(3.0) if merge else pair
+    ref = np.tanh(oo.conv1d(merged, wp, bp, pad=3, pre_slope=0.01).astype(np.float64))
+    # x, r1, r2 enter the plan as ONE [B, 3C, T] input; 1-tap convs with selection weights (exact copies) slice it
+    X = _t(np.concatenate([x, r1, r2], axis=1))
+    sel = [torch.zeros((C, 3 * C, 1), device=_dev()) for _ in range(3)]
+    for j in range(3):
+        sel[j][:, j * C:(j + 1) * C, 0] = torch.eye(C, device=_dev())
+    plan3 = _native.Plan(3 * C)
+    for j in range(3):
+        plan3.add_conv1d(_native.SLOT_IN, 2 + j, _native.pack_conv1d(sel[j]), None, 3 * C, C, 1)
+    plan3.add_resblock_pair(2, 5, _native.pack_pair(_t(w1), SPLIT), _native.pack_pair(_t(w2), SPLIT), _t(b1), _t(b2), C, k, dil,
+                            0.1, prec=SPLIT, add1=3 if merge else _native.SLOT_NONE, add2=4 if merge else _native.SLOT_NONE,
+                            out_div=3.0 if merge else 1.0)
+    plan3.set_pair_output_conv(_t(wp.reshape(C, 7)), _t(bp), _native.SLOT_OUT, 0.01, _native.POST_TANH)
+    y = plan3.run(X)
+    assert tuple(y.shape) == (B, 1, T) and _rel(y, ref) <= 4e-6
+
+
 CONVT_CASES = [  # B, Cin, Cout, Tin, stride, pad, out_pad
     (1, 256, 128, 300, 8, 4, 0), (2, 128, 64, 257, 5, 3, 1), (1, 128, 32, 129, 2, 1, 0), (1, 512, 256, 40, 8, 4, 0),
     (3, 128, 64, 1, 10, 5, 0), (2, 256, 64, 127, 6, 3, 0), (1, 128, 64, 128, 3, 2, 1), (1, 256, 256, 200, 4, 2, 0),

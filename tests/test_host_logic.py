@@ -266,6 +266,18 @@ def test_plan_shape_inference_without_gpu():
     assert L.fv_plan_add_conv1d_split_f16(w, 0, 2, -1, -1, -1, -1, dummy, None, 64, 3, 1, _native.PAD_CAUSAL, 0.2, 1.0, 0, 1.0) != 0
     assert b"pad_mode" in L.fv_last_error()
     L.fv_plan_destroy(w)
+    # conv_post folded into the last pair: a 16-channel split-f16 pair only; the op's output becomes [B, 1, T]
+    f = L.fv_plan_create(16)
+    assert L.fv_plan_add_resblock_pair_ex(f, 0, 2, -1, -1, -1, -1, dummy, dummy, None, None, 16, 3, 5, 0.1, 1.0, 0, 1.0, S) == 0
+    assert L.fv_plan_set_pair_output_conv(f, dummy, None, 1, 0.01, 1) == 0
+    assert L.fv_plan_output_shape(f, 400, ctypes.byref(c), ctypes.byref(n)) == 0
+    assert (c.value, n.value) == (1, 400)
+    assert L.fv_plan_set_pair_output_conv(f, dummy, None, 1, 0.01, 1) != 0          # already folded
+    assert L.fv_plan_add_resblock_pair_ex(f, 0, 2, -1, -1, -1, -1, dummy, dummy, None, None, 16, 3, 5, 0.1, 1.0, 0, 1.0,
+                                          _native.PAIR_F32) == 0
+    assert L.fv_plan_set_pair_output_conv(f, dummy, None, 3, 0.01, 1) != 0          # fp32 pair
+    assert b"16-channel split-f16" in L.fv_last_error()
+    L.fv_plan_destroy(f)
     # transposed conv with split-f16 operands: kernel = 2 strides, 128+ input channels; same length law as the fp32 op
     t = L.fv_plan_create(128)
     assert L.fv_packed_conv_transpose1d_split_floats(128, 64, 10, 5) == 5 * 1 * 8 * 2048
