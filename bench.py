@@ -15,11 +15,13 @@ over RCCL once; every rank runs its own utterances (weak scaling: the path has n
 every step's waveforms are gathered to rank 0 INSIDE the timed region (asynchronously, overlapping the
 next step's forward); the same steps without the gather are timed too and reported beside it.
 
-``--config large512`` (BASELINE.json configs[4]): HiFi-GAN large, 512 utterances of 80 x 1000 per step --
-a fixed job (strong scaling): rank 0 holds the mels, scatters one block per rank, every rank synthesises
-its block and encodes it to int16 on the GPU (fv_encode_16bits), rank 0 gathers the int16 waveforms;
-scatter, forward, encode and gather are all inside the timed step, and rank 0 checks gathered rows
-against its own single-utterance runs bit for bit.
+The fixed job (BASELINE.json configs[4]): HiFi-GAN large, 512 utterances of 80 x 1000 per step -- strong
+scaling: rank 0 holds the mels, scatters one block per rank, every rank synthesises its block and encodes it
+to int16 on the GPU (fv_encode_16bits), rank 0 gathers the int16 waveforms; scatter, forward, encode and
+gather are all inside the timed step (the same step without scatter / gather is timed beside it), and rank 0
+checks gathered rows against its own single-utterance runs bit for bit.  ``--config large512`` makes it the
+headline of the line; the default run appends it as ``strong_scaling_job`` (one timed step; ``--no-job``
+skips it), so that one invocation per GPU count gives both scaling curves.
 
 Prints ONE JSON line: value = whole-job audio samples / second, plus RTF at 22.05 kHz and 24 kHz, the
 roofline of the dominant kernel family (fp32-MFMA convs, per-launch HIP events on the launch stream),
@@ -47,8 +49,9 @@ CONFS = {"light": "conf/hifigan/light.yaml", "large512": "conf/hifigan/large.yam
 T_FRAMES = 1000
 JOB_UTTERANCES = int(os.environ.get("FV_BENCH_JOB", "512"))   # --config large512 (the env override is for tests)
 # the arithmetic the path computes in: fp32 tensors, fp32 accumulation; on the ResBlock stages every fp32 product is
-# formed from split-f16 operand pairs on the f16 matrix cores (fp32-class accuracy)
-DTYPE = "f32" if os.environ.get("FV_PAIR_PREC", "split") == "f32" else "f32 (products as split-f16 pairs, fp32 accumulate)"
+# formed from split-f16 operand pairs on the f16 matrix cores (fp32-class accuracy); the
+# exact-fp32 figure of the same forward rides in the line as `exact_fp32`
+DTYPE = "f32 (products as split-f16 pairs, fp32 accumulate)"
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
 PEAK_F16_MFMA_TFLOPS = 2500.0   # dense f16 matrix peak (same guide; the sparse headline figure is twice that)
 PEAK_HBM_GBS = 8000.0
@@ -159,7 +162,6 @@ def roofline_report(model, mel, ms_per_step, reps=5):
     same forward): one event after every launch, a launch's duration = end of its predecessor to its own end (what
     rocprofv3 reports as a dispatch's duration; the durations add up to the step), cost of the event record calibrated
     out.  `roofline` is about the family that takes most of the step."""
-    os.environ["FV_SINGLE_LANE"] = "1"
     for _ in range(2):
         with torch.no_grad():
             model(mel)
@@ -171,7 +173,6 @@ def roofline_report(model, mel, ms_per_step, reps=5):
             model(mel)
     torch.cuda.synchronize()
     _native.profile_enable(False)
-    del os.environ["FV_SINGLE_LANE"]
     kinds = {"conv32": _native.KERNEL_CONV_MFMA32, "conv16": _native.KERNEL_CONV_MFMA16,
              "pair16": _native.KERNEL_PAIR16, "pair32": _native.KERNEL_PAIR32,
              "pairh16": _native.KERNEL_PAIRH16, "pairh32": _native.KERNEL_PAIRH32,
@@ -198,9 +199,11 @@ def roofline_report(model, mel, ms_per_step, reps=5):
     ups = fam("convt")                                       # split-f16 transposed convs (convt_kernel)
     all_ms = (fp32["ms"] + wide["ms"] + pairs["ms"] + ups["ms"] + rec["narrow"]["ms"]) / reps
     all_flops = fp32["flops"] + wide["flops"] + pairs["flops"] + ups["flops"]
-    # Sum of kernel time must fit inside the step; if the calibration ever fails that test, fall back to
-    # the whole-step figure (launch gaps included: a lower bound of the kernels' rate)
-    consistent = all_ms <= ms_per_step * 1.05      # (completion-to-completion durations add up to the step)
+    # The event cost is calibrated so that the durations add up to the timed step (they are completion-to-completion
+    # on one stream: apart from the event records there is nothing else in the replay) -- so this test can only fail
+    # when the calibration was clamped (event cost > the null-kernel figure); the independent check of the per-launch
+    # figures is the committed rocprofv3 kernel trace of the same command (profiles/, avg_launch_us vs its AverageNs).
+    consistent = all_ms <= ms_per_step * 1.05
     note = "" if consistent else "; INCONSISTENT with the step time -> whole-step figure used"
 
     def rate(f):
@@ -222,7 +225,8 @@ def roofline_report(model, mel, ms_per_step, reps=5):
                 "launch before it to its own end (dispatch latency included, as in rocprofv3's dispatch durations); "
                 "single-stream replay of the same forward, "
                 f"cost of the event record subtracted ({event_ms * 1e3:.2f} us per launch: the replay with events against "
-                f"the timed step without; {bracket_ms * 1e3:.2f} us between two null kernels)" + note)
+                f"the timed step without -- i.e. the durations add up to the step BY CONSTRUCTION; the independent check is "
+                f"the rocprofv3 kernel trace under profiles/; {bracket_ms * 1e3:.2f} us between two null kernels)" + note)
     if wide["ms"] >= fp32["ms"]:
         dom, peak = wide, PEAK_F16_MFMA_TFLOPS / 3.0
         roofline = {
@@ -307,17 +311,89 @@ def roofline_report(model, mel, ms_per_step, reps=5):
                      else "2 fused-pair launches + the fused MRF stage end (fv::pair_kernel, fv::pair_sum_kernel)"
                      if rec["pair16"]["launches"] else "16x16x4-MFMA conv launches"),
         "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
-        "achieved": survey / (st_ms * 1e-3) / 1e9 if st_ms > 0 else 0.0,
-        "frac": survey / (st_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if st_ms > 0 else 0.0,
-        "bytes": survey, "bytes_rule": "SURVEY.md section 8(d): every conv's input and output once + the residual "
-                                       "read + weights, layer by layer (unfused accounting)",
-        "fused_external_bytes": stage["bytes"] / reps,
-        "fused_external_gbs": stage["bytes"] / reps / (st_ms * 1e-3) / 1e9 if st_ms > 0 else 0.0,
+        "achieved": stage["bytes"] / reps / (st_ms * 1e-3) / 1e9 if st_ms > 0 else 0.0,
+        "frac": stage["bytes"] / reps / (st_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if st_ms > 0 else 0.0,
+        "bytes": stage["bytes"] / reps,
+        "bytes_rule": "SURVEY.md section 8(d): a fused kernel is charged only its EXTERNAL tensors -- per fused-pair "
+                      "launch each member's input, output (+ twin), the MRF addends and the weights, once",
+        "effective": {"what": "the same time against the layer-by-layer (unfused) bytes of SURVEY 8(d): every conv's "
+                              "input and output once + the residual read + weights -- what an unfused implementation "
+                              "at this speed would have to move",
+                      "bytes": survey,
+                      "gbs": survey / (st_ms * 1e-3) / 1e9 if st_ms > 0 else 0.0,
+                      "frac": survey / (st_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if st_ms > 0 else 0.0},
         "ms": st_ms, "launches_per_step": stage["launches"] // reps,
         "tflops": stage["flops"] / (stage["ms"] * 1e-3) / 1e12 if stage["ms"] > 0 else 0.0,
         "measured": "per-launch HIP events, completion to completion (event cost subtracted); HBM traffic by PMC: profiles/",
     }
     return roofline, hbm
+
+
+def build_model(config, dev, dist, rank, precision="split"):
+    """conf yaml -> generator on `dev` with the seeded weights (built on rank 0, broadcast over RCCL at N > 1), weight
+    norm removed; returns (model, cfg, state dict on rank 0)."""
+    from fastvocoder_amd import parallel
+    cfg = load_conf(config)
+    model = build_generator(MODEL, cfg)
+    model.precision = precision
+    sd = seeded_state_dict(MODEL, cfg, seed=0) if rank == 0 else None
+    if rank == 0:
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev).eval()
+    if dist is not None:
+        parallel.broadcast_weights(model, src=0)          # RCCL broadcast, once
+    model.remove_weight_norm()
+    return model, cfg, sd
+
+
+def run_job(args, dev, dist, world, rank, steps, warmup):
+    """BASELINE.json configs[4]: HiFi-GAN large, JOB_UTTERANCES utterances of 80 x 1000 per step, sharded over the
+    ranks (strong scaling).  Returns (elapsed seconds, steps, samples per utterance, utterances, extras)."""
+    from fastvocoder_amd import audio, parallel
+    model, _, _ = build_model("large512", dev, dist, rank)
+    total_utt = JOB_UTTERANCES
+    mels = torch.from_numpy(utterance_mels(0, total_utt)).to(dev) if rank == 0 else None
+
+    def rank_block(block):
+        outs = []
+        with torch.no_grad():
+            for a in range(0, block.shape[0], args.sub):
+                w = model(block[a:a + args.sub].contiguous())
+                outs.append(audio.encode_16bits(w, 1.0))      # per-row peak normalise -> int16, on the GPU
+        return torch.cat(outs, dim=0)
+
+    def step():
+        if dist is None:
+            return rank_block(mels)
+        return parallel.synthesize_sharded(rank_block, mels, world, rank, scatter=True, device=dev)
+
+    rank_block(torch.from_numpy(utterance_mels(0, min(args.sub, 2))).to(dev))   # plan build, not a step
+    torch.cuda.synchronize()
+    elapsed, pcm = timed_steps(step, steps, warmup, dist, dev)
+    extra = {}
+    if dist is not None:
+        # the same job with every rank's block already on its GPU and left there: no scatter, no gather
+        lo, hi = parallel.shard_range(total_utt, world, rank)
+        own = torch.from_numpy(utterance_mels(lo, hi - lo)).to(dev) if hi > lo else None
+        e2, _ = timed_steps((lambda: rank_block(own) if own is not None else None), steps, warmup, dist, dev)
+        extra["without_gather"] = {"ms_per_step": 1e3 * e2 / steps,
+                                   "what": "the same job with every rank's mels resident and its int16 waveforms left "
+                                           "on the rank: forward + wav sink only, no scatter, no gather"}
+    if rank == 0:
+        assert pcm.dtype == torch.int16 and pcm.shape[0] == total_utt
+        # gathered rows == this rank's own single-utterance runs of the same mels, bit for bit
+        per = (total_utt + world - 1) // world
+        for idx in sorted({0, 1, per - 1, per % total_utt, total_utt - 1}):
+            one = rank_block(mels[idx:idx + 1])
+            assert torch.equal(one[0], pcm[idx]), f"utterance {idx} differs between the sharded job and a solo run"
+        assert not model.check_range()
+    samples_per_utt = int(pcm.shape[-1]) if rank == 0 else 240 * T_FRAMES
+    workload = (f"HiFi-GAN large (conf/hifigan/large.yaml), {total_utt} utterances of mel 80x{T_FRAMES} per step "
+                f"sharded over {world} GPU(s): scatter of mels from rank 0, forward in sub-batches of {args.sub}, "
+                "int16 wav sink on the GPU, gather to rank 0 -- all inside the timed step; BASELINE.json configs[4]")
+    del model
+    torch.cuda.empty_cache()
+    return elapsed, samples_per_utt, total_utt, workload, extra
 
 
 def main():
@@ -331,6 +407,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true",
                     help="light, N > 1: leave the waveforms on the ranks that made them (headline without the gather)")
+    ap.add_argument("--no-job", action="store_true", help="light: skip the appended strong-scaling job (configs[4])")
+    ap.add_argument("--no-exact", action="store_true", help="light: skip the exact-fp32 leg")
     args = ap.parse_args()
     steps = args.steps if args.steps is not None else (50 if args.config == "light" else 2)
     warmup = args.warmup if args.warmup is not None else (5 if args.config == "light" else 1)
@@ -344,38 +422,38 @@ def main():
         sys.exit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
                  "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    # FV_BENCH_ONE_GPU=1 (tests): every rank on device 0 -- world_size > 1 through the real generator on a 1-GPU box
+    if os.environ.get("FV_BENCH_ONE_GPU", "0") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    # FV_BENCH_FORCE_DIST=1: take the N > 1 code path (RCCL init, broadcast, scatter, gather, barrier,
+    # FV_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, broadcast, scatter, gather, barrier,
     # all-reduce) with a single rank too -- a self-test of that path on a 1-GPU box
     force_dist = os.environ.get("FV_BENCH_FORCE_DIST", "0") == "1"
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL needs one GPU per rank; ranks that share a device (FV_BENCH_ONE_GPU) meet over gloo, which moves
+        # device tensors through the host
+        backend = os.environ.get("FV_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
-    cfg = load_conf(args.config)
     from fastvocoder_amd import parallel
-    model = build_generator(MODEL, cfg)
-    sd = seeded_state_dict(MODEL, cfg, seed=0) if rank == 0 else None
-    if rank == 0:
-        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    model = model.to(dev).eval()
-    if dist is not None:
-        parallel.broadcast_weights(model, src=0)          # RCCL broadcast, once
-    model.remove_weight_norm()
-
     extra = {}
     if args.config == "light":
+        model, cfg, sd = build_model("light", dev, dist, rank)
         B = args.batch
         mel = torch.from_numpy(utterance_mels(rank * B, B)).to(dev)
         gather = parallel.WaveformGather(world, rank, dev) if dist is not None else None
 
-        def make_step(with_gather):
+        def make_step(net, with_gather):
             def step():
                 with torch.no_grad():
-                    wav = model(mel)
+                    wav = net(mel)
                 if with_gather:
                     gather(wav)           # asynchronous: overlaps the next step's forward
                 return wav
@@ -391,14 +469,17 @@ def main():
             model(mel)
         torch.cuda.synchronize()
         use_gather = gather is not None and not args.no_gather
-        step, done = make_step(use_gather)
+        step, done = make_step(model, use_gather)
         elapsed, wav = timed_steps(step, steps, warmup, dist, dev, after=done)
+        # the timed forwards ran stream-ordered (range_guard "auto": forward's check is deferred): the check, now
+        guard_clean = not model.check_range()
+        assert guard_clean, "a timed forward left the split-f16 range: its output is not the reference's"
         if use_gather:
             bufs = gather.flush()
             if rank == 0:          # rank 0 holds every rank's last waveforms, its own block bit for bit
                 assert len(bufs) == world and all(tuple(b.shape) == tuple(wav.shape) for b in bufs)
-                assert torch.equal(bufs[0], wav)
-            step2, done2 = make_step(False)
+                assert torch.equal(bufs[0].to(wav.device), wav)
+            step2, done2 = make_step(model, False)
             e2, _ = timed_steps(step2, steps, warmup, dist, dev, after=done2)
             extra["without_gather"] = {"ms_per_step": 1e3 * e2 / steps,
                                        "what": "the same steps with the waveforms left on the ranks that made them"}
@@ -410,40 +491,8 @@ def main():
                     + ("; waveforms gathered to rank 0 inside the timed steps" if use_gather else ""))
         scaling = "weak"
     else:
-        # ---- the fixed 512-utterance job, BASELINE.json configs[4] ----
-        total_utt = JOB_UTTERANCES
-        mels = torch.from_numpy(utterance_mels(0, total_utt)).to(dev) if rank == 0 else None
-        from fastvocoder_amd import audio
-
-        def rank_block(block):
-            outs = []
-            with torch.no_grad():
-                for a in range(0, block.shape[0], args.sub):
-                    w = model(block[a:a + args.sub].contiguous())
-                    outs.append(audio.encode_16bits(w, 1.0))      # per-row peak normalise -> int16, on the GPU
-            return torch.cat(outs, dim=0)
-
-        def step():
-            if dist is None:
-                return rank_block(mels)
-            return parallel.synthesize_sharded(rank_block, mels, world, rank, scatter=True, device=dev)
-
-        rank_block(torch.from_numpy(utterance_mels(0, min(args.sub, 2))).to(dev))   # plan build, not a step
-        torch.cuda.synchronize()
-        elapsed, pcm = timed_steps(step, steps, warmup, dist, dev)
+        elapsed, samples_per_utt, utt_per_step, workload, extra = run_job(args, dev, dist, world, rank, steps, warmup)
         golden_err = None
-        if rank == 0:
-            assert pcm.dtype == torch.int16 and pcm.shape[0] == total_utt
-            # gathered rows == this rank's own single-utterance runs of the same mels, bit for bit
-            per = (total_utt + world - 1) // world
-            for idx in sorted({0, 1, per - 1, per % total_utt, total_utt - 1}):
-                one = rank_block(mels[idx:idx + 1])
-                assert torch.equal(one[0], pcm[idx]), f"utterance {idx} differs between the sharded job and a solo run"
-        samples_per_utt = int(pcm.shape[-1]) if rank == 0 else 240 * T_FRAMES
-        utt_per_step = total_utt
-        workload = (f"HiFi-GAN large (conf/hifigan/large.yaml), {total_utt} utterances of mel 80x{T_FRAMES} per step "
-                    f"sharded over {world} GPU(s): scatter of mels from rank 0, forward in sub-batches of {args.sub}, "
-                    "int16 wav sink on the GPU, gather to rank 0 -- all inside the timed step; BASELINE.json configs[4]")
         scaling = "strong"
         mel = None
 
@@ -451,6 +500,7 @@ def main():
     value = total_samples / elapsed
     ms_per_step = 1e3 * elapsed / steps
 
+    out = None
     if rank == 0:
         dur22, dur24 = total_samples / 22050.0, total_samples / 24000.0
         out = {
@@ -467,12 +517,34 @@ def main():
                              "what": "last timed output, utterance 0, vs tests/golden/full_hifigan_light.npz "
                                      "(the reference's own output for this mel and these weights)"}
         out.update(extra)
+    if args.config == "light":
+        # ---- exact fp32: the same forward with every product on the fp32 matrix cores (precision = "f32") ----------
+        if not args.no_exact:
+            exact, _, _ = build_model("light", dev, dist, rank, precision="f32")
+            with torch.no_grad():
+                exact(mel)
+            torch.cuda.synchronize()
+            stepx, donex = make_step(exact, False)
+            ex, wavx = timed_steps(stepx, steps, warmup, dist, dev, after=donex)
+            if rank == 0:
+                flop = 124.9408e9 * B      # algorithmic conv FLOP of one light forward at T = 1000
+                out["exact_fp32"] = {
+                    "ms_per_step": 1e3 * ex / steps, "value": samples_per_utt * utt_per_step * steps / ex,
+                    "unit": "samples/s", "rtf_22k05": ex / (samples_per_utt * utt_per_step * steps / 22050.0),
+                    "frac_of_fp32_mfma_peak": flop / (ex / steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                    "max_abs_vs_reference_golden": check_against_golden(wavx[0]),
+                    "max_abs_vs_split_f16": float((wavx[0] - wav[0]).abs().max()),
+                    "what": "the same model, steps and timing with precision = 'f32': v_mfma_f32_32x32x2_f32 / 16x16x4_f32 "
+                            "everywhere (exact fp32 products, bit for bit an fmaf chain); without gather"}
+            del exact
+            torch.cuda.empty_cache()
+    if rank == 0:
         if args.config == "light":
             out["config"]["plan_ops_per_forward"] = model._trunk_plan(T_FRAMES).num_ops()
             roofline, hbm = roofline_report(model, mel, ms_per_step)
             out["roofline"] = roofline
             out["roofline_hbm_stage"] = hbm
-            # host time to enqueue one forward (plan replay: ~28 launches), no synchronisation inside
+            # host time to enqueue one forward (plan replay: ~24 launches), no synchronisation inside
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(10):
@@ -481,9 +553,18 @@ def main():
             enq = (time.perf_counter() - t0) / 10
             torch.cuda.synchronize()
             out["host_enqueue_ms_per_forward"] = 1e3 * enq
+            # the range guard (engine.NativeModule.range_guard): forward checks lazily under the default policy; the
+            # same steps with a synchronous check per call (what `inference` does) beside them
+            model.range_guard = "sync"
+            stepg, doneg = make_step(model, False)
+            eg, _ = timed_steps(stepg, min(steps, 20), 2, None, dev, after=doneg)
+            model.range_guard = "auto"
+            out["range_guard"] = {"policy": "auto: forward checks at the next call / check_range(), inference before it "
+                                            "returns", "timed_steps_clean": guard_clean,
+                                  "ms_per_step_sync_checked": 1e3 * eg / min(steps, 20)}
             # PCIe-inclusive rate of the drop-in boundary (never `value`): Generator.inference takes a
             # HOST mel [T,80] and the caller wants a HOST waveform -- pageable numpy in, numpy out,
-            # one utterance per call, fully synchronous (H2D + forward + D2H per call)
+            # one utterance per call, fully synchronous (H2D + forward + range check + D2H per call)
             if world == 1:
                 mel_np = seeded_mel(T_FRAMES, seed=1)
                 for _ in range(3):
@@ -496,10 +577,22 @@ def main():
                 dt = (time.perf_counter() - t0) / reps_io
                 out["host_to_host"] = {"ms_per_utterance": 1e3 * dt, "samples_per_s": y_host.size / dt,
                                        "what": "Generator.inference(numpy mel) -> numpy waveform, per call: "
-                                               "H2D 320 KB + forward + D2H 960 KB, pageable memory, synchronous"}
+                                               "H2D 320 KB + forward + range check + D2H 960 KB, pageable memory, "
+                                               "synchronous"}
             if not args.no_cpu_baseline and world == 1:
                 out["cpu_baseline"] = cpu_baseline(cfg, sd, seeded_mel(T_FRAMES, seed=1))
                 out["cpu_baseline"]["rtf_22k05"] = out["cpu_baseline"]["seconds"] / (samples_per_utt / 22050.0)
+    if args.config == "light" and not args.no_job:
+        # ---- the strong-scaling job, appended: one timed step (all ranks take part) --------------------------------
+        del model
+        torch.cuda.empty_cache()
+        ej, spu, utt, wl, xj = run_job(args, dev, dist, world, rank, 1, 1)
+        if rank == 0:
+            tot = spu * utt
+            out["strong_scaling_job"] = dict({"value": tot / ej, "unit": "samples/s", "ms_per_step": 1e3 * ej, "steps": 1,
+                                              "warmup": 1, "scaling": "strong", "n_gpus": world,
+                                              "rtf_22k05": ej / (tot / 22050.0), "workload": wl}, **xj)
+    if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

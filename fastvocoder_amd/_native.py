@@ -28,12 +28,22 @@ PAD_CAUSAL = 2      # flag: pad (k-1)*dil on both sides, keep the first Tin outp
 POST_NONE, POST_TANH, POST_RELU = 0, 1, 2
 SLOT_NONE, SLOT_IN, SLOT_OUT, SLOT_TMP0, MAX_SLOTS = -1, 0, 1, 2, 32
 SLOT_AUX_IN0, SLOT_AUX_IN1, SLOT_OUT2 = 28, 29, 30    # caller-provided tensors of Plan.run(aux=..., out2=...)
-ABI_VERSION = 8
+ABI_VERSION = 9
 PAIR_F32, PAIR_SPLIT_F16 = 0, 1   # arithmetic of the fused ResBlock-pair kernels (fastvocoder_hip.h)
+
+
+ERR_RANGE = -4                    # fv_plan_check_range: a split-f16 kernel met an operand beyond the f16 range
 
 
 class NativeError(RuntimeError):
     pass
+
+
+class RangeError(NativeError):
+    """A weight or an activation lies outside the domain of the split-f16 kernels (|v| < 65520, the f16 range;
+    include/fastvocoder_hip.h FV_PAIR_SPLIT_F16): the computation has to be repeated with PAIR_F32 arithmetic.
+    engine.NativeModule does that by itself; the exception reaches a caller only from the single-operator
+    functions of this module."""
 
 
 def source_hash():
@@ -130,8 +140,8 @@ def lib():
     L.fv_conv_transpose1d_fused.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, i, f, vp]
     L.fv_packed_conv_transpose1d_split_floats.argtypes = [i, i, i, i]
     L.fv_packed_conv_transpose1d_split_floats.restype = i64
-    L.fv_pack_conv_transpose1d_split_f16.argtypes = [vp, vp, i, i, i, i, vp]
-    L.fv_conv_transpose1d_split_f16.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, f, vp]
+    L.fv_pack_conv_transpose1d_split_f16.argtypes = [vp, vp, i, i, i, i, vp, vp]
+    L.fv_conv_transpose1d_split_f16.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, f, vp, vp]
     L.fv_plan_add_conv_transpose1d_split_f16.argtypes = [vp, i, i, i, vp, vp, i, i, i, i, i, i, f, f]
     L.fv_pqmf_synthesis.argtypes = [vp, vp, vp, i, i, i, i, vp]
     L.fv_conv1d_2src_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, f, vp]
@@ -157,11 +167,11 @@ def lib():
     L.fv_plan_add_resblock_pair.argtypes = [vp, i, i, i, vp, vp, vp, vp, i, i, i, f, f]
     L.fv_packed_pair_floats_ex.argtypes = [i, i, i]
     L.fv_packed_pair_floats_ex.restype = i64
-    L.fv_pack_pair_weight_ex.argtypes = [vp, vp, i, i, i, vp]
+    L.fv_pack_pair_weight_ex.argtypes = [vp, vp, i, i, i, vp, vp]
     L.fv_resblock1_fused_ex.argtypes = [i, pp, pp, pp, pp, pp, pp, pp, pp, pp, pp, ctypes.POINTER(i), i, i, i, i, f, f,
-                                        i, f, i, vp]
+                                        i, f, i, vp, vp]
     L.fv_plan_add_resblock_pair_ex.argtypes = [vp, i, i, i, i, i, i, vp, vp, vp, vp, i, i, i, f, f, i, f, i]
-    L.fv_conv1d_split_f16.argtypes = [i, pp, pp, pp, pp, pp, pp, pp, pp, ctypes.POINTER(i), i, i, i, i, i, f, f, i, f, vp]
+    L.fv_conv1d_split_f16.argtypes = [i, pp, pp, pp, pp, pp, pp, pp, pp, ctypes.POINTER(i), i, i, i, i, i, f, f, i, f, vp, vp]
     L.fv_plan_set_pair_output_conv.argtypes = [vp, vp, vp, i, f, i]
     L.fv_plan_add_conv1d_split_f16.argtypes = [vp, i, i, i, i, i, i, vp, vp, i, i, i, i, f, f, i, f]
     L.fv_plan_add_mrf_sum.argtypes = [vp, ctypes.POINTER(i), i, i, pp, pp, pp, pp, i, ctypes.POINTER(i), i, f, f, i, f]
@@ -172,7 +182,9 @@ def lib():
     L.fv_plan_add_conv1d.argtypes = [vp, i, i, i, i, i, i, vp, vp, i, i, i, i, i, i, f, f, i, f]
     L.fv_plan_add_conv_transpose1d.argtypes = [vp, i, i, i, vp, vp, i, i, i, i, i, i, f, i, f]
     L.fv_plan_add_pqmf_synthesis.argtypes = [vp, i, i, vp, i, i]
-    L.fv_plan_set_lane.argtypes = [vp, i]
+    L.fv_plan_set_guard.argtypes = [vp, vp]
+    L.fv_plan_check_range.argtypes = [vp, vp]
+    L.fv_tuning_set.argtypes = [ctypes.c_char_p, i]
     L.fv_plan_set_group.argtypes = [vp, i]
     L.fv_plan_output_shape.argtypes = [vp, i, ctypes.POINTER(i), ctypes.POINTER(i64)]
     L.fv_plan_workspace_bytes.argtypes = [vp, i, i]
@@ -234,6 +246,49 @@ class _on:
         return self._guard.__exit__(*exc)
 
 
+class GuardWord:
+    """Two int32 words in pinned, device-mapped host memory: [0] raised by the split-f16 kernels of a run when an
+    activation left the f16 range (fv_plan_set_guard), [1] by the pack kernels when a weight does.  The kernels write
+    them through the host pointer; the host reads them after the stream has drained (or, lazily, whenever)."""
+
+    def __init__(self):
+        self.t = torch.zeros(2, dtype=torch.int32).pin_memory()
+
+    def ptr(self, i=0):
+        return self.t.data_ptr() + 4 * i
+
+    def peek(self, i=0):
+        """The word as it is now (no synchronisation)."""
+        return int(self.t[i])
+
+    def clear(self, i=0):
+        self.t[i] = 0
+
+
+def tuning_set(key, value):
+    """Test / tuning hook (fv_tuning_set): one of the launchers' switches, process-wide."""
+    check(lib().fv_tuning_set(key.encode(), int(value)))
+
+
+def _flag_ptr(flag):
+    """Address of a range-flag word: None, a GuardWord (weights: word 1), an int address or an int32 tensor."""
+    if flag is None:
+        return None
+    if isinstance(flag, GuardWord):
+        return flag.ptr(1)
+    if isinstance(flag, int):
+        return flag
+    return flag.data_ptr()
+
+
+def _guard_ptr(guard):
+    if guard is None:
+        return None
+    if isinstance(guard, GuardWord):
+        return guard.ptr(0)
+    return guard.data_ptr()
+
+
 # ---------------------------------------------------------------------------
 # weight preparation
 # ---------------------------------------------------------------------------
@@ -275,8 +330,9 @@ def conv_transpose_split_supported(cin, cout, k, stride, pad, out_pad):
             and 0 <= pad <= stride and -stride <= out_pad < stride)
 
 
-def pack_conv_transpose1d_split(w, stride):
-    """ConvTranspose1d weight [Cin,Cout,2*stride] -> split-f16 stage image of convt_kernel (flat fp32-typed tensor)."""
+def pack_conv_transpose1d_split(w, stride, flag=None):
+    """ConvTranspose1d weight [Cin,Cout,2*stride] -> split-f16 stage image of convt_kernel (flat fp32-typed tensor).
+    ``flag`` (GuardWord / int32 tensor): raised by the kernel when a weight is outside the f16 range."""
     w = w.detach().contiguous().float()
     cin, cout, k = w.shape
     n = lib().fv_packed_conv_transpose1d_split_floats(cin, cout, k, stride)
@@ -284,7 +340,8 @@ def pack_conv_transpose1d_split(w, stride):
         raise NativeError(f"pack_conv_transpose1d_split: Cin={cin} Cout={cout} k={k} stride={stride} is not built")
     out = torch.empty(n, dtype=torch.float32, device=w.device)
     with _on(w) as stream:
-        check(lib().fv_pack_conv_transpose1d_split_f16(_ptr(w, "w"), _ptr(out), cin, cout, k, stride, stream))
+        check(lib().fv_pack_conv_transpose1d_split_f16(_ptr(w, "w"), _ptr(out), cin, cout, k, stride, _flag_ptr(flag),
+                                                       stream))
     return out
 
 
@@ -316,9 +373,10 @@ def pack_upsample_conv1d(w, rate, pad):
     return out
 
 
-def pack_pair(w, prec=PAIR_F32):
+def pack_pair(w, prec=PAIR_F32, flag=None):
     """ResBlock Conv1d weight [C,C,k] -> A-operand image of the fused pair kernels (flat tensor); ``prec``
-    selects the fp32 (pair_kernels.hpp) or the split-f16 layout (pairh_kernels.hpp)."""
+    selects the fp32 (pair_kernels.hpp) or the split-f16 layout (pairh_kernels.hpp).  ``flag`` (GuardWord / int32
+    tensor, split-f16 only): raised by the kernel when a weight is outside the f16 range."""
     w = w.detach().contiguous().float()
     c, c2, k = w.shape
     if c != c2:
@@ -328,7 +386,7 @@ def pack_pair(w, prec=PAIR_F32):
         raise NativeError(f"pack_pair: no packed layout for C={c} k={k} arithmetic {prec}")
     out = torch.empty(n, dtype=torch.float32, device=w.device)
     with _on(w) as stream:
-        check(lib().fv_pack_pair_weight_ex(_ptr(w, "w"), _ptr(out), c, k, prec, stream))
+        check(lib().fv_pack_pair_weight_ex(_ptr(w, "w"), _ptr(out), c, k, prec, _flag_ptr(flag), stream))
     return out
 
 
@@ -352,7 +410,7 @@ def _vp_array(tensors, name, allow_none=False):
 # ---------------------------------------------------------------------------
 
 def resblock1_fused(xs, w1s, w2s, b1s, b2s, ks, dil, slope, act_slope=1.0, outs=None, outs_act=None,
-                    prec=PAIR_F32, add1=None, add2=None, out_div=1.0, post=POST_NONE, mids=None):
+                    prec=PAIR_F32, add1=None, add2=None, out_div=1.0, post=POST_NONE, mids=None, guard=None):
     """n = len(xs) independent fused ResBlock pairs in one launch (fv_resblock1_fused_ex):
     y_j = x_j + conv2_j(lrelu(conv1_j(lrelu(x_j)) + b1_j)) + b2_j; w1s / w2s from pack_pair(w, prec).
     With add1 / add2 (split-f16 arithmetic): y_j = post(((y_j + add1_j) + add2_j) / out_div)."""
@@ -372,12 +430,12 @@ def resblock1_fused(xs, w1s, w2s, b1s, b2s, ks, dil, slope, act_slope=1.0, outs=
                                           _vp_array(mids, "mid", True),
                                           _vp_array(a1, "add1", True), _vp_array(a2, "add2", True),
                                           (ctypes.c_int * n)(*ks), B, C, T, dil, float(slope), float(out_div), post,
-                                          float(act_slope), prec, stream))
+                                          float(act_slope), prec, _guard_ptr(guard), stream))
     return outs
 
 
 def conv1d_split_f16(xs, packed, biases, ks, dil, pre_slope=1.0, res=None, add1=None, add2=None, out_div=1.0,
-                     post=POST_NONE, act_slope=1.0, outs=None, outs_act=None, pad_mode=PAD_ZERO):
+                     post=POST_NONE, act_slope=1.0, outs=None, outs_act=None, pad_mode=PAD_ZERO, guard=None):
     """n = len(xs) independent 'same' convs with split-f16 operands in one launch (fv_conv1d_split_f16), C = 64 ... 512:
     y_j = post((conv(pad(lrelu(x_j, pre_slope))) + bias_j + res_j + add1_j + add2_j) / out_div), zero or reflection
     padding; packed from pack_pair(w, PAIR_SPLIT_F16)."""
@@ -393,7 +451,8 @@ def conv1d_split_f16(xs, packed, biases, ks, dil, pre_slope=1.0, res=None, add1=
                                         _vp_array(biases, "bias", True), _vp_array(rs, "res", True),
                                         _vp_array(a1, "add1", True), _vp_array(a2, "add2", True), _vp_array(outs, "y"),
                                         _vp_array(acts, "y_act", True), (ctypes.c_int * n)(*ks), B, C, T, dil,
-                                        pad_mode, float(pre_slope), float(out_div), post, float(act_slope), stream))
+                                        pad_mode, float(pre_slope), float(out_div), post, float(act_slope),
+                                        _guard_ptr(guard), stream))
     return outs
 
 
@@ -459,7 +518,7 @@ def conv_transpose1d_fused(x, packed, bias, cout, k, stride, pad, out_pad, pre_s
 
 
 def conv_transpose1d_split_f16(x, packed, bias, cout, k, stride, pad, out_pad, pre_slope=1.0, out=None, out_act=None,
-                               act_slope=1.0):
+                               act_slope=1.0, guard=None):
     """ConvTranspose1d (kernel = 2 stride) with split-f16 operands (fv_conv_transpose1d_split_f16)."""
     B, cin, T = x.shape
     tout = (T - 1) * stride - 2 * pad + k + out_pad
@@ -468,7 +527,8 @@ def conv_transpose1d_split_f16(x, packed, bias, cout, k, stride, pad, out_pad, p
     with _on(x, packed, bias, out, out_act) as stream:
         check(lib().fv_conv_transpose1d_split_f16(_ptr(x, "x"), _ptr(packed, "packed"), _ptr(bias, "bias", True),
                                                   _ptr(out, "out"), _ptr(out_act, "out_act", True), B, cin, cout, T, k,
-                                                  stride, pad, out_pad, float(pre_slope), float(act_slope), stream))
+                                                  stride, pad, out_pad, float(pre_slope), float(act_slope),
+                                                  _guard_ptr(guard), stream))
     return out
 
 
@@ -535,6 +595,9 @@ class Plan:
         self._keep = []        # packed weights / biases the native plan references
         self._ws = None
         self._ws_key = None
+        self._guard = None     # GuardWord of the owning module (set_guard)
+        self._dev = None       # device of the last run
+        self.guarded = False   # the plan holds split-f16 launches (PlanBuilder.finalize)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -658,8 +721,21 @@ class Plan:
     def set_sum_order(self, own_first):
         check(lib().fv_plan_set_sum_order(self._h, 1 if own_first else 0))
 
-    def set_lane(self, lane):
-        check(lib().fv_plan_set_lane(self._h, lane))
+    def set_guard(self, guard):
+        """Range guard of the plan's split-f16 launches (fv_plan_set_guard): a GuardWord, or None."""
+        self._guard = self.keep(guard) if guard is not None else None
+        check(lib().fv_plan_set_guard(self._h, guard.ptr(0) if guard is not None else None))
+
+    def check_range(self):
+        """Drain the current stream, then: did a split-f16 kernel of the runs since the last check meet an operand
+        beyond the f16 range?  (fv_plan_check_range; clears the word.)"""
+        if self._guard is None:
+            return False
+        rc = lib().fv_plan_check_range(self._h, torch.cuda.current_stream(self._dev).cuda_stream)
+        if rc == ERR_RANGE:
+            return True
+        check(rc)
+        return False
 
     def set_group(self, group):
         check(lib().fv_plan_set_group(self._h, group))
@@ -669,9 +745,19 @@ class Plan:
         self.keep(h)
         check(lib().fv_plan_add_pqmf_synthesis(self._h, x, y, _ptr(h, "h"), h.shape[0], h.shape[1]))
 
-    def set_output_offset(self, aux_slot, y2_slot=SLOT_NONE):
-        """The op added last subtracts auxiliary input ``aux_slot`` in its epilogue (fv_plan_set_output_offset)."""
+    def set_output_offset(self, aux_slot, y2_slot=SLOT_NONE, y_slot=SLOT_OUT):
+        """The op added last (output slot ``y_slot``) subtracts auxiliary input ``aux_slot`` in its epilogue
+        (fv_plan_set_output_offset)."""
         check(lib().fv_plan_set_output_offset(self._h, aux_slot, y2_slot))
+        self.__dict__.setdefault("_aux_of", {})[aux_slot] = y_slot
+
+    def _aux_elems(self, T, aux_slot):
+        """Elements per utterance of the tensor auxiliary input ``aux_slot`` is subtracted from (None: unused)."""
+        y = self.__dict__.get("_aux_of", {}).get(aux_slot)
+        if y is None:
+            return None
+        c, n = self.slot_shape(T, y)
+        return c * n
 
     def slot_shape(self, T, slot):
         c, n = ctypes.c_int(), ctypes.c_int64()
@@ -697,6 +783,7 @@ class Plan:
         if out is None:
             out = torch.empty((B, c, n), dtype=torch.float32, device=x.device)
         key = (B, T, x.device)
+        self._dev = x.device
         if self._ws_key != key:
             nbytes = lib().fv_plan_workspace_bytes(self._h, B, T)
             if nbytes < 0:
@@ -709,8 +796,24 @@ class Plan:
             second = torch.empty((B, c2, n2), dtype=torch.float32, device=x.device)
         aux = list(aux) + [None] * (2 - len(aux))
         ptrs = (ctypes.c_void_p * 2)(*[_ptr(a, "aux", True) for a in aux])
-        batched = (ctypes.c_int * 2)(*[1 if (a is not None and a.dim() == 3 and a.shape[0] == B and B > 1) else 0
-                                       for a in aux])
+        # an auxiliary input is an output offset: exactly the element count of the tensor it is subtracted from
+        # (per utterance, or one row per utterance) -- the kernels index it without bounds
+        batched = []
+        for j, a in enumerate(aux):
+            if a is None:
+                batched.append(0)
+                continue
+            per = self._aux_elems(T, SLOT_AUX_IN0 + j)
+            if per is None:
+                raise NativeError(f"auxiliary input {j} was given, but no op of the plan subtracts it")
+            if a.numel() == per:
+                batched.append(0)
+            elif a.numel() == B * per:
+                batched.append(1)
+            else:
+                raise NativeError(f"auxiliary input {j} has {a.numel()} elements; the tensor it is subtracted from has "
+                                  f"{per} per utterance (batch {B})")
+        batched = (ctypes.c_int * 2)(*batched)
         with _on(x, out, self._ws, second, *aux, *self._keep[:1]) as stream:
             check(lib().fv_plan_run_aux(self._h, B, T, _ptr(x, "input"), _ptr(out, "out"), _ptr(second, "out2", True),
                                         ptrs, batched, self._ws.data_ptr(), self._ws.numel(), stream))

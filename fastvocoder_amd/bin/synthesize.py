@@ -46,14 +46,28 @@ def build_generator(model_name, config):
     raise Exception("no model find!")
 
 
-def load_checkpoint(path, device):
-    """torch.load restricted to tensors and plain containers when possible; published checkpoints carry a
-    numpy ``'pattern'`` entry (bin/publish.py:71-75), which needs the unrestricted unpickler -- only then,
-    and only for a file the caller chose, is it used."""
+def _numpy_globals():
+    """What a pickled numpy array needs from the unpickler: published checkpoints carry a numpy ``'pattern'`` entry
+    (bin/publish.py:71-75).  Allow-listing these keeps torch.load's restricted (weights_only) unpickler in charge."""
     try:
-        return torch.load(path, map_location=device, weights_only=True)
-    except Exception:   # noqa: BLE001 - numpy arrays / legacy pickles
+        from numpy._core.multiarray import _reconstruct
+    except ImportError:                                   # numpy 1.x
+        from numpy.core.multiarray import _reconstruct
+    kinds = (np.float16, np.float32, np.float64, np.int8, np.int16, np.int32, np.int64, np.uint8, np.bool_)
+    return [np.ndarray, np.dtype, _reconstruct] + sorted({type(np.dtype(k)) for k in kinds}, key=lambda t: t.__name__)
+
+
+def load_checkpoint(path, device, unsafe=None):
+    """torch.load with the restricted (weights_only) unpickler: tensors, plain containers and numpy arrays (allow-listed
+    globals) -- everything a training or a published checkpoint of the reference holds.  Anything else in the file is
+    refused; the unrestricted unpickler, which EXECUTES what a file tells it to, runs only on explicit request
+    (``unsafe=True`` or FV_UNSAFE_LOAD=1 in the environment: a file the caller trusts)."""
+    if unsafe is None:
+        unsafe = os.environ.get("FV_UNSAFE_LOAD", "0") == "1"
+    if unsafe:
         return torch.load(path, map_location=device, weights_only=False)
+    with torch.serialization.safe_globals(_numpy_globals()):
+        return torch.load(path, map_location=device, weights_only=True)
 
 
 def default_device():

@@ -10,6 +10,7 @@
 #include <utility>
 #include <vector>
 
+#include <ctype.h>
 #include <string.h>
 #include <unistd.h>
 
@@ -240,9 +241,12 @@ __global__ void pack_pair_kernel(const float* __restrict__ w, float* __restrict_
 
 // Conv1d weight [C, C, k] -> the split-f16 A operands of pairh_kernels.hpp:
 // Wh[(K step s * MH + row half h) * 2 + split half][lane][8 halves]; lane = (row m = lane & 15, K block g = lane >> 4),
+// (range_flag: an optional device-visible word that is set to 1 when a weight is outside the f16 range -- that layer has
+// to run on the fp32 kernels)
+constexpr float kSplitLimit = 65520.f;   // the smallest magnitude that rounds to inf in f16
 // C = 16: tap = 2s + (g >> 1), channels 8 (g & 1) .. + 7 (an odd tap count is padded with a zero tap);
 // C = 32: tap = s, channels 8g .. 8g + 7.  Split: h1 = f16(w), h2 = f16((w - h1) * 2048), round to nearest.
-__global__ void pack_pairh_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int C, int k) {
+__global__ void pack_pairh_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int C, int k, int* range_flag) {
     const int MH = C / 16, tps = 32 / C, KS = (k + tps - 1) / tps;
     const int64_t total = (int64_t)KS * MH * 2 * 64 * 8;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -254,6 +258,7 @@ __global__ void pack_pairh_kernel(const float* __restrict__ w, _Float16* __restr
         const int ci = tps == 2 ? 8 * (g & 1) + j : 8 * g + j;
         const float v = tap < k ? w[((size_t)co * C + ci) * k + tap] : 0.f;
         const _Float16 h1 = (_Float16)v;
+        if (range_flag && !(fabsf(v) < kSplitLimit)) *range_flag = 1;   // f16(v) would be inf (or v is not finite)
         wp[i] = half == 0 ? h1 : (_Float16)((v - (float)h1) * 2048.f);
     }
 }
@@ -261,7 +266,7 @@ __global__ void pack_pairh_kernel(const float* __restrict__ w, _Float16* __restr
 // Conv1d weight [C, C, k], C = 64 / 128 -> the streamed split-f16 A operands of convh_kernels.hpp:
 // Wh[row tile mt][K step s = tap * C/32 + cg][row sixteenth mh][split half][lane][8 halves];
 // lane = (row = lane & 15, K block kb = lane >> 4): co = 64 mt + 16 mh + row, ci = 32 cg + 8 kb + j.
-__global__ void pack_convh_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int C, int k) {
+__global__ void pack_convh_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int C, int k, int* range_flag) {
     // above 128 channels the input channels come in chunks of 128: [row tile][chunk][step inside the chunk]...
     const int NCH = C > 128 ? C / 128 : 1, CC = C / NCH, CG = CC / 32, NSTEP = k * CG;
     const int64_t total = (int64_t)(C / 64) * NCH * NSTEP * 4 * 2 * 64 * 8;
@@ -273,13 +278,14 @@ __global__ void pack_convh_kernel(const float* __restrict__ w, _Float16* __restr
         const int co = 64 * mt + 16 * mh + (lane & 15), ci = CC * chunk + 32 * cg + 8 * (lane >> 4) + j;
         const float v = w[((size_t)co * C + ci) * k + tap];
         const _Float16 h1 = (_Float16)v;
+        if (range_flag && !(fabsf(v) < kSplitLimit)) *range_flag = 1;   // f16(v) would be inf (or v is not finite)
         wp[i] = half == 0 ? h1 : (_Float16)((v - (float)h1) * 2048.f);
     }
 }
 
 // ConvTranspose1d weights w[Cin][Cout][2 s] for convt_kernel (convh_kernels.hpp): the same stage layout, rows
 // m = co * s + phase, K = (tap, ci): tap 0 multiplies x[u - 1] (kernel index s + phase), tap 1 x[u] (kernel index phase)
-__global__ void pack_convth_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int Cin, int Cout, int s_) {
+__global__ void pack_convth_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int Cin, int Cout, int s_, int* range_flag) {
     const int NCH = (Cin + 127) / 128, CG = 4, NSTEP = 2 * CG, k = 2 * s_;
     const int64_t total = (int64_t)((Cout * s_ + 63) / 64) * NCH * NSTEP * 4 * 2 * 64 * 8;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -291,6 +297,7 @@ __global__ void pack_convth_kernel(const float* __restrict__ w, _Float16* __rest
         const int ci = 128 * chunk + 32 * cg + 8 * (lane >> 4) + j;
         const float v = ci < Cin && co < Cout ? w[((size_t)ci * Cout + co) * k + (tap == 0 ? s_ + ph : ph)] : 0.f;
         const _Float16 h1 = (_Float16)v;
+        if (range_flag && !(fabsf(v) < kSplitLimit)) *range_flag = 1;   // f16(v) would be inf (or v is not finite)
         wp[i] = half == 0 ? h1 : (_Float16)((v - (float)h1) * 2048.f);
     }
 }
@@ -309,12 +316,6 @@ struct Op {
     int Cin, Cout, k, dil, pad, pad_mode, stride, out_pad;
     float pre_slope, out_div, act_slope;
     int post;
-    // concurrency: ops on different lanes run on different streams; deps[] are the ops on
-    // OTHER lanes this op must wait for (derived from slot reads/writes by compile_lanes)
-    int lane;
-    int ndeps;
-    int deps[3];
-    bool signal;   // some op on another lane waits for this one: record its event
     // two-source conv (1 tap): GEMM rows ci >= Cin1 are read from slot x2 (Cin - Cin1 channels)
     int x2 = FV_SLOT_NONE;
     int Cin1 = 0;
@@ -340,8 +341,6 @@ struct Op {
     int sub = FV_SLOT_NONE;   // fv_plan_set_output_offset: auxiliary input subtracted in this op's epilogue
 };
 
-constexpr int kMaxLanes = 4;
-
 struct Shape {
     int C;
     int64_t T;
@@ -353,25 +352,12 @@ struct Shape {
 struct fv_plan {
     int in_channels;
     std::vector<fv::Op> ops;
-    int cur_lane = 0;
     int cur_group = 0;
     int cur_own_first = 0;
-    int n_lanes = 1;
-    bool compiled = false;
-    // lanes 1.. run on plan-owned streams; one event per signalling op + fork/join events
-    hipStream_t lane_stream[fv::kMaxLanes] = {};
-    std::vector<hipEvent_t> op_event;
-    hipEvent_t fork_event = nullptr;
-    hipEvent_t join_event[fv::kMaxLanes] = {};
-    ~fv_plan() {
-        for (hipEvent_t e : op_event)
-            if (e) (void)hipEventDestroy(e);
-        if (fork_event) (void)hipEventDestroy(fork_event);
-        for (int l = 0; l < fv::kMaxLanes; ++l) {
-            if (join_event[l]) (void)hipEventDestroy(join_event[l]);
-            if (lane_stream[l]) (void)hipStreamDestroy(lane_stream[l]);
-        }
-    }
+    // range guard of the split-f16 launches (fv_plan_set_guard): a caller-owned word in pinned, device-mapped host
+    // memory -- the host's and the device's view of it
+    int* guard_host = nullptr;
+    int* guard_dev = nullptr;
 };
 
 namespace fv {
@@ -523,7 +509,7 @@ static ConvParams make_params(const Op& o, const float* x, float* y, float* y2, 
 
 static int run_op(const Op& o, const float* x, float* y, float* y2, const float* res, const float* acc,
                   const float* acc2, int B, int64_t Tin, hipStream_t s, const float* x2 = nullptr,
-                  const float* sub = nullptr, int sub_batched = 0) {
+                  const float* sub = nullptr, int sub_batched = 0, int* guard = nullptr) {
     if (o.type == OP_PQMF) return launch_pqmf(x, o.wp, y, y2, sub, sub_batched, B, o.Cin, o.k, (int)Tin, s);
     if (o.type == OP_CONVT && o.prec == FV_PAIR_SPLIT_F16) {
         PairParams pp = {};
@@ -532,6 +518,7 @@ static int run_op(const Op& o, const float* x, float* y, float* y2, const float*
         pp.slope = o.pre_slope;
         pp.act_slope = o.act_slope;
         pp.prec = FV_PAIR_SPLIT_F16;
+        pp.guard = guard;
         pp.m[0].x = x;
         pp.m[0].w1 = o.wp;
         pp.m[0].b1 = o.bias;
@@ -540,75 +527,6 @@ static int run_op(const Op& o, const float* x, float* y, float* y2, const float*
         return launch_convt(pp, o.Cin, o.Cout, o.stride, o.pad, (int)conv_out_len(o, Tin), s);
     }
     return launch_conv(make_params(o, x, y, y2, res, acc, acc2, B, Tin, x2, sub, sub_batched), s);
-}
-
-// Cross-lane dependencies from the slots each op reads and writes (RAW, WAR, WAW):
-// same-lane order is the stream's; for every other lane only its latest
-// conflicting op matters.  Creates the lane streams and events on first use.
-static int compile_lanes(fv_plan* plan) {
-    if (plan->compiled) return 0;
-    const int n = (int)plan->ops.size();
-    int last_write[FV_MAX_SLOTS];
-    std::vector<int> readers[FV_MAX_SLOTS];
-    for (int i = 0; i < FV_MAX_SLOTS; ++i) last_write[i] = -1;
-    plan->n_lanes = 1;
-    for (Op& o : plan->ops) {
-        o.ndeps = 0;
-        o.signal = false;
-        if (o.lane + 1 > plan->n_lanes) plan->n_lanes = o.lane + 1;
-    }
-    for (int i = 0; i < n; ++i) {
-        Op& o = plan->ops[i];
-        int latest[kMaxLanes];
-        for (int l = 0; l < kMaxLanes; ++l) latest[l] = -1;
-        auto need = [&](int j) {
-            if (j >= 0 && plan->ops[j].lane != o.lane && j > latest[plan->ops[j].lane])
-                latest[plan->ops[j].lane] = j;
-        };
-        const int reads[9] = {o.x, o.res, o.acc, o.acc2, o.x2, o.xb, o.xc, o.resb, o.resc};
-        const int writes[4] = {o.y, o.y2, o.tmpb, o.tmpc};
-        for (int s : reads)
-            if (s != FV_SLOT_NONE) need(last_write[s]);
-        for (int s : writes) {
-            if (s == FV_SLOT_NONE) continue;
-            need(last_write[s]);
-            for (int r : readers[s]) need(r);
-        }
-        for (int l = 0; l < kMaxLanes; ++l) {
-            if (latest[l] < 0) continue;
-            o.deps[o.ndeps++] = latest[l];
-            plan->ops[latest[l]].signal = true;
-        }
-        for (int s : reads)
-            if (s != FV_SLOT_NONE) readers[s].push_back(i);
-        for (int s : writes) {
-            if (s == FV_SLOT_NONE) continue;
-            last_write[s] = i;
-            readers[s].clear();
-        }
-    }
-    for (hipEvent_t e : plan->op_event)
-        if (e) (void)hipEventDestroy(e);
-    plan->op_event.assign(n, nullptr);
-    if (plan->n_lanes > 1) {
-        for (int i = 0; i < n; ++i)
-            if (plan->ops[i].signal) FV_HIP(hipEventCreateWithFlags(&plan->op_event[i], hipEventDisableTiming));
-        if (!plan->fork_event) FV_HIP(hipEventCreateWithFlags(&plan->fork_event, hipEventDisableTiming));
-        for (int l = 1; l < plan->n_lanes; ++l) {
-            if (!plan->lane_stream[l]) {
-                // FV_LANE_PRIO=1: the highest lane (the ResBlock with the largest kernel, i.e.
-                // the critical chain of an MRF stage) gets the greatest stream priority
-                int lo = 0, hi = 0;
-                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-                const bool prio = fv_getenv("FV_LANE_PRIO") && atoi(fv_getenv("FV_LANE_PRIO")) != 0;
-                const int pr = (prio && l == plan->n_lanes - 1) ? hi : lo;
-                FV_HIP(hipStreamCreateWithPriority(&plan->lane_stream[l], hipStreamNonBlocking, pr));
-            }
-            if (!plan->join_event[l]) FV_HIP(hipEventCreateWithFlags(&plan->join_event[l], hipEventDisableTiming));
-        }
-    }
-    plan->compiled = true;
-    return 0;
 }
 
 // CausalConv1d keeps the first Tin outputs of a conv padded on both sides: only a pad of
@@ -653,32 +571,42 @@ int allow_dynamic_lds(const void* kernel, size_t bytes) {
     return 0;
 }
 
-const char* fv_getenv(const char* name) {
-    struct Entry {
-        const char* name;
-        const char* value;
-    };
-    thread_local uintptr_t gen = 0;
-    thread_local Entry cache[48];
-    thread_local int n = 0;
-    uintptr_t h = 0x9e3779b97f4a7c15ull;
-    if (environ)
-        for (char** e = environ; *e; ++e) h = (h ^ reinterpret_cast<uintptr_t>(*e)) * 0x100000001b3ull;
-    if (h != gen) {
-        gen = h;
-        n = 0;
+// Tuning switches (fv_internal.h struct Tuning).  Defaults unless the process was started with FV_TUNING=1, in which
+// case the FV_* variables of the table below are read ONCE, here; after that the launch path never touches the
+// environment.  fv_tuning_set changes an entry at run time (tests: different block counts / schedules must give the
+// same bits).
+static Tuning g_tuning;
+static std::once_flag g_tuning_once;
+struct TuningEntry {
+    const char* key;      // fv_tuning_set key; the environment variable is "FV_" + upper case
+    int Tuning::*field;
+};
+static const TuningEntry kTuningTable[] = {
+    {"pair_dbg", &Tuning::pair_dbg},       {"dbg", &Tuning::conv_dbg},           {"sched", &Tuning::sched},
+    {"sched_switch", &Tuning::sched_switch}, {"convh_skel", &Tuning::convh_skel}, {"convp_skel", &Tuning::convp_skel},
+    {"pairh_skel", &Tuning::pairh_skel},   {"pair_skel", &Tuning::pair_skel},    {"convh_blocks", &Tuning::convh_blocks},
+    {"pair_blocks", &Tuning::pair_blocks}, {"sum3_min", &Tuning::sum3_min},      {"lds_budget", &Tuning::lds_budget},
+    {"units", &Tuning::units},             {"shape16", &Tuning::shape16},        {"shape32", &Tuning::shape32},
+    {"shape64", &Tuning::shape64},         {"krows", &Tuning::krows},            {"grid_cap", &Tuning::grid_cap},
+    {"no_group", &Tuning::no_group},       {"convh_carry", &Tuning::convh_carry},
+};
+static void tuning_from_env() {
+    const char* on = getenv("FV_TUNING");
+    if (!on || atoi(on) != 1) return;
+    for (const TuningEntry& e : kTuningTable) {
+        char name[64] = "FV_";
+        size_t n = 3;
+        for (const char* c = e.key; *c && n + 1 < sizeof(name); ++c) name[n++] = (char)toupper((unsigned char)*c);
+        name[n] = 0;
+        const char* v = getenv(name);
+        if (v && *v) g_tuning.*(e.field) = atoi(v);
     }
-    for (int i = 0; i < n; ++i)
-        if (cache[i].name == name || strcmp(cache[i].name, name) == 0) return cache[i].value;
-    const char* v = getenv(name);
-    if (n < 48) cache[n++] = {name, v};
-    return v;
+    const char* tp = getenv("FV_PAIR_TRACE_PTR");
+    if (tp && *tp) g_tuning.trace_ptr = strtoull(tp, nullptr, 0);
 }
-
-int tuning_dbg_flags() {
-    const char* on = fv_getenv("FV_TUNING");
-    const char* d = fv_getenv("FV_PAIR_DBG");
-    return on && atoi(on) == 1 && d ? atoi(d) : 0;
+const Tuning& tuning() {
+    std::call_once(g_tuning_once, tuning_from_env);
+    return g_tuning;
 }
 
 int device_cu_count() {
@@ -900,19 +828,20 @@ int64_t fv_packed_conv_transpose1d_split_floats(int Cin, int Cout, int k, int st
     return (int64_t)((Cout * stride + 63) / 64) * ((Cin + 127) / 128) * 8 * 2048;   // row tiles x chunks x 8 K steps x 8 KB
 }
 
-int fv_pack_conv_transpose1d_split_f16(const float* w, float* packed, int Cin, int Cout, int k, int stride, void* stream) {
+int fv_pack_conv_transpose1d_split_f16(const float* w, float* packed, int Cin, int Cout, int k, int stride, int* range_flag,
+                                       void* stream) {
     if (!w || !packed) return fail(FV_ERR_INVALID_ARG, "pack_conv_transpose1d_split_f16: null tensor");
     if (int rc = check_convt_split_args(Cin, Cout, k, stride, 0, 0)) return rc;
     const int64_t total = fv_packed_conv_transpose1d_split_floats(Cin, Cout, k, stride) * 2;
     hipLaunchKernelGGL(pack_convth_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       reinterpret_cast<_Float16*>(packed), Cin, Cout, stride);
+                       reinterpret_cast<_Float16*>(packed), Cin, Cout, stride, range_flag);
     FV_HIP(hipGetLastError());
     return 0;
 }
 
 int fv_conv_transpose1d_split_f16(const float* x, const float* packed, const float* bias, float* y, float* y_act, int B,
                                   int Cin, int Cout, int Tin, int k, int stride, int pad, int out_pad, float pre_slope,
-                                  float act_slope, void* stream) {
+                                  float act_slope, int* guard, void* stream) {
     if (!x || !packed || !y) return fail(FV_ERR_INVALID_ARG, "conv_transpose1d_split_f16: null tensor");
     if (int rc = check_convt_split_args(Cin, Cout, k, stride, pad, out_pad)) return rc;
     if (x == y || x == y_act || (y_act && y_act == y))
@@ -934,7 +863,7 @@ int fv_conv_transpose1d_split_f16(const float* x, const float* packed, const flo
     if (B < 0 || Tin < 0) return fail(FV_ERR_INVALID_ARG, "conv_transpose1d_split_f16: B=%d Tin=%d", B, Tin);
     if (B == 0 || Tin == 0) return 0;
     if (conv_out_len(o, Tin) <= 0) return fail(FV_ERR_INVALID_ARG, "conv_transpose1d_split_f16: empty output");
-    return run_op(o, x, y, y_act, nullptr, nullptr, nullptr, B, Tin, (hipStream_t)stream);
+    return run_op(o, x, y, y_act, nullptr, nullptr, nullptr, B, Tin, (hipStream_t)stream, nullptr, nullptr, 0, guard);
 }
 
 int fv_pqmf_synthesis(const float* x, const float* h, float* y, int B, int S, int ntaps, int Tsub,
@@ -1010,8 +939,6 @@ int fv_plan_add_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, 
     o.pre_slope = pre_slope;
     o.out_div = out_div;
     o.post = post;
-    o.lane = plan->cur_lane;
-    plan->compiled = false;
     plan->ops.push_back(o);
     return 0;
 }
@@ -1123,8 +1050,6 @@ int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot, int y_
     o.pre_slope = pre_slope;
     o.out_div = 1.f;
     o.post = post;
-    o.lane = plan->cur_lane;
-    plan->compiled = false;
     plan->ops.push_back(o);
     return 0;
 }
@@ -1158,8 +1083,6 @@ int fv_plan_add_pqmf_synthesis(fv_plan_t* plan, int x_slot, int y_slot, const fl
     o.Cin = S;
     o.Cout = 1;
     o.k = ntaps;
-    o.lane = plan->cur_lane;
-    plan->compiled = false;
     plan->ops.push_back(o);
     return 0;
 }
@@ -1185,7 +1108,7 @@ int64_t fv_packed_pair_floats_ex(int C, int k, int prec) {
     return (int64_t)((k + tps - 1) / tps) * (C / 16) * 512;   // K steps x row halves x 2 split halves x 64 lanes x 16 bytes
 }
 
-int fv_pack_pair_weight_ex(const float* w, float* packed, int C, int k, int prec, void* stream) {
+int fv_pack_pair_weight_ex(const float* w, float* packed, int C, int k, int prec, int* range_flag, void* stream) {
     if (prec == FV_PAIR_F32) return fv_pack_pair_weight(w, packed, C, k, stream);
     if (prec != FV_PAIR_SPLIT_F16) return fail(FV_ERR_INVALID_ARG, "pack_pair_weight: unknown arithmetic %d", prec);
     if (!w || !packed) return fail(FV_ERR_INVALID_ARG, "pack_pair_weight: null tensor");
@@ -1194,10 +1117,10 @@ int fv_pack_pair_weight_ex(const float* w, float* packed, int C, int k, int prec
     const int64_t total = fv_packed_pair_floats_ex(C, k, prec) * 2;
     if (C >= 64)
         hipLaunchKernelGGL(pack_convh_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           w, reinterpret_cast<_Float16*>(packed), C, k);
+                           w, reinterpret_cast<_Float16*>(packed), C, k, range_flag);
     else
         hipLaunchKernelGGL(pack_pairh_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           w, reinterpret_cast<_Float16*>(packed), C, k);
+                           w, reinterpret_cast<_Float16*>(packed), C, k, range_flag);
     FV_HIP(hipGetLastError());
     return 0;
 }
@@ -1242,14 +1165,14 @@ int fv_resblock1_fused(int n, const float* const* x, const float* const* w1, con
                        const float* const* b1, const float* const* b2, float* const* y, float* const* y_act,
                        const int* k, int B, int C, int T, int dil, float slope, float act_slope, void* stream) {
     return fv_resblock1_fused_ex(n, x, w1, w2, b1, b2, y, y_act, nullptr, nullptr, nullptr, k, B, C, T, dil, slope,
-                                 1.f, FV_POST_NONE, act_slope, FV_PAIR_F32, stream);
+                                 1.f, FV_POST_NONE, act_slope, FV_PAIR_F32, nullptr, stream);
 }
 
 int fv_resblock1_fused_ex(int n, const float* const* x, const float* const* w1, const float* const* w2,
                           const float* const* b1, const float* const* b2, float* const* y, float* const* y_act,
                           float* const* mid, const float* const* add1, const float* const* add2, const int* k, int B,
                           int C, int T, int dil, float slope, float out_div, int post, float act_slope, int prec,
-                          void* stream) {
+                          int* guard, void* stream) {
     if (!x || !w1 || !w2 || !y || !k) return fail(FV_ERR_INVALID_ARG, "resblock1_fused: null argument");
     if (int rc = check_pair_args(n, C, k, dil, prec)) return rc;
     PairParams pp = {};
@@ -1261,6 +1184,7 @@ int fv_resblock1_fused_ex(int n, const float* const* x, const float* const* w1, 
     pp.out_div = out_div;
     pp.post = post;
     pp.prec = prec;
+    pp.guard = prec == FV_PAIR_SPLIT_F16 ? guard : nullptr;
     for (int j = 0; j < n; ++j) {
         if (!x[j] || !y[j] || x[j] == y[j] || (y_act && y_act[j] && (y_act[j] == y[j] || y_act[j] == x[j])))
             return fail(FV_ERR_INVALID_ARG, "resblock1_fused: member %d: null tensor, or y / y_act aliases x or each other", j);
@@ -1279,7 +1203,7 @@ int fv_resblock1_fused_ex(int n, const float* const* x, const float* const* w1, 
         mb.y_act = y_act ? y_act[j] : nullptr;
         mb.k = k[j];
     }
-    if (C == 64 && !fv_getenv("FV_PAIR64_UNFUSED")) return launch_convp(pp, dil, (hipStream_t)stream);
+    if (C == 64) return launch_convp(pp, dil, (hipStream_t)stream);
     if (C >= 64) return launch_wide_pairs(pp, mid, C, dil, (hipStream_t)stream);
     return launch_pairs(pp, C, dil, (hipStream_t)stream);
 }
@@ -1352,7 +1276,6 @@ int fv_plan_add_resblock_pair_ex(fv_plan_t* plan, int x_slot, int y_slot, int y_
     o.acc2 = add2_slot;
     o.tmpb = mid_slot;
     o.group = plan->cur_group;
-    o.lane = plan->cur_lane;
     o.Cin = o.Cout = C;
     o.k = k;
     o.dil = dil;
@@ -1366,7 +1289,6 @@ int fv_plan_add_resblock_pair_ex(fv_plan_t* plan, int x_slot, int y_slot, int y_
     o.pb1[0] = bias1;
     o.pb2[0] = bias2;
     o.pk[0] = k;
-    plan->compiled = false;
     plan->ops.push_back(o);
     return 0;
 }
@@ -1388,7 +1310,7 @@ static int check_convh_args(int n, int C, const int* k, int dil, int pad_mode) {
 int fv_conv1d_split_f16(int n, const float* const* x, const float* const* packed, const float* const* bias,
                         const float* const* res, const float* const* add1, const float* const* add2, float* const* y,
                         float* const* y_act, const int* k, int B, int C, int T, int dil, int pad_mode, float pre_slope,
-                        float out_div, int post, float act_slope, void* stream) {
+                        float out_div, int post, float act_slope, int* guard, void* stream) {
     if (!x || !packed || !y || !k) return fail(FV_ERR_INVALID_ARG, "conv1d_split_f16: null argument");
     if (int rc = check_convh_args(n, C, k, dil, pad_mode)) return rc;
     PairParams pp = {};
@@ -1400,6 +1322,7 @@ int fv_conv1d_split_f16(int n, const float* const* x, const float* const* packed
     pp.out_div = out_div;
     pp.post = post;
     pp.prec = FV_PAIR_SPLIT_F16;
+    pp.guard = guard;
     pp.reflect = pad_mode == FV_PAD_REFLECT;
     for (int j = 0; j < n; ++j) {
         PairMember& mb = pp.m[j];
@@ -1443,7 +1366,6 @@ int fv_plan_add_conv1d_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_
     o.acc = add1_slot;
     o.acc2 = add2_slot;
     o.group = plan->cur_group;
-    o.lane = plan->cur_lane;
     o.Cin = o.Cout = C;
     o.k = k;
     o.dil = dil;
@@ -1456,7 +1378,6 @@ int fv_plan_add_conv1d_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_
     o.pw1[0] = packed;
     o.pb1[0] = bias;
     o.pk[0] = k;
-    plan->compiled = false;
     plan->ops.push_back(o);
     return 0;
 }
@@ -1483,7 +1404,6 @@ int fv_plan_add_mrf_sum(fv_plan_t* plan, const int* x_slots, int y_slot, int y_a
     o.y = y_slot;
     o.y2 = y_act_slot;
     o.res = o.acc = o.acc2 = FV_SLOT_NONE;
-    o.lane = plan->cur_lane;
     o.Cin = o.Cout = C;
     o.k = k[0];
     o.dil = dil;
@@ -1498,7 +1418,6 @@ int fv_plan_add_mrf_sum(fv_plan_t* plan, const int* x_slots, int y_slot, int y_a
         o.pb2[j] = bias2 ? bias2[j] : nullptr;
         o.pk[j] = k[j];
     }
-    plan->compiled = false;
     plan->ops.push_back(o);
     return 0;
 }
@@ -1519,7 +1438,6 @@ int fv_plan_set_output_offset(fv_plan_t* plan, int aux_slot, int y2_slot) {
         if (o.type != OP_PQMF) o.act_slope = 1.f;
     }
     o.sub = aux_slot;
-    plan->compiled = false;
     return 0;
 }
 
@@ -1539,7 +1457,6 @@ int fv_plan_set_pair_output_conv(fv_plan_t* plan, const float* w, const float* b
     o.y = y_slot;
     o.act_slope = act_slope;
     o.post = post;
-    plan->compiled = false;
     return 0;
 }
 
@@ -1552,12 +1469,6 @@ int fv_plan_set_group(fv_plan_t* plan, int group) {
 int fv_plan_set_sum_order(fv_plan_t* plan, int own_first) {
     if (!plan) return fail(FV_ERR_INVALID_ARG, "plan_set_sum_order: null plan");
     plan->cur_own_first = own_first ? 1 : 0;
-    return 0;
-}
-
-int fv_plan_set_lane(fv_plan_t* plan, int lane) {
-    if (!plan || lane < 0 || lane >= kMaxLanes) return fail(FV_ERR_INVALID_ARG, "plan_set_lane: lane %d (0..%d)", lane, kMaxLanes - 1);
-    plan->cur_lane = lane;
     return 0;
 }
 
@@ -1619,16 +1530,7 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
                     (long long)workspace_bytes);
     base[FV_SLOT_IN] = const_cast<float*>(in);
     base[FV_SLOT_OUT] = out;
-    if (int rc = compile_lanes(plan)) return rc;
-    hipStream_t lanes[kMaxLanes];
-    lanes[0] = (hipStream_t)stream;
-    const bool multi = plan->n_lanes > 1 && !fv_getenv("FV_SINGLE_LANE");
-    for (int l = 1; l < kMaxLanes; ++l) lanes[l] = multi && l < plan->n_lanes ? plan->lane_stream[l] : lanes[0];
-    if (multi) {
-        // fork: the side lanes start after everything already queued on the caller's stream
-        FV_HIP(hipEventRecord(plan->fork_event, lanes[0]));
-        for (int l = 1; l < plan->n_lanes; ++l) FV_HIP(hipStreamWaitEvent(lanes[l], plan->fork_event, 0));
-    }
+    hipStream_t const s = (hipStream_t)stream;
     // shapes again, op by op (a slot may change shape when it is reused)
     for (int i = 0; i < FV_MAX_SLOTS; ++i) sh[i].set = false;
     sh[FV_SLOT_IN] = {plan->in_channels, T, true};
@@ -1639,16 +1541,11 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             size_t m = n + 1;
             if (o.group != 0)
                 while (m < plan->ops.size() && m - n < 3 && plan->ops[m].type == OP_CONVH && plan->ops[m].group == o.group &&
-                       plan->ops[m].lane == o.lane && plan->ops[m].Cin == o.Cin && plan->ops[m].dil == o.dil &&
+                       plan->ops[m].Cin == o.Cin && plan->ops[m].dil == o.dil &&
                        plan->ops[m].pad_mode == o.pad_mode &&
                        plan->ops[m].pre_slope == o.pre_slope && plan->ops[m].act_slope == o.act_slope &&
                        plan->ops[m].out_div == o.out_div && plan->ops[m].post == o.post)
                     ++m;
-            hipStream_t s = lanes[o.lane];
-            if (multi)
-                for (size_t q = n; q < m; ++q)
-                    for (int d = 0; d < plan->ops[q].ndeps; ++d)
-                        FV_HIP(hipStreamWaitEvent(s, plan->op_event[plan->ops[q].deps[d]], 0));
             PairParams pp = {};
             pp.B = B;
             pp.T = (int)sh[o.x].T;
@@ -1657,6 +1554,7 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             pp.out_div = o.out_div;
             pp.post = o.post;
             pp.prec = FV_PAIR_SPLIT_F16;
+            pp.guard = plan->guard_dev;
             pp.reflect = o.pad_mode == FV_PAD_REFLECT;
             pp.n_members = (int)(m - n);
             for (size_t q = n; q < m; ++q) {
@@ -1675,7 +1573,6 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             if (int rc = launch_convh(pp, o.Cin, o.dil, s)) return rc;
             for (size_t q = n; q < m; ++q) {
                 const Op& qo = plan->ops[q];
-                if (multi && qo.signal) FV_HIP(hipEventRecord(plan->op_event[q], s));
                 sh[qo.y] = {qo.Cout, sh[qo.x].T, true};
                 if (qo.y2 != FV_SLOT_NONE) sh[qo.y2] = sh[qo.y];
             }
@@ -1687,16 +1584,11 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             size_t m = n + 1;
             if (o.type == OP_PAIR && o.group != 0)
                 while (m < plan->ops.size() && m - n < 3 && plan->ops[m].type == OP_PAIR && plan->ops[m].group == o.group &&
-                       plan->ops[m].lane == o.lane && plan->ops[m].Cin == o.Cin && plan->ops[m].dil == o.dil &&
+                       plan->ops[m].Cin == o.Cin && plan->ops[m].dil == o.dil &&
                        plan->ops[m].pre_slope == o.pre_slope && plan->ops[m].act_slope == o.act_slope && !o.fold_w &&
                        !plan->ops[m].fold_w &&
                        plan->ops[m].prec == o.prec && plan->ops[m].out_div == o.out_div && plan->ops[m].post == o.post)
                     ++m;
-            hipStream_t s = lanes[o.lane];
-            if (multi)
-                for (size_t q = n; q < m; ++q)
-                    for (int d = 0; d < plan->ops[q].ndeps; ++d)
-                        FV_HIP(hipStreamWaitEvent(s, plan->op_event[plan->ops[q].deps[d]], 0));
             PairParams pp = {};
             pp.B = B;
             pp.T = (int)sh[o.x].T;
@@ -1705,6 +1597,7 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             pp.out_div = o.out_div;
             pp.post = o.post;
             pp.prec = o.prec;
+            pp.guard = plan->guard_dev;
             if (o.type == OP_MRFSUM) {
                 const int xs3[3] = {o.x, o.xb, o.xc};
                 pp.sum = 1;
@@ -1743,7 +1636,7 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
                     }
                 }
             }
-            if (o.Cin == 64 && !fv_getenv("FV_PAIR64_UNFUSED")) {
+            if (o.Cin == 64 && o.prec == FV_PAIR_SPLIT_F16) {
                 if (int rc = launch_convp(pp, o.dil, s)) return rc;
             } else if (o.Cin >= 64) {
                 float* mids[3] = {nullptr, nullptr, nullptr};
@@ -1752,7 +1645,6 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             } else if (int rc = launch_pairs(pp, o.Cin, o.dil, s)) return rc;
             for (size_t q = n; q < m; ++q) {
                 const Op& qo = plan->ops[q];
-                if (multi && qo.signal) FV_HIP(hipEventRecord(plan->op_event[q], s));
                 sh[qo.y] = {qo.fold_w ? 1 : qo.Cout, sh[qo.x].T, true};
                 if (qo.y2 != FV_SLOT_NONE) sh[qo.y2] = sh[qo.y];
             }
@@ -1765,7 +1657,7 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             ConvParams gp[3];
             int cnt = 0;
             while (m < plan->ops.size() && plan->ops[m].group == o.group && plan->ops[m].type == OP_CONV &&
-                   plan->ops[m].lane == o.lane && cnt < 3) {
+                   cnt < 3) {
                 const Op& q = plan->ops[m];
                 gp[cnt++] = make_params(q, base[q.x], base[q.y], q.y2 == FV_SLOT_NONE ? nullptr : base[q.y2],
                                         q.res == FV_SLOT_NONE ? nullptr : base[q.res],
@@ -1774,15 +1666,9 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
                                         q.x2 == FV_SLOT_NONE ? nullptr : base[q.x2]);
                 ++m;
             }
-            hipStream_t s = lanes[o.lane];
-            if (multi)
-                for (size_t q = n; q < m; ++q)
-                    for (int d = 0; d < plan->ops[q].ndeps; ++d)
-                        FV_HIP(hipStreamWaitEvent(s, plan->op_event[plan->ops[q].deps[d]], 0));
             if (int rc = launch_conv_group(gp, cnt, s)) return rc;
             for (size_t q = n; q < m; ++q) {
                 const Op& qo = plan->ops[q];
-                if (multi && qo.signal) FV_HIP(hipEventRecord(plan->op_event[q], s));
                 sh[qo.y] = {qo.Cout, conv_out_len(qo, sh[qo.x].T), true};
                 if (qo.y2 != FV_SLOT_NONE) sh[qo.y2] = sh[qo.y];
             }
@@ -1790,9 +1676,7 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             continue;
         }
         if (o.sum3) {
-            hipStream_t s3 = lanes[o.lane];
-            if (multi)
-                for (int d = 0; d < o.ndeps; ++d) FV_HIP(hipStreamWaitEvent(s3, plan->op_event[o.deps[d]], 0));
+            hipStream_t s3 = s;
             Op mb = o, mc = o;           // members 1, 2: same layer geometry, their own taps / weights
             mb.k = o.kb; mb.pad = (o.kb - 1) / 2; mb.wp = o.wpb; mb.bias = nullptr;
             mc.k = o.kc; mc.pad = (o.kc - 1) / 2; mc.wp = o.wpc; mc.bias = nullptr;
@@ -1803,7 +1687,7 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             const int64_t T3 = sh[o.x].T;
             const int Mp = pad_rows(o.Cout);
             const int64_t blocks = (int64_t)(Mp == 16 ? 1 : Mp / 32) * ((T3 + 127) / 128);
-            const int min_blocks = fv_getenv("FV_SUM3_MIN") ? atoi(fv_getenv("FV_SUM3_MIN")) : 800;   // measured: HiFi-GAN light, B = 1
+            const int min_blocks = tuning().sum3_min;   // 800 -- measured: HiFi-GAN light, B = 1
             int rc3;
             if (blocks >= min_blocks && Mp == o.Cout) {   // (whole row tiles only: the kernel's epilogue is the affine one)
                 ConvParams ps[3] = {
@@ -1828,7 +1712,6 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
                 }
             }
             if (rc3) return rc3;
-            if (multi && o.signal) FV_HIP(hipEventRecord(plan->op_event[n], s3));
             sh[o.y] = {o.Cout, conv_out_len(o, sh[o.x].T), true};
             if (o.y2 != FV_SLOT_NONE) sh[o.y2] = sh[o.y];
             continue;
@@ -1839,28 +1722,54 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
         const float* acc = o.acc == FV_SLOT_NONE ? nullptr : base[o.acc];
         const float* acc2 = o.acc2 == FV_SLOT_NONE ? nullptr : base[o.acc2];
         float* y2 = o.y2 == FV_SLOT_NONE ? nullptr : base[o.y2];
-        hipStream_t s = lanes[o.lane];
-        if (multi)
-            for (int d = 0; d < o.ndeps; ++d) FV_HIP(hipStreamWaitEvent(s, plan->op_event[o.deps[d]], 0));
         if (int rc = run_op(o, base[o.x], base[o.y], y2, res, acc, acc2, B, Tin, s,
                             o.x2 == FV_SLOT_NONE ? nullptr : base[o.x2], o.sub == FV_SLOT_NONE ? nullptr : base[o.sub],
-                            o.sub == FV_SLOT_NONE ? 0 : aux_b[o.sub - FV_SLOT_AUX_IN0]))
+                            o.sub == FV_SLOT_NONE ? 0 : aux_b[o.sub - FV_SLOT_AUX_IN0], plan->guard_dev))
             return rc;
-        if (multi && o.signal) FV_HIP(hipEventRecord(plan->op_event[n], s));
         sh[o.y] = {o.type == OP_PQMF ? 1 : o.Cout, Tout, true};
         if (o.y2 != FV_SLOT_NONE) sh[o.y2] = sh[o.y];
-    }
-    if (multi) {
-        // join: later work on the caller's stream sees every lane's results
-        for (int l = 1; l < plan->n_lanes; ++l) {
-            FV_HIP(hipEventRecord(plan->join_event[l], lanes[l]));
-            FV_HIP(hipStreamWaitEvent(lanes[0], plan->join_event[l], 0));
-        }
     }
     return 0;
 }
 
 int fv_plan_num_ops(fv_plan_t* plan) { return plan ? (int)plan->ops.size() : 0; }
+
+int fv_plan_set_guard(fv_plan_t* plan, int* word) {
+    if (!plan) return fail(FV_ERR_INVALID_ARG, "plan_set_guard: null plan");
+    plan->guard_host = plan->guard_dev = nullptr;
+    if (!word) return 0;
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, word, 0) != hipSuccess || !dev) {
+        (void)hipGetLastError();
+        return fail(FV_ERR_INVALID_ARG, "plan_set_guard: the guard word must live in pinned, device-mapped host memory "
+                                        "(hipHostMalloc / torch pin_memory)");
+    }
+    plan->guard_host = word;
+    plan->guard_dev = static_cast<int*>(dev);
+    return 0;
+}
+
+int fv_plan_check_range(fv_plan_t* plan, void* stream) {
+    if (!plan) return fail(FV_ERR_INVALID_ARG, "plan_check_range: null plan");
+    if (!plan->guard_host) return 0;
+    FV_HIP(hipStreamSynchronize((hipStream_t)stream));
+    volatile int* w = plan->guard_host;
+    if (*w == 0) return 0;
+    *w = 0;
+    return fail(FV_ERR_RANGE, "a split-f16 kernel met an operand beyond the f16 range (|v| >= 65520) or a non-finite "
+                              "value: the results of the last run are not valid; repeat it on an fp32-precision plan");
+}
+
+int fv_tuning_set(const char* key, int value) {
+    if (!key) return fail(FV_ERR_INVALID_ARG, "tuning_set: null key");
+    (void)tuning();                         // the environment (FV_TUNING=1) is read first, once
+    for (const TuningEntry& e : kTuningTable)
+        if (strcmp(e.key, key) == 0) {
+            g_tuning.*(e.field) = value;
+            return 0;
+        }
+    return fail(FV_ERR_INVALID_ARG, "tuning_set: unknown key '%s'", key);
+}
 
 int fv_profile_enable(int on) {
     g_prof_on = on != 0;

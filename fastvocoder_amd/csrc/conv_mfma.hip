@@ -39,11 +39,6 @@ struct Geometry {
     int threads() const { return 64 * wm * wn * wk; }
 };
 
-int env_int(const char* name, int dflt) {
-    const char* v = fv_getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
 // LDS image of the input tile: ncol4c float4 columns per channel row.  For the
 // 16x16x4 MFMA the row stride is made = 16 (mod 32) floats so the two k-rows a
 // half-wave reads sit on disjoint banks.
@@ -75,7 +70,7 @@ size_t plan_staging(ConvParams& p, const Geometry& g, int k_rows_target) {
         const int nw = g.wm * g.wn * g.wk;
         const bool dma_ok = round_up(c * p.ncol4c, 64) / 64 <= kMaxDmaX * nw &&
                             round_up(c * p.k * g.m_t() / 4, 64) / 64 <= kMaxDmaW * nw;
-        if (best && (!dma_ok || ns * per_buf > (size_t)env_int("FV_LDS_BUDGET", 39) * 1024)) break;
+        if (best && (!dma_ok || ns * per_buf > (size_t)tuning().lds_budget * 1024)) break;
         if (!dma_ok) return 0;
         // a stage of a two-source conv must not straddle the boundary between its tensors
         const bool src_ok = !p.x2 || p.Cin1 % c == 0;
@@ -152,7 +147,7 @@ int prepare_conv(ConvParams& p, LaunchInfo& li, int members = 1, int force_shape
                       (1 + (p.res != nullptr) + (p.acc_in != nullptr) + (p.acc_in2 != nullptr) +
                        (p.y_act != nullptr)) +
                       (double)p.Cin * p.k * p.M);
-    p.dbg = env_int("FV_DBG", 0);
+    p.dbg = tuning().conv_dbg;
     li.narrow = p.ups == 1 && p.M <= 4;
     if (li.narrow) {
         li.kind = FV_KERNEL_CONV_NARROW;
@@ -187,7 +182,7 @@ int prepare_conv(ConvParams& p, LaunchInfo& li, int members = 1, int force_shape
     // ``members`` = convs sharing the launch (3 in a grouped MRF launch): that many times the
     // units, so the wide 32x128 tile -- least weight re-streaming per MFMA (64 B vs 128 B of
     // L2->LDS traffic per instruction for the 64-column shapes) -- already pays at C = 128, T = 8000.
-    const int want = env_int("FV_UNITS", 500);
+    const int want = tuning().units;
     int shape;
     if (m16) shape = units(0) >= want ? 0 : 1;
     else if (units(2) * members >= want) shape = 2;
@@ -196,19 +191,19 @@ int prepare_conv(ConvParams& p, LaunchInfo& li, int members = 1, int force_shape
     else shape = 4;
     // a phase-major transposed conv needs row tiles that hold one phase: m_t must divide Cout
     if (p.phase_major && p.Cout % kShapes[shape].m_t() != 0) shape = units(3) * members >= 400 ? 3 : 4;
-    int force = env_int(m16 ? "FV_SHAPE16" : (m64 ? "FV_SHAPE64" : "FV_SHAPE32"), -1);
+    int force = m16 ? tuning().shape16 : (m64 ? tuning().shape64 : tuning().shape32);
     if (force_shape >= 0) force = force_shape;
     if (force >= 0 && force < kNumShapes && kShapes[force].mf == (m16 ? 16 : 32) &&
         p.Mpad % kShapes[force].m_t() == 0 && !(p.phase_major && p.Cout % kShapes[force].m_t() != 0))
         shape = force;
     const Geometry g = kShapes[shape];
     li.shape = shape;
-    li.lds = plan_staging(p, g, env_int("FV_KROWS", 176));
+    li.lds = plan_staging(p, g, tuning().krows);
     if (!li.lds) return fail(FV_ERR_UNSUPPORTED, "conv: k=%d dil=%d cannot be staged (window too wide)", p.k, p.dil);
     p.n_tiles = (p.Tq + g.n_t() - 1) / g.n_t();
     const int m_tiles = p.Mpad / g.m_t();
     // runs of consecutive time tiles per block: cap the grid
-    const int cap = env_int("FV_GRID_CAP", 1024);
+    const int cap = tuning().grid_cap;
     int runs = p.n_tiles;
     const long per_batch_cap = cap / ((long)p.B * m_tiles) > 0 ? cap / ((long)p.B * m_tiles) : 1;
     if (runs > per_batch_cap) runs = (int)per_batch_cap;
@@ -288,7 +283,7 @@ int launch_conv_sum3(ConvParams* ps, hipStream_t s) {
 int launch_conv_group(ConvParams* ps, int n, hipStream_t s) {
     // three members (11, 7, 3 taps) or the two large ones (11, 7): the kernel is the same, the
     // third problem just has an empty grid
-    bool ok = (n == 3 || n == 2) && !env_int("FV_NO_GROUP", 0);
+    bool ok = (n == 3 || n == 2) && !tuning().no_group;
     LaunchInfo li[3];
     int order[3] = {0, 1, 2};
     if (ok) {

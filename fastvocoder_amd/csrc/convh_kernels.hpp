@@ -183,6 +183,7 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
     decode(item, b, ntile, mtile);
     if (!first) pair_barrier();                         // everybody is done with the previous member's LDS
     pair_stamp(p, 8, wave, lane, 7, 12);
+    float bad = 0.f;                                    // range guard (pairh_kernels.hpp range_note)
     ConvHRaw<G> raw;
     auto chunk_channels = [&](int c) { return G::TR ? min(G::C, p.ctot - c * G::C) : G::C; };
     convh_load_raw<G>(raw, mb.x + b * ustride, p.T, ntile * G::NTC - G::P, tid, true, p.reflect != 0, chunk_channels(0));
@@ -372,6 +373,7 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             v[i] = fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[h][i];
+                            range_note(bad, v[i]);
                             a[i] = act(v[i], p.act_slope);
                             if (!mb.y_act) v[i] = a[i];              // no twin: y itself is stored activated
                         }
@@ -432,7 +434,10 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
                 for (int f = 0; f < G::NFW; ++f) {
                     float v[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = hi[h][f][i];
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = hi[h][f][i];
+                        range_note(bad, v[i]);
+                    }
                     const int t = t0 + col0 + f * 16;
                     pair_store(p, mb.y, mb.y_act, p.ctot, b, 64 * mtile + row0 + 16 * h, t, t < p.T && !(p.dbg & 8), v, fin);
                 }
@@ -452,6 +457,7 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
     }
     // the DMAs requested for a next item that does not exist wrote zeros; nothing is in flight past this point
     pair_wait_vm0();
+    range_flag(p, bad);
 }
 
 // 8 waves per block, one block per CU (150-160 KB of LDS): 2 waves per SIMD, 256 VGPRs
@@ -467,21 +473,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     PairParams q;
     q.n_members = p.n_members; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = p.out_div;
     q.act_slope = p.act_slope; q.post = p.post; q.x_off = p.x_off; q.img_off = p.img_off; q.dbg = p.dbg; q.trace = p.trace;
-    q.ctot = p.ctot; q.nch = p.nch; q.nmt = p.nmt; q.reflect = p.reflect;
+    q.ctot = p.ctot; q.nch = p.nch; q.nmt = p.nmt; q.reflect = p.reflect; q.guard = p.guard;
     int n_items[3], cost[3];
 #pragma unroll
     for (int m = 0; m < 3; ++m) { n_items[m] = p.m[m].n_items; cost[m] = p.m[m].cost; }
     asm volatile("" ::"s"(q.n_members), "s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.out_div), "s"(q.act_slope),
                  "s"(q.post), "s"(q.x_off), "s"(q.img_off), "s"(q.dbg), "s"(q.trace), "s"(n_items[0]), "s"(n_items[1]),
-                 "s"(n_items[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.reflect));
+                 "s"(n_items[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.reflect),
+                 "s"(q.guard));
     // this block's items of each member: from the host's schedule (pair_schedule: few, unequal items per block), or its
     // contiguous share of the cost-weighted item sequence
-    const int* const sched = p.sched;
+    const bool sched = p.sched_on != 0;
     int slo[3] = {0, 0, 0}, shi[3] = {0, 0, 0};
     if (sched) {
-        const int* e = sched + blockIdx.x * 6;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) { slo[m] = e[2 * m]; shi[m] = e[2 * m + 1]; }
+        // two words of the kernel arguments per block: (lo : 11, count : 5) of member 0 | member 1 << 16, member 2
+        const unsigned w0 = p.sched[2 * blockIdx.x], w1 = p.sched[2 * blockIdx.x + 1];
+        slo[0] = (int)(w0 & 2047u);         shi[0] = slo[0] + (int)((w0 >> 11) & 31u);
+        slo[1] = (int)((w0 >> 16) & 2047u); shi[1] = slo[1] + (int)(w0 >> 27);
+        slo[2] = (int)(w1 & 2047u);         shi[2] = slo[2] + (int)((w1 >> 11) & 31u);
         asm volatile("" ::"s"(slo[0]), "s"(shi[0]), "s"(slo[1]), "s"(shi[1]), "s"(slo[2]), "s"(shi[2]));
     }
     long long total = 0;
@@ -532,13 +541,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     q.n_members = 1; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = 1.f;
     q.act_slope = p.act_slope; q.post = 0; q.x_off = p.x_off; q.img_off = p.img_off; q.dbg = p.dbg; q.trace = p.trace;
     q.ctot = p.ctot; q.nch = p.nch; q.nmt = p.nmt; q.reflect = 0; q.ups = p.ups; q.pad_t = p.pad_t; q.Tout = p.Tout; q.cout = p.cout;
+    q.guard = p.guard;
     PairMember mb;
     mb.x = p.m[0].x; mb.w1 = p.m[0].w1; mb.b1 = p.m[0].b1; mb.res = nullptr; mb.add1 = nullptr; mb.add2 = nullptr;
     mb.y = p.m[0].y; mb.y_act = p.m[0].y_act; mb.k = 2; mb.n_tiles = p.m[0].n_tiles;
     const int n_items = p.m[0].n_items;
     asm volatile("" ::"s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.act_slope), "s"(q.x_off), "s"(q.img_off), "s"(q.dbg),
                  "s"(q.trace), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.ups), "s"(q.pad_t), "s"(q.Tout), "s"(q.cout), "s"(mb.x), "s"(mb.w1),
-                 "s"(mb.b1), "s"(mb.y), "s"(mb.y_act), "s"(mb.n_tiles), "s"(n_items));
+                 "s"(mb.b1), "s"(mb.y), "s"(mb.y_act), "s"(mb.n_tiles), "s"(n_items), "s"(q.guard));
     // equal items: block b takes [b n / nblk, (b + 1) n / nblk)
     const int lo = (int)((long long)blockIdx.x * n_items / q.nblk), hi = (int)((long long)(blockIdx.x + 1) * n_items / q.nblk);
     if (lo < hi) convh_run_member<ConvHGeom<CG, 2, 2, 1, true>>(q, mb, lo, hi, smem, wave, lane, true);

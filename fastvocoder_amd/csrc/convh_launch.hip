@@ -1,6 +1,7 @@
 // Host side of the split-f16 wide-channel conv kernels (convh_kernels.hpp): validation, tile geometry, LDS layout,
 // persistent grid, launch.  Device code: convh_inst_c64.hip / convh_inst_c128.hip.
 #include <stdlib.h>
+#include <string.h>
 
 #include <array>
 #include <map>
@@ -26,66 +27,70 @@ extern template int launch_convh_geom<2, 2>(const PairParams&, int, size_t, hipS
 // member) 56.7 -> 47.7 us at 128 channels, 49.7 -> 47.0 at 64; three-member launches gain nothing (128 channels:
 // a 7-tap + 3-tap block pays a member switch, a pipeline drain and refill, for what it saves) or lose (64 channels,
 // 58 vs 55 us: more switches than the contiguous cut has), so they keep the contiguous cut (FV_SCHED=2: all).
-const int* pair_schedule(const PairParams& p, int nblk) {
+void pair_schedule(PairParams& p, int nblk) {
+    typedef std::array<unsigned, 2 * kSchedBlocks> Table;
     static std::mutex mu;
-    static std::map<std::array<int, 10>, const int*> cache;
-    const char* off = fv_getenv("FV_SCHED");
-    if (off && atoi(off) == 0) return nullptr;
+    static std::map<std::array<int, 9>, Table> cache;           // host memory only; a process sees a handful of shapes
+    p.sched_on = 0;
+    const Tuning& tn = tuning();
+    if (tn.sched == 0) return;
     long long items = 0;
     for (int m = 0; m < p.n_members; ++m) items += p.m[m].n_items;
-    if (p.n_members < 2 || nblk < 2 || items > 6LL * nblk) return nullptr;
-    if (p.n_members != 2 && !(off && atoi(off) == 2)) return nullptr;
-    const int sw = fv_getenv("FV_SCHED_SWITCH") ? atoi(fv_getenv("FV_SCHED_SWITCH")) : 4;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::array<int, 10> key = {dev, nblk, p.n_members, sw, 0, 0, 0, 0, 0, 0};
+    if (p.n_members < 2 || nblk < 2 || nblk > kSchedBlocks || items > 6LL * nblk) return;
+    if (p.n_members != 2 && tn.sched != 2) return;
+    for (int m = 0; m < p.n_members; ++m)
+        if (p.m[m].n_items > 2047) return;                       // 11-bit item numbers
+    const int sw = tn.sched_switch;
+    std::array<int, 9> key = {nblk, p.n_members, sw, 0, 0, 0, 0, 0, 0};
     for (int m = 0; m < p.n_members; ++m) {
-        key[4 + 2 * m] = p.m[m].n_items;
-        key[5 + 2 * m] = p.m[m].cost;
+        key[3 + 2 * m] = p.m[m].n_items;
+        key[4 + 2 * m] = p.m[m].cost;
     }
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
-    if (it != cache.end()) return it->second;
-    if (cache.size() >= 256) return nullptr;                     // (a process sees a handful of shapes)
-    int order[3] = {0, 1, 2};
-    for (int i = 0; i < p.n_members; ++i)
-        for (int j = i + 1; j < p.n_members; ++j)
-            if (p.m[order[j]].cost > p.m[order[i]].cost) std::swap(order[i], order[j]);
-    std::vector<long long> load(nblk, 0);
-    std::vector<int> cnt((size_t)nblk * 3, 0);
-    for (int oi = 0; oi < p.n_members; ++oi) {
-        const int m = order[oi], c = p.m[m].cost;
-        for (int i = 0; i < p.m[m].n_items; ++i) {
-            int best = 0;
-            long long best_end = -1;
-            for (int b = 0; b < nblk; ++b) {
-                const long long end = load[b] + c + (cnt[(size_t)b * 3 + m] == 0 && load[b] > 0 ? sw : 0);
-                if (best_end < 0 || end < best_end) {
-                    best_end = end;
-                    best = b;
+    if (it == cache.end()) {
+        if (cache.size() >= 256) return;
+        int order[3] = {0, 1, 2};
+        for (int i = 0; i < p.n_members; ++i)
+            for (int j = i + 1; j < p.n_members; ++j)
+                if (p.m[order[j]].cost > p.m[order[i]].cost) std::swap(order[i], order[j]);
+        std::vector<long long> load(nblk, 0);
+        std::vector<int> cnt((size_t)nblk * 3, 0);
+        for (int oi = 0; oi < p.n_members; ++oi) {
+            const int m = order[oi], c = p.m[m].cost;
+            for (int i = 0; i < p.m[m].n_items; ++i) {
+                int best = 0;
+                long long best_end = -1;
+                for (int b = 0; b < nblk; ++b) {
+                    const long long end = load[b] + c + (cnt[(size_t)b * 3 + m] == 0 && load[b] > 0 ? sw : 0);
+                    if (best_end < 0 || end < best_end) {
+                        best_end = end;
+                        best = b;
+                    }
                 }
+                load[best] = best_end;
+                ++cnt[(size_t)best * 3 + m];
             }
-            load[best] = best_end;
-            ++cnt[(size_t)best * 3 + m];
         }
-    }
-    std::vector<int> table((size_t)nblk * 6, 0);
-    for (int m = 0; m < p.n_members; ++m) {
-        int at = 0;
+        Table t = {};
+        bool fits = true;
+        int at[3] = {0, 0, 0};
         for (int b = 0; b < nblk; ++b) {
-            table[(size_t)b * 6 + 2 * m] = at;
-            at += cnt[(size_t)b * 3 + m];
-            table[(size_t)b * 6 + 2 * m + 1] = at;
+            unsigned e[3] = {0, 0, 0};
+            for (int m = 0; m < p.n_members; ++m) {
+                const int c = cnt[(size_t)b * 3 + m];
+                if (c > 31) fits = false;                        // 5-bit counts
+                e[m] = (unsigned)at[m] | ((unsigned)c << 11);
+                at[m] += c;
+            }
+            t[2 * b] = e[0] | (e[1] << 16);
+            t[2 * b + 1] = e[2];
         }
+        if (!fits) return;
+        it = cache.emplace(key, t).first;
     }
-    int* dptr = nullptr;
-    if (hipMalloc(&dptr, table.size() * sizeof(int)) != hipSuccess) return nullptr;
-    if (hipMemcpy(dptr, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(dptr);
-        return nullptr;
-    }
-    cache[key] = dptr;
-    return dptr;
+    memcpy(p.sched, it->second.data(), sizeof(unsigned) * 2 * (size_t)nblk);
+    p.sched_on = 1;
 }
 
 // run-time mirror of ConvHGeom<>
@@ -136,7 +141,7 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
         p.nch = g.NCH;
         p.nmt = g.NMT;
         // a tile costs its stages (LDS / matrix time) plus loads, conversion, epilogue
-        mb.cost = g.NST * g.NCH + (fv_getenv("FV_CONVH_SKEL") ? atoi(fv_getenv("FV_CONVH_SKEL")) : (C == 64 ? 5 : 2));
+        mb.cost = g.NST * g.NCH + (tuning().convh_skel >= 0 ? tuning().convh_skel : (C == 64 ? 5 : 2));
         if (g.XIMG > img_bytes) img_bytes = g.XIMG;
         items += mb.n_items;
         flops += 2.0 * p.B * (double)C * C * mb.k * p.T;
@@ -152,13 +157,12 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     const size_t lds = floats * 4;
     if (lds > 160 * 1024) return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: %zu bytes of LDS", lds);
     const int cus = device_cu_count();
-    const char* force = fv_getenv("FV_CONVH_BLOCKS");
-    long long nblk = force && atoi(force) > 0 ? atoi(force) : cus;     // one 8-wave block per CU
+    long long nblk = tuning().convh_blocks > 0 ? tuning().convh_blocks : cus;     // one 8-wave block per CU
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
-    p.sched = pair_schedule(p, p.nblk);
-    p.dbg = tuning_dbg_flags();
-    p.trace = fv_getenv("FV_PAIR_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(fv_getenv("FV_PAIR_TRACE_PTR"), nullptr, 0)) : nullptr;
+    pair_schedule(p, p.nblk);
+    p.dbg = tuning().pair_dbg;
+    p.trace = reinterpret_cast<unsigned long long*>(tuning().trace_ptr);
     profile_begin(s);
     const int rc = C >= 128 ? launch_convh_geom<4, 2>(p, dil, lds, s) : launch_convh_geom<2, 2>(p, dil, lds, s);
     profile_end(s, C == 64 ? FV_KERNEL_CONVH64 : FV_KERNEL_CONVH128, flops, bytes);
@@ -203,11 +207,11 @@ int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout,
     p.x_off = 0;                       // ring of 4 weight stages
     p.img_off = 4 * 16384 / 4;
     const size_t lds = 4 * 16384 + (size_t)img_bytes;
-    const char* force = fv_getenv("FV_CONVH_BLOCKS");
-    long long nblk = force && atoi(force) > 0 ? atoi(force) : device_cu_count();
+    long long nblk = tuning().convh_blocks > 0 ? tuning().convh_blocks : device_cu_count();
     if (nblk > mb.n_items) nblk = mb.n_items;
     p.nblk = (int)nblk;
-    p.dbg = tuning_dbg_flags();
+    p.sched_on = 0;
+    p.dbg = tuning().pair_dbg;
     p.trace = nullptr;
     profile_begin(s);
     const int rc = launch_convt_geom(p, lds, s);
@@ -249,7 +253,7 @@ int launch_convp(PairParams p, int dil, hipStream_t s) {
         const int nout = g.NTC - (mb.k - 1);
         mb.n_tiles = (p.T + nout - 1) / nout;
         mb.n_items = mb.n_tiles * p.B;
-        mb.cost = 2 * g.NST + (fv_getenv("FV_CONVP_SKEL") ? atoi(fv_getenv("FV_CONVP_SKEL")) : 5);
+        mb.cost = 2 * g.NST + tuning().convp_skel;
         if (g.XIMG > img_bytes) img_bytes = g.XIMG;
         items += mb.n_items;
         flops += 2.0 * 2.0 * p.B * (double)C * C * mb.k * p.T;
@@ -266,12 +270,11 @@ int launch_convp(PairParams p, int dil, hipStream_t s) {
     floats += 2 * (size_t)C;
     const size_t lds = floats * 4;
     if (lds > 160 * 1024) return fail(FV_ERR_UNSUPPORTED, "resblock pair: %zu bytes of LDS", lds);
-    const char* force = fv_getenv("FV_CONVH_BLOCKS");
-    long long nblk = force && atoi(force) > 0 ? atoi(force) : device_cu_count();
+    long long nblk = tuning().convh_blocks > 0 ? tuning().convh_blocks : device_cu_count();
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
-    p.sched = pair_schedule(p, p.nblk);
-    p.dbg = tuning_dbg_flags();
+    pair_schedule(p, p.nblk);
+    p.dbg = tuning().pair_dbg;
     p.trace = nullptr;
     profile_begin(s);
     const int rc = dil == 1 ? launch_convp_dil<1>(p, lds, s) : dil == 3 ? launch_convp_dil<3>(p, lds, s) : launch_convp_dil<5>(p, lds, s);

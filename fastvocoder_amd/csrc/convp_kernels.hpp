@@ -61,6 +61,7 @@ __device__ __forceinline__ void convp_run_member(const PairParams& p, const Pair
     int g0 = 0;
     int b = item / mb.n_tiles, tile = item - b * mb.n_tiles;
     if (!first) pair_barrier();
+    float bad = 0.f;                                     // range guard (pairh_kernels.hpp range_note)
     ConvHRaw<H> raw;
     convh_load_raw<H>(raw, mb.x + b * ustride, p.T, tile * G::NOUT - G::P1 - G::P2, tid, true);
 #pragma unroll
@@ -262,7 +263,10 @@ __device__ __forceinline__ void convp_run_member(const PairParams& p, const Pair
             for (int f = 0; f < G::NFW; ++f) {
                 float v[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = hi[h][f][i];
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = hi[h][f][i];
+                    range_note(bad, v[i]);
+                }
                 const int col = col0 + f * 16;
                 pair_store(p, mb.y, mb.y_act, G::C, b, row0 + 16 * h, t0 + col,
                            col < G::NOUT && t0 + col < p.T && !(p.dbg & 8), v, fin);
@@ -275,6 +279,7 @@ __device__ __forceinline__ void convp_run_member(const PairParams& p, const Pair
         tile = ntile;
     }
     pair_wait_vm0();
+    range_flag(p, bad);
 }
 
 // one 8-wave block per CU (150 KB of LDS), 2 waves per SIMD
@@ -287,21 +292,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     PairParams q;
     q.n_members = p.n_members; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = p.out_div;
     q.act_slope = p.act_slope; q.post = p.post; q.x_off = p.x_off; q.img_off = p.img_off; q.mid_off = p.mid_off;
-    q.bias_off = p.bias_off; q.dbg = p.dbg; q.trace = p.trace;
+    q.bias_off = p.bias_off; q.dbg = p.dbg; q.trace = p.trace; q.guard = p.guard;
     int n_items[3], cost[3];
 #pragma unroll
     for (int m = 0; m < 3; ++m) { n_items[m] = p.m[m].n_items; cost[m] = p.m[m].cost; }
     asm volatile("" ::"s"(q.n_members), "s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.out_div), "s"(q.act_slope),
                  "s"(q.post), "s"(q.x_off), "s"(q.img_off), "s"(q.mid_off), "s"(q.bias_off), "s"(q.dbg), "s"(q.trace),
-                 "s"(n_items[0]), "s"(n_items[1]), "s"(n_items[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]));
+                 "s"(n_items[0]), "s"(n_items[1]), "s"(n_items[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]), "s"(q.guard));
     // this block's items of each member: from the host's schedule (pair_schedule: few, unequal items per block), or its
     // contiguous share of the cost-weighted item sequence
-    const int* const sched = p.sched;
+    const bool sched = p.sched_on != 0;
     int slo[3] = {0, 0, 0}, shi[3] = {0, 0, 0};
     if (sched) {
-        const int* e = sched + blockIdx.x * 6;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) { slo[m] = e[2 * m]; shi[m] = e[2 * m + 1]; }
+        // two words of the kernel arguments per block: (lo : 11, count : 5) of member 0 | member 1 << 16, member 2
+        const unsigned w0 = p.sched[2 * blockIdx.x], w1 = p.sched[2 * blockIdx.x + 1];
+        slo[0] = (int)(w0 & 2047u);         shi[0] = slo[0] + (int)((w0 >> 11) & 31u);
+        slo[1] = (int)((w0 >> 16) & 2047u); shi[1] = slo[1] + (int)(w0 >> 27);
+        slo[2] = (int)(w1 & 2047u);         shi[2] = slo[2] + (int)((w1 >> 11) & 31u);
         asm volatile("" ::"s"(slo[0]), "s"(shi[0]), "s"(slo[1]), "s"(shi[1]), "s"(slo[2]), "s"(shi[2]));
     }
     long long total = 0;

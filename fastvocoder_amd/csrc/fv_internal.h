@@ -106,7 +106,7 @@ struct ConvParams {
     int nx_inst, nw_inst;         // 64-lane DMA instructions per stage for the x / w image
     int red_off;    // float offset of the split-K reduction area in LDS
     int vec_ok;     // rows are 16-byte aligned: float4 global loads allowed
-    int dbg;        // ablation switches (FV_DBG, tuning only): 1 no epilogue, 2 no restaging, 4 no MFMA
+    int dbg;        // ablation switches (Tuning::conv_dbg, timing experiments only): 1 no epilogue, 2 no restaging, 4 no MFMA
     double alg_flops;   // > 0: algorithmic FLOPs of the layer for the measurement hook (a transposed conv in
                         // polyphase form executes zero taps that the reference's MAC count does not contain)
 };
@@ -130,14 +130,32 @@ int launch_conv_sum3(ConvParams* ps, hipStream_t stream);
 // tens of microseconds of host time on a path whose whole forward is under a millisecond); api.hip
 int allow_dynamic_lds(const void* kernel, size_t bytes);
 int device_cu_count();
-// FV_PAIR_DBG: ablation switches of the persistent kernels (timing experiments; the results are WRONG).  Honoured only
-// together with FV_TUNING=1 so that a stray environment variable cannot corrupt a product run.
-int tuning_dbg_flags();
-// getenv for the launch path: a launch reads eight to ten tuning variables and glibc's getenv walks the whole
-// environment for each (~0.3 us; 45 launches make a MelGAN forward at batch 1, which is host-bound).  Values are cached
-// per thread until the environment changes (detected by a hash of the environ entries' addresses: setenv / putenv /
-// unsetenv replace or move entries).
-const char* fv_getenv(const char* name);
+// Tuning switches of the launchers.  These are NOT product configuration: the defaults below are what every product run
+// uses, and the launch path never reads the environment.  A process started with FV_TUNING=1 reads FV_<NAME> once, at
+// the first launch (tools/ sweeps); tests change entries through fv_tuning_set (api.hip) to prove that block counts and
+// schedules do not change results.  pair_dbg / conv_dbg are ablation switches for timing experiments: results are WRONG.
+struct Tuning {
+    int pair_dbg = 0;        // persistent kernels: 1 no x prefetch after a block's first tile, 2 no conversion, 4 no MFMA, 8 no stores, 16 no residual loads
+    int conv_dbg = 0;        // fp32 conv kernels (FV_DBG): 1 no epilogue, 2 no restaging, 4 no MFMA
+    int sched = 1;           // 0: contiguous cost cut only; 1: host schedule for two-member launches; 2: ... and three
+    int sched_switch = 4;    // cost units a block pays for taking up another member (pair_schedule)
+    int convh_skel = -1;     // per-tile constant of the partition cost (-1: the launcher's own: 5 at 64 channels, 2 above)
+    int convp_skel = 5;
+    int pairh_skel = -1;     // (-1: 8 at 16 channels, 6 at 32)
+    int pair_skel = -1;      // (-1: 4 at 16 channels, 3 at 32)
+    int convh_blocks = 0;    // > 0: persistent blocks of the convh / convp / convt launches (default: one per CU)
+    int pair_blocks = 0;     // > 0: ... of the pair launches
+    int sum3_min = 800;      // fewest tiles for which the three last convs of an MRF stage run as ONE fp32 launch
+    int lds_budget = 39;     // fp32 conv kernels: KiB of LDS per block
+    int units = 500;
+    int shape16 = -1, shape32 = -1, shape64 = -1;   // >= 0: force a tile shape of the fp32 conv kernel
+    int krows = 176;
+    int grid_cap = 1024;
+    int no_group = 0;
+    int convh_carry = 1;     // weight ring and window prefetch carried across a member switch (convh / convp)
+    unsigned long long trace_ptr = 0;   // FV_PAIR_TRACE_PTR (with -DFV_PAIR_TRACE builds only): device buffer for cycle stamps
+};
+const Tuning& tuning();
 
 // ---- fused ResBlock1 pairs (pair_kernels.hpp / pair_launch.hip) ---------------------------------------
 // one ResBlock's pair (a "member" of the launch)
@@ -159,6 +177,8 @@ struct PairMember {
     int w_off;           // float offset of this member's two weight images in dynamic LDS
 };
 
+constexpr int kSchedBlocks = 256;     // blocks a launch's schedule can describe (one per CU)
+
 struct PairParams {
     PairMember m[3];
     int n_members;
@@ -174,8 +194,10 @@ struct PairParams {
     const float* fold_w; // pairh, C = 16, one member (pairh_run_member<G, true>): conv_post folded into the pair -- its
     const float* fold_b; //   weights [C][7], bias [1] or null, output [B, 1, T]; `post` is applied to that output,
     float* fold_y;       //   act_slope to the pair's own (never stored) output in front of it
-    const int* sched;    // convh / convp: per block [member][lo, hi) item ranges (pair_schedule), or null: the kernel
-                         // cuts the cost-weighted item sequence into nblk contiguous shares itself (pair_share)
+    int* guard;          // split-f16 kernels: device-visible word set to 1 when a final value is not finite (an operand
+                         // left the f16 range): pairh_kernels.hpp range_note; null: no check
+    int sched_on;        // convh / convp: sched[] holds this launch's block schedule (pair_schedule); 0: the kernel cuts
+                         // the cost-weighted item sequence into nblk contiguous shares itself (pair_share)
     int reflect;         // convh: rows outside [0, T) are the mirrored samples (ReflectionPad1d) instead of zeros
     int ups, pad_t, Tout, cout;   // transposed conv (convt_kernel): stride, padding, output samples, output channels;
                                   // T = input samples, ctot = input channels (64: half a chunk), rows m = co * ups +
@@ -185,9 +207,13 @@ struct PairParams {
     int img_off;         // split-f16 kernels: float offset of the x image (x_off: the member's packed weights)
     int bias_off;        // ... of the staged biases: per member [b1[C] | b2[C]]
     unsigned long long* trace;   // tuning aid (FV_PAIR_TRACE_PTR): s_memtime stamps [block < 8][wave][tile < 8][16 events]
-    int dbg;             // ablation switches (FV_PAIR_DBG, timing experiments only -- results are wrong):
+    int dbg;             // ablation switches (Tuning::pair_dbg, timing experiments only -- results are wrong):
                          // 1 no x DMA after a block's first tile, 2 no activation pass, 4 no MFMA,
                          // 8 no stores, 16 no residual loads
+    // Block schedule (few, unequal items per block): two words per block, member m's items [lo, lo + count) packed as
+    // lo (11 bits) | count (5 bits): word 0 = member 0 | member 1 << 16, word 1 = member 2.  Part of the kernel
+    // arguments: no device table, no copy, legal under stream capture.
+    unsigned sched[2 * kSchedBlocks];
 };
 
 // tile geometry of the pair kernels, the run-time mirror of PairGeom<> (pair_kernels.hpp)
@@ -232,9 +258,9 @@ struct ConvHShape {
 ConvHShape convh_shape(int C, int k, int dil);
 int launch_convh(PairParams p, int C, int dil, hipStream_t stream);
 // Few, unequal items per block (batch 1: 378 items of three costs on 256 blocks): a longest-processing-time-first
-// assignment instead of the contiguous cut -- device table [nblk][3][2] (cached per shape), or null when every block
+// assignment instead of the contiguous cut, written into p.sched (host cache per shape); p.sched_on = 0 when every block
 // has many items anyway
-const int* pair_schedule(const PairParams& p, int nblk);
+void pair_schedule(PairParams& p, int nblk);
 // fused ResBlock pair at C = 64 with split-f16 operands and streamed weights (convp_kernels.hpp): members use x, w1, w2
 // (fv_pack_pair_weight_ex images), b1, b2, add1 / add2, y, y_act, k
 int launch_convp(PairParams p, int dil, hipStream_t stream);

@@ -102,7 +102,7 @@ static int launch_pairs_split(PairParams p, int C, int dil, hipStream_t s) {
         // a tile costs its K steps (two convs, LDS-bandwidth bound) plus a part that does not depend on the taps
         // (loads, convert pass, epilogues, stores, barriers): measured per member alone (tools/pair_bench.py)
         // 0.8 us per step + 8 steps' worth at C = 16, 1.6 us per step + 6 steps' worth at C = 32 (240-column tiles)
-        mb.cost = g.KS + (fv_getenv("FV_PAIRH_SKEL") ? atoi(fv_getenv("FV_PAIRH_SKEL")) : (C == 16 ? 8 : 6));
+        mb.cost = g.KS + (tuning().pairh_skel >= 0 ? tuning().pairh_skel : (C == 16 ? 8 : 6));
         mb.w_off = 0;
         if (2 * g.WB > w_bytes) w_bytes = 2 * g.WB;
         if (g.XIMG > img_bytes) img_bytes = g.XIMG;
@@ -126,12 +126,12 @@ static int launch_pairs_split(PairParams p, int C, int dil, hipStream_t s) {
     floats += 2 * (size_t)C;
     const size_t lds = floats * 4;
     if (lds > (C == 16 ? 80 : 160) * 1024) return fail(FV_ERR_UNSUPPORTED, "resblock pair, split-f16: %zu bytes of LDS", lds);
-    const char* force = fv_getenv("FV_PAIR_BLOCKS");
     // 15-16 waves per CU (4 per SIMD): two 8-wave blocks at C = 16, one 15-wave block at C = 32
-    long long nblk = force && atoi(force) > 0 ? atoi(force) : (C == 16 ? 2LL : 1LL) * num_cus();
+    long long nblk = tuning().pair_blocks > 0 ? tuning().pair_blocks : (C == 16 ? 2LL : 1LL) * num_cus();
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
-    p.dbg = tuning_dbg_flags();
+    p.sched_on = 0;
+    p.dbg = tuning().pair_dbg;
     p.trace = nullptr;
     profile_begin(s);
     const int rc = C == 16 ? launch_pairh_geom<1, FV_PAIRH16_NF, FV_PAIRH16_NG>(p, dil, lds, s) : launch_pairh_geom<2, 1, FV_PAIRH32_NG>(p, dil, lds, s);
@@ -187,7 +187,7 @@ int launch_pairs(PairParams p, int C, int dil, hipStream_t s) {
         // a tile costs its MFMA time (proportional to the taps) plus a per-tile part that does not depend on
         // them (staging, activation pass, barriers, epilogue): measured 4.2k + 1.1k * taps cycles at C = 16,
         // 6k + 2.0k * taps at C = 32 (tools/pair_trace.py) -- in units of one tap's time
-        mb.cost = mb.k + (fv_getenv("FV_PAIR_SKEL") ? atoi(fv_getenv("FV_PAIR_SKEL")) : (C == 16 ? 4 : 3));
+        mb.cost = mb.k + (tuning().pair_skel >= 0 ? tuning().pair_skel : (C == 16 ? 4 : 3));
         if (p.sum) {
             mb.w_off = (int)floats;
             floats += 2 * (size_t)g.WF;
@@ -221,12 +221,13 @@ int launch_pairs(PairParams p, int C, int dil, hipStream_t s) {
     int per_cu = (int)(160 * 1024 / lds);
     if (per_cu * g0.NW > 16) per_cu = 16 / g0.NW;      // <= 128 VGPRs: 4 waves per SIMD
     if (per_cu < 1) per_cu = 1;
-    const char* force = fv_getenv("FV_PAIR_BLOCKS");
-    long long nblk = force && atoi(force) > 0 ? atoi(force) : (long long)per_cu * num_cus();
+    long long nblk = tuning().pair_blocks > 0 ? tuning().pair_blocks : (long long)per_cu * num_cus();
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
-    p.dbg = tuning_dbg_flags();
-    p.trace = fv_getenv("FV_PAIR_TRACE_PTR") ? reinterpret_cast<unsigned long long*>(strtoull(fv_getenv("FV_PAIR_TRACE_PTR"), nullptr, 0)) : nullptr;
+    p.sched_on = 0;
+    p.guard = nullptr;                 // (exact fp32 products: no operand range to guard)
+    p.dbg = tuning().pair_dbg;
+    p.trace = reinterpret_cast<unsigned long long*>(tuning().trace_ptr);
 
     profile_begin(s);
     int rc;

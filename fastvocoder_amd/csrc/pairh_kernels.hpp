@@ -34,7 +34,8 @@
 // the whole tile, no LDS landing buffer); conv1 -> + b1, lrelu, zero outside [0, T), split -> intermediate image;
 // barrier; conv2 -> + b2 + residual (fp32, from global memory); convert pass for the next tile (lrelu, split,
 // transpose registers -> x image); stores -> HBM; barrier.  Two barriers per tile.
-// Limits: |activation| and |weight| < 65504 (f16 range); beyond that use the fp32 kernels (FV_PAIR_PREC=f32).
+// Limits: |activation| and |weight| < 65520 (f16 range); beyond that the range guard (range_note / range_flag below) fires
+// and the host repeats the call on the fp32 kernels.
 #pragma once
 #include "pair_kernels.hpp"
 
@@ -57,6 +58,16 @@ __device__ __forceinline__ float split_act(float v, float slope) {
 }
 __device__ __forceinline__ _Float16 split_rem(float v, _Float16 h1) {
     return (_Float16)fmaf((float)h1, -kSplitScale, v * kSplitScale);
+}
+
+// Range guard of the split-f16 kernels.  An operand beyond the f16 range (|v| >= 65520: f16(v) = inf) turns every output
+// it feeds into inf or NaN -- where the fp32 reference stays finite.  Every split kernel therefore folds its final values
+// into one register per thread (v * 0 is NaN exactly when v is inf or NaN: one VALU instruction per stored element) and a
+// thread that saw a non-finite value raises the launch's guard word (PairParams::guard, fv_plan_set_guard): the host then
+// repeats the call on the exact-fp32 kernels (fv_plan_check_range, engine.py NativeModule._guarded).
+__device__ __forceinline__ void range_note(float& bad, float v) { bad = fmaf(v, 0.f, bad); }
+__device__ __forceinline__ void range_flag(const PairParams& p, float bad) {
+    if (p.guard && bad != bad) *p.guard = 1;
 }
 
 template <int MH_, int NF_, int NG_, int KT_, int DIL_>
@@ -270,6 +281,7 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
     int item = item0;
     int b = item / mb.n_tiles, tile = item - b * mb.n_tiles;
     if (!first) pair_barrier();                         // everybody is done with the previous member's LDS
+    float bad = 0.f;                                    // range guard: NaN once a final value was not finite
     PairHRaw<G> raw;
     pairh_load_raw<G>(raw, mb.x + b * ustride, p.T, tile * TSTRIDE - TSHIFT - HEAD, tid);
     pairh_stage_weights<G>(mb, wl, wave, lane);
@@ -383,6 +395,12 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
 #pragma unroll
                     for (int i = 0; i < 4; ++i) hi[h][f][i] = (hi[h][f][i] + lo[h][f][i]) + res[h][f][i];
         }
+#pragma unroll
+        for (int h = 0; h < G::MH; ++h)
+#pragma unroll
+            for (int f = 0; f < G::NF; ++f)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) range_note(bad, hi[h][f][i]);
         if constexpr (FOLD) {
             // the activated tile -> LDS (the intermediate image's space: every wave is past its conv2 reads after the
             // barrier), zero outside [0, T) and beyond the tile's valid columns; then one output sample per thread
@@ -435,6 +453,7 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
         b = nb;
         tile = ntile;
     }
+    range_flag(p, bad);
 }
 
 template <int MH, int NF, int NG, int DIL, bool FOLD>
@@ -461,7 +480,7 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu(pairh_w
     PairParams q;
     q.n_members = p.n_members; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = p.out_div;
     q.act_slope = p.act_slope; q.post = p.post; q.x_off = p.x_off; q.img_off = p.img_off; q.mid_off = p.mid_off;
-    q.bias_off = p.bias_off; q.dbg = p.dbg; q.trace = p.trace;
+    q.bias_off = p.bias_off; q.dbg = p.dbg; q.trace = p.trace; q.guard = p.guard;
     q.fold_w = p.fold_w; q.fold_b = p.fold_b; q.fold_y = p.fold_y;
     int n_tiles[3], cost[3];
 #pragma unroll
@@ -469,7 +488,7 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu(pairh_w
     asm volatile("" ::"s"(q.n_members), "s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.out_div), "s"(q.act_slope),
                  "s"(q.post), "s"(q.x_off), "s"(q.img_off), "s"(q.mid_off), "s"(q.bias_off), "s"(q.dbg), "s"(q.trace),
                  "s"(n_tiles[0]), "s"(n_tiles[1]), "s"(n_tiles[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]), "s"(q.fold_w),
-                 "s"(q.fold_b), "s"(q.fold_y));
+                 "s"(q.fold_b), "s"(q.fold_y), "s"(q.guard));
     long long total = 0;
 #pragma unroll
     for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_tiles[m] * q.B * cost[m] : 0;

@@ -9,7 +9,6 @@ into a :class:`PlanBuilder`, which folds weight norm and packs every weight on
 the GPU once, and the resulting native plan is replayed for every call until a
 parameter changes.
 """
-import os
 import warnings
 
 import torch
@@ -35,7 +34,13 @@ def effective_weight(conv):
     return conv.weight.detach().contiguous().float()
 
 
-_SPLIT_CONVT = os.environ.get("FV_SPLIT_CONVT", "1") != "0"   # upsamplers with 64+ input channels on convt_kernel
+def pair_precision(precision, channels):
+    """Arithmetic of the ResBlock / ResidualStack / upsampler kernels for a layer of ``channels`` channels under the
+    policy ``precision``: "split" = split-f16 operands (csrc/pairh_kernels.hpp, convh_kernels.hpp; fp32-class accuracy,
+    DESIGN.md section 3.7) wherever that kernel exists, "f32" = the exact-fp32 MFMA kernels everywhere."""
+    if precision == "f32":
+        return _native.PAIR_F32
+    return _native.PAIR_SPLIT_F16 if _native.pair_supported(channels, 3, 1, _native.PAIR_SPLIT_F16) else _native.PAIR_F32
 
 
 class PlanBuilder:
@@ -52,13 +57,18 @@ class PlanBuilder:
     convs read it with ``pre_slope = 1``.
     """
 
-    def __init__(self, in_channels):
+    def __init__(self, in_channels, precision="split", fold_post=True, guard=None):
+        """``precision``: "split" | "f32" (pair_precision); ``fold_post``: conv_post may ride in the last pair's launch;
+        ``guard``: the owning module's _native.GuardWord -- the pack kernels raise its weight word, the split-f16
+        launches of the finished plan its activation word."""
         self.plan = _native.Plan(in_channels)
         self._next = _native.SLOT_TMP0
         self.ops = []
-        self.lane = 0       # concurrency lane of the ops being recorded (see fv_plan_set_lane)
         self.group = 0      # non-zero: ops recorded under it are mutually independent (fv_plan_set_group)
         self._groups = 0
+        self.precision = precision
+        self.fold_post = bool(fold_post)
+        self.guard = guard
 
     def tmp(self):
         s = self._next
@@ -96,7 +106,7 @@ class PlanBuilder:
             if pad != 0:
                 raise _native.NativeError("BatchNorm folds only into an unpadded conv")
             weight, bias = _native.fold_batchnorm_conv(weight, bias, batchnorm)
-        self.ops.append(dict(kind="conv", lane=self.lane, group=self.group, x=src, y=dst, res=res, acc=acc,
+        self.ops.append(dict(kind="conv", group=self.group, x=src, y=dst, res=res, acc=acc,
                              acc2=acc2, pre_slope=float(pre_slope), own_first=bool(own_first),
                              packed=_native.pack_conv1d(weight), bias=bias,
                              cin=conv.in_channels, cout=conv.out_channels, k=k, dil=d, pad=pad,
@@ -117,7 +127,7 @@ class PlanBuilder:
         w = torch.cat([effective_weight(conv_a), effective_weight(conv_b)], dim=1).contiguous()
         ba, bb = self._bias(conv_a), self._bias(conv_b)
         bias = ba if bb is None else (bb if ba is None else (ba + bb).contiguous())
-        self.ops.append(dict(kind="conv2", lane=self.lane, x=src_a, x2=src_b, y=dst, res=res, acc=SLOT_NONE,
+        self.ops.append(dict(kind="conv2", x=src_a, x2=src_b, y=dst, res=res, acc=SLOT_NONE,
                              pre_slope=float(pre_slope_a), packed=_native.pack_conv1d(w), bias=bias,
                              cin1=conv_a.in_channels, cin2=conv_b.in_channels, cout=conv_a.out_channels,
                              post=post))
@@ -133,29 +143,16 @@ class PlanBuilder:
                 raise _native.NativeError("conv_sum3: three undilated 'same' C->C convs are required")
         biases = [self._bias(c) for c in convs]
         bias = None if all(b is None for b in biases) else sum(b for b in biases if b is not None).contiguous()
-        self.ops.append(dict(kind="sum3", lane=self.lane, x=srcs[0], xb=srcs[1], xc=srcs[2], y=dst,
+        self.ops.append(dict(kind="sum3", x=srcs[0], xb=srcs[1], xc=srcs[2], y=dst,
                              res=ress[0], resb=ress[1], resc=ress[2], tmps=list(tmps), acc=SLOT_NONE,
                              pre_slope=float(pre_slope),
                              packed=[_native.pack_conv1d(effective_weight(c)) for c in convs], bias=bias,
                              channels=c0.in_channels, ks=[c.kernel_size[0] for c in convs],
                              out_div=float(out_div), post=post))
 
-    @staticmethod
-    def pair_precision(channels):
-        """Arithmetic of the fused pair kernels for a stage of ``channels`` channels: split-f16 operands
-        (csrc/pairh_kernels.hpp; fp32-class accuracy) where that kernel exists, the fp32
-        MFMA kernels otherwise.  FV_PAIR_PREC=f32 forces the fp32 kernels (activations beyond the f16 range)."""
-        if os.environ.get("FV_PAIR_PREC", "split") == "f32":
-            return _native.PAIR_F32
-        return _native.PAIR_SPLIT_F16 if _native.pair_supported(channels, 3, 1, _native.PAIR_SPLIT_F16) \
-            else _native.PAIR_F32
-
-    @staticmethod
-    def pair_mode_tag():
-        """Part of a plan's cache key: the arithmetic policy in force (FV_PAIR_PREC; FV_FOLD_POST=0: conv_post as a
-        launch of its own)."""
-        return ("s" if os.environ.get("FV_PAIR_PREC", "split") == "f32" else "h") + \
-            ("n" if os.environ.get("FV_FOLD_POST", "1") == "0" else "")
+    def pair_precision(self, channels):
+        """Arithmetic (PAIR_F32 / PAIR_SPLIT_F16) of a ``channels``-channel layer under this builder's policy."""
+        return pair_precision(self.precision, channels)
 
     @staticmethod
     def pair_fusable(conv1, conv2, prec=None):
@@ -170,15 +167,15 @@ class PlanBuilder:
     def _pair_member(self, conv1, conv2, prec=_native.PAIR_F32):
         if not self.pair_fusable(conv1, conv2, prec):
             raise _native.NativeError("resblock pair: shape not built into the fused kernels")
-        return dict(w1=_native.pack_pair(effective_weight(conv1), prec),
-                    w2=_native.pack_pair(effective_weight(conv2), prec),
+        return dict(w1=_native.pack_pair(effective_weight(conv1), prec, self.guard),
+                    w2=_native.pack_pair(effective_weight(conv2), prec, self.guard),
                     b1=self._bias(conv1), b2=self._bias(conv2), k=conv1.kernel_size[0])
 
     @staticmethod
     def pair_fold_supported(conv1, out_conv, prec):
         """Can ``out_conv`` (HiFi-GAN's conv_post: 16 -> 1 channels, 7 taps, 'same' zero padding) be folded into the
         fused pair in front of it (fv_plan_set_pair_output_conv)?"""
-        return (os.environ.get("FV_FOLD_POST", "1") != "0" and prec == _native.PAIR_SPLIT_F16 and conv1.in_channels == 16
+        return (prec == _native.PAIR_SPLIT_F16 and conv1.in_channels == 16
                 and isinstance(out_conv, torch.nn.Conv1d) and out_conv.in_channels == 16 and out_conv.out_channels == 1
                 and out_conv.kernel_size[0] == 7 and out_conv.stride[0] == 1 and out_conv.dilation[0] == 1
                 and out_conv.padding[0] == 3 and out_conv.groups == 1)
@@ -200,20 +197,19 @@ class PlanBuilder:
         wide = conv1.in_channels >= 64      # two conv launches through the scratch slot ``mid`` (csrc/convh_kernels.hpp)
         if wide and mid == SLOT_NONE:
             raise _native.NativeError("resblock pair: a scratch slot (mid) is needed at 64 channels and above")
-        self.ops.append(dict(kind="pair", lane=self.lane, group=self.group, x=src, y=dst, res=SLOT_NONE,
+        self.ops.append(dict(kind="pair", group=self.group, x=src, y=dst, res=SLOT_NONE,
                              acc=add1, acc2=add2, pre_slope=1.0, slope=float(slope),
                              channels=conv1.in_channels, dil=conv1.dilation[0], prec=prec,
                              out_div=float(out_div), post=post, mid=mid if wide else SLOT_NONE,
                              tmps=[mid] if wide else [], **m))
 
-    @staticmethod
-    def conv_split_supported(conv, pad, pad_mode=PAD_ZERO):
+    def conv_split_supported(self, conv, pad, pad_mode=PAD_ZERO):
         """Is this a 'same' conv (zero or reflection padding ``pad`` applied in front of it) the split-f16 conv kernels
         are built for, and is that arithmetic in force?"""
         c, k, d = conv.in_channels, conv.kernel_size[0], conv.dilation[0]
         return (conv.stride[0] == 1 and conv.groups == 1 and conv.out_channels == c and pad == d * (k - 1) // 2
                 and pad_mode in (PAD_ZERO, PAD_REFLECT) and c in (64, 128, 256, 512)
-                and PlanBuilder.pair_precision(c) == _native.PAIR_SPLIT_F16
+                and self.pair_precision(c) == _native.PAIR_SPLIT_F16
                 and _native.conv_split_supported(c, k, d))
 
     def conv_split(self, conv, src, dst, slope, res=SLOT_NONE, add1=SLOT_NONE, add2=SLOT_NONE, out_div=1.0,
@@ -229,9 +225,9 @@ class PlanBuilder:
                 and pad_mode in (PAD_ZERO, PAD_REFLECT) and (pad_mode == PAD_ZERO or conv.padding[0] == 0)
                 and c in (64, 128, 256, 512) and _native.conv_split_supported(c, k, d)):
             raise _native.NativeError("conv_split: shape not built into the split-f16 conv kernels")
-        self.ops.append(dict(kind="convh", lane=self.lane, group=self.group, x=src, y=dst, res=res, acc=add1, acc2=add2,
+        self.ops.append(dict(kind="convh", group=self.group, x=src, y=dst, res=res, acc=add1, acc2=add2,
                              pre_slope=1.0, slope=float(slope), channels=c, k=k, dil=d, pad_mode=pad_mode,
-                             packed=_native.pack_pair(effective_weight(conv), _native.PAIR_SPLIT_F16),
+                             packed=_native.pack_pair(effective_weight(conv), _native.PAIR_SPLIT_F16, self.guard),
                              bias=self._bias(conv), out_div=float(out_div), post=post))
 
     def mrf_sum(self, pairs, srcs, dst, slope, out_div, post=POST_NONE):
@@ -241,7 +237,7 @@ class PlanBuilder:
         c1 = pairs[0][0]
         if any(p[0].dilation[0] != c1.dilation[0] or p[0].in_channels != c1.in_channels for p in pairs):
             raise _native.NativeError("mrf_sum: the three pairs must share channels and dilation")
-        self.ops.append(dict(kind="mrfsum", lane=self.lane, x=srcs[0], xb=srcs[1], xc=srcs[2], y=dst,
+        self.ops.append(dict(kind="mrfsum", x=srcs[0], xb=srcs[1], xc=srcs[2], y=dst,
                              res=SLOT_NONE, acc=SLOT_NONE, pre_slope=1.0, slope=float(slope),
                              channels=c1.in_channels, dil=c1.dilation[0], members=ms, out_div=float(out_div),
                              post=post))
@@ -254,17 +250,17 @@ class PlanBuilder:
         k, s = convt.kernel_size[0], convt.stride[0]
         p, op = convt.padding[0], convt.output_padding[0]
         cin, cout = convt.in_channels, convt.out_channels
-        if (_SPLIT_CONVT and post == POST_NONE and self.pair_precision(cin) == _native.PAIR_SPLIT_F16
+        if (post == POST_NONE and self.pair_precision(cin) == _native.PAIR_SPLIT_F16
                 and _native.conv_transpose_split_supported(cin, cout, k, s, p, op - int(trim))):
             # kernel = 2 strides, 128+ input channels: split-f16 operands (csrc/convh_kernels.hpp convt_kernel)
             # (src is read raw, the activation is applied on chip: nothing is hoisted into its producer)
-            self.ops.append(dict(kind="convT", split=True, lane=self.lane, x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE,
+            self.ops.append(dict(kind="convT", split=True, x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE,
                                  pre_slope=1.0, slope=float(pre_slope),
-                                 packed=_native.pack_conv_transpose1d_split(effective_weight(convt), s),
+                                 packed=_native.pack_conv_transpose1d_split(effective_weight(convt), s, self.guard),
                                  bias=self._bias(convt), cin=cin, cout=cout, k=k, stride=s, pad=p,
                                  out_pad=op - int(trim), post=post))
             return
-        self.ops.append(dict(kind="convT", lane=self.lane, x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE,
+        self.ops.append(dict(kind="convT", x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE,
                              pre_slope=float(pre_slope),
                              packed=_native.pack_conv_transpose1d(effective_weight(convt), s, p),
                              bias=self._bias(convt), cin=cin, cout=cout,
@@ -276,7 +272,7 @@ class PlanBuilder:
         if conv.stride[0] != 1 or conv.dilation[0] != 1 or conv.groups != 1:
             raise _native.NativeError("UpsampleLayer: only a stride-1, undilated, dense conv is supported")
         k, p, u = conv.kernel_size[0], conv.padding[0], layer.upsample_rate
-        self.ops.append(dict(kind="upconv", lane=self.lane, x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE,
+        self.ops.append(dict(kind="upconv", x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE,
                              pre_slope=float(pre_slope),
                              packed=_native.pack_upsample_conv1d(effective_weight(conv), u, p),
                              bias=self._bias(conv), cin=conv.in_channels, cout=conv.out_channels,
@@ -287,7 +283,7 @@ class PlanBuilder:
         with Cout = 1, kernel L, stride hop (weight [C,1,L] = W^T)."""
         L, C = basis_weight.shape
         w = basis_weight.detach().float().t().contiguous().view(C, 1, L)
-        self.ops.append(dict(kind="convT", lane=self.lane, x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE,
+        self.ops.append(dict(kind="convT", x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE,
                              pre_slope=float(pre_slope), packed=_native.pack_conv_transpose1d(w, hop, 0),
                              bias=None, cin=C, cout=1, k=L, stride=hop, pad=0, out_pad=0, post=POST_NONE))
 
@@ -306,7 +302,7 @@ class PlanBuilder:
     def pqmf_synthesis(self, synthesis_filter, src, dst):
         S = synthesis_filter.shape[1]
         h = synthesis_filter.detach().reshape(S, -1).contiguous().float()
-        self.ops.append(dict(kind="pqmf", lane=self.lane, x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE, pre_slope=1.0, h=h))
+        self.ops.append(dict(kind="pqmf", x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE, pre_slope=1.0, h=h))
 
     # -- activation hoisting ---------------------------------------------------
     def _hoist_activations(self):
@@ -398,7 +394,6 @@ class PlanBuilder:
         self._hoist_activations()
         self.plan.halo_frames = self.receptive_halo()
         for op in self.ops:
-            self.plan.set_lane(op["lane"])
             self.plan.set_group(op.get("group", 0))
             self.plan.set_sum_order(op.get("own_first", False))
             if op["kind"] == "conv":
@@ -459,7 +454,12 @@ class PlanBuilder:
             else:
                 self.plan.add_pqmf_synthesis(op["x"], op["y"], op["h"])
             if "sub" in op:
-                self.plan.set_output_offset(op["sub"], op["sub_y2"])
+                self.plan.set_output_offset(op["sub"], op["sub_y2"], op["y"])
+        # the split-f16 launches of this plan report operands beyond the f16 range through the owner's guard word
+        self.plan.guarded = any(op["kind"] == "convh" or op.get("split") or op.get("prec") == _native.PAIR_SPLIT_F16
+                                for op in self.ops)
+        if self.plan.guarded and self.guard is not None:
+            self.plan.set_guard(self.guard)
         return self.plan
 
 
@@ -467,6 +467,9 @@ class PlanBuilder:
 # (``conv.weight = nn.Parameter(...)``, torch's remove_weight_norm on a submodule) is not in a
 # module's memoised tensor list, so in-place version counters alone would miss it.  Walking
 # the module tree on every call instead costs ~350 us for a HiFi-GAN (a quarter of a step).
+# The epoch only triggers a RE-SCAN of the module's own tensors: plans are keyed on what the scan
+# finds (identity + version of every tensor), so constructing an unrelated module elsewhere in the
+# process costs one walk, not a rebuild of every live model's plans.
 _registration_epoch = [0]
 
 
@@ -480,22 +483,57 @@ torch.nn.modules.module.register_module_buffer_registration_hook(_bump_epoch)
 
 class NativeModule(torch.nn.Module):
     """Base of every module on the path: caches native plans keyed by a name and
-    rebuilds them when any parameter/buffer was modified, replaced or moved."""
+    rebuilds them when any parameter/buffer was modified, replaced or moved.
+
+    Policy attributes (plain attributes: set them on an instance, or on the class for every model):
+
+    ``precision``    "split" (default): ResBlock / ResidualStack / upsampler layers with 16 ... 512 channels form
+                     every fp32 product from split-f16 operand pairs on the f16 matrix cores (fp32-class accuracy,
+                     DESIGN.md section 3.7; domain |v| < 65520); "f32": the exact-fp32 MFMA kernels everywhere.
+    ``range_guard``  what happens when a weight or an activation leaves the split-f16 domain (the reference, fp32
+                     ATen, is defined for any finite fp32).  Weights are always checked when a plan is built.  Activations:
+                     "sync" -- every call waits for its kernels and reads the guard word they raise; an out-of-range
+                         call is repeated on the fp32 kernels before it returns, and the module stays on them (one
+                         warning).  Results are always the reference's; calls are synchronous.
+                     "lazy" -- calls stay stream-ordered (asynchronous); the word is looked at when the NEXT call
+                         starts (and by ``check_range()``): the module then switches to the fp32 kernels with a
+                         warning, but the call that overflowed has already returned non-finite values.
+                     "auto" (default) -- "sync" for the calls whose result is bound for the host (``inference``,
+                         ``inference_minus``, the Synthesizer flows: the reference's drop-in surface -- the caller's
+                         ``.cpu()`` waits for the stream anyway), "lazy" for ``forward`` and the standalone blocks
+                         (tensor in, tensor out, pipelined by the caller; ``check_range()`` is the explicit barrier).
+                     "off"  -- no check.
+    ``fuse_pairs``   ResBlock1 pairs as fused launches (default) or conv by conv (round-1 path; A/B runs).
+    ``fold_post``    HiFi-GAN's conv_post inside the last pair's launch (default) or as a launch of its own.
+    """
+
+    precision = "split"
+    range_guard = "auto"
+    fuse_pairs = True
+    fold_post = True
 
     def __init__(self):
         super().__init__()
         self._fv_plans = {}
         self._fv_tensors = None
         self._fv_epoch = -1
+        self._fv_key = None
+        self._fv_guard = None
+        self._fv_overflow = False
 
     # -- cache bookkeeping -------------------------------------------------
+    def _fv_policy(self):
+        """The policy a plan is built under (part of every plan's cache key)."""
+        prec = "f32" if (self.precision == "f32" or self._fv_overflow) else "split"
+        return prec, bool(self.fuse_pairs), bool(self.fold_post)
+
     def _fv_state(self):
-        """(registration epoch, sum of in-place version counters of the tensors the plans bake in, arithmetic policy
-        in force -- FV_PAIR_PREC decides which kernels a plan records)."""
+        """(identity + in-place version of every tensor the plans bake in, policy in force).  The tensor list is
+        re-scanned only when some module somewhere registered a parameter or buffer since the last scan."""
         if self._fv_tensors is None or self._fv_epoch != _registration_epoch[0]:
             self._fv_tensors = list(self.parameters()) + list(self.buffers())
             self._fv_epoch = _registration_epoch[0]
-        return self._fv_epoch, sum(t._version for t in self._fv_tensors), PlanBuilder.pair_mode_tag()
+        return tuple((id(t), t._version) for t in self._fv_tensors), self._fv_policy()
 
     # A native plan is a raw handle plus pointers into THIS module's packed weights: a copied or
     # unpickled module must not share it (double free, stale device pointers) -- it rebuilds its own.
@@ -504,14 +542,20 @@ class NativeModule(torch.nn.Module):
         state["_fv_plans"] = {}
         state["_fv_tensors"] = None
         state["_fv_epoch"] = -1
+        state["_fv_guard"] = None
+        state.pop("_fv_zero", None)       # cached device waveforms (zero-mel responses) are not part of a model
+        state.pop("_zero_cache", None)
         return state
 
     def invalidate_plans(self):
-        """Drop cached native plans (packed weights).  Called automatically on
-        load_state_dict / .to() / weight-norm changes / in-place parameter
-        updates; call it by hand after writing through ``param.data``."""
+        """Drop cached native plans (packed weights) and everything derived from the weights.  Called automatically on
+        load_state_dict / .to() / weight-norm changes / in-place parameter updates; call it by hand after writing
+        through ``param.data``."""
         self._fv_plans = {}
         self._fv_tensors = None
+        self._fv_overflow = False         # new weights: the split-f16 path gets its chance again
+        self.__dict__.pop("_fv_zero", None)
+        self.__dict__.pop("_zero_cache", None)
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -544,18 +588,69 @@ class NativeModule(torch.nn.Module):
                 "device (model.to('cuda')); there is no CPU fallback")
         return dev
 
+    def _guard_word(self):
+        if self._fv_guard is None:
+            self._fv_guard = _native.GuardWord()
+        return self._fv_guard
+
+    def _went_out_of_range(self, what):
+        """Sticky: from now on (until the weights change) this module's plans use the exact-fp32 kernels."""
+        self._fv_overflow = True
+        warnings.warn(f"{type(self).__name__}: {what} outside the split-f16 range (|v| >= 65520); this model now runs "
+                      "on the exact-fp32 kernels (precision = 'f32')", RuntimeWarning, stacklevel=3)
+
     def _plan(self, name, emit, in_channels):
-        """Return the cached plan ``name`` or build it with ``emit(builder)``."""
+        """Return the cached plan ``name`` or build it with ``emit(builder)``.  A split-f16 plan whose pack kernels
+        meet a weight beyond the f16 range is discarded and rebuilt with fp32 arithmetic."""
         state = self._fv_state()
-        hit = self._fv_plans.get(name)
+        hit = self._fv_plans.get((name, state[1]))
         if hit is not None and hit[0] == state:
             return hit[1]
+        prec, _, fold = state[1]
+        guard = self._guard_word() if (prec == "split" and self.range_guard != "off") else None
         with torch.no_grad():
-            pb = PlanBuilder(in_channels)
+            pb = PlanBuilder(in_channels, precision=prec, fold_post=fold, guard=guard)
             emit(pb)
             plan = pb.finalize()
-        self._fv_plans[name] = (state, plan)
+            if guard is not None and plan.guarded:
+                torch.cuda.current_stream().synchronize()      # one-off, at plan build: the pack kernels' verdict
+                if guard.peek(1):
+                    guard.clear(1)
+                    self._went_out_of_range("a weight lies")
+                    return self._plan(name, emit, in_channels)
+        self._fv_plans[(name, state[1])] = (state, plan)
         return plan
+
+    def _exec(self, plan_for, x, sync=False, **run_kw):
+        """``plan_for(T).run(x, **run_kw)`` under the module's range guard (class docstring); ``sync``: the result is
+        bound for the host ("auto" checks it before returning).  ``plan_for`` must resolve the plan through
+        :meth:`_plan` every time it is called: after an overflow it returns the fp32 plan."""
+        mode = self.range_guard
+        if mode == "auto":
+            mode = "sync" if sync else "lazy"
+        if mode == "lazy" and not self._fv_overflow and self._fv_guard is not None and self._fv_guard.peek(0):
+            self._fv_guard.clear(0)
+            self._went_out_of_range("an EARLIER call met an activation (its output holds non-finite values)")
+        plan = plan_for(x.shape[2])
+        out = plan.run(x, **run_kw)
+        if mode == "sync" and plan.guarded and plan.check_range():
+            self._went_out_of_range("an activation lies")
+            out = plan_for(x.shape[2]).run(x, **run_kw)
+        return out
+
+    def check_range(self):
+        """Wait for this module's queued work and report whether a split-f16 kernel has met an out-of-range operand
+        since the last check (True: the module has switched to the fp32 kernels; earlier outputs of a "lazy" module
+        may hold non-finite values)."""
+        if self._fv_guard is None:
+            return False
+        torch.cuda.current_stream().synchronize()
+        if not self._fv_guard.peek(0):
+            return False
+        self._fv_guard.clear(0)
+        if not self._fv_overflow:
+            self._went_out_of_range("an activation lay")
+        return True
 
     # Longest input (frames) handed to one plan run; longer inputs are cut into chunks with
     # receptive-field halos (SURVEY.md section 8 f-4).  One launch addresses < 1 GiB per
@@ -564,7 +659,7 @@ class NativeModule(torch.nn.Module):
     # keeps the workspace bounded and costs < 1 % in halo recomputation.
     max_frames_per_run = 16384
 
-    def _run_plan(self, plan, x, chunk_frames=None):
+    def _run_plan(self, plan, x, chunk_frames=None, sync=False):
         """plan.run(x), time-chunked when x is longer than ``chunk_frames``
         (default ``max_frames_per_run``).  ``plan`` is a native plan or a callable ``T -> plan``
         (variants of one graph whose fused ops depend on the length, all with the same
@@ -572,11 +667,10 @@ class NativeModule(torch.nn.Module):
         plan_for = plan if callable(plan) else (lambda T: plan)
         chunk = self.max_frames_per_run if chunk_frames is None else int(chunk_frames)
         if chunk <= 0 or x.shape[2] <= chunk:
-            return plan_for(x.shape[2]).run(x)
-        return self._run_chunked(plan_for, x, chunk)
+            return self._exec(plan_for, x, sync=sync)
+        return self._run_chunked(plan_for, x, chunk, sync)
 
-    @staticmethod
-    def _run_chunked(plan_for, x, chunk):
+    def _run_chunked(self, plan_for, x, chunk, sync=False):
         """Exact chunked evaluation: each chunk of ``chunk`` frames is run with ``halo`` extra
         frames of real input on both sides (clipped at the utterance ends, where the layers'
         own zero / reflection padding applies as in a whole run) and only its interior is
@@ -593,7 +687,7 @@ class NativeModule(torch.nn.Module):
         for a in range(0, T, chunk):
             b = min(T, a + chunk)
             lo, hi = max(0, a - halo), min(T, b + halo)
-            y = plan_for(hi - lo).run(x[:, :, lo:hi].contiguous())
+            y = self._exec(plan_for, x[:, :, lo:hi].contiguous(), sync=sync)
             first = a * hop if a > 0 else 0
             last = b * hop if b < T else total
             out[:, :, first:last] = y[:, :, first - lo * hop: last - lo * hop]
@@ -607,13 +701,12 @@ class NativeModule(torch.nn.Module):
         the chunked route and one elementwise subtraction."""
         bias = bias.detach().to(device=x.device, dtype=torch.float32)
         if x.shape[2] > self.max_frames_per_run:
-            out = self._run_plan(plan_for, x)
+            out = self._run_plan(plan_for, x, sync=True)
             return out, out - bias.reshape((-1,) + tuple(out.shape[1:]))
-        plan = plan_for(x.shape[2])
-        c, n = plan.output_shape(x.shape[2])
+        c, n = plan_for(x.shape[2]).output_shape(x.shape[2])
         if bias.numel() not in (c * n, x.shape[0] * c * n):
             raise _native.NativeError(f"bias has {bias.numel()} elements, the output {c} x {n} per utterance")
-        return plan.run(x, aux=(bias.reshape(-1, c, n).contiguous(),), out2=True)
+        return self._exec(plan_for, x, sync=True, aux=(bias.reshape(-1, c, n).contiguous(),), out2=True)
 
     def _prepare(self, x):
         """Any array-like -> contiguous fp32 tensor on this module's device."""

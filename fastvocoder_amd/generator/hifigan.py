@@ -13,12 +13,11 @@ Every activation, bias, residual add, the MRF sum and its /num_kernels, and
 tanh are epilogue/prologue work of the conv kernels: the whole forward is
 ``num_convs`` launches (78 for the shipped 4-stage configs) and nothing else.
 """
-import os
-
 import torch
 
 from .._native import PAIR_SPLIT_F16
-from .engine import NativeModule, PlanBuilder, POST_TANH, SLOT_IN, SLOT_NONE, SLOT_OUT, weight_norm  # noqa: F401
+from .engine import (NativeModule, PlanBuilder, POST_TANH, SLOT_IN, SLOT_NONE, SLOT_OUT, pair_precision,  # noqa: F401
+                     weight_norm)
 from .modules import LRELU_SLOPE, ResBlock1, ResBlock2, UpsampleLayer
 from .pqmf import PQMF
 
@@ -64,9 +63,10 @@ class _HiFiGANBase(NativeModule):
         self.reset_parameters()
 
     # -- fused ResBlock pairs ------------------------------------------------
-    def _stage_fusable(self, i):
-        """Stage i can run on the fused ResBlock-pair kernels (csrc/pair_kernels.hpp): the classic
-        ResBlock1 trio (3 / 7 / 11 taps) with one dilation per pair position, 16 or 32 channels."""
+    def _stage_fusable(self, i, precision):
+        """Stage i can run on the fused ResBlock-pair kernels (csrc/pair_kernels.hpp, pairh_kernels.hpp, convp / convh):
+        the classic ResBlock1 trio (3 / 7 / 11 taps) with one dilation per pair position, at a channel count the
+        kernels of ``precision`` are built for."""
         nk = self.num_kernels
         blocks = [self.resblocks[i * nk + j] for j in range(nk)]
         if nk != 3 or not all(isinstance(b, ResBlock1) for b in blocks):
@@ -76,13 +76,14 @@ class _HiFiGANBase(NativeModule):
         dils = [[c.dilation[0] for c in b.convs1] for b in blocks]
         if any(d != dils[0] for d in dils):
             return False
-        prec = PlanBuilder.pair_precision(blocks[0].channels)
+        prec = pair_precision(precision, blocks[0].channels)
         return all(PlanBuilder.pair_fusable(c1, c2, prec) for b in blocks for c1, c2 in zip(b.convs1, b.convs2))
 
     def _fused_flags(self, T):
         """Per stage: run it fused for a mel of T frames?  The pair kernels need 16-byte aligned rows
-        (stage length % 4 == 0); FV_PAIR=0 keeps every stage on the conv-by-conv path (A/B runs)."""
-        if os.environ.get("FV_PAIR", "1") == "0" or os.environ.get("FV_MRF", "group") != "group":
+        (stage length % 4 == 0); ``fuse_pairs = False`` keeps every stage on the conv-by-conv path (A/B runs)."""
+        precision, fuse, _ = self._fv_policy()
+        if not fuse:
             return (False,) * self.num_upsamples
         flags, t = [], int(T)
         for i in range(self.num_upsamples):
@@ -91,7 +92,7 @@ class _HiFiGANBase(NativeModule):
                 t = t * up.upsample_rate + 2 * up.conv.padding[0] - (up.conv.kernel_size[0] - 1)
             else:
                 t = (t - 1) * up.stride[0] - 2 * up.padding[0] + up.kernel_size[0] + up.output_padding[0]
-            flags.append(t > 0 and t % 4 == 0 and self._stage_fusable(i))
+            flags.append(t > 0 and t % 4 == 0 and self._stage_fusable(i, precision))
         return tuple(flags)
 
     def _emit_fused_stage(self, pb, blocks, up, x, scratch, parts, fold=None):
@@ -103,7 +104,7 @@ class _HiFiGANBase(NativeModule):
         ch = blocks[0].channels
         curs = [up] * nk
         prec = pb.pair_precision(ch)
-        if prec == PAIR_SPLIT_F16 and (ch >= 128 or (ch >= 64 and os.environ.get("FV_PAIR64_UNFUSED"))):
+        if prec == PAIR_SPLIT_F16 and ch >= 128:
             # 128 channels: the pair's two images do not fit in LDS next to the weight ring, a pair is two launches of
             # the split-f16 conv kernel (csrc/convh_kernels.hpp); 64 channels run fused (csrc/convp_kernels.hpp) below.  Per pair position: the three blocks' first convs, then their second convs
             # (+ residual); at the last position the second convs of blocks 1.. store r_1.., and the first block's
@@ -165,32 +166,33 @@ class _HiFiGANBase(NativeModule):
         pb.conv_sum3(convs, srcs, ress, parts[:2], x, pre_slope=LRELU_SLOPE, out_div=float(nk))
 
     # -- op emission ---------------------------------------------------------
-    def _fold_post(self, fused):
+    def _fold_post(self, pb, fused):
         """conv_post can run inside the last stage's last launch (PlanBuilder.pair_fold_supported): the classic trio
         of 16-channel ResBlock1s as split-f16 fused pairs, one output channel."""
-        if not fused or not fused[-1] or self.num_kernels != 3:
+        if not pb.fold_post or not fused or not fused[-1] or self.num_kernels != 3:
             return False
         blocks = self.resblocks[-3:]
         return PlanBuilder.pair_fold_supported(blocks[0].convs1[-1], self.conv_post,
-                                               PlanBuilder.pair_precision(blocks[0].channels))
+                                               pb.pair_precision(blocks[0].channels))
 
     def _emit_trunk(self, pb, dst, fused=None, fold_post=False):
         """mel (SLOT_IN) -> tanh(conv_post(...)) in ``dst``; ``fused``: per-stage flags (_fused_flags); ``fold_post``:
         conv_post inside the last pair's launch (not for the plans whose LAST op subtracts an output offset)."""
-        fold_post = fold_post and self._fold_post(fused)
+        fold_post = fold_post and self._fold_post(pb, fused)
         x, up = pb.tmp(), pb.tmp()
         nk = self.num_kernels
         # The nk ResBlocks of a stage are independent given the upsampled input, and at
         # batch 1 one conv cannot fill 256 CUs.  Their steps are therefore emitted
         # interleaved -- conv number s of every block forms one GROUP, which the
         # executor runs as a single launch when the blocks are the classic 3/7/11-tap
-        # trio (fv_plan_set_group), else one launch each.  At the last step the blocks after
-        # the first (the 7- and 11-tap ones) still share a launch and store r_1, r_2; the
-        # FIRST block's final conv -- the cheapest -- runs after them and forms
-        # ((r_0 + r_1) + r_2) / nk in its epilogue (own value first: fv_plan_set_sum_order),
-        # which is the reference's summation order bit for bit (hifigan.py:97-103).
+        # trio (fv_plan_set_group), else one launch each.  Fused stages: _emit_fused_stage.
+        # Conv-by-conv stages (shapes the pair kernels are not built for, rows that are not
+        # 16-byte aligned): the three last convs accumulate into one output tile in ONE launch
+        # (conv_sum3) when they are the classic trio; otherwise the blocks after the first
+        # store r_1, r_2 and the FIRST block's final conv -- the cheapest -- runs after them and
+        # forms ((r_0 + r_1) + r_2) / nk in its epilogue (own value first: fv_plan_set_sum_order),
+        # the reference's summation order bit for bit (hifigan.py:97-103).
         # Measured on MI355X (HiFi-GAN light, B = 1, per forward): see DESIGN.md section 3.2.
-        mode = os.environ.get("FV_MRF", "group")
         parts = [pb.tmp() for _ in range(nk - 1)]          # r_1 .. r_{nk-1}
         scratch = [[pb.tmp(), pb.tmp(), pb.tmp()] for _ in range(nk)]
         pb.conv(self.conv_pre, SLOT_IN, x)
@@ -207,16 +209,10 @@ class _HiFiGANBase(NativeModule):
                     return
                 self._emit_fused_stage(pb, blocks, up, x, scratch, parts)
                 continue
-            if nk <= 3 and mode != "chain":
+            if nk <= 3:
                 steps = blocks[0].num_steps()
                 states = [dict() for _ in range(nk)]
-                # which block's final conv carries the sum: the first (cheapest; the others' final
-                # convs then share a launch) or, FV_MRF_CARRIER=last, the last
-                # FV_MRF_FINAL=sum3 (default): the three last convs accumulate into one output tile in
-                # ONE launch (no r_1 / r_2 tensors; the sum is formed inside the fp32 accumulator);
-                # =carrier: the reference's association, bit for bit, in two launches (below)
-                sum3 = (os.environ.get("FV_MRF_FINAL", "sum3") == "sum3" and nk == 3 and mode == "group"
-                        and all(isinstance(b, ResBlock1) for b in blocks)
+                sum3 = (nk == 3 and all(isinstance(b, ResBlock1) for b in blocks)
                         and sorted(b.convs2[-1].kernel_size[0] for b in blocks) == [3, 7, 11])
                 if sum3:
                     for st in range(steps - 1):
@@ -228,28 +224,19 @@ class _HiFiGANBase(NativeModule):
                                               for j in range(nk)])
                     pb.conv_sum3(convs, srcs, ress, parts[:2], x, pre_slope=LRELU_SLOPE, out_div=float(nk))
                     continue
-                carrier = nk - 1 if os.environ.get("FV_MRF_CARRIER", "first") == "last" else 0
-                others = [j for j in range(nk) if j != carrier]
+                others = list(range(1, nk))
                 for st in range(steps):
                     final = st == steps - 1
                     members = others if final else range(nk)
-                    if mode == "lanes":
-                        for j in members:
-                            pb.lane = j
-                            blocks[j].emit_step(pb, st, states[j], up, parts[others.index(j)] if final else x,
-                                                scratch[j])
-                        pb.lane = 0
-                    else:
-                        pb.begin_group()
-                        for j in members:
-                            blocks[j].emit_step(pb, st, states[j], up, parts[others.index(j)] if final else x,
-                                                scratch[j])
-                        pb.end_group()
-                # the carrier's final conv: ((r_0 + r_1) + r_2) / nk in the reference's order
-                blocks[carrier].emit_step(pb, steps - 1, states[carrier], up, x, scratch[carrier],
-                                          acc=parts[0] if nk > 1 else SLOT_NONE,
-                                          acc2=parts[1] if nk > 2 else SLOT_NONE, out_div=float(nk),
-                                          own_first=carrier == 0)
+                    pb.begin_group()
+                    for j in members:
+                        blocks[j].emit_step(pb, st, states[j], up, parts[others.index(j)] if final else x,
+                                            scratch[j])
+                    pb.end_group()
+                # the first block's final conv: ((r_0 + r_1) + r_2) / nk in the reference's order
+                blocks[0].emit_step(pb, steps - 1, states[0], up, x, scratch[0],
+                                    acc=parts[0] if nk > 1 else SLOT_NONE,
+                                    acc2=parts[1] if nk > 2 else SLOT_NONE, out_div=float(nk), own_first=True)
             else:
                 # generic: a running sum chained through the blocks, one after the other
                 for j in range(nk):
@@ -261,7 +248,7 @@ class _HiFiGANBase(NativeModule):
 
     def _trunk_plan(self, T):
         fused = self._fused_flags(T)
-        return self._plan("trunk" + PlanBuilder.pair_mode_tag() + "".join("f" if f else "-" for f in fused),
+        return self._plan("trunk" + "".join("f" if f else "-" for f in fused),
                           lambda pb: self._emit_trunk(pb, SLOT_OUT, fused, fold_post=True), 80)
 
     def _emit_inference(self, pb, fused):
@@ -274,7 +261,7 @@ class _HiFiGANBase(NativeModule):
         def emit(pb):
             self._emit_inference(pb, fused)
             pb.subtract_output(0, second=True)
-        return self._plan("minus" + PlanBuilder.pair_mode_tag() + "".join("f" if f else "-" for f in fused), emit, 80)
+        return self._plan("minus" + "".join("f" if f else "-" for f in fused), emit, 80)
 
     def inference_minus(self, x, bias):
         """x [T,80], bias [n] (e.g. the response to an all-zero mel) -> (waveform, waveform - bias), both 1-D,
@@ -283,8 +270,8 @@ class _HiFiGANBase(NativeModule):
         est, rem = self._run_minus(self._minus_plan, x, bias)
         return est.squeeze(), rem.squeeze()
 
-    def _trunk(self, x):
-        return self._run_plan(self._trunk_plan, x)
+    def _trunk(self, x, sync=False):
+        return self._run_plan(self._trunk_plan, x, sync=sync)
 
 
 class HiFiGANGenerator(_HiFiGANBase):
@@ -307,7 +294,7 @@ class HiFiGANGenerator(_HiFiGANBase):
     def inference(self, x):
         """x [T,80] (ndarray or tensor) -> 1-D waveform."""
         x = self._prepare(x)
-        return self._trunk(x.transpose(1, 0).unsqueeze(0).contiguous()).squeeze()
+        return self._trunk(x.transpose(1, 0).unsqueeze(0).contiguous(), sync=True).squeeze()
 
 
 class MultiBandHiFiGANGenerator(_HiFiGANBase):
@@ -342,13 +329,13 @@ class MultiBandHiFiGANGenerator(_HiFiGANBase):
 
     def _full_plan(self, T):
         fused = self._fused_flags(T)
-        return self._plan("inference" + PlanBuilder.pair_mode_tag() + "".join("f" if f else "-" for f in fused),
+        return self._plan("inference" + "".join("f" if f else "-" for f in fused),
                           lambda pb: self._emit_full(pb, fused), 80)
 
     def inference(self, x):
         """x [T,80] -> 1-D full-band waveform (trunk + PQMF synthesis, one plan)."""
         x = self._prepare(x).transpose(1, 0).unsqueeze(0).contiguous()
-        return self._run_plan(self._full_plan, x).squeeze()
+        return self._run_plan(self._full_plan, x, sync=True).squeeze()
 
     def synthesize_batch(self, x):
         """x [B,80,T] -> full-band waveforms [B, 4*T'] (batched ``inference``)."""

@@ -111,9 +111,9 @@ class MelGANGenerator(_MelGANTrunk):
         self.reset_parameters()
         self.pqmf = None  # attribute kept for parity with the reference (melgan.py:123)
 
-    def _run(self, x):
-        return self._run_plan(self._plan("trunk", lambda pb: self._emit_layers(pb, SLOT_OUT, self._final_post),
-                                    self._in_channels), x)
+    def _run(self, x, sync=False):
+        return self._run_plan(lambda T: self._plan("trunk", lambda pb: self._emit_layers(pb, SLOT_OUT, self._final_post),
+                                                   self._in_channels), x, sync=sync)
 
     def forward(self, c):
         """c [B,in_channels,T] -> [B, T*prod(upsample_scales)] (channel 0)."""
@@ -134,7 +134,7 @@ class MelGANGenerator(_MelGANTrunk):
     def inference(self, c):
         """c [T,in_channels] -> squeezed waveform."""
         c = self._prepare(c)
-        return self._run(c.transpose(1, 0).unsqueeze(0).contiguous()).squeeze()
+        return self._run(c.transpose(1, 0).unsqueeze(0).contiguous(), sync=True).squeeze()
 
 
 class BasisMelGANGenerator(_MelGANTrunk):
@@ -169,18 +169,18 @@ class BasisMelGANGenerator(_MelGANTrunk):
 
     def _weights(self, x):
         """Trunk + ReLU in its native layout [B, C, F]."""
-        return self._run_plan(self._plan("trunk", lambda pb: self._emit_layers(pb, SLOT_OUT, self._final_post),
-                                    self._in_channels), x)
+        return self._run_plan(lambda T: self._plan("trunk", lambda pb: self._emit_layers(pb, SLOT_OUT, self._final_post),
+                                                   self._in_channels), x)
 
     def _emit_full(self, pb):
         w = pb.tmp()
         self._emit_layers(pb, w, self._final_post)
         self.basis_signal.emit(pb, w, SLOT_OUT)
 
-    def _samples(self, x):
+    def _samples(self, x, sync=False):
         """mel [B,C,T] -> [B, (F-1)*L/2 + L] in one plan (weights stay on chip/HBM
         scratch, no [B,F,L] frame tensor)."""
-        return self._run_plan(self._plan("full", self._emit_full, self._in_channels), x)[:, 0, :]
+        return self._run_plan(lambda T: self._plan("full", self._emit_full, self._in_channels), x, sync=sync)[:, 0, :]
 
     def _zero_response(self, T):
         """(zero_weight [1,C,F], zero_est [1,1,n]): the generator's response to an all-zero mel of T frames.
@@ -196,7 +196,7 @@ class BasisMelGANGenerator(_MelGANTrunk):
                 cache.pop(next(iter(cache)))
             dev = self._device()
             zero = torch.zeros((1, self._in_channels, int(T)), dtype=torch.float32, device=dev)
-            est, w = self._plan("zero", emit, self._in_channels).run(zero, out2=True)
+            est, w = self._exec(lambda T: self._plan("zero", emit, self._in_channels), zero, out2=True)
             cache[key] = (w, est)
         return cache[key]
 
@@ -212,8 +212,8 @@ class BasisMelGANGenerator(_MelGANTrunk):
             outs = []
             for inp in (torch.zeros_like(c[:1]), c):
                 w = self._weights(inp)                                   # [B,C,F]
-                src = self._plan("ola", lambda pb: self.basis_signal.emit(pb, SLOT_IN, SLOT_OUT),
-                                 w.shape[1]).run(w)[:, 0, :]
+                src = self._exec(lambda T: self._plan("ola", lambda pb: self.basis_signal.emit(pb, SLOT_IN, SLOT_OUT),
+                                                      w.shape[1]), w)[:, 0, :]
                 outs.append((src[:, : w.shape[2] * hop], w.transpose(1, 2)))
             (zs, zw), (s, w) = outs
             return s - zs, w - zw
@@ -225,7 +225,7 @@ class BasisMelGANGenerator(_MelGANTrunk):
             pb.subtract_output(0, second=True)                       # SLOT_OUT2 = weight - zero_weight
             self.basis_signal.emit(pb, w, SLOT_OUT)
             pb.subtract_output(1, second=False)                      # SLOT_OUT  = est - zero_est
-        s, w = self._plan("forward", emit, self._in_channels).run(c, aux=(zw, zs), out2=True)
+        s, w = self._exec(lambda T: self._plan("forward", emit, self._in_channels), c, aux=(zw, zs), out2=True)
         return s[:, 0, : w.shape[2] * hop], w.transpose(1, 2)
 
     def _minus_plan(self, T):
@@ -243,7 +243,7 @@ class BasisMelGANGenerator(_MelGANTrunk):
     def inference(self, c):
         """c [T,in_channels] -> squeezed waveform of (F-1)*L/2 + L samples."""
         c = self._prepare(c)
-        return self._samples(c.transpose(1, 0).unsqueeze(0).contiguous()).squeeze()
+        return self._samples(c.transpose(1, 0).unsqueeze(0).contiguous(), sync=True).squeeze()
 
     def test(self, weight):
         """weight [B,F,C] -> basis synthesis only (reference basis_melgan.py:210-212)."""

@@ -6,8 +6,6 @@ calling code carry over; the arithmetic is in csrc/.
 Each block can also be called on its own (``block(x)``, x ``[B,C,T]`` on a ROCm
 device): it then runs a private plan SLOT_IN -> SLOT_OUT.
 """
-import os
-
 import torch
 
 from .engine import (NativeModule, PAD_CAUSAL, PAD_REFLECT, PAD_ZERO, POST_NONE, SLOT_IN, SLOT_NONE,
@@ -15,8 +13,6 @@ from .engine import (NativeModule, PAD_CAUSAL, PAD_REFLECT, PAD_ZERO, POST_NONE,
 from .. import _native
 
 LRELU_SLOPE = 0.1  # reference modules.py:9
-_FUSE_SKIP = os.environ.get("FV_FUSE_SKIP", "1") != "0"   # ResidualStack: 1x1 + skip 1x1 as one launch
-_SPLIT_STACK = os.environ.get("FV_SPLIT_STACK", "1") != "0"   # ... its dilated conv on the split-f16 conv kernels
 
 
 def get_padding(kernel_size, dilation=1):
@@ -51,7 +47,7 @@ class _Block(NativeModule):
 
         def build(pb):
             self.emit(pb, SLOT_IN, SLOT_OUT, [pb.tmp() for _ in range(self.scratch_slots())])
-        return self._plan("forward", build, self.channels).run(x)
+        return self._exec(lambda T: self._plan("forward", build, self.channels), x)
 
 
 class ResBlock1(_Block):
@@ -103,10 +99,10 @@ class ResBlock1(_Block):
         for step in range(self.num_steps()):
             self.emit_step(pb, step, state, src, dst, scratch, acc=acc, out_div=out_div)
 
-    def pairs_fusable(self):
+    def pairs_fusable(self, precision="split"):
         """Every (dilated conv, conv) pair has a shape the fused pair kernels are built for."""
-        from .engine import PlanBuilder
-        prec = PlanBuilder.pair_precision(self.channels)
+        from .engine import PlanBuilder, pair_precision
+        prec = pair_precision(precision, self.channels)
         return all(PlanBuilder.pair_fusable(c1, c2, prec) for c1, c2 in zip(self.convs1, self.convs2))
 
     def emit_fused(self, pb, src, dst, scratch):
@@ -120,13 +116,19 @@ class ResBlock1(_Block):
 
     def forward(self, x):
         x = self._prepare(x)
-        if x.shape[2] % 4 != 0 or not self.pairs_fusable() or os.environ.get("FV_PAIR", "1") == "0":
-            return super().forward(x)
+
+        def fused():
+            return x.shape[2] % 4 == 0 and self.fuse_pairs and self.pairs_fusable(self._fv_policy()[0])
 
         def build(pb):
             self.emit_fused(pb, SLOT_IN, SLOT_OUT, [pb.tmp() for _ in range(3)])
-        from .engine import PlanBuilder
-        return self._plan("forward_fused" + PlanBuilder.pair_mode_tag(), build, self.channels).run(x)
+
+        def plan_for(T):      # (re-evaluated after a range overflow: the fp32 pair kernels exist at 16 / 32 channels only)
+            if fused():
+                return self._plan("forward_fused", build, self.channels)
+            return self._plan("forward", lambda pb: self.emit(pb, SLOT_IN, SLOT_OUT, [pb.tmp() for _ in range(3)]),
+                              self.channels)
+        return self._exec(plan_for, x)
 
 
 class ResBlock2(_Block):
@@ -203,6 +205,8 @@ class ResidualStack(_Block):
     ``stack`` keeps the reference's Sequential indices: conv at .2 and .4, or, with
     ``use_causal_conv``, a CausalConv1d at .1 (keys ``stack.1.conv.*``) and the 1x1 at .3."""
 
+    fuse_skip = True      # stack[4] + skip_layer as ONE GEMM over the concatenated K range (False: three launches; A/B)
+
     def __init__(self, kernel_size=3, channels=32, dilation=1, bias=True,
                  nonlinear_activation="LeakyReLU",
                  nonlinear_activation_params={"negative_slope": 0.2},
@@ -243,13 +247,13 @@ class ResidualStack(_Block):
         hidden, skip = scratch[:2]
         dilated, pointwise = (self.stack[i] for i in self._conv_at)
         dilated = getattr(dilated, "conv", dilated)               # CausalConv1d wraps its conv
-        if _SPLIT_STACK and pb.conv_split_supported(dilated, self._pad, self._pad_mode):
+        if pb.conv_split_supported(dilated, self._pad, self._pad_mode):
             # 64 ... 512 channels: the dilated conv with split-f16 operands (csrc/convh_kernels.hpp), the
             # reflected samples are mirrored addresses of its window loader
             pb.conv_split(dilated, src, hidden, self._slope, pad=self._pad, pad_mode=self._pad_mode)
         else:
             pb.conv(dilated, src, hidden, pad=self._pad, pad_mode=self._pad_mode, pre_slope=self._slope)
-        if _FUSE_SKIP and self.channels > 4:
+        if self.fuse_skip and self.channels > 4:
             # stack[4](act(hidden)) + skip_layer(src): one GEMM over the concatenated K range;
             # the skip branch costs no launch and no [B,C,T] round trip (src is read raw)
             pb.conv_sum_1x1(pointwise, hidden, self.skip_layer, src, dst, pre_slope_a=self._slope, post=post)
@@ -289,8 +293,8 @@ class LastLinear(NativeModule):
 
     def forward(self, x):
         x = self._prepare(x)
-        return self._plan("forward", lambda pb: self.emit(pb, SLOT_IN, SLOT_OUT, [pb.tmp()]),
-                          self.hidden_channel).run(x)
+        return self._exec(lambda T: self._plan("forward", lambda pb: self.emit(pb, SLOT_IN, SLOT_OUT, [pb.tmp()]),
+                                               self.hidden_channel), x)
 
 
 class LastLayer(NativeModule):
@@ -313,8 +317,8 @@ class LastLayer(NativeModule):
 
     def forward(self, x):
         x = self._prepare(x)
-        return self._plan("forward", lambda pb: self.emit(pb, SLOT_IN, SLOT_OUT),
-                          self.in_channels).run(x)
+        return self._exec(lambda T: self._plan("forward", lambda pb: self.emit(pb, SLOT_IN, SLOT_OUT),
+                                               self.in_channels), x)
 
 
 class BasisSignalLayer(NativeModule):
@@ -336,8 +340,8 @@ class BasisSignalLayer(NativeModule):
     def forward(self, weight):
         """weight [B,F,C] (the reference's layout) -> [B,(F-1)*L/2+L]."""
         w = self._prepare(weight).transpose(1, 2).contiguous()
-        out = self._plan("forward", lambda pb: self.emit(pb, SLOT_IN, SLOT_OUT),
-                         self.layer.weight.shape[1]).run(w)
+        out = self._exec(lambda T: self._plan("forward", lambda pb: self.emit(pb, SLOT_IN, SLOT_OUT),
+                                              self.layer.weight.shape[1]), w)
         return out[:, 0, :]
 
 
@@ -355,8 +359,9 @@ class CausalConvTranspose1d(NativeModule):
 
     def forward(self, x):
         x = self._prepare(x)
-        return self._plan("forward", lambda pb: pb.conv_transpose(self.deconv, SLOT_IN, SLOT_OUT, trim=self.stride),
-                          self.in_channels).run(x)
+        return self._exec(lambda T: self._plan("forward", lambda pb: pb.conv_transpose(self.deconv, SLOT_IN, SLOT_OUT,
+                                                                                        trim=self.stride),
+                                               self.in_channels), x)
 
 
 class UpsampleLayer(NativeModule):
@@ -376,5 +381,5 @@ class UpsampleLayer(NativeModule):
 
     def forward(self, x):
         x = self._prepare(x)
-        return self._plan("forward", lambda pb: pb.upsample_conv(self, SLOT_IN, SLOT_OUT),
-                          self.in_channel).run(x)
+        return self._exec(lambda T: self._plan("forward", lambda pb: pb.upsample_conv(self, SLOT_IN, SLOT_OUT),
+                                               self.in_channel), x)

@@ -10,6 +10,10 @@ traffic is
                peer sends over its own direct xGMI link to the root (7 links
                used concurrently) instead of a ring bound by one link.
 There is no all-reduce and no collective inside the generator.
+
+Backends: "nccl" (RCCL) moves device tensors directly and needs one GPU per rank.  Under "gloo" device tensors are
+staged through the host (gloo's scatter / gather take CPU tensors only): that is how several ranks can share ONE GPU
+in tests (tests/test_gpu_multi.py: world_size 2 through the real generator on a 1-GPU box) and how the CPU tests run.
 """
 import torch
 import torch.distributed as dist
@@ -23,11 +27,21 @@ def shard_range(n_items, world_size, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _staged(group, *tensors):
+    """Device tensors have to travel through the host (gloo)?"""
+    return dist.get_backend(group) == "gloo" and any(t is not None and t.is_cuda for t in tensors)
+
+
 def broadcast_weights(model, src=0, group=None):
     """Broadcast every parameter and buffer of ``model`` from ``src`` in place."""
     with torch.no_grad():
         for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, src=src, group=group)
+            if _staged(group, t):
+                host = t.data.cpu()
+                dist.broadcast(host, src=src, group=group)
+                t.data.copy_(host)
+            else:
+                dist.broadcast(t.data, src=src, group=group)
     if hasattr(model, "invalidate_plans"):
         for m in model.modules():
             if hasattr(m, "invalidate_plans"):
@@ -60,6 +74,8 @@ class WaveformGather:
 
     def __call__(self, wav):
         wav = wav.contiguous()
+        if _staged(self.group, wav):
+            wav = wav.cpu()      # (gloo: through the host; the copy waits for the forward)
         self.flush()             # the receive buffers are about to be reused
         if self.rank == self.dst:
             if self._shape != tuple(wav.shape):
@@ -90,15 +106,18 @@ def synthesize_sharded(forward_fn, mels, world_size=None, rank=None, dst=0, grou
     rank = dist.get_rank(group) if rank is None else rank
     if scatter:
         device = mels.device if mels is not None else device
-        shape = torch.tensor(list(mels.shape) if rank == dst else [0, 0, 0], dtype=torch.int64, device=device)
+        staged = dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
+        wire_dev = "cpu" if staged else device
+        shape = torch.tensor(list(mels.shape) if rank == dst else [0, 0, 0], dtype=torch.int64, device=wire_dev)
         dist.broadcast(shape, src=dst, group=group)
         B, C, T = (int(v) for v in shape.tolist())
     else:
         B = mels.shape[0]
+        staged = _staged(group, mels)
     lo, hi = shard_range(B, world_size, rank)
     per = (B + world_size - 1) // world_size
     if scatter:
-        block = torch.empty((per, C, T), dtype=torch.float32, device=device)
+        block = torch.empty((per, C, T), dtype=torch.float32, device=wire_dev)
         parts = None
         if rank == dst:
             parts = []
@@ -108,8 +127,9 @@ def synthesize_sharded(forward_fn, mels, world_size=None, rank=None, dst=0, grou
                 if b - a < per:
                     filler = part[-1:] if b > a else torch.zeros_like(mels[:1])
                     part = torch.cat([part] + [filler] * (per - (b - a)), dim=0)
-                parts.append(part.contiguous())
+                parts.append(part.contiguous().to(wire_dev))
         dist.scatter(block, scatter_list=parts, src=dst, group=group)
+        block = block.to(device)
     else:
         block = mels[lo:hi]
         if hi - lo < per:   # pad with a copy of the last row (or a zero row for an empty block)
@@ -118,6 +138,8 @@ def synthesize_sharded(forward_fn, mels, world_size=None, rank=None, dst=0, grou
     wav = forward_fn(block.contiguous()).contiguous()
     # RCCL / gloo have no 16-bit integer type: int16 PCM travels as its bytes
     wire = wav.view(torch.uint8) if wav.dtype == torch.int16 else wav
+    if staged:
+        wire = wire.cpu()
     bufs = [torch.empty_like(wire) for _ in range(world_size)] if rank == dst else None
     dist.gather(wire, gather_list=bufs, dst=dst, group=group)
     if rank != dst:
@@ -126,4 +148,4 @@ def synthesize_sharded(forward_fn, mels, world_size=None, rank=None, dst=0, grou
     for r in range(world_size):
         a, b = shard_range(B, world_size, r)
         rows.append(bufs[r].view(wav.dtype)[: b - a])
-    return torch.cat(rows, dim=0)
+    return torch.cat(rows, dim=0).to(wav.device)

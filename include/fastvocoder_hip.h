@@ -30,11 +30,14 @@
 extern "C" {
 #endif
 
-#define FV_ABI_VERSION 8
+#define FV_ABI_VERSION 9
 
 #define FV_ERR_INVALID_ARG (-1)
 #define FV_ERR_UNSUPPORTED (-2)
 #define FV_ERR_WORKSPACE (-3)
+/* a split-f16 kernel met an operand beyond the f16 range or a non-finite value (fv_plan_check_range): the run's results
+ * are not valid; the caller repeats it with FV_PAIR_F32 arithmetic */
+#define FV_ERR_RANGE (-4)
 
 /* padding of a conv's input: zero "same" padding (torch.nn.Conv1d padding=,
  * model/generator/modules.py:193-221) or reflection padding + valid conv
@@ -157,7 +160,12 @@ int fv_resblock1_fused(int n, const float* const* x, const float* const* w1, con
  *       and a product is three v_mfma_f32_16x16x32_f16 terms a1 b1 + (a1 b2 + a2 b1)/2048 accumulated in
  *       fp32.  Per layer the result is as close to the exact sum as an fp32 FMA chain (measured: DESIGN.md
  *       section 3.7, tests/test_split_precision.py); 5.3x fewer matrix-core cycles, which turns the C = 16
- *       layers from matrix-bound into HBM / LDS-bound.  Needs |v| < 65504 for activations and weights.
+ *       layers from matrix-bound into HBM / LDS-bound.  DOMAIN: |v| < 65520 (the f16 range) for activations and
+ *       weights -- where the reference (fp32 ATen) is defined for any finite fp32.  The domain is enforced, not assumed:
+ *       the pack functions raise `range_flag` for a weight outside it, and every split-f16 kernel raises its `guard`
+ *       word when a final value is not finite (an operand beyond the range turns into inf in f16 and every output it
+ *       feeds into inf / NaN); the caller then repeats the layer / the run with FV_PAIR_F32 (fv_plan_check_range).
+ *       range_flag / guard: int32 words any kernel can write (device memory or pinned host memory), NULL = no check.
  *       Weights: fv_pack_pair_weight_ex(prec) images ([K step][row half][split half][lane][8 f16]).
  *       C = 16 / 32: one fused launch (intermediate and weights in LDS).  C = 64: one fused launch, the weights of
  *       both convs stream through an LDS ring (csrc/convp_kernels.hpp).  C = 128 / 256 / 512: the pair's two LDS images do not
@@ -171,12 +179,12 @@ int fv_resblock1_fused(int n, const float* const* x, const float* const* w1, con
 #define FV_PAIR_F32 0
 #define FV_PAIR_SPLIT_F16 1
 int64_t fv_packed_pair_floats_ex(int C, int k, int prec);
-int fv_pack_pair_weight_ex(const float* w, float* packed, int C, int k, int prec, void* stream);
+int fv_pack_pair_weight_ex(const float* w, float* packed, int C, int k, int prec, int* range_flag, void* stream);
 int fv_resblock1_fused_ex(int n, const float* const* x, const float* const* w1, const float* const* w2,
                           const float* const* b1, const float* const* b2, float* const* y, float* const* y_act,
                           float* const* mid, const float* const* add1, const float* const* add2, const int* k, int B,
                           int C, int T, int dil, float slope, float out_div, int post, float act_slope, int prec,
-                          void* stream);
+                          int* guard, void* stream);
 
 /*
  * Conv1d of the wide ResBlock stages with split-f16 operands (arithmetic: FV_PAIR_SPLIT_F16 above), n = 1..3
@@ -197,7 +205,7 @@ int fv_resblock1_fused_ex(int n, const float* const* x, const float* const* w1, 
 int fv_conv1d_split_f16(int n, const float* const* x, const float* const* packed, const float* const* bias,
                         const float* const* res, const float* const* add1, const float* const* add2, float* const* y,
                         float* const* y_act, const int* k, int B, int C, int T, int dil, int pad_mode, float pre_slope,
-                        float out_div, int post, float act_slope, void* stream);
+                        float out_div, int post, float act_slope, int* guard, void* stream);
 
 /*
  * ConvTranspose1d with split-f16 operands (arithmetic: FV_PAIR_SPLIT_F16 above) for the upsamplers whose kernel is two
@@ -214,10 +222,11 @@ int fv_conv1d_split_f16(int n, const float* const* x, const float* const* packed
  * (fv_packed_conv_transpose1d_split_floats floats; 0 = shape not supported).
  */
 int64_t fv_packed_conv_transpose1d_split_floats(int Cin, int Cout, int k, int stride);
-int fv_pack_conv_transpose1d_split_f16(const float* w, float* packed, int Cin, int Cout, int k, int stride, void* stream);
+int fv_pack_conv_transpose1d_split_f16(const float* w, float* packed, int Cin, int Cout, int k, int stride, int* range_flag,
+                                       void* stream);
 int fv_conv_transpose1d_split_f16(const float* x, const float* packed, const float* bias, float* y, float* y_act, int B,
                                   int Cin, int Cout, int Tin, int k, int stride, int pad, int out_pad, float pre_slope,
-                                  float act_slope, void* stream);
+                                  float act_slope, int* guard, void* stream);
 
 /*
  * End of an MRF stage (hifigan.py:97-103): the LAST pairs of the three ResBlocks and the mean, one launch:
@@ -407,12 +416,6 @@ int fv_plan_add_pqmf_synthesis(fv_plan_t* plan, int x_slot, int y_slot, const fl
  */
 int fv_plan_set_output_offset(fv_plan_t* plan, int aux_slot, int y2_slot);
 
-/* Concurrency lanes (0..3): ops appended after this call belong to `lane`.  Lane 0
- * runs on the caller's stream, other lanes on plan-owned streams; cross-lane
- * ordering is derived from the slots each op reads and writes (events), with a
- * fork/join around every fv_plan_run.  Used to run the independent ResBlocks of
- * an MRF stage (hifigan.py:97-103) side by side when one utterance alone cannot
- * fill 256 CUs. */
 /* Association of the MRF running sum in the epilogue of the conv1d ops added from now on:
  * 0 (default)  y = ((acc + acc2) + own) / out_div   -- the LAST ResBlock's conv carries the sum
  * 1            y = ((own + acc) + acc2) / out_div   -- the FIRST ResBlock's conv carries it
@@ -420,7 +423,6 @@ int fv_plan_set_output_offset(fv_plan_t* plan, int aux_slot, int y2_slot);
  * bit for bit; 1 lets the two large-kernel blocks finish as one grouped launch while the
  * cheapest (3-tap) conv forms the sum. */
 int fv_plan_set_sum_order(fv_plan_t* plan, int own_first);
-int fv_plan_set_lane(fv_plan_t* plan, int lane);
 
 /* Grouping: consecutive conv1d ops appended under the same non-zero group id are
  * declared mutually independent by the caller.  When they are the 11/7/3-tap
@@ -447,6 +449,26 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
 
 /* number of kernel launches one fv_plan_run enqueues */
 int fv_plan_num_ops(fv_plan_t* plan);
+
+/*
+ * Range guard of a plan's split-f16 launches (FV_PAIR_SPLIT_F16 above: operands must lie inside the f16 range).
+ * fv_plan_set_guard: `word` is an int32 in PINNED, DEVICE-MAPPED host memory (hipHostMalloc / torch pin_memory), owned by
+ *   the caller and zero-initialised; every split-f16 kernel the plan launches sets it to 1 when one of its final values
+ *   is not finite.  NULL removes the guard.
+ * fv_plan_check_range: waits for `stream` (the stream of the plan's last run) to drain, then returns 0 when the word is
+ *   clear; otherwise clears it and returns FV_ERR_RANGE: the outputs of the run(s) since the last check are not valid
+ *   (inf / NaN where the fp32 reference is finite) and must be recomputed on a plan built with FV_PAIR_F32 arithmetic --
+ *   fastvocoder_amd/generator/engine.py does that automatically (NativeModule.range_guard).
+ */
+int fv_plan_set_guard(fv_plan_t* plan, int* word);
+int fv_plan_check_range(fv_plan_t* plan, void* stream);
+
+/*
+ * Test / tuning hook, not product configuration: sets one of the launchers' tuning switches (csrc/fv_internal.h struct
+ * Tuning: "convh_blocks", "pair_blocks", "sched", "sched_switch", "sum3_min", ...) for the whole process.  The launch
+ * path reads no environment variable; a process started with FV_TUNING=1 reads FV_<KEY> once at its first launch.
+ */
+int fv_tuning_set(const char* key, int value);
 
 /* ------------------------------------------------------------------ *
  * measurement hook (bench.py): per-launch timing of the dominant kernel

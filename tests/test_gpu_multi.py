@@ -1,6 +1,7 @@
 """GPU tests of the N > 1 code path with the REAL HIP generator on one GPU: a 1-rank RCCL process group
-(FV_BENCH_FORCE_DIST=1) drives bench.py's broadcast / gather / scatter legs, and
-parallel.synthesize_sharded runs the real forward.  The 8-GPU curve itself is the driver's."""
+(FV_BENCH_FORCE_DIST=1) drives bench.py's broadcast / gather / scatter legs, parallel.synthesize_sharded runs the real
+forward, and TWO ranks share cuda:0 under torch.distributed.run (gloo with host-staged device tensors: RCCL wants one
+GPU per rank) so that world_size > 1 has met the real generator before the driver's 8-GPU run."""
 import json
 import os
 import subprocess
@@ -29,7 +30,7 @@ def _bench(*args, **env):
 def test_bench_light_through_the_distributed_path():
     """Default workload through RCCL init, weight broadcast, per-step gather inside the timed region,
     barrier bracket and MAX all-reduce; the timed output is checked against the reference golden."""
-    out = _bench("--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    out = _bench("--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-job", "--no-exact")
     assert out["n_gpus"] == 1 and out["scaling"] == "weak" and out["unit"] == "samples/s"
     assert "gathered to rank 0 inside the timed steps" in out["config"]["workload"]
     assert out["parity"]["max_abs_vs_reference_golden"] <= 1e-4
@@ -37,7 +38,10 @@ def test_bench_light_through_the_distributed_path():
     assert abs(out["value"] - 240000 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-6
     r = out["roofline"]
     assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and r["kernel_ms_per_step"] <= out["ms_per_step"] * 1.05
-    assert out["roofline_hbm_stage"]["bytes"] > 6.0e8      # 18 convs x (2 or 3) x 15.36 MB, SURVEY 8(d)
+    h = out["roofline_hbm_stage"]
+    assert h["effective"]["bytes"] > 6.0e8               # 18 convs x (2 or 3) x 15.36 MB, SURVEY 8(d), layer by layer
+    assert 2.0e8 < h["bytes"] < h["effective"]["bytes"] and h["frac"] < h["effective"]["frac"]   # external tensors only
+    assert out["range_guard"]["timed_steps_clean"] is True
 
 
 def test_bench_large512_job_shape_on_one_rank():
@@ -47,6 +51,42 @@ def test_bench_large512_job_shape_on_one_rank():
     assert out["scaling"] == "strong" and out["config"]["global_batch"] == 6
     assert "int16 wav sink" in out["config"]["workload"]
     assert abs(out["value"] - 6 * 240000 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-6
+
+
+def _torchrun2(*args, **env):
+    """bench.py as two ranks on ONE GPU: `python -m torch.distributed.run --nproc-per-node 2`, both ranks on cuda:0."""
+    e = dict(os.environ, FV_BENCH_ONE_GPU="1", FV_BENCH_BACKEND="gloo", **env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FV_BENCH_FORCE_DIST"):
+        e.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", os.path.join(cases.ROOT, "bench.py"), "--gpus", "2", *args]
+    r = subprocess.run(cmd, env=e, cwd=cases.ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_share_the_gpu_strong_scaling_job():
+    """BASELINE configs[4] with world_size 2 and the real generator: root scatter of 8 mels, two HIP forwards (one
+    per rank, sub-batches of 2), int16 sink, root gather -- rows bit-identical to the root's own solo runs (asserted
+    inside bench.py), and the job without scatter / gather timed beside it."""
+    out = _torchrun2("--config", "large512", "--steps", "1", "--warmup", "0", "--sub", "2", FV_BENCH_JOB="8")
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["global_batch"] == 8
+    assert out["without_gather"]["ms_per_step"] > 0
+    assert abs(out["value"] - 8 * 240000 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-6
+
+
+def test_two_ranks_share_the_gpu_default_line_has_both_curves():
+    """The default invocation at N = 2: the weak-scaling headline (each rank its own utterance, gathered inside the
+    steps, golden-checked on rank 0) AND the appended strong-scaling job, each with its no-gather figure."""
+    out = _torchrun2("--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-exact", FV_BENCH_JOB="6")
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 2
+    assert out["parity"]["max_abs_vs_reference_golden"] <= 1e-4
+    assert out["without_gather"]["ms_per_step"] > 0
+    job = out["strong_scaling_job"]
+    assert job["scaling"] == "strong" and job["n_gpus"] == 2 and job["without_gather"]["ms_per_step"] > 0
+    assert "6 utterances" in job["workload"]
 
 
 def test_synthesize_sharded_with_the_hip_generator():

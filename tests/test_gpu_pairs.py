@@ -8,7 +8,6 @@ import pytest
 import torch
 
 from fastvocoder_amd import _native
-from fastvocoder_amd.generator.engine import PlanBuilder
 from oracle import ops as oo
 
 pytestmark = pytest.mark.gpu
@@ -317,25 +316,34 @@ def test_conv1d_split_f16_reflection_rejects():
         _native.conv1d_split_f16(x, w, [None], [3], 1, pad_mode=_native.PAD_CAUSAL)
 
 
-def test_block_schedule_gives_the_same_bits(monkeypatch):
+@pytest.fixture
+def tuning():
+    """fv_tuning_set for the duration of a test (process-wide switches of the launchers: restored afterwards)."""
+    defaults = {"sched": 1, "sched_switch": 4, "convh_blocks": 0, "pair_blocks": 0, "convh_carry": 1}
+    yield _native.tuning_set
+    for k, v in defaults.items():
+        _native.tuning_set(k, v)
+
+
+def test_block_schedule_gives_the_same_bits(tuning):
     """Few, unequal items per block (batch 1): the host's longest-processing-time-first block schedule
-    (csrc/convh_launch.hip pair_schedule) against the kernels' own contiguous partition (FV_SCHED=0) -- every item is
-    computed exactly once either way, so the results are bit-identical; also with a switch cost that makes blocks
-    take up two and three members."""
+    (csrc/convh_launch.hip pair_schedule, handed to the kernel inside its arguments) against the kernels' own
+    contiguous partition (sched = 0) -- every item is computed exactly once either way, so the results are
+    bit-identical; also with a switch cost that makes blocks take up two and three members."""
     rng = np.random.RandomState(78)
-    monkeypatch.setenv("FV_SCHED", "2")            # (by default only two-member launches are scheduled)
+    tuning("sched", 2)                             # every launch with few items per block is scheduled
     for C, T, dil, ks in ((128, 8000, 3, (11, 7, 3)), (64, 9000, 5, (11, 7, 3)), (256, 700, 1, (7, 11, 3)), (128, 5000, 5, (11, 7))):
         ms = [_member(rng, 1, C, T, k, True) for k in ks]
         xs = [_t(m[0]) for m in ms]
         h1, h2 = [_native.pack_pair(_t(m[1]), SPLIT) for m in ms], [_native.pack_pair(_t(m[3]), SPLIT) for m in ms]
         b1s, b2s = [_t(m[2]) for m in ms], [_t(m[4]) for m in ms]
         sched = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, prec=SPLIT)
-        monkeypatch.setenv("FV_SCHED_SWITCH", "0")
+        tuning("sched_switch", 0)
         sched0 = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, prec=SPLIT)
-        monkeypatch.delenv("FV_SCHED_SWITCH")
-        monkeypatch.setenv("FV_SCHED", "0")
+        tuning("sched_switch", 4)
+        tuning("sched", 0)
         plain = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, prec=SPLIT)
-        monkeypatch.setenv("FV_SCHED", "2")
+        tuning("sched", 2)
         for a, b, c in zip(sched, sched0, plain):
             assert torch.equal(a, c) and torch.equal(b, c)
         ref = _pair_ref(*ms[0], dil, 0.1)
@@ -383,7 +391,7 @@ CONVT_CASES = [  # B, Cin, Cout, Tin, stride, pad, out_pad
 
 
 @pytest.mark.parametrize("case", CONVT_CASES, ids=lambda c: "x".join(str(v) for v in c))
-def test_conv_transpose1d_split_f16_vs_oracle(case, monkeypatch):
+def test_conv_transpose1d_split_f16_vs_oracle(case, tuning):
     """fv_conv_transpose1d_split_f16 (kernel = 2 strides; reference hifigan.py:45-46, melgan.py:37-39) against the
     oracle's transposed conv: every stride the shipped configs use, ragged ends, trimmed tail, activated twin."""
     B, cin, cout, T, s, pad, op = case
@@ -405,9 +413,9 @@ def test_conv_transpose1d_split_f16_vs_oracle(case, monkeypatch):
     y3 = _native.conv_transpose1d_split_f16(X, P, Bi, cout, k, s, pad, op, pre_slope=0.1, act_slope=0.2)
     assert _rel(y3, oo.lrelu(ref, 0.2)) <= 4e-6
     # a few persistent blocks walking many tiles (and row tiles of one column tile): same bits
-    monkeypatch.setenv("FV_CONVH_BLOCKS", "3")
+    tuning("convh_blocks", 3)
     few = _native.conv_transpose1d_split_f16(X, P, Bi, cout, k, s, pad, op, pre_slope=0.1)
-    monkeypatch.delenv("FV_CONVH_BLOCKS")
+    tuning("convh_blocks", 0)
     assert torch.equal(few, y)
     if B > 1:                                      # an utterance alone and inside the batch: same bits
         one = _native.conv_transpose1d_split_f16(X[1:2].contiguous(), P, Bi, cout, k, s, pad, op, pre_slope=0.1)
@@ -428,7 +436,7 @@ def test_conv_transpose1d_split_f16_rejects():
 
 
 @pytest.mark.parametrize("blocks", [1, 3, 7])
-def test_persistent_blocks_walk_many_tiles_and_cross_members(monkeypatch, blocks):
+def test_persistent_blocks_walk_many_tiles_and_cross_members(tuning, blocks):
     """With few persistent blocks every block walks several tiles and crosses from one member to the next (the small
     cases above give each block one tile): forced grid sizes, same results bit for bit as the full grid."""
     rng = np.random.RandomState(77)
@@ -440,25 +448,24 @@ def test_persistent_blocks_walk_many_tiles_and_cross_members(monkeypatch, blocks
         b1s, b2s = [_t(m[2]) for m in ms], [_t(m[4]) for m in ms]
         full = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, prec=SPLIT)
         refs = [_pair_ref(x, w1, b1, w2, b2, dil, 0.1) for x, w1, b1, w2, b2 in ms]
-        monkeypatch.setenv("FV_PAIR_BLOCKS", str(blocks))
-        monkeypatch.setenv("FV_CONVH_BLOCKS", str(blocks))
+        tuning("pair_blocks", blocks)
+        tuning("convh_blocks", blocks)
         few = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, prec=SPLIT)
-        monkeypatch.delenv("FV_PAIR_BLOCKS")
-        monkeypatch.delenv("FV_CONVH_BLOCKS")
+        tuning("pair_blocks", 0)
+        tuning("convh_blocks", 0)
         for yf, yw, ref in zip(full, few, refs):
             assert _rel(yw, ref) <= 4e-6
             assert torch.equal(yf, yw)
         if C == 64:                                  # fused (convp_kernels.hpp) == two conv launches (convh), bit for bit
-            monkeypatch.setenv("FV_PAIR64_UNFUSED", "1")
-            two = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, prec=SPLIT)
-            monkeypatch.delenv("FV_PAIR64_UNFUSED")
+            mids = _native.conv1d_split_f16(xs, h1, b1s, list(ks), dil, pre_slope=0.1)
+            two = _native.conv1d_split_f16(mids, h2, b2s, list(ks), 1, pre_slope=0.1, res=xs)
             for yf, yt in zip(full, two):
                 assert torch.equal(yf, yt)
         if C <= 32:                                  # the fp32 kernels share the partition code
             f1, f2 = [_native.pack_pair(_t(m[1])) for m in ms], [_native.pack_pair(_t(m[3])) for m in ms]
-            monkeypatch.setenv("FV_PAIR_BLOCKS", str(blocks))
+            tuning("pair_blocks", blocks)
             y32 = _native.resblock1_fused(xs, f1, f2, b1s, b2s, list(ks), dil, 0.1)
-            monkeypatch.delenv("FV_PAIR_BLOCKS")
+            tuning("pair_blocks", 0)
             for y, ref in zip(y32, refs):
                 assert _rel(y, ref) <= 2e-5
 
@@ -524,6 +531,100 @@ def test_resblock1_on_the_fused_path_vs_reference_goldens():
                     p.copy_(torch.from_numpy(flat[off:off + p.numel()].reshape(tuple(p.shape))))
                     off += p.numel()
             y = rb(x)
-            name = "forward_fused" + PlanBuilder.pair_mode_tag()
-            assert name in rb._fv_plans and rb._fv_plans[name][1].num_ops() == 3
+            plans = {name: plan for (name, _), (_, plan) in rb._fv_plans.items()}
+            assert "forward_fused" in plans and plans["forward_fused"].num_ops() == 3
             assert _rel(y, g[f"rb1_c{ch}_k{k}_out"]) <= 2e-5
+
+
+# ---------------------------------------------------------------------------
+# the domain of the split-f16 arithmetic: activation scales, and what happens outside the f16 range
+# ---------------------------------------------------------------------------
+def _rel_to(a, ref):
+    """max |a - ref| relative to max |ref| (no floor: these tests move the tensors' scale)."""
+    a = a.detach().cpu().numpy().astype(np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert a.shape == ref.shape
+    return float(np.abs(a - ref).max()) / float(np.abs(ref).max())
+
+
+@pytest.mark.parametrize("scale", [1e-4, 1e-2, 1e2, 1e3])
+def test_split_kernels_at_activation_scales(scale):
+    """Every split-f16 kernel family (pairh at 16 / 32 channels, convp at 64, convh at 128, convt) with activations and
+    biases at scale 1e-4 ... 1e3 against the double-accumulating C oracle.  v = h1 + h2/2048 keeps 22 bits of every
+    operand whatever its scale as long as h1 is a normal f16; below 6.1e-5 h1 is a SUBNORMAL f16 and the claim is that
+    gfx950 (conversion and MFMA alike) does not flush it -- flushed, the 46 % of a 1e-4-scale tensor below that bound
+    would keep 11 bits and the error would be ~1e-4 of the tensor, not the 1e-5 allowed here (operands below the
+    smallest normal f16 keep an ABSOLUTE resolution of 2^-35, which is 3e-7 of a 5e-5 value)."""
+    tol = 1e-5 if scale < 1e-3 else 4e-6
+    rng = np.random.RandomState(int(1000 + np.log10(scale)))
+    guard = torch.zeros(1, dtype=torch.int32, device=_dev())
+    for C, T, k, dil in ((16, 700, 7, 3), (32, 500, 3, 5), (64, 300, 3, 1), (128, 200, 3, 3)):
+        x, w1, b1, w2, b2 = _member(rng, 1, C, T, k, True)
+        x, b1, b2 = (x * scale).astype(np.float32), (b1 * scale).astype(np.float32), (b2 * scale).astype(np.float32)
+        ref = _pair_ref(x, w1, b1, w2, b2, dil, 0.1)
+        y = _native.resblock1_fused([_t(x)], [_native.pack_pair(_t(w1), SPLIT)], [_native.pack_pair(_t(w2), SPLIT)],
+                                    [_t(b1)], [_t(b2)], [k], dil, 0.1, prec=SPLIT, guard=guard)[0]
+        assert _rel_to(y, ref) <= tol, (C, scale, _rel_to(y, ref))
+    cin, cout, T, s = 128, 64, 150, 4
+    x = (rng.randn(1, cin, T) * scale).astype(np.float32)
+    w = (rng.randn(cin, cout, 2 * s) / np.sqrt(cin * 2)).astype(np.float32)
+    b = (rng.randn(cout) * scale).astype(np.float32)
+    ref = oo.conv_transpose1d(x, w, b, s, s // 2, 0, pre_slope=0.1)
+    y = _native.conv_transpose1d_split_f16(_t(x), _native.pack_conv_transpose1d_split(_t(w), s), _t(b), cout, 2 * s, s,
+                                           s // 2, 0, pre_slope=0.1, guard=guard)
+    assert _rel_to(y, ref) <= tol, ("convt", scale, _rel_to(y, ref))
+    assert int(guard.item()) == 0                     # every operand was inside the f16 range: no guard raised
+
+
+def test_range_guard_of_the_split_kernels():
+    """Outside the f16 range (|v| >= 65520) the split-f16 kernels do not apply: the pack kernels raise their range flag
+    for such a weight, and every kernel family raises its guard word when an activation (input or the intermediate of a
+    fused pair) overflows -- while operands just inside the range leave both clear."""
+    rng = np.random.RandomState(5)
+    dev = _dev()
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    for C, k in ((16, 3), (32, 7), (64, 11), (128, 3)):
+        w = (rng.randn(C, C, k) / np.sqrt(C * k)).astype(np.float32)
+        w[1, 2, 0] = 65000.0
+        _native.pack_pair(_t(w), SPLIT, flag)
+        assert int(flag.item()) == 0
+        w[1, 2, 0] = -70000.0
+        _native.pack_pair(_t(w), SPLIT, flag)
+        assert int(flag.item()) == 1
+        flag.zero_()
+    wt = (rng.randn(128, 32, 8)).astype(np.float32)
+    wt[5, 5, 5] = np.inf
+    _native.pack_conv_transpose1d_split(_t(wt), 4, flag)
+    assert int(flag.item()) == 1
+    guard = torch.zeros(1, dtype=torch.int32, device=dev)
+    for C, T, k, dil in ((16, 600, 3, 1), (32, 600, 7, 3), (64, 400, 3, 5), (128, 300, 3, 1)):
+        x, w1, b1, w2, b2 = _member(rng, 2, C, T, k, True)
+        ws = [_native.pack_pair(_t(w1), SPLIT)], [_native.pack_pair(_t(w2), SPLIT)]
+        args = ([_t(b1)], [_t(b2)], [k], dil, 0.1)
+        x[1, C // 2, T // 3] = 60000.0                # inside: finite result, no flag
+        y = _native.resblock1_fused([_t(x)], *ws, *args, prec=SPLIT, guard=guard)[0]
+        assert bool(torch.isfinite(y).all()) and int(guard.item()) == 0
+        assert _rel(y, _pair_ref(x, w1, b1, w2, b2, dil, 0.1)) <= 4e-6
+        x[1, C // 2, T // 3] = 1.0e6                  # outside: the guard is raised (and the output is not finite)
+        y = _native.resblock1_fused([_t(x)], *ws, *args, prec=SPLIT, guard=guard)[0]
+        assert int(guard.item()) == 1 and not bool(torch.isfinite(y).all())
+        guard.zero_()
+        # ... while the fp32 kernels (16 / 32 channels) take the same input in their stride
+        if C <= 32:
+            y32 = _native.resblock1_fused([_t(x)], [_native.pack_pair(_t(w1))], [_native.pack_pair(_t(w2))], *args)[0]
+            assert bool(torch.isfinite(y32).all()) and _rel_to(y32, _pair_ref(x, w1, b1, w2, b2, dil, 0.1)) <= 2e-5
+    # the intermediate of a fused pair overflows although its input does not: large first conv
+    C, T, k = 16, 500, 3
+    x, w1, b1, w2, b2 = _member(rng, 1, C, T, k, True)
+    w1 = (w1 * 3000.0).astype(np.float32)
+    x = (x * 100.0).astype(np.float32)
+    y = _native.resblock1_fused([_t(x)], [_native.pack_pair(_t(w1), SPLIT)], [_native.pack_pair(_t(w2), SPLIT)],
+                                [_t(b1)], [_t(b2)], [k], 1, 0.1, prec=SPLIT, guard=guard)[0]
+    assert int(guard.item()) == 1
+    guard.zero_()
+    x = rng.randn(1, 128, 100).astype(np.float32)
+    x[0, 3, 50] = -2.0e5
+    wT = (rng.randn(128, 64, 8) / 16).astype(np.float32)
+    _native.conv_transpose1d_split_f16(_t(x), _native.pack_conv_transpose1d_split(_t(wT), 4), None, 64, 8, 4, 2, 0,
+                                       pre_slope=1.0, guard=guard)
+    assert int(guard.item()) == 1

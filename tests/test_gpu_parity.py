@@ -302,18 +302,23 @@ def test_two_source_1x1_conv_vs_oracle(case):
     assert _rel(y, np.maximum(ref - (b1 + b2)[None, :, None] + res, 0)) <= 2e-5
 
 
-def test_fused_skip_equals_unfused_residual_stack(monkeypatch):
-    """The K-concatenated ResidualStack tail vs the three-launch form (FV_FUSE_SKIP=0)."""
+def _plans(module):
+    """name -> native plan of a module's plan cache (keyed by (name, policy))."""
+    return {name: plan for (name, _), (_, plan) in module._fv_plans.items()}
+
+
+def test_fused_skip_equals_unfused_residual_stack():
+    """The K-concatenated ResidualStack tail vs the three-launch form (fuse_skip = False)."""
     from fastvocoder_amd.generator import modules
     torch.manual_seed(1)
     rs = modules.ResidualStack(kernel_size=3, channels=64, dilation=3).to(_dev())
     x = torch.randn(2, 64, 500, device=_dev())
     fused = rs(x).cpu().numpy()
-    assert rs._fv_plans["forward"][1].num_ops() == 2
-    monkeypatch.setattr(modules, "_FUSE_SKIP", False)
+    assert _plans(rs)["forward"].num_ops() == 2
+    rs.fuse_skip = False
     rs.invalidate_plans()
     plain = rs(x).cpu().numpy()
-    assert rs._fv_plans["forward"][1].num_ops() == 3
+    assert _plans(rs)["forward"].num_ops() == 3
     assert np.abs(fused - plain).max() <= 1e-5 * max(1.0, np.abs(plain).max())
 
 
@@ -345,73 +350,42 @@ def test_activated_twin_outputs():
     assert torch.equal(u2, u) and torch.equal(u_act, torch.where(u >= 0, u, u * 0.2))
 
 
-def test_concurrency_lanes_do_not_change_results(monkeypatch):
-    """The three ResBlocks of an MRF stage run on separate streams; forcing a single
-    stream must give the same waveform bit for bit."""
-    cfg = cases.load_conf("conf/hifigan/light.yaml")
-    m, _ = _model("hifigan", cfg, seed=0)
-    x = torch.from_numpy(seeded_mel(300, seed=21, batch=2)).to(_dev())
-    with torch.no_grad():
-        a = m(x).clone()
-        monkeypatch.setenv("FV_SINGLE_LANE", "1")
-        b = m(x).clone()
-        monkeypatch.delenv("FV_SINGLE_LANE")
-        c = m(x).clone()
-    torch.cuda.synchronize()
-    assert torch.equal(a, b) and torch.equal(a, c)
-
-
 @pytest.mark.parametrize("tag", ["hifigan_s", "mb_s", "hifigan_up"])
-def test_mrf_sum3_kernel_forced_on_small_configs(monkeypatch, golden_dir, tag):
+def test_mrf_sum3_kernel_forced_on_small_configs(golden_dir, tag):
     """fv_plan_add_conv1d_sum3 picks its one-launch kernel only for layers with >= 800 tiles; forcing
-    it (FV_SUM3_MIN=1) on the shrunken configs -- 64/32/16/8-channel stages, ragged row tiles,
+    it (tuning switch sum3_min = 1) on the shrunken configs -- 64/32/16/8-channel stages, ragged row tiles,
     unaligned lengths -- must still match the reference goldens; channel counts <= 4 keep the
     two-launch form."""
-    monkeypatch.setenv("FV_SUM3_MIN", "1")
-    name, cfg = next((n, c) for t, n, c in cases.SMALL if t == tag)
-    g = np.load(os.path.join(golden_dir, f"small_{tag}.npz"))
-    m, sd = _model(name, cfg, seed=7)
-    y = m.inference(seeded_mel(cases.SMALL_T, seed=5))
-    assert _err(y, g["inference"]) <= TOL
-    f = m(torch.from_numpy(seeded_mel(cases.SMALL_T, seed=6, batch=cases.SMALL_B)).to(_dev()))
-    assert _err(f, g["forward"]) <= TOL
+    _native.tuning_set("sum3_min", 1)
+    try:
+        name, cfg = next((n, c) for t, n, c in cases.SMALL if t == tag)
+        g = np.load(os.path.join(golden_dir, f"small_{tag}.npz"))
+        m, sd = _model(name, cfg, seed=7)
+        m.fuse_pairs = False                        # the conv-by-conv path is where sum3 lives
+        y = m.inference(seeded_mel(cases.SMALL_T, seed=5))
+        assert _err(y, g["inference"]) <= TOL
+        f = m(torch.from_numpy(seeded_mel(cases.SMALL_T, seed=6, batch=cases.SMALL_B)).to(_dev()))
+        assert _err(f, g["forward"]) <= TOL
+    finally:
+        _native.tuning_set("sum3_min", 800)
 
 
-@pytest.mark.parametrize("mrf,carrier", [("group", "last"), ("group", "first"), ("lanes", "first"), ("chain", "first")])
-def test_mrf_schedules_agree(monkeypatch, mrf, carrier):
-    """The MRF stage can be scheduled as grouped launches with the first block's conv carrying
-    the sum (default), with the last block's, on three streams, or as the plain sequential
-    chain: same arithmetic per element (only tile shapes, i.e. fp32 summation order inside a
-    conv, may differ), and every schedule stays within tolerance of the oracle elsewhere."""
-    cfg = cases.load_conf("conf/hifigan/light.yaml")
-    x = torch.from_numpy(seeded_mel(200, seed=22, batch=1)).to(_dev())
-    ref_model, _ = _model("hifigan", cfg, seed=0)
-    with torch.no_grad():
-        ref = ref_model(x).cpu().numpy()
-    monkeypatch.setenv("FV_MRF", mrf)
-    monkeypatch.setenv("FV_MRF_CARRIER", carrier)
-    monkeypatch.setenv("FV_MRF_FINAL", "carrier")       # the reference run above used the default (sum3)
-    m, _ = _model("hifigan", cfg, seed=0)
-    with torch.no_grad():
-        got = m(x).cpu().numpy()
-    assert np.abs(got - ref).max() <= 2e-6
-
-
-@pytest.mark.parametrize("prec,pair", [("f32", "1"), ("f32", "0"), ("split", "0")])
-def test_arithmetic_switches_agree(monkeypatch, prec, pair):
-    """FV_PAIR_PREC=f32 (exact-fp32 MFMA on every stage) and FV_PAIR=0 (no fused ResBlock pairs: round-1 conv-by-conv
-    path) give the default path's result up to fp32 summation noise."""
+@pytest.mark.parametrize("prec,pair", [("f32", True), ("f32", False), ("split", False)])
+def test_arithmetic_policies_agree(prec, pair):
+    """precision = "f32" (exact-fp32 MFMA on every stage) and fuse_pairs = False (no fused ResBlock pairs: the
+    conv-by-conv path) give the default path's result up to fp32 summation noise."""
     cfg = cases.load_conf("conf/hifigan/light.yaml")
     x = torch.from_numpy(seeded_mel(200, seed=23, batch=2)).to(_dev())
     ref_model, _ = _model("hifigan", cfg, seed=0)
     with torch.no_grad():
         ref = ref_model(x).cpu().numpy()
-    monkeypatch.setenv("FV_PAIR_PREC", prec)
-    monkeypatch.setenv("FV_PAIR", pair)
     m, _ = _model("hifigan", cfg, seed=0)
+    m.precision, m.fuse_pairs = prec, pair
     with torch.no_grad():
         got = m(x).cpu().numpy()
     assert np.abs(got - ref).max() <= 4e-6
+    ops = _plans(m)
+    assert len(ops) == 1 and not m.check_range()
 
 
 def test_causal_conv_transpose_vs_reference_fixture(golden_dir):
@@ -813,3 +787,85 @@ def test_basis_forward_caches_the_zero_pass():
         m.invalidate_plans()
         c = m(x)
         assert torch.equal(a[0], c[0])
+
+
+# ---------------------------------------------------------------------------
+# outside the split-f16 domain: the reference is defined for any finite fp32 -- so is the engine
+# ---------------------------------------------------------------------------
+def _scaled_hifigan(gain, seed=0):
+    """HiFi-GAN light whose first upsampler is `gain` times too loud and whose conv_post undoes it: every ResBlock
+    stage then works at `gain` times its usual scale (beyond the f16 range for gain = 1e6) while the waveform stays
+    comparable to the unscaled model's (leaky ReLU is homogeneous; only the biases do not scale)."""
+    cfg = cases.load_conf("conf/hifigan/light.yaml")
+    m, _ = _model("hifigan", cfg, seed=seed)
+    m.remove_weight_norm()
+    with torch.no_grad():
+        m.ups[0].weight.mul_(gain)
+        m.conv_post.weight.mul_(1.0 / gain)
+    return m
+
+
+def test_generator_beyond_the_f16_range_repeats_on_fp32():
+    """Activations beyond 65504 inside the generator: `inference` (range_guard "auto" = synchronous) notices, repeats
+    the call on the exact-fp32 kernels and returns what a precision = "f32" model returns, bit for bit; the module
+    then stays on the fp32 kernels.  `forward` (deferred check) reports at the next call / check_range()."""
+    mel = seeded_mel(64, seed=31)
+    exact = _scaled_hifigan(1e6)
+    exact.precision = "f32"
+    with torch.no_grad():
+        want = exact.inference(mel)
+    assert bool(torch.isfinite(want).all()) and float(want.abs().max()) > 1e-3
+    m = _scaled_hifigan(1e6)
+    with pytest.warns(RuntimeWarning, match="split-f16 range"), torch.no_grad():
+        got = m.inference(mel)
+    assert torch.equal(got, want)
+    assert m._fv_policy()[0] == "f32"
+    with torch.no_grad():
+        again = m.inference(mel)                    # no second warning, no second split-f16 attempt
+    assert torch.equal(again, want)
+    # the oracle agrees with the fp32 path on this model (the reference's arithmetic has no such limit)
+    sd = {k: v.detach().cpu().numpy() for k, v in exact.state_dict().items()}
+    ref = torch_port.inference("hifigan", mel, sd, cases.load_conf("conf/hifigan/light.yaml")).numpy()
+    assert _err(want, ref) <= TOL
+    # forward: stream-ordered, the check is deferred
+    lazy = _scaled_hifigan(1e6)
+    x = torch.from_numpy(seeded_mel(64, seed=31, batch=1)).to(_dev())
+    with torch.no_grad():
+        first = lazy(x)
+        with pytest.warns(RuntimeWarning, match="split-f16 range"):
+            assert lazy.check_range()
+        second = lazy(x)
+    assert not bool(torch.isfinite(first).all())
+    assert torch.equal(second[0], want)
+    # a model that stays inside the range never leaves the split-f16 kernels
+    ok = _scaled_hifigan(100.0)
+    with torch.no_grad():
+        y = ok.inference(mel)
+    assert ok._fv_policy()[0] == "split" and bool(torch.isfinite(y).all()) and not ok.check_range()
+    # "sync" on forward: checked before the call returns
+    strict = _scaled_hifigan(1e6)
+    strict.range_guard = "sync"
+    with pytest.warns(RuntimeWarning, match="split-f16 range"), torch.no_grad():
+        assert torch.equal(strict(x)[0], want)
+
+
+def test_weight_beyond_the_f16_range_builds_an_fp32_plan():
+    """A checkpoint with a weight outside the f16 range: the pack kernels flag it while the plan is built and the plan
+    is rebuilt with fp32 arithmetic -- the first call already returns the fp32 path's result."""
+    cfg = cases.load_conf("conf/hifigan/light.yaml")
+    mel = seeded_mel(48, seed=33)
+
+    def build():
+        m, _ = _model("hifigan", cfg, seed=0)
+        m.remove_weight_norm()
+        with torch.no_grad():
+            m.resblocks[4].convs1[1].weight[3, 5, 1] = 1.0e5
+        return m
+    exact = build()
+    exact.precision = "f32"
+    m = build()
+    with torch.no_grad():
+        want = exact.inference(mel)
+        with pytest.warns(RuntimeWarning, match="a weight lies outside the split-f16 range"):
+            got = m.inference(mel)
+    assert bool(torch.isfinite(want).all()) and torch.equal(got, want)

@@ -302,3 +302,26 @@ def test_encode_16bits_matches_reference_semantics():
     assert abs(x[1] + 13106.8) < 0.1          # scaled in place, like the reference
     z = encode_16bits(np.zeros(4, np.float32))
     assert z.tolist() == [0, 0, 0, 0]         # max(0.01, peak) guard
+
+
+def test_checkpoint_loader_is_restricted_unless_asked(tmp_path):
+    """load_checkpoint reads what the reference's checkpoints hold (tensors, containers, the published numpy
+    'pattern', bin/publish.py:71-75) with torch's restricted unpickler, and REFUSES a file that needs arbitrary code
+    (no silent fall-back to the unrestricted unpickler); `unsafe=True` is the explicit opt-in."""
+    import pickle
+    from fastvocoder_amd.bin.synthesize import load_checkpoint
+    good = tmp_path / "published.pth.tar"
+    torch.save({"model": {"w": torch.arange(6.0).reshape(2, 3)}, "pattern": np.linspace(0, 1, 7).astype(np.float32),
+                "step": 3}, good)
+    ck = load_checkpoint(str(good), "cpu")
+    assert torch.equal(ck["model"]["w"], torch.arange(6.0).reshape(2, 3)) and ck["step"] == 3
+    assert isinstance(ck["pattern"], np.ndarray) and ck["pattern"].dtype == np.float32 and ck["pattern"].shape == (7,)
+
+    class Evil:
+        def __reduce__(self):
+            return (os.path.join, ("never", "called"))
+    bad = tmp_path / "evil.pth.tar"
+    torch.save({"model": {}, "extra": Evil()}, bad)
+    with pytest.raises(pickle.UnpicklingError):
+        load_checkpoint(str(bad), "cpu")
+    assert load_checkpoint(str(bad), "cpu", unsafe=True)["extra"] == os.path.join("never", "called")
