@@ -196,6 +196,7 @@ struct PairParams {
     float* fold_y;       //   act_slope to the pair's own (never stored) output in front of it
     int* guard;          // split-f16 kernels: device-visible word set to 1 when a final value is not finite (an operand
                          // left the f16 range): pairh_kernels.hpp range_note; null: no check
+    int carry;           // convh / convp: a member's last tile prefetches weights and window of the block's next member
     int sched_on;        // convh / convp: sched[] holds this launch's block schedule (pair_schedule); 0: the kernel cuts
                          // the cost-weighted item sequence into nblk contiguous shares itself (pair_share)
     int reflect;         // convh: rows outside [0, T) are the mirrored samples (ReflectionPad1d) instead of zeros

@@ -65,7 +65,15 @@ __device__ __forceinline__ _Float16 split_rem(float v, _Float16 h1) {
 // into one register per thread (v * 0 is NaN exactly when v is inf or NaN: one VALU instruction per stored element) and a
 // thread that saw a non-finite value raises the launch's guard word (PairParams::guard, fv_plan_set_guard): the host then
 // repeats the call on the exact-fp32 kernels (fv_plan_check_range, engine.py NativeModule._guarded).
-__device__ __forceinline__ void range_note(float& bad, float v) { bad = fmaf(v, 0.f, bad); }
+// (only values that are actually stored count: the columns a tile computes beyond its valid outputs read LDS rows that
+// hold whatever the previous phase left there -- finite or not, they are discarded)
+__device__ __forceinline__ void range_note4(float& bad, float v0, float v1, float v2, float v3, bool stored) {
+    float t = fmaf(v0, 0.f, bad);
+    t = fmaf(v1, 0.f, t);
+    t = fmaf(v2, 0.f, t);
+    t = fmaf(v3, 0.f, t);
+    bad = stored ? t : bad;
+}
 __device__ __forceinline__ void range_flag(const PairParams& p, float bad) {
     if (p.guard && bad != bad) *p.guard = 1;
 }
@@ -398,9 +406,10 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
 #pragma unroll
         for (int h = 0; h < G::MH; ++h)
 #pragma unroll
-            for (int f = 0; f < G::NF; ++f)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) range_note(bad, hi[h][f][i]);
+            for (int f = 0; f < G::NF; ++f) {
+                const int col = col0 + f * 16, t = t0 + col;
+                range_note4(bad, hi[h][f][0], hi[h][f][1], hi[h][f][2], hi[h][f][3], col < G::NOUT && t >= 0 && t < p.T);
+            }
         if constexpr (FOLD) {
             // the activated tile -> LDS (the intermediate image's space: every wave is past its conv2 reads after the
             // barrier), zero outside [0, T) and beyond the tile's valid columns; then one output sample per thread

@@ -601,8 +601,11 @@ class NativeModule(torch.nn.Module):
 
     def _plan(self, name, emit, in_channels):
         """Return the cached plan ``name`` or build it with ``emit(builder)``.  A split-f16 plan whose pack kernels
-        meet a weight beyond the f16 range is discarded and rebuilt with fp32 arithmetic."""
+        meet a weight beyond the f16 range is discarded and rebuilt with fp32 arithmetic.  ``name`` may be a callable
+        (and ``emit`` should then consult the same things): graphs whose shape depends on the policy -- which stages
+        run fused -- are named and emitted under the policy in force at that moment."""
         state = self._fv_state()
+        name_of, name = name, (name() if callable(name) else name)
         hit = self._fv_plans.get((name, state[1]))
         if hit is not None and hit[0] == state:
             return hit[1]
@@ -617,7 +620,7 @@ class NativeModule(torch.nn.Module):
                 if guard.peek(1):
                     guard.clear(1)
                     self._went_out_of_range("a weight lies")
-                    return self._plan(name, emit, in_channels)
+                    return self._plan(name_of, emit, in_channels)
         self._fv_plans[(name, state[1])] = (state, plan)
         return plan
 

@@ -246,22 +246,24 @@ class _HiFiGANBase(NativeModule):
                                    out_div=float(nk) if last else 1.0)
         pb.conv(self.conv_post, x, dst, pre_slope=DEFAULT_LRELU_SLOPE, post=POST_TANH)
 
+    def _flag_tag(self, T):
+        return "".join("f" if f else "-" for f in self._fused_flags(T))
+
+    # (which stages run fused depends on the policy in force -- after a range overflow the fp32 pair kernels exist at 16 /
+    # 32 channels only -- so plan names and emit functions evaluate _fused_flags when they are used, not here)
     def _trunk_plan(self, T):
-        fused = self._fused_flags(T)
-        return self._plan("trunk" + "".join("f" if f else "-" for f in fused),
-                          lambda pb: self._emit_trunk(pb, SLOT_OUT, fused, fold_post=True), 80)
+        return self._plan(lambda: "trunk" + self._flag_tag(T),
+                          lambda pb: self._emit_trunk(pb, SLOT_OUT, self._fused_flags(T), fold_post=True), 80)
 
     def _emit_inference(self, pb, fused):
         self._emit_trunk(pb, SLOT_OUT, fused)
 
     def _minus_plan(self, T):
         """The inference graph whose last op also writes (output - auxiliary input) to the second output."""
-        fused = self._fused_flags(T)
-
         def emit(pb):
-            self._emit_inference(pb, fused)
+            self._emit_inference(pb, self._fused_flags(T))
             pb.subtract_output(0, second=True)
-        return self._plan("minus" + "".join("f" if f else "-" for f in fused), emit, 80)
+        return self._plan(lambda: "minus" + self._flag_tag(T), emit, 80)
 
     def inference_minus(self, x, bias):
         """x [T,80], bias [n] (e.g. the response to an all-zero mel) -> (waveform, waveform - bias), both 1-D,
@@ -328,9 +330,8 @@ class MultiBandHiFiGANGenerator(_HiFiGANBase):
         self._emit_full(pb, fused)
 
     def _full_plan(self, T):
-        fused = self._fused_flags(T)
-        return self._plan("inference" + "".join("f" if f else "-" for f in fused),
-                          lambda pb: self._emit_full(pb, fused), 80)
+        return self._plan(lambda: "inference" + self._flag_tag(T),
+                          lambda pb: self._emit_full(pb, self._fused_flags(T)), 80)
 
     def inference(self, x):
         """x [T,80] -> 1-D full-band waveform (trunk + PQMF synthesis, one plan)."""

@@ -117,18 +117,12 @@ class ResBlock1(_Block):
     def forward(self, x):
         x = self._prepare(x)
 
-        def fused():
+        def fused():     # (evaluated under the policy in force: after a range overflow the fp32 pair kernels exist at 16 / 32 channels only)
             return x.shape[2] % 4 == 0 and self.fuse_pairs and self.pairs_fusable(self._fv_policy()[0])
 
         def build(pb):
-            self.emit_fused(pb, SLOT_IN, SLOT_OUT, [pb.tmp() for _ in range(3)])
-
-        def plan_for(T):      # (re-evaluated after a range overflow: the fp32 pair kernels exist at 16 / 32 channels only)
-            if fused():
-                return self._plan("forward_fused", build, self.channels)
-            return self._plan("forward", lambda pb: self.emit(pb, SLOT_IN, SLOT_OUT, [pb.tmp() for _ in range(3)]),
-                              self.channels)
-        return self._exec(plan_for, x)
+            (self.emit_fused if fused() else self.emit)(pb, SLOT_IN, SLOT_OUT, [pb.tmp() for _ in range(3)])
+        return self._exec(lambda T: self._plan(lambda: "forward_fused" if fused() else "forward", build, self.channels), x)
 
 
 class ResBlock2(_Block):
