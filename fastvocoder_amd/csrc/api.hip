@@ -588,7 +588,7 @@ static const TuningEntry kTuningTable[] = {
     {"pair_blocks", &Tuning::pair_blocks}, {"sum3_min", &Tuning::sum3_min},      {"lds_budget", &Tuning::lds_budget},
     {"units", &Tuning::units},             {"shape16", &Tuning::shape16},        {"shape32", &Tuning::shape32},
     {"shape64", &Tuning::shape64},         {"krows", &Tuning::krows},            {"grid_cap", &Tuning::grid_cap},
-    {"no_group", &Tuning::no_group},       {"convh_carry", &Tuning::convh_carry},
+    {"no_group", &Tuning::no_group},
 };
 static void tuning_from_env() {
     const char* on = getenv("FV_TUNING");

@@ -68,38 +68,20 @@ struct ConvHGeom {
     static constexpr int XRP = (XROWS + 15) / 16 * 16;   // image: [split half][8-channel block][XRP rows][8 halves]
     static constexpr int XHALF = CB * XRP * 16;          // (layout and why: PairHGeom)
     static constexpr int XR = (XROWS * CB + NT - 1) / NT;   // (row, 8-channel block) conversion tasks per thread
-    // ... of the widest window a launch of this kernel can meet (11 taps; dilation 9 exists with 3 taps only): every member
-    // issues THAT many raw loads per window (tasks beyond its own window are out of range: no memory traffic), so the
-    // raw registers and the static vmcnt counts are the same for every tap count of a launch -- which is what lets a
-    // block's last tile of one member prefetch the first window of the next (ConvHNext)
-    static constexpr int KTM = TR ? KT : (DIL > 5 ? 3 : 11);
-    static constexpr int XRM = (((NTC + (KTM - 1) * DIL + 3) / 4 * 4) * CB + NT - 1) / NT;
     static constexpr int STAGE_BYTES = 16384, RING = 4;
     static constexpr int WTILE = NSTEP * 8192;           // packed bytes of one 64-row tile
     static constexpr int NMT = C / 64;
     static constexpr int RAWST = NST >= 4 ? NST - 4 : 0; // stage at which the next tile's raw window is requested
-    static constexpr int NRAW = XRM * 8;
+    static constexpr int NRAW = XR * 8;
     static constexpr int RESST = NST - 2;                // ... this tile's bias and residual
     static constexpr int NRES = TR ? 8 : 8 + 8 * NFW;
     static_assert(NSTEP % 2 == 0 && NST >= 3 && NFW % 2 == 0, "stages of two steps, at least three");
     static_assert(((CG - 1) * 4 * XRP + (KT - 1) * DIL + 16 * (NFW - 1)) * 16 + 16 < 65536, "ds_read immediate range");
 };
 
-template <int XRM>
-struct ConvHRawT {
-    float v[XRM][8];
-};
 template <class G>
-using ConvHRaw = ConvHRawT<G::XRM>;
-
-// What a block runs after the current member: its next member's first item -- the current member's last tile requests that
-// member's first weight stages and first window instead of nothing, and converts the window, so that the switch costs no
-// pipeline drain and refill (k = 0: nothing follows; Tuning::convh_carry = 0 disables the hand-over).
-// (only the member's index travels in registers: its pointers and sizes are read from the kernel arguments where the
-// hand-over needs them -- the K loop of these kernels has no scalar registers to spare)
-struct ConvHNext {
-    int m;               // index of the next member in the launch's PairParams::m (-1: none)
-    int item;            // its first item for this block
+struct ConvHRaw {
+    float v[G::XR][8];
 };
 
 // raw window rows [tA, tA + XROWS) of all C channels -> registers; rows outside [0, T) (or `live` false) read as zero,
@@ -111,7 +93,7 @@ __device__ __forceinline__ void convh_load_raw(ConvHRaw<G>& r, const float* xb, 
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)cvalid * (unsigned)T * 4u);
     const unsigned t4 = (unsigned)T * 4u;
 #pragma unroll
-    for (int q = 0; q < G::XRM; ++q) {
+    for (int q = 0; q < G::XR; ++q) {
         const int idx = tid + q * G::NT;
         const int cb = idx / G::XROWS, row = idx - cb * G::XROWS;
         int t = tA + row;
@@ -158,23 +140,10 @@ __device__ __forceinline__ void convh_dma_stage(__amdgpu_buffer_rsrc_t rw, float
     dma16(rw, dst + 256, o + 1024u);
 }
 
-// f(geometry of a member with k taps of the launch this geometry G belongs to)
-template <class G, class F>
-__device__ __forceinline__ void convh_with_taps(int k, F&& f) {
-    if constexpr (G::TR || G::DIL > 5) f(G{});
-    else if (k == 11) f(ConvHGeom<G::CG, G::NFW, 11, G::DIL>{});
-    else if (k == 7) f(ConvHGeom<G::CG, G::NFW, 7, G::DIL>{});
-    else f(ConvHGeom<G::CG, G::NFW, 3, G::DIL>{});
-}
-
-// items [item0, hi_item) of ONE member; item = (utterance * n_tiles + column tile) * p.nmt + row tile.
-// raw / g0_io / primed / nx: the hand-over between the members of a block (ConvHNext) -- `primed`: the previous member's
-// last tile has requested this member's first three weight stages (ring position g0_io) and converted its first window;
-// nx: what this member's last tile does for the one after it.
+// items [item0, hi_item) of ONE member; item = (utterance * n_tiles + column tile) * p.nmt + row tile
 template <class G>
 __device__ __forceinline__ void convh_run_member(const PairParams& p, const PairMember& mb, int item0, int hi_item,
-                                                 float* smem, int wave, int lane_in, bool first, ConvHRaw<G>& raw,
-                                                 const PairParams& pk, const ConvHNext& nx, int& g0_io, bool primed) {
+                                                 float* smem, int wave, int lane_in, bool first) {
     typedef __attribute__((address_space(3))) const f16x8 LdsH8;
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
@@ -203,7 +172,7 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
         ph = m - co * p.ups;
     };
     int item = item0, chunk = 0;
-    int g0 = primed ? g0_io : 0;                                            // stage counter of the run (ring slot = g & 3)
+    int g0 = 0;                                                             // stage counter of the run (ring slot = g & 3)
     auto decode = [&](int it, int& b, int& nt, int& mt) {
         mt = it % nmt;
         const int q = it / nmt;
@@ -215,32 +184,17 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
     if (!first) pair_barrier();                         // everybody is done with the previous member's LDS
     pair_stamp(p, 8, wave, lane, 7, 12);
     float bad = 0.f;                                    // range guard (pairh_kernels.hpp range_note)
+    ConvHRaw<G> raw;
     auto chunk_channels = [&](int c) { return G::TR ? min(G::C, p.ctot - c * G::C) : G::C; };
-    if (!primed) {
-        convh_load_raw<G>(raw, mb.x + b * ustride, p.T, ntile * G::NTC - G::P, tid, true, p.reflect != 0, chunk_channels(0));
+    convh_load_raw<G>(raw, mb.x + b * ustride, p.T, ntile * G::NTC - G::P, tid, true, p.reflect != 0, chunk_channels(0));
 #pragma unroll
-        for (int st = 0; st < 3; ++st)
-            convh_dma_stage<G>(rw, ring, st, (unsigned)(mtile * nch * G::WTILE + st * G::STAGE_BYTES), wave, lane);
-        pair_stamp(p, 8, wave, lane, 7, 11);
-        pair_wait_vm0();
-        pair_stamp(p, 8, wave, lane, 7, 10);
-        if (!(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid);
-    }
+    for (int st = 0; st < 3; ++st)
+        convh_dma_stage<G>(rw, ring, st, (unsigned)(mtile * nch * G::WTILE + st * G::STAGE_BYTES), wave, lane);
+    pair_stamp(p, 8, wave, lane, 7, 11);
+    pair_wait_vm0();
+    pair_stamp(p, 8, wave, lane, 7, 10);
+    if (!(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid);
     pair_stamp(p, 8, wave, lane, 7, 13);                 // (tuning aid, -DFV_PAIR_TRACE) prologue done
-    // the hand-over target: the next member's first item (same channel / row-tile structure, its own taps and tile
-    // count), decoded from the kernel arguments `pk` where it is needed -- in the block's last tile of this member only
-    // (the index and the thread id are laundered where they are used: everything derived from them would otherwise be
-    // hoisted out of the tile loop -- a block's worth of loop-invariant addresses held in registers the K loop needs)
-    auto next_item = [&](int& hb, int& hnt, int& hmt, int& hk) {
-        int m1 = nx.m;
-        asm volatile("" : "+s"(m1));
-        const PairMember& nm = pk.m[m1];
-        hk = nm.k;
-        hmt = nx.item % nmt;
-        const int q = nx.item / nmt;
-        hb = q / nm.n_tiles;
-        hnt = q - hb * nm.n_tiles;
-    };
     f32x4 hi[2][G::NFW], lo[2][G::NFW];                // live across the channel chunks of an item
     for (int it = 0;; ++it) {
         const int t0 = ntile * G::NTC;
@@ -256,7 +210,6 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
         int nb = b, nnt = ntile, nmt_ = mtile;
         if (more && last) decode(nitem, nb, nnt, nmt_);
         const bool new_win = more && (nb != b || nnt != ntile || nchunk != chunk);
-        const bool hand = !more && nx.m >= 0;            // the block's last tile of this member: prefetch for the next one
         const unsigned wnext = (unsigned)((nmt_ * nch + nchunk) * G::WTILE), wcur = (unsigned)((mtile * nch + chunk) * G::WTILE);
         if (chunk == 0) {
 #pragma unroll
@@ -289,37 +242,13 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
 #endif
             pair_barrier();
             constexpr int NS = GS + 3;
-            if constexpr (NS < G::NST) {
-                convh_dma_stage<G>(rw, ring, (g0 + NS) & 3, wcur + (unsigned)(NS * G::STAGE_BYTES), wave, lane);
-            } else if (hand) {                           // the next member's stage NS - NST, from ITS packed image
-                int hb, hnt, hmt, hk;
-                next_item(hb, hnt, hmt, hk);
-                const unsigned wt = (unsigned)(hk * G::CG * 8192);               // its WTILE
-                int m1 = nx.m;
-                asm volatile("" : "+s"(m1));
-                const __amdgpu_buffer_rsrc_t rwn = make_rsrc(pk.m[m1].w1, (unsigned)(nmt * nch) * wt);
-                convh_dma_stage<G>(rwn, ring, (g0 + NS) & 3, (unsigned)(hmt * nch) * wt + (unsigned)((NS - G::NST) * G::STAGE_BYTES),
-                                   wave, lane);
-            } else {
-                convh_dma_stage<G>(rw, ring, (g0 + NS) & 3,
-                                   more ? wnext + (unsigned)((NS - G::NST) * G::STAGE_BYTES) : kOutOfRange, wave, lane);
-            }
-            if constexpr (GS == G::RAWST) {
-                if (hand) {
-                    int hb, hnt, hmt, hk;
-                    next_item(hb, hnt, hmt, hk);
-                    int m1 = nx.m, tidh = tid;
-                    asm volatile("" : "+s"(m1), "+v"(tidh));
-                    const float* const hx = pk.m[m1].x;
-                    convh_with_taps<G>(hk, [&](auto GN) {
-                        typedef decltype(GN) N;
-                        convh_load_raw<N>(raw, hx + hb * ustride, p.T, hnt * N::NTC - N::P, tidh, !(p.dbg & 1), p.reflect != 0, N::C);
-                    });
-                } else {
-                    convh_load_raw<G>(raw, mb.x + nb * ustride + nchunk * cstride, p.T, nnt * G::NTC - G::P, tid,
-                                      new_win && !(p.dbg & 1), p.reflect != 0, chunk_channels(nchunk));
-                }
-            }
+            unsigned off;
+            if constexpr (NS < G::NST) off = wcur + (unsigned)(NS * G::STAGE_BYTES);
+            else off = more ? wnext + (unsigned)((NS - G::NST) * G::STAGE_BYTES) : kOutOfRange;
+            convh_dma_stage<G>(rw, ring, (g0 + NS) & 3, off, wave, lane);
+            if constexpr (GS == G::RAWST)
+                convh_load_raw<G>(raw, mb.x + nb * ustride + nchunk * cstride, p.T, nnt * G::NTC - G::P, tid,
+                                  new_win && !(p.dbg & 1), p.reflect != 0, chunk_channels(nchunk));
             if constexpr (GS == G::RESST) {
                 // bias and residual of THIS tile: in flight during the last two stages
                 // (before the tile's last chunk the same loads are issued out of range: the wait counts stay static)
@@ -516,16 +445,8 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
         // the stores first, the conversion of the next window after them: a vmcnt wait cannot tell stores from loads,
         // the next tile's first stage waits would otherwise sit behind the stores' round trip
         if (new_win && !(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid);
-        if (hand && !(p.dbg & 2)) {
-            int m1 = nx.m, tidh = tid;
-            asm volatile("" : "+s"(m1), "+v"(tidh));
-            convh_with_taps<G>(pk.m[m1].k, [&](auto GN) { convh_convert<decltype(GN)>(raw, ximg, p.slope, tidh); });
-        }
         pair_stamp(p, 8, wave, lane, it, 6);
-        if (!more) {
-            g0_io = g0 + G::NST;                         // where the next member's stage 0 sits in the ring
-            break;
-        }
+        if (!more) break;
         g0 += G::NST;
         item = nitem;
         chunk = nchunk;
@@ -533,9 +454,8 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
         ntile = nnt;
         mtile = nmt_;
     }
-    // the DMAs requested for a next item that does not exist wrote zeros; nothing is in flight past this point (after a
-    // hand-over the next member's first stage waits count them, as between two tiles)
-    if (nx.m < 0) pair_wait_vm0();
+    // the DMAs requested for a next item that does not exist wrote zeros; nothing is in flight past this point
+    pair_wait_vm0();
     range_flag(p, bad);
 }
 
@@ -575,31 +495,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     long long total = 0;
 #pragma unroll
     for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_items[m] * cost[m] : 0;
-    // this block's item range of every member first: a member's last tile prefetches for the next member WITH items
-    int mlo[3] = {0, 0, 0}, mhi[3] = {0, 0, 0};
-    {
-        long long base = 0;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            if (m < q.n_members) {
-                if (sched) {
-                    mlo[m] = slo[m];
-                    mhi[m] = shi[m];
-                } else {
-                    mlo[m] = pair_share(blockIdx.x, total, base, cost[m], n_items[m], q.nblk);
-                    mhi[m] = pair_share(blockIdx.x + 1, total, base, cost[m], n_items[m], q.nblk);
-                }
-                base += (long long)n_items[m] * cost[m];
-            }
-        }
-    }
-    const bool carry = p.carry != 0;
-    ConvHRawT<ConvHGeom<CG, NFW, (DIL > 5 ? 3 : 11), DIL>::XRM> raw;
-    int g0 = 0;
-    bool first = true, primed = false;
+    long long base = 0;
+    bool first = true;
     for (int m = 0; m < q.n_members; ++m) {
-        const int lo = m == 0 ? mlo[0] : m == 1 ? mlo[1] : mlo[2];
-        const int hi = m == 0 ? mhi[0] : m == 1 ? mhi[1] : mhi[2];
+        const int n = m == 0 ? n_items[0] : m == 1 ? n_items[1] : n_items[2];
+        const int cm = m == 0 ? cost[0] : m == 1 ? cost[1] : cost[2];
+        int lo, hi;
+        if (sched) {
+            lo = m == 0 ? slo[0] : m == 1 ? slo[1] : slo[2];
+            hi = m == 0 ? shi[0] : m == 1 ? shi[1] : shi[2];
+        } else {
+            lo = pair_share(blockIdx.x, total, base, cm, n, q.nblk);
+            hi = pair_share(blockIdx.x + 1, total, base, cm, n, q.nblk);
+        }
+        base += (long long)n * cm;
         if (lo >= hi) continue;
         // ... and this member's pointers and sizes in one more
         PairMember mb;
@@ -607,22 +516,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         mb.add2 = p.m[m].add2; mb.y = p.m[m].y; mb.y_act = p.m[m].y_act; mb.k = p.m[m].k; mb.n_tiles = p.m[m].n_tiles;
         asm volatile("" ::"s"(mb.x), "s"(mb.w1), "s"(mb.b1), "s"(mb.res), "s"(mb.add1), "s"(mb.add2), "s"(mb.y), "s"(mb.y_act),
                      "s"(mb.k), "s"(mb.n_tiles));
-        ConvHNext nx = {-1, 0};
-        if (carry) {
-            const int m1 = m + 1 < q.n_members && (m == 0 ? mlo[1] < mhi[1] : mlo[2] < mhi[2]) ? m + 1
-                           : (m == 0 && q.n_members > 2 && mlo[2] < mhi[2] ? 2 : -1);
-            if (m1 > 0) {
-                nx.m = m1;
-                nx.item = m1 == 1 ? mlo[1] : mlo[2];
-            }
-        }
         if constexpr (DIL > 5)                            // (dilation 9 is MelGAN's third ResidualStack layer: 3 taps only)
-            convh_run_member<ConvHGeom<CG, NFW, 3, DIL>>(q, mb, lo, hi, smem, wave, lane, first, raw, p, nx, g0, primed);
-        else if (mb.k == 11) convh_run_member<ConvHGeom<CG, NFW, 11, DIL>>(q, mb, lo, hi, smem, wave, lane, first, raw, p, nx, g0, primed);
-        else if (mb.k == 7) convh_run_member<ConvHGeom<CG, NFW, 7, DIL>>(q, mb, lo, hi, smem, wave, lane, first, raw, p, nx, g0, primed);
-        else convh_run_member<ConvHGeom<CG, NFW, 3, DIL>>(q, mb, lo, hi, smem, wave, lane, first, raw, p, nx, g0, primed);
+            convh_run_member<ConvHGeom<CG, NFW, 3, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
+        else if (mb.k == 11) convh_run_member<ConvHGeom<CG, NFW, 11, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
+        else if (mb.k == 7) convh_run_member<ConvHGeom<CG, NFW, 7, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
+        else convh_run_member<ConvHGeom<CG, NFW, 3, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
         first = false;
-        primed = nx.m >= 0;
     }
     pair_stamp(q, 8, wave, lane, 7, 14);
 }
@@ -651,11 +550,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                  "s"(mb.b1), "s"(mb.y), "s"(mb.y_act), "s"(mb.n_tiles), "s"(n_items), "s"(q.guard));
     // equal items: block b takes [b n / nblk, (b + 1) n / nblk)
     const int lo = (int)((long long)blockIdx.x * n_items / q.nblk), hi = (int)((long long)(blockIdx.x + 1) * n_items / q.nblk);
-    typedef ConvHGeom<CG, 2, 2, 1, true> GT;
-    ConvHRaw<GT> raw;
-    const ConvHNext nx = {-1, 0};
-    int g0 = 0;
-    if (lo < hi) convh_run_member<GT>(q, mb, lo, hi, smem, wave, lane, true, raw, p, nx, g0, false);
+    if (lo < hi) convh_run_member<ConvHGeom<CG, 2, 2, 1, true>>(q, mb, lo, hi, smem, wave, lane, true);
 }
 
 }  // namespace fv

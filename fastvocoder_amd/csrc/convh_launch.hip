@@ -161,7 +161,6 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
     pair_schedule(p, p.nblk);
-    p.carry = tuning().convh_carry;
     p.dbg = tuning().pair_dbg;
     p.trace = reinterpret_cast<unsigned long long*>(tuning().trace_ptr);
     profile_begin(s);
@@ -275,7 +274,6 @@ int launch_convp(PairParams p, int dil, hipStream_t s) {
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
     pair_schedule(p, p.nblk);
-    p.carry = tuning().convh_carry;
     p.dbg = tuning().pair_dbg;
     p.trace = nullptr;
     profile_begin(s);

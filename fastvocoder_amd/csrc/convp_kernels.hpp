@@ -30,11 +30,9 @@ struct ConvPGeom {
     static_assert(KT - 1 <= 16 && NST1 >= 3, "taps");
 };
 
-// (raw / nx / g0_io / primed: the hand-over between the members of a block, as in convh_run_member)
 template <class G>
 __device__ __forceinline__ void convp_run_member(const PairParams& p, const PairMember& mb, int item0, int hi_item,
-                                                 float* smem, int wave, int lane_in, bool first, ConvHRaw<typename G::H>& raw,
-                                                 const PairParams& pk, const ConvHNext& nx, int& g0_io, bool primed) {
+                                                 float* smem, int wave, int lane_in, bool first) {
     typedef typename G::H H;
     typedef __attribute__((address_space(3))) const f16x8 LdsH8;
     int lane = lane_in;
@@ -60,15 +58,14 @@ __device__ __forceinline__ void convp_run_member(const PairParams& p, const Pair
     const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(mb.w1, (unsigned)H::WTILE);
     const __amdgpu_buffer_rsrc_t rw2 = make_rsrc(mb.w2, (unsigned)H::WTILE);
     int item = item0;
-    int g0 = primed ? g0_io : 0;
+    int g0 = 0;
     int b = item / mb.n_tiles, tile = item - b * mb.n_tiles;
     if (!first) pair_barrier();
     float bad = 0.f;                                     // range guard (pairh_kernels.hpp range_note)
-    if (!primed) {
-        convh_load_raw<H>(raw, mb.x + b * ustride, p.T, tile * G::NOUT - G::P1 - G::P2, tid, true);
+    ConvHRaw<H> raw;
+    convh_load_raw<H>(raw, mb.x + b * ustride, p.T, tile * G::NOUT - G::P1 - G::P2, tid, true);
 #pragma unroll
-        for (int st = 0; st < 3; ++st) convh_dma_stage<H>(rw1, ring, st, (unsigned)(st * H::STAGE_BYTES), wave, lane);
-    }
+    for (int st = 0; st < 3; ++st) convh_dma_stage<H>(rw1, ring, st, (unsigned)(st * H::STAGE_BYTES), wave, lane);
     if (tid < G::C) {
         bl[tid] = mb.b1 ? mb.b1[tid] : 0.f;
         bl[G::C + tid] = mb.b2 ? mb.b2[tid] : 0.f;
@@ -76,15 +73,12 @@ __device__ __forceinline__ void convp_run_member(const PairParams& p, const Pair
     // rows [NM, MRP) of the intermediate feed only discarded columns: finite values once
     for (int idx = tid; idx < 2 * (G::C / 8) * 64; idx += 512)
         reinterpret_cast<float*>(mimg + ((idx >> 6) * G::MRP + G::NM) * 16)[idx & 63] = 0.f;
-    if (!primed) {
-        pair_wait_vm0();
-        if (!(p.dbg & 2)) convh_convert<H>(raw, ximg, p.slope, tid);
-    }
+    pair_wait_vm0();
+    if (!(p.dbg & 2)) convh_convert<H>(raw, ximg, p.slope, tid);
     for (;;) {
         const int t0 = tile * G::NOUT;
         const int nitem = item + 1;
         const bool more = nitem < hi_item;
-        const bool hand = !more && nx.m >= 0;            // the block's last tile of this member: prefetch for the next one
         int nb = b, ntile = tile + 1;
         if (ntile == mb.n_tiles) {
             ntile = 0;
@@ -108,30 +102,11 @@ __device__ __forceinline__ void convp_run_member(const PairParams& p, const Pair
                 convh_dma_stage<H>(rw1, ring, (g0 + NS) & 3, (unsigned)(NS * H::STAGE_BYTES), wave, lane);
             else if constexpr (NS < G::NST)
                 convh_dma_stage<H>(rw2, ring, (g0 + NS) & 3, (unsigned)((NS - G::NST1) * H::STAGE_BYTES), wave, lane);
-            else if (hand) {                             // the next member's conv1 stage NS - NST (read from the kernel arguments)
-                int m1 = nx.m;
-                asm volatile("" : "+s"(m1));           // (laundered: see convh_run_member)
-                const __amdgpu_buffer_rsrc_t rwn = make_rsrc(pk.m[m1].w1, (unsigned)(pk.m[m1].k * 2 * 8192));
-                convh_dma_stage<H>(rwn, ring, (g0 + NS) & 3, (unsigned)((NS - G::NST) * H::STAGE_BYTES), wave, lane);
-            } else
+            else
                 convh_dma_stage<H>(rw1, ring, (g0 + NS) & 3,
                                    more ? (unsigned)((NS - G::NST) * H::STAGE_BYTES) : kOutOfRange, wave, lane);
-            if constexpr (GS == G::RAWST) {
-                if (hand) {                               // its first tile: its own taps -- window start and tile advance differ
-                    int m1 = nx.m, tidh = tid;
-                    asm volatile("" : "+s"(m1), "+v"(tidh));
-                    const PairMember& nm = pk.m[m1];
-                    const int hb = nx.item / nm.n_tiles, htile = nx.item - hb * nm.n_tiles;
-                    const float* const hx = nm.x;
-                    convh_with_taps<H>(nm.k, [&](auto GN) {
-                        typedef decltype(GN) N;
-                        constexpr int NOUTN = N::NTC - (N::KT - 1), PN = (N::KT - 1) * N::DIL / 2 + (N::KT - 1) / 2;
-                        convh_load_raw<N>(raw, hx + hb * ustride, p.T, htile * NOUTN - PN, tidh, !(p.dbg & 1));
-                    });
-                } else {
-                    convh_load_raw<H>(raw, mb.x + nb * ustride, p.T, ntile * G::NOUT - G::P1 - G::P2, tid, more && !(p.dbg & 1));
-                }
-            }
+            if constexpr (GS == G::RAWST)
+                convh_load_raw<H>(raw, mb.x + nb * ustride, p.T, ntile * G::NOUT - G::P1 - G::P2, tid, more && !(p.dbg & 1));
             if constexpr (GS == G::RESST) {
                 const __amdgpu_buffer_rsrc_t rr = make_rsrc(mb.x + b * ustride, ubytes);     // the residual is x itself
 #pragma unroll
@@ -295,21 +270,13 @@ __device__ __forceinline__ void convp_run_member(const PairParams& p, const Pair
                            col < G::NOUT && t0 + col < p.T && !(p.dbg & 8), v, fin);
             }
         if (more && !(p.dbg & 2)) convh_convert<H>(raw, ximg, p.slope, tid);
-        if (hand && !(p.dbg & 2)) {
-            int m1 = nx.m, tidh = tid;
-            asm volatile("" : "+s"(m1), "+v"(tidh));
-            convh_with_taps<H>(pk.m[m1].k, [&](auto GN) { convh_convert<decltype(GN)>(raw, ximg, p.slope, tidh); });
-        }
-        if (!more) {
-            g0_io = g0 + G::NST;
-            break;
-        }
+        if (!more) break;
         g0 += G::NST;
         item = nitem;
         b = nb;
         tile = ntile;
     }
-    if (nx.m < 0) pair_wait_vm0();
+    pair_wait_vm0();
     range_flag(p, bad);
 }
 
@@ -345,50 +312,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     long long total = 0;
 #pragma unroll
     for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_items[m] * cost[m] : 0;
-    int mlo[3] = {0, 0, 0}, mhi[3] = {0, 0, 0};
-    {
-        long long base = 0;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            if (m < q.n_members) {
-                if (sched) {
-                    mlo[m] = slo[m];
-                    mhi[m] = shi[m];
-                } else {
-                    mlo[m] = pair_share(blockIdx.x, total, base, cost[m], n_items[m], q.nblk);
-                    mhi[m] = pair_share(blockIdx.x + 1, total, base, cost[m], n_items[m], q.nblk);
-                }
-                base += (long long)n_items[m] * cost[m];
-            }
-        }
-    }
-    const bool carry = p.carry != 0;
-    ConvHRawT<ConvHGeom<2, 2, 11, DIL>::XRM> raw;
-    int g0 = 0;
-    bool first = true, primed = false;
+    long long base = 0;
+    bool first = true;
     for (int m = 0; m < q.n_members; ++m) {
-        const int lo = m == 0 ? mlo[0] : m == 1 ? mlo[1] : mlo[2];
-        const int hi = m == 0 ? mhi[0] : m == 1 ? mhi[1] : mhi[2];
+        const int n = m == 0 ? n_items[0] : m == 1 ? n_items[1] : n_items[2];
+        const int cm = m == 0 ? cost[0] : m == 1 ? cost[1] : cost[2];
+        int lo, hi;
+        if (sched) {
+            lo = m == 0 ? slo[0] : m == 1 ? slo[1] : slo[2];
+            hi = m == 0 ? shi[0] : m == 1 ? shi[1] : shi[2];
+        } else {
+            lo = pair_share(blockIdx.x, total, base, cm, n, q.nblk);
+            hi = pair_share(blockIdx.x + 1, total, base, cm, n, q.nblk);
+        }
+        base += (long long)n * cm;
         if (lo >= hi) continue;
         PairMember mb;
         mb.x = p.m[m].x; mb.w1 = p.m[m].w1; mb.w2 = p.m[m].w2; mb.b1 = p.m[m].b1; mb.b2 = p.m[m].b2; mb.add1 = p.m[m].add1;
         mb.add2 = p.m[m].add2; mb.y = p.m[m].y; mb.y_act = p.m[m].y_act; mb.k = p.m[m].k; mb.n_tiles = p.m[m].n_tiles;
         asm volatile("" ::"s"(mb.x), "s"(mb.w1), "s"(mb.w2), "s"(mb.b1), "s"(mb.b2), "s"(mb.add1), "s"(mb.add2), "s"(mb.y),
                      "s"(mb.y_act), "s"(mb.k), "s"(mb.n_tiles));
-        ConvHNext nx = {-1, 0};
-        if (carry) {
-            const int m1 = m + 1 < q.n_members && (m == 0 ? mlo[1] < mhi[1] : mlo[2] < mhi[2]) ? m + 1
-                           : (m == 0 && q.n_members > 2 && mlo[2] < mhi[2] ? 2 : -1);
-            if (m1 > 0) {
-                nx.m = m1;
-                nx.item = m1 == 1 ? mlo[1] : mlo[2];
-            }
-        }
-        if (mb.k == 11) convp_run_member<ConvPGeom<11, DIL>>(q, mb, lo, hi, smem, wave, lane, first, raw, p, nx, g0, primed);
-        else if (mb.k == 7) convp_run_member<ConvPGeom<7, DIL>>(q, mb, lo, hi, smem, wave, lane, first, raw, p, nx, g0, primed);
-        else convp_run_member<ConvPGeom<3, DIL>>(q, mb, lo, hi, smem, wave, lane, first, raw, p, nx, g0, primed);
+        if (mb.k == 11) convp_run_member<ConvPGeom<11, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
+        else if (mb.k == 7) convp_run_member<ConvPGeom<7, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
+        else convp_run_member<ConvPGeom<3, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
         first = false;
-        primed = nx.m >= 0;
     }
 }
 

@@ -152,7 +152,6 @@ struct Tuning {
     int krows = 176;
     int grid_cap = 1024;
     int no_group = 0;
-    int convh_carry = 1;     // weight ring and window prefetch carried across a member switch (convh / convp)
     unsigned long long trace_ptr = 0;   // FV_PAIR_TRACE_PTR (with -DFV_PAIR_TRACE builds only): device buffer for cycle stamps
 };
 const Tuning& tuning();
@@ -196,7 +195,6 @@ struct PairParams {
     float* fold_y;       //   act_slope to the pair's own (never stored) output in front of it
     int* guard;          // split-f16 kernels: device-visible word set to 1 when a final value is not finite (an operand
                          // left the f16 range): pairh_kernels.hpp range_note; null: no check
-    int carry;           // convh / convp: a member's last tile prefetches weights and window of the block's next member
     int sched_on;        // convh / convp: sched[] holds this launch's block schedule (pair_schedule); 0: the kernel cuts
                          // the cost-weighted item sequence into nblk contiguous shares itself (pair_share)
     int reflect;         // convh: rows outside [0, T) are the mirrored samples (ReflectionPad1d) instead of zeros

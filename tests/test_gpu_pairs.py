@@ -319,7 +319,7 @@ def test_conv1d_split_f16_reflection_rejects():
 @pytest.fixture
 def tuning():
     """fv_tuning_set for the duration of a test (process-wide switches of the launchers: restored afterwards)."""
-    defaults = {"sched": 1, "sched_switch": 4, "convh_blocks": 0, "pair_blocks": 0, "convh_carry": 1}
+    defaults = {"sched": 1, "sched_switch": 4, "convh_blocks": 0, "pair_blocks": 0}
     yield _native.tuning_set
     for k, v in defaults.items():
         _native.tuning_set(k, v)

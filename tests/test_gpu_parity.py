@@ -793,14 +793,16 @@ def test_basis_forward_caches_the_zero_pass():
 # outside the split-f16 domain: the reference is defined for any finite fp32 -- so is the engine
 # ---------------------------------------------------------------------------
 def _scaled_hifigan(gain, seed=0):
-    """HiFi-GAN light whose first upsampler is `gain` times too loud and whose conv_post undoes it: every ResBlock
-    stage then works at `gain` times its usual scale (beyond the f16 range for gain = 1e6) while the waveform stays
-    comparable to the unscaled model's (leaky ReLU is homogeneous; only the biases do not scale)."""
+    """HiFi-GAN light whose conv_pre (an fp32 kernel: no weight limit) is `gain` times too loud and whose conv_post
+    undoes it: every split-f16 layer then works at `gain` times its usual scale (beyond the f16 range for gain = 1e6)
+    with its weights untouched, while the waveform stays comparable to the unscaled model's (leaky ReLU is homogeneous;
+    only the inner biases do not scale)."""
     cfg = cases.load_conf("conf/hifigan/light.yaml")
     m, _ = _model("hifigan", cfg, seed=seed)
     m.remove_weight_norm()
     with torch.no_grad():
-        m.ups[0].weight.mul_(gain)
+        m.conv_pre.weight.mul_(gain)
+        m.conv_pre.bias.mul_(gain)
         m.conv_post.weight.mul_(1.0 / gain)
     return m
 
@@ -829,7 +831,7 @@ def test_generator_beyond_the_f16_range_repeats_on_fp32():
     assert _err(want, ref) <= TOL
     # forward: stream-ordered, the check is deferred
     lazy = _scaled_hifigan(1e6)
-    x = torch.from_numpy(seeded_mel(64, seed=31, batch=1)).to(_dev())
+    x = torch.from_numpy(np.ascontiguousarray(mel.T[None])).to(_dev())      # the same mel, forward layout [1, 80, T]
     with torch.no_grad():
         first = lazy(x)
         with pytest.warns(RuntimeWarning, match="split-f16 range"):

@@ -1,6 +1,6 @@
-"""A/B of the block schedule and the member hand-over of the weight-streaming kernels (tuning aid):
-HiFi-GAN light, B utterances of 1000 frames; for every (convh_carry, sched, sched_switch) setting the step time, the
-per-family kernel time and whether the waveform is bit-identical to the default's.  python tools/carry_sweep.py [B]"""
+"""A/B of the block schedule of the weight-streaming kernels (tuning aid): HiFi-GAN light, B utterances of 1000
+frames; for every (sched, sched_switch, convh_skel, convp_skel) setting the step time, the per-family kernel time and
+whether the waveform is bit-identical to the default's.  python tools/sched_sweep.py [B]"""
 import os
 import sys
 import time
@@ -45,13 +45,20 @@ def families(reps=5):
 
 
 ref = None
-for carry, sched, sw in ((1, 1, 4), (0, 1, 4), (1, 2, 4), (1, 2, 2), (1, 2, 1), (1, 2, 0), (0, 2, 4), (1, 0, 4), (0, 0, 4)):
-    _native.tuning_set("convh_carry", carry)
+settings = [(1, 4, -1, 5)]
+for sched in (2,):
+    for sw in (0, 4):
+        for hs, ps in ((-1, 5), (6, 8), (10, 12), (14, 16)):
+            settings.append((sched, sw, hs, ps))
+settings += [(1, 4, 6, 8), (1, 4, 10, 12), (0, 4, 6, 8), (0, 4, 10, 12)]
+for sched, sw, hs, ps in settings:
     _native.tuning_set("sched", sched)
     _native.tuning_set("sched_switch", sw)
+    _native.tuning_set("convh_skel", hs)
+    _native.tuning_set("convp_skel", ps)
     ms, y = run()
     ms2, _ = run()
     if ref is None:
         ref = y.clone()
-    print(f"carry={carry} sched={sched} switch={sw}: {ms:.4f} / {ms2:.4f} ms/step  families(us incl. event cost) {families()}"
-          f"  same_bits={bool(torch.equal(y, ref))}", flush=True)
+    print(f"sched={sched} switch={sw} convh_skel={hs} convp_skel={ps}: {ms:.4f} / {ms2:.4f} ms/step  "
+          f"families(us incl. event cost) {families()}  same_bits={bool(torch.equal(y, ref))}", flush=True)
