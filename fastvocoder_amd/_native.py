@@ -18,7 +18,8 @@ _CSRC = os.path.join(_HERE, "csrc")
 # so that the ~170 kernel variants compile in parallel
 SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip", "wav_sink.hip", "conv_inst_narrow.hip",
            "pair_launch.hip", "pair_inst_c16.hip", "pair_inst_c32.hip", "pairh_inst_c16.hip", "pairh_inst_c32.hip",
-           "convh_launch.hip", "convh_inst_c64.hip", "convh_inst_c128.hip", "convp_inst.hip", "convt_inst.hip"] + \
+           "convh_launch.hip", "convh_inst_c64.hip", "convh_inst_c128.hip", "convp_inst.hip", "convt_inst.hip",
+           "convg_inst.hip"] + \
           [f"conv_inst_s{i}.hip" for i in range(6)]
 HEADERS = ["fv_internal.h", "conv_kernels.hpp", "pair_kernels.hpp", "pair_inst.hpp", "pairh_kernels.hpp",
            "pairh_inst.hpp", "convh_kernels.hpp", "convh_inst.hpp", "convp_kernels.hpp"]
@@ -146,6 +147,13 @@ def lib():
     L.fv_pqmf_synthesis.argtypes = [vp, vp, vp, i, i, i, i, vp]
     L.fv_conv1d_2src_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, f, vp]
     L.fv_plan_add_conv1d_2src.argtypes = [vp, i, i, i, i, i, vp, vp, i, i, i, i, f]
+    L.fv_packed_conv1x1_2src_split_floats.argtypes = [i]
+    L.fv_packed_conv1x1_2src_split_floats.restype = i64
+    L.fv_pack_conv1x1_2src_split_f16.argtypes = [vp, vp, vp, i, vp, vp]
+    L.fv_conv1x1_2src_split_f16.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, f, i, f, vp, vp]
+    L.fv_plan_add_conv1x1_2src_split_f16.argtypes = [vp, i, i, i, i, i, vp, vp, i, f, i, f]
+    L.fv_conv_post_pqmf.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, f, i, i, vp]
+    L.fv_plan_add_conv_post_pqmf.argtypes = [vp, i, i, vp, vp, i, i, i, i, f, i, vp, i]
     L.fv_plan_set_sum_order.argtypes = [vp, i]
     L.fv_plan_add_conv1d_sum3.argtypes = [vp, ctypes.POINTER(i), ctypes.POINTER(i), ctypes.POINTER(i), i, i,
                                           ctypes.POINTER(vp), vp,
@@ -345,6 +353,26 @@ def pack_conv_transpose1d_split(w, stride, flag=None):
     return out
 
 
+def conv1x1_2src_split_supported(channels):
+    """Channel counts of the split-f16 two-source 1x1 conv (csrc/convh_launch.hip launch_convg)."""
+    return channels in (128, 256, 512)
+
+
+def pack_conv1x1_2src_split(w1, w2, flag=None):
+    """Two 1x1 Conv1d weights [C,C,1] -> split-f16 stage image of convg_kernel for y = W1 act(x) + W2 x2 (flat tensor)."""
+    w1, w2 = w1.detach().contiguous().float(), w2.detach().contiguous().float()
+    c = w1.shape[0]
+    if tuple(w1.shape) != (c, c, 1) or tuple(w2.shape) != (c, c, 1):
+        raise NativeError(f"pack_conv1x1_2src_split: two [C,C,1] weights expected, got {tuple(w1.shape)}, {tuple(w2.shape)}")
+    n = lib().fv_packed_conv1x1_2src_split_floats(c)
+    if n <= 0:
+        raise NativeError(f"pack_conv1x1_2src_split: C={c} is not built (128, 256, 512)")
+    out = torch.empty(n, dtype=torch.float32, device=w1.device)
+    with _on(w1, w2) as stream:
+        check(lib().fv_pack_conv1x1_2src_split_f16(_ptr(w1, "w1"), _ptr(w2, "w2"), _ptr(out), c, _flag_ptr(flag), stream))
+    return out
+
+
 def fold_batchnorm_conv(w, b, bn):
     """Fold an eval-mode ``torch.nn.BatchNorm1d`` into the conv weight/bias that follow it;
     returns (w', b') on w's device."""
@@ -502,6 +530,20 @@ def conv1d_2src_fused(x, x2, packed, bias, cout, res=None, post=POST_NONE, out=N
     return out
 
 
+def conv1x1_2src_split_f16(x, x2, packed, bias, pre_slope=1.0, res=None, post=POST_NONE, out=None, out_act=None,
+                           act_slope=1.0, guard=None):
+    """y = post(W1 lrelu(x, pre_slope) + W2 x2 + bias + res), split-f16 operands (fv_conv1x1_2src_split_f16);
+    packed = pack_conv1x1_2src_split(W1, W2)."""
+    B, c, T = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    with _on(x, x2, packed, bias, res, out, out_act) as stream:
+        check(lib().fv_conv1x1_2src_split_f16(_ptr(x, "x"), _ptr(x2, "x2"), _ptr(packed, "packed"), _ptr(bias, "bias", True),
+                                              _ptr(res, "res", True), _ptr(out, "out"), _ptr(out_act, "out_act", True), B, c,
+                                              T, float(pre_slope), post, float(act_slope), _guard_ptr(guard), stream))
+    return out
+
+
 def conv_transpose1d_fused(x, packed, bias, cout, k, stride, pad, out_pad, pre_slope=1.0,
                            post=POST_NONE, out=None, out_act=None, act_slope=1.0):
     B, cin, T = x.shape
@@ -582,6 +624,19 @@ def pqmf_synthesis(x, synthesis_filter, y):
     return y
 
 
+def conv_post_pqmf(x, packed, bias, synthesis_filter, k, pad, pre_slope=1.0, post=POST_TANH):
+    """pqmf_synthesis(post(conv1d(lrelu(x, pre_slope)) + bias)) in one launch (fv_conv_post_pqmf): x [B,Cin,T],
+    packed = pack_conv1d(w [S,Cin,k]), synthesis_filter [1,S,ntaps] -> [B,1,S*T]."""
+    B, cin, T = x.shape
+    S = synthesis_filter.shape[1]
+    h = synthesis_filter.reshape(S, -1).contiguous().float()
+    y = torch.empty((B, 1, S * T), dtype=torch.float32, device=x.device)
+    with _on(x, packed, bias, h, y) as stream:
+        check(lib().fv_conv_post_pqmf(_ptr(x, "x"), _ptr(packed, "packed"), _ptr(bias, "bias", True), _ptr(h, "h"),
+                                      _ptr(y, "y"), B, cin, S, T, k, pad, float(pre_slope), post, h.shape[1], stream))
+    return y
+
+
 # ---------------------------------------------------------------------------
 # plans
 # ---------------------------------------------------------------------------
@@ -652,6 +707,15 @@ class Plan:
         check(lib().fv_plan_add_conv1d_2src(self._h, x, x2, y, y_act, res, _ptr(packed, "packed"),
                                             _ptr(bias, "bias", True), cin1, cin2, cout, post,
                                             float(act_slope)))
+
+    def add_conv1x1_2src_split_f16(self, x, x2, y, packed, bias, channels, pre_slope=1.0, res=SLOT_NONE, post=POST_NONE,
+                                   y_act=SLOT_NONE, act_slope=1.0):
+        self.keep(packed)
+        if bias is not None:
+            self.keep(bias)
+        check(lib().fv_plan_add_conv1x1_2src_split_f16(self._h, x, x2, y, y_act, res, _ptr(packed, "packed"),
+                                                       _ptr(bias, "bias", True), channels, float(pre_slope), post,
+                                                       float(act_slope)))
 
     def add_upsample_conv1d(self, x, y, packed, bias, cin, cout, k, rate, pad, pre_slope=1.0,
                             post=POST_NONE, y_act=SLOT_NONE, act_slope=1.0):
@@ -745,6 +809,14 @@ class Plan:
         self.keep(h)
         check(lib().fv_plan_add_pqmf_synthesis(self._h, x, y, _ptr(h, "h"), h.shape[0], h.shape[1]))
 
+    def add_conv_post_pqmf(self, x, y, packed, bias, cin, k, pad, h, pre_slope=1.0, post=POST_TANH):
+        """conv_post (cin -> S sub-bands) + post + PQMF synthesis as one op (fv_plan_add_conv_post_pqmf); h [S, ntaps]."""
+        for t in (packed, bias, h):
+            if t is not None:
+                self.keep(t)
+        check(lib().fv_plan_add_conv_post_pqmf(self._h, x, y, _ptr(packed, "packed"), _ptr(bias, "bias", True), cin,
+                                               h.shape[0], k, pad, float(pre_slope), post, _ptr(h, "h"), h.shape[1]))
+
     def set_output_offset(self, aux_slot, y2_slot=SLOT_NONE, y_slot=SLOT_OUT):
         """The op added last (output slot ``y_slot``) subtracts auxiliary input ``aux_slot`` in its epilogue
         (fv_plan_set_output_offset)."""
@@ -829,7 +901,7 @@ def profile_enable(on):
 
 
 KERNEL_CONV_MFMA32, KERNEL_CONV_MFMA16, KERNEL_CONV_NARROW, KERNEL_PAIR16, KERNEL_PAIR32 = 0, 1, 2, 3, 4
-KERNEL_PAIRH16, KERNEL_PAIRH32, KERNEL_CONVH64, KERNEL_CONVH128, KERNEL_CONVT = 5, 6, 7, 8, 9
+KERNEL_PAIRH16, KERNEL_PAIRH32, KERNEL_CONVH64, KERNEL_CONVH128, KERNEL_CONVT, KERNEL_CONVG = 5, 6, 7, 8, 9, 10
 
 
 def profile_bracket_cost(n=200):

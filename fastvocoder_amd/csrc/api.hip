@@ -283,6 +283,24 @@ __global__ void pack_convh_kernel(const float* __restrict__ w, _Float16* __restr
     }
 }
 
+// Two 1x1 conv weights as one [C][2 C] matrix [W1 | W2] (w1, w2: [C][C][1]) for convg_kernel: the stage layout of
+// pack_convh_kernel with one tap and 2 C / 128 chunks of 128 input channels -- W1's, then W2's
+__global__ void pack_convg_kernel(const float* __restrict__ w1, const float* __restrict__ w2, _Float16* __restrict__ wp,
+                                  int C, int* range_flag) {
+    const int NCH = 2 * C / 128, NSTEP = 4;
+    const int64_t total = (int64_t)(C / 64) * NCH * NSTEP * 4 * 2 * 64 * 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63), half = (int)((i >> 9) & 1), mh = (int)((i >> 10) & 3);
+        const int ms = (int)(i >> 12), s = ms % NSTEP, mc = ms / NSTEP, chunk = mc % NCH, mt = mc / NCH;
+        const int co = 64 * mt + 16 * mh + (lane & 15), ci = 128 * chunk + 32 * s + 8 * (lane >> 4) + j;
+        const float v = ci < C ? w1[(size_t)co * C + ci] : w2[(size_t)co * C + (ci - C)];
+        const _Float16 h1 = (_Float16)v;
+        if (range_flag && !(fabsf(v) < kSplitLimit)) *range_flag = 1;
+        wp[i] = half == 0 ? h1 : (_Float16)((v - (float)h1) * 2048.f);
+    }
+}
+
 // ConvTranspose1d weights w[Cin][Cout][2 s] for convt_kernel (convh_kernels.hpp): the same stage layout, rows
 // m = co * s + phase, K = (tap, ci): tap 0 multiplies x[u - 1] (kernel index s + phase), tap 1 x[u] (kernel index phase)
 __global__ void pack_convth_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int Cin, int Cout, int s_, int* range_flag) {
@@ -305,7 +323,7 @@ __global__ void pack_convth_kernel(const float* __restrict__ w, _Float16* __rest
 // ---------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------
-enum OpType { OP_CONV = 0, OP_CONVT = 1, OP_PQMF = 2, OP_UPCONV = 3, OP_PAIR = 4, OP_MRFSUM = 5, OP_CONVH = 6 };
+enum OpType { OP_CONV = 0, OP_CONVT = 1, OP_PQMF = 2, OP_UPCONV = 3, OP_PAIR = 4, OP_MRFSUM = 5, OP_CONVH = 6, OP_CONVG = 7 };
 
 struct Op {
     int type;
@@ -339,6 +357,10 @@ struct Op {
     const float* fold_w = nullptr;
     const float* fold_b = nullptr;
     int sub = FV_SLOT_NONE;   // fv_plan_set_output_offset: auxiliary input subtracted in this op's epilogue
+    // fv_plan_add_conv_post_pqmf: an OP_CONV (Cout = S sub-bands) whose launch also runs the PQMF synthesis: y is the
+    // FULL-BAND output [B, 1, S * T']
+    const float* pq_h = nullptr;
+    int pq_taps = 0;
 };
 
 struct Shape {
@@ -363,9 +385,11 @@ struct fv_plan {
 namespace fv {
 
 static int64_t conv_out_len(const Op& o, int64_t Tin) {
-    if (o.type == OP_PAIR || o.type == OP_MRFSUM || o.type == OP_CONVH) return Tin;
-    if (o.type == OP_CONV)
-        return (o.pad_mode & FV_PAD_CAUSAL) ? Tin : Tin + 2LL * o.pad - (int64_t)o.dil * (o.k - 1);
+    if (o.type == OP_PAIR || o.type == OP_MRFSUM || o.type == OP_CONVH || o.type == OP_CONVG) return Tin;
+    if (o.type == OP_CONV) {
+        const int64_t t = (o.pad_mode & FV_PAD_CAUSAL) ? Tin : Tin + 2LL * o.pad - (int64_t)o.dil * (o.k - 1);
+        return o.pq_h ? t * o.Cout : t;      // (conv_post + pqmf: the S sub-bands interleave into S * T' samples)
+    }
     if (o.type == OP_CONVT) return (Tin - 1) * o.stride - 2LL * o.pad + o.k + o.out_pad;
     if (o.type == OP_UPCONV) return Tin * o.stride + 2LL * o.pad - (o.k - 1);
     return Tin * o.Cin;  // PQMF: S sub-bands interleave into S*Tsub samples
@@ -394,7 +418,7 @@ static int infer(const fv_plan* plan, int B, int T, Shape* sh, int64_t* slot_ele
                         o.x2, o.Cin - o.Cin1);
         const int64_t Tout = conv_out_len(o, sh[o.x].T);
         if (Tout <= 0) return fail(FV_ERR_INVALID_ARG, "op %zu: empty output (T=%lld)", n, (long long)sh[o.x].T);
-        const int Cout = o.type == OP_PQMF ? 1 : o.Cout;
+        const int Cout = (o.type == OP_PQMF || o.pq_h) ? 1 : o.Cout;
         const int aux[3] = {o.res, o.acc, o.acc2};
         for (int a = 0; a < 3; ++a) {
             if (aux[a] == FV_SLOT_NONE) continue;
@@ -511,6 +535,32 @@ static int run_op(const Op& o, const float* x, float* y, float* y2, const float*
                   const float* acc2, int B, int64_t Tin, hipStream_t s, const float* x2 = nullptr,
                   const float* sub = nullptr, int sub_batched = 0, int* guard = nullptr) {
     if (o.type == OP_PQMF) return launch_pqmf(x, o.wp, y, y2, sub, sub_batched, B, o.Cin, o.k, (int)Tin, s);
+    if (o.pq_h) {
+        Op c = o;                              // the conv in front: [B, S, T'] sub-bands that never leave the CU
+        c.pq_h = nullptr;
+        return launch_conv_post_pqmf(make_params(c, x, y, nullptr, nullptr, nullptr, nullptr, B, Tin), o.pq_h, o.pq_taps, y, y2,
+                                     sub, sub_batched, s);
+    }
+    if (o.type == OP_CONVG) {
+        PairParams pp = {};
+        pp.B = B;
+        pp.T = (int)Tin;
+        pp.slope = o.pre_slope;
+        pp.act_slope = o.act_slope;
+        pp.post = o.post;
+        pp.prec = FV_PAIR_SPLIT_F16;
+        pp.guard = guard;
+        pp.sub = sub;
+        pp.sub_batched = sub_batched;
+        pp.m[0].x = x;
+        pp.m[0].x2 = x2;
+        pp.m[0].w1 = o.wp;
+        pp.m[0].b1 = o.bias;
+        pp.m[0].res = res;
+        pp.m[0].y = y;
+        pp.m[0].y_act = y2;
+        return launch_convg(pp, o.Cout, s);
+    }
     if (o.type == OP_CONVT && o.prec == FV_PAIR_SPLIT_F16) {
         PairParams pp = {};
         pp.B = B;
@@ -1017,6 +1067,60 @@ int fv_conv1d_2src_fused(const float* x, const float* x2, const float* packed, c
     return run_op(o, x, y, y_act, res, nullptr, nullptr, B, T, (hipStream_t)stream, x2);
 }
 
+// ---- two-source 1x1 conv with split-f16 operands (convg_kernel) ----
+int64_t fv_packed_conv1x1_2src_split_floats(int C) {
+    if (C != 128 && C != 256 && C != 512) return 0;
+    return (int64_t)(C / 64) * (2 * C / 128) * 4 * 2048;      // row tiles x chunks x 4 K steps x 8 KB
+}
+
+int fv_pack_conv1x1_2src_split_f16(const float* w1, const float* w2, float* packed, int C, int* range_flag, void* stream) {
+    if (!w1 || !w2 || !packed) return fail(FV_ERR_INVALID_ARG, "pack_conv1x1_2src_split_f16: null tensor");
+    const int64_t total = fv_packed_conv1x1_2src_split_floats(C) * 2;
+    if (total <= 0) return fail(FV_ERR_UNSUPPORTED, "pack_conv1x1_2src_split_f16: C = %d (128, 256 or 512)", C);
+    hipLaunchKernelGGL(pack_convg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w1, w2,
+                       reinterpret_cast<_Float16*>(packed), C, range_flag);
+    FV_HIP(hipGetLastError());
+    return 0;
+}
+
+int fv_conv1x1_2src_split_f16(const float* x, const float* x2, const float* packed, const float* bias, const float* res,
+                              float* y, float* y_act, int B, int C, int T, float pre_slope, int post, float act_slope,
+                              int* guard, void* stream) {
+    if (!x || !x2 || !packed || !y) return fail(FV_ERR_INVALID_ARG, "conv1x1_2src_split_f16: null tensor");
+    if (x == y || x2 == y || x == y_act || x2 == y_act || (y_act && y_act == y) || (res && (res == y || res == y_act)))
+        return fail(FV_ERR_INVALID_ARG, "conv1x1_2src_split_f16: y / y_act must not alias an input or each other");
+    if (B < 0 || T < 0) return fail(FV_ERR_INVALID_ARG, "conv1x1_2src_split_f16: B=%d T=%d", B, T);
+    Op o = {};
+    o.type = OP_CONVG;
+    o.wp = packed;
+    o.bias = bias;
+    o.Cin = 2 * C;
+    o.Cin1 = C;
+    o.Cout = C;
+    o.k = 1;
+    o.dil = 1;
+    o.pre_slope = pre_slope;
+    o.out_div = 1.f;
+    o.post = post;
+    o.act_slope = act_slope;
+    return run_op(o, x, y, y_act, res, nullptr, nullptr, B, T, (hipStream_t)stream, x2, nullptr, 0, guard);
+}
+
+int fv_plan_add_conv1x1_2src_split_f16(fv_plan_t* plan, int x_slot, int x2_slot, int y_slot, int y_act_slot, int res_slot,
+                                       const float* packed, const float* bias, int C, float pre_slope, int post,
+                                       float act_slope) {
+    if (fv_packed_conv1x1_2src_split_floats(C) <= 0)
+        return fail(FV_ERR_UNSUPPORTED, "plan_add_conv1x1_2src_split_f16: C = %d (128, 256 or 512)", C);
+    if (int rc = fv_plan_add_conv1d_2src(plan, x_slot, x2_slot, y_slot, y_act_slot, res_slot, packed, bias, C, C, C, post,
+                                         act_slope))
+        return rc;
+    Op& o = plan->ops.back();
+    o.type = OP_CONVG;
+    o.pre_slope = pre_slope;
+    o.prec = FV_PAIR_SPLIT_F16;
+    return 0;
+}
+
 int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot,
                                  const float* packed, const float* bias, int Cin, int Cout, int k,
                                  int stride, int pad, int out_pad, float pre_slope, int post,
@@ -1063,6 +1167,45 @@ int fv_plan_add_conv_transpose1d_split_f16(fv_plan_t* plan, int x_slot, int y_sl
         return rc;
     plan->ops.back().prec = FV_PAIR_SPLIT_F16;
     return 0;
+}
+
+int fv_plan_add_conv_post_pqmf(fv_plan_t* plan, int x_slot, int y_slot, const float* packed, const float* bias, int Cin,
+                               int S, int k, int pad, float pre_slope, int post, const float* h, int ntaps) {
+    if (!h || S != 4 || ntaps != 63)
+        return fail(FV_ERR_UNSUPPORTED, "plan_add_conv_post_pqmf: S=%d ntaps=%d (4 sub-bands, 63 taps)", S, ntaps);
+    if (int rc = fv_plan_add_conv1d(plan, x_slot, y_slot, FV_SLOT_NONE, FV_SLOT_NONE, FV_SLOT_NONE, FV_SLOT_NONE, packed, bias,
+                                    Cin, S, k, 1, pad, FV_PAD_ZERO, pre_slope, 1.f, post, 1.f))
+        return rc;
+    Op& o = plan->ops.back();
+    o.group = 0;
+    o.pq_h = h;
+    o.pq_taps = ntaps;
+    return 0;
+}
+
+int fv_conv_post_pqmf(const float* x, const float* packed, const float* bias, const float* h, float* y, int B, int Cin,
+                      int S, int T, int k, int pad, float pre_slope, int post, int ntaps, void* stream) {
+    if (!x || !packed || !h || !y) return fail(FV_ERR_INVALID_ARG, "conv_post_pqmf: null tensor");
+    if (S != 4 || ntaps != 63) return fail(FV_ERR_UNSUPPORTED, "conv_post_pqmf: S=%d ntaps=%d (4 sub-bands, 63 taps)", S, ntaps);
+    if (int rc = check_conv_args(Cin, S, k, 1)) return rc;
+    Op o = {};
+    o.type = OP_CONV;
+    o.act_slope = 1.f;
+    o.wp = packed;
+    o.bias = bias;
+    o.Cin = Cin;
+    o.Cout = S;
+    o.k = k;
+    o.dil = 1;
+    o.pad = pad;
+    o.pre_slope = pre_slope;
+    o.out_div = 1.f;
+    o.post = post;
+    o.pq_h = h;
+    o.pq_taps = ntaps;
+    if (B <= 0 || T <= 0) return 0;
+    if (conv_out_len(o, T) <= 0) return fail(FV_ERR_INVALID_ARG, "conv_post_pqmf: empty output");
+    return run_op(o, x, y, nullptr, nullptr, nullptr, nullptr, B, T, (hipStream_t)stream);
 }
 
 int fv_plan_add_pqmf_synthesis(fv_plan_t* plan, int x_slot, int y_slot, const float* h, int S,
@@ -1430,7 +1573,7 @@ int fv_plan_set_output_offset(fv_plan_t* plan, int aux_slot, int y2_slot) {
     Op& o = plan->ops.back();
     if (o.type == OP_PAIR || o.type == OP_MRFSUM || o.type == OP_CONVH || o.sum3 || o.group != 0 ||
         (o.type == OP_CONVT && o.prec == FV_PAIR_SPLIT_F16))   // (a pair with a folded output conv included)
-        return fail(FV_ERR_UNSUPPORTED, "plan_set_output_offset: only plain conv / transposed conv / pqmf ops carry an offset");
+        return fail(FV_ERR_UNSUPPORTED, "plan_set_output_offset: only plain conv / transposed conv / two-source 1x1 / pqmf ops carry an offset");
     if (y2_slot != FV_SLOT_NONE) {
         if (o.y2 != FV_SLOT_NONE) return fail(FV_ERR_INVALID_ARG, "plan_set_output_offset: the op already has a second output");
         if (y2_slot == o.y || y2_slot == o.x || y2_slot == FV_SLOT_IN) return fail(FV_ERR_INVALID_ARG, "plan_set_output_offset: y2 aliases");
@@ -1726,7 +1869,7 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
                             o.x2 == FV_SLOT_NONE ? nullptr : base[o.x2], o.sub == FV_SLOT_NONE ? nullptr : base[o.sub],
                             o.sub == FV_SLOT_NONE ? 0 : aux_b[o.sub - FV_SLOT_AUX_IN0], plan->guard_dev))
             return rc;
-        sh[o.y] = {o.type == OP_PQMF ? 1 : o.Cout, Tout, true};
+        sh[o.y] = {(o.type == OP_PQMF || o.pq_h) ? 1 : o.Cout, Tout, true};
         if (o.y2 != FV_SLOT_NONE) sh[o.y2] = sh[o.y];
     }
     return 0;

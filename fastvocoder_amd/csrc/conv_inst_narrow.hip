@@ -13,4 +13,12 @@ int launch_narrow(const ConvParams& p, size_t lds, int grid_x, hipStream_t s) {
     return 0;
 }
 
+int launch_post_pqmf_kernel(const ConvParams& p, const PqmfTail& q, size_t lds, int grid_x, hipStream_t s) {
+    dim3 grid(grid_x, p.B), block(256);
+    hipLaunchKernelGGL(conv_post_pqmf_kernel<4>, grid, block, lds, s, p, q);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, "conv_post + pqmf launch: %s", hipGetErrorString(e));
+    return 0;
+}
+
 }  // namespace fv

@@ -1070,6 +1070,105 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(ConvParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// conv_post + tanh + PQMF synthesis in one launch (Multiband-HiFi-GAN's inference tail, multiband_hifigan.py:114-115,136
+// with pqmf.py:121-135): the narrow conv above for MO = S sub-bands, whose activated tile goes to LDS instead of HBM,
+// followed by the polyphase synthesis of pqmf.hip on that tile.  A block computes 256 sub-band samples and emits the
+// S * 240 full-band samples whose 16 live taps per band lie inside them (8 sub-band samples of halo either side are
+// recomputed by the neighbours): the [B, S, T'] sub-band tensor never exists.  Same FMA order as the two kernels it
+// replaces: bit-identical to conv_narrow_kernel followed by pqmf_synthesis_kernel.
+// ---------------------------------------------------------------------------
+
+template <int MO>
+__global__ __launch_bounds__(256) void conv_post_pqmf_kernel(ConvParams p, PqmfTail q) {
+    constexpr int NT = 256, NW = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;
+    float* ws = smem + p.xbuf;  // [ci_chunk*k][16]
+    float* sb = smem + q.tail_off;          // [MO][256]: tanh(conv_post) of the block's sub-band window
+    float* hs = sb + MO * 256;              // [MO][ntaps], scaled by MO (pqmf.hip)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const int bx = xcd_remap(blockIdx.x, gridDim.x);
+    const int t0 = bx * kPqmfAdvance - kPqmfHalo;        // first sub-band sample of the window (a multiple of 4)
+    const int k = p.k;
+    const int aoff = (((-p.pad) % 4) + 4) % 4;
+    const int tA = t0 - p.pad - aoff;
+    float acc[MO];
+#pragma unroll
+    for (int m = 0; m < MO; ++m) acc[m] = 0.f;
+    const __amdgpu_buffer_rsrc_t rx =
+        make_rsrc(p.x + (size_t)b * p.Cin * (size_t)p.Tin, (unsigned)p.Cin * (unsigned)p.Tin * 4u);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.wp, (unsigned)p.Cin * (unsigned)p.k * (unsigned)p.Mpad * 4u);
+    DmaPlan dp;
+    dma_plan<NW, 16>(p, dp, 0, wave, lane);
+    const float slope = p.pre_slope;
+    for (int i = tid; i < MO * q.ntaps; i += NT) hs[i] = q.h[i] * (float)MO;
+    for (int ci0 = 0; ci0 < p.Cin; ci0 += p.ci_chunk) {
+        dma_w<NW, 16>(p, dp, rw, ws, ci0, wave);
+        stage_x<NW, NT, true>(p, dp, rx, xs, p.x + (size_t)b * p.Cin * (size_t)p.Tin, p.Cin, ci0, tA, wave, lane, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float* pb = xs + aoff + tid;
+        for (int ci = 0; ci < p.ci_chunk; ++ci) {
+            for (int tap = 0; tap < k; ++tap) {
+                const float xv = act(pb[ci * p.xw + tap * p.dil], slope);
+                const float* wrow = ws + (ci * k + tap) * 16;
+#pragma unroll
+                for (int m = 0; m < MO; ++m) acc[m] = fmaf(wrow[m], xv, acc[m]);
+            }
+        }
+        __syncthreads();
+    }
+    {
+        // the sub-bands of this window: + bias, post; zero outside [0, Tsub) (the synthesis filter sees a zero-padded signal)
+        const int t = t0 + tid;
+        const bool ok = t >= 0 && t < p.Tq;
+#pragma unroll
+        for (int m = 0; m < MO; ++m) {
+            float v = acc[m] + (p.bias ? p.bias[m] : 0.f);
+            if (p.post == FV_POST_TANH) v = tanhf(v);
+            else if (p.post == FV_POST_RELU) v = fmaxf(v, 0.f);
+            sb[m * 256 + tid] = ok ? v : 0.f;
+        }
+    }
+    __syncthreads();
+    const int Tsub = p.Tq, ntaps = q.ntaps, half = (ntaps - 1) / 2;
+    const long long T = (long long)MO * Tsub;
+#pragma unroll
+    for (int r = 0; r < MO; ++r) {
+        const int local = tid + NT * r;
+        const long long n = (long long)MO * bx * kPqmfAdvance + local;
+        if (local >= MO * kPqmfAdvance || n >= T) continue;
+        int j0 = (int)((half - n) % MO);
+        if (j0 < 0) j0 += MO;
+        const int mbase = (int)((n + j0 - half) / MO);  // exact: divisible by construction
+        float a = 0.f;
+        for (int kb = 0; kb < MO; ++kb) {
+            const float* xr = sb + kb * 256 - t0;
+            const float* hr = hs + kb * ntaps;
+            for (int j = j0, i = 0; j < ntaps; j += MO, ++i) {
+                const int m = mbase + i;
+                if (m >= 0 && m < Tsub) a = fmaf(hr[j], xr[m], a);
+            }
+        }
+        const size_t o = (size_t)b * (size_t)T + (size_t)n;
+        if (q.sub) {
+            const float d = a - q.sub[(q.sub_batched ? (size_t)b * (size_t)T : 0) + (size_t)n];
+            if (q.y2) {
+                q.y[o] = a;
+                q.y2[o] = d;
+            } else {
+                q.y[o] = d;
+            }
+        } else {
+            q.y[o] = a;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // launch of one tile shape: picks the kernel variant (tap count, dilation, SLOW / ACT) --
 // instantiated once per shape in conv_inst_*.hip so that the shapes compile in parallel
 // ---------------------------------------------------------------------------

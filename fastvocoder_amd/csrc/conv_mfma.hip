@@ -12,6 +12,7 @@ int launch_geom(const ConvParams& p, size_t lds, int grid_x, hipStream_t s);
 template <int MF, int WM, int WN, int WK, int NR>
 int launch_group_geom(const GroupParams& gp, size_t lds, int grid_x, int B, int dil, hipStream_t s);
 int launch_narrow(const ConvParams& p, size_t lds, int grid_x, hipStream_t s);
+int launch_post_pqmf_kernel(const ConvParams& p, const PqmfTail& q, size_t lds, int grid_x, hipStream_t s);
 template <int MF, int WN, int NR>
 int launch_sum3_geom(const Sum3Params& sp, size_t lds, int grid_x, hipStream_t s);
 extern template int launch_sum3_geom<32, 4, 1>(const Sum3Params&, size_t, int, hipStream_t);
@@ -228,6 +229,25 @@ int launch_conv(ConvParams p, hipStream_t s) {
         rc = launch_shape(li.shape, p, li.lds, li.grid_x, s);
     }
     profile_end(s, li.kind, li.flops, li.bytes);
+    return rc;
+}
+
+int launch_conv_post_pqmf(ConvParams p, const float* h, int ntaps, float* y, float* y2, const float* sub, int sub_batched,
+                          hipStream_t s) {
+    if (p.B <= 0 || p.Tq <= 0 || p.Cin <= 0) return 0;
+    if (p.M != 4 || p.ups != 1 || ntaps != 63 || p.res || p.acc_in || p.y_act)
+        return fail(FV_ERR_UNSUPPORTED, "conv_post + pqmf: 4 sub-bands, 63 taps, a plain conv in front (Cout=%d ntaps=%d)", p.M, ntaps);
+    if ((double)p.M * p.Tq * 4.0 >= 1073741824.0)
+        return fail(FV_ERR_UNSUPPORTED, "conv_post + pqmf: the utterance exceeds the 1 GiB range of the kernels; split it");
+    LaunchInfo li;
+    if (int rc = prepare_conv(p, li)) return rc;
+    if (!li.narrow) return fail(FV_ERR_UNSUPPORTED, "conv_post + pqmf: not a narrow conv");
+    PqmfTail q = {h, y, y2, sub, sub_batched, ntaps, (int)(li.lds / 4)};
+    const size_t lds = li.lds + (size_t)(4 * 256 + round_up(4 * ntaps, 4)) * 4;
+    const int grid_x = (p.Tq + kPqmfAdvance - 1) / kPqmfAdvance;
+    profile_begin(s);
+    const int rc = launch_post_pqmf_kernel(p, q, lds, grid_x, s);
+    profile_end(s, li.kind, li.flops + 2.0 * p.B * 4.0 * p.Tq * ntaps, li.bytes - 4.0 * p.B * 4.0 * p.Tq + 4.0 * p.B * 4.0 * p.Tq);
     return rc;
 }
 

@@ -51,10 +51,11 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 // TR: the transposed conv of convt_kernel below (KT = 2 taps x[u-1], x[u]; rows are (output channel, phase))
-template <int CG_, int NFW_, int KT_, int DIL_, bool TR_ = false>
+// TWO: the two-source 1x1 conv of convg_kernel below (KT = 1; the K range is [lrelu(x); x2], chunks of 128 channels)
+template <int CG_, int NFW_, int KT_, int DIL_, bool TR_ = false, bool TWO_ = false>
 struct ConvHGeom {
     static constexpr int CG = CG_, NFW = NFW_, KT = KT_, DIL = DIL_;
-    static constexpr bool TR = TR_;
+    static constexpr bool TR = TR_, TWO = TWO_;
     static constexpr int C = 32 * CG;
     static constexpr int WM = 2, WN = 4, NW = 8, NT = 512;
     static constexpr int NTC = 16 * NFW * WN;            // output columns per tile
@@ -75,7 +76,7 @@ struct ConvHGeom {
     static constexpr int NRAW = XR * 8;
     static constexpr int RESST = NST - 2;                // ... this tile's bias and residual
     static constexpr int NRES = TR ? 8 : 8 + 8 * NFW;
-    static_assert(NSTEP % 2 == 0 && NST >= 3 && NFW % 2 == 0, "stages of two steps, at least three");
+    static_assert(NSTEP % 2 == 0 && (NST >= 3 || (TWO && NST == 2)) && NFW % 2 == 0, "stages of two steps, at least three per chunk (two: 1x1)");
     static_assert(((CG - 1) * 4 * XRP + (KT - 1) * DIL + 16 * (NFW - 1)) * 16 + 16 < 65536, "ds_read immediate range");
 };
 
@@ -186,14 +187,21 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
     float bad = 0.f;                                    // range guard (pairh_kernels.hpp range_note)
     ConvHRaw<G> raw;
     auto chunk_channels = [&](int c) { return G::TR ? min(G::C, p.ctot - c * G::C) : G::C; };
-    convh_load_raw<G>(raw, mb.x + b * ustride, p.T, ntile * G::NTC - G::P, tid, true, p.reflect != 0, chunk_channels(0));
+    // the input channels of chunk c: the tensor they come from, and the slope of their on-chip activation
+    // (TWO: the first half of the chunks is lrelu(x, slope), the second half x2 as it is -- ResidualStack's skip branch)
+    auto chunk_src = [&](int c, int bb) -> const float* {
+        if constexpr (G::TWO) return (c < nch / 2 ? mb.x : mb.x2) + bb * ustride + (c < nch / 2 ? c : c - nch / 2) * cstride;
+        else return mb.x + bb * ustride + c * cstride;
+    };
+    auto chunk_slope = [&](int c) { return G::TWO && c >= nch / 2 ? 1.f : p.slope; };
+    convh_load_raw<G>(raw, chunk_src(0, b), p.T, ntile * G::NTC - G::P, tid, true, p.reflect != 0, chunk_channels(0));
 #pragma unroll
     for (int st = 0; st < 3; ++st)
         convh_dma_stage<G>(rw, ring, st, (unsigned)(mtile * nch * G::WTILE + st * G::STAGE_BYTES), wave, lane);
     pair_stamp(p, 8, wave, lane, 7, 11);
     pair_wait_vm0();
     pair_stamp(p, 8, wave, lane, 7, 10);
-    if (!(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid);
+    if (!(p.dbg & 2)) convh_convert<G>(raw, ximg, chunk_slope(0), tid);
     pair_stamp(p, 8, wave, lane, 7, 13);                 // (tuning aid, -DFV_PAIR_TRACE) prologue done
     f32x4 hi[2][G::NFW], lo[2][G::NFW];                // live across the channel chunks of an item
     for (int it = 0;; ++it) {
@@ -243,11 +251,17 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
             pair_barrier();
             constexpr int NS = GS + 3;
             unsigned off;
-            if constexpr (NS < G::NST) off = wcur + (unsigned)(NS * G::STAGE_BYTES);
+            if constexpr (G::TWO) {
+                // two stages per chunk: three stages ahead can be two chunks on.  The stages of an item (all chunks of one
+                // row tile) are contiguous in the packed image: stage number inside the item, else the next item's
+                const int lin = chunk * G::NST + NS, spi = nch * G::NST;
+                if (lin < spi) off = (unsigned)(mtile * nch * G::WTILE + lin * G::STAGE_BYTES);
+                else off = item + 1 < hi_item ? (unsigned)(((item + 1) % nmt) * nch * G::WTILE + (lin - spi) * G::STAGE_BYTES) : kOutOfRange;
+            } else if constexpr (NS < G::NST) off = wcur + (unsigned)(NS * G::STAGE_BYTES);
             else off = more ? wnext + (unsigned)((NS - G::NST) * G::STAGE_BYTES) : kOutOfRange;
             convh_dma_stage<G>(rw, ring, (g0 + NS) & 3, off, wave, lane);
             if constexpr (GS == G::RAWST)
-                convh_load_raw<G>(raw, mb.x + nb * ustride + nchunk * cstride, p.T, nnt * G::NTC - G::P, tid,
+                convh_load_raw<G>(raw, chunk_src(nchunk, nb), p.T, nnt * G::NTC - G::P, tid,
                                   new_win && !(p.dbg & 1), p.reflect != 0, chunk_channels(nchunk));
             if constexpr (GS == G::RESST) {
                 // bias and residual of THIS tile: in flight during the last two stages
@@ -402,14 +416,14 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
             }
         } else
         if (last) {
-            const bool fin = mb.add1 != nullptr;
+            const bool fin = G::TWO || mb.add1 != nullptr;      // (TWO: the op's post applies to its one member)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int f = 0; f < G::NFW; ++f)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) hi[h][f][i] = (fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[h][i]) + res[h][f][i];
-            if (fin) {
+            if (mb.add1 != nullptr) {
                 const __amdgpu_buffer_rsrc_t r1 = make_rsrc(mb.add1 + b * ustride, ubytes);
                 const __amdgpu_buffer_rsrc_t r2 = make_rsrc(mb.add2 ? mb.add2 + b * ustride : mb.add1, mb.add2 ? ubytes : 0u);
 #pragma unroll
@@ -429,6 +443,41 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
 #pragma unroll
                         for (int i = 0; i < 4; ++i) hi[h][f][i] = (hi[h][f][i] + lo[h][f][i]) + res[h][f][i];
             }
+            if (G::TWO && p.sub != nullptr) {
+                // the op carries an output offset (bias removal, basis_melgan.py:147-159): y2 = act(post(y)) - sub, or y
+                // itself when there is no second output -- conv_kernels.hpp's epilogue rule
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.sub + (p.sub_batched ? b * ustride : 0), ubytes);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int f = 0; f < G::NFW; ++f)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) res[h][f][i] = buffer_load1s(rs, voff[f], (unsigned)(16 * h + i) * t4);
+                pair_wait_vm0();
+                const __amdgpu_buffer_rsrc_t ry = make_rsrc(mb.y + b * ustride, ubytes);
+                const __amdgpu_buffer_rsrc_t ra = make_rsrc(mb.y_act ? mb.y_act + b * ustride : mb.y, mb.y_act ? ubytes : 0u);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int f = 0; f < G::NFW; ++f) {
+                        const int t = t0 + col0 + f * 16;
+                        range_note4(bad, hi[h][f][0], hi[h][f][1], hi[h][f][2], hi[h][f][3], t < p.T);
+                        const unsigned vo = (p.dbg & 8) ? kOutOfRange : voff[f];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float v = hi[h][f][i];
+                            if (p.post == FV_POST_TANH) v = tanhf(v);
+                            else if (p.post == FV_POST_RELU) v = fmaxf(v, 0.f);
+                            const float a = (p.act_slope != 1.f ? act(v, p.act_slope) : v) - res[h][f][i];
+                            if (mb.y_act) {
+                                buffer_store1s(ry, vo, (unsigned)(16 * h + i) * t4, v);
+                                buffer_store1s(ra, vo, (unsigned)(16 * h + i) * t4, a);
+                            } else {
+                                buffer_store1s(ry, vo, (unsigned)(16 * h + i) * t4, a);
+                            }
+                        }
+                    }
+            } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -440,11 +489,12 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
                     range_note4(bad, v[0], v[1], v[2], v[3], t < p.T);
                     pair_store(p, mb.y, mb.y_act, p.ctot, b, 64 * mtile + row0 + 16 * h, t, t < p.T && !(p.dbg & 8), v, fin);
                 }
+            }
         }
         pair_stamp(p, 8, wave, lane, it, 5);
         // the stores first, the conversion of the next window after them: a vmcnt wait cannot tell stores from loads,
         // the next tile's first stage waits would otherwise sit behind the stores' round trip
-        if (new_win && !(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid);
+        if (new_win && !(p.dbg & 2)) convh_convert<G>(raw, ximg, chunk_slope(nchunk), tid);
         pair_stamp(p, 8, wave, lane, it, 6);
         if (!more) break;
         g0 += G::NST;
@@ -551,6 +601,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // equal items: block b takes [b n / nblk, (b + 1) n / nblk)
     const int lo = (int)((long long)blockIdx.x * n_items / q.nblk), hi = (int)((long long)(blockIdx.x + 1) * n_items / q.nblk);
     if (lo < hi) convh_run_member<ConvHGeom<CG, 2, 2, 1, true>>(q, mb, lo, hi, smem, wave, lane, true);
+}
+
+// Two-source 1x1 conv: y = post(W1 lrelu(x, slope) + W2 x2 + bias + res) -- the tail of MelGAN's ResidualStack
+// (modules.py:362-366,382: stack[4](act(h)) + skip_layer(c)) as ONE GEMM over the concatenated K range [lrelu(x); x2], on
+// the same streamed-weight pipeline: an item (utterance, column tile, row tile of 64) walks 2 C / 128 chunks of 128 input
+// channels, the first half from x (activated while it is split), the second half from x2 as it is; a chunk is 4 K steps =
+// two weight stages, the accumulators stay in registers across the chunks.  C = 128, 256 or 512 channels in and out.
+template <int CG>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void convg_kernel(PairParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    PairParams q;
+    q.n_members = 1; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = 1.f;
+    q.act_slope = p.act_slope; q.post = p.post; q.x_off = p.x_off; q.img_off = p.img_off; q.dbg = p.dbg; q.trace = p.trace;
+    q.ctot = p.ctot; q.nch = p.nch; q.nmt = p.nmt; q.reflect = 0; q.guard = p.guard; q.sub = p.sub; q.sub_batched = p.sub_batched;
+    PairMember mb;
+    mb.x = p.m[0].x; mb.x2 = p.m[0].x2; mb.w1 = p.m[0].w1; mb.b1 = p.m[0].b1; mb.res = p.m[0].res; mb.add1 = nullptr;
+    mb.add2 = nullptr; mb.y = p.m[0].y; mb.y_act = p.m[0].y_act; mb.k = 1; mb.n_tiles = p.m[0].n_tiles;
+    const int n_items = p.m[0].n_items;
+    asm volatile("" ::"s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.act_slope), "s"(q.post), "s"(q.x_off), "s"(q.img_off),
+                 "s"(q.dbg), "s"(q.trace), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.guard), "s"(q.sub), "s"(q.sub_batched), "s"(mb.x), "s"(mb.x2), "s"(mb.w1),
+                 "s"(mb.b1), "s"(mb.res), "s"(mb.y), "s"(mb.y_act), "s"(mb.n_tiles), "s"(n_items));
+    // equal items: block b takes [b n / nblk, (b + 1) n / nblk) -- row tiles of one column tile stay together
+    const int lo = (int)((long long)blockIdx.x * n_items / q.nblk), hi = (int)((long long)(blockIdx.x + 1) * n_items / q.nblk);
+    if (lo < hi) convh_run_member<ConvHGeom<CG, 2, 1, 1, false, true>>(q, mb, lo, hi, smem, wave, lane, true);
 }
 
 }  // namespace fv

@@ -221,6 +221,47 @@ int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout,
     return rc;
 }
 
+// ---- two-source 1x1 conv (convg_kernel) -----------------------------------------------------------------------------
+int launch_convg(PairParams p, int C, hipStream_t s) {
+    if (p.B <= 0 || p.T <= 0) return 0;
+    if (C != 128 && C != 256 && C != 512)
+        return fail(FV_ERR_UNSUPPORTED, "split-f16 two-source 1x1 conv: C = %d (128, 256 or 512)", C);
+    if ((double)C * p.T * 4.0 >= 1073741824.0)
+        return fail(FV_ERR_UNSUPPORTED, "split-f16 two-source 1x1 conv: one utterance's tensor (%d x %d floats) exceeds the "
+                    "1 GiB buffer-descriptor range; split the utterance", C, p.T);
+    if (p.slope < 0.f || p.slope > 1.f || p.act_slope < 0.f || p.act_slope > 1.f)
+        return fail(FV_ERR_INVALID_ARG, "split-f16 two-source 1x1 conv: activation slope outside [0, 1]");
+    PairMember& mb = p.m[0];
+    if (!mb.x || !mb.x2 || !mb.w1 || !mb.y) return fail(FV_ERR_INVALID_ARG, "split-f16 two-source 1x1 conv: null tensor");
+    if (reinterpret_cast<uintptr_t>(mb.w1) & 15)
+        return fail(FV_ERR_UNSUPPORTED, "split-f16 two-source 1x1 conv: packed weights must be 16-byte aligned");
+    p.n_members = 1;
+    p.ctot = C;                                // channels of each input and of the output
+    p.nch = 2 * C / 128;                       // chunks of 128 input channels: x's, then x2's
+    p.nmt = C / 64;
+    p.reflect = 0;
+    p.out_div = 1.f;
+    const int NTC = 128;
+    mb.k = 1;
+    mb.n_tiles = (p.T + NTC - 1) / NTC;
+    mb.n_items = mb.n_tiles * p.B * p.nmt;
+    mb.cost = 1;
+    p.x_off = 0;                               // ring of 4 weight stages
+    p.img_off = 4 * 16384 / 4;
+    const size_t lds = 4 * 16384 + (size_t)(4 * 128 * 128);      // + image: 128 channels x 128 rows x (2 + 2) bytes
+    long long nblk = tuning().convh_blocks > 0 ? tuning().convh_blocks : device_cu_count();
+    if (nblk > mb.n_items) nblk = mb.n_items;
+    p.nblk = (int)nblk;
+    p.sched_on = 0;
+    p.dbg = tuning().pair_dbg;
+    p.trace = nullptr;
+    profile_begin(s);
+    const int rc = launch_convg_geom(p, lds, s);
+    profile_end(s, FV_KERNEL_CONVG, 2.0 * p.B * (double)C * 2 * C * p.T,
+                4.0 * (2.0 * C * C + (double)p.B * C * p.T * (3 + (mb.res ? 1 : 0) + (mb.y_act ? 1 : 0))));
+    return rc;
+}
+
 // ---- fused pair at C = 64 (convp_kernels.hpp) --------------------------------------------------------------------
 extern template int launch_convp_dil<1>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convp_dil<3>(const PairParams&, size_t, hipStream_t);

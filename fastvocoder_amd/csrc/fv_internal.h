@@ -160,6 +160,7 @@ const Tuning& tuning();
 // one ResBlock's pair (a "member" of the launch)
 struct PairMember {
     const float* x;      // [B, C, T] raw input = residual
+    const float* x2;     // two-source 1x1 conv (convg_kernel): the second input [B, C, T], read as it is
     const float* w1;     // fv_pack_pair_weight image of conv1 / conv2
     const float* w2;
     const float* b1;     // [C] or null
@@ -193,6 +194,8 @@ struct PairParams {
     const float* fold_w; // pairh, C = 16, one member (pairh_run_member<G, true>): conv_post folded into the pair -- its
     const float* fold_b; //   weights [C][7], bias [1] or null, output [B, 1, T]; `post` is applied to that output,
     float* fold_y;       //   act_slope to the pair's own (never stored) output in front of it
+    const float* sub;    // convg_kernel: optional output offset (fv_plan_set_output_offset): subtracted after post / activation from
+    int sub_batched;     //   the twin when there is one (y stays raw), else from y; [C, T] or (sub_batched) [B, C, T]
     int* guard;          // split-f16 kernels: device-visible word set to 1 when a final value is not finite (an operand
                          // left the f16 range): pairh_kernels.hpp range_note; null: no check
     int sched_on;        // convh / convp: sched[] holds this launch's block schedule (pair_schedule); 0: the kernel cuts
@@ -271,6 +274,10 @@ int launch_convh_geom(const PairParams& p, int dil, size_t lds, hipStream_t s);
 // convh_kernels.hpp): member 0 uses x, w1 (fv_pack_conv_transpose1d_split_f16 image), b1, y, y_act
 int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout, hipStream_t stream);
 int launch_convt_geom(const PairParams& p, size_t lds, hipStream_t s);
+// y = post(W1 lrelu(x, slope) + W2 x2 + bias + res), 1-tap convs C -> C with split-f16 operands (convg_kernel): member 0
+// uses x, x2, w1 (fv_pack_conv1x1_2src_split_f16 image), b1, res, y, y_act; C = 128, 256 or 512
+int launch_convg(PairParams p, int C, hipStream_t stream);
+int launch_convg_geom(const PairParams& p, size_t lds, hipStream_t s);
 // n (1..3) members, plain (sum = 0: one raw output each) or sum mode (one output: mean of the members)
 int launch_pairs(PairParams p, int C, int dil, hipStream_t stream);
 template <int MH, int NF, int NG>
@@ -287,6 +294,21 @@ int launch_pairh_geom(const PairParams& p, int dil, size_t lds, hipStream_t s);
 // the SLOW / ACT variants stage some tiles synchronously: always two buffers, full waits
 constexpr int kRingStages(bool slow, bool act) { return (slow || act) ? 2 : FV_RING; }
 constexpr int kMaxDmaX = 6, kMaxDmaW = 8;   // LDS-DMA instructions per wave per stage (host-checked)
+
+// conv_post + tanh + PQMF synthesis in one launch (conv_post_pqmf_kernel, conv_kernels.hpp): what follows the narrow conv
+struct PqmfTail {
+    const float* h;       // [S][ntaps] synthesis filter
+    float* y;             // [B][S * Tsub] full band
+    float* y2;            // optional: y - sub (y stays plain), the bias-removal flows
+    const float* sub;     // optional offset [S * Tsub] or [B][S * Tsub]
+    int sub_batched;
+    int ntaps;
+    int tail_off;         // float offset of [tile S x 256 | filter S x ntaps] in dynamic LDS
+};
+constexpr int kPqmfHalo = 8, kPqmfAdvance = 256 - 2 * kPqmfHalo;   // sub-band samples a block recomputes / advances by
+// p: the conv_post as a plain conv (Cout = S = 4 sub-bands, post = tanh); y [B, 1, S * Tq]
+int launch_conv_post_pqmf(ConvParams p, const float* h, int ntaps, float* y, float* y2, const float* sub, int sub_batched,
+                          hipStream_t stream);
 
 int launch_conv(ConvParams p, hipStream_t stream);
 // n mutually independent convs; one grouped launch when they form an MRF position

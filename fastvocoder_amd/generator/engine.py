@@ -115,15 +115,27 @@ class PlanBuilder:
     def conv_sum_1x1(self, conv_a, src_a, conv_b, src_b, dst, pre_slope_a=1.0, res=SLOT_NONE,
                      post=POST_NONE):
         """dst = post(conv_a(act(src_a)) + conv_b(src_b) [+ res]) for two 1x1 Conv1d containers, as
-        ONE launch: the K range of the GEMM is the concatenation of the two inputs
-        (fv_conv1d_2src_fused).  The kernel applies no input activation, so ``pre_slope_a`` must
-        be absorbed by the producer of ``src_a`` -- activation hoisting does that whenever
-        ``src_a`` has no consumer that needs it raw (checked in :meth:`finalize`)."""
+        ONE launch: the K range of the GEMM is the concatenation of the two inputs.
+        128 / 256 / 512 channels under the split-f16 policy (and ``split``): fv_conv1x1_2src_split_f16 -- ``src_a`` is
+        read raw and activated on chip.  Otherwise fv_conv1d_2src_fused (fp32 MFMA): that kernel applies no input
+        activation, so ``pre_slope_a`` must be absorbed by the producer of ``src_a`` -- activation hoisting does that
+        whenever ``src_a`` has no consumer that needs it raw (checked in :meth:`finalize`)."""
         for c in (conv_a, conv_b):
             if c.kernel_size[0] != 1 or c.stride[0] != 1 or c.groups != 1 or c.padding[0] != 0:
                 raise _native.NativeError("conv_sum_1x1: both layers must be plain 1x1 convs")
         if conv_a.out_channels != conv_b.out_channels:
             raise _native.NativeError("conv_sum_1x1: the two convs must have the same output channels")
+        ch = conv_a.out_channels
+        if (conv_a.in_channels == ch and conv_b.in_channels == ch and _native.conv1x1_2src_split_supported(ch)
+                and self.pair_precision(ch) == _native.PAIR_SPLIT_F16):
+            ba, bb = self._bias(conv_a), self._bias(conv_b)
+            bias = ba if bb is None else (bb if ba is None else (ba + bb).contiguous())
+            self.ops.append(dict(kind="conv2h", x=src_a, x2=src_b, y=dst, res=res, acc=SLOT_NONE, pre_slope=1.0,
+                                 slope=float(pre_slope_a), split=True,
+                                 packed=_native.pack_conv1x1_2src_split(effective_weight(conv_a), effective_weight(conv_b),
+                                                                        self.guard),
+                                 bias=bias, channels=ch, post=post))
+            return
         w = torch.cat([effective_weight(conv_a), effective_weight(conv_b)], dim=1).contiguous()
         ba, bb = self._bias(conv_a), self._bias(conv_b)
         bias = ba if bb is None else (bb if ba is None else (ba + bb).contiguous())
@@ -294,10 +306,30 @@ class PlanBuilder:
         Bias removal without a separate elementwise pass (reference bin/synthesize.py:74-80,
         basis_melgan.py:147-159, bin/test.py:82-91)."""
         op = self.ops[-1]
-        if op["kind"] not in ("conv", "conv2", "convT", "upconv", "pqmf") or op.get("group", 0) or op.get("split"):
-            raise _native.NativeError("subtract_output: the last op must be a plain conv / transposed conv / pqmf")
+        if (op["kind"] not in ("conv", "conv2", "conv2h", "convT", "upconv", "pqmf", "postpqmf") or op.get("group", 0)
+                or (op.get("split") and op["kind"] != "conv2h")):
+            raise _native.NativeError("subtract_output: the last op must be a plain conv / transposed conv / two-source "
+                                      "1x1 conv / pqmf")
         op["sub"] = SLOT_AUX_IN0 + int(aux)
         op["sub_y2"] = SLOT_OUT2 if second else SLOT_NONE
+
+    @staticmethod
+    def post_pqmf_supported(conv, synthesis_filter):
+        """conv_post + PQMF synthesis as one launch (fv_conv_post_pqmf): 4 sub-bands, 63 taps, a plain 'same' conv."""
+        k = conv.kernel_size[0]
+        return (isinstance(conv, torch.nn.Conv1d) and conv.out_channels == 4 and conv.stride[0] == 1 and conv.groups == 1
+                and conv.dilation[0] == 1 and conv.padding[0] == (k - 1) // 2 and tuple(synthesis_filter.shape[1:]) == (4, 63))
+
+    def conv_post_pqmf(self, conv, synthesis_filter, src, dst, pre_slope=1.0, post=POST_NONE):
+        """dst [B,1,4T'] = pqmf_synthesis(post(conv(lrelu(src, pre_slope)))): Multiband-HiFi-GAN's inference tail in one
+        launch; the sub-bands stay on chip."""
+        if not self.post_pqmf_supported(conv, synthesis_filter):
+            raise _native.NativeError("conv_post_pqmf: needs a 4-band 'same' conv and a 63-tap synthesis filter")
+        S = synthesis_filter.shape[1]
+        h = synthesis_filter.detach().reshape(S, -1).contiguous().float()
+        self.ops.append(dict(kind="postpqmf", x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE, pre_slope=float(pre_slope),
+                             packed=_native.pack_conv1d(effective_weight(conv)), bias=self._bias(conv),
+                             cin=conv.in_channels, k=conv.kernel_size[0], pad=conv.padding[0], post=post, h=h))
 
     def pqmf_synthesis(self, synthesis_filter, src, dst):
         S = synthesis_filter.shape[1]
@@ -312,7 +344,7 @@ class PlanBuilder:
             op.setdefault("y_act", SLOT_NONE)
             op.setdefault("act_slope", 1.0)
         for i, op in enumerate(ops):
-            if op["kind"] == "pqmf":
+            if op["kind"] in ("pqmf", "postpqmf"):
                 continue
             y = op["y"]
             # consumers of this definition of slot y: until the slot is written again
@@ -364,7 +396,7 @@ class PlanBuilder:
                 own, rate = max(op["pad"], reach - op["pad"]), 1
             elif op["kind"] == "sum3":
                 own, rate = max(op["ks"]) // 2, 1
-            elif op["kind"] == "conv2":
+            elif op["kind"] in ("conv2", "conv2h"):
                 own, rate = 0, 1
             elif op["kind"] == "convh":
                 own, rate = (op["k"] - 1) // 2 * op["dil"], 1
@@ -376,6 +408,9 @@ class PlanBuilder:
                 own, rate = -(-op["k"] // op["stride"]) + 1, op["stride"]
             elif op["kind"] == "upconv":
                 own, rate = -(-(op["k"] + op["rate"]) // op["rate"]) + 1, op["rate"]
+            elif op["kind"] == "postpqmf":                  # conv (k taps) in front of the synthesis filter
+                S, ntaps = op["h"].shape
+                own, rate = -(-(ntaps // 2) // S) + 1 + op["k"] // 2, S
             else:                                           # pqmf synthesis: S bands, ntaps taps
                 S, ntaps = op["h"].shape
                 own, rate = -(-(ntaps // 2) // S) + 1, S
@@ -436,6 +471,10 @@ class PlanBuilder:
                 self.plan.add_conv1d_2src(op["x"], op["x2"], op["y"], op["packed"], op["bias"], op["cin1"],
                                           op["cin2"], op["cout"], res=op["res"], post=op["post"],
                                           y_act=op["y_act"], act_slope=op["act_slope"])
+            elif op["kind"] == "conv2h":
+                self.plan.add_conv1x1_2src_split_f16(op["x"], op["x2"], op["y"], op["packed"], op["bias"], op["channels"],
+                                                     pre_slope=op["slope"], res=op["res"], post=op["post"],
+                                                     y_act=op["y_act"], act_slope=op["act_slope"])
             elif op["kind"] == "convT" and op.get("split"):
                 self.plan.add_conv_transpose1d_split_f16(op["x"], op["y"], op["packed"], op["bias"], op["cin"],
                                                          op["cout"], op["k"], op["stride"], op["pad"], op["out_pad"],
@@ -451,6 +490,9 @@ class PlanBuilder:
                                               op["cout"], op["k"], op["rate"], op["pad"],
                                               pre_slope=op["pre_slope"], post=op["post"],
                                               y_act=op["y_act"], act_slope=op["act_slope"])
+            elif op["kind"] == "postpqmf":
+                self.plan.add_conv_post_pqmf(op["x"], op["y"], op["packed"], op["bias"], op["cin"], op["k"], op["pad"],
+                                             op["h"], pre_slope=op["pre_slope"], post=op["post"])
             else:
                 self.plan.add_pqmf_synthesis(op["x"], op["y"], op["h"])
             if "sub" in op:

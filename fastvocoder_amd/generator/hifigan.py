@@ -26,6 +26,7 @@ DEFAULT_LRELU_SLOPE = 0.01  # F.leaky_relu's default, used before conv_post (hif
 
 class _HiFiGANBase(NativeModule):
     _post_channels = 1
+    fuse_pqmf = True      # Multiband: conv_post + tanh + PQMF synthesis as one launch (False: two; A/B and bit-identity tests)
 
     def __init__(self, resblock_kernel_sizes, upsample_rates, upsample_initial_channel,
                  resblock_type, upsample_kernel_sizes, resblock_dilation_sizes, transposedconv,
@@ -175,9 +176,11 @@ class _HiFiGANBase(NativeModule):
         return PlanBuilder.pair_fold_supported(blocks[0].convs1[-1], self.conv_post,
                                                pb.pair_precision(blocks[0].channels))
 
-    def _emit_trunk(self, pb, dst, fused=None, fold_post=False):
+    def _emit_trunk(self, pb, dst, fused=None, fold_post=False, pqmf=None):
         """mel (SLOT_IN) -> tanh(conv_post(...)) in ``dst``; ``fused``: per-stage flags (_fused_flags); ``fold_post``:
-        conv_post inside the last pair's launch (not for the plans whose LAST op subtracts an output offset)."""
+        conv_post inside the last pair's launch (not for the plans whose LAST op subtracts an output offset); ``pqmf``:
+        a synthesis filter -- ``dst`` then receives the full-band signal, conv_post + tanh + PQMF synthesis being ONE
+        launch (PlanBuilder.conv_post_pqmf; two where that kernel does not apply)."""
         fold_post = fold_post and self._fold_post(pb, fused)
         x, up = pb.tmp(), pb.tmp()
         nk = self.num_kernels
@@ -244,7 +247,14 @@ class _HiFiGANBase(NativeModule):
                     blocks[j].emit(pb, up, x if last else parts[0], scratch[0],
                                    acc=parts[0] if j > 0 else SLOT_NONE,
                                    out_div=float(nk) if last else 1.0)
-        pb.conv(self.conv_post, x, dst, pre_slope=DEFAULT_LRELU_SLOPE, post=POST_TANH)
+        if pqmf is not None and pb.post_pqmf_supported(self.conv_post, pqmf) and self.fuse_pqmf:
+            pb.conv_post_pqmf(self.conv_post, pqmf, x, dst, pre_slope=DEFAULT_LRELU_SLOPE, post=POST_TANH)
+        elif pqmf is not None:
+            sub = pb.tmp()
+            pb.conv(self.conv_post, x, sub, pre_slope=DEFAULT_LRELU_SLOPE, post=POST_TANH)
+            pb.pqmf_synthesis(pqmf, sub, dst)
+        else:
+            pb.conv(self.conv_post, x, dst, pre_slope=DEFAULT_LRELU_SLOPE, post=POST_TANH)
 
     def _flag_tag(self, T):
         return "".join("f" if f else "-" for f in self._fused_flags(T))
@@ -322,9 +332,7 @@ class MultiBandHiFiGANGenerator(_HiFiGANBase):
         return self._trunk(self._prepare(x))
 
     def _emit_full(self, pb, fused=None):
-        sub = pb.tmp()
-        self._emit_trunk(pb, sub, fused)
-        pb.pqmf_synthesis(self.pqmf.synthesis_filter, sub, SLOT_OUT)
+        self._emit_trunk(pb, SLOT_OUT, fused, pqmf=self.pqmf.synthesis_filter)
 
     def _emit_inference(self, pb, fused):
         self._emit_full(pb, fused)

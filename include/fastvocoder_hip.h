@@ -257,6 +257,23 @@ int fv_conv1d_2src_fused(const float* x, const float* x2, const float* packed, c
                          int Cout, int T, int post, float act_slope, void* stream);
 
 /*
+ * The same operator with split-f16 operands (arithmetic and domain: FV_PAIR_SPLIT_F16 above) for C -> C stacks,
+ * C = 128, 256 or 512 -- MelGAN's and Basis-MelGAN's ResidualStack tails (modules.py:362-366,382):
+ *
+ *     y = post( W1 * lrelu(x, pre_slope) + W2 * x2 + bias + res ),   y_act = lrelu(y, act_slope)
+ *
+ * x is read RAW and activated on chip while it is split (nothing is hoisted into its producer), x2 is read as it is.
+ * One GEMM over the K range [lrelu(x); x2] on the streamed-weight pipeline of fv_conv1d_split_f16 (csrc/convh_kernels.hpp
+ * convg_kernel).  packed: fv_pack_conv1x1_2src_split_f16 of the two [C, C, 1] weights (fv_packed_conv1x1_2src_split_floats
+ * floats; 0 = C not supported); bias = b1 + b2 or NULL.
+ */
+int64_t fv_packed_conv1x1_2src_split_floats(int C);
+int fv_pack_conv1x1_2src_split_f16(const float* w1, const float* w2, float* packed, int C, int* range_flag, void* stream);
+int fv_conv1x1_2src_split_f16(const float* x, const float* x2, const float* packed, const float* bias, const float* res,
+                              float* y, float* y_act, int B, int C, int T, float pre_slope, int post, float act_slope,
+                              int* guard, void* stream);
+
+/*
  * y = post( conv_transpose1d(lrelu(x, pre_slope); w, stride, pad, out_pad) + bias )
  *
  * Replaces F.leaky_relu + torch.nn.ConvTranspose1d at hifigan.py:95-96,
@@ -294,6 +311,18 @@ int fv_upsample_conv1d_fused(const float* x, const float* packed, const float* b
  */
 int fv_pqmf_synthesis(const float* x, const float* h, float* y, int B, int S, int ntaps,
                       int Tsub, void* stream);
+
+/*
+ * Multiband-HiFi-GAN's inference tail in ONE launch (multiband_hifigan.py:113-115,136 with pqmf.py:121-135):
+ *
+ *     y = pqmf_synthesis( post( conv1d( lrelu(x, pre_slope); w [S, Cin, k], zero padding pad ) + bias ) )
+ *
+ * conv_post's S = 4 activated sub-bands stay in LDS and feed the polyphase synthesis (ntaps = 63) directly: the
+ * [B, S, T] sub-band tensor never exists and one launch disappears.  Same FMA order as fv_conv1d_fused followed by
+ * fv_pqmf_synthesis: identical bits.  x [B, Cin, T]; packed: fv_pack_conv1d_weight of w; h [S, ntaps]; y [B, S * T].
+ */
+int fv_conv_post_pqmf(const float* x, const float* packed, const float* bias, const float* h, float* y, int B, int Cin,
+                      int S, int T, int k, int pad, float pre_slope, int post, int ntaps, void* stream);
 
 /*
  * PQMF.analysis (pqmf.py:108-119): ntaps-tap FIR per band over the zero-padded signal,
@@ -351,6 +380,9 @@ int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot, int y_
 int fv_plan_add_conv1d_2src(fv_plan_t* plan, int x_slot, int x2_slot, int y_slot, int y_act_slot,
                             int res_slot, const float* packed, const float* bias, int Cin1,
                             int Cin2, int Cout, int post, float act_slope);
+int fv_plan_add_conv1x1_2src_split_f16(fv_plan_t* plan, int x_slot, int x2_slot, int y_slot, int y_act_slot, int res_slot,
+                                       const float* packed, const float* bias, int C, float pre_slope, int post,
+                                       float act_slope);
 /*
  * y = act( ( sum_{j<3} ( conv1d(x_j; w_j, k_j taps, 'same' zero padding) + res_j ) + bias_sum ) / out_div )
  *
@@ -405,6 +437,10 @@ int fv_plan_add_upsample_conv1d(fv_plan_t* plan, int x_slot, int y_slot, int y_a
                                 float act_slope);
 int fv_plan_add_pqmf_synthesis(fv_plan_t* plan, int x_slot, int y_slot, const float* h,
                                int S, int ntaps);
+/* fv_conv_post_pqmf as a plan op: y_slot receives the FULL-BAND signal [B, 1, S * T']; may carry an output offset
+ * (fv_plan_set_output_offset) like the pqmf op */
+int fv_plan_add_conv_post_pqmf(fv_plan_t* plan, int x_slot, int y_slot, const float* packed, const float* bias, int Cin,
+                               int S, int k, int pad, float pre_slope, int post, const float* h, int ntaps);
 
 /*
  * Bias removal in the epilogue (bin/synthesize.py:74-80 est - generator(0); basis_melgan.py:147-159
@@ -490,6 +526,7 @@ int fv_tuning_set(const char* key, int value);
 #define FV_KERNEL_CONVH64 7     /* conv1d with split-f16 operands, C = 64 (ResBlock pairs of the wide stages) */
 #define FV_KERNEL_CONVH128 8    /* ... C = 128 */
 #define FV_KERNEL_CONVT 9       /* transposed conv (kernel = 2 strides) with split-f16 operands (convt_kernel) */
+#define FV_KERNEL_CONVG 10      /* two-source 1x1 conv (ResidualStack tail) with split-f16 operands (convg_kernel) */
 int fv_profile_enable(int on);
 /* what the measurement adds to a launch (subtract it per launch): a launch's duration is measured completion to
  * completion on its stream, from the end event of the launch before it to its own (its dispatch latency included, as

@@ -628,3 +628,52 @@ def test_range_guard_of_the_split_kernels():
     _native.conv_transpose1d_split_f16(_t(x), _native.pack_conv_transpose1d_split(_t(wT), 4), None, 64, 8, 4, 2, 0,
                                        pre_slope=1.0, guard=guard)
     assert int(guard.item()) == 1
+
+
+# ---------------------------------------------------------------------------
+# two-source 1x1 conv with split-f16 operands (convg_kernel): ResidualStack's tail
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [(1, 128, 300), (2, 256, 257), (1, 512, 130), (3, 128, 1), (1, 256, 1000), (2, 128, 129)],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_conv1x1_2src_split_f16_vs_oracle(case, tuning):
+    """y = post(W1 lrelu(x, s) + W2 x2 + b + res) (reference modules.py:362-366,382: stack[4](act(h)) + skip_layer(c))
+    against the oracle's two 1x1 convs: every channel count, ragged lengths, residual, ReLU, activated twin, and a few
+    persistent blocks walking many (row tile, chunk) items -- same bits."""
+    B, C, T = case
+    rng = np.random.RandomState(C + T)
+    x, x2 = rng.randn(B, C, T).astype(np.float32), rng.randn(B, C, T).astype(np.float32)
+    w1 = (rng.randn(C, C, 1) / np.sqrt(C)).astype(np.float32)
+    w2 = (rng.randn(C, C, 1) / np.sqrt(C)).astype(np.float32)
+    b = rng.randn(C).astype(np.float32)
+    res = rng.randn(B, C, T).astype(np.float32)
+    ref = oo.conv1d(x, w1, None, pre_slope=0.2) + oo.conv1d(x2, w2, b)
+    P = _native.pack_conv1x1_2src_split(_t(w1), _t(w2))
+    guard = torch.zeros(1, dtype=torch.int32, device=_dev())
+    y = _native.conv1x1_2src_split_f16(_t(x), _t(x2), P, _t(b), pre_slope=0.2, guard=guard)
+    assert tuple(y.shape) == ref.shape and _rel(y, ref) <= 4e-6
+    twin = torch.empty_like(y)
+    y2 = _native.conv1x1_2src_split_f16(_t(x), _t(x2), P, None, pre_slope=0.2, res=_t(res), post=_native.POST_RELU,
+                                        out_act=twin, act_slope=0.1, guard=guard)
+    want = np.maximum(ref - b[None, :, None] + res, 0)
+    assert _rel(y2, want) <= 4e-6 and _rel(twin, oo.lrelu(want, 0.1)) <= 4e-6
+    assert int(guard.item()) == 0
+    tuning("convh_blocks", 3)
+    few = _native.conv1x1_2src_split_f16(_t(x), _t(x2), P, _t(b), pre_slope=0.2)
+    tuning("convh_blocks", 0)
+    assert torch.equal(few, y)
+    if B > 1:
+        one = _native.conv1x1_2src_split_f16(_t(x[1:2]), _t(x2[1:2]), P, _t(b), pre_slope=0.2)
+        assert torch.equal(one, y[1:2])
+    x2[0, 1, 0] = 3.0e5                                # the raw branch leaves the f16 range: guard
+    _native.conv1x1_2src_split_f16(_t(x), _t(x2), P, _t(b), pre_slope=0.2, guard=guard)
+    assert int(guard.item()) == 1
+
+
+def test_conv1x1_2src_split_f16_rejects():
+    with pytest.raises(_native.NativeError, match="not built"):
+        _native.pack_conv1x1_2src_split(torch.zeros((64, 64, 1), device=_dev()), torch.zeros((64, 64, 1), device=_dev()))
+    z = torch.zeros((128, 128, 1), device=_dev())
+    P = _native.pack_conv1x1_2src_split(z, z)
+    x = torch.zeros((1, 128, 10), device=_dev())
+    with pytest.raises(_native.NativeError, match="alias"):
+        _native.conv1x1_2src_split_f16(x, x, P, None, out=x)

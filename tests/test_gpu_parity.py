@@ -871,3 +871,26 @@ def test_weight_beyond_the_f16_range_builds_an_fp32_plan():
         with pytest.warns(RuntimeWarning, match="a weight lies outside the split-f16 range"):
             got = m.inference(mel)
     assert bool(torch.isfinite(want).all()) and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("path", ["conf/multiband-hifigan/light.yaml", "conf/multiband-hifigan/large.yaml"])
+def test_conv_post_and_pqmf_in_one_launch_give_the_same_bits(path):
+    """Multiband-HiFi-GAN's inference tail (multiband_hifigan.py:113-115,136): conv_post + tanh + PQMF synthesis as ONE
+    launch (fv_conv_post_pqmf: the sub-bands stay in LDS) against the two launches it replaces -- same FMA order, so
+    identical bits: single utterance, a ragged batch, and the bias-removal plan (output offset in the last epilogue)."""
+    cfg = cases.load_conf(path)
+    fused, _ = _model("multiband-hifigan", cfg, seed=0)
+    plain, _ = _model("multiband-hifigan", cfg, seed=0)
+    plain.fuse_pqmf = False
+    mel = seeded_mel(61, seed=41)
+    with torch.no_grad():
+        a, b = fused.inference(mel), plain.inference(mel)
+        assert torch.equal(a, b) and a.numel() == plain.inference(mel).numel()
+        x = torch.from_numpy(seeded_mel(333, seed=42, batch=3)).to(_dev())
+        assert torch.equal(fused.synthesize_batch(x), plain.synthesize_batch(x))
+        bias = plain.inference(np.zeros_like(mel))
+        (e1, r1), (e2, r2) = fused.inference_minus(mel, bias), plain.inference_minus(mel, bias)
+        assert torch.equal(e1, e2) and torch.equal(r1, r2) and torch.equal(e1, a)
+    n_f = _plans(fused)
+    n_p = _plans(plain)
+    assert all(n_f[k].num_ops() == n_p[k].num_ops() - 1 for k in n_f)
