@@ -634,6 +634,7 @@ struct TuningEntry {
 static const TuningEntry kTuningTable[] = {
     {"pair_dbg", &Tuning::pair_dbg},       {"dbg", &Tuning::conv_dbg},           {"sched", &Tuning::sched},
     {"sched_switch", &Tuning::sched_switch}, {"convh_skel", &Tuning::convh_skel}, {"convp_skel", &Tuning::convp_skel},
+    {"convq_skel", &Tuning::convq_skel},   {"pair128_unfused", &Tuning::pair128_unfused},
     {"pairh_skel", &Tuning::pairh_skel},   {"pair_skel", &Tuning::pair_skel},    {"convh_blocks", &Tuning::convh_blocks},
     {"pair_blocks", &Tuning::pair_blocks}, {"sum3_min", &Tuning::sum3_min},      {"lds_budget", &Tuning::lds_budget},
     {"units", &Tuning::units},             {"shape16", &Tuning::shape16},        {"shape32", &Tuning::shape32},
@@ -1347,6 +1348,7 @@ int fv_resblock1_fused_ex(int n, const float* const* x, const float* const* w1, 
         mb.k = k[j];
     }
     if (C == 64) return launch_convp(pp, dil, (hipStream_t)stream);
+    if (C == 128 && !tuning().pair128_unfused) return launch_convq(pp, dil, (hipStream_t)stream);
     if (C >= 64) return launch_wide_pairs(pp, mid, C, dil, (hipStream_t)stream);
     return launch_pairs(pp, C, dil, (hipStream_t)stream);
 }
@@ -1781,6 +1783,8 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             }
             if (o.Cin == 64 && o.prec == FV_PAIR_SPLIT_F16) {
                 if (int rc = launch_convp(pp, o.dil, s)) return rc;
+            } else if (o.Cin == 128 && o.prec == FV_PAIR_SPLIT_F16 && !tuning().pair128_unfused) {
+                if (int rc = launch_convq(pp, o.dil, s)) return rc;
             } else if (o.Cin >= 64) {
                 float* mids[3] = {nullptr, nullptr, nullptr};
                 for (size_t q = n; q < m; ++q) mids[q - n] = base[plan->ops[q].tmpb];

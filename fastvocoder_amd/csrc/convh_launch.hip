@@ -323,4 +323,66 @@ int launch_convp(PairParams p, int dil, hipStream_t s) {
     return rc;
 }
 
+// ---- fused pair at C = 128 (convq_kernels.hpp) -------------------------------------------------------------------
+extern template int launch_convq_dil<1>(const PairParams&, size_t, hipStream_t);
+extern template int launch_convq_dil<3>(const PairParams&, size_t, hipStream_t);
+extern template int launch_convq_dil<5>(const PairParams&, size_t, hipStream_t);
+
+int launch_convq(PairParams p, int dil, hipStream_t s) {
+    const int C = 128, NM = 64;
+    if (p.B <= 0 || p.T <= 0) return 0;
+    if (dil != 1 && dil != 3 && dil != 5) return fail(FV_ERR_UNSUPPORTED, "resblock pair: dilation %d (1, 3 or 5)", dil);
+    if (p.n_members < 1 || p.n_members > 3) return fail(FV_ERR_INVALID_ARG, "resblock pair: %d members", p.n_members);
+    if ((double)C * p.T * 4.0 >= 1073741824.0)
+        return fail(FV_ERR_UNSUPPORTED, "resblock pair: one utterance's tensor (%d x %d floats) exceeds the 1 GiB "
+                    "buffer-descriptor range; split the utterance", C, p.T);
+    if (p.slope < 0.f || p.slope > 1.f || p.act_slope < 0.f || p.act_slope > 1.f)
+        return fail(FV_ERR_INVALID_ARG, "resblock pair: activation slope outside [0, 1]");
+    for (int i = 0; i < p.n_members; ++i)        // largest taps first (cost order of the contiguous partition)
+        for (int j = i + 1; j < p.n_members; ++j)
+            if (p.m[j].k > p.m[i].k) { PairMember t = p.m[i]; p.m[i] = p.m[j]; p.m[j] = t; }
+    int img_bytes = 0;
+    double flops = 0, bytes = 0;
+    long long items = 0;
+    for (int i = 0; i < p.n_members; ++i) {
+        PairMember& mb = p.m[i];
+        if (mb.k != 11 && mb.k != 7 && mb.k != 3) return fail(FV_ERR_UNSUPPORTED, "resblock pair: %d taps (3, 7 or 11)", mb.k);
+        if (!mb.x || !mb.w1 || !mb.w2 || !mb.y) return fail(FV_ERR_INVALID_ARG, "resblock pair: null tensor (member %d)", i);
+        if (mb.add2 && !mb.add1) return fail(FV_ERR_INVALID_ARG, "resblock pair: add2 without add1 (member %d)", i);
+        if ((reinterpret_cast<uintptr_t>(mb.w1) | reinterpret_cast<uintptr_t>(mb.w2)) & 15)
+            return fail(FV_ERR_UNSUPPORTED, "resblock pair: packed weights must be 16-byte aligned");
+        const int nout = NM - (mb.k - 1);
+        mb.n_tiles = (p.T + nout - 1) / nout;
+        mb.n_items = mb.n_tiles * p.B;
+        mb.cost = 4 * mb.k + (tuning().convq_skel >= 0 ? tuning().convq_skel : 5);     // K steps of one conv + per-tile work
+        const int xrows = (NM + (mb.k - 1) * dil + 3) / 4 * 4;
+        const int img = 4 * C * ((xrows + 15) / 16 * 16);
+        if (img > img_bytes) img_bytes = img;
+        items += mb.n_items;
+        flops += 2.0 * 2.0 * p.B * (double)C * C * mb.k * p.T;
+        bytes += 4.0 * (2.0 * C * C * mb.k + (double)p.B * C * p.T * ((mb.y_act ? 3 : 2) + (mb.add1 ? 1 : 0) + (mb.add2 ? 1 : 0)));
+    }
+    size_t floats = 0;
+    p.x_off = 0;                       // ring of 3 weight stages (one K step of all 128 rows each)
+    floats += 3 * 16384 / 4;
+    p.img_off = (int)floats;
+    floats += (size_t)img_bytes / 4;
+    p.mid_off = (int)floats;
+    floats += (size_t)4 * C * (NM + 16) / 4;
+    p.bias_off = (int)floats;
+    floats += 2 * (size_t)C;
+    const size_t lds = floats * 4;
+    if (lds > 160 * 1024) return fail(FV_ERR_UNSUPPORTED, "resblock pair: %zu bytes of LDS", lds);
+    long long nblk = tuning().convh_blocks > 0 ? tuning().convh_blocks : device_cu_count();
+    if (nblk > items) nblk = items;
+    p.nblk = (int)nblk;
+    pair_schedule(p, p.nblk);
+    p.dbg = tuning().pair_dbg;
+    p.trace = nullptr;
+    profile_begin(s);
+    const int rc = dil == 1 ? launch_convq_dil<1>(p, lds, s) : dil == 3 ? launch_convq_dil<3>(p, lds, s) : launch_convq_dil<5>(p, lds, s);
+    profile_end(s, FV_KERNEL_CONVH128, flops, bytes);
+    return rc;
+}
+
 }  // namespace fv

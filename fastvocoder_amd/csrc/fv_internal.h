@@ -141,6 +141,8 @@ struct Tuning {
     int sched_switch = 4;    // cost units a block pays for taking up another member (pair_schedule)
     int convh_skel = -1;     // per-tile constant of the partition cost (-1: the launcher's own: 5 at 64 channels, 2 above)
     int convp_skel = 5;
+    int convq_skel = -1;     // (-1: 5)
+    int pair128_unfused = 0; // 1: 128-channel ResBlock pairs as two conv launches (convh) instead of the fused convq kernel (A/B, bit-identity tests)
     int pairh_skel = -1;     // (-1: 8 at 16 channels, 6 at 32)
     int pair_skel = -1;      // (-1: 4 at 16 channels, 3 at 32)
     int convh_blocks = 0;    // > 0: persistent blocks of the convh / convp / convt launches (default: one per CU)
@@ -268,6 +270,11 @@ void pair_schedule(PairParams& p, int nblk);
 int launch_convp(PairParams p, int dil, hipStream_t stream);
 template <int DIL>
 int launch_convp_dil(const PairParams& p, size_t lds, hipStream_t s);
+// fused ResBlock pair at C = 128 (convq_kernels.hpp): 128-row x 64-column tiles, one K step per weight stage; members as
+// launch_convp (w1 / w2: the fv_pack_pair_weight_ex images of the conv kernel, [row tile][step][8 KB])
+int launch_convq(PairParams p, int dil, hipStream_t stream);
+template <int DIL>
+int launch_convq_dil(const PairParams& p, size_t lds, hipStream_t s);
 template <int CG, int NFW>
 int launch_convh_geom(const PairParams& p, int dil, size_t lds, hipStream_t s);
 // ConvTranspose1d with split-f16 operands, k = 2 stride, Cin = 64 or a multiple of 128 (convt_kernel in

@@ -105,9 +105,10 @@ class _HiFiGANBase(NativeModule):
         ch = blocks[0].channels
         curs = [up] * nk
         prec = pb.pair_precision(ch)
-        if prec == PAIR_SPLIT_F16 and ch >= 128:
-            # 128 channels: the pair's two images do not fit in LDS next to the weight ring, a pair is two launches of
-            # the split-f16 conv kernel (csrc/convh_kernels.hpp); 64 channels run fused (csrc/convp_kernels.hpp) below.  Per pair position: the three blocks' first convs, then their second convs
+        if prec == PAIR_SPLIT_F16 and ch > 128:
+            # 256 / 512 channels (HiFi-GAN large): a pair is two launches of the split-f16 conv kernel
+            # (csrc/convh_kernels.hpp); 64 and 128 channels run fused (csrc/convp_kernels.hpp, convq_kernels.hpp)
+            # below.  Per pair position: the three blocks' first convs, then their second convs
             # (+ residual); at the last position the second convs of blocks 1.. store r_1.., and the first block's
             # runs after them with ((r_0 + r_1) + r_2) / nk in its epilogue -- the reference's order, bit for bit.
             for pi in range(npairs):

@@ -319,7 +319,7 @@ def test_conv1d_split_f16_reflection_rejects():
 @pytest.fixture
 def tuning():
     """fv_tuning_set for the duration of a test (process-wide switches of the launchers: restored afterwards)."""
-    defaults = {"sched": 1, "sched_switch": 4, "convh_blocks": 0, "pair_blocks": 0}
+    defaults = {"sched": 1, "sched_switch": 4, "convh_blocks": 0, "pair_blocks": 0, "pair128_unfused": 0}
     yield _native.tuning_set
     for k, v in defaults.items():
         _native.tuning_set(k, v)
@@ -456,7 +456,7 @@ def test_persistent_blocks_walk_many_tiles_and_cross_members(tuning, blocks):
         for yf, yw, ref in zip(full, few, refs):
             assert _rel(yw, ref) <= 4e-6
             assert torch.equal(yf, yw)
-        if C == 64:                                  # fused (convp_kernels.hpp) == two conv launches (convh), bit for bit
+        if C in (64, 128):                           # fused (convp / convq_kernels.hpp) == two conv launches (convh), bit for bit
             mids = _native.conv1d_split_f16(xs, h1, b1s, list(ks), dil, pre_slope=0.1)
             two = _native.conv1d_split_f16(mids, h2, b2s, list(ks), 1, pre_slope=0.1, res=xs)
             for yf, yt in zip(full, two):
