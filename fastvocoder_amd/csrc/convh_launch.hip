@@ -27,7 +27,9 @@ extern template int launch_convh_geom<2, 2>(const PairParams&, int, size_t, hipS
 // member) 56.7 -> 47.7 us at 128 channels, 49.7 -> 47.0 at 64; three-member launches gain nothing (128 channels:
 // a 7-tap + 3-tap block pays a member switch, a pipeline drain and refill, for what it saves) or lose (64 channels,
 // 58 vs 55 us: more switches than the contiguous cut has), so they keep the contiguous cut (FV_SCHED=2: all).
-void pair_schedule(PairParams& p, int nblk) {
+// (three_members: the kernel wants its three-member launches scheduled too -- the fused 128-channel pairs, whose tiles
+// are long enough for the balance to show: 191 -> 170 us over the four launches of a stage; Tuning::sched = 2: all)
+void pair_schedule(PairParams& p, int nblk, bool three_members) {
     typedef std::array<unsigned, 2 * kSchedBlocks> Table;
     static std::mutex mu;
     static std::map<std::array<int, 9>, Table> cache;           // host memory only; a process sees a handful of shapes
@@ -37,7 +39,7 @@ void pair_schedule(PairParams& p, int nblk) {
     long long items = 0;
     for (int m = 0; m < p.n_members; ++m) items += p.m[m].n_items;
     if (p.n_members < 2 || nblk < 2 || nblk > kSchedBlocks || items > 6LL * nblk) return;
-    if (p.n_members != 2 && tn.sched != 2) return;
+    if (p.n_members != 2 && tn.sched != 2 && !three_members) return;
     for (int m = 0; m < p.n_members; ++m)
         if (p.m[m].n_items > 2047) return;                       // 11-bit item numbers
     const int sw = tn.sched_switch;
@@ -376,7 +378,7 @@ int launch_convq(PairParams p, int dil, hipStream_t s) {
     long long nblk = tuning().convh_blocks > 0 ? tuning().convh_blocks : device_cu_count();
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
-    pair_schedule(p, p.nblk);
+    pair_schedule(p, p.nblk, true);
     p.dbg = tuning().pair_dbg;
     p.trace = nullptr;
     profile_begin(s);

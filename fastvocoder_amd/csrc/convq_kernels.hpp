@@ -32,6 +32,7 @@ struct ConvQGeom {
     static constexpr int XR = (XROWS * CB + NT - 1) / NT, XRM = XR;
     static constexpr int MRP = NM + 16;                  // rows of the intermediate image (>= NM + KT - 1, multiple of 16)
     static constexpr int MHALF = CB * MRP * 16;
+    // (a ring of four stages fits at dilation 1 and 3 -- smaller x image -- and was measured: no difference)
     static constexpr int STAGE_BYTES = 16384, RING = 3, AHEAD = RING - 1;
     static constexpr int WTILE = NSTEP * 8192;           // packed bytes of one 64-row tile of a conv ([tile][step][8 KB])
     static constexpr int RAWST = NST - 8;                // stage at which the next tile's raw window is requested

@@ -264,7 +264,7 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t stream);
 // Few, unequal items per block (batch 1: 378 items of three costs on 256 blocks): a longest-processing-time-first
 // assignment instead of the contiguous cut, written into p.sched (host cache per shape); p.sched_on = 0 when every block
 // has many items anyway
-void pair_schedule(PairParams& p, int nblk);
+void pair_schedule(PairParams& p, int nblk, bool three_members = false);
 // fused ResBlock pair at C = 64 with split-f16 operands and streamed weights (convp_kernels.hpp): members use x, w1, w2
 // (fv_pack_pair_weight_ex images), b1, b2, add1 / add2, y, y_act, k
 int launch_convp(PairParams p, int dil, hipStream_t stream);
