@@ -6,7 +6,7 @@ import subprocess
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src, dst = f"gpurun_out/{tag}", "profiles"
 os.makedirs(dst, exist_ok=True)
 shutil.copy(f"{src}/stats/bench_kernel_stats.csv", f"{dst}/{tag}_bench_kernel_stats.csv")
@@ -26,7 +26,7 @@ with open(f"{dst}/{tag}_mfma_counters.txt", "w") as f:
     f.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY\n"
             "#   SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace -- python bench.py --steps 5 --warmup 2\n"
             "# MI355X, HiFi-GAN light B=1 T=1000; per-dispatch averages; GRBM_GUI_ACTIVE is summed over the 8 XCDs\n")
-    fams = {"split-f16 convs with streamed weights (convh_kernel, convp_kernel)": ("convh_kernel", "convp_kernel"), "split-f16 fused pairs (pairh_kernel)": ("pairh_kernel",),
+    fams = {"split-f16 convs with streamed weights (convh_kernel, convp_kernel, convq_kernel)": ("convh_kernel", "convp_kernel", "convq_kernel"), "split-f16 fused pairs (pairh_kernel)": ("pairh_kernel",),
             "split-f16 transposed convs (convt_kernel)": ("convt_kernel",),
             "fp32-MFMA convs (conv_mfma_kernel + conv_group3_kernel + conv_sum3_kernel + pair_kernel + pair_sum_kernel)":
                 ("conv_mfma_kernel", "conv_group3_kernel", "conv_sum3_kernel", "fv::pair_kernel", "pair_sum_kernel")}
