@@ -45,7 +45,8 @@ def families(reps=5):
     torch.cuda.synchronize()
     _native.profile_enable(False)
     out = {}
-    for name, kind in (("convh128", _native.KERNEL_CONVH128), ("convh64", _native.KERNEL_CONVH64)):
+    for name, kind in (("convh128", _native.KERNEL_CONVH128), ("convh64", _native.KERNEL_CONVH64),
+                       ("pairh32", _native.KERNEL_PAIRH32), ("pairh16", _native.KERNEL_PAIRH16)):
         r = _native.profile_collect(kind)
         out[name] = (round(1e3 * r["ms"] / reps, 1), r["launches"] // reps)
     _native.profile_collect(-1)
