@@ -303,8 +303,9 @@ __global__ void pack_convg_kernel(const float* __restrict__ w1, const float* __r
 
 // ConvTranspose1d weights w[Cin][Cout][2 s] for convt_kernel (convh_kernels.hpp): the same stage layout, rows
 // m = co * s + phase, K = (tap, ci): tap 0 multiplies x[u - 1] (kernel index s + phase), tap 1 x[u] (kernel index phase)
+// (64 input channels: one chunk of 64 = two 32-channel groups per tap; otherwise chunks of 128)
 __global__ void pack_convth_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int Cin, int Cout, int s_, int* range_flag) {
-    const int NCH = (Cin + 127) / 128, CG = 4, NSTEP = 2 * CG, k = 2 * s_;
+    const int CC = Cin == 64 ? 64 : 128, NCH = (Cin + CC - 1) / CC, CG = CC / 32, NSTEP = 2 * CG, k = 2 * s_;
     const int64_t total = (int64_t)((Cout * s_ + 63) / 64) * NCH * NSTEP * 4 * 2 * 64 * 8;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -312,7 +313,7 @@ __global__ void pack_convth_kernel(const float* __restrict__ w, _Float16* __rest
         const int ms = (int)(i >> 12), st = ms % NSTEP, mc = ms / NSTEP, chunk = mc % NCH, mt = mc / NCH;
         const int tap = st / CG, cg = st % CG;
         const int m = 64 * mt + 16 * mh + (lane & 15), co = m / s_, ph = m - co * s_;
-        const int ci = 128 * chunk + 32 * cg + 8 * (lane >> 4) + j;
+        const int ci = CC * chunk + 32 * cg + 8 * (lane >> 4) + j;
         const float v = ci < Cin && co < Cout ? w[((size_t)ci * Cout + co) * k + (tap == 0 ? s_ + ph : ph)] : 0.f;
         const _Float16 h1 = (_Float16)v;
         if (range_flag && !(fabsf(v) < kSplitLimit)) *range_flag = 1;   // f16(v) would be inf (or v is not finite)
@@ -876,7 +877,8 @@ int64_t fv_packed_conv_transpose1d_split_floats(int Cin, int Cout, int k, int st
     if ((Cin != 64 && Cin != 128 && Cin != 256 && Cin != 512) || stride < 2 || stride > 16 || k != 2 * stride ||
         Cout <= 0 || Cout * stride < 64)
         return 0;
-    return (int64_t)((Cout * stride + 63) / 64) * ((Cin + 127) / 128) * 8 * 2048;   // row tiles x chunks x 8 K steps x 8 KB
+    const int cc = Cin == 64 ? 64 : 128;                                             // input channels per chunk
+    return (int64_t)((Cout * stride + 63) / 64) * ((Cin + cc - 1) / cc) * (2 * cc / 32) * 2048;   // row tiles x chunks x K steps x 8 KB
 }
 
 int fv_pack_conv_transpose1d_split_f16(const float* w, float* packed, int Cin, int Cout, int k, int stride, int* range_flag,

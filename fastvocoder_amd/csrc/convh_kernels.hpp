@@ -76,7 +76,7 @@ struct ConvHGeom {
     static constexpr int NRAW = XR * 8;
     static constexpr int RESST = NST - 2;                // ... this tile's bias and residual
     static constexpr int NRES = TR ? 8 : 8 + 8 * NFW;
-    static_assert(NSTEP % 2 == 0 && (NST >= 3 || (TWO && NST == 2)) && NFW % 2 == 0, "stages of two steps, at least three per chunk (two: 1x1)");
+    static_assert(NSTEP % 2 == 0 && NST >= 2 && NFW % 2 == 0, "stages of two steps, at least two per chunk");
     static_assert(((CG - 1) * 4 * XRP + (KT - 1) * DIL + 16 * (NFW - 1)) * 16 + 16 < 65536, "ds_read immediate range");
 };
 
@@ -194,10 +194,19 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
         else return mb.x + bb * ustride + c * cstride;
     };
     auto chunk_slope = [&](int c) { return G::TWO && c >= nch / 2 ? 1.f : p.slope; };
+    // Two stages per chunk (the two-source 1x1 conv; the transposed conv of 64 input channels): three stages ahead can be
+    // two chunks -- or, with one chunk per item, two ITEMS -- on.  The stages of an item (all chunks of one row tile) are
+    // contiguous in the packed image: stage number `lin` counted from the first stage of item `it`, wherever it falls
+    auto stage_off = [&](int it, int lin) -> unsigned {
+        const int spi = nch * G::NST;
+        const int it2 = it + lin / spi, st = lin % spi;
+        return it2 < hi_item ? (unsigned)((it2 % nmt) * nch * G::WTILE + st * G::STAGE_BYTES) : kOutOfRange;
+    };
     convh_load_raw<G>(raw, chunk_src(0, b), p.T, ntile * G::NTC - G::P, tid, true, p.reflect != 0, chunk_channels(0));
 #pragma unroll
     for (int st = 0; st < 3; ++st)
-        convh_dma_stage<G>(rw, ring, st, (unsigned)(mtile * nch * G::WTILE + st * G::STAGE_BYTES), wave, lane);
+        convh_dma_stage<G>(rw, ring, st, G::NST < 3 ? stage_off(item, st) : (unsigned)(mtile * nch * G::WTILE + st * G::STAGE_BYTES),
+                           wave, lane);
     pair_stamp(p, 8, wave, lane, 7, 11);
     pair_wait_vm0();
     pair_stamp(p, 8, wave, lane, 7, 10);
@@ -251,13 +260,8 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
             pair_barrier();
             constexpr int NS = GS + 3;
             unsigned off;
-            if constexpr (G::TWO) {
-                // two stages per chunk: three stages ahead can be two chunks on.  The stages of an item (all chunks of one
-                // row tile) are contiguous in the packed image: stage number inside the item, else the next item's
-                const int lin = chunk * G::NST + NS, spi = nch * G::NST;
-                if (lin < spi) off = (unsigned)(mtile * nch * G::WTILE + lin * G::STAGE_BYTES);
-                else off = item + 1 < hi_item ? (unsigned)(((item + 1) % nmt) * nch * G::WTILE + (lin - spi) * G::STAGE_BYTES) : kOutOfRange;
-            } else if constexpr (NS < G::NST) off = wcur + (unsigned)(NS * G::STAGE_BYTES);
+            if constexpr (G::NST < 3) off = stage_off(item, chunk * G::NST + NS);
+            else if constexpr (NS < G::NST) off = wcur + (unsigned)(NS * G::STAGE_BYTES);
             else off = more ? wnext + (unsigned)((NS - G::NST) * G::STAGE_BYTES) : kOutOfRange;
             convh_dma_stage<G>(rw, ring, (g0 + NS) & 3, off, wave, lane);
             if constexpr (GS == G::RAWST)

@@ -191,7 +191,8 @@ int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout,
         return fail(FV_ERR_UNSUPPORTED, "split-f16 transposed conv: packed weights must be 16-byte aligned");
     p.n_members = 1;
     p.ctot = Cin;
-    p.nch = (Cin + 127) / 128;                // 64 input channels: half a chunk, the other half multiplies zeros
+    const int cc = Cin == 64 ? 64 : 128;      // input channels per chunk (64 input channels: one chunk of 64, two K steps per tap)
+    p.nch = (Cin + cc - 1) / cc;
     p.nmt = (Cout * stride + 63) / 64;        // rows beyond Cout * stride: zero weights, stores dropped
     p.cout = Cout;
     p.ups = stride;
@@ -205,7 +206,7 @@ int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout,
     mb.n_items = mb.n_tiles * p.B * p.nmt;
     mb.cost = 1;
     const int xrows = (NTC + 1 + 3) / 4 * 4;
-    const int img_bytes = 4 * 128 * ((xrows + 15) / 16 * 16);
+    const int img_bytes = 4 * cc * ((xrows + 15) / 16 * 16);
     p.x_off = 0;                       // ring of 4 weight stages
     p.img_off = 4 * 16384 / 4;
     const size_t lds = 4 * 16384 + (size_t)img_bytes;
@@ -216,7 +217,7 @@ int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout,
     p.dbg = tuning().pair_dbg;
     p.trace = nullptr;
     profile_begin(s);
-    const int rc = launch_convt_geom(p, lds, s);
+    const int rc = launch_convt_geom(p, cc / 32, lds, s);
     // MACs of a ConvTranspose1d = Tin * Cin * Cout * k
     profile_end(s, FV_KERNEL_CONVT, 2.0 * p.B * (double)p.T * Cin * Cout * 2 * stride,
                 4.0 * ((double)Cin * Cout * 2 * stride + (double)p.B * ((double)Cin * p.T + (double)Cout * Tout * (mb.y_act ? 2 : 1))));

@@ -280,7 +280,7 @@ int launch_convh_geom(const PairParams& p, int dil, size_t lds, hipStream_t s);
 // ConvTranspose1d with split-f16 operands, k = 2 stride, Cin = 64 or a multiple of 128 (convt_kernel in
 // convh_kernels.hpp): member 0 uses x, w1 (fv_pack_conv_transpose1d_split_f16 image), b1, y, y_act
 int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout, hipStream_t stream);
-int launch_convt_geom(const PairParams& p, size_t lds, hipStream_t s);
+int launch_convt_geom(const PairParams& p, int cg, size_t lds, hipStream_t s);
 // y = post(W1 lrelu(x, slope) + W2 x2 + bias + res), 1-tap convs C -> C with split-f16 operands (convg_kernel): member 0
 // uses x, x2, w1 (fv_pack_conv1x1_2src_split_f16 image), b1, res, y, y_act; C = 128, 256 or 512
 int launch_convg(PairParams p, int C, hipStream_t stream);

@@ -282,7 +282,7 @@ def test_plan_shape_inference_without_gpu():
     t = L.fv_plan_create(128)
     assert L.fv_packed_conv_transpose1d_split_floats(128, 64, 10, 5) == 5 * 1 * 8 * 2048
     assert L.fv_packed_conv_transpose1d_split_floats(256, 128, 16, 8) == 16 * 2 * 8 * 2048
-    assert L.fv_packed_conv_transpose1d_split_floats(64, 32, 6, 3) == 2 * 1 * 8 * 2048     # 96 rows, 64 channels: padded
+    assert L.fv_packed_conv_transpose1d_split_floats(64, 32, 6, 3) == 2 * 1 * 4 * 2048     # 96 rows -> 2 tiles; 64-channel chunks
     assert L.fv_packed_conv_transpose1d_split_floats(32, 16, 4, 2) == 0
     assert L.fv_packed_conv_transpose1d_split_floats(128, 64, 11, 5) == 0
     assert L.fv_plan_add_conv_transpose1d_split_f16(t, 0, 1, -1, dummy, None, 128, 64, 10, 5, 3, 1, 0.1, 1.0) == 0
