@@ -381,6 +381,10 @@ struct fv_plan {
     // memory -- the host's and the device's view of it
     int* guard_host = nullptr;
     int* guard_dev = nullptr;
+    // chained launches (fv_internal.h PairChain): flags and schedule tables on the device, chains launched so far in
+    // the current run
+    fv::ChainBuffers chain;
+    int chain_count = 0;
 };
 
 namespace fv {
@@ -636,6 +640,7 @@ static const TuningEntry kTuningTable[] = {
     {"pair_dbg", &Tuning::pair_dbg},       {"dbg", &Tuning::conv_dbg},           {"sched", &Tuning::sched},
     {"sched_switch", &Tuning::sched_switch}, {"convh_skel", &Tuning::convh_skel}, {"convp_skel", &Tuning::convp_skel},
     {"convq_skel", &Tuning::convq_skel},   {"pair128_unfused", &Tuning::pair128_unfused},
+    {"chain", &Tuning::chain},             {"chain_spin", &Tuning::chain_spin},
     {"pairh_skel", &Tuning::pairh_skel},   {"pair_skel", &Tuning::pair_skel},    {"convh_blocks", &Tuning::convh_blocks},
     {"pair_blocks", &Tuning::pair_blocks}, {"sum3_min", &Tuning::sum3_min},      {"lds_budget", &Tuning::lds_budget},
     {"units", &Tuning::units},             {"shape16", &Tuning::shape16},        {"shape32", &Tuning::shape32},
@@ -947,7 +952,10 @@ fv_plan_t* fv_plan_create(int in_channels) {
     return p;
 }
 
-void fv_plan_destroy(fv_plan_t* plan) { delete plan; }
+void fv_plan_destroy(fv_plan_t* plan) {
+    if (plan) plan->chain.release();
+    delete plan;
+}
 
 static int check_slot(int s, bool allow_none) {
     if (s == FV_SLOT_NONE && allow_none) return 0;
@@ -1678,6 +1686,7 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
     base[FV_SLOT_IN] = const_cast<float*>(in);
     base[FV_SLOT_OUT] = out;
     hipStream_t const s = (hipStream_t)stream;
+    plan->chain_count = 0;
     // shapes again, op by op (a slot may change shape when it is reused)
     for (int i = 0; i < FV_MAX_SLOTS; ++i) sh[i].set = false;
     sh[FV_SLOT_IN] = {plan->in_channels, T, true};
@@ -1728,6 +1737,10 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
         }
         // ---- fused ResBlock pairs: the members of a group (the three ResBlocks of an MRF stage) in one launch ----
         if (o.type == OP_PAIR || o.type == OP_MRFSUM) {
+            // the launch that starts at op n0: its members [n0, end) and its parameters (Tn: samples per utterance)
+            auto gather = [&](size_t n0, int Tn, PairParams& pp) -> size_t {
+            const Op& o = plan->ops[n0];
+            const size_t n = n0;
             size_t m = n + 1;
             if (o.type == OP_PAIR && o.group != 0)
                 while (m < plan->ops.size() && m - n < 3 && plan->ops[m].type == OP_PAIR && plan->ops[m].group == o.group &&
@@ -1736,9 +1749,9 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
                        !plan->ops[m].fold_w &&
                        plan->ops[m].prec == o.prec && plan->ops[m].out_div == o.out_div && plan->ops[m].post == o.post)
                     ++m;
-            PairParams pp = {};
+            pp = {};
             pp.B = B;
-            pp.T = (int)sh[o.x].T;
+            pp.T = Tn;
             pp.slope = o.pre_slope;
             pp.act_slope = o.act_slope;
             pp.out_div = o.out_div;
@@ -1783,6 +1796,43 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
                     }
                 }
             }
+            return m;
+            };
+            auto set_shapes = [&](size_t n0, size_t m0) {
+                for (size_t q = n0; q < m0; ++q) {
+                    const Op& qo = plan->ops[q];
+                    sh[qo.y] = {qo.fold_w ? 1 : qo.Cout, sh[qo.x].T, true};
+                    if (qo.y2 != FV_SLOT_NONE) sh[qo.y2] = sh[qo.y];
+                }
+            };
+            PairParams pp;
+            const size_t m = gather(n, (int)sh[o.x].T, pp);
+            // the launches of an MRF stage that follow (same channels, samples, arithmetic): one chained launch
+            if (o.type == OP_PAIR && o.Cin == 64 && o.prec == FV_PAIR_SPLIT_F16 && !o.fold_w && plan->guard_dev && tuning().chain) {
+                PairParams cph[kChainPhases];
+                int cdil[kChainPhases];
+                size_t cend[kChainPhases];
+                int np = 0;
+                size_t at = n;
+                while (np < kChainPhases && at < plan->ops.size()) {
+                    const Op& f = plan->ops[at];
+                    if (f.type != OP_PAIR || f.Cin != o.Cin || f.prec != o.prec || f.fold_w) break;
+                    cend[np] = gather(at, (int)sh[o.x].T, cph[np]);
+                    cdil[np] = f.dil;
+                    at = cend[np];
+                    ++np;
+                }
+                if (np >= 2) {
+                    const int rc = launch_convp_chain(cph, cdil, np, plan->chain, plan->chain_count, s);
+                    if (rc < 0) return rc;
+                    if (rc == 0) {
+                        ++plan->chain_count;
+                        set_shapes(n, cend[np - 1]);
+                        n = cend[np - 1] - 1;
+                        continue;
+                    }
+                }
+            }
             if (o.Cin == 64 && o.prec == FV_PAIR_SPLIT_F16) {
                 if (int rc = launch_convp(pp, o.dil, s)) return rc;
             } else if (o.Cin == 128 && o.prec == FV_PAIR_SPLIT_F16 && !tuning().pair128_unfused) {
@@ -1792,11 +1842,7 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
                 for (size_t q = n; q < m; ++q) mids[q - n] = base[plan->ops[q].tmpb];
                 if (int rc = launch_wide_pairs(pp, mids, o.Cin, o.dil, s)) return rc;
             } else if (int rc = launch_pairs(pp, o.Cin, o.dil, s)) return rc;
-            for (size_t q = n; q < m; ++q) {
-                const Op& qo = plan->ops[q];
-                sh[qo.y] = {qo.fold_w ? 1 : qo.Cout, sh[qo.x].T, true};
-                if (qo.y2 != FV_SLOT_NONE) sh[qo.y2] = sh[qo.y];
-            }
+            set_shapes(n, m);
             n = m - 1;
             continue;
         }

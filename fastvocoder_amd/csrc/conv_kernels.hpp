@@ -125,6 +125,17 @@ __device__ __forceinline__ void buffer_store1s(__amdgpu_buffer_rsrc_t r, unsigne
 __device__ __forceinline__ void buffer_store1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)byte_off, 0, 0);
 }
+// ... with cache-policy bits (AUX: 0 plain, kAuxAgent = sc1: the access is coherent device-wide -- stores write through
+// the XCD's L2, loads do not hit in it; what tensors that cross the phases of a chained launch need, fv_internal.h PairChain)
+constexpr int kAuxAgent = 16;
+template <int AUX>
+__device__ __forceinline__ float buffer_load1s_aux(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned s_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, (int)s_off, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ void buffer_store1s_aux(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned s_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)byte_off, (int)s_off, AUX);
+}
 // 16 bytes per lane straight into LDS: lane l lands at lds + 16*l (wave-uniform base)
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, float* lds, unsigned byte_off) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 16, (int)byte_off, 0, 0, 0);

@@ -87,7 +87,7 @@ struct ConvHRaw {
 
 // raw window rows [tA, tA + XROWS) of all C channels -> registers; rows outside [0, T) (or `live` false) read as zero,
 // or (reflect: MelGAN's ReflectionPad1d, pad < T) as the row mirrored at the first / last sample
-template <class G>
+template <class G, int AUX = 0>
 __device__ __forceinline__ void convh_load_raw(ConvHRaw<G>& r, const float* xb, int T, int tA, int tid, bool live,
                                                bool reflect = false, int cvalid = G::C) {
     // (cvalid < G::C: the transposed conv of a 64-channel input -- the missing channels read as zero)
@@ -105,7 +105,7 @@ __device__ __forceinline__ void convh_load_raw(ConvHRaw<G>& r, const float* xb, 
         const bool ok = live && idx < G::XROWS * G::CB && t >= 0 && t < T;
         const unsigned voff = ok ? (unsigned)(cb * 8 * T + t) * 4u : kOutOfRange;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r.v[q][j] = buffer_load1s(rx, voff, (unsigned)j * t4);
+        for (int j = 0; j < 8; ++j) r.v[q][j] = buffer_load1s_aux<AUX>(rx, voff, (unsigned)j * t4);
     }
 }
 

@@ -30,10 +30,26 @@ struct ConvPGeom {
     static_assert(KT - 1 <= 16 && NST1 >= 3, "taps");
 };
 
-template <class G>
-__device__ __forceinline__ void convp_run_member(const PairParams& p, const PairMember& mb, int item0, int hi_item,
-                                                 float* smem, int wave, int lane_in, bool first) {
+// CHAIN: a phase of a chained launch (fv_internal.h PairChain): activations move with agent-scope accesses, an item
+// waits for the flags of the tiles it reads (`dep`: the member's dependency descriptors, in the kernel arguments) and
+// raises its own once its stores are acknowledged.
+template <class G, bool CHAIN = false>
+__device__ __forceinline__ void convp_run_member(const PairCore& p, const PairMember& mb, int item0, int hi_item,
+                                                 float* smem, int wave, int lane_in, bool first,
+                                                 const PairMember::Dep* dep = nullptr, const ChainCtx* cc = nullptr,
+                                                 int dir_in = 1) {
+    // items item0, item0 + dir, ... up to (not including) hi_item; dir = -1 in chained launches only (the block
+    // schedule alternates the direction from phase to phase: fv_internal.h PairChain)
+    const int dir = CHAIN ? dir_in : 1;
     typedef typename G::H H;
+#ifdef FV_CHAIN_PLAIN
+    constexpr int AUX = 0;                               // (timing experiment: results are not coherent)
+#else
+    constexpr int AUX = CHAIN ? kAuxAgent : 0;
+#endif
+    // stage entries at which the tile BEFORE is signalled (its stores were issued a window conversion ago: vmcnt(0) is
+    // nearly free there) and at which the next item's flags are requested (three entries ahead of their use)
+    constexpr int SIGST = 0, FLST = G::RAWST >= 3 ? G::RAWST - 3 : 0;
     typedef __attribute__((address_space(3))) const f16x8 LdsH8;
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
@@ -61,9 +77,16 @@ __device__ __forceinline__ void convp_run_member(const PairParams& p, const Pair
     int g0 = 0;
     int b = item / mb.n_tiles, tile = item - b * mb.n_tiles;
     if (!first) pair_barrier();
+    pair_stamp(p, 8, wave, lane, 7, 12);                 // (tuning aid, -DFV_PAIR_TRACE: tools/convp_trace.py) run start
     float bad = 0.f;                                     // range guard (pairh_kernels.hpp range_note)
     ConvHRaw<H> raw;
-    convh_load_raw<H>(raw, mb.x + b * ustride, p.T, tile * G::NOUT - G::P1 - G::P2, tid, true);
+    unsigned fo = kOutOfRange, fv = 0;                   // chained: this lane's flag of the next item, its value
+    if constexpr (CHAIN) {
+        fo = chain_dep_offset(dep, b, tile * G::NOUT, G::NOUT, p.T, lane);
+        fv = chain_load(*cc, fo);
+        if (!(p.dbg & 64) && !chain_ready(*cc, fo, fv)) chain_spin(*cc, fo, lane);
+    }
+    convh_load_raw<H, AUX>(raw, mb.x + b * ustride, p.T, tile * G::NOUT - G::P1 - G::P2, tid, true);
 #pragma unroll
     for (int st = 0; st < 3; ++st) convh_dma_stage<H>(rw1, ring, st, (unsigned)(st * H::STAGE_BYTES), wave, lane);
     if (tid < G::C) {
@@ -74,15 +97,24 @@ __device__ __forceinline__ void convp_run_member(const PairParams& p, const Pair
     for (int idx = tid; idx < 2 * (G::C / 8) * 64; idx += 512)
         reinterpret_cast<float*>(mimg + ((idx >> 6) * G::MRP + G::NM) * 16)[idx & 63] = 0.f;
     pair_wait_vm0();
+    pair_stamp(p, 8, wave, lane, 7, 10);
     if (!(p.dbg & 2)) convh_convert<H>(raw, ximg, p.slope, tid);
-    for (;;) {
+    pair_stamp(p, 8, wave, lane, 7, 13);
+    for (int it = 0;; ++it) {
+        pair_stamp(p, 8, wave, lane, it, 0);
         const int t0 = tile * G::NOUT;
-        const int nitem = item + 1;
-        const bool more = nitem < hi_item;
-        int nb = b, ntile = tile + 1;
+        const int nitem = item + dir;
+        const bool more = nitem != hi_item;
+        int nb = b, ntile = tile + dir;
         if (ntile == mb.n_tiles) {
             ntile = 0;
             ++nb;
+        }
+        if constexpr (CHAIN) {
+            if (ntile < 0) {
+                ntile = mb.n_tiles - 1;
+                --nb;
+            }
         }
         f32x4 hi[2][G::NFW], lo[2][G::NFW];
         float res[2][G::NFW][4];
@@ -94,9 +126,14 @@ __device__ __forceinline__ void convp_run_member(const PairParams& p, const Pair
             {
                 constexpr bool raw_between = GS >= 3 && G::RAWST >= GS - 3 && G::RAWST <= GS - 1;
                 constexpr bool res_between = GS >= 3 && G::RESST >= GS - 3 && G::RESST <= GS - 1;
-                wait_vm<4 + (raw_between ? G::NRAW : 0) + (res_between ? G::NRES : 0)>();
+                constexpr bool flag_between = CHAIN && FLST >= GS - 3 && FLST <= GS - 1;
+                if constexpr (CHAIN && GS == SIGST) wait_vm<0>();       // ... and the stores of the tile before
+                else wait_vm<4 + (raw_between ? G::NRAW : 0) + (res_between ? G::NRES : 0) + (flag_between ? 1 : 0)>();
             }
             pair_barrier();
+            if constexpr (CHAIN && GS == SIGST) {
+                if (tid == 0 && item != item0) chain_signal(*cc, mb.flag_off + item - dir);
+            }
             constexpr int NS = GS + 3;                   // this tile's stage NS, or the next tile's NS - NST
             if constexpr (NS < G::NST1)
                 convh_dma_stage<H>(rw1, ring, (g0 + NS) & 3, (unsigned)(NS * H::STAGE_BYTES), wave, lane);
@@ -105,8 +142,16 @@ __device__ __forceinline__ void convp_run_member(const PairParams& p, const Pair
             else
                 convh_dma_stage<H>(rw1, ring, (g0 + NS) & 3,
                                    more ? (unsigned)((NS - G::NST) * H::STAGE_BYTES) : kOutOfRange, wave, lane);
-            if constexpr (GS == G::RAWST)
-                convh_load_raw<H>(raw, mb.x + nb * ustride, p.T, ntile * G::NOUT - G::P1 - G::P2, tid, more && !(p.dbg & 1));
+            if constexpr (CHAIN && GS == FLST) {
+                fo = more ? chain_dep_offset(dep, nb, ntile * G::NOUT, G::NOUT, p.T, lane) : kOutOfRange;
+                fv = chain_load(*cc, fo);
+            }
+            if constexpr (GS == G::RAWST) {
+                if constexpr (CHAIN) {
+                    if (!(p.dbg & 64) && !chain_ready(*cc, fo, fv)) chain_spin(*cc, fo, lane);
+                }
+                convh_load_raw<H, AUX>(raw, mb.x + nb * ustride, p.T, ntile * G::NOUT - G::P1 - G::P2, tid, more && !(p.dbg & 1));
+            }
             if constexpr (GS == G::RESST) {
                 const __amdgpu_buffer_rsrc_t rr = make_rsrc(mb.x + b * ustride, ubytes);     // the residual is x itself
 #pragma unroll
@@ -116,7 +161,7 @@ __device__ __forceinline__ void convp_run_member(const PairParams& p, const Pair
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) res[h][f][i] = buffer_load1s(rr, voff[f], (unsigned)(16 * h + i) * t4);
+                        for (int i = 0; i < 4; ++i) res[h][f][i] = buffer_load1s_aux<AUX>(rr, voff[f], (unsigned)(16 * h + i) * t4);
                 }
             }
         };
@@ -193,6 +238,7 @@ __device__ __forceinline__ void convp_run_member(const PairParams& p, const Pair
         };
 
         conv(IntC<0>{});
+        pair_stamp(p, 8, wave, lane, it, 1);
         {
             // conv1 -> intermediate image: column u of the tile is time t0 - P2 + u; conv2's zero padding applies to
             // the intermediate: columns outside [0, T) are zero, not conv1 of the padded input
@@ -221,11 +267,14 @@ __device__ __forceinline__ void convp_run_member(const PairParams& p, const Pair
             }
         }
         pair_barrier();                                  // the intermediate is complete (and nobody reads the x image any more)
+        pair_stamp(p, 8, wave, lane, it, 2);
         // fetch_a of conv2's first step: its stage was entered (barrier, DMA landed) during conv1's last group
         conv(IntC<1>{});
+        pair_stamp(p, 8, wave, lane, it, 3);
         // ---- epilogue: outputs, then the image of the next window ----------------------------------------------
         pair_barrier();                                  // every wave is done with the intermediate
         wait_vm<2>();                                    // raw window, residual: everything but the DMA of the last entry
+        pair_stamp(p, 8, wave, lane, it, 4);
         const bool fin = mb.add1 != nullptr;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -246,8 +295,8 @@ __device__ __forceinline__ void convp_run_member(const PairParams& p, const Pair
                 for (int f = 0; f < G::NFW; ++f)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        lo[h][f][i] = buffer_load1s(r1, voff[f], (unsigned)(16 * h + i) * t4);
-                        res[h][f][i] = buffer_load1s(r2, voff[f], (unsigned)(16 * h + i) * t4);
+                        lo[h][f][i] = buffer_load1s_aux<AUX>(r1, voff[f], (unsigned)(16 * h + i) * t4);
+                        res[h][f][i] = buffer_load1s_aux<AUX>(r2, voff[f], (unsigned)(16 * h + i) * t4);
                     }
             pair_wait_vm0();
 #pragma unroll
@@ -266,10 +315,12 @@ __device__ __forceinline__ void convp_run_member(const PairParams& p, const Pair
                 for (int i = 0; i < 4; ++i) v[i] = hi[h][f][i];
                 const int col = col0 + f * 16;
                 range_note4(bad, v[0], v[1], v[2], v[3], col < G::NOUT && t0 + col < p.T);
-                pair_store(p, mb.y, mb.y_act, G::C, b, row0 + 16 * h, t0 + col,
+                pair_store<AUX>(p, mb.y, mb.y_act, G::C, b, row0 + 16 * h, t0 + col,
                            col < G::NOUT && t0 + col < p.T && !(p.dbg & 8), v, fin);
             }
+        pair_stamp(p, 8, wave, lane, it, 5);
         if (more && !(p.dbg & 2)) convh_convert<H>(raw, ximg, p.slope, tid);
+        pair_stamp(p, 8, wave, lane, it, 6);
         if (!more) break;
         g0 += G::NST;
         item = nitem;
@@ -277,6 +328,10 @@ __device__ __forceinline__ void convp_run_member(const PairParams& p, const Pair
         tile = ntile;
     }
     pair_wait_vm0();
+    if constexpr (CHAIN) {
+        pair_barrier();                                  // every wave's stores of the last tile are acknowledged
+        if (tid == 0) chain_signal(*cc, mb.flag_off + item);
+    }
     range_flag(p, bad);
 }
 

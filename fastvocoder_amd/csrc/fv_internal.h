@@ -1,6 +1,8 @@
 // Internal declarations shared by the translation units of libfastvocoder_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <vector>
 #include <stdint.h>
 
 #include "../../include/fastvocoder_hip.h"
@@ -143,6 +145,9 @@ struct Tuning {
     int convp_skel = 5;
     int convq_skel = -1;     // (-1: 5)
     int pair128_unfused = 0; // 1: 128-channel ResBlock pairs as two conv launches (convh) instead of the fused convq kernel (A/B, bit-identity tests)
+    int chain = 0;            // 1: the dependent pair launches of a 64-channel MRF stage as one chained launch (PairChain;
+                              // measured no faster at batch 1, convh_launch.hip chain_schedule: off)
+    int chain_spin = 1 << 19; // polls a chained block waits for a flag before it gives up
     int pairh_skel = -1;     // (-1: 8 at 16 channels, 6 at 32)
     int pair_skel = -1;      // (-1: 4 at 16 channels, 3 at 32)
     int convh_blocks = 0;    // > 0: persistent blocks of the convh / convp / convt launches (default: one per CU)
@@ -177,11 +182,20 @@ struct PairMember {
     int cost;            // relative cost of one tile of this member (partition weights): taps + per-tile overhead
     int n_tiles;         // tiles per utterance
     int w_off;           // float offset of this member's two weight images in dynamic LDS
+    // chained launches (PairChain below): where this member's tiles raise their flags, and the flags its inputs
+    // x / add1 / add2 wait for when an earlier phase of the same launch produces them
+    int flag_off;        // first flag of this member's items (item = utterance * n_tiles + tile), or -1
+    struct Dep {
+        int off;         // first flag of the producing member's items, or -1: the input was complete before the launch
+        int nout;        // output samples per tile of the producer
+        int n_tiles;     // its tiles per utterance
+        int halo;        // samples needed on either side of the consumer's tile
+    } dep[3];
 };
 
 constexpr int kSchedBlocks = 256;     // blocks a launch's schedule can describe (one per CU)
 
-struct PairParams {
+struct PairCore {
     PairMember m[3];
     int n_members;
     int sum;             // members accumulate into m[0].y ( / out_div, activation)
@@ -214,10 +228,32 @@ struct PairParams {
     int dbg;             // ablation switches (Tuning::pair_dbg, timing experiments only -- results are wrong):
                          // 1 no x DMA after a block's first tile, 2 no activation pass, 4 no MFMA,
                          // 8 no stores, 16 no residual loads
+    // chained launches: flags[] (device memory, one word per item of every phase) holds `epoch` once the item's
+    // outputs are visible device-wide; null: an ordinary launch
+    unsigned* flags;
+    unsigned flag_bytes;
+    unsigned epoch;
+};
+
+struct PairParams : PairCore {
     // Block schedule (few, unequal items per block): two words per block, member m's items [lo, lo + count) packed as
     // lo (11 bits) | count (5 bits): word 0 = member 0 | member 1 << 16, word 1 = member 2.  Part of the kernel
     // arguments: no device table, no copy, legal under stream capture.
     unsigned sched[2 * kSchedBlocks];
+};
+
+// The dependent launches of an MRF stage (pair positions 1, 2, 3 of the three ResBlocks: four launches) as ONE
+// persistent launch: every block runs its share of phase 0, then of phase 1, ...; a tile of a later phase waits for the
+// flags of the tiles it reads (its own window + halo in the producing member, the summands of the stage's last
+// launch) instead of for a kernel boundary.  Tensors that cross phases are written and read with agent-scope (sc1)
+// accesses: the XCDs' L2s are not coherent with each other inside a launch (tools/flag_probe.hip).
+constexpr int kChainPhases = 4;
+struct PairChain {
+    PairCore ph[kChainPhases];
+    int dil[kChainPhases];
+    int n_phases;
+    const unsigned* sched;       // device memory: the block schedule [phase][block][4] (chain_schedule, convh_launch.hip)
+    int spin_limit;              // polls before a waiting block gives up (raises guard word 2 and goes on)
 };
 
 // tile geometry of the pair kernels, the run-time mirror of PairGeom<> (pair_kernels.hpp)
@@ -270,6 +306,27 @@ void pair_schedule(PairParams& p, int nblk, bool three_members = false);
 int launch_convp(PairParams p, int dil, hipStream_t stream);
 template <int DIL>
 int launch_convp_dil(const PairParams& p, size_t lds, hipStream_t s);
+// Device-side state of a plan's chained launches (PairChain): the item flags (shared by the plan's chains: every launch
+// has its own epoch), one block-schedule table per chain of the run, their host mirrors.
+struct ChainBuffers {
+    unsigned* flags = nullptr;
+    size_t flag_words = 0;
+    unsigned epoch = 0;
+    struct Table {
+        unsigned* dev = nullptr;
+        std::vector<unsigned> host;      // what dev holds
+        std::vector<int> key;            // shapes the schedule below was computed for
+        std::vector<unsigned> sched;
+    };
+    std::vector<Table> tables;
+    void release();
+};
+// n (2 .. kChainPhases) dependent pair launches at 64 channels as one chained launch (convp_chain.hpp); ph[i] / dil[i] as
+// launch_convp would get them, in launch order.  Returns 0 (launched), < 0 (error) or 1: not chained (a phase reads what a
+// later one overwrites, a tile spans too many producer tiles, the stream is being captured before the tables are on
+// the device, ...) -- nothing was launched, the caller launches the phases one by one.
+int launch_convp_chain(PairParams* ph, const int* dil, int n, ChainBuffers& cb, int chain_index, hipStream_t stream);
+int launch_convp_chain_kernel(const PairChain& c, int nblk, size_t lds, hipStream_t s);
 // fused ResBlock pair at C = 128 (convq_kernels.hpp): 128-row x 64-column tiles, one K step per weight stage; members as
 // launch_convp (w1 / w2: the fv_pack_pair_weight_ex images of the conv kernel, [row tile][step][8 KB])
 int launch_convq(PairParams p, int dil, hipStream_t stream);

@@ -75,7 +75,7 @@ __device__ __forceinline__ void pair_drain_vm() { __builtin_amdgcn_s_waitcnt(0x0
 
 // tuning aid, compiled in with -DFV_PAIR_TRACE only (tools/pair_trace.py): time stamp `ev` of this wave's
 // `it`-th tile (every 64th block, tiles 0..7 only)
-__device__ __forceinline__ void pair_stamp(const PairParams& p, int nw, int wave, int lane, int it, int ev) {
+__device__ __forceinline__ void pair_stamp(const PairCore& p, int nw, int wave, int lane, int it, int ev) {
 #ifdef FV_PAIR_TRACE
     if (p.trace && (blockIdx.x & 63) == 0 && blockIdx.x < 512 && it < 8 && lane == 0)
         p.trace[(((size_t)(blockIdx.x >> 6) * nw + wave) * 8 + it) * 16 + ev] = __builtin_amdgcn_s_memtime();
@@ -308,7 +308,8 @@ __device__ __forceinline__ void pair_conv1(const PairLane<G>& L, const float* bl
 }
 
 // final stores of a tile: v = post(v / out_div), y (and the activated twin)
-__device__ __forceinline__ void pair_store(const PairParams& p, float* y, float* y_act, int C, int b, int row0, int t,
+template <int AUX = 0>
+__device__ __forceinline__ void pair_store(const PairCore& p, float* y, float* y_act, int C, int b, int row0, int t,
                                            bool ok, float (&v)[4], bool finish) {
     const size_t boff = (size_t)b * C * (size_t)p.T;
     const unsigned bytes = (unsigned)C * (unsigned)p.T * 4u;
@@ -331,16 +332,16 @@ __device__ __forceinline__ void pair_store(const PairParams& p, float* y, float*
     if (y_act) {
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(y_act + boff, bytes);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) buffer_store1s(ry, voff, (unsigned)i * t4, v[i]);
+        for (int i = 0; i < 4; ++i) buffer_store1s_aux<AUX>(ry, voff, (unsigned)i * t4, v[i]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) buffer_store1s(ra, voff, (unsigned)i * t4, act(v[i], p.act_slope));
+        for (int i = 0; i < 4; ++i) buffer_store1s_aux<AUX>(ra, voff, (unsigned)i * t4, act(v[i], p.act_slope));
     } else {
         if (p.act_slope != 1.f) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = act(v[i], p.act_slope);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) buffer_store1s(ry, voff, (unsigned)i * t4, v[i]);
+        for (int i = 0; i < 4; ++i) buffer_store1s_aux<AUX>(ry, voff, (unsigned)i * t4, v[i]);
     }
 }
 

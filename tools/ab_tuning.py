@@ -14,7 +14,7 @@ import bench  # noqa: E402
 from fastvocoder_amd import _native  # noqa: E402
 
 DEFAULTS = {"sched": 1, "sched_switch": 4, "convh_skel": -1, "convp_skel": 5, "convq_skel": -1, "pair128_unfused": 0,
-            "convh_blocks": 0, "pair_blocks": 0}
+            "convh_blocks": 0, "pair_blocks": 0, "chain": 0, "pair_dbg": 0}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1)
