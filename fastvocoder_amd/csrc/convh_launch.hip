@@ -248,7 +248,14 @@ int launch_convg(PairParams p, int C, hipStream_t s) {
     const int NTC = 128;
     mb.k = 1;
     mb.n_tiles = (p.T + NTC - 1) / NTC;
-    mb.n_items = mb.n_tiles * p.B * p.nmt;
+    // 128 output rows per item (convr_kernels.hpp: a converted chunk of the inputs feeds two 64-row tiles), or 64
+    // (convg_kernel; Tuning::convg_rows64, A/B and bit-identity tests)
+    // [measured, MI355X] Basis-MelGAN light, 64 utterances: 16.3 -> 14.0 ms per step on 128-row tiles; MelGAN, one
+    // utterance of 200 frames (13 - 100 column tiles per launch): 0.44 -> 0.47 ms -- with fewer items than CUs the
+    // 64-row tiles keep more of the chip busy.  -1: by the item count.
+    const int cus = device_cu_count();
+    const bool wide = tuning().convg_rows64 < 0 ? (long long)mb.n_tiles * p.B * (p.nmt / 2) * 10 >= 7LL * cus : !tuning().convg_rows64;
+    mb.n_items = mb.n_tiles * p.B * (wide ? p.nmt / 2 : p.nmt);
     mb.cost = 1;
     p.x_off = 0;                               // ring of 4 weight stages
     p.img_off = 4 * 16384 / 4;
@@ -260,7 +267,7 @@ int launch_convg(PairParams p, int C, hipStream_t s) {
     p.dbg = tuning().pair_dbg;
     p.trace = nullptr;
     profile_begin(s);
-    const int rc = launch_convg_geom(p, lds, s);
+    const int rc = wide ? launch_convr_geom(p, lds, s) : launch_convg_geom(p, lds, s);
     profile_end(s, FV_KERNEL_CONVG, 2.0 * p.B * (double)C * 2 * C * p.T,
                 4.0 * (2.0 * C * C + (double)p.B * C * p.T * (3 + (mb.res ? 1 : 0) + (mb.y_act ? 1 : 0))));
     return rc;

@@ -127,8 +127,11 @@ __device__ __forceinline__ void convp_run_member(const PairCore& p, const PairMe
                 constexpr bool raw_between = GS >= 3 && G::RAWST >= GS - 3 && G::RAWST <= GS - 1;
                 constexpr bool res_between = GS >= 3 && G::RESST >= GS - 3 && G::RESST <= GS - 1;
                 constexpr bool flag_between = CHAIN && FLST >= GS - 3 && FLST <= GS - 1;
+                // (the first three stages of a tile landed before the tile in front issued its stores -- its epilogue
+                // waits for them: a count here would wait for those stores, which are younger and retire late)
                 if constexpr (CHAIN && GS == SIGST) wait_vm<0>();       // ... and the stores of the tile before
-                else wait_vm<4 + (raw_between ? G::NRAW : 0) + (res_between ? G::NRES : 0) + (flag_between ? 1 : 0)>();
+                else if constexpr (GS >= 3)
+                    wait_vm<4 + (raw_between ? G::NRAW : 0) + (res_between ? G::NRES : 0) + (flag_between ? 1 : 0)>();
             }
             pair_barrier();
             if constexpr (CHAIN && GS == SIGST) {
@@ -273,7 +276,7 @@ __device__ __forceinline__ void convp_run_member(const PairCore& p, const PairMe
         pair_stamp(p, 8, wave, lane, it, 3);
         // ---- epilogue: outputs, then the image of the next window ----------------------------------------------
         pair_barrier();                                  // every wave is done with the intermediate
-        wait_vm<2>();                                    // raw window, residual: everything but the DMA of the last entry
+        wait_vm<0>();                                    // raw window, residual, the next tile's first three weight stages
         pair_stamp(p, 8, wave, lane, it, 4);
         const bool fin = mb.add1 != nullptr;
 #pragma unroll

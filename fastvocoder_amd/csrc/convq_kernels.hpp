@@ -134,7 +134,8 @@ __device__ __forceinline__ void convq_run_member(const PairParams& p, const Pair
                 // / the residual if they were requested at one of those entries (for GS < AHEAD the DMA was issued in the
                 // previous tile, whose raw / residual requests were waited for in its epilogue)
                 constexpr bool raw_between = GS >= G::AHEAD && G::RAWST >= GS - G::AHEAD && G::RAWST <= GS - 1;
-                wait_vm<2 * (G::AHEAD - 1) + (raw_between ? G::NRAW : 0)>();
+                // (GS < AHEAD: landed before that epilogue issued its stores -- no count, it would wait for the stores)
+                if constexpr (GS >= G::AHEAD) wait_vm<2 * (G::AHEAD - 1) + (raw_between ? G::NRAW : 0)>();
             }
             pair_barrier();
             constexpr int NS = GS + G::AHEAD;            // this tile's stage NS, or the next tile's NS - NST

@@ -1,0 +1,263 @@
+// Two-source 1x1 conv with split-f16 operands, 128 output rows per tile:
+//
+//     y = post( W1 lrelu(x, slope) + W2 x2 + bias + res )              (ResidualStack's tail, reference modules.py:351-359:
+//                                                                        conv1x1(lrelu(dilated conv)) + skip1x1(c))
+//
+// convg_kernel (convh_kernels.hpp, 64 rows x 128 columns per tile) one size up.  The GEMM has K = 2 C and no taps: every
+// 128-channel chunk of the inputs is loaded, activated, split and written to the LDS image for FOUR K steps only, and
+// that conversion is VALU work the matrix cores wait for (0.9 us per chunk against 0.64 us of MFMAs on a 64-row tile).
+// Here a block owns 128 rows x 128 columns (8 waves = 4 row slabs of 32 x 2 column groups of 64; per wave and K step
+// 4 A + 8 B ds_read_b128 for 24 MFMAs), so a converted chunk feeds twice the MFMAs.  A weight stage is ONE K step of all
+// 128 rows (two 8 KB pieces, one per 64-row tile of the image fv_pack_conv1x1_2src_split_f16 lays out), ring of four:
+// LDS = image 64 KB + ring 64 KB.  Same K order per output as convg_kernel: identical bits.
+#pragma once
+#include "convh_kernels.hpp"
+
+namespace fv {
+
+struct ConvRGeom {
+    static constexpr int C = 128, CG = 4, CB = 16, NFW = 4, NT = 512;
+    static constexpr int NTC = 128;                      // output columns per tile
+    static constexpr int NSTEP = CG;                     // K steps of 32 per chunk = weight stages per chunk
+    static constexpr int XROWS = NTC, XRP = NTC;         // image: [split half][8-channel block][XRP rows][8 halves]
+    static constexpr int XHALF = CB * XRP * 16;
+    static constexpr int XR = XROWS * CB / NT;           // (row, 8-channel block) conversion tasks per thread
+    static constexpr int NRAW = XR * 8;
+    static constexpr int STAGE_BYTES = 16384, RING = 4, AHEAD = 3;
+    static constexpr int WTILE = NSTEP * 8192;           // packed bytes of one (64-row tile, chunk): [step][8 KB]
+    static_assert(((CG - 1) * 4 * XRP + 16 * (NFW - 1)) * 16 + 16 < 65536, "ds_read immediate range");
+};
+
+// items [item0, hi_item) of the launch's one member: item = ((utterance * n_tiles) + column tile) * nrt + row pair
+__device__ __forceinline__ void convr_run(const PairParams& p, const PairMember& mb, int item0, int hi_item, float* smem,
+                                          int wave, int lane_in) {
+    typedef ConvRGeom G;
+    typedef __attribute__((address_space(3))) const f16x8 LdsH8;
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int tid = wave * 64 + lane;
+    float* const ring = smem + p.x_off;
+    char* const ximg = reinterpret_cast<char*>(smem + p.img_off);
+    const int n = lane & 15, kb = lane >> 4;
+    const int ws = wave >> 1, wn = wave & 1;             // row slab of 32, column group of 64
+    const int col0 = wn * (16 * G::NFW) + n;
+    const char* const bptr = ximg + (kb * G::XRP + col0) * 16;
+    // A: slot * 4096 + ((row tile * 4 + row sixteenth) * 2 + split half) * 256 floats; this wave: sixteenths 2 ws, 2 ws + 1
+    const float* const aptr = ring + (2 * ws) * 512 + lane * 4;
+    const int row0 = 32 * ws + 4 * kb;                   // + 16 h + i: row inside the 128-row tile
+
+    const int nch = p.nch, nrt = p.nmt / 2;              // chunks of 128 input channels (x's, then x2's); row pairs
+    const int spi = nch * G::NSTEP;                      // stages per item
+    const size_t ustride = (size_t)p.ctot * (size_t)p.T;
+    const size_t cstride = (size_t)G::C * (size_t)p.T;
+    const unsigned ubytes = (unsigned)p.ctot * (unsigned)p.T * 4u;
+    const unsigned t4 = (unsigned)p.T * 4u;
+    const unsigned pair_stride = (unsigned)(nch * G::WTILE);        // from a 64-row tile's image to the next one's
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(mb.w1, (unsigned)(p.nmt * nch * G::WTILE));
+    auto decode = [&](int it, int& b, int& nt, int& rt) {
+        rt = it % nrt;
+        const int q = it / nrt;
+        b = q / mb.n_tiles;
+        nt = q - b * mb.n_tiles;
+    };
+    // stage `lin` counted from the first stage of item `it` (it may lie in a later item): byte offset of its piece of the
+    // first 64-row tile of the pair, or kOutOfRange past the block's last item
+    auto stage_off = [&](int it, int lin) -> unsigned {
+        const int it2 = it + lin / spi, st = lin % spi;
+        return it2 < hi_item ? (unsigned)((it2 % nrt) * 2) * pair_stride + (unsigned)((st / G::NSTEP) * G::WTILE + (st % G::NSTEP) * 8192)
+                             : kOutOfRange;
+    };
+    auto dma_stage = [&](int slot, unsigned off) {
+        float* dst = ring + slot * (G::STAGE_BYTES / 4) + wave * 512;
+        const unsigned o = off == kOutOfRange ? kOutOfRange : off + (unsigned)(wave >> 2) * pair_stride + (unsigned)((wave & 3) * 2048 + lane * 16);
+        dma16(rw, dst, o);
+        dma16(rw, dst + 256, o == kOutOfRange ? kOutOfRange : o + 1024u);
+    };
+    // chunk c of the K range: the tensor it comes from and the slope of its on-chip activation
+    auto chunk_src = [&](int c, int bb) -> const float* {
+        return (c < nch / 2 ? mb.x : mb.x2) + bb * ustride + (c < nch / 2 ? c : c - nch / 2) * cstride;
+    };
+    auto chunk_slope = [&](int c) { return c >= nch / 2 ? 1.f : p.slope; };
+
+    int item = item0, chunk = 0;
+    int b, ntile, rt;
+    decode(item, b, ntile, rt);
+    float bad = 0.f;                                     // range guard (pairh_kernels.hpp range_note4)
+    ConvHRaw<G> raw;
+    convh_load_raw<G>(raw, chunk_src(0, b), p.T, ntile * G::NTC, tid, true);
+#pragma unroll
+    for (int st = 0; st < G::AHEAD; ++st) dma_stage(st, stage_off(item, st));
+    pair_wait_vm0();
+    if (!(p.dbg & 2)) convh_convert<G>(raw, ximg, chunk_slope(0), tid);
+    f32x4 hi[2][G::NFW], lo[2][G::NFW];                  // live across the chunks of an item
+    for (;;) {
+        const int t0 = ntile * G::NTC;
+        int nchunk = chunk + 1, nitem = item;
+        if (nchunk == nch) {
+            nchunk = 0;
+            nitem = item + 1;
+        }
+        const bool last = nchunk == 0;                   // the item's last chunk: the epilogue runs
+        const bool more = nitem < hi_item;               // there is a next (item, chunk)
+        int nb = b, nnt = ntile, nrt_ = rt;
+        if (more && last) decode(nitem, nb, nnt, nrt_);
+        if (chunk == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int f = 0; f < G::NFW; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f16x8 abuf[2][2][2], bbuf[2][G::NFW][2];
+
+        // ---- stage entry (stage = K step GS of this chunk, ring slot GS): its weights are in the slot for every wave;
+        // every wave holds the A operands of the stage before in registers, so that slot is free: request the stage three
+        // further on into it
+        auto entry = [&](auto GC) {
+            constexpr int GS = decltype(GC)::value;
+            {
+                // this stage's DMA was issued three entries ago; loads return in order: it has landed once at most as
+                // many loads are outstanding as were issued after it -- the DMAs of the two entries in between, plus
+                // the raw window when it was requested at one of them (entry 0 of this chunk)
+                constexpr bool raw_between = GS >= 1;
+                wait_vm<4 + (raw_between ? G::NRAW : 0)>();
+            }
+            pair_barrier();
+            dma_stage((GS + 3) & 3, stage_off(item, chunk * G::NSTEP + GS + 3));
+            if constexpr (GS == 0)
+                convh_load_raw<G>(raw, chunk_src(nchunk, nb), p.T, nnt * G::NTC, tid, more && !(p.dbg & 1));
+        };
+        auto fetch_a = [&](auto SC, f16x8 (&dst)[2][2]) {
+            constexpr int S = decltype(SC)::value;
+            LdsCF* a = lds_opaque(aptr + S * (G::STAGE_BYTES / 4));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                dst[h][0] = *reinterpret_cast<LdsH8*>(a + h * 512);
+                dst[h][1] = *reinterpret_cast<LdsH8*>(a + h * 512 + 256);
+            }
+        };
+        LdsCF* const bb = lds_opaque(reinterpret_cast<const float*>(bptr));
+        LdsCF* const bb2 = lds_opaque(reinterpret_cast<const float*>(bptr + G::XHALF));
+        auto fetch_b = [&](auto SC, f16x8 (&dst)[G::NFW][2]) {
+            constexpr int S = decltype(SC)::value;
+            constexpr int off = (S * 4 * G::XRP) * 4;
+#pragma unroll
+            for (int e = 0; e < G::NFW; ++e) {
+                dst[e][0] = *reinterpret_cast<LdsH8*>(bb + off + e * 64);
+                dst[e][1] = *reinterpret_cast<LdsH8*>(bb2 + off + e * 64);
+            }
+        };
+        entry(IntC<0>{});
+        fetch_a(IntC<0>{}, abuf[0]);
+        fetch_b(IntC<0>{}, bbuf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, G::NSTEP>([&](auto UC) {
+            constexpr int U = decltype(UC)::value;
+            if constexpr (U + 1 < G::NSTEP) {
+                entry(IntC<U + 1>{});
+                fetch_a(IntC<U + 1>{}, abuf[(U + 1) & 1]);
+                fetch_b(IntC<U + 1>{}, bbuf[(U + 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < G::NFW; ++e)
+                    hi[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[U & 1][h][0], bbuf[U & 1][e][0], hi[h][e], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < G::NFW; ++e)
+                    lo[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[U & 1][h][0], bbuf[U & 1][e][1], lo[h][e], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < G::NFW; ++e)
+                    lo[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[U & 1][h][1], bbuf[U & 1][e][0], lo[h][e], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // ---- end of the chunk: (the item's outputs,) then the image of the next window --------------------------
+        pair_barrier();                                  // every wave is done with the image
+        if (last) {
+            const int rowt = 128 * rt + row0;
+            const __amdgpu_buffer_rsrc_t rb = make_rsrc(mb.b1 ? mb.b1 : mb.w1, mb.b1 ? (unsigned)p.ctot * 4u : 0u);
+            const __amdgpu_buffer_rsrc_t rr = make_rsrc(mb.res ? mb.res + b * ustride : mb.w1, mb.res ? ubytes : 0u);
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.sub ? p.sub + (p.sub_batched ? b * ustride : 0) : mb.w1, p.sub ? ubytes : 0u);
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc(mb.y + b * ustride, ubytes);
+            const __amdgpu_buffer_rsrc_t ra = make_rsrc(mb.y_act ? mb.y_act + b * ustride : mb.y, mb.y_act ? ubytes : 0u);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float bv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[i] = buffer_load1(rb, (unsigned)(rowt + 16 * h + i) * 4u);
+#pragma unroll
+                for (int f = 0; f < G::NFW; ++f) {
+                    const int t = t0 + col0 + f * 16;
+                    const unsigned voff = t < p.T ? (unsigned)((rowt + 16 * h) * p.T + t) * 4u : kOutOfRange;
+                    float rv[4], sv[4], v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        rv[i] = buffer_load1s(rr, voff, (unsigned)i * t4);
+                        sv[i] = buffer_load1s(rs, voff, (unsigned)i * t4);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = (fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[i]) + rv[i];
+                    range_note4(bad, v[0], v[1], v[2], v[3], t < p.T);
+                    const unsigned vo = (p.dbg & 8) ? kOutOfRange : voff;
+                    if (p.sub != nullptr) {
+                        // the op carries an output offset (bias removal, basis_melgan.py:147-159): y2 = act(post(y)) - sub,
+                        // or y itself when there is no second output -- conv_kernels.hpp's epilogue rule
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float w = v[i];
+                            if (p.post == FV_POST_TANH) w = tanhf(w);
+                            else if (p.post == FV_POST_RELU) w = fmaxf(w, 0.f);
+                            const float a = (p.act_slope != 1.f ? act(w, p.act_slope) : w) - sv[i];
+                            if (mb.y_act) {
+                                buffer_store1s(ry, vo, (unsigned)i * t4, w);
+                                buffer_store1s(ra, vo, (unsigned)i * t4, a);
+                            } else {
+                                buffer_store1s(ry, vo, (unsigned)i * t4, a);
+                            }
+                        }
+                    } else {
+                        pair_store(p, mb.y, mb.y_act, p.ctot, b, rowt + 16 * h, t, t < p.T && !(p.dbg & 8), v, true);
+                    }
+                }
+            }
+        }
+        // the stores first, the conversion of the next window after them (convh_run_member)
+        if (more && !(p.dbg & 2)) convh_convert<G>(raw, ximg, chunk_slope(nchunk), tid);
+        if (!more) break;
+        item = nitem;
+        chunk = nchunk;
+        b = nb;
+        ntile = nnt;
+        rt = nrt_;
+    }
+    // the DMAs requested for a next item that does not exist wrote zeros; nothing is in flight past this point
+    pair_wait_vm0();
+    range_flag(p, bad);
+}
+
+// one 8-wave block per CU (128 KB of LDS), 2 waves per SIMD
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void convr_kernel(PairParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    PairParams q;
+    q.n_members = 1; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = 1.f;
+    q.act_slope = p.act_slope; q.post = p.post; q.x_off = p.x_off; q.img_off = p.img_off; q.dbg = p.dbg; q.trace = p.trace;
+    q.ctot = p.ctot; q.nch = p.nch; q.nmt = p.nmt; q.reflect = 0; q.guard = p.guard; q.sub = p.sub; q.sub_batched = p.sub_batched;
+    PairMember mb;
+    mb.x = p.m[0].x; mb.x2 = p.m[0].x2; mb.w1 = p.m[0].w1; mb.b1 = p.m[0].b1; mb.res = p.m[0].res; mb.add1 = nullptr;
+    mb.add2 = nullptr; mb.y = p.m[0].y; mb.y_act = p.m[0].y_act; mb.k = 1; mb.n_tiles = p.m[0].n_tiles;
+    const int n_items = p.m[0].n_items;
+    asm volatile("" ::"s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.act_slope), "s"(q.post), "s"(q.x_off), "s"(q.img_off),
+                 "s"(q.dbg), "s"(q.trace), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.guard), "s"(q.sub), "s"(q.sub_batched), "s"(mb.x), "s"(mb.x2), "s"(mb.w1),
+                 "s"(mb.b1), "s"(mb.res), "s"(mb.y), "s"(mb.y_act), "s"(mb.n_tiles), "s"(n_items));
+    // equal items: block b takes [b n / nblk, (b + 1) n / nblk) -- the row pairs of one column tile stay together
+    const int lo = (int)((long long)blockIdx.x * n_items / q.nblk), hi = (int)((long long)(blockIdx.x + 1) * n_items / q.nblk);
+    if (lo < hi) convr_run(q, mb, lo, hi, smem, wave, lane);
+}
+
+}  // namespace fv

@@ -319,7 +319,8 @@ def test_conv1d_split_f16_reflection_rejects():
 @pytest.fixture
 def tuning():
     """fv_tuning_set for the duration of a test (process-wide switches of the launchers: restored afterwards)."""
-    defaults = {"sched": 1, "sched_switch": 4, "convh_blocks": 0, "pair_blocks": 0, "pair128_unfused": 0}
+    defaults = {"sched": 1, "sched_switch": 4, "convh_blocks": 0, "pair_blocks": 0, "pair128_unfused": 0, "convg_rows64": -1,
+                "chain": 0}
     yield _native.tuning_set
     for k, v in defaults.items():
         _native.tuning_set(k, v)
@@ -649,6 +650,7 @@ def test_conv1x1_2src_split_f16_vs_oracle(case, tuning):
     ref = oo.conv1d(x, w1, None, pre_slope=0.2) + oo.conv1d(x2, w2, b)
     P = _native.pack_conv1x1_2src_split(_t(w1), _t(w2))
     guard = torch.zeros(1, dtype=torch.int32, device=_dev())
+    tuning("convg_rows64", 0)                          # 128-row tiles whatever the size (the default picks by item count)
     y = _native.conv1x1_2src_split_f16(_t(x), _t(x2), P, _t(b), pre_slope=0.2, guard=guard)
     assert tuple(y.shape) == ref.shape and _rel(y, ref) <= 4e-6
     twin = torch.empty_like(y)
@@ -664,6 +666,16 @@ def test_conv1x1_2src_split_f16_vs_oracle(case, tuning):
     if B > 1:
         one = _native.conv1x1_2src_split_f16(_t(x[1:2]), _t(x2[1:2]), P, _t(b), pre_slope=0.2)
         assert torch.equal(one, y[1:2])
+    # 128-row tiles (convr_kernel, the default) against 64-row tiles (convg_kernel): the same K order per output
+    tuning("convg_rows64", 1)
+    narrow = _native.conv1x1_2src_split_f16(_t(x), _t(x2), P, _t(b), pre_slope=0.2)
+    twin64 = torch.empty_like(y)
+    narrow2 = _native.conv1x1_2src_split_f16(_t(x), _t(x2), P, None, pre_slope=0.2, res=_t(res), post=_native.POST_RELU,
+                                             out_act=twin64, act_slope=0.1)
+    tuning("convg_rows64", -1)
+    auto = _native.conv1x1_2src_split_f16(_t(x), _t(x2), P, _t(b), pre_slope=0.2)
+    tuning("convg_rows64", 0)
+    assert torch.equal(narrow, y) and torch.equal(narrow2, y2) and torch.equal(twin64, twin) and torch.equal(auto, y)
     x2[0, 1, 0] = 3.0e5                                # the raw branch leaves the f16 range: guard
     _native.conv1x1_2src_split_f16(_t(x), _t(x2), P, _t(b), pre_slope=0.2, guard=guard)
     assert int(guard.item()) == 1

@@ -28,7 +28,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--only", type=int, default=None, help="index into CONFIGS (0-based): run just that one")
+    ap.add_argument("--tuning", default="", help='launcher switches "key=value,..." (fv_tuning_set) for an A/B')
     args = ap.parse_args()
+    for kv in filter(None, args.tuning.split(",")):
+        k, v = kv.split("=")
+        _native.tuning_set(k, int(v))
     dev = torch.device("cuda:0")
     for idx, (label, name, path, B, T) in enumerate(CONFIGS):
         if args.only is not None and idx != args.only:
