@@ -127,6 +127,15 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     int img_bytes = 0;
     double flops = 0, bytes = 0;
     long long items = 0;
+    const int cus = device_cu_count();
+    // 128 channels and more: 128-row tiles (convs_kernel, convr_kernels.hpp -- a chunk's window is converted once for
+    // both 64-row tiles) when the launch has items enough for the chip that way (as launch_convg); Tuning::convh_rows64
+    bool wide = false;
+    if (C >= 128) {
+        long long w = 0;
+        for (int i = 0; i < p.n_members; ++i) w += (long long)((p.T + 127) / 128) * p.B * (C / 128);
+        wide = tuning().convh_rows64 < 0 ? w * 10 >= 7LL * cus : !tuning().convh_rows64;
+    }
     for (int i = 0; i < p.n_members; ++i) {
         PairMember& mb = p.m[i];
         if (mb.k != 11 && mb.k != 7 && mb.k != 3) return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: %d taps (3, 7 or 11)", mb.k);
@@ -139,7 +148,7 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
             return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: packed weights must be 16-byte aligned");
         const ConvHShape g = convh_shape(C, mb.k, dil);
         mb.n_tiles = (p.T + g.NTC - 1) / g.NTC;
-        mb.n_items = mb.n_tiles * p.B * g.NMT;
+        mb.n_items = mb.n_tiles * p.B * (wide ? g.NMT / 2 : g.NMT);
         p.ctot = C;
         p.nch = g.NCH;
         p.nmt = g.NMT;
@@ -159,7 +168,6 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     p.bias_off = 0;                    // (biases are read from global memory in the epilogue)
     const size_t lds = floats * 4;
     if (lds > 160 * 1024) return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: %zu bytes of LDS", lds);
-    const int cus = device_cu_count();
     long long nblk = tuning().convh_blocks > 0 ? tuning().convh_blocks : cus;     // one 8-wave block per CU
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
@@ -167,7 +175,8 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     p.dbg = tuning().pair_dbg;
     p.trace = reinterpret_cast<unsigned long long*>(tuning().trace_ptr);
     profile_begin(s);
-    const int rc = C >= 128 ? launch_convh_geom<4, 2>(p, dil, lds, s) : launch_convh_geom<2, 2>(p, dil, lds, s);
+    const int rc = wide ? launch_convs_geom(p, dil, lds, s)
+                 : C >= 128 ? launch_convh_geom<4, 2>(p, dil, lds, s) : launch_convh_geom<2, 2>(p, dil, lds, s);
     profile_end(s, C == 64 ? FV_KERNEL_CONVH64 : FV_KERNEL_CONVH128, flops, bytes);
     return rc;
 }
@@ -265,7 +274,7 @@ int launch_convg(PairParams p, int C, hipStream_t s) {
     p.nblk = (int)nblk;
     p.sched_on = 0;
     p.dbg = tuning().pair_dbg;
-    p.trace = nullptr;
+    p.trace = reinterpret_cast<unsigned long long*>(tuning().trace_ptr);
     profile_begin(s);
     const int rc = wide ? launch_convr_geom(p, lds, s) : launch_convg_geom(p, lds, s);
     profile_end(s, FV_KERNEL_CONVG, 2.0 * p.B * (double)C * 2 * C * p.T,

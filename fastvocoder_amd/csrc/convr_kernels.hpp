@@ -15,23 +15,33 @@
 
 namespace fv {
 
+// TWO: the two-source 1x1 conv (KT = 1; K range [lrelu(x); x2]); else a 'same' conv with KT taps of dilation DIL --
+// convh_kernel's convs on 128-row tiles: the (halo'd) window of a 128-channel chunk is converted once for KT * 4 K steps
+// of BOTH 64-row tiles (ResidualStack's dilated conv, reflection-padded; HiFi-GAN large's 256 / 512-channel ResBlocks)
+template <int KT_, int DIL_, bool TWO_ = false>
 struct ConvRGeom {
+    static constexpr int KT = KT_, DIL = DIL_;
+    static constexpr bool TWO = TWO_;
     static constexpr int C = 128, CG = 4, CB = 16, NFW = 4, NT = 512;
     static constexpr int NTC = 128;                      // output columns per tile
-    static constexpr int NSTEP = CG;                     // K steps of 32 per chunk = weight stages per chunk
-    static constexpr int XROWS = NTC, XRP = NTC;         // image: [split half][8-channel block][XRP rows][8 halves]
+    static constexpr int NSTEP = KT * CG;                // K steps of 32 per chunk = weight stages per chunk (tap-major)
+    static constexpr int P = (KT - 1) * DIL / 2;
+    static constexpr int XROWS = (NTC + (KT - 1) * DIL + 3) / 4 * 4;
+    static constexpr int XRP = (XROWS + 15) / 16 * 16;   // image: [split half][8-channel block][XRP rows][8 halves]
     static constexpr int XHALF = CB * XRP * 16;
-    static constexpr int XR = XROWS * CB / NT;           // (row, 8-channel block) conversion tasks per thread
+    static constexpr int XR = (XROWS * CB + NT - 1) / NT;   // (row, 8-channel block) conversion tasks per thread
     static constexpr int NRAW = XR * 8;
     static constexpr int STAGE_BYTES = 16384, RING = 4, AHEAD = 3;
     static constexpr int WTILE = NSTEP * 8192;           // packed bytes of one (64-row tile, chunk): [step][8 KB]
-    static_assert(((CG - 1) * 4 * XRP + 16 * (NFW - 1)) * 16 + 16 < 65536, "ds_read immediate range");
+    static constexpr int RAWST = NSTEP >= 8 ? NSTEP - 6 : 0;   // stage entry at which the next window is requested
+    static_assert(NSTEP % RING == 0, "ring slot = step & 3");
+    static_assert(((CG - 1) * 4 * XRP + (KT - 1) * DIL + 16 * (NFW - 1)) * 16 + 16 < 65536, "ds_read immediate range");
 };
 
 // items [item0, hi_item) of the launch's one member: item = ((utterance * n_tiles) + column tile) * nrt + row pair
+template <class G>
 __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember& mb, int item0, int hi_item, float* smem,
-                                          int wave, int lane_in) {
-    typedef ConvRGeom G;
+                                          int wave, int lane_in, bool first) {
     typedef __attribute__((address_space(3))) const f16x8 LdsH8;
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
@@ -46,7 +56,7 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
     const float* const aptr = ring + (2 * ws) * 512 + lane * 4;
     const int row0 = 32 * ws + 4 * kb;                   // + 16 h + i: row inside the 128-row tile
 
-    const int nch = p.nch, nrt = p.nmt / 2;              // chunks of 128 input channels (x's, then x2's); row pairs
+    const int nch = p.nch, nrt = p.nmt / 2;              // chunks of 128 input channels (TWO: x's, then x2's); row pairs
     const int spi = nch * G::NSTEP;                      // stages per item
     const size_t ustride = (size_t)p.ctot * (size_t)p.T;
     const size_t cstride = (size_t)G::C * (size_t)p.T;
@@ -75,22 +85,25 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
     };
     // chunk c of the K range: the tensor it comes from and the slope of its on-chip activation
     auto chunk_src = [&](int c, int bb) -> const float* {
-        return (c < nch / 2 ? mb.x : mb.x2) + bb * ustride + (c < nch / 2 ? c : c - nch / 2) * cstride;
+        if constexpr (G::TWO) return (c < nch / 2 ? mb.x : mb.x2) + bb * ustride + (c < nch / 2 ? c : c - nch / 2) * cstride;
+        else return mb.x + bb * ustride + c * cstride;
     };
-    auto chunk_slope = [&](int c) { return c >= nch / 2 ? 1.f : p.slope; };
+    auto chunk_slope = [&](int c) { return G::TWO && c >= nch / 2 ? 1.f : p.slope; };
 
     int item = item0, chunk = 0;
     int b, ntile, rt;
     decode(item, b, ntile, rt);
+    if (!first) pair_barrier();                          // everybody is done with the previous member's LDS
     float bad = 0.f;                                     // range guard (pairh_kernels.hpp range_note4)
     ConvHRaw<G> raw;
-    convh_load_raw<G>(raw, chunk_src(0, b), p.T, ntile * G::NTC, tid, true);
+    convh_load_raw<G>(raw, chunk_src(0, b), p.T, ntile * G::NTC - G::P, tid, true, p.reflect != 0);
 #pragma unroll
     for (int st = 0; st < G::AHEAD; ++st) dma_stage(st, stage_off(item, st));
     pair_wait_vm0();
     if (!(p.dbg & 2)) convh_convert<G>(raw, ximg, chunk_slope(0), tid);
     f32x4 hi[2][G::NFW], lo[2][G::NFW];                  // live across the chunks of an item
-    for (;;) {
+    for (int it = 0;; ++it) {
+        pair_stamp(p, 8, wave, lane, it, 0);             // (tuning aid, -DFV_PAIR_TRACE: tools/convr_trace.py)
         const int t0 = ntile * G::NTC;
         int nchunk = chunk + 1, nitem = item;
         if (nchunk == nch) {
@@ -118,17 +131,18 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
                 // this stage's DMA was issued three entries ago; loads return in order: it has landed once at most as
                 // many loads are outstanding as were issued after it -- the DMAs of the two entries in between, plus
                 // the raw window when it was requested at one of them (entry 0 of this chunk)
-                constexpr bool raw_between = GS >= 1;
+                // (an entry of the chunk before does not count: its window was converted before this chunk began)
+                constexpr bool raw_between = G::RAWST <= GS - 1 && G::RAWST >= (GS >= 3 ? GS - 3 : 0);
                 wait_vm<4 + (raw_between ? G::NRAW : 0)>();
             }
             pair_barrier();
             dma_stage((GS + 3) & 3, stage_off(item, chunk * G::NSTEP + GS + 3));
-            if constexpr (GS == 0)
-                convh_load_raw<G>(raw, chunk_src(nchunk, nb), p.T, nnt * G::NTC, tid, more && !(p.dbg & 1));
+            if constexpr (GS == G::RAWST)
+                convh_load_raw<G>(raw, chunk_src(nchunk, nb), p.T, nnt * G::NTC - G::P, tid, more && !(p.dbg & 1), p.reflect != 0);
         };
         auto fetch_a = [&](auto SC, f16x8 (&dst)[2][2]) {
             constexpr int S = decltype(SC)::value;
-            LdsCF* a = lds_opaque(aptr + S * (G::STAGE_BYTES / 4));
+            LdsCF* a = lds_opaque(aptr + (S & 3) * (G::STAGE_BYTES / 4));
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 dst[h][0] = *reinterpret_cast<LdsH8*>(a + h * 512);
@@ -139,7 +153,8 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
         LdsCF* const bb2 = lds_opaque(reinterpret_cast<const float*>(bptr + G::XHALF));
         auto fetch_b = [&](auto SC, f16x8 (&dst)[G::NFW][2]) {
             constexpr int S = decltype(SC)::value;
-            constexpr int off = (S * 4 * G::XRP) * 4;
+            constexpr int tap = S / G::CG, cg = S % G::CG;
+            constexpr int off = (cg * 4 * G::XRP + tap * G::DIL) * 4;
 #pragma unroll
             for (int e = 0; e < G::NFW; ++e) {
                 dst[e][0] = *reinterpret_cast<LdsH8*>(bb + off + e * 64);
@@ -147,6 +162,7 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
             }
         };
         entry(IntC<0>{});
+        pair_stamp(p, 8, wave, lane, it, 1);
         fetch_a(IntC<0>{}, abuf[0]);
         fetch_b(IntC<0>{}, bbuf[0]);
         __builtin_amdgcn_sched_barrier(0);
@@ -176,7 +192,9 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
             __builtin_amdgcn_sched_barrier(0);
         });
         // ---- end of the chunk: (the item's outputs,) then the image of the next window --------------------------
+        pair_stamp(p, 8, wave, lane, it, 2);
         pair_barrier();                                  // every wave is done with the image
+        pair_stamp(p, 8, wave, lane, it, 3);
         if (last) {
             const int rowt = 128 * rt + row0;
             const __amdgpu_buffer_rsrc_t rb = make_rsrc(mb.b1 ? mb.b1 : mb.w1, mb.b1 ? (unsigned)p.ctot * 4u : 0u);
@@ -201,9 +219,22 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = (fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[i]) + rv[i];
+                    if (!G::TWO && mb.add1 != nullptr) {
+                        // the last launch of an MRF stage: ((own + add1) + add2), the reference's order (convh_run_member)
+                        const __amdgpu_buffer_rsrc_t r1 = make_rsrc(mb.add1 + b * ustride, ubytes);
+                        const __amdgpu_buffer_rsrc_t r2 = make_rsrc(mb.add2 ? mb.add2 + b * ustride : mb.add1, mb.add2 ? ubytes : 0u);
+                        float a1[4], a2[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            a1[i] = buffer_load1s(r1, voff, (unsigned)i * t4);
+                            a2[i] = buffer_load1s(r2, voff, (unsigned)i * t4);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = (v[i] + a1[i]) + a2[i];
+                    }
                     range_note4(bad, v[0], v[1], v[2], v[3], t < p.T);
                     const unsigned vo = (p.dbg & 8) ? kOutOfRange : voff;
-                    if (p.sub != nullptr) {
+                    if (G::TWO && p.sub != nullptr) {
                         // the op carries an output offset (bias removal, basis_melgan.py:147-159): y2 = act(post(y)) - sub,
                         // or y itself when there is no second output -- conv_kernels.hpp's epilogue rule
 #pragma unroll
@@ -220,13 +251,22 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
                             }
                         }
                     } else {
-                        pair_store(p, mb.y, mb.y_act, p.ctot, b, rowt + 16 * h, t, t < p.T && !(p.dbg & 8), v, true);
+                        pair_store(p, mb.y, mb.y_act, p.ctot, b, rowt + 16 * h, t, t < p.T && !(p.dbg & 8), v,
+                                   G::TWO || mb.add1 != nullptr);
                     }
                 }
             }
         }
+        pair_stamp(p, 8, wave, lane, it, 4);
         // the stores first, the conversion of the next window after them (convh_run_member)
-        if (more && !(p.dbg & 2)) convh_convert<G>(raw, ximg, chunk_slope(nchunk), tid);
+        if (more && !(p.dbg & 2)) {
+#ifdef FV_PAIR_TRACE
+            pair_wait_vm0();                             // (the raw window: its own stamp)
+            pair_stamp(p, 8, wave, lane, it, 5);
+#endif
+            convh_convert<G>(raw, ximg, chunk_slope(nchunk), tid);
+        }
+        pair_stamp(p, 8, wave, lane, it, 6);
         if (!more) break;
         item = nitem;
         chunk = nchunk;
@@ -257,7 +297,66 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                  "s"(mb.b1), "s"(mb.res), "s"(mb.y), "s"(mb.y_act), "s"(mb.n_tiles), "s"(n_items));
     // equal items: block b takes [b n / nblk, (b + 1) n / nblk) -- the row pairs of one column tile stay together
     const int lo = (int)((long long)blockIdx.x * n_items / q.nblk), hi = (int)((long long)(blockIdx.x + 1) * n_items / q.nblk);
-    if (lo < hi) convr_run(q, mb, lo, hi, smem, wave, lane);
+    if (lo < hi) convr_run<ConvRGeom<1, 1, true>>(q, mb, lo, hi, smem, wave, lane, true);
+}
+
+// 'same' convs with KT taps (3 / 7 / 11) of dilation DIL, C = 128, 256 or 512 channels in and out, on 128-row tiles: the
+// members of a launch as in convh_kernel (contiguous cost-weighted shares, or the host's block schedule)
+template <int DIL>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void convs_kernel(PairParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    PairParams q;
+    q.n_members = p.n_members; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = p.out_div;
+    q.act_slope = p.act_slope; q.post = p.post; q.x_off = p.x_off; q.img_off = p.img_off; q.dbg = p.dbg; q.trace = p.trace;
+    q.ctot = p.ctot; q.nch = p.nch; q.nmt = p.nmt; q.reflect = p.reflect; q.guard = p.guard; q.sub = nullptr; q.sub_batched = 0;
+    int n_items[3], cost[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { n_items[m] = p.m[m].n_items; cost[m] = p.m[m].cost; }
+    asm volatile("" ::"s"(q.n_members), "s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.out_div), "s"(q.act_slope),
+                 "s"(q.post), "s"(q.x_off), "s"(q.img_off), "s"(q.dbg), "s"(q.trace), "s"(n_items[0]), "s"(n_items[1]),
+                 "s"(n_items[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.reflect),
+                 "s"(q.guard));
+    const bool sched = p.sched_on != 0;
+    int slo[3] = {0, 0, 0}, shi[3] = {0, 0, 0};
+    if (sched) {
+        const unsigned w0 = p.sched[2 * blockIdx.x], w1 = p.sched[2 * blockIdx.x + 1];
+        slo[0] = (int)(w0 & 2047u);         shi[0] = slo[0] + (int)((w0 >> 11) & 31u);
+        slo[1] = (int)((w0 >> 16) & 2047u); shi[1] = slo[1] + (int)(w0 >> 27);
+        slo[2] = (int)(w1 & 2047u);         shi[2] = slo[2] + (int)((w1 >> 11) & 31u);
+        asm volatile("" ::"s"(slo[0]), "s"(shi[0]), "s"(slo[1]), "s"(shi[1]), "s"(slo[2]), "s"(shi[2]));
+    }
+    long long total = 0;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_items[m] * cost[m] : 0;
+    long long base = 0;
+    bool first = true;
+    for (int m = 0; m < q.n_members; ++m) {
+        const int n = m == 0 ? n_items[0] : m == 1 ? n_items[1] : n_items[2];
+        const int cm = m == 0 ? cost[0] : m == 1 ? cost[1] : cost[2];
+        int lo, hi;
+        if (sched) {
+            lo = m == 0 ? slo[0] : m == 1 ? slo[1] : slo[2];
+            hi = m == 0 ? shi[0] : m == 1 ? shi[1] : shi[2];
+        } else {
+            lo = pair_share(blockIdx.x, total, base, cm, n, q.nblk);
+            hi = pair_share(blockIdx.x + 1, total, base, cm, n, q.nblk);
+        }
+        base += (long long)n * cm;
+        if (lo >= hi) continue;
+        PairMember mb;
+        mb.x = p.m[m].x; mb.x2 = nullptr; mb.w1 = p.m[m].w1; mb.b1 = p.m[m].b1; mb.res = p.m[m].res; mb.add1 = p.m[m].add1;
+        mb.add2 = p.m[m].add2; mb.y = p.m[m].y; mb.y_act = p.m[m].y_act; mb.k = p.m[m].k; mb.n_tiles = p.m[m].n_tiles;
+        asm volatile("" ::"s"(mb.x), "s"(mb.w1), "s"(mb.b1), "s"(mb.res), "s"(mb.add1), "s"(mb.add2), "s"(mb.y), "s"(mb.y_act),
+                     "s"(mb.k), "s"(mb.n_tiles));
+        if constexpr (DIL > 5)                            // (dilation 9 is MelGAN's third ResidualStack layer: 3 taps only)
+            convr_run<ConvRGeom<3, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
+        else if (mb.k == 11) convr_run<ConvRGeom<11, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
+        else if (mb.k == 7) convr_run<ConvRGeom<7, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
+        else convr_run<ConvRGeom<3, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
+        first = false;
+    }
 }
 
 }  // namespace fv

@@ -277,6 +277,48 @@ def test_conv1d_split_f16_vs_oracle(case):
         _native.conv1d_split_f16([torch.zeros((1, 32, 16), device=_dev())], P[:1], [None], [ks[0]], dil)
 
 
+@pytest.mark.parametrize("case", [(1, 128, 260, 5, (11, 7, 3)), (3, 128, 129, 1, (11,)), (1, 256, 300, 5, (11, 3)), (2, 512, 140, 3, (7,)),
+                                  (2, 256, 1000, 9, (3,)), (1, 512, 257, 1, (3, 7, 11)), (1, 128, 1, 3, (3,))],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_conv1d_split_f16_on_128_row_tiles_gives_the_same_bits(case, tuning):
+    """The split-f16 convs at 128 channels and more on 128-row tiles (csrc/convr_kernels.hpp convs_kernel: a chunk's window
+    is converted once for both 64-row tiles) against the 64-row tiles of convh_kernel: the same K order per output, so
+    identical bits -- zero and reflection padding, every epilogue form, few persistent blocks, and the oracle."""
+    B, C, T, dil, ks = case
+    rng = np.random.RandomState(7 * T + C + dil)
+    n = len(ks)
+    xs = [rng.randn(B, C, T).astype(np.float32) for _ in ks]
+    ws = [(rng.randn(C, C, k) / np.sqrt(C * k)).astype(np.float32) for k in ks]
+    X, P = [_t(x) for x in xs], [_native.pack_pair(_t(w), SPLIT) for w in ws]
+    Bi = [_t(rng.randn(C).astype(np.float32)) for _ in ks]
+    R, A1, A2 = [[_t(rng.randn(B, C, T).astype(np.float32)) for _ in ks] for _ in range(3)]
+    reflect = (max(ks) - 1) // 2 * dil < T
+
+    def forms():
+        out = [_native.conv1d_split_f16(X, P, Bi, list(ks), dil, pre_slope=0.1)]
+        acts = [torch.empty_like(x) for x in X]
+        out.append(_native.conv1d_split_f16(X, P, Bi, list(ks), dil, pre_slope=0.1, res=R, add1=A1, add2=A2, out_div=3.0,
+                                            act_slope=0.01, outs_act=acts))
+        out.append(acts)
+        out.append(_native.conv1d_split_f16(X, P, [None] * n, list(ks), dil, pre_slope=0.1, add1=A1, out_div=2.0,
+                                            post=_native.POST_TANH))
+        if reflect:
+            out.append(_native.conv1d_split_f16(X, P, Bi, list(ks), dil, pre_slope=0.2, pad_mode=_native.PAD_REFLECT,
+                                                act_slope=0.2))
+        return [t.clone() for ts in out for t in ts]
+
+    tuning("convh_rows64", 1)
+    narrow = forms()
+    tuning("convh_rows64", 0)
+    wide = forms()
+    tuning("convh_blocks", 3)
+    few = forms()
+    tuning("convh_blocks", 0)
+    assert all(torch.equal(a, b) for a, b in zip(narrow, wide)) and all(torch.equal(a, b) for a, b in zip(wide, few))
+    for y, x, w, b, k in zip(wide[:n], xs, ws, Bi, ks):
+        assert _rel(y, oo.conv1d(x, w, b.cpu().numpy(), dil=dil, pad=(k - 1) * dil // 2, pre_slope=0.1)) <= 4e-6
+
+
 @pytest.mark.parametrize("case", [(2, 64, 300, 9, (3,)), (1, 128, 130, 9, (3,)), (2, 256, 257, 3, (3,)), (1, 64, 12, 1, (3, 7)),
                                   (1, 512, 50, 9, (3,)), (3, 128, 10, 9, (3,)), (1, 64, 128, 5, (11, 3))],
                          ids=lambda c: "x".join(str(v) for v in c))
@@ -320,7 +362,7 @@ def test_conv1d_split_f16_reflection_rejects():
 def tuning():
     """fv_tuning_set for the duration of a test (process-wide switches of the launchers: restored afterwards)."""
     defaults = {"sched": 1, "sched_switch": 4, "convh_blocks": 0, "pair_blocks": 0, "pair128_unfused": 0, "convg_rows64": -1,
-                "chain": 0}
+                "convh_rows64": -1, "chain": 0}
     yield _native.tuning_set
     for k, v in defaults.items():
         _native.tuning_set(k, v)

@@ -42,6 +42,8 @@ def main():
         m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(name, cfg).items()})
         m = m.to(dev).eval()
         m.remove_weight_norm()
+        if "pair_dbg" in args.tuning:
+            m.range_guard = "off"        # (ablation switches give wrong values: timing only)
         mel = torch.from_numpy(seeded_mel(T, seed=1, batch=B)).to(dev)
         if name == "multiband-hifigan":
             fn = lambda: m.synthesize_batch(mel)
