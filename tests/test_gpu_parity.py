@@ -918,3 +918,33 @@ def test_chained_stage_launch_gives_the_same_bits():
             assert not m.check_range() and not m._fv_overflow
     finally:
         _native.tuning_set("chain", 0)
+
+
+@pytest.mark.parametrize("name,path", [("basis-melgan", "conf/basis-melgan/light.yaml"), ("melgan", "conf/melgan/original.yaml"),
+                                       ("hifigan", "conf/hifigan/large.yaml")], ids=["basis", "melgan", "hifigan-large"])
+def test_128_row_tiles_give_the_same_waveform_bits(name, path):
+    """The launchers pick 128-row tiles (csrc/convr_kernels.hpp: convr_kernel for ResidualStack's 1x1 + skip GEMM,
+    convs_kernel for the convs at 128+ channels) for launches that fill the chip and 64-row tiles otherwise; both give
+    identical bits, so whole generators do too whichever is forced: forward, the bias-removal flow (the output offset of
+    the GEMM's epilogue), and a batch."""
+    cfg = cases.load_conf(path)
+    m, _ = _model(name, cfg, seed=0)
+    mel = seeded_mel(40, seed=9)
+    x = torch.from_numpy(seeded_mel(33, seed=8, batch=2)).to(_dev())
+    outs = []
+    try:
+        for rows64 in (1, 0):
+            _native.tuning_set("convg_rows64", rows64)
+            _native.tuning_set("convh_rows64", rows64)
+            m.invalidate_plans()
+            with torch.no_grad():
+                bias = m.inference(np.zeros_like(mel)).clone()
+                est, rem = m.inference_minus(mel, bias)
+                y = m(x)
+                ys = (y,) if isinstance(y, torch.Tensor) else tuple(y)
+                outs.append((bias, est.clone(), rem.clone()) + tuple(t.clone() for t in ys))
+    finally:
+        _native.tuning_set("convg_rows64", -1)
+        _native.tuning_set("convh_rows64", -1)
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    assert not m.check_range()
