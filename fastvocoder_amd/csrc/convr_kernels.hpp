@@ -121,6 +121,8 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
                 for (int f = 0; f < G::NFW; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         f16x8 abuf[2][2][2], bbuf[2][G::NFW][2];
+        float bv[2][4];                                  // the item's bias: requested in front of the last step's MFMAs (both
+                                                         // operand queues' other halves are dead there: no register cost)
 
         // ---- stage entry (stage = K step GS of this chunk, ring slot GS): its weights are in the slot for every wave;
         // every wave holds the A operands of the stage before in registers, so that slot is free: request the stage three
@@ -172,6 +174,13 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
                 entry(IntC<U + 1>{});
                 fetch_a(IntC<U + 1>{}, abuf[(U + 1) & 1]);
                 fetch_b(IntC<U + 1>{}, bbuf[(U + 1) & 1]);
+            } else {
+                // (consumed in the epilogue below, before the next stage entry: the entries' wait counts do not see it)
+                const __amdgpu_buffer_rsrc_t rb = make_rsrc(mb.b1 ? mb.b1 : mb.w1, mb.b1 && last ? (unsigned)p.ctot * 4u : 0u);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bv[h][i] = buffer_load1(rb, (unsigned)(128 * rt + row0 + 16 * h + i) * 4u);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -197,28 +206,28 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
         pair_stamp(p, 8, wave, lane, it, 3);
         if (last) {
             const int rowt = 128 * rt + row0;
-            const __amdgpu_buffer_rsrc_t rb = make_rsrc(mb.b1 ? mb.b1 : mb.w1, mb.b1 ? (unsigned)p.ctot * 4u : 0u);
             const __amdgpu_buffer_rsrc_t rr = make_rsrc(mb.res ? mb.res + b * ustride : mb.w1, mb.res ? ubytes : 0u);
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.sub ? p.sub + (p.sub_batched ? b * ustride : 0) : mb.w1, p.sub ? ubytes : 0u);
             const __amdgpu_buffer_rsrc_t ry = make_rsrc(mb.y + b * ustride, ubytes);
             const __amdgpu_buffer_rsrc_t ra = make_rsrc(mb.y_act ? mb.y_act + b * ustride : mb.y, mb.y_act ? ubytes : 0u);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                float bv[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) bv[i] = buffer_load1(rb, (unsigned)(rowt + 16 * h + i) * 4u);
 #pragma unroll
                 for (int f = 0; f < G::NFW; ++f) {
                     const int t = t0 + col0 + f * 16;
                     const unsigned voff = t < p.T ? (unsigned)((rowt + 16 * h) * p.T + t) * 4u : kOutOfRange;
-                    float rv[4], sv[4], v[4];
+                    float rv[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
+                    // (uniform branches: a launch without residual / offset does not wait for loads that return zeros)
+                    if (mb.res != nullptr) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        rv[i] = buffer_load1s(rr, voff, (unsigned)i * t4);
-                        sv[i] = buffer_load1s(rs, voff, (unsigned)i * t4);
+                        for (int i = 0; i < 4; ++i) rv[i] = buffer_load1s(rr, voff, (unsigned)i * t4);
+                    }
+                    if (G::TWO && p.sub != nullptr) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sv[i] = buffer_load1s(rs, voff, (unsigned)i * t4);
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = (fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[i]) + rv[i];
+                    for (int i = 0; i < 4; ++i) v[i] = (fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[h][i]) + rv[i];
                     if (!G::TWO && mb.add1 != nullptr) {
                         // the last launch of an MRF stage: ((own + add1) + add2), the reference's order (convh_run_member)
                         const __amdgpu_buffer_rsrc_t r1 = make_rsrc(mb.add1 + b * ustride, ubytes);
