@@ -35,7 +35,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int dil = c.dil[ph];
         // this block's share of the phase (chain_schedule, convh_launch.hip): per member lo | count << 20, word 3: bit 0 =
         // the phase runs from the last item down
-        const unsigned* tab = c.sched + ((size_t)ph * gridDim.x + blockIdx.x) * 4;
+        const unsigned* tab = c.sched + ((size_t)ph * gridDim.x + xcd_remap((int)blockIdx.x, (int)gridDim.x)) * 4;
         const unsigned w0 = tab[0], w1 = tab[1], w2 = tab[2], w3 = tab[3];
         const int dir = (w3 & 1u) ? -1 : 1;
 #ifdef FV_PAIR_TRACE

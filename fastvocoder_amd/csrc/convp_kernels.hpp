@@ -361,7 +361,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int slo[3] = {0, 0, 0}, shi[3] = {0, 0, 0};
     if (sched) {
         // two words of the kernel arguments per block: (lo : 11, count : 5) of member 0 | member 1 << 16, member 2
-        const unsigned w0 = p.sched[2 * blockIdx.x], w1 = p.sched[2 * blockIdx.x + 1];
+        const unsigned w0 = p.sched[2 * xcd_remap((int)blockIdx.x, (int)gridDim.x)], w1 = p.sched[2 * xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1];
         slo[0] = (int)(w0 & 2047u);         shi[0] = slo[0] + (int)((w0 >> 11) & 31u);
         slo[1] = (int)((w0 >> 16) & 2047u); shi[1] = slo[1] + (int)(w0 >> 27);
         slo[2] = (int)(w1 & 2047u);         shi[2] = slo[2] + (int)((w1 >> 11) & 31u);
@@ -380,8 +380,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             lo = m == 0 ? slo[0] : m == 1 ? slo[1] : slo[2];
             hi = m == 0 ? shi[0] : m == 1 ? shi[1] : shi[2];
         } else {
-            lo = pair_share(blockIdx.x, total, base, cm, n, q.nblk);
-            hi = pair_share(blockIdx.x + 1, total, base, cm, n, q.nblk);
+            lo = pair_share(xcd_remap((int)blockIdx.x, (int)gridDim.x), total, base, cm, n, q.nblk);
+            hi = pair_share(xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1, total, base, cm, n, q.nblk);
         }
         base += (long long)n * cm;
         if (lo >= hi) continue;

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                  "s"(q.dbg), "s"(q.trace), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.guard), "s"(q.sub), "s"(q.sub_batched), "s"(mb.x), "s"(mb.x2), "s"(mb.w1),
                  "s"(mb.b1), "s"(mb.res), "s"(mb.y), "s"(mb.y_act), "s"(mb.n_tiles), "s"(n_items));
     // equal items: block b takes [b n / nblk, (b + 1) n / nblk) -- the row pairs of one column tile stay together
-    const int lo = (int)((long long)blockIdx.x * n_items / q.nblk), hi = (int)((long long)(blockIdx.x + 1) * n_items / q.nblk);
+    const int lo = (int)((long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * n_items / q.nblk), hi = (int)((long long)(xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1) * n_items / q.nblk);
     if (lo < hi) convr_run<ConvRGeom<1, 1, true>>(q, mb, lo, hi, smem, wave, lane, true);
 }
 
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bool sched = p.sched_on != 0;
     int slo[3] = {0, 0, 0}, shi[3] = {0, 0, 0};
     if (sched) {
-        const unsigned w0 = p.sched[2 * blockIdx.x], w1 = p.sched[2 * blockIdx.x + 1];
+        const unsigned w0 = p.sched[2 * xcd_remap((int)blockIdx.x, (int)gridDim.x)], w1 = p.sched[2 * xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1];
         slo[0] = (int)(w0 & 2047u);         shi[0] = slo[0] + (int)((w0 >> 11) & 31u);
         slo[1] = (int)((w0 >> 16) & 2047u); shi[1] = slo[1] + (int)(w0 >> 27);
         slo[2] = (int)(w1 & 2047u);         shi[2] = slo[2] + (int)((w1 >> 11) & 31u);
@@ -349,8 +349,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             lo = m == 0 ? slo[0] : m == 1 ? slo[1] : slo[2];
             hi = m == 0 ? shi[0] : m == 1 ? shi[1] : shi[2];
         } else {
-            lo = pair_share(blockIdx.x, total, base, cm, n, q.nblk);
-            hi = pair_share(blockIdx.x + 1, total, base, cm, n, q.nblk);
+            lo = pair_share(xcd_remap((int)blockIdx.x, (int)gridDim.x), total, base, cm, n, q.nblk);
+            hi = pair_share(xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1, total, base, cm, n, q.nblk);
         }
         base += (long long)n * cm;
         if (lo >= hi) continue;

@@ -478,8 +478,8 @@ __global__ __launch_bounds__(64 * MH * NG) FV_PAIR_WAVES void pair_kernel(PairPa
     bool first = true;
     for (int m = 0; m < p.n_members; ++m) {
         const int n = p.m[m].n_tiles * p.B;
-        const int lo = pair_share(blockIdx.x, total, base, p.m[m].cost, n, p.nblk);
-        const int hi = pair_share(blockIdx.x + 1, total, base, p.m[m].cost, n, p.nblk);
+        const int lo = pair_share(xcd_remap((int)blockIdx.x, (int)gridDim.x), total, base, p.m[m].cost, n, p.nblk);
+        const int hi = pair_share(xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1, total, base, p.m[m].cost, n, p.nblk);
         base += (long long)n * p.m[m].cost;
         if (lo >= hi) continue;
         pair_run_any<MH, NF, NG, DIL>(p, m, lo, hi, smem, wave, lane, tid, first);
@@ -545,8 +545,8 @@ __global__ __launch_bounds__(64 * MH * NG) FV_PAIR_WAVES void pair_sum_kernel(Pa
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* const xs = smem + p.x_off;
     const int n = p.m[0].n_tiles * p.B;
-    int item = (int)((long long)blockIdx.x * n / p.nblk);
-    const int hi = (int)((long long)(blockIdx.x + 1) * n / p.nblk);
+    int item = (int)((long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * n / p.nblk);
+    const int hi = (int)((long long)(xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1) * n / p.nblk);
     if (item >= hi) return;
     const size_t ustride = (size_t)G0::C * (size_t)p.T;
     const int nout = p.n_out_sum;

@@ -572,8 +572,8 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu(pairh_w
         const int nt = m == 0 ? n_tiles[0] : m == 1 ? n_tiles[1] : n_tiles[2];
         const int cm = m == 0 ? cost[0] : m == 1 ? cost[1] : cost[2];
         const int n = nt * q.B;
-        const int lo = pair_share(blockIdx.x, total, base, cm, n, q.nblk);
-        const int hi = pair_share(blockIdx.x + 1, total, base, cm, n, q.nblk);
+        const int lo = pair_share(xcd_remap((int)blockIdx.x, (int)gridDim.x), total, base, cm, n, q.nblk);
+        const int hi = pair_share(xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1, total, base, cm, n, q.nblk);
         base += (long long)n * cm;
         if (lo >= hi) continue;
         // ... and this member's pointers and sizes in one more
