@@ -213,7 +213,11 @@ int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout,
     const int ncols = (Tout + pad + stride - 1) / stride;          // u = (n + pad) / stride of the last sample, + 1
     mb.k = 2;
     mb.n_tiles = (ncols + NTC - 1) / NTC;
-    mb.n_items = mb.n_tiles * p.B * p.nmt;
+    // 128 and more input channels: 128-row tiles (convu_kernel, convr_kernels.hpp) when that still gives the chip items
+    // enough, as launch_convg / launch_convh; Tuning::convt_rows64
+    const long long wide_items = (long long)mb.n_tiles * p.B * ((p.nmt + 1) / 2);
+    const bool wide = cc == 128 && (tuning().convt_rows64 < 0 ? wide_items * 10 >= 7LL * device_cu_count() : !tuning().convt_rows64);
+    mb.n_items = wide ? (int)wide_items : mb.n_tiles * p.B * p.nmt;
     mb.cost = 1;
     const int xrows = (NTC + 1 + 3) / 4 * 4;
     const int img_bytes = 4 * cc * ((xrows + 15) / 16 * 16);
@@ -227,7 +231,7 @@ int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout,
     p.dbg = tuning().pair_dbg;
     p.trace = nullptr;
     profile_begin(s);
-    const int rc = launch_convt_geom(p, cc / 32, lds, s);
+    const int rc = wide ? launch_convu_geom(p, lds, s) : launch_convt_geom(p, cc / 32, lds, s);
     // MACs of a ConvTranspose1d = Tin * Cin * Cout * k
     profile_end(s, FV_KERNEL_CONVT, 2.0 * p.B * (double)p.T * Cin * Cout * 2 * stride,
                 4.0 * ((double)Cin * Cout * 2 * stride + (double)p.B * ((double)Cin * p.T + (double)Cout * Tout * (mb.y_act ? 2 : 1))));

@@ -8,6 +8,12 @@ int launch_convr_geom(const PairParams& p, size_t lds, hipStream_t s) {
     FV_HIP(hipGetLastError());
     return 0;
 }
+int launch_convu_geom(const PairParams& p, size_t lds, hipStream_t s) {
+    if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(convu_kernel), lds)) return rc;
+    hipLaunchKernelGGL(convu_kernel, dim3(p.nblk), dim3(512), lds, s, p);
+    FV_HIP(hipGetLastError());
+    return 0;
+}
 template <int DIL>
 static int launch_convs_dil(const PairParams& p, size_t lds, hipStream_t s) {
     auto kern = convs_kernel<DIL>;

@@ -18,14 +18,15 @@ namespace fv {
 // TWO: the two-source 1x1 conv (KT = 1; K range [lrelu(x); x2]); else a 'same' conv with KT taps of dilation DIL --
 // convh_kernel's convs on 128-row tiles: the (halo'd) window of a 128-channel chunk is converted once for KT * 4 K steps
 // of BOTH 64-row tiles (ResidualStack's dilated conv, reflection-padded; HiFi-GAN large's 256 / 512-channel ResBlocks)
-template <int KT_, int DIL_, bool TWO_ = false>
+// TR: the transposed conv of convt_kernel (KT = 2 taps x[u-1], x[u]; rows are (output channel, phase): convh_kernels.hpp)
+template <int KT_, int DIL_, bool TWO_ = false, bool TR_ = false>
 struct ConvRGeom {
     static constexpr int KT = KT_, DIL = DIL_;
-    static constexpr bool TWO = TWO_;
+    static constexpr bool TWO = TWO_, TR = TR_;
     static constexpr int C = 128, CG = 4, CB = 16, NFW = 4, NT = 512;
     static constexpr int NTC = 128;                      // output columns per tile
     static constexpr int NSTEP = KT * CG;                // K steps of 32 per chunk = weight stages per chunk (tap-major)
-    static constexpr int P = (KT - 1) * DIL / 2;
+    static constexpr int P = TR ? 1 : (KT - 1) * DIL / 2;
     static constexpr int XROWS = (NTC + (KT - 1) * DIL + 3) / 4 * 4;
     static constexpr int XRP = (XROWS + 15) / 16 * 16;   // image: [split half][8-channel block][XRP rows][8 halves]
     static constexpr int XHALF = CB * XRP * 16;
@@ -56,7 +57,10 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
     const float* const aptr = ring + (2 * ws) * 512 + lane * 4;
     const int row0 = 32 * ws + 4 * kb;                   // + 16 h + i: row inside the 128-row tile
 
-    const int nch = p.nch, nrt = p.nmt / 2;              // chunks of 128 input channels (TWO: x's, then x2's); row pairs
+    const int nch = p.nch, nrt = G::TR ? (p.nmt + 1) / 2 : p.nmt / 2;   // chunks of 128 input channels (TWO: x's, then x2's); row pairs
+                                                         // (TR: an odd tile count -- the last pair's second tile lies beyond
+                                                         // the packed image: its DMAs read zeros, its stores are dropped)
+
     const int spi = nch * G::NSTEP;                      // stages per item
     const size_t ustride = (size_t)p.ctot * (size_t)p.T;
     const size_t cstride = (size_t)G::C * (size_t)p.T;
@@ -176,11 +180,25 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
                 fetch_b(IntC<U + 1>{}, bbuf[(U + 1) & 1]);
             } else {
                 // (consumed in the epilogue below, before the next stage entry: the entries' wait counts do not see it)
-                const __amdgpu_buffer_rsrc_t rb = make_rsrc(mb.b1 ? mb.b1 : mb.w1, mb.b1 && last ? (unsigned)p.ctot * 4u : 0u);
+                if constexpr (G::TR) {
+                    const __amdgpu_buffer_rsrc_t rb = make_rsrc(mb.b1 ? mb.b1 : mb.w1, mb.b1 && last ? (unsigned)p.cout * 4u : 0u);
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                    for (int h = 0; h < 2; ++h) {
+                        const int m = 128 * rt + row0 + 16 * h;
+                        int co = (int)((unsigned)m / (unsigned)p.ups), ph = m - co * p.ups;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) bv[h][i] = buffer_load1(rb, (unsigned)(128 * rt + row0 + 16 * h + i) * 4u);
+                        for (int i = 0; i < 4; ++i) {
+                            bv[h][i] = buffer_load1(rb, (unsigned)co * 4u);
+                            if (++ph == p.ups) { ph = 0; ++co; }
+                        }
+                    }
+                } else {
+                    const __amdgpu_buffer_rsrc_t rb = make_rsrc(mb.b1 ? mb.b1 : mb.w1, mb.b1 && last ? (unsigned)p.ctot * 4u : 0u);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) bv[h][i] = buffer_load1(rb, (unsigned)(128 * rt + row0 + 16 * h + i) * 4u);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -204,6 +222,53 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
         pair_stamp(p, 8, wave, lane, it, 2);
         pair_barrier();                                  // every wave is done with the image
         pair_stamp(p, 8, wave, lane, it, 3);
+        if constexpr (G::TR) {
+            if (last) {
+                // y[co][ups u + phase - pad]: a lane's four rows are four consecutive phases -- inside one output channel
+                // four consecutive samples, one 16-byte store (convh_run_member's epilogue, rows 128 rt + ...)
+                const size_t yoff = (size_t)b * (size_t)p.cout * (size_t)p.Tout;
+                const unsigned ybytes = (unsigned)p.cout * (unsigned)p.Tout * 4u;
+                const __amdgpu_buffer_rsrc_t ry = make_rsrc(mb.y + yoff, ybytes);
+                const __amdgpu_buffer_rsrc_t ra = make_rsrc(mb.y_act ? mb.y_act + yoff : mb.y, mb.y_act ? ybytes : 0u);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int m0 = 128 * rt + row0 + 16 * h;
+                    const int co0 = (int)((unsigned)m0 / (unsigned)p.ups), ph0 = m0 - co0 * p.ups;
+                    const bool one_row = ph0 + 3 < p.ups;
+#pragma unroll
+                    for (int f = 0; f < G::NFW; ++f) {
+                        const int n0 = (t0 + col0 + f * 16) * p.ups - p.pad_t;
+                        float v[4], a[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            v[i] = fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[h][i];
+                            a[i] = act(v[i], p.act_slope);
+                            if (!mb.y_act) v[i] = a[i];              // no twin: y itself is stored activated
+                        }
+                        range_note4(bad, v[0], v[1], v[2], v[3], true);
+                        if (one_row && n0 + ph0 >= 0 && n0 + ph0 + 3 < p.Tout && !(p.dbg & 8)) {
+                            const unsigned off = (unsigned)(co0 * p.Tout + n0 + ph0) * 4u;
+                            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                                                                         __float_as_uint(v[3])}, ry, (int)off, 0, 0);
+                            if (mb.y_act)
+                                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(a[0]), __float_as_uint(a[1]),
+                                                                             __float_as_uint(a[2]), __float_as_uint(a[3])}, ra, (int)off, 0, 0);
+                        } else {
+                            int co = co0, ph = ph0;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int n = n0 + ph;
+                                const unsigned off = n >= 0 && n < p.Tout && !(p.dbg & 8) ? (unsigned)(co * p.Tout + n) * 4u : kOutOfRange;
+                                buffer_store1(ry, off, v[i]);
+                                if (mb.y_act) buffer_store1(ra, off, a[i]);
+                                if (++ph == p.ups) { ph = 0; ++co; }
+                            }
+                        }
+                    }
+                }
+            }
+        } else
         if (last) {
             const int rowt = 128 * rt + row0;
             const __amdgpu_buffer_rsrc_t rr = make_rsrc(mb.res ? mb.res + b * ustride : mb.w1, mb.res ? ubytes : 0u);
@@ -366,6 +431,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         else convr_run<ConvRGeom<3, DIL>>(q, mb, lo, hi, smem, wave, lane, first);
         first = false;
     }
+}
+
+// ConvTranspose1d, kernel = 2 x stride, 128 or more input channels, on 128-row tiles (rows = (output channel, phase)):
+// convt_kernel's GEMM with a chunk's window converted once for two 64-row tiles
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void convu_kernel(PairParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    PairParams q;
+    q.n_members = 1; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = 1.f;
+    q.act_slope = p.act_slope; q.post = 0; q.x_off = p.x_off; q.img_off = p.img_off; q.dbg = p.dbg; q.trace = p.trace;
+    q.ctot = p.ctot; q.nch = p.nch; q.nmt = p.nmt; q.reflect = 0; q.ups = p.ups; q.pad_t = p.pad_t; q.Tout = p.Tout; q.cout = p.cout;
+    q.guard = p.guard; q.sub = nullptr; q.sub_batched = 0;
+    PairMember mb;
+    mb.x = p.m[0].x; mb.x2 = nullptr; mb.w1 = p.m[0].w1; mb.b1 = p.m[0].b1; mb.res = nullptr; mb.add1 = nullptr; mb.add2 = nullptr;
+    mb.y = p.m[0].y; mb.y_act = p.m[0].y_act; mb.k = 2; mb.n_tiles = p.m[0].n_tiles;
+    const int n_items = p.m[0].n_items;
+    asm volatile("" ::"s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.act_slope), "s"(q.x_off), "s"(q.img_off), "s"(q.dbg),
+                 "s"(q.trace), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.ups), "s"(q.pad_t), "s"(q.Tout), "s"(q.cout), "s"(mb.x), "s"(mb.w1),
+                 "s"(mb.b1), "s"(mb.y), "s"(mb.y_act), "s"(mb.n_tiles), "s"(n_items), "s"(q.guard));
+    const int blk = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int lo = (int)((long long)blk * n_items / q.nblk), hi = (int)((long long)(blk + 1) * n_items / q.nblk);
+    if (lo < hi) convr_run<ConvRGeom<2, 1, false, true>>(q, mb, lo, hi, smem, wave, lane, true);
 }
 
 }  // namespace fv

@@ -146,6 +146,7 @@ struct Tuning {
     int convq_skel = -1;     // (-1: 5)
     int pair128_unfused = 0; // 1: 128-channel ResBlock pairs as two conv launches (convh) instead of the fused convq kernel (A/B, bit-identity tests)
     int convh_rows64 = -1;    // the split-f16 convs at 128+ channels on 64-row tiles (1: convh_kernel) or 128-row ones (0: convs_kernel); -1: by size
+    int convt_rows64 = -1;    // the split-f16 transposed conv (128+ input channels) on 64-row tiles (1) or 128-row ones (0); -1: by size
     int convg_rows64 = -1;    // the two-source 1x1 conv on 64-row tiles (1: convg_kernel) or 128-row ones (0: convr_kernel); -1: by size
     int chain = 0;            // 1: the dependent pair launches of a 64-channel MRF stage as one chained launch (PairChain;
                               // measured no faster at batch 1, convh_launch.hip chain_schedule: off)
@@ -346,6 +347,7 @@ int launch_convg(PairParams p, int C, hipStream_t stream);
 int launch_convg_geom(const PairParams& p, size_t lds, hipStream_t s);
 int launch_convr_geom(const PairParams& p, size_t lds, hipStream_t s);     // 128-row tiles (convr_kernels.hpp)
 int launch_convs_geom(const PairParams& p, int dil, size_t lds, hipStream_t s);   // convh's convs on 128-row tiles
+int launch_convu_geom(const PairParams& p, size_t lds, hipStream_t s);            // convt's GEMM on 128-row tiles
 // n (1..3) members, plain (sum = 0: one raw output each) or sum mode (one output: mean of the members)
 int launch_pairs(PairParams p, int C, int dil, hipStream_t stream);
 template <int MH, int NF, int NG>

@@ -362,7 +362,7 @@ def test_conv1d_split_f16_reflection_rejects():
 def tuning():
     """fv_tuning_set for the duration of a test (process-wide switches of the launchers: restored afterwards)."""
     defaults = {"sched": 1, "sched_switch": 4, "convh_blocks": 0, "pair_blocks": 0, "pair128_unfused": 0, "convg_rows64": -1,
-                "convh_rows64": -1, "chain": 0}
+                "convh_rows64": -1, "convt_rows64": -1, "chain": 0}
     yield _native.tuning_set
     for k, v in defaults.items():
         _native.tuning_set(k, v)
@@ -463,6 +463,22 @@ def test_conv_transpose1d_split_f16_vs_oracle(case, tuning):
     if B > 1:                                      # an utterance alone and inside the batch: same bits
         one = _native.conv_transpose1d_split_f16(X[1:2].contiguous(), P, Bi, cout, k, s, pad, op, pre_slope=0.1)
         assert torch.equal(one, y[1:2])
+    if cin >= 128:
+        # 128-row tiles (csrc/convr_kernels.hpp convu_kernel: the window of a chunk converted once for two 64-row tiles,
+        # an odd count of row tiles leaves the last pair half empty) against 64-row tiles: the same K order, same bits
+        outs = []
+        for rows64 in (1, 0):
+            tuning("convt_rows64", rows64)
+            tw = torch.empty_like(y)
+            outs.append((_native.conv_transpose1d_split_f16(X, P, Bi, cout, k, s, pad, op, pre_slope=0.1).clone(),
+                         _native.conv_transpose1d_split_f16(X, P, None, cout, k, s, pad, op, pre_slope=0.1, out_act=tw,
+                                                            act_slope=0.2).clone(), tw))
+            tuning("convh_blocks", 3)
+            outs.append((_native.conv_transpose1d_split_f16(X, P, Bi, cout, k, s, pad, op, pre_slope=0.1).clone(),))
+            tuning("convh_blocks", 0)
+        tuning("convt_rows64", -1)
+        assert torch.equal(outs[0][0], y) and all(torch.equal(a, b) for a, b in zip(outs[0], outs[2]))
+        assert torch.equal(outs[1][0], y) and torch.equal(outs[3][0], y)
 
 
 def test_conv_transpose1d_split_f16_rejects():
