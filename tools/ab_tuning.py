@@ -14,7 +14,7 @@ import bench  # noqa: E402
 from fastvocoder_amd import _native  # noqa: E402
 
 DEFAULTS = {"sched": 1, "sched_switch": 4, "convh_skel": -1, "convp_skel": 5, "convq_skel": -1, "pair128_unfused": 0,
-            "convh_blocks": 0, "pair_blocks": 0, "chain": 0, "pair_dbg": 0}
+            "convh_blocks": 0, "pair_blocks": 0, "chain": 0, "pair_dbg": 0, "shape32": -1, "shape64": -1, "units": 500}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1)
@@ -46,7 +46,8 @@ def families(reps=5):
     _native.profile_enable(False)
     out = {}
     for name, kind in (("convh128", _native.KERNEL_CONVH128), ("convh64", _native.KERNEL_CONVH64),
-                       ("pairh32", _native.KERNEL_PAIRH32), ("pairh16", _native.KERNEL_PAIRH16)):
+                       ("pairh32", _native.KERNEL_PAIRH32), ("pairh16", _native.KERNEL_PAIRH16),
+                       ("conv32", _native.KERNEL_CONV_MFMA32), ("convt", _native.KERNEL_CONVT)):
         r = _native.profile_collect(kind)
         out[name] = (round(1e3 * r["ms"] / reps, 1), r["launches"] // reps)
     _native.profile_collect(-1)
