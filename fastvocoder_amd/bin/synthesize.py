@@ -54,7 +54,11 @@ def _numpy_globals():
     except ImportError:                                   # numpy 1.x
         from numpy.core.multiarray import _reconstruct
     kinds = (np.float16, np.float32, np.float64, np.int8, np.int16, np.int32, np.int64, np.uint8, np.bool_)
-    return [np.ndarray, np.dtype, _reconstruct] + sorted({type(np.dtype(k)) for k in kinds}, key=lambda t: t.__name__)
+    # torch's allow-list matches on the qualified NAME a pickle spells: numpy 1.x files (the reference's published
+    # checkpoints) say numpy.core.multiarray._reconstruct, numpy 2.x files numpy._core.multiarray._reconstruct --
+    # the same function; both spellings are registered whatever numpy runs here
+    rebuild = [(_reconstruct, "numpy.core.multiarray._reconstruct"), (_reconstruct, "numpy._core.multiarray._reconstruct")]
+    return [np.ndarray, np.dtype] + rebuild + sorted({type(np.dtype(k)) for k in kinds}, key=lambda t: t.__name__)
 
 
 def load_checkpoint(path, device, unsafe=None):

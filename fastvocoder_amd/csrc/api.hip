@@ -244,9 +244,57 @@ __global__ void pack_pair_kernel(const float* __restrict__ w, float* __restrict_
 // (range_flag: an optional device-visible word that is set to 1 when a weight is outside the f16 range -- that layer has
 // to run on the fp32 kernels)
 constexpr float kSplitLimit = 65520.f;   // the smallest magnitude that rounds to inf in f16
+
+// Power-of-two prescale of the split-f16 weights, per GEMM row (= output channel; transposed conv: (output channel, phase)).
+// f16 halves keep 22 bits of a weight only while h1 is a NORMAL f16 (|w| >= 2^-14): a layer whose weights are small --
+// and whose activations are correspondingly large, the product being O(1) -- would lose them.  The pack functions therefore
+// scale every row by 2^e so that its largest magnitude lands in [2^13, 2^14) (exact in fp32; elements down to 2^-28 of the
+// row's maximum keep their 22 bits, smaller ones an absolute 2^-50 of it), and write 2^-e behind the image: the kernels'
+// epilogues multiply the accumulated sum by it inside the fused multiply-add that adds the bias -- acc * 2^-e is exact, so
+// the result is the one an unscaled weight of unlimited f16 exponent range would give.  Weight overflow cannot happen any
+// more (the flag remains for non-finite weights).
+// mode 0: Conv1d w [rows][n] (n = Cin k);  1: two 1x1 convs [W1 | W2], w [rows][n], w2 [rows][n];
+// mode 2: ConvTranspose1d w [Cin = n][Cout][2 s], rows m = co s + phase (rows >= Cout s: padding, scale 1)
+__global__ __launch_bounds__(64) void row_scale_kernel(const float* __restrict__ w, const float* __restrict__ w2,
+                                                       float* __restrict__ inv, int rows, int n, int mode, int Cout, int s_) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    float m = 0.f;
+    bool finite = true;
+    auto take = [&](float v) {
+        finite = finite && fabsf(v) < __builtin_inff();
+        m = fmaxf(m, fabsf(v));
+    };
+    if (mode == 2) {
+        const int co = r / s_, ph = r - co * s_;
+        if (co < Cout)
+            for (int ci = lane; ci < n; ci += 64) {
+                take(w[((size_t)ci * Cout + co) * (2 * s_) + ph]);
+                take(w[((size_t)ci * Cout + co) * (2 * s_) + s_ + ph]);
+            }
+    } else {
+        for (int i = lane; i < n; i += 64) {
+            take(w[(size_t)r * n + i]);
+            if (mode == 1) take(w2[(size_t)r * n + i]);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, o));
+        finite = __shfl_xor((int)finite, o) != 0 && finite;
+    }
+    if (lane == 0) {
+        int e = 0;
+        if (finite && m > 0.f) {
+            int x;
+            frexpf(m, &x);                    // m = f 2^x, f in [0.5, 1)
+            e = 14 - x;                       // m 2^e in [2^13, 2^14)
+            e = e > 110 ? 110 : e < -110 ? -110 : e;
+        }
+        inv[r] = ldexpf(1.f, -e);
+    }
+}
 // C = 16: tap = 2s + (g >> 1), channels 8 (g & 1) .. + 7 (an odd tap count is padded with a zero tap);
 // C = 32: tap = s, channels 8g .. 8g + 7.  Split: h1 = f16(w), h2 = f16((w - h1) * 2048), round to nearest.
-__global__ void pack_pairh_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int C, int k, int* range_flag) {
+__global__ void pack_pairh_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, const float* __restrict__ inv, int C, int k, int* range_flag) {
     const int MH = C / 16, tps = 32 / C, KS = (k + tps - 1) / tps;
     const int64_t total = (int64_t)KS * MH * 2 * 64 * 8;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -256,7 +304,7 @@ __global__ void pack_pairh_kernel(const float* __restrict__ w, _Float16* __restr
         const int g = lane >> 4, co = 16 * h + (lane & 15);
         const int tap = tps == 2 ? 2 * s + (g >> 1) : s;
         const int ci = tps == 2 ? 8 * (g & 1) + j : 8 * g + j;
-        const float v = tap < k ? w[((size_t)co * C + ci) * k + tap] : 0.f;
+        const float v = (tap < k ? w[((size_t)co * C + ci) * k + tap] : 0.f) * (1.f / inv[co]);
         const _Float16 h1 = (_Float16)v;
         if (range_flag && !(fabsf(v) < kSplitLimit)) *range_flag = 1;   // f16(v) would be inf (or v is not finite)
         wp[i] = half == 0 ? h1 : (_Float16)((v - (float)h1) * 2048.f);
@@ -266,7 +314,7 @@ __global__ void pack_pairh_kernel(const float* __restrict__ w, _Float16* __restr
 // Conv1d weight [C, C, k], C = 64 / 128 -> the streamed split-f16 A operands of convh_kernels.hpp:
 // Wh[row tile mt][K step s = tap * C/32 + cg][row sixteenth mh][split half][lane][8 halves];
 // lane = (row = lane & 15, K block kb = lane >> 4): co = 64 mt + 16 mh + row, ci = 32 cg + 8 kb + j.
-__global__ void pack_convh_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int C, int k, int* range_flag) {
+__global__ void pack_convh_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, const float* __restrict__ inv, int C, int k, int* range_flag) {
     // above 128 channels the input channels come in chunks of 128: [row tile][chunk][step inside the chunk]...
     const int NCH = C > 128 ? C / 128 : 1, CC = C / NCH, CG = CC / 32, NSTEP = k * CG;
     const int64_t total = (int64_t)(C / 64) * NCH * NSTEP * 4 * 2 * 64 * 8;
@@ -276,7 +324,7 @@ __global__ void pack_convh_kernel(const float* __restrict__ w, _Float16* __restr
         const int ms = (int)(i >> 12), s = ms % NSTEP, mc = ms / NSTEP, chunk = mc % NCH, mt = mc / NCH;
         const int tap = s / CG, cg = s % CG;
         const int co = 64 * mt + 16 * mh + (lane & 15), ci = CC * chunk + 32 * cg + 8 * (lane >> 4) + j;
-        const float v = w[((size_t)co * C + ci) * k + tap];
+        const float v = w[((size_t)co * C + ci) * k + tap] * (1.f / inv[co]);
         const _Float16 h1 = (_Float16)v;
         if (range_flag && !(fabsf(v) < kSplitLimit)) *range_flag = 1;   // f16(v) would be inf (or v is not finite)
         wp[i] = half == 0 ? h1 : (_Float16)((v - (float)h1) * 2048.f);
@@ -286,7 +334,7 @@ __global__ void pack_convh_kernel(const float* __restrict__ w, _Float16* __restr
 // Two 1x1 conv weights as one [C][2 C] matrix [W1 | W2] (w1, w2: [C][C][1]) for convg_kernel: the stage layout of
 // pack_convh_kernel with one tap and 2 C / 128 chunks of 128 input channels -- W1's, then W2's
 __global__ void pack_convg_kernel(const float* __restrict__ w1, const float* __restrict__ w2, _Float16* __restrict__ wp,
-                                  int C, int* range_flag) {
+                                  const float* __restrict__ inv, int C, int* range_flag) {
     const int NCH = 2 * C / 128, NSTEP = 4;
     const int64_t total = (int64_t)(C / 64) * NCH * NSTEP * 4 * 2 * 64 * 8;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -294,7 +342,7 @@ __global__ void pack_convg_kernel(const float* __restrict__ w1, const float* __r
         const int j = (int)(i & 7), lane = (int)((i >> 3) & 63), half = (int)((i >> 9) & 1), mh = (int)((i >> 10) & 3);
         const int ms = (int)(i >> 12), s = ms % NSTEP, mc = ms / NSTEP, chunk = mc % NCH, mt = mc / NCH;
         const int co = 64 * mt + 16 * mh + (lane & 15), ci = 128 * chunk + 32 * s + 8 * (lane >> 4) + j;
-        const float v = ci < C ? w1[(size_t)co * C + ci] : w2[(size_t)co * C + (ci - C)];
+        const float v = (ci < C ? w1[(size_t)co * C + ci] : w2[(size_t)co * C + (ci - C)]) * (1.f / inv[co]);
         const _Float16 h1 = (_Float16)v;
         if (range_flag && !(fabsf(v) < kSplitLimit)) *range_flag = 1;
         wp[i] = half == 0 ? h1 : (_Float16)((v - (float)h1) * 2048.f);
@@ -304,7 +352,7 @@ __global__ void pack_convg_kernel(const float* __restrict__ w1, const float* __r
 // ConvTranspose1d weights w[Cin][Cout][2 s] for convt_kernel (convh_kernels.hpp): the same stage layout, rows
 // m = co * s + phase, K = (tap, ci): tap 0 multiplies x[u - 1] (kernel index s + phase), tap 1 x[u] (kernel index phase)
 // (64 input channels: one chunk of 64 = two 32-channel groups per tap; otherwise chunks of 128)
-__global__ void pack_convth_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int Cin, int Cout, int s_, int* range_flag) {
+__global__ void pack_convth_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, const float* __restrict__ inv, int Cin, int Cout, int s_, int* range_flag) {
     const int CC = Cin == 64 ? 64 : 128, NCH = (Cin + CC - 1) / CC, CG = CC / 32, NSTEP = 2 * CG, k = 2 * s_;
     const int64_t total = (int64_t)((Cout * s_ + 63) / 64) * NCH * NSTEP * 4 * 2 * 64 * 8;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -314,7 +362,7 @@ __global__ void pack_convth_kernel(const float* __restrict__ w, _Float16* __rest
         const int tap = st / CG, cg = st % CG;
         const int m = 64 * mt + 16 * mh + (lane & 15), co = m / s_, ph = m - co * s_;
         const int ci = CC * chunk + 32 * cg + 8 * (lane >> 4) + j;
-        const float v = ci < Cin && co < Cout ? w[((size_t)ci * Cout + co) * k + (tap == 0 ? s_ + ph : ph)] : 0.f;
+        const float v = (ci < Cin && co < Cout ? w[((size_t)ci * Cout + co) * k + (tap == 0 ? s_ + ph : ph)] : 0.f) * (1.f / inv[m]);
         const _Float16 h1 = (_Float16)v;
         if (range_flag && !(fabsf(v) < kSplitLimit)) *range_flag = 1;   // f16(v) would be inf (or v is not finite)
         wp[i] = half == 0 ? h1 : (_Float16)((v - (float)h1) * 2048.f);
@@ -884,16 +932,21 @@ int64_t fv_packed_conv_transpose1d_split_floats(int Cin, int Cout, int k, int st
         Cout <= 0 || Cout * stride < 64)
         return 0;
     const int cc = Cin == 64 ? 64 : 128;                                             // input channels per chunk
-    return (int64_t)((Cout * stride + 63) / 64) * ((Cin + cc - 1) / cc) * (2 * cc / 32) * 2048;   // row tiles x chunks x K steps x 8 KB
+    const int64_t row_tiles = (Cout * stride + 63) / 64;
+    // row tiles x chunks x K steps x 8 KB, then one float per (padded) row: the inverse of its power-of-two prescale
+    return row_tiles * ((Cin + cc - 1) / cc) * (2 * cc / 32) * 2048 + row_tiles * 64;
 }
 
 int fv_pack_conv_transpose1d_split_f16(const float* w, float* packed, int Cin, int Cout, int k, int stride, int* range_flag,
                                        void* stream) {
     if (!w || !packed) return fail(FV_ERR_INVALID_ARG, "pack_conv_transpose1d_split_f16: null tensor");
     if (int rc = check_convt_split_args(Cin, Cout, k, stride, 0, 0)) return rc;
-    const int64_t total = fv_packed_conv_transpose1d_split_floats(Cin, Cout, k, stride) * 2;
+    const int rows = (Cout * stride + 63) / 64 * 64;
+    const int64_t image = fv_packed_conv_transpose1d_split_floats(Cin, Cout, k, stride) - rows, total = image * 2;
+    hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)rows), dim3(64), 0, (hipStream_t)stream, w, (const float*)nullptr,
+                       packed + image, rows, Cin, 2, Cout, stride);
     hipLaunchKernelGGL(pack_convth_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       reinterpret_cast<_Float16*>(packed), Cin, Cout, stride, range_flag);
+                       reinterpret_cast<_Float16*>(packed), packed + image, Cin, Cout, stride, range_flag);
     FV_HIP(hipGetLastError());
     return 0;
 }
@@ -1082,15 +1135,17 @@ int fv_conv1d_2src_fused(const float* x, const float* x2, const float* packed, c
 // ---- two-source 1x1 conv with split-f16 operands (convg_kernel) ----
 int64_t fv_packed_conv1x1_2src_split_floats(int C) {
     if (C != 128 && C != 256 && C != 512) return 0;
-    return (int64_t)(C / 64) * (2 * C / 128) * 4 * 2048;      // row tiles x chunks x 4 K steps x 8 KB
+    return (int64_t)(C / 64) * (2 * C / 128) * 4 * 2048 + C;  // row tiles x chunks x 4 K steps x 8 KB, + the rows' inverse prescales
 }
 
 int fv_pack_conv1x1_2src_split_f16(const float* w1, const float* w2, float* packed, int C, int* range_flag, void* stream) {
     if (!w1 || !w2 || !packed) return fail(FV_ERR_INVALID_ARG, "pack_conv1x1_2src_split_f16: null tensor");
-    const int64_t total = fv_packed_conv1x1_2src_split_floats(C) * 2;
-    if (total <= 0) return fail(FV_ERR_UNSUPPORTED, "pack_conv1x1_2src_split_f16: C = %d (128, 256 or 512)", C);
+    if (fv_packed_conv1x1_2src_split_floats(C) <= 0)
+        return fail(FV_ERR_UNSUPPORTED, "pack_conv1x1_2src_split_f16: C = %d (128, 256 or 512)", C);
+    const int64_t image = fv_packed_conv1x1_2src_split_floats(C) - C, total = image * 2;
+    hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)C), dim3(64), 0, (hipStream_t)stream, w1, w2, packed + image, C, C, 1, 0, 0);
     hipLaunchKernelGGL(pack_convg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w1, w2,
-                       reinterpret_cast<_Float16*>(packed), C, range_flag);
+                       reinterpret_cast<_Float16*>(packed), packed + image, C, range_flag);
     FV_HIP(hipGetLastError());
     return 0;
 }
@@ -1185,6 +1240,9 @@ int fv_plan_add_conv_post_pqmf(fv_plan_t* plan, int x_slot, int y_slot, const fl
                                int S, int k, int pad, float pre_slope, int post, const float* h, int ntaps) {
     if (!h || S != 4 || ntaps != 63)
         return fail(FV_ERR_UNSUPPORTED, "plan_add_conv_post_pqmf: S=%d ntaps=%d (4 sub-bands, 63 taps)", S, ntaps);
+    // a 'same' conv: the kernel writes S * T samples per utterance, the output's size (a larger pad would run past it)
+    if (k % 2 != 1 || pad != (k - 1) / 2)
+        return fail(FV_ERR_INVALID_ARG, "plan_add_conv_post_pqmf: k=%d pad=%d (odd kernel, pad = (k - 1) / 2)", k, pad);
     if (int rc = fv_plan_add_conv1d(plan, x_slot, y_slot, FV_SLOT_NONE, FV_SLOT_NONE, FV_SLOT_NONE, FV_SLOT_NONE, packed, bias,
                                     Cin, S, k, 1, pad, FV_PAD_ZERO, pre_slope, 1.f, post, 1.f))
         return rc;
@@ -1200,6 +1258,9 @@ int fv_conv_post_pqmf(const float* x, const float* packed, const float* bias, co
     if (!x || !packed || !h || !y) return fail(FV_ERR_INVALID_ARG, "conv_post_pqmf: null tensor");
     if (S != 4 || ntaps != 63) return fail(FV_ERR_UNSUPPORTED, "conv_post_pqmf: S=%d ntaps=%d (4 sub-bands, 63 taps)", S, ntaps);
     if (int rc = check_conv_args(Cin, S, k, 1)) return rc;
+    // a 'same' conv: y holds S * T samples per utterance (a larger pad would make the kernel store past it)
+    if (k % 2 != 1 || pad != (k - 1) / 2)
+        return fail(FV_ERR_INVALID_ARG, "conv_post_pqmf: k=%d pad=%d (odd kernel, pad = (k - 1) / 2)", k, pad);
     Op o = {};
     o.type = OP_CONV;
     o.act_slope = 1.f;
@@ -1256,11 +1317,12 @@ int fv_pack_pair_weight(const float* w, float* packed, int C, int k, void* strea
 
 int64_t fv_packed_pair_floats_ex(int C, int k, int prec) {
     if (prec != FV_PAIR_SPLIT_F16) return fv_packed_pair_floats(C, k);
+    // (+ C: one float per row behind the image, the inverse of the row's power-of-two prescale -- row_scale_kernel)
     if (C == 64 || C == 128 || C == 256 || C == 512)
-        return (int64_t)(C / 64) * k * (C / 32) * 2048;                       // row tiles x (chunks x) K steps x 8 KB
+        return (int64_t)(C / 64) * k * (C / 32) * 2048 + C;                   // row tiles x (chunks x) K steps x 8 KB
     if (C != 16 && C != 32) return 0;
     const int tps = 32 / C;
-    return (int64_t)((k + tps - 1) / tps) * (C / 16) * 512;   // K steps x row halves x 2 split halves x 64 lanes x 16 bytes
+    return (int64_t)((k + tps - 1) / tps) * (C / 16) * 512 + C;   // K steps x row halves x 2 split halves x 64 lanes x 16 bytes
 }
 
 int fv_pack_pair_weight_ex(const float* w, float* packed, int C, int k, int prec, int* range_flag, void* stream) {
@@ -1269,13 +1331,15 @@ int fv_pack_pair_weight_ex(const float* w, float* packed, int C, int k, int prec
     if (!w || !packed) return fail(FV_ERR_INVALID_ARG, "pack_pair_weight: null tensor");
     if ((C != 16 && C != 32 && C != 64 && C != 128 && C != 256 && C != 512) || k <= 0)
         return fail(FV_ERR_INVALID_ARG, "pack_pair_weight: C=%d (16 ... 512, a power of two) k=%d", C, k);
-    const int64_t total = fv_packed_pair_floats_ex(C, k, prec) * 2;
+    const int64_t image = fv_packed_pair_floats_ex(C, k, prec) - C, total = image * 2;
+    hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)C), dim3(64), 0, (hipStream_t)stream, w, (const float*)nullptr,
+                       packed + image, C, C * k, 0, 0, 0);
     if (C >= 64)
         hipLaunchKernelGGL(pack_convh_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           w, reinterpret_cast<_Float16*>(packed), C, k, range_flag);
+                           w, reinterpret_cast<_Float16*>(packed), packed + image, C, k, range_flag);
     else
         hipLaunchKernelGGL(pack_pairh_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           w, reinterpret_cast<_Float16*>(packed), C, k, range_flag);
+                           w, reinterpret_cast<_Float16*>(packed), packed + image, C, k, range_flag);
     FV_HIP(hipGetLastError());
     return 0;
 }
@@ -1952,8 +2016,9 @@ int fv_plan_check_range(fv_plan_t* plan, void* stream) {
     volatile int* w = plan->guard_host;
     if (*w == 0) return 0;
     *w = 0;
-    return fail(FV_ERR_RANGE, "a split-f16 kernel met an operand beyond the f16 range (|v| >= 65520) or a non-finite "
-                              "value: the results of the last run are not valid; repeat it on an fp32-precision plan");
+    return fail(FV_ERR_RANGE, "a split-f16 kernel met an operand outside its domain (|v| >= 65520 or a non-finite value; "
+                              "or operands that were smaller than 2^-10 throughout a block's share of a tensor): the "
+                              "results of the last run are not valid; repeat it on an fp32-precision plan");
 }
 
 int fv_tuning_set(const char* key, int value) {

@@ -75,7 +75,7 @@ struct ConvHGeom {
     static constexpr int RAWST = NST >= 4 ? NST - 4 : 0; // stage at which the next tile's raw window is requested
     static constexpr int NRAW = XR * 8;
     static constexpr int RESST = NST - 2;                // ... this tile's bias and residual
-    static constexpr int NRES = TR ? 8 : 8 + 8 * NFW;
+    static constexpr int NRES = TR ? 16 : 16 + 8 * NFW;  // loads of a tile's bias, inverse row prescales (+ residual)
     static_assert(NSTEP % 2 == 0 && NST >= 2 && NFW % 2 == 0, "stages of two steps, at least two per chunk");
     static_assert(((CG - 1) * 4 * XRP + (KT - 1) * DIL + 16 * (NFW - 1)) * 16 + 16 < 65536, "ds_read immediate range");
 };
@@ -109,20 +109,24 @@ __device__ __forceinline__ void convh_load_raw(ConvHRaw<G>& r, const float* xb, 
     }
 }
 
+// (low: the low side of the range guard, pairh_kernels.hpp LowGuard; which: the operand tensor the window belongs to)
 template <class G>
-__device__ __forceinline__ void convh_convert(const ConvHRaw<G>& r, char* ximg, float slope, int tid) {
+__device__ __forceinline__ void convh_convert(const ConvHRaw<G>& r, char* ximg, float slope, int tid, LowGuard& low, int which = 0) {
 #pragma unroll
     for (int q = 0; q < G::XR; ++q) {
         const int idx = tid + q * G::NT;
         const int cb = idx / G::XROWS, row = idx - cb * G::XROWS;
         f16x8 h1, h2;
+        float va[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float v = split_act(r.v[q][j], slope);
+            va[j] = v;
             const _Float16 a = (_Float16)v;
             h1[j] = a;
             h2[j] = split_rem(v, a);
         }
+        low_note(low, which, low_max8(va));
         if (idx < G::XROWS * G::CB) {
             *reinterpret_cast<f16x8*>(ximg + (cb * G::XRP + row) * 16) = h1;
             *reinterpret_cast<f16x8*>(ximg + (cb * G::XRP + row) * 16 + G::XHALF) = h2;
@@ -184,7 +188,8 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
     decode(item, b, ntile, mtile);
     if (!first) pair_barrier();                         // everybody is done with the previous member's LDS
     pair_stamp(p, 8, wave, lane, 7, 12);
-    float bad = 0.f;                                    // range guard (pairh_kernels.hpp range_note)
+    float bad = 0.f;                                    // range guard (pairh_kernels.hpp range_note, LowGuard)
+    LowGuard low;
     ConvHRaw<G> raw;
     auto chunk_channels = [&](int c) { return G::TR ? min(G::C, p.ctot - c * G::C) : G::C; };
     // the input channels of chunk c: the tensor they come from, and the slope of their on-chip activation
@@ -210,7 +215,7 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
     pair_stamp(p, 8, wave, lane, 7, 11);
     pair_wait_vm0();
     pair_stamp(p, 8, wave, lane, 7, 10);
-    if (!(p.dbg & 2)) convh_convert<G>(raw, ximg, chunk_slope(0), tid);
+    if (!(p.dbg & 2)) convh_convert<G>(raw, ximg, chunk_slope(0), tid, low, 0);
     pair_stamp(p, 8, wave, lane, 7, 13);                 // (tuning aid, -DFV_PAIR_TRACE) prologue done
     f32x4 hi[2][G::NFW], lo[2][G::NFW];                // live across the channel chunks of an item
     for (int it = 0;; ++it) {
@@ -234,7 +239,7 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
 #pragma unroll
                 for (int f = 0; f < G::NFW; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        float res[2][G::NFW][4], bv[2][4];
+        float res[2][G::NFW][4], bv[2][4], sv[2][4];     // sv: the rows' inverse weight prescales (behind the packed image)
         unsigned voff[G::NFW];
         f16x8 abuf[2][2][2], bbuf[3][2][2];         // A one group ahead, B two (from the image: no ring slot involved)
 
@@ -269,8 +274,9 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
                 convh_load_raw<G>(raw, chunk_src(nchunk, nb), p.T, nnt * G::NTC - G::P, tid,
                                   new_win && !(p.dbg & 1), p.reflect != 0, chunk_channels(nchunk));
             if constexpr (GS == G::RESST) {
-                // bias and residual of THIS tile: in flight during the last two stages
+                // bias, inverse row prescales and residual of THIS tile: in flight during the last two stages
                 // (before the tile's last chunk the same loads are issued out of range: the wait counts stay static)
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(mb.w1 + (size_t)nmt * nch * (G::WTILE / 4), last ? (unsigned)(nmt * 64) * 4u : 0u);
                 if constexpr (G::TR) {
                     const __amdgpu_buffer_rsrc_t rb = make_rsrc(mb.b1 ? mb.b1 : mb.w1, mb.b1 && last ? (unsigned)cout * 4u : 0u);
 #pragma unroll
@@ -282,13 +288,18 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
                             bv[h][i] = buffer_load1(rb, (unsigned)co * 4u);
                             if (++ph == p.ups) { ph = 0; ++co; }
                         }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sv[h][i] = buffer_load1(rs, (unsigned)(64 * mtile + row0 + 16 * h + i) * 4u);
                     }
                 } else {
                 const __amdgpu_buffer_rsrc_t rb = make_rsrc(mb.b1 ? mb.b1 : mb.w1, mb.b1 && last ? (unsigned)p.ctot * 4u : 0u);
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) bv[h][i] = buffer_load1(rb, (unsigned)(64 * mtile + row0 + 16 * h + i) * 4u);
+                    for (int i = 0; i < 4; ++i) {
+                        bv[h][i] = buffer_load1(rb, (unsigned)(64 * mtile + row0 + 16 * h + i) * 4u);
+                        sv[h][i] = buffer_load1(rs, (unsigned)(64 * mtile + row0 + 16 * h + i) * 4u);
+                    }
                 const __amdgpu_buffer_rsrc_t rr = make_rsrc(mb.res ? mb.res + b * ustride : mb.w1, mb.res ? ubytes : 0u);
 #pragma unroll
                 for (int f = 0; f < G::NFW; ++f) {
@@ -391,7 +402,7 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
                         float v[4], a[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            v[i] = fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[h][i];
+                            v[i] = fmaf(fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]), sv[h][i], bv[h][i]);
                             a[i] = act(v[i], p.act_slope);
                             if (!mb.y_act) v[i] = a[i];              // no twin: y itself is stored activated
                         }
@@ -427,7 +438,8 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
 #pragma unroll
                 for (int f = 0; f < G::NFW; ++f)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) hi[h][f][i] = (fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[h][i]) + res[h][f][i];
+                    for (int i = 0; i < 4; ++i)
+                        hi[h][f][i] = fmaf(fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]), sv[h][i], bv[h][i]) + res[h][f][i];
             if (mb.add1 != nullptr) {
                 const __amdgpu_buffer_rsrc_t r1 = make_rsrc(mb.add1 + b * ustride, ubytes);
                 const __amdgpu_buffer_rsrc_t r2 = make_rsrc(mb.add2 ? mb.add2 + b * ustride : mb.add1, mb.add2 ? ubytes : 0u);
@@ -499,7 +511,7 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
         pair_stamp(p, 8, wave, lane, it, 5);
         // the stores first, the conversion of the next window after them: a vmcnt wait cannot tell stores from loads,
         // the next tile's first stage waits would otherwise sit behind the stores' round trip
-        if (new_win && !(p.dbg & 2)) convh_convert<G>(raw, ximg, chunk_slope(nchunk), tid);
+        if (new_win && !(p.dbg & 2)) convh_convert<G>(raw, ximg, chunk_slope(nchunk), tid, low, G::TWO && nchunk >= nch / 2 ? 1 : 0);
         pair_stamp(p, 8, wave, lane, it, 6);
         if (!more) break;
         g0 += G::NST;
@@ -512,6 +524,8 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
     // the DMAs requested for a next item that does not exist wrote zeros; nothing is in flight past this point
     pair_wait_vm0();
     range_flag(p, bad);
+    pair_barrier();                                      // every wave's ring DMAs have landed: the ring is scratch now
+    low_flag(p, low, ring, wave, lane, G::NW);
 }
 
 // 8 waves per block, one block per CU (150-160 KB of LDS): 2 waves per SIMD, 256 VGPRs

@@ -334,7 +334,7 @@ static int prepare_convp(PairParams& p, int dil, size_t& lds_out, double& flops,
     p.mid_off = (int)floats;
     floats += (size_t)4 * C * (128 + 16) / 4;
     p.bias_off = (int)floats;
-    floats += 2 * (size_t)C;
+    floats += 4 * (size_t)C + 16;      // [b1 | b2 | inverse row prescales of conv1 | conv2 | scratch of the low-range guard]
     const size_t lds = floats * 4;
     if (lds > 160 * 1024) return fail(FV_ERR_UNSUPPORTED, "resblock pair: %zu bytes of LDS", lds);
     long long nblk = tuning().convh_blocks > 0 ? tuning().convh_blocks : device_cu_count();
@@ -616,7 +616,7 @@ int launch_convq(PairParams p, int dil, hipStream_t s) {
     p.mid_off = (int)floats;
     floats += (size_t)4 * C * (NM + 16) / 4;
     p.bias_off = (int)floats;
-    floats += 2 * (size_t)C;
+    floats += 4 * (size_t)C + 16;      // [b1 | b2 | inverse row prescales of conv1 | conv2 | scratch of the low-range guard]
     const size_t lds = floats * 4;
     if (lds > 160 * 1024) return fail(FV_ERR_UNSUPPORTED, "resblock pair: %zu bytes of LDS", lds);
     long long nblk = tuning().convh_blocks > 0 ? tuning().convh_blocks : device_cu_count();

@@ -78,6 +78,7 @@ __device__ __forceinline__ void convp_run_member(const PairCore& p, const PairMe
     int b = item / mb.n_tiles, tile = item - b * mb.n_tiles;
     if (!first) pair_barrier();
     pair_stamp(p, 8, wave, lane, 7, 12);                 // (tuning aid, -DFV_PAIR_TRACE: tools/convp_trace.py) run start
+    LowGuard low;                                        // low side of the range guard (pairh_kernels.hpp)
     float bad = 0.f;                                     // range guard (pairh_kernels.hpp range_note)
     ConvHRaw<H> raw;
     unsigned fo = kOutOfRange, fv = 0;                   // chained: this lane's flag of the next item, its value
@@ -92,13 +93,15 @@ __device__ __forceinline__ void convp_run_member(const PairCore& p, const PairMe
     if (tid < G::C) {
         bl[tid] = mb.b1 ? mb.b1[tid] : 0.f;
         bl[G::C + tid] = mb.b2 ? mb.b2[tid] : 0.f;
+        bl[2 * G::C + tid] = mb.w1[(H::WTILE) / 4 + tid];      // the rows' inverse weight prescales: behind the packed images
+        bl[3 * G::C + tid] = mb.w2[(H::WTILE) / 4 + tid];
     }
     // rows [NM, MRP) of the intermediate feed only discarded columns: finite values once
     for (int idx = tid; idx < 2 * (G::C / 8) * 64; idx += 512)
         reinterpret_cast<float*>(mimg + ((idx >> 6) * G::MRP + G::NM) * 16)[idx & 63] = 0.f;
     pair_wait_vm0();
     pair_stamp(p, 8, wave, lane, 7, 10);
-    if (!(p.dbg & 2)) convh_convert<H>(raw, ximg, p.slope, tid);
+    if (!(p.dbg & 2)) convh_convert<H>(raw, ximg, p.slope, tid, low);
     pair_stamp(p, 8, wave, lane, 7, 13);
     for (int it = 0;; ++it) {
         pair_stamp(p, 8, wave, lane, it, 0);
@@ -246,28 +249,37 @@ __device__ __forceinline__ void convp_run_member(const PairCore& p, const PairMe
             // conv1 -> intermediate image: column u of the tile is time t0 - P2 + u; conv2's zero padding applies to
             // the intermediate: columns outside [0, T) are zero, not conv1 of the padded input
             const int tm = t0 - G::P2;
+            float lowm = 0.f;                            // largest magnitude of this tile's intermediate in this lane
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                float bv[4];
+                float bv[4], sv[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bv[i] = bl[row0 + 16 * h + i];
+                for (int i = 0; i < 4; ++i) {
+                    bv[i] = bl[row0 + 16 * h + i];
+                    sv[i] = bl[2 * G::C + row0 + 16 * h + i];
+                }
 #pragma unroll
                 for (int f = 0; f < G::NFW; ++f) {
                     const int t = tm + col0 + f * 16;
                     const bool ok = t >= 0 && t < p.T;
                     f16x4 h1, h2;
+                    float va[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float v = split_act(fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[i], p.slope);
+                        float v = split_act(fmaf(fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]), sv[i], bv[i]), p.slope);
                         v = ok ? v : 0.f;
+                        va[i] = v;
                         const _Float16 a = (_Float16)v;
                         h1[i] = a;
                         h2[i] = split_rem(v, a);
                     }
+                    lowm = low_max3(lowm, va[0], va[1]);
+                    lowm = low_max3(lowm, va[2], va[3]);
                     *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16)) = h1;
                     *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16) + G::MHALF) = h2;
                 }
             }
+            low_note(low, 1, lowm);
         }
         pair_barrier();                                  // the intermediate is complete (and nobody reads the x image any more)
         pair_stamp(p, 8, wave, lane, it, 2);
@@ -281,13 +293,17 @@ __device__ __forceinline__ void convp_run_member(const PairCore& p, const PairMe
         const bool fin = mb.add1 != nullptr;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            float bv[4];
+            float bv[4], sv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bv[i] = bl[G::C + row0 + 16 * h + i];
+            for (int i = 0; i < 4; ++i) {
+                bv[i] = bl[G::C + row0 + 16 * h + i];
+                sv[i] = bl[3 * G::C + row0 + 16 * h + i];
+            }
 #pragma unroll
             for (int f = 0; f < G::NFW; ++f)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) hi[h][f][i] = (fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[i]) + res[h][f][i];
+                for (int i = 0; i < 4; ++i)
+                    hi[h][f][i] = fmaf(fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]), sv[i], bv[i]) + res[h][f][i];
         }
         if (fin) {
             const __amdgpu_buffer_rsrc_t r1 = make_rsrc(mb.add1 + b * ustride, ubytes);
@@ -322,7 +338,7 @@ __device__ __forceinline__ void convp_run_member(const PairCore& p, const PairMe
                            col < G::NOUT && t0 + col < p.T && !(p.dbg & 8), v, fin);
             }
         pair_stamp(p, 8, wave, lane, it, 5);
-        if (more && !(p.dbg & 2)) convh_convert<H>(raw, ximg, p.slope, tid);
+        if (more && !(p.dbg & 2)) convh_convert<H>(raw, ximg, p.slope, tid, low);
         pair_stamp(p, 8, wave, lane, it, 6);
         if (!more) break;
         g0 += G::NST;
@@ -336,6 +352,7 @@ __device__ __forceinline__ void convp_run_member(const PairCore& p, const PairMe
         if (tid == 0) chain_signal(*cc, mb.flag_off + item);
     }
     range_flag(p, bad);
+    low_flag(p, low, bl + 4 * G::C, wave, lane, 8);
 }
 
 // one 8-wave block per CU (150 KB of LDS), 2 waves per SIMD

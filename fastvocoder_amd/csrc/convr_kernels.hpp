@@ -98,13 +98,14 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
     int b, ntile, rt;
     decode(item, b, ntile, rt);
     if (!first) pair_barrier();                          // everybody is done with the previous member's LDS
+    LowGuard low;                                        // low side of the range guard (pairh_kernels.hpp)
     float bad = 0.f;                                     // range guard (pairh_kernels.hpp range_note4)
     ConvHRaw<G> raw;
     convh_load_raw<G>(raw, chunk_src(0, b), p.T, ntile * G::NTC - G::P, tid, true, p.reflect != 0);
 #pragma unroll
     for (int st = 0; st < G::AHEAD; ++st) dma_stage(st, stage_off(item, st));
     pair_wait_vm0();
-    if (!(p.dbg & 2)) convh_convert<G>(raw, ximg, chunk_slope(0), tid);
+    if (!(p.dbg & 2)) convh_convert<G>(raw, ximg, chunk_slope(0), tid, low, 0);
     f32x4 hi[2][G::NFW], lo[2][G::NFW];                  // live across the chunks of an item
     for (int it = 0;; ++it) {
         pair_stamp(p, 8, wave, lane, it, 0);             // (tuning aid, -DFV_PAIR_TRACE: tools/convr_trace.py)
@@ -125,8 +126,9 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
                 for (int f = 0; f < G::NFW; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         f16x8 abuf[2][2][2], bbuf[2][G::NFW][2];
-        float bv[2][4];                                  // the item's bias: requested in front of the last step's MFMAs (both
-                                                         // operand queues' other halves are dead there: no register cost)
+        float bv[2][4], qv[2][4];                        // the item's bias and inverse row prescales (behind the packed image):
+                                                         // requested in front of the last step's MFMAs (both operand queues'
+                                                         // other halves are dead there: no register cost)
 
         // ---- stage entry (stage = K step GS of this chunk, ring slot GS): its weights are in the slot for every wave;
         // every wave holds the A operands of the stage before in registers, so that slot is free: request the stage three
@@ -199,6 +201,14 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
 #pragma unroll
                         for (int i = 0; i < 4; ++i) bv[h][i] = buffer_load1(rb, (unsigned)(128 * rt + row0 + 16 * h + i) * 4u);
                 }
+                {
+                    // (TR: an odd tile count -- the rows of the last pair's second tile lie beyond the tail: they read zeros)
+                    const __amdgpu_buffer_rsrc_t rs = make_rsrc(mb.w1 + (size_t)p.nmt * nch * (G::WTILE / 4), last ? (unsigned)(p.nmt * 64) * 4u : 0u);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) qv[h][i] = buffer_load1(rs, (unsigned)(128 * rt + row0 + 16 * h + i) * 4u);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -241,7 +251,7 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
                         float v[4], a[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            v[i] = fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[h][i];
+                            v[i] = fmaf(fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]), qv[h][i], bv[h][i]);
                             a[i] = act(v[i], p.act_slope);
                             if (!mb.y_act) v[i] = a[i];              // no twin: y itself is stored activated
                         }
@@ -292,7 +302,7 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
                         for (int i = 0; i < 4; ++i) sv[i] = buffer_load1s(rs, voff, (unsigned)i * t4);
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = (fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[h][i]) + rv[i];
+                    for (int i = 0; i < 4; ++i) v[i] = fmaf(fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]), qv[h][i], bv[h][i]) + rv[i];
                     if (!G::TWO && mb.add1 != nullptr) {
                         // the last launch of an MRF stage: ((own + add1) + add2), the reference's order (convh_run_member)
                         const __amdgpu_buffer_rsrc_t r1 = make_rsrc(mb.add1 + b * ustride, ubytes);
@@ -338,7 +348,7 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
             pair_wait_vm0();                             // (the raw window: its own stamp)
             pair_stamp(p, 8, wave, lane, it, 5);
 #endif
-            convh_convert<G>(raw, ximg, chunk_slope(nchunk), tid);
+            convh_convert<G>(raw, ximg, chunk_slope(nchunk), tid, low, G::TWO && nchunk >= nch / 2 ? 1 : 0);
         }
         pair_stamp(p, 8, wave, lane, it, 6);
         if (!more) break;
@@ -351,6 +361,8 @@ __device__ __forceinline__ void convr_run(const PairParams& p, const PairMember&
     // the DMAs requested for a next item that does not exist wrote zeros; nothing is in flight past this point
     pair_wait_vm0();
     range_flag(p, bad);
+    pair_barrier();                                      // every wave's ring DMAs have landed: the ring is scratch now
+    low_flag(p, low, ring, wave, lane, 8);
 }
 
 // one 8-wave block per CU (128 KB of LDS), 2 waves per SIMD

@@ -123,7 +123,7 @@ static int launch_pairs_split(PairParams p, int C, int dil, hipStream_t s) {
     p.mid_off = (int)floats;
     floats += (size_t)mid_bytes / 4;
     p.bias_off = (int)floats;
-    floats += 2 * (size_t)C;
+    floats += 4 * (size_t)C + 16;      // [b1 | b2 | inverse row prescales of conv1 | conv2 | scratch of the low-range guard]
     const size_t lds = floats * 4;
     if (lds > (C == 16 ? 80 : 160) * 1024) return fail(FV_ERR_UNSUPPORTED, "resblock pair, split-f16: %zu bytes of LDS", lds);
     // 15-16 waves per CU (4 per SIMD): two 8-wave blocks at C = 16, one 15-wave block at C = 32

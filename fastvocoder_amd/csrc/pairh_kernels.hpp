@@ -78,6 +78,56 @@ __device__ __forceinline__ void range_flag(const PairCore& p, float bad) {
     if (p.guard && bad != bad) *p.guard = 1;
 }
 
+// The LOW side of the domain.  h1 = f16(v) is a normal f16 number -- and the pair keeps 22 bits of v -- only for
+// |v| >= 2^-14; below that the pair keeps an ABSOLUTE 2^-36.  That is harmless for the small elements of a tensor whose
+// scale is ordinary (2^-36 is 2^-26 of a 2^-10 maximum: below the fp32 rounding of its large elements), and it is a loss
+// for a tensor that is small as a whole -- whose consumer's weights are correspondingly large.  Weights are taken care of
+// at pack time (a power-of-two prescale per row: api.hip row_scale_kernel); for activations every split kernel watches
+// the magnitudes of the operands it actually splits (the window conversion, the intermediate of a fused pair: ~0.6 VALU
+// instructions per element, v_max3_f32 with |.| modifiers and two compares per group), and a block one of whose operand
+// tensors was not all zero and all below kSplitLow raises the guard word (value 4): the host repeats the call on the
+// exact-fp32 kernels, as it does for the high side.  The test is per BLOCK (every channel of hundreds of samples), never per element: silence inside an
+// ordinary signal stays on the split kernels, and a false alarm costs time, not accuracy.
+constexpr float kSplitLow = 0x1p-10f;
+// Per wave, in ONE scalar register (no VGPR is spent on the guard): has any lane split an operand of
+// magnitude >= kSplitLow (big), any non-zero operand (nz) -- separately for the two operand tensors a kernel splits
+// ([0] the input window; [1] the intermediate of a fused pair / the second source of the two-source 1x1 conv): a small
+// input in front of an ordinary intermediate is still a small input.
+struct LowGuard {
+    unsigned bits = 0;      // 1: [0] big, 2: [0] nz, 4: [1] big, 8: [1] nz -- one scalar register
+};
+__device__ __forceinline__ float low_max3(float a, float b, float c) {
+    float t;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(t) : "v"(a), "v"(b), "v"(c));
+    return t;
+}
+// t: the largest magnitude of a group of operands this lane has just split
+__device__ __forceinline__ void low_note(LowGuard& g, int which, float t) {
+    const unsigned b = (__builtin_amdgcn_ballot_w64(t >= kSplitLow) != 0 ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(t > 0.f) != 0 ? 2u : 0u);
+    g.bits |= b << (2 * which);
+}
+__device__ __forceinline__ float low_max8(const float (&v)[8]) {
+    float t = low_max3(v[0], v[1], v[2]);
+    t = low_max3(t, v[3], v[4]);
+    t = low_max3(t, v[5], v[6]);
+    return low_max3(t, v[7], v[7]);
+}
+// end of a member's run: the block's verdict through `scratch` (>= 16 words of LDS no one else uses), one flag per block.
+// Every wave of the block calls it (two barriers).
+__device__ __forceinline__ void low_flag(const PairCore& p, const LowGuard& g, float* scratch, int wave, int lane, int nwaves) {
+    if (!p.guard) return;
+    const unsigned bits = g.bits;
+    unsigned* const su = reinterpret_cast<unsigned*>(scratch);
+    if (lane == 0) su[wave] = bits;
+    pair_barrier();
+    if (wave == 0 && lane == 0) {
+        unsigned all = 0;
+        for (int w = 0; w < nwaves; ++w) all |= su[w];
+        if (((all & 2u) && !(all & 1u)) || ((all & 8u) && !(all & 4u))) *p.guard = 4;
+    }
+    pair_barrier();                                      // scratch may be written again (the block's next member)
+}
+
 // ---- chained launches (fv_internal.h PairChain): per-item flags instead of kernel boundaries -----------------------
 // flags[0] is the launch's abort word (a block that waited spin_limit polls raises it, and the guard word, and every
 // block stops waiting: the host repeats the call unchained); item flags start at kChainFlagBase.  A flag holds the
@@ -201,19 +251,22 @@ __device__ __forceinline__ void pairh_load_raw(PairHRaw<G>& r, const float* xb, 
 }
 
 template <class G>
-__device__ __forceinline__ void pairh_convert(const PairHRaw<G>& r, char* ximg, float slope, int tid) {
+__device__ __forceinline__ void pairh_convert(const PairHRaw<G>& r, char* ximg, float slope, int tid, LowGuard& low) {
 #pragma unroll
     for (int q = 0; q < PairHRaw<G>::XR; ++q) {
         const int idx = tid + q * G::NT;
         const int cb = idx / G::XROWS, row = idx - cb * G::XROWS;
         f16x8 h1, h2;
+        float va[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float v = split_act(r.v[q][j], slope);
+            va[j] = v;
             const _Float16 a = (_Float16)v;
             h1[j] = a;
             h2[j] = split_rem(v, a);
         }
+        low_note(low, 0, low_max8(va));
         if (idx < G::XROWS * PairHRaw<G>::CB) {
             *reinterpret_cast<f16x8*>(ximg + (cb * G::XRP + row) * 16) = h1;
             *reinterpret_cast<f16x8*>(ximg + (cb * G::XRP + row) * 16 + G::XHALF) = h2;
@@ -230,6 +283,18 @@ __device__ __forceinline__ void pairh_stage_weights(const PairMember& mb, float*
     for (int j = wave; j < NI; j += G::NW) {
         dma16(r1, wl + j * 256, (unsigned)(j * 1024 + lane * 16));
         dma16(r2, wl + G::WB / 4 + j * 256, (unsigned)(j * 1024 + lane * 16));
+    }
+}
+
+// biases and the rows' inverse weight prescales (behind the packed images: api.hip row_scale_kernel) of a member ->
+// LDS [b1[C] | b2[C] | s1[C] | s2[C]]
+template <class G>
+__device__ __forceinline__ void pairh_stage_bias(const PairMember& mb, float* bl, int tid) {
+    if (tid < G::C) {
+        bl[tid] = mb.b1 ? mb.b1[tid] : 0.f;
+        bl[G::C + tid] = mb.b2 ? mb.b2[tid] : 0.f;
+        bl[2 * G::C + tid] = mb.w1[G::WB / 4 + tid];
+        bl[3 * G::C + tid] = mb.w2[G::WB / 4 + tid];
     }
 }
 
@@ -355,15 +420,16 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
     int b = item / mb.n_tiles, tile = item - b * mb.n_tiles;
     if (!first) pair_barrier();                         // everybody is done with the previous member's LDS
     float bad = 0.f;                                    // range guard: NaN once a final value was not finite
+    LowGuard low;                                       // ... and its low side: were the operands small as a whole
     PairHRaw<G> raw;
     pairh_load_raw<G>(raw, mb.x + b * ustride, p.T, tile * TSTRIDE - TSHIFT - HEAD, tid);
     pairh_stage_weights<G>(mb, wl, wave, lane);
-    pair_stage_bias<G>(mb, bl, tid);
+    pairh_stage_bias<G>(mb, bl, tid);
     // rows [NM, MROWS) of the intermediate feed only discarded columns / the zero tap: finite values once
     for (int idx = tid; idx < 2 * (G::C / 8) * 64; idx += G::NT)
         reinterpret_cast<float*>(mimg + ((idx >> 6) * G::MRP + G::NM) * 16)[idx & 63] = 0.f;
     pair_wait_vm0();
-    pairh_convert<G>(raw, ximg, p.slope, tid);
+    pairh_convert<G>(raw, ximg, p.slope, tid, low);
     pair_barrier();
     for (;;) {
         const int t0 = tile * TSTRIDE - TSHIFT;
@@ -403,28 +469,37 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
             // intermediate column u of the tile is time t0 - P2 + u; conv2's zero padding applies to the
             // intermediate: columns outside [0, T) are zero, not conv1 of the padded input
             const int tm = t0 - G::P2;
+            float lowm = 0.f;                            // largest magnitude of this tile's intermediate in this lane
 #pragma unroll
             for (int h = 0; h < G::MH; ++h) {
-                float bv[4];
+                float bv[4], sv[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bv[i] = bl[16 * h + row0 + i];
+                for (int i = 0; i < 4; ++i) {
+                    bv[i] = bl[16 * h + row0 + i];
+                    sv[i] = bl[2 * G::C + 16 * h + row0 + i];
+                }
 #pragma unroll
                 for (int f = 0; f < G::NF; ++f) {
                     const int t = tm + col0 + f * 16;
                     const bool ok = t >= 0 && t < p.T;
                     f16x4 h1, h2;
+                    float va[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float v = split_act(fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[i], p.slope);
+                        float v = split_act(fmaf(fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]), sv[i], bv[i]), p.slope);
                         v = ok ? v : 0.f;
+                        va[i] = v;
                         const _Float16 a = (_Float16)v;
                         h1[i] = a;
                         h2[i] = split_rem(v, a);
                     }
+                    lowm = low_max3(lowm, va[0], va[1]);
+                    lowm = low_max3(lowm, va[2], va[3]);
                     *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16)) = h1;
                     *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16) + G::MHALF) = h2;
                 }
             }
+            low_note(low, 1, lowm);
         }
         pair_barrier();                                  // (C) intermediate complete, x image free
 #pragma unroll
@@ -435,17 +510,21 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
         // raw window and residual have been in flight for two conv phases; no store is outstanding here
         // (the previous tile's were issued a tile ago and are drained with the same wait)
         pair_wait_vm0();
-        if (more && !(p.dbg & 2)) pairh_convert<G>(raw, ximg, p.slope, tid);
+        if (more && !(p.dbg & 2)) pairh_convert<G>(raw, ximg, p.slope, tid, low);
         const bool fin = mb.add1 != nullptr;
 #pragma unroll
         for (int h = 0; h < G::MH; ++h) {
-            float bv[4];
+            float bv[4], sv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bv[i] = bl[G::C + 16 * h + row0 + i];
+            for (int i = 0; i < 4; ++i) {
+                bv[i] = bl[G::C + 16 * h + row0 + i];
+                sv[i] = bl[3 * G::C + 16 * h + row0 + i];
+            }
 #pragma unroll
             for (int f = 0; f < G::NF; ++f)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) hi[h][f][i] = (fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]) + bv[i]) + res[h][f][i];
+                for (int i = 0; i < 4; ++i)
+                    hi[h][f][i] = fmaf(fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]), sv[i], bv[i]) + res[h][f][i];
         }
         if (fin) {
             // last launch of an MRF stage: (r0 + r1) + r2 in the reference's order (hifigan.py:99-103)
@@ -528,6 +607,7 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
         tile = ntile;
     }
     range_flag(p, bad);
+    low_flag(p, low, bl + 4 * G::C, wave, lane, G::NW);
 }
 
 template <int MH, int NF, int NG, int DIL, bool FOLD>

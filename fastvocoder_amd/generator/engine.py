@@ -531,9 +531,11 @@ class NativeModule(torch.nn.Module):
 
     ``precision``    "split" (default): ResBlock / ResidualStack / upsampler layers with 16 ... 512 channels form
                      every fp32 product from split-f16 operand pairs on the f16 matrix cores (fp32-class accuracy,
-                     DESIGN.md section 3.7; domain |v| < 65520); "f32": the exact-fp32 MFMA kernels everywhere.
-    ``range_guard``  what happens when a weight or an activation leaves the split-f16 domain (the reference, fp32
-                     ATen, is defined for any finite fp32).  Weights are always checked when a plan is built.  Activations:
+                     DESIGN.md section 3.7; domain: activations below 65520 in magnitude and not smaller than 2^-10
+                     as a whole tensor -- weights of any finite magnitude are rescaled by a power of two per output row
+                     when they are packed); "f32": the exact-fp32 MFMA kernels everywhere.
+    ``range_guard``  what happens when an activation leaves the split-f16 domain on either side, or a weight is not finite
+                     (the reference, fp32 ATen, is defined for any finite fp32).  Weights are checked when a plan is built.  Activations:
                      "sync" -- every call waits for its kernels and reads the guard word they raise; an out-of-range
                          call is repeated on the fp32 kernels before it returns, and the module stays on them (one
                          warning).  Results are always the reference's; calls are synchronous.
@@ -567,7 +569,8 @@ class NativeModule(torch.nn.Module):
     def _fv_policy(self):
         """The policy a plan is built under (part of every plan's cache key)."""
         prec = "f32" if (self.precision == "f32" or self._fv_overflow) else "split"
-        return prec, bool(self.fuse_pairs), bool(self.fold_post)
+        # (the guard is part of the key: a plan built under range_guard = "off" carries no guard word)
+        return prec, bool(self.fuse_pairs), bool(self.fold_post), self.range_guard != "off"
 
     def _fv_state(self):
         """(identity + in-place version of every tensor the plans bake in, policy in force).  The tensor list is
@@ -638,8 +641,9 @@ class NativeModule(torch.nn.Module):
     def _went_out_of_range(self, what):
         """Sticky: from now on (until the weights change) this module's plans use the exact-fp32 kernels."""
         self._fv_overflow = True
-        warnings.warn(f"{type(self).__name__}: {what} outside the split-f16 range (|v| >= 65520); this model now runs "
-                      "on the exact-fp32 kernels (precision = 'f32')", RuntimeWarning, stacklevel=3)
+        warnings.warn(f"{type(self).__name__}: {what} outside the split-f16 range (|v| >= 65520 or not finite, or a "
+                      "tensor that is smaller than 2^-10 as a whole); this model now runs on the exact-fp32 kernels "
+                      "(precision = 'f32')", RuntimeWarning, stacklevel=3)
 
     def _plan(self, name, emit, in_channels):
         """Return the cached plan ``name`` or build it with ``emit(builder)``.  A split-f16 plan whose pack kernels
@@ -651,14 +655,15 @@ class NativeModule(torch.nn.Module):
         hit = self._fv_plans.get((name, state[1]))
         if hit is not None and hit[0] == state:
             return hit[1]
-        prec, _, fold = state[1]
-        guard = self._guard_word() if (prec == "split" and self.range_guard != "off") else None
+        prec, _, fold, guarded = state[1]
+        guard = self._guard_word() if (prec == "split" and guarded) else None
         with torch.no_grad():
             pb = PlanBuilder(in_channels, precision=prec, fold_post=fold, guard=guard)
             emit(pb)
             plan = pb.finalize()
             if guard is not None and plan.guarded:
-                torch.cuda.current_stream().synchronize()      # one-off, at plan build: the pack kernels' verdict
+                # one-off, at plan build: the pack kernels' verdict (they ran on the MODULE's device, under _on())
+                torch.cuda.current_stream(self._device()).synchronize()
                 if guard.peek(1):
                     guard.clear(1)
                     self._went_out_of_range("a weight lies")
@@ -689,7 +694,7 @@ class NativeModule(torch.nn.Module):
         may hold non-finite values)."""
         if self._fv_guard is None:
             return False
-        torch.cuda.current_stream().synchronize()
+        torch.cuda.current_stream(self._device()).synchronize()
         if not self._fv_guard.peek(0):
             return False
         self._fv_guard.clear(0)

@@ -83,7 +83,7 @@ class _HiFiGANBase(NativeModule):
     def _fused_flags(self, T):
         """Per stage: run it fused for a mel of T frames?  The pair kernels need 16-byte aligned rows
         (stage length % 4 == 0); ``fuse_pairs = False`` keeps every stage on the conv-by-conv path (A/B runs)."""
-        precision, fuse, _ = self._fv_policy()
+        precision, fuse = self._fv_policy()[:2]
         if not fuse:
             return (False,) * self.num_upsamples
         flags, t = [], int(T)

@@ -160,13 +160,23 @@ int fv_resblock1_fused(int n, const float* const* x, const float* const* w1, con
  *       and a product is three v_mfma_f32_16x16x32_f16 terms a1 b1 + (a1 b2 + a2 b1)/2048 accumulated in
  *       fp32.  Per layer the result is as close to the exact sum as an fp32 FMA chain (measured: DESIGN.md
  *       section 3.7, tests/test_split_precision.py); 5.3x fewer matrix-core cycles, which turns the C = 16
- *       layers from matrix-bound into HBM / LDS-bound.  DOMAIN: |v| < 65520 (the f16 range) for activations and
- *       weights -- where the reference (fp32 ATen) is defined for any finite fp32.  The domain is enforced, not assumed:
- *       the pack functions raise `range_flag` for a weight outside it, and every split-f16 kernel raises its `guard`
- *       word when a final value is not finite (an operand beyond the range turns into inf in f16 and every output it
- *       feeds into inf / NaN); the caller then repeats the layer / the run with FV_PAIR_F32 (fv_plan_check_range).
+ *       layers from matrix-bound into HBM / LDS-bound.  DOMAIN -- where the reference (fp32 ATen) is defined for any
+ *       finite fp32 -- enforced, not assumed:
+ *         weights: any finite fp32.  The pack functions scale every GEMM row by a power of two so that its largest
+ *           magnitude lies in [2^13, 2^14) (exact; the f16 pair keeps 22 bits of every element down to 2^-28 of the
+ *           row's maximum) and store the inverse behind the image; the kernels multiply the accumulated sum by it inside
+ *           the fused multiply-add that adds the bias (exact).  `range_flag` is raised for a non-finite weight.
+ *         activations, high side: |v| < 65520.  An operand beyond the f16 range turns into inf in f16 and every output
+ *           it feeds into inf / NaN: every split-f16 kernel raises its `guard` word (value 1) when a final value is not
+ *           finite.
+ *         activations, low side: below 2^-14 the pair keeps an absolute 2^-36 instead of 22 bits -- harmless inside an
+ *           ordinary tensor, a loss for one that is small as a whole (with correspondingly large weights behind it).
+ *           Every kernel keeps the largest magnitude of the operands it splits; a block whose operands were not all zero
+ *           and all below 2^-10 raises `guard` (value 4).
+ *         In both cases the caller repeats the layer / the run with FV_PAIR_F32 (fv_plan_check_range).
  *       range_flag / guard: int32 words any kernel can write (device memory or pinned host memory), NULL = no check.
- *       Weights: fv_pack_pair_weight_ex(prec) images ([K step][row half][split half][lane][8 f16]).
+ *       Weights: fv_pack_pair_weight_ex(prec) images ([K step][row half][split half][lane][8 f16], then one float per
+ *       row: the inverse prescale).
  *       C = 16 / 32: one fused launch (intermediate and weights in LDS).  C = 64: one fused launch, the weights of
  *       both convs stream through an LDS ring (csrc/convp_kernels.hpp).  C = 128 / 256 / 512: the pair's two LDS images do not
  *       fit next to the ring; it runs as two launches of the split-f16 conv kernel (csrc/convh_kernels.hpp) and

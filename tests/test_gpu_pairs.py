@@ -632,25 +632,30 @@ def test_split_kernels_at_activation_scales(scale):
     y = _native.conv_transpose1d_split_f16(_t(x), _native.pack_conv_transpose1d_split(_t(w), s), _t(b), cout, 2 * s, s,
                                            s // 2, 0, pre_slope=0.1, guard=guard)
     assert _rel_to(y, ref) <= tol, ("convt", scale, _rel_to(y, ref))
-    assert int(guard.item()) == 0                     # every operand was inside the f16 range: no guard raised
+    # inside the domain no guard is raised; a tensor of scale 1e-4 (largest magnitude 4e-4 < 2^-10) is below its LOW side:
+    # the kernels flag it (4) -- a plan would repeat the call on the fp32 kernels -- although gfx950 still keeps it at 1e-5
+    assert int(guard.item()) == (4 if scale < 1e-3 else 0)
 
 
 def test_range_guard_of_the_split_kernels():
-    """Outside the f16 range (|v| >= 65520) the split-f16 kernels do not apply: the pack kernels raise their range flag
-    for such a weight, and every kernel family raises its guard word when an activation (input or the intermediate of a
-    fused pair) overflows -- while operands just inside the range leave both clear."""
+    """Outside the f16 range (|v| >= 65520) the split-f16 kernels do not apply to ACTIVATIONS: every kernel family
+    raises its guard word when an activation (input or the intermediate of a fused pair) overflows -- while operands
+    just inside the range leave it clear.  Weights of any finite magnitude are rescaled when they are packed (the pack
+    kernels raise their flag for a non-finite one only)."""
     rng = np.random.RandomState(5)
     dev = _dev()
     flag = torch.zeros(1, dtype=torch.int32, device=dev)
     for C, k in ((16, 3), (32, 7), (64, 11), (128, 3)):
         w = (rng.randn(C, C, k) / np.sqrt(C * k)).astype(np.float32)
-        w[1, 2, 0] = 65000.0
-        _native.pack_pair(_t(w), SPLIT, flag)
-        assert int(flag.item()) == 0
-        w[1, 2, 0] = -70000.0
+        for big in (65000.0, -70000.0, 3.0e30):       # any finite weight: its row is rescaled by a power of two
+            w[1, 2, 0] = big
+            _native.pack_pair(_t(w), SPLIT, flag)
+            assert int(flag.item()) == 0
+        w[1, 2, 0] = np.nan                           # ... a non-finite one is flagged
         _native.pack_pair(_t(w), SPLIT, flag)
         assert int(flag.item()) == 1
         flag.zero_()
+        w[1, 2, 0] = 0.01
     wt = (rng.randn(128, 32, 8)).astype(np.float32)
     wt[5, 5, 5] = np.inf
     _native.pack_conv_transpose1d_split(_t(wt), 4, flag)
@@ -747,3 +752,144 @@ def test_conv1x1_2src_split_f16_rejects():
     x = torch.zeros((1, 128, 10), device=_dev())
     with pytest.raises(_native.NativeError, match="alias"):
         _native.conv1x1_2src_split_f16(x, x, P, None, out=x)
+
+
+# ---------------------------------------------------------------------------
+# the LOW side of the domain: small weights behind large activations, small tensors
+# ---------------------------------------------------------------------------
+def _pow2(e):
+    return np.float32(2.0 ** e)
+
+
+@pytest.mark.parametrize("wexp,aexp", [(-10, 10), (-14, 13), (-17, 14), (-20, 14), (-40, 12), (12, -6)])
+def test_split_kernels_at_weight_scales(wexp, aexp):
+    """Weights x 2^wexp (down to far below the smallest normal f16, 2^-14) behind activations x 2^aexp, every split-f16
+    kernel family -- pairh (16 / 32 channels), convp (64), convq (128), convh / convs (64 ... 256, 64- and 128-row tiles),
+    convt / convu, convg / convr -- against the double-accumulating C oracle at the SAME tolerance as at ordinary scales
+    (4e-6 of the tensor's scale; an fp32 FMA chain is at ~1e-6): the pack functions' per-row power-of-two prescale makes
+    the weights' magnitude irrelevant.  Round 3's kernels were 10x ... 100x off here (tests/test_split_precision.py)."""
+    ws, xs = _pow2(wexp), _pow2(aexp - 2)      # (randn reaches 4.5: x 2^(aexp - 2) stays below 65504 at aexp = 14)
+    rng = np.random.RandomState(7000 + wexp * 31 + aexp)
+    guard = torch.zeros(1, dtype=torch.int32, device=_dev())
+    tol = 4e-6
+    # fused pairs: x O(1), conv1 x 2^aexp (the INTERMEDIATE is the large activation), conv2's weights x 2^wexp with rows of
+    # unequal scale (weight norm's g).  The pair's branch y - x is what is compared (fp32 rounding of x + branch allowed for).
+    for C, T, k, dil in ((16, 700, 7, 3), (32, 500, 11, 5), (64, 300, 3, 1), (128, 200, 7, 3)):
+        x, w1, b1, w2, b2 = _member(rng, 2, C, T, k, True)
+        rows = (2.0 ** rng.randint(-2, 3, size=(C, 1, 1))).astype(np.float32)
+        w1, b1, w2 = w1 * xs, b1 * xs, w2 * ws * rows
+        ref = _pair_ref(x, w1, b1, w2, b2, dil, 0.1)
+        y = _native.resblock1_fused([_t(x)], [_native.pack_pair(_t(w1), SPLIT)], [_native.pack_pair(_t(w2), SPLIT)],
+                                    [_t(b1)], [_t(b2)], [k], dil, 0.1, prec=SPLIT, guard=guard)[0]
+        br, br_ref = y.detach().cpu().numpy().astype(np.float64) - x, ref.astype(np.float64) - x
+        err = np.abs(br - br_ref).max()
+        assert err <= tol * np.abs(br_ref).max() + 2.5e-7 * np.abs(ref).max(), (C, wexp, aexp, err / np.abs(br_ref).max())
+    # plain convs on 64-row (convh) and 128-row (convs) tiles, zero and reflection padding
+    for C, T, k, dil, refl in ((64, 300, 7, 3, False), (128, 260, 11, 5, False), (256, 200, 3, 9, True), (512, 140, 3, 1, False)):
+        x = rng.randn(1, C, T).astype(np.float32) * xs
+        w = (rng.randn(C, C, k) / np.sqrt(C * k)).astype(np.float32) * ws
+        b = rng.randn(C).astype(np.float32)
+        ref = oo.conv1d(x, w, b, dil=dil, pad=(k - 1) * dil // 2, pad_mode=oo.PAD_REFLECT if refl else oo.PAD_ZERO, pre_slope=0.1)
+        P = _native.pack_pair(_t(w), SPLIT)
+        for rows64 in (1, 0):
+            _native.tuning_set("convh_rows64", rows64)
+            y = _native.conv1d_split_f16([_t(x)], [P], [_t(b)], [k], dil, pre_slope=0.1, guard=guard,
+                                         pad_mode=_native.PAD_REFLECT if refl else _native.PAD_ZERO)[0]
+            _native.tuning_set("convh_rows64", -1)
+            assert _rel_to(y, ref) <= tol, ("conv", C, rows64, wexp, aexp, _rel_to(y, ref))
+    # transposed convs (64-row and 128-row tiles)
+    for cin, cout, T, s in ((64, 32, 150, 3), (128, 64, 150, 4), (256, 128, 90, 8)):
+        x = rng.randn(1, cin, T).astype(np.float32) * xs
+        w = (rng.randn(cin, cout, 2 * s) / np.sqrt(cin * 2)).astype(np.float32) * ws
+        w *= (2.0 ** rng.randint(-2, 3, size=(cin, 1, 1))).astype(np.float32)                  # weight norm's g of a ConvTranspose1d
+        b = rng.randn(cout).astype(np.float32)
+        ref = oo.conv_transpose1d(x, w, b, s, s // 2 + s % 2, s % 2, pre_slope=0.1)
+        P = _native.pack_conv_transpose1d_split(_t(w), s)
+        for rows64 in (1, 0):
+            _native.tuning_set("convt_rows64", rows64)
+            y = _native.conv_transpose1d_split_f16(_t(x), P, _t(b), cout, 2 * s, s, s // 2 + s % 2, s % 2, pre_slope=0.1, guard=guard)
+            _native.tuning_set("convt_rows64", -1)
+            assert _rel_to(y, ref) <= tol, ("convt", cin, rows64, wexp, aexp, _rel_to(y, ref))
+    # ResidualStack's 1x1 + skip GEMM: the two halves of the K range at different scales
+    for C, T in ((128, 300), (256, 200)):
+        x, x2 = rng.randn(1, C, T).astype(np.float32) * xs, rng.randn(1, C, T).astype(np.float32) * xs
+        w1 = (rng.randn(C, C, 1) / np.sqrt(C)).astype(np.float32) * ws
+        w2 = (rng.randn(C, C, 1) / np.sqrt(C)).astype(np.float32) * ws * _pow2(-3)
+        b = rng.randn(C).astype(np.float32)
+        ref = oo.conv1d(x, w1, None, pre_slope=0.2) + oo.conv1d(x2, w2, b)
+        P = _native.pack_conv1x1_2src_split(_t(w1), _t(w2))
+        for rows64 in (1, 0):
+            _native.tuning_set("convg_rows64", rows64)
+            y = _native.conv1x1_2src_split_f16(_t(x), _t(x2), P, _t(b), pre_slope=0.2, guard=guard)
+            _native.tuning_set("convg_rows64", -1)
+            assert _rel_to(y, ref) <= tol, ("convg", C, rows64, wexp, aexp, _rel_to(y, ref))
+    assert int(guard.item()) == 0                     # nothing here leaves the domain on either side
+
+
+def test_low_side_of_the_range_guard():
+    """A tensor that is small as a WHOLE (largest magnitude below 2^-10) is outside the split-f16 domain: every kernel
+    family raises guard value 4 for it (input window, or the intermediate of a fused pair); a tensor with small regions,
+    an all-zero tensor and one whose maximum is 2^-9 are inside."""
+    rng = np.random.RandomState(77)
+    guard = torch.zeros(1, dtype=torch.int32, device=_dev())
+
+    def fired():
+        v = int(guard.item())
+        guard.zero_()
+        return v
+
+    for C, T, k, dil in ((16, 2000, 3, 1), (32, 900, 7, 3), (64, 400, 3, 5), (128, 300, 3, 1)):
+        x, w1, b1, w2, b2 = _member(rng, 2, C, T, k, True)
+        ws = [_native.pack_pair(_t(w1), SPLIT)], [_native.pack_pair(_t(w2), SPLIT)]
+        args = ([_t(b1)], [_t(b2)], [k], dil, 0.1)
+        xn = (x / np.abs(x).max()).astype(np.float32)
+        _native.resblock1_fused([_t(xn * _pow2(-9))], *ws, *args, prec=SPLIT, guard=guard)
+        assert fired() == 0                           # largest magnitude 2^-9: inside
+        _native.resblock1_fused([_t(xn * _pow2(-11))], *ws, *args, prec=SPLIT, guard=guard)
+        assert fired() == 4                           # 2^-11: the whole tensor is below the low side (although the
+                                                      # intermediate, which the biases dominate, is ordinary)
+        quiet = x.copy()
+        quiet[:, :, T // 3: T // 3 + 40] *= _pow2(-20)     # silence inside an ordinary signal is not
+        y = _native.resblock1_fused([_t(quiet)], *ws, *args, prec=SPLIT, guard=guard)[0]
+        assert fired() == 0 and _rel(y, _pair_ref(quiet, w1, b1, w2, b2, dil, 0.1)) <= 4e-6
+        # all zeros (the zero-mel pass of a model without biases): exact in f16, nothing to lose
+        _native.resblock1_fused([_t(np.zeros_like(x))], *ws, [None], [None], [k], dil, 0.1, prec=SPLIT, guard=guard)
+        assert fired() == 0
+        # the INTERMEDIATE of the fused pair is small although input and output are not: conv1 x 2^-14, conv2 x 2^14
+        small = [_native.pack_pair(_t(w1 * _pow2(-14)), SPLIT)], [_native.pack_pair(_t(w2 * _pow2(14)), SPLIT)]
+        _native.resblock1_fused([_t(x)], *small, [_t(b1 * _pow2(-14))], [_t(b2)], [k], dil, 0.1, prec=SPLIT, guard=guard)
+        assert fired() == 4
+    x = rng.randn(1, 128, 200).astype(np.float32)
+    xn = (x / np.abs(x).max()).astype(np.float32)
+    w = (rng.randn(128, 128, 3) / 20).astype(np.float32)
+    P = _native.pack_pair(_t(w), SPLIT)
+    for rows64 in (1, 0):
+        _native.tuning_set("convh_rows64", rows64)
+        _native.conv1d_split_f16([_t(xn * _pow2(-12))], [P], [None], [3], 1, pre_slope=0.1, guard=guard)
+        assert fired() == 4
+        _native.conv1d_split_f16([_t(xn * _pow2(-8))], [P], [None], [3], 1, pre_slope=0.1, guard=guard)
+        assert fired() == 0
+    _native.tuning_set("convh_rows64", -1)
+    wT = (rng.randn(128, 64, 8) / 16).astype(np.float32)
+    PT = _native.pack_conv_transpose1d_split(_t(wT), 4)
+    for rows64 in (1, 0):
+        _native.tuning_set("convt_rows64", rows64)
+        _native.conv_transpose1d_split_f16(_t(xn * _pow2(-12)), PT, None, 64, 8, 4, 2, 0, pre_slope=1.0, guard=guard)
+        assert fired() == 4
+        _native.conv_transpose1d_split_f16(_t(xn * _pow2(-8)), PT, None, 64, 8, 4, 2, 0, pre_slope=1.0, guard=guard)
+        assert fired() == 0
+    _native.tuning_set("convt_rows64", -1)
+    w1 = (rng.randn(128, 128, 1) / 11).astype(np.float32)
+    PG = _native.pack_conv1x1_2src_split(_t(w1), _t(w1))
+    for rows64 in (1, 0):
+        _native.tuning_set("convg_rows64", rows64)
+        _native.conv1x1_2src_split_f16(_t(xn * _pow2(-12)), _t(xn * _pow2(-13)), PG, None, pre_slope=0.2, guard=guard)
+        assert fired() == 4
+        # the two sources are two operand tensors: one of them at an ordinary scale does not hide the other
+        _native.conv1x1_2src_split_f16(_t(xn * _pow2(-12)), _t(xn), PG, None, pre_slope=0.2, guard=guard)
+        assert fired() == 4
+        _native.conv1x1_2src_split_f16(_t(xn), _t(xn * _pow2(-12)), PG, None, pre_slope=0.2, guard=guard)
+        assert fired() == 4
+        _native.conv1x1_2src_split_f16(_t(xn * _pow2(-3)), _t(xn * _pow2(-9)), PG, None, pre_slope=0.2, guard=guard)
+        assert fired() == 0
+    _native.tuning_set("convg_rows64", -1)

@@ -851,26 +851,46 @@ def test_generator_beyond_the_f16_range_repeats_on_fp32():
         assert torch.equal(strict(x)[0], want)
 
 
-def test_weight_beyond_the_f16_range_builds_an_fp32_plan():
-    """A checkpoint with a weight outside the f16 range: the pack kernels flag it while the plan is built and the plan
-    is rebuilt with fp32 arithmetic -- the first call already returns the fp32 path's result."""
+def test_weights_of_any_magnitude_stay_on_the_split_kernels():
+    """Weights far outside the f16 range inside a generator (round 3: a weight beyond 65504 meant an fp32 plan, one below
+    6e-5 lost bits silently).  Every ResBlock's first convs 2^10 times too large and its second convs 2^-10 times too small
+    -- weights of 2e-5, below the smallest normal f16, behind intermediates in the thousands: the same function in exact
+    arithmetic (leaky ReLU is homogeneous), and the same output within the fp32 noise on the split-f16 kernels -- the
+    pack functions rescale every row by a power of two -- with no guard raised."""
     cfg = cases.load_conf("conf/hifigan/light.yaml")
     mel = seeded_mel(48, seed=33)
+    plain, _ = _model("hifigan", cfg, seed=0)
+    m, _ = _model("hifigan", cfg, seed=0)
+    m.remove_weight_norm()
+    with torch.no_grad():
+        for rb in m.resblocks:
+            for c1, c2 in zip(rb.convs1, rb.convs2):
+                c1.weight.mul_(2.0 ** 10)
+                c1.bias.mul_(2.0 ** 10)
+                c2.weight.mul_(2.0 ** -10)
+        want = plain.inference(mel)
+        got = m.inference(mel)
+    assert m._fv_policy()[0] == "split" and not m.check_range()
+    assert float(want.abs().max()) > 0.05 and _err(got, want.cpu().numpy()) <= 2e-5
 
-    def build():
-        m, _ = _model("hifigan", cfg, seed=0)
-        m.remove_weight_norm()
-        with torch.no_grad():
-            m.resblocks[4].convs1[1].weight[3, 5, 1] = 1.0e5
-        return m
-    exact = build()
+
+def test_generator_below_the_low_side_repeats_on_fp32():
+    """The low side of the domain end to end: conv_pre 2^-20 times too quiet (conv_post undoes it) -- the first split-f16
+    layer sees a tensor that is small as a whole, the guard fires (4), `inference` repeats the call on the exact-fp32
+    kernels and returns the fp32 model's output bit for bit; at 2^-6 the model stays on the split kernels."""
+    mel = seeded_mel(64, seed=31)
+    exact = _scaled_hifigan(2.0 ** -20)
     exact.precision = "f32"
-    m = build()
     with torch.no_grad():
         want = exact.inference(mel)
-        with pytest.warns(RuntimeWarning, match="a weight lies outside the split-f16 range"):
-            got = m.inference(mel)
-    assert bool(torch.isfinite(want).all()) and torch.equal(got, want)
+    m = _scaled_hifigan(2.0 ** -20)
+    with pytest.warns(RuntimeWarning, match="split-f16 range"), torch.no_grad():
+        got = m.inference(mel)
+    assert torch.equal(got, want) and m._fv_policy()[0] == "f32"
+    ok = _scaled_hifigan(2.0 ** -6)
+    with torch.no_grad():
+        y = ok.inference(mel)
+    assert ok._fv_policy()[0] == "split" and bool(torch.isfinite(y).all()) and not ok.check_range()
 
 
 @pytest.mark.parametrize("path", ["conf/multiband-hifigan/light.yaml", "conf/multiband-hifigan/large.yaml"])

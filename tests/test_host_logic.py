@@ -170,11 +170,11 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert _native.lib().fv_packed_pair_floats(32, 11) == 32 * 32 * 11
     # split-f16 images: C = 16: (k+1)/2 K steps x 2 KB; C = 32: k steps x 2 row halves; C = 64 / 128: row tiles x k C/32 steps x 8 KB
     L = _native.lib()
-    assert L.fv_packed_pair_floats_ex(16, 11, _native.PAIR_SPLIT_F16) == 6 * 512
-    assert L.fv_packed_pair_floats_ex(32, 7, _native.PAIR_SPLIT_F16) == 7 * 2 * 512
-    assert L.fv_packed_pair_floats_ex(64, 11, _native.PAIR_SPLIT_F16) == 22 * 2048
-    assert L.fv_packed_pair_floats_ex(128, 3, _native.PAIR_SPLIT_F16) == 2 * 12 * 2048
-    assert L.fv_packed_pair_floats_ex(512, 7, _native.PAIR_SPLIT_F16) == 8 * 4 * 28 * 2048      # row tiles x chunks x steps
+    assert L.fv_packed_pair_floats_ex(16, 11, _native.PAIR_SPLIT_F16) == 6 * 512 + 16      # (+ C: the rows' inverse prescales)
+    assert L.fv_packed_pair_floats_ex(32, 7, _native.PAIR_SPLIT_F16) == 7 * 2 * 512 + 32
+    assert L.fv_packed_pair_floats_ex(64, 11, _native.PAIR_SPLIT_F16) == 22 * 2048 + 64
+    assert L.fv_packed_pair_floats_ex(128, 3, _native.PAIR_SPLIT_F16) == 2 * 12 * 2048 + 128
+    assert L.fv_packed_pair_floats_ex(512, 7, _native.PAIR_SPLIT_F16) == 8 * 4 * 28 * 2048 + 512      # row tiles x chunks x steps
     assert L.fv_packed_pair_floats_ex(48, 3, _native.PAIR_SPLIT_F16) == 0
     assert L.fv_packed_pair_floats_ex(32, 11, _native.PAIR_F32) == 32 * 32 * 11
     # host-only entry points that need no device
@@ -235,6 +235,9 @@ def test_plan_shape_inference_without_gpu():
     assert (c.value, n.value) == (1, 4 * (60 * 100 - 20))
     assert L.fv_plan_workspace_bytes(h, 2, 100) > 0
     assert L.fv_plan_num_ops(h) == 5
+    # conv_post + PQMF in one launch writes S * T samples per utterance: only a 'same' conv fits its output
+    assert L.fv_plan_add_conv_post_pqmf(h, 2, 3, dummy, None, 8, 4, 7, 4, 1.0, 1, dummy, 63) != 0
+    assert b"pad = (k - 1) / 2" in L.fv_last_error() and L.fv_plan_num_ops(h) == 5
     # UpsampleLayer: rate*T + 2*pad - (k-1)
     u = L.fv_plan_create(8)
     assert L.fv_plan_add_upsample_conv1d(u, 0, 1, -1, dummy, None, 8, 4, 16, 8, 8, 0.1, 0, 1.0) == 0
@@ -280,9 +283,9 @@ def test_plan_shape_inference_without_gpu():
     L.fv_plan_destroy(f)
     # transposed conv with split-f16 operands: kernel = 2 strides, 128+ input channels; same length law as the fp32 op
     t = L.fv_plan_create(128)
-    assert L.fv_packed_conv_transpose1d_split_floats(128, 64, 10, 5) == 5 * 1 * 8 * 2048
-    assert L.fv_packed_conv_transpose1d_split_floats(256, 128, 16, 8) == 16 * 2 * 8 * 2048
-    assert L.fv_packed_conv_transpose1d_split_floats(64, 32, 6, 3) == 2 * 1 * 4 * 2048     # 96 rows -> 2 tiles; 64-channel chunks
+    assert L.fv_packed_conv_transpose1d_split_floats(128, 64, 10, 5) == 5 * 1 * 8 * 2048 + 320     # (+ one float per padded row)
+    assert L.fv_packed_conv_transpose1d_split_floats(256, 128, 16, 8) == 16 * 2 * 8 * 2048 + 1024
+    assert L.fv_packed_conv_transpose1d_split_floats(64, 32, 6, 3) == 2 * 1 * 4 * 2048 + 128     # 96 rows -> 2 tiles; 64-channel chunks
     assert L.fv_packed_conv_transpose1d_split_floats(32, 16, 4, 2) == 0
     assert L.fv_packed_conv_transpose1d_split_floats(128, 64, 11, 5) == 0
     assert L.fv_plan_add_conv_transpose1d_split_f16(t, 0, 1, -1, dummy, None, 128, 64, 10, 5, 3, 1, 0.1, 1.0) == 0
@@ -316,6 +319,25 @@ def test_checkpoint_loader_is_restricted_unless_asked(tmp_path):
     ck = load_checkpoint(str(good), "cpu")
     assert torch.equal(ck["model"]["w"], torch.arange(6.0).reshape(2, 3)) and ck["step"] == 3
     assert isinstance(ck["pattern"], np.ndarray) and ck["pattern"].dtype == np.float32 and ck["pattern"].shape == (7,)
+
+    # the same file as numpy 1.x wrote it (the reference's published checkpoints): the array's rebuild function is
+    # spelled numpy.core.multiarray._reconstruct there, numpy._core... in a numpy 2.x file -- both load
+    import zipfile
+    other = tmp_path / "published_other_numpy.pth.tar"
+    with zipfile.ZipFile(good) as zi, zipfile.ZipFile(other, "w", zipfile.ZIP_STORED) as zo:
+        swapped = 0
+        for item in zi.infolist():
+            data = zi.read(item.filename)
+            if item.filename.endswith("data.pkl"):
+                a, b = b"numpy._core.multiarray", b"numpy.core.multiarray"
+                if a not in data:
+                    a, b = b, a
+                swapped = data.count(a)
+                data = data.replace(a, b)
+            zo.writestr(item, data)
+    assert swapped >= 1
+    ck2 = load_checkpoint(str(other), "cpu")
+    assert np.array_equal(ck2["pattern"], ck["pattern"]) and torch.equal(ck2["model"]["w"], ck["model"]["w"])
 
     class Evil:
         def __reduce__(self):
