@@ -90,12 +90,38 @@ def check_against_golden(wav_row):
     return err
 
 
+def host_cpu():
+    """(model string, physical cores, logical CPUs) of this host, from /proc/cpuinfo (the CPU
+    baseline states what it ran on)."""
+    model, phys, logical = "unknown", set(), 0
+    try:
+        pid = cid = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                key, _, val = line.partition(":")
+                key, val = key.strip(), val.strip()
+                if key == "processor":
+                    logical += 1
+                elif key == "model name" and model == "unknown":
+                    model = val
+                elif key == "physical id":
+                    pid = val
+                elif key == "core id":
+                    cid = val
+                    phys.add((pid, cid))
+    except OSError:
+        pass
+    return model, (len(phys) or logical or (os.cpu_count() or 0)), (logical or (os.cpu_count() or 0))
+
+
 def cpu_baseline(cfg, sd, mel):
-    """The reference's CPU path (un-fused ATen op sequence) on this box's cores:
-    one warm-up + best of 3 passes over ONE utterance of the same workload."""
+    """The reference's CPU path (un-fused ATen op sequence) on this box's cores: one warm-up + best of 3 passes over
+    ONE utterance of the same workload with torch's default thread count, and -- SURVEY.md section 8(d) -- one pass on
+    ONE thread over the first quarter of the same utterance (bounded: the whole leg stays within ~20 s)."""
     from oracle import torch_port  # the only oracle use in bench: the CPU baseline leg
     folded = torch_port.fold_state_dict(sd)
     threads = torch.get_num_threads()
+    cpu_model, physical, logical = host_cpu()
     torch_port.inference(MODEL, mel, folded, cfg)
     best = float("inf")
     n = 0
@@ -104,10 +130,91 @@ def cpu_baseline(cfg, sd, mel):
         y = torch_port.inference(MODEL, mel, folded, cfg)
         best = min(best, time.perf_counter() - t0)
         n = int(y.numel())
+    short = mel[:max(mel.shape[0] // 4, 1)]
+    torch.set_num_threads(1)
+    try:
+        t0 = time.perf_counter()
+        y1 = torch_port.inference(MODEL, short, folded, cfg)
+        one = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(threads)
+    n1 = int(y1.numel())
     return {"value": n / best, "unit": "samples/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model, "physical_cores": physical, "logical_cpus": logical,
             "sample": f"1 utterance, mel 80x{mel.shape[0]} -> {n} samples, best of 3 after 1 warm-up, "
-                      f"ATen port of the reference generator, {threads} threads",
-            "seconds": best}
+                      f"ATen port of the reference generator, {threads} threads ({physical} physical cores, {cpu_model})",
+            "seconds": best,
+            "one_thread": {"value": n1 / one, "unit": "samples/s", "cores": 1, "seconds": one,
+                           "rtf_22k05": one / (n1 / 22050.0),
+                           "sample": f"the first {short.shape[0]} frames of the same mel -> {n1} samples, ONE pass on one "
+                                     "thread (torch.set_num_threads(1)), no warm-up"}}
+
+
+# The other single-GPU BASELINE.json configs (parity-test cases; the headline stays configs[1]): label, model name, yaml,
+# batch, frames, golden fixture, timed steps.  Utterance 0 of every batch is the mel its golden was made from.
+OTHER_CONFIGS = [
+    ("config1_melgan_T200_B1", "melgan", "conf/melgan/original.yaml", 1, 200, "synthesize_melgan.npz", 50),
+    ("config3_mb_hifigan_light_pqmf_B32", "multiband-hifigan", "conf/multiband-hifigan/light.yaml", 32, 1000, "full_mb_light.npz", 4),
+    ("config4_basis_melgan_light_B64", "basis-melgan", "conf/basis-melgan/light.yaml", 64, 1000, "full_basis.npz", 4),
+]
+
+
+def other_configs(dev):
+    """BASELINE.json configs 1, 3 and 4 on this GPU, driver-timed in the same line as the headline: ms/step, samples/s,
+    RTF, algorithmic TFLOP/s -- each with utterance 0 of its LAST timed output checked against the reference's golden."""
+    import yaml
+    out = {}
+    for label, name, path, B, T, golden, steps in OTHER_CONFIGS:
+        with open(os.path.join(ROOT, path)) as f:
+            cfg = yaml.safe_load(f)
+        m = build_generator(name, cfg)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(name, cfg, seed=0).items()})
+        m = m.to(dev).eval()
+        m.remove_weight_norm()
+        g = np.load(os.path.join(ROOT, "tests", "golden", golden))
+        if name == "melgan":
+            first = np.random.RandomState(0).rand(80, T).astype(np.float32)      # config 1's mel (make_golden.py)
+        else:
+            first = seeded_mel(T, seed=1).T
+        rows = [first] + [seeded_mel(T, seed=2 + i).T for i in range(B - 1)]
+        mel = torch.from_numpy(np.ascontiguousarray(np.stack(rows), dtype=np.float32)).to(dev)
+        if name == "multiband-hifigan":
+            fn = lambda: m.synthesize_batch(mel)          # trunk + conv_post + tanh + PQMF synthesis: `inference` per row
+        elif name == "basis-melgan":
+            fn = lambda: m._samples(mel)                  # trunk + basis matmul + overlap-add: `inference` per row
+        else:
+            fn = lambda: m(mel)
+        with torch.no_grad():
+            y = fn()                                      # plan build (weight packing): not a step
+            torch.cuda.synchronize()
+            _native.profile_enable(True)
+            fn()
+            torch.cuda.synchronize()
+            _native.profile_enable(False)
+            prof = _native.profile_collect(-1)
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                y = fn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+        assert not m.check_range(), label
+        row = y[0].double().cpu().numpy().reshape(-1)
+        if name == "melgan":
+            err = float(np.abs(row - g["est"].astype(np.float64)).max())
+        else:
+            assert row.size == int(g["T1000_n"]), (label, row.size, int(g["T1000_n"]))
+            err = float(np.abs(row[g["T1000_idx"]] - g["T1000_samples"]).max())
+        assert err <= TOL, f"{label}: output differs from the reference golden by {err:.3e} > {TOL}"
+        n = int(y.numel())
+        out[label] = {"model": name, "conf": path, "batch": B, "frames": T, "steps": steps, "ms_per_step": 1e3 * dt,
+                      "value": n / dt, "unit": "samples/s", "rtf_22k05": dt / (n / 22050.0),
+                      "algorithmic_tflops": prof["flops"] / dt / 1e12, "launches_per_step": int(prof["launches"]),
+                      "max_abs_vs_reference_golden": err, "golden": "tests/golden/" + golden}
+        del m, mel, y
+        torch.cuda.empty_cache()
+    return out
 
 
 def timed_steps(step, steps, warmup, dist, dev, after=None):
@@ -409,6 +516,7 @@ def main():
                     help="light, N > 1: leave the waveforms on the ranks that made them (headline without the gather)")
     ap.add_argument("--no-job", action="store_true", help="light: skip the appended strong-scaling job (configs[4])")
     ap.add_argument("--no-exact", action="store_true", help="light: skip the exact-fp32 leg")
+    ap.add_argument("--no-others", action="store_true", help="light: skip BASELINE configs 1, 3, 4 (other_configs)")
     args = ap.parse_args()
     steps = args.steps if args.steps is not None else (50 if args.config == "light" else 2)
     warmup = args.warmup if args.warmup is not None else (5 if args.config == "light" else 1)
@@ -582,6 +690,9 @@ def main():
             if not args.no_cpu_baseline and world == 1:
                 out["cpu_baseline"] = cpu_baseline(cfg, sd, seeded_mel(T_FRAMES, seed=1))
                 out["cpu_baseline"]["rtf_22k05"] = out["cpu_baseline"]["seconds"] / (samples_per_utt / 22050.0)
+    if args.config == "light" and not args.no_others and world == 1 and rank == 0:
+        # ---- BASELINE configs 1, 3, 4: parity cases, driver-timed beside the headline (~1 s of GPU time) -------------
+        out["other_configs"] = other_configs(dev)
     if args.config == "light" and not args.no_job:
         # ---- the strong-scaling job, appended: one timed step (all ranks take part) --------------------------------
         del model

@@ -139,6 +139,11 @@ def lib():
     L.fv_pack_conv_transpose1d_weight.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.fv_conv1d_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, f, i, f, vp]
     L.fv_conv_transpose1d_fused.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, i, f, vp]
+    L.fv_packed_basis_floats.argtypes = [i, i]
+    L.fv_packed_basis_floats.restype = i64
+    L.fv_pack_basis.argtypes = [vp, vp, i, i, vp]
+    L.fv_basis_ola.argtypes = [vp, vp, vp, i, i, i, i, vp]
+    L.fv_generator_run.argtypes = [vp, i, i, vp, vp, vp, i64, vp]
     L.fv_packed_conv_transpose1d_split_floats.argtypes = [i, i, i, i]
     L.fv_packed_conv_transpose1d_split_floats.restype = i64
     L.fv_pack_conv_transpose1d_split_f16.argtypes = [vp, vp, i, i, i, i, vp, vp]
@@ -556,6 +561,27 @@ def conv_transpose1d_fused(x, packed, bias, cout, k, stride, pad, out_pad, pre_s
                                               _ptr(out_act, "out_act", True), B, cin, cout, T, k, stride,
                                               pad, out_pad, float(pre_slope), post, float(act_slope),
                                               stream))
+    return out
+
+
+def pack_basis(W):
+    """BasisSignalLayer weight W [L, C] (nn.Linear.weight) -> fv_pack_basis image (flat tensor)."""
+    L_, c = W.shape
+    n = lib().fv_packed_basis_floats(L_, c)
+    if n <= 0:
+        raise NativeError(f"pack_basis: L={L_} (even, >= 2) C={c}")
+    out = torch.empty(n, dtype=torch.float32, device=W.device)
+    with _on(W, out) as stream:
+        check(lib().fv_pack_basis(_ptr(W, "W"), _ptr(out), L_, c, stream))
+    return out
+
+
+def basis_ola(weight, packed_basis, L_):
+    """fv_basis_ola: weight [B, C, F] (channel-major trunk output) -> [B, 1, (F - 1) L/2 + L]."""
+    B, c, F = weight.shape
+    out = torch.empty((B, 1, (F - 1) * (L_ // 2) + L_), dtype=torch.float32, device=weight.device)
+    with _on(weight, packed_basis, out) as stream:
+        check(lib().fv_basis_ola(_ptr(weight, "weight"), _ptr(packed_basis, "packed_basis"), _ptr(out), B, c, F, L_, stream))
     return out
 
 

@@ -914,6 +914,40 @@ int fv_conv_transpose1d_fused(const float* x, const float* packed, const float* 
     return run_op(o, x, y, y_act, nullptr, nullptr, nullptr, B, Tin, (hipStream_t)stream);
 }
 
+// ---- BasisSignalLayer + overlap_and_add (reference modules.py:255-267, :34-73) under its own name ----
+// frames = weight W^T, out[hop f + j] += frames[f, j]: a ConvTranspose1d with Cin = C, Cout = 1, k = L, stride = hop = L / 2,
+// pad = 0 whose weight [C, 1, L] is W^T -- the frame tensor [B, F, L] is never materialised.  fv_pack_basis transposes
+// nn.Linear's W [L, C] into the scratch behind the packed image and packs it like any transposed-conv weight.
+__global__ void transpose_basis_kernel(const float* __restrict__ W, float* __restrict__ wT, int L, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L * C) wT[(i % C) * L + i / C] = W[i];      // W[j][c] -> wT[c][0][j]
+}
+
+int64_t fv_packed_basis_floats(int L, int C) {
+    if (L < 2 || L % 2 != 0 || C <= 0) return 0;
+    return fv_packed_conv_transpose1d_floats(C, 1, L, L / 2, 0) + (int64_t)L * C;
+}
+
+int fv_pack_basis(const float* W, float* packed, int L, int C, void* stream) {
+    if (!W || !packed) return fail(FV_ERR_INVALID_ARG, "pack_basis: null tensor");
+    if (fv_packed_basis_floats(L, C) <= 0) return fail(FV_ERR_INVALID_ARG, "pack_basis: L=%d (even, >= 2) C=%d", L, C);
+    float* wT = packed + fv_packed_conv_transpose1d_floats(C, 1, L, L / 2, 0);
+    hipLaunchKernelGGL(transpose_basis_kernel, dim3((unsigned)((L * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, wT, L, C);
+    FV_HIP(hipGetLastError());
+    return fv_pack_conv_transpose1d_weight(wT, packed, C, 1, L, L / 2, 0, stream);
+}
+
+int fv_basis_ola(const float* weight, const float* packed_basis, float* out, int B, int C, int F, int L, void* stream) {
+    if (L < 2 || L % 2 != 0) return fail(FV_ERR_INVALID_ARG, "basis_ola: L=%d (even, >= 2)", L);
+    return fv_conv_transpose1d_fused(weight, packed_basis, nullptr, out, nullptr, B, C, 1, F, L, L / 2, 0, 0, 1.f, FV_POST_NONE,
+                                     1.f, stream);
+}
+
+int fv_generator_run(fv_plan_t* plan, int B, int T, const float* mel, float* out, void* workspace, int64_t workspace_bytes,
+                     void* stream) {
+    return fv_plan_run(plan, B, T, mel, out, workspace, workspace_bytes, stream);
+}
+
 // ---- ConvTranspose1d with split-f16 operands (convt_kernel) ----
 static int check_convt_split_args(int Cin, int Cout, int k, int stride, int pad, int out_pad) {
     if (Cin != 64 && Cin != 128 && Cin != 256 && Cin != 512)

@@ -300,6 +300,19 @@ int fv_conv_transpose1d_fused(const float* x, const float* packed, const float* 
                               int post, float act_slope, void* stream);
 
 /*
+ * BasisSignalLayer + overlap_and_add (reference model/generator/modules.py:255-267, :34-73; Basis-MelGAN's last step,
+ * basis_melgan.py:140-162): frames = weight W^T (F.linear, no bias), out[hop f + j] += frames[f, j], hop = L / 2.
+ *   weight [B, C, F]: the trunk's output as it lies in memory (channel-major: the reference's transpose(1, 2) view);
+ *   W [L, C]: basis_signal.layer.weight;   out [B, 1, hop (F - 1) + L]   (L = 30, C = 256: [B, 15 F + 15]).
+ * One launch: the op is a ConvTranspose1d(C -> 1, kernel L, stride hop, pad 0) with weight W^T on the fp32-MFMA kernel
+ * (fv_conv_transpose1d_fused); the [B, F, L] frame tensor is never materialised.  packed_basis: fv_pack_basis of W
+ * (fv_packed_basis_floats(L, C) floats: the packed image and, behind it, the transposed weight it was made from).
+ */
+int64_t fv_packed_basis_floats(int L, int C);
+int fv_pack_basis(const float* W, float* packed, int L, int C, void* stream);
+int fv_basis_ola(const float* weight, const float* packed_basis, float* out, int B, int C, int F, int L, void* stream);
+
+/*
  * y = post( conv1d( nearest_repeat(lrelu(x, pre_slope), rate); w, padding = pad ) + bias )
  *
  * Replaces the reference's UpsampleLayer (modules.py:160-177: Stretch2d nearest x rate,
@@ -492,6 +505,11 @@ int fv_plan_run(fv_plan_t* plan, int B, int T, const float* in, float* out,
 int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, float* out2,
                     const float* const* aux_in, const int* aux_batched, void* workspace,
                     int64_t workspace_bytes, void* stream);
+
+/* The whole-graph entry under the name SURVEY.md section 8(b) lists: the generator forward of a built plan,
+ * mel [B,Cin0,T] -> out [B,Cout,Tout] (fv_plan_run; workspace: fv_plan_workspace_bytes(plan, B, T)). */
+int fv_generator_run(fv_plan_t* plan, int B, int T, const float* mel, float* out, void* workspace,
+                     int64_t workspace_bytes, void* stream);
 
 /* number of kernel launches one fv_plan_run enqueues */
 int fv_plan_num_ops(fv_plan_t* plan);

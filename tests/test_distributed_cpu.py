@@ -96,6 +96,83 @@ def _worker(rank, world, port, B, out_path):
         dist.destroy_process_group()
 
 
+def _fake_generator_counting(calls):
+    def fn(mels):
+        calls.append(int(mels.shape[0]))
+        return _fake_generator(mels)
+    return fn
+
+
+def _worker_job(rank, world, port, B, T):
+    """BASELINE config 5's shape on CPU: 512 utterances (tiny T) scattered from the root over 8 ranks, int16 sink,
+    gathered back; a ragged batch where no rank may run a filler row; utterances of different lengths by length."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(7)
+        mels = torch.rand(B, 80, T, generator=g)
+
+        def sink(block):
+            return (_fake_generator(block) * 50).to(torch.int16)
+        out = parallel.synthesize_sharded(sink, mels if rank == 0 else None, scatter=True, device=torch.device("cpu"))
+        if rank == 0:
+            assert out.shape == (B, 3 * T) and out.dtype == torch.int16 and torch.equal(out, sink(mels))
+        # ragged: B' rows over `world` ranks -- every rank runs exactly its own rows (no filler-row forwards)
+        for Bp in (world + 3, 3, 1):
+            calls = []
+            out = parallel.synthesize_sharded(_fake_generator_counting(calls), mels[:Bp] if rank == 0 else None,
+                                              scatter=True, device=torch.device("cpu"))
+            lo, hi = parallel.shard_range(Bp, world, rank)
+            assert calls == ([hi - lo] if hi > lo else []), (rank, Bp, calls)
+            if rank == 0:
+                assert torch.equal(out, _fake_generator(mels[:Bp]))
+        # utterances of different lengths: longest-first assignment, results in utterance order on the root
+        lens = [int(v) for v in torch.randint(3, 40, (3 * world + 1,), generator=torch.Generator().manual_seed(3))]
+        ragged = [torch.rand(80, n, generator=torch.Generator().manual_seed(100 + i)) for i, n in enumerate(lens)]
+        res = parallel.synthesize_ragged(_fake_generator, ragged)
+        if rank == 0:
+            assert len(res) == len(ragged)
+            for r, m in zip(res, ragged):
+                assert torch.equal(r, _fake_generator(m[None])[0])
+        else:
+            assert res is None
+        # one flat broadcast for a whole module tree (parameters AND buffers, mixed dtypes)
+        torch.manual_seed(rank)
+        net = torch.nn.Sequential(torch.nn.Conv1d(3, 4, 3), torch.nn.BatchNorm1d(4), torch.nn.Linear(4, 2))
+        parallel.broadcast_weights(net, src=0)
+        torch.manual_seed(0)
+        ref = torch.nn.Sequential(torch.nn.Conv1d(3, 4, 3), torch.nn.BatchNorm1d(4), torch.nn.Linear(4, 2))
+        for (ka, a), (kb, b) in zip(sorted(net.state_dict().items()), sorted(ref.state_dict().items())):
+            assert ka == kb and a.dtype == b.dtype and torch.equal(a, b), ka
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_job_of_512_utterances_over_8_ranks_gloo():
+    """BASELINE.json configs[4]'s control flow at full utterance count and world size (tiny T), on CPU."""
+    mp.spawn(_worker_job, args=(8, _free_port(), 512, 4), nprocs=8, join=True)
+
+
+def test_length_sorted_assignment_balances_ragged_batches():
+    rng = np.random.RandomState(0)
+    for world in (2, 3, 8):
+        for n in (1, 5, 8, 40, 513):
+            lens = rng.randint(50, 3000, size=n).tolist()
+            plan = parallel.assign_by_length(lens, world)
+            assert sorted(i for ix in plan for i in ix) == list(range(n))                 # a partition
+            assert all(ix == sorted(ix) for ix in plan)
+            loads = [sum(lens[i] for i in ix) for ix in plan]
+            opt = max(max(lens), -(-sum(lens) // world))                                   # lower bound of any assignment
+            assert max(loads) <= (4.0 / 3.0) * opt + 1, (world, n, max(loads), opt)
+            assert plan == parallel.assign_by_length(lens, world)                          # deterministic
+    # contiguous blocks of a length-sorted batch would put all the long utterances on one rank
+    lens = list(range(100, 900, 100))
+    loads = [sum(lens[i] for i in ix) for ix in parallel.assign_by_length(lens, 2)]
+    assert abs(loads[0] - loads[1]) <= 100
+
+
 @pytest.mark.parametrize("world,B", [(2, 5), (2, 4), (3, 7), (2, 1)])
 def test_sharded_synthesis_gloo(tmp_path, world, B):
     port = _free_port()

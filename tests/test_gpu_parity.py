@@ -417,6 +417,41 @@ def test_conv_transpose_no_padding_is_overlap_add():
     assert _rel(y[:, 0, :], ref) <= 2e-5
 
 
+def test_basis_ola_and_generator_run_entries():
+    """SURVEY.md section 8(b)'s named C entries.  fv_basis_ola (+ fv_pack_basis of nn.Linear's W [L, C]) against the
+    oracle's linear + overlap_and_add and against the reference's own BasisSignalLayer output (blocks.npz `basis_out`);
+    fv_generator_run = fv_plan_run on a built plan, same bits as the module's forward."""
+    import ctypes
+    rng = np.random.RandomState(5)
+    W = rng.uniform(-0.2, 0.2, size=(30, 48)).astype(np.float32)
+    wt = np.abs(rng.randn(2, 48, 37)).astype(np.float32)
+    dev = _dev()
+    y = _native.basis_ola(torch.from_numpy(wt).to(dev), _native.pack_basis(torch.from_numpy(W).to(dev)), 30)
+    assert tuple(y.shape) == (2, 1, 36 * 15 + 30) and _rel(y[:, 0, :], oo.basis_ola(wt, W, 15)) <= 2e-5
+    g = np.load(os.path.join(golden_dir, "blocks.npz"))
+    bw = torch.from_numpy(g["basis_weight"]).to(dev).transpose(1, 2).contiguous()       # [B, F, C] -> [B, C, F]
+    y = _native.basis_ola(bw, _native.pack_basis(torch.from_numpy(g["basis_W"]).to(dev)), 30)
+    assert _rel(y[:, 0, :], g["basis_out"]) <= 2e-5
+    with pytest.raises(_native.NativeError, match="even"):
+        _native.pack_basis(torch.zeros((7, 16), device=dev))
+    # fv_generator_run: the plan of a small HiFi-GAN, called through the C entry with a caller-owned workspace
+    tag, name, cfg = next(c for c in cases.SMALL if c[0] == "hifigan_s")
+    m, _ = _model(name, cfg, seed=7)
+    x = torch.from_numpy(np.ascontiguousarray(seeded_mel(cases.SMALL_T, seed=5).T[None])).to(dev)
+    with torch.no_grad():
+        want = m(x)
+        plan = m._trunk_plan(x.shape[2])
+    L = _native.lib()
+    ws_bytes = L.fv_plan_workspace_bytes(plan._h, 1, x.shape[2])
+    ws = torch.empty(max(ws_bytes, 4) // 4 + 64, dtype=torch.float32, device=dev)
+    out = torch.empty_like(want).unsqueeze(1).contiguous()
+    torch.cuda.synchronize()
+    _native.check(L.fv_generator_run(plan._h, 1, x.shape[2], ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                     ctypes.c_void_p(ws.data_ptr()), ws_bytes, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, 0, :], want)
+
+
 def test_fold_weight_norm_vs_torch():
     rng = np.random.RandomState(9)
     for shape in [(64, 32, 7), (128, 64, 16), (5, 3, 1)]:
