@@ -112,26 +112,24 @@ __device__ __forceinline__ void convh_load_raw(ConvHRaw<G>& r, const float* xb, 
 // (low: the low side of the range guard, pairh_kernels.hpp LowGuard; which: the operand tensor the window belongs to)
 template <class G>
 __device__ __forceinline__ void convh_convert(const ConvHRaw<G>& r, char* ximg, float slope, int tid, LowGuard& low, int which = 0) {
+    float lowm = 0.f;
 #pragma unroll
     for (int q = 0; q < G::XR; ++q) {
         const int idx = tid + q * G::NT;
         const int cb = idx / G::XROWS, row = idx - cb * G::XROWS;
-        f16x8 h1, h2;
-        float va[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float v = split_act(r.v[q][j], slope);
-            va[j] = v;
-            const _Float16 a = (_Float16)v;
-            h1[j] = a;
-            h2[j] = split_rem(v, a);
-        }
-        low_note(low, which, low_max8(va));
         if (idx < G::XROWS * G::CB) {
-            *reinterpret_cast<f16x8*>(ximg + (cb * G::XRP + row) * 16) = h1;
-            *reinterpret_cast<f16x8*>(ximg + (cb * G::XRP + row) * 16 + G::XHALF) = h2;
+            F16x8Parts h1, h2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2 a = split_act2(f32x2{r.v[q][2 * j], r.v[q][2 * j + 1]}, slope);
+                lowm = low_max3(lowm, a.x, a.y);
+                split2(a, h1.p[j], h2.p[j]);
+            }
+            *reinterpret_cast<f16x8*>(ximg + (cb * G::XRP + row) * 16) = __builtin_bit_cast(f16x8, h1);
+            *reinterpret_cast<f16x8*>(ximg + (cb * G::XRP + row) * 16 + G::XHALF) = __builtin_bit_cast(f16x8, h2);
         }
     }
+    low_note(low, which, lowm);
 }
 
 // one stage of packed weights -> ring slot (2 DMA instructions per wave); byte_off: offset of the stage inside the

@@ -96,6 +96,34 @@ void pair_schedule(PairParams& p, int nblk, bool three_members) {
     p.sched_on = 1;
 }
 
+// pair_kernels.hpp pair_share on the host (the same integers)
+static long long host_share(long long blk, long long total, long long base, int cost, long long n, int nblk) {
+    const long long num = blk * total - base * nblk;
+    if (num <= 0) return 0;
+    const long long den = (long long)cost * nblk;
+    const long long j = (num + den - 1) / den;
+    return j > n ? n : j;
+}
+
+void pair_cut_schedule(PairParams& p, int nblk, const long long* n) {
+    if (nblk < 1 || nblk > 2 * kSchedBlocks) return;
+    long long total = 0, items = 0;
+    for (int m = 0; m < p.n_members; ++m) {
+        total += n[m] * p.m[m].cost;
+        items += n[m];
+    }
+    if (items >= (1LL << 31)) return;
+    for (int i = 0; i < nblk; ++i) {
+        long long g = 0, base = 0;
+        for (int m = 0; m < p.n_members; ++m) {
+            g += host_share(i, total, base, p.m[m].cost, n[m], nblk);
+            base += n[m] * p.m[m].cost;
+        }
+        p.sched[i] = (unsigned)g;
+    }
+    p.sched_on = 2;
+}
+
 // run-time mirror of ConvHGeom<>
 ConvHShape convh_shape(int C, int k, int dil) {
     ConvHShape g = {};

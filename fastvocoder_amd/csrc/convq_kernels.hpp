@@ -97,7 +97,8 @@ __device__ __forceinline__ void convq_run_member(const PairParams& p, const Pair
     int b = item / mb.n_tiles, tile = item - b * mb.n_tiles;
     if (!first) pair_barrier();
     LowGuard low;                                        // low side of the range guard (pairh_kernels.hpp)
-    float bad = 0.f;                                     // range guard (pairh_kernels.hpp range_note4)
+    f32x2 bad2 = {0.f, 0.f};                             // range guard (pairh_kernels.hpp range_note4p)
+    const float rcp = div_rcp(p.out_div);                // the MRF mean's divisor (pair_kernels.hpp div_exact)
     ConvHRaw<G> raw;
     convh_load_raw<G>(raw, mb.x + b * ustride, p.T, tile * G::NOUT - G::P1 - G::P2, tid, true);
 #pragma unroll
@@ -229,32 +230,19 @@ __device__ __forceinline__ void convq_run_member(const PairParams& p, const Pair
             // conv1 -> intermediate image: column u of the tile is time t0 - P2 + u; conv2's zero padding applies to
             // the intermediate: columns outside [0, T) are zero, not conv1 of the padded input
             const int tm = t0 - G::P2;
+            const bool inside = tm >= 0 && tm + G::NM <= p.T;     // (uniform) no column of this tile needs the mask
             float lowm = 0.f;                            // largest magnitude of this tile's intermediate in this lane
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                float bv[4], sv[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    bv[i] = bl[row0 + 16 * h + i];
-                    sv[i] = bl[2 * G::C + row0 + 16 * h + i];
-                }
+                const f32x2* const b2 = reinterpret_cast<const f32x2*>(bl + row0 + 16 * h);
+                const f32x2* const s2 = reinterpret_cast<const f32x2*>(bl + 2 * G::C + row0 + 16 * h);
+                const f32x2 b01 = b2[0], b23 = b2[1], s01 = s2[0], s23 = s2[1];
 #pragma unroll
                 for (int f = 0; f < G::NFW; ++f) {
                     const int t = tm + col0 + f * 16;
-                    const bool ok = t >= 0 && t < p.T;
                     f16x4 h1, h2;
-                    float va[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float v = split_act(fmaf(fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]), sv[i], bv[i]), p.slope);
-                        v = ok ? v : 0.f;
-                        va[i] = v;
-                        const _Float16 a = (_Float16)v;
-                        h1[i] = a;
-                        h2[i] = split_rem(v, a);
-                    }
-                    lowm = low_max3(lowm, va[0], va[1]);
-                    lowm = low_max3(lowm, va[2], va[3]);
+                    if (inside) split_mid4<false>(hi[h][f], lo[h][f], s01, s23, b01, b23, p.slope, true, h1, h2, lowm);
+                    else split_mid4<true>(hi[h][f], lo[h][f], s01, s23, b01, b23, p.slope, t >= 0 && t < p.T, h1, h2, lowm);
                     *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16)) = h1;
                     *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16) + G::MHALF) = h2;
                 }
@@ -281,17 +269,11 @@ __device__ __forceinline__ void convq_run_member(const PairParams& p, const Pair
         const bool fin = mb.add1 != nullptr;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            float bv[4], sv[4];
+            const f32x2* const b2 = reinterpret_cast<const f32x2*>(bl + G::C + row0 + 16 * h);
+            const f32x2* const s2 = reinterpret_cast<const f32x2*>(bl + 3 * G::C + row0 + 16 * h);
+            const f32x2 b01 = b2[0], b23 = b2[1], s01 = s2[0], s23 = s2[1];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                bv[i] = bl[G::C + row0 + 16 * h + i];
-                sv[i] = bl[3 * G::C + row0 + 16 * h + i];
-            }
-#pragma unroll
-            for (int f = 0; f < G::NFW; ++f)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    hi[h][f][i] = fmaf(fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]), sv[i], bv[i]) + res[h][f][i];
+            for (int f = 0; f < G::NFW; ++f) combine4(hi[h][f], lo[h][f], s01, s23, b01, b23, res[h][f]);
         }
         if (fin) {
             const __amdgpu_buffer_rsrc_t r1 = make_rsrc(mb.add1 + b * ustride, ubytes);
@@ -321,9 +303,9 @@ __device__ __forceinline__ void convq_run_member(const PairParams& p, const Pair
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = hi[h][f][i];
                 const int col = col0 + f * 16;
-                range_note4(bad, v[0], v[1], v[2], v[3], col < G::NOUT && t0 + col < p.T);
+                range_note4p(bad2, hi[h][f]);         // (every column is computed from real, zero-padded data)
                 pair_store(p, mb.y, mb.y_act, G::C, b, row0 + 16 * h, t0 + col,
-                           col < G::NOUT && t0 + col < p.T && !(p.dbg & 8), v, fin);
+                           col < G::NOUT && t0 + col < p.T && !(p.dbg & 8), v, fin, rcp);
             }
         if (more && !(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid, low);
         if (!more) break;
@@ -333,7 +315,7 @@ __device__ __forceinline__ void convq_run_member(const PairParams& p, const Pair
         tile = ntile;
     }
     pair_wait_vm0();
-    range_flag(p, bad);
+    range_flag(p, bad2.x + bad2.y);
     low_flag(p, low, bl + 4 * G::C, wave, lane, 8);
 }
 

@@ -304,6 +304,10 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t stream);
 // assignment instead of the contiguous cut, written into p.sched (host cache per shape); p.sched_on = 0 when every block
 // has many items anyway
 void pair_schedule(PairParams& p, int nblk, bool three_members = false);
+// The kernels' own contiguous, cost-balanced cut (pair_share) computed on the host: p.sched[i] = the global item number
+// (members concatenated) share i starts at, i = 0 .. nblk - 1 (nblk <= 2 kSchedBlocks entries), p.sched_on = 2; n[m]: items
+// of member m.  Left alone (sched_on unchanged) when the table does not fit.
+void pair_cut_schedule(PairParams& p, int nblk, const long long* n);
 // fused ResBlock pair at C = 64 with split-f16 operands and streamed weights (convp_kernels.hpp): members use x, w1, w2
 // (fv_pack_pair_weight_ex images), b1, b2, add1 / add2, y, y_act, k
 int launch_convp(PairParams p, int dil, hipStream_t stream);

@@ -307,10 +307,23 @@ __device__ __forceinline__ void pair_conv1(const PairLane<G>& L, const float* bl
     }
 }
 
+// v / d for the divisors of the MRF mean (hifigan.py:103: xs / num_kernels, a small integer) in three instructions instead
+// of the ~11 of an IEEE division: q0 = v r, e = fma(-d, q0, v) (the exact residual), q = fma(e, r, q0) with r = RN(1 / d)
+// is the correctly rounded quotient for every finite v whose quotient is a normal number (Markstein; checked exhaustively
+// over all 2^24 significands for d = 1 .. 16 on the CPU, tests/test_split_precision.py, and on the GPU against the
+// hardware's own division, fv_div_probe).  Non-finite v: the range guard has fired anyway.
+// div_rcp: 1 / d where that holds, else 0 (-> IEEE division).
+__device__ __forceinline__ float div_rcp(float d) { return (d >= 1.f && d <= 16.f && d == truncf(d)) ? 1.f / d : 0.f; }
+__device__ __forceinline__ float div_exact(float v, float d, float r) {
+    const float q0 = v * r;
+    return fmaf(fmaf(-d, q0, v), r, q0);
+}
+
 // final stores of a tile: v = post(v / out_div), y (and the activated twin)
+// (rcp: div_rcp(p.out_div) computed once per run, or 0)
 template <int AUX = 0>
 __device__ __forceinline__ void pair_store(const PairCore& p, float* y, float* y_act, int C, int b, int row0, int t,
-                                           bool ok, float (&v)[4], bool finish) {
+                                           bool ok, float (&v)[4], bool finish, float rcp = 0.f) {
     const size_t boff = (size_t)b * C * (size_t)p.T;
     const unsigned bytes = (unsigned)C * (unsigned)p.T * 4u;
     const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + boff, bytes);
@@ -318,8 +331,13 @@ __device__ __forceinline__ void pair_store(const PairCore& p, float* y, float* y
     const unsigned t4 = (unsigned)p.T * 4u;
     if (finish) {
         if (p.out_div != 1.f) {
+            if (rcp != 0.f) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = v[i] / p.out_div;
+                for (int i = 0; i < 4; ++i) v[i] = div_exact(v[i], p.out_div, rcp);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = v[i] / p.out_div;
+            }
         }
         if (p.post == FV_POST_TANH) {
 #pragma unroll

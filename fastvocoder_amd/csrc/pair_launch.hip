@@ -131,8 +131,13 @@ static int launch_pairs_split(PairParams p, int C, int dil, hipStream_t s) {
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
     p.sched_on = 0;
+    {
+        long long n[3] = {0, 0, 0};
+        for (int i = 0; i < p.n_members; ++i) n[i] = (long long)p.m[i].n_tiles * p.B;
+        pair_cut_schedule(p, p.nblk, n);           // the blocks' shares as a table in the kernel arguments
+    }
     p.dbg = tuning().pair_dbg;
-    p.trace = nullptr;
+    p.trace = reinterpret_cast<unsigned long long*>(tuning().trace_ptr);
     profile_begin(s);
     const int rc = C == 16 ? launch_pairh_geom<1, FV_PAIRH16_NF, FV_PAIRH16_NG>(p, dil, lds, s) : launch_pairh_geom<2, 1, FV_PAIRH32_NG>(p, dil, lds, s);
     profile_end(s, C == 16 ? FV_KERNEL_PAIRH16 : FV_KERNEL_PAIRH32, flops, bytes);

@@ -60,6 +60,36 @@ __device__ __forceinline__ _Float16 split_rem(float v, _Float16 h1) {
     return (_Float16)fmaf((float)h1, -kSplitScale, v * kSplitScale);
 }
 
+// ---- the same arithmetic on PAIRS of elements, with the instructions spelled out (round 4) ---------------------------
+// Per element the split is lrelu (v_pk_mul_f32 for two elements + v_max_f32), h1 = f16(a) (v_cvt_pk_f16_f32 for two),
+// a * 2048 (v_pk_mul_f32 for two) and h2 = f16(fma(h1, -2048, a * 2048)) -- v_fma_mixlo_f16 / v_fma_mixhi_f16: the f16
+// operand is read straight from its half of the packed register, the fp32 result is rounded to f16 into one half of the
+// destination: conversion and packing are part of the instruction.  3.5 VALU instructions per element where hipcc's own
+// selection of the scalar code above took 5.6 (it converted h1 back to fp32 for three of four pairs).  Bit for bit the
+// same values: (a - h1) * 2048 is exact in fp32 either way.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 split_act2(f32x2 v, float slope) {
+    const f32x2 t = v * f32x2{slope, slope};
+    f32x2 r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r.x) : "v"(v.x), "v"(t.x));
+    asm("v_max_f32 %0, %1, %2" : "=v"(r.y) : "v"(v.y), "v"(t.y));
+    return r;
+}
+// a (activated, fp32) -> h1 = f16(a), h2 = f16((a - h1) * 2048), two elements
+__device__ __forceinline__ void split2(f32x2 a, f16x2& h1, f16x2& h2) {
+    h1 = __builtin_convertvector(a, f16x2);
+    const f32x2 a2 = a * f32x2{kSplitScale, kSplitScale};
+    const float neg = -kSplitScale;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(h2) : "v"(h1), "s"(neg), "v"(a2.x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(h2) : "v"(h1), "s"(neg), "v"(a2.y));
+}
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+struct F16x8Parts {
+    f16x2 p[4];
+};
+
 // Range guard of the split-f16 kernels.  An operand beyond the f16 range (|v| >= 65520: f16(v) = inf) turns every output
 // it feeds into inf or NaN -- where the fp32 reference stays finite.  Every split kernel therefore folds its final values
 // into one register per thread (v * 0 is NaN exactly when v is inf or NaN: one VALU instruction per stored element) and a
@@ -126,6 +156,46 @@ __device__ __forceinline__ void low_flag(const PairCore& p, const LowGuard& g, f
         if (((all & 2u) && !(all & 1u)) || ((all & 8u) && !(all & 4u))) *p.guard = 4;
     }
     pair_barrier();                                      // scratch may be written again (the block's next member)
+}
+
+// ---- epilogue pieces of the fused pairs, on pairs of rows (v_pk_fma_f32 / v_pk_mul_f32) --------------------------------
+// A D fragment holds four consecutive rows of one column; s / b: the rows' inverse weight prescales and biases as two
+// register pairs each (rows 0-1, 2-3).
+// conv1 -> the intermediate's image entry: m = lrelu((hi + lo / 2048) s + b, slope), zero outside the sequence (MASK: only
+// tiles that touch a sequence end pay for the select), split into h1 / h2; lowm: the lane's largest magnitude (LowGuard)
+template <bool MASK>
+__device__ __forceinline__ void split_mid4(const f32x4& hi, const f32x4& lo, f32x2 s01, f32x2 s23, f32x2 b01, f32x2 b23,
+                                           float slope, bool ok, f16x4& h1, f16x4& h2, float& lowm) {
+    const f32x2 c = {kSplitInv, kSplitInv};
+    f32x2 a01 = split_act2(fma2(fma2(f32x2{lo[0], lo[1]}, c, f32x2{hi[0], hi[1]}), s01, b01), slope);
+    f32x2 a23 = split_act2(fma2(fma2(f32x2{lo[2], lo[3]}, c, f32x2{hi[2], hi[3]}), s23, b23), slope);
+    if constexpr (MASK) {
+        a01.x = ok ? a01.x : 0.f;
+        a01.y = ok ? a01.y : 0.f;
+        a23.x = ok ? a23.x : 0.f;
+        a23.y = ok ? a23.y : 0.f;
+    }
+    lowm = low_max3(lowm, a01.x, a01.y);
+    lowm = low_max3(lowm, a23.x, a23.y);
+    f16x2 p0, q0, p1, q1;
+    split2(a01, p0, q0);
+    split2(a23, p1, q1);
+    h1 = f16x4{p0.x, p0.y, p1.x, p1.y};
+    h2 = f16x4{q0.x, q0.y, q1.x, q1.y};
+}
+// conv2: (hi + lo / 2048) s + b + res -> hi (res: four floats, rows 0 .. 3)
+__device__ __forceinline__ void combine4(f32x4& hi, const f32x4& lo, f32x2 s01, f32x2 s23, f32x2 b01, f32x2 b23,
+                                         const float (&res)[4]) {
+    const f32x2 c = {kSplitInv, kSplitInv};
+    const f32x2 v01 = fma2(fma2(f32x2{lo[0], lo[1]}, c, f32x2{hi[0], hi[1]}), s01, b01) + f32x2{res[0], res[1]};
+    const f32x2 v23 = fma2(fma2(f32x2{lo[2], lo[3]}, c, f32x2{hi[2], hi[3]}), s23, b23) + f32x2{res[2], res[3]};
+    hi = f32x4{v01.x, v01.y, v23.x, v23.y};
+}
+// the range guard on a fragment, two rows per instruction (bad2: NaN in either half once a value was not finite)
+__device__ __forceinline__ void range_note4p(f32x2& bad2, const f32x4& v) {
+    const f32x2 z = {0.f, 0.f};
+    bad2 = fma2(f32x2{v[0], v[1]}, z, bad2);
+    bad2 = fma2(f32x2{v[2], v[3]}, z, bad2);
 }
 
 // ---- chained launches (fv_internal.h PairChain): per-item flags instead of kernel boundaries -----------------------
@@ -225,53 +295,92 @@ struct PairHGeom {
 };
 
 // ---- raw x window: global -> registers (a whole tile ahead) -> image [XROWS][h1 | h2], activated -------------
-// task = (row t of the window, block of 8 channels); a thread owns XR tasks, lanes along t (coalesced rows)
+// task = (row t of the window, block of 8 channels), lanes along t (coalesced rows).  The tasks are FULL whole rounds of
+// the block's NT threads plus REM left-over tasks.  Round 3 gave the left-over tasks to threads 0 .. REM - 1: at C = 16
+// (632 tasks, 512 threads) waves 0 and 1 converted twice what the other six did and the whole block waited for them at the
+// tile's last barrier [measured, tools/pairh_trace.py: convert 2000 against 1000-1200 cycles].  Now a left-over task is cut
+// into Q parts of 8 / Q channels (Q = 4 when 4 REM threads exist, else 2, else 1) that go to Q x REM threads: the longest
+// conversion of a tile is 1 + 1/Q rounds instead of 2.
 template <class G>
 struct PairHRaw {
     static constexpr int CB = G::C / 8;
-    static constexpr int XR = (G::XROWS * CB + G::NT - 1) / G::NT;
-    float v[XR][8];
+    static constexpr int TASKS = G::XROWS * CB;
+    static constexpr int FULL = TASKS / G::NT, REM = TASKS - FULL * G::NT;
+    static constexpr int Q = REM == 0 ? 1 : 4 * REM <= G::NT ? 4 : 2 * REM <= G::NT ? 2 : 1;
+    static constexpr int PART = 8 / Q;                 // channels of a left-over part
+    float v[FULL > 0 ? FULL : 1][8];
+    float w[PART];
 };
 
 // tA: time of window row 0; rows outside [0, T) read as zero (per-lane offset: the descriptor only bounds the tensor)
 template <class G>
 __device__ __forceinline__ void pairh_load_raw(PairHRaw<G>& r, const float* xb, int T, int tA, int tid) {
+    typedef PairHRaw<G> R;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)G::C * (unsigned)T * 4u);
     const unsigned t4 = (unsigned)T * 4u;
 #pragma unroll
-    for (int q = 0; q < PairHRaw<G>::XR; ++q) {
+    for (int q = 0; q < R::FULL; ++q) {
         const int idx = tid + q * G::NT;
         const int cb = idx / G::XROWS, row = idx - cb * G::XROWS;
         const int t = tA + row;
-        const bool ok = idx < G::XROWS * PairHRaw<G>::CB && t >= 0 && t < T;
-        const unsigned voff = ok ? (unsigned)(cb * 8 * T + t) * 4u : kOutOfRange;
+        const unsigned voff = t >= 0 && t < T ? (unsigned)(cb * 8 * T + t) * 4u : kOutOfRange;
 #pragma unroll
         for (int j = 0; j < 8; ++j) r.v[q][j] = buffer_load1s(rx, voff, (unsigned)j * t4);
+    }
+    if constexpr (R::REM > 0) {
+        const int idx = R::FULL * G::NT + tid / R::Q, part = tid % R::Q;
+        const int cb = idx / G::XROWS, row = idx - cb * G::XROWS;
+        const int t = tA + row;
+        const bool ok = tid < R::Q * R::REM && t >= 0 && t < T;
+        const unsigned voff = ok ? (unsigned)((cb * 8 + part * R::PART) * T + t) * 4u : kOutOfRange;
+#pragma unroll
+        for (int j = 0; j < R::PART; ++j) r.w[j] = buffer_load1s(rx, voff, (unsigned)j * t4);
     }
 }
 
 template <class G>
 __device__ __forceinline__ void pairh_convert(const PairHRaw<G>& r, char* ximg, float slope, int tid, LowGuard& low) {
+    typedef PairHRaw<G> R;
+    float lowm = 0.f;
 #pragma unroll
-    for (int q = 0; q < PairHRaw<G>::XR; ++q) {
+    for (int q = 0; q < R::FULL; ++q) {
         const int idx = tid + q * G::NT;
         const int cb = idx / G::XROWS, row = idx - cb * G::XROWS;
-        f16x8 h1, h2;
-        float va[8];
+        F16x8Parts h1, h2;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float v = split_act(r.v[q][j], slope);
-            va[j] = v;
-            const _Float16 a = (_Float16)v;
-            h1[j] = a;
-            h2[j] = split_rem(v, a);
+        for (int j = 0; j < 4; ++j) {
+            const f32x2 a = split_act2(f32x2{r.v[q][2 * j], r.v[q][2 * j + 1]}, slope);
+            lowm = low_max3(lowm, a.x, a.y);
+            split2(a, h1.p[j], h2.p[j]);
         }
-        low_note(low, 0, low_max8(va));
-        if (idx < G::XROWS * PairHRaw<G>::CB) {
-            *reinterpret_cast<f16x8*>(ximg + (cb * G::XRP + row) * 16) = h1;
-            *reinterpret_cast<f16x8*>(ximg + (cb * G::XRP + row) * 16 + G::XHALF) = h2;
+        *reinterpret_cast<f16x8*>(ximg + (cb * G::XRP + row) * 16) = __builtin_bit_cast(f16x8, h1);
+        *reinterpret_cast<f16x8*>(ximg + (cb * G::XRP + row) * 16 + G::XHALF) = __builtin_bit_cast(f16x8, h2);
+    }
+    if constexpr (R::REM > 0) {
+        if (tid < R::Q * R::REM) {
+            const int idx = R::FULL * G::NT + tid / R::Q, part = tid % R::Q;
+            const int cb = idx / G::XROWS, row = idx - cb * G::XROWS;
+            char* const dst = ximg + (cb * G::XRP + row) * 16 + part * (2 * R::PART);
+            f16x2 h1[R::PART / 2], h2[R::PART / 2];
+#pragma unroll
+            for (int j = 0; j < R::PART / 2; ++j) {
+                const f32x2 a = split_act2(f32x2{r.w[2 * j], r.w[2 * j + 1]}, slope);
+                lowm = low_max3(lowm, a.x, a.y);
+                split2(a, h1[j], h2[j]);
+            }
+            if constexpr (R::PART == 2) {
+                *reinterpret_cast<f16x2*>(dst) = h1[0];
+                *reinterpret_cast<f16x2*>(dst + G::XHALF) = h2[0];
+            } else if constexpr (R::PART == 4) {
+                *reinterpret_cast<f16x4*>(dst) = f16x4{h1[0].x, h1[0].y, h1[1].x, h1[1].y};
+                *reinterpret_cast<f16x4*>(dst + G::XHALF) = f16x4{h2[0].x, h2[0].y, h2[1].x, h2[1].y};
+            } else {
+                *reinterpret_cast<f16x8*>(dst) = f16x8{h1[0].x, h1[0].y, h1[1].x, h1[1].y, h1[2].x, h1[2].y, h1[3].x, h1[3].y};
+                *reinterpret_cast<f16x8*>(dst + G::XHALF) = f16x8{h2[0].x, h2[0].y, h2[1].x, h2[1].y, h2[2].x, h2[2].y, h2[3].x, h2[3].y};
+            }
         }
     }
+    low_note(low, 0, lowm);
 }
 
 // the two weight images of a member: global -> LDS by LDS-DMA ([conv1 | conv2], G::WB bytes each)
@@ -419,7 +528,10 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
     int item = item0;
     int b = item / mb.n_tiles, tile = item - b * mb.n_tiles;
     if (!first) pair_barrier();                         // everybody is done with the previous member's LDS
+    pair_stamp(p, G::NW, wave, lane, 7, 12);
     float bad = 0.f;                                    // range guard: NaN once a final value was not finite
+    f32x2 bad2 = {0.f, 0.f};                            //   (two rows per instruction outside the FOLD variant)
+    const float rcp = div_rcp(p.out_div);               // the MRF mean's divisor (pair_kernels.hpp div_exact)
     LowGuard low;                                       // ... and its low side: were the operands small as a whole
     PairHRaw<G> raw;
     pairh_load_raw<G>(raw, mb.x + b * ustride, p.T, tile * TSTRIDE - TSHIFT - HEAD, tid);
@@ -431,9 +543,11 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
     pair_wait_vm0();
     pairh_convert<G>(raw, ximg, p.slope, tid, low);
     pair_barrier();
+    pair_stamp(p, G::NW, wave, lane, 7, 13);
     for (;;) {
         const int t0 = tile * TSTRIDE - TSHIFT;
         const int nitem = item + 1;
+        pair_stamp(p, G::NW, wave, lane, item - item0, 0);   // (tuning aid, -DFV_PAIR_TRACE: tools/pairh_trace.py)
         const bool more = nitem < hi_item;
         int nb = b, ntile = tile + 1;
         if (ntile == mb.n_tiles) {
@@ -441,6 +555,9 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
             ++nb;
         }
         // the next tile's raw window: in flight for the whole tile; then this tile's residual (fp32, L2 hits)
+        // (requesting the window of the tile AFTER the next right behind the conversion instead -- the registers are free
+        // from there -- was measured slower: 383 against 338 us per three-member launch at C = 32, B = 8: the loads then
+        // compete with the tile's own stores and residual reads; round 4, tools/build_variant.py)
         if (more && !(p.dbg & 1)) pairh_load_raw<G>(raw, mb.x + nb * ustride, p.T, ntile * TSTRIDE - TSHIFT - HEAD, tid);
         float res[G::MH][G::NF][4];
         const unsigned ubytes = (unsigned)G::C * (unsigned)p.T * 4u;
@@ -465,66 +582,53 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
 #pragma unroll
             for (int f = 0; f < G::NF; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!(p.dbg & 4)) pairh_mma<G, G::TPS * G::DIL * 16, G::XHALF>(wl, xb, hi, lo, lane);
+        pair_stamp(p, G::NW, wave, lane, item - item0, 1);
         {
             // intermediate column u of the tile is time t0 - P2 + u; conv2's zero padding applies to the
             // intermediate: columns outside [0, T) are zero, not conv1 of the padded input
             const int tm = t0 - G::P2;
+            const bool inside = tm >= 0 && tm + G::NM <= p.T;     // (uniform) no column of this tile needs the mask
             float lowm = 0.f;                            // largest magnitude of this tile's intermediate in this lane
 #pragma unroll
             for (int h = 0; h < G::MH; ++h) {
-                float bv[4], sv[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    bv[i] = bl[16 * h + row0 + i];
-                    sv[i] = bl[2 * G::C + 16 * h + row0 + i];
-                }
+                const f32x2* const b2 = reinterpret_cast<const f32x2*>(bl + 16 * h + row0);
+                const f32x2* const s2 = reinterpret_cast<const f32x2*>(bl + 2 * G::C + 16 * h + row0);
+                const f32x2 b01 = b2[0], b23 = b2[1], s01 = s2[0], s23 = s2[1];
 #pragma unroll
                 for (int f = 0; f < G::NF; ++f) {
                     const int t = tm + col0 + f * 16;
-                    const bool ok = t >= 0 && t < p.T;
                     f16x4 h1, h2;
-                    float va[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float v = split_act(fmaf(fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]), sv[i], bv[i]), p.slope);
-                        v = ok ? v : 0.f;
-                        va[i] = v;
-                        const _Float16 a = (_Float16)v;
-                        h1[i] = a;
-                        h2[i] = split_rem(v, a);
-                    }
-                    lowm = low_max3(lowm, va[0], va[1]);
-                    lowm = low_max3(lowm, va[2], va[3]);
+                    if (inside) split_mid4<false>(hi[h][f], lo[h][f], s01, s23, b01, b23, p.slope, true, h1, h2, lowm);
+                    else split_mid4<true>(hi[h][f], lo[h][f], s01, s23, b01, b23, p.slope, t >= 0 && t < p.T, h1, h2, lowm);
                     *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16)) = h1;
                     *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16) + G::MHALF) = h2;
                 }
             }
             low_note(low, 1, lowm);
         }
+        pair_stamp(p, G::NW, wave, lane, item - item0, 2);
         pair_barrier();                                  // (C) intermediate complete, x image free
+        pair_stamp(p, G::NW, wave, lane, item - item0, 3);
 #pragma unroll
         for (int h = 0; h < G::MH; ++h)
 #pragma unroll
             for (int f = 0; f < G::NF; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!(p.dbg & 4)) pairh_mma<G, G::TPS * 16, G::MHALF>(wl + G::WB / 4, mbase, hi, lo, lane);
+        pair_stamp(p, G::NW, wave, lane, item - item0, 4);
         // raw window and residual have been in flight for two conv phases; no store is outstanding here
         // (the previous tile's were issued a tile ago and are drained with the same wait)
         pair_wait_vm0();
+        pair_stamp(p, G::NW, wave, lane, item - item0, 5);
         if (more && !(p.dbg & 2)) pairh_convert<G>(raw, ximg, p.slope, tid, low);
+        pair_stamp(p, G::NW, wave, lane, item - item0, 6);
         const bool fin = mb.add1 != nullptr;
 #pragma unroll
         for (int h = 0; h < G::MH; ++h) {
-            float bv[4], sv[4];
+            const f32x2* const b2 = reinterpret_cast<const f32x2*>(bl + G::C + 16 * h + row0);
+            const f32x2* const s2 = reinterpret_cast<const f32x2*>(bl + 3 * G::C + 16 * h + row0);
+            const f32x2 b01 = b2[0], b23 = b2[1], s01 = s2[0], s23 = s2[1];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                bv[i] = bl[G::C + 16 * h + row0 + i];
-                sv[i] = bl[3 * G::C + 16 * h + row0 + i];
-            }
-#pragma unroll
-            for (int f = 0; f < G::NF; ++f)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    hi[h][f][i] = fmaf(fmaf(lo[h][f][i], kSplitInv, hi[h][f][i]), sv[i], bv[i]) + res[h][f][i];
+            for (int f = 0; f < G::NF; ++f) combine4(hi[h][f], lo[h][f], s01, s23, b01, b23, res[h][f]);
         }
         if (fin) {
             // last launch of an MRF stage: (r0 + r1) + r2 in the reference's order (hifigan.py:99-103)
@@ -547,12 +651,19 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
 #pragma unroll
                     for (int i = 0; i < 4; ++i) hi[h][f][i] = (hi[h][f][i] + lo[h][f][i]) + res[h][f][i];
         }
+        pair_stamp(p, G::NW, wave, lane, item - item0, 7);
+        // (FOLD: the activated tile below overwrites the zeroed rows behind the intermediate, so discarded columns can read
+        // any bit pattern there: only stored values count.  Otherwise every column is computed from real, zero-padded data.)
 #pragma unroll
         for (int h = 0; h < G::MH; ++h)
 #pragma unroll
             for (int f = 0; f < G::NF; ++f) {
-                const int col = col0 + f * 16, t = t0 + col;
-                range_note4(bad, hi[h][f][0], hi[h][f][1], hi[h][f][2], hi[h][f][3], col < G::NOUT && t >= 0 && t < p.T);
+                if constexpr (FOLD) {
+                    const int col = col0 + f * 16, t = t0 + col;
+                    range_note4(bad, hi[h][f][0], hi[h][f][1], hi[h][f][2], hi[h][f][3], col < G::NOUT && t >= 0 && t < p.T);
+                } else {
+                    range_note4p(bad2, hi[h][f]);
+                }
             }
         if constexpr (FOLD) {
             // the activated tile -> LDS (the intermediate image's space: every wave is past its conv2 reads after the
@@ -568,7 +679,7 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float v = hi[h][f][i];
-                        if (fin) v = v / p.out_div;
+                        if (fin) v = rcp != 0.f ? div_exact(v, p.out_div, rcp) : v / p.out_div;
                         sb[(16 * h + row0 + i) * G::NM + col] = ok ? act(v, p.act_slope) : 0.f;
                     }
                 }
@@ -597,16 +708,18 @@ __device__ __forceinline__ void pairh_run_member(const PairParams& p, const Pair
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = hi[h][f][i];
                 pair_store(p, mb.y, mb.y_act, G::C, b, 16 * h + row0, t0 + col,
-                           col < G::NOUT && t0 + col < p.T && !(p.dbg & 8), v, fin);
+                           col < G::NOUT && t0 + col < p.T && !(p.dbg & 8), v, fin, rcp);
             }
         }
+        pair_stamp(p, G::NW, wave, lane, item - item0, 8);
         if (!more) break;
         pair_barrier();                                  // (A) the next x image is complete; the intermediate is free
+        pair_stamp(p, G::NW, wave, lane, item - item0, 9);
         item = nitem;
         b = nb;
         tile = ntile;
     }
-    range_flag(p, bad);
+    range_flag(p, bad + (bad2.x + bad2.y));
     low_flag(p, low, bl + 4 * G::C, wave, lane, G::NW);
 }
 
@@ -629,6 +742,7 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu(pairh_w
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    pair_stamp(p, NG, wave, lane, 7, 15);
     // the launch's scalars in one batch of kernarg loads (see convh_kernel: left to itself hipcc loads every field
     // right before its first use, a chain of dependent s_load round trips between kernel entry and the first tile)
     PairParams q;
@@ -643,18 +757,40 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu(pairh_w
                  "s"(q.post), "s"(q.x_off), "s"(q.img_off), "s"(q.mid_off), "s"(q.bias_off), "s"(q.dbg), "s"(q.trace),
                  "s"(n_tiles[0]), "s"(n_tiles[1]), "s"(n_tiles[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]), "s"(q.fold_w),
                  "s"(q.fold_b), "s"(q.fold_y), "s"(q.guard));
+    // This block's share of the cost-weighted item sequence (members one after the other): from the host's table when
+    // there is one (p.sched_on == 2, pair_cut_schedule: the global item number every share starts at -- two scalar loads
+    // instead of ~600 scalar instructions of 64-bit arithmetic between kernel entry and the first load, 1.8 us per launch
+    // [measured, tools/pairh_trace.py]), else computed here (pair_share).
+    const int share = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const bool cut = p.sched_on == 2;
+    int g_lo = 0, g_hi = 0;
+    if (cut) {
+        g_lo = (int)p.sched[share];                     // (nblk entries; the last share ends with the last item)
+        g_hi = share + 1 < q.nblk ? (int)p.sched[share + 1] : (n_tiles[0] + (q.n_members > 1 ? n_tiles[1] : 0) + (q.n_members > 2 ? n_tiles[2] : 0)) * q.B;
+        asm volatile("" ::"s"(g_lo), "s"(g_hi));
+    }
     long long total = 0;
+    if (!cut) {
 #pragma unroll
-    for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_tiles[m] * q.B * cost[m] : 0;
+        for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_tiles[m] * q.B * cost[m] : 0;
+    }
     long long base = 0;
+    int off = 0;
     bool first = true;
     for (int m = 0; m < q.n_members; ++m) {
         const int nt = m == 0 ? n_tiles[0] : m == 1 ? n_tiles[1] : n_tiles[2];
         const int cm = m == 0 ? cost[0] : m == 1 ? cost[1] : cost[2];
         const int n = nt * q.B;
-        const int lo = pair_share(xcd_remap((int)blockIdx.x, (int)gridDim.x), total, base, cm, n, q.nblk);
-        const int hi = pair_share(xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1, total, base, cm, n, q.nblk);
-        base += (long long)n * cm;
+        int lo, hi;
+        if (cut) {
+            lo = min(max(g_lo - off, 0), n);
+            hi = min(max(g_hi - off, 0), n);
+            off += n;
+        } else {
+            lo = pair_share(share, total, base, cm, n, q.nblk);
+            hi = pair_share(share + 1, total, base, cm, n, q.nblk);
+            base += (long long)n * cm;
+        }
         if (lo >= hi) continue;
         // ... and this member's pointers and sizes in one more
         PairMember mb;

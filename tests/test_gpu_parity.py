@@ -428,7 +428,7 @@ def test_basis_ola_and_generator_run_entries():
     dev = _dev()
     y = _native.basis_ola(torch.from_numpy(wt).to(dev), _native.pack_basis(torch.from_numpy(W).to(dev)), 30)
     assert tuple(y.shape) == (2, 1, 36 * 15 + 30) and _rel(y[:, 0, :], oo.basis_ola(wt, W, 15)) <= 2e-5
-    g = np.load(os.path.join(golden_dir, "blocks.npz"))
+    g = np.load(os.path.join(cases.ROOT, "tests", "golden", "blocks.npz"))
     bw = torch.from_numpy(g["basis_weight"]).to(dev).transpose(1, 2).contiguous()       # [B, F, C] -> [B, C, F]
     y = _native.basis_ola(bw, _native.pack_basis(torch.from_numpy(g["basis_W"]).to(dev)), 30)
     assert _rel(y[:, 0, :], g["basis_out"]) <= 2e-5

@@ -22,6 +22,19 @@ def child(lib, batch, model_name):
     import torch
     from fastvocoder_amd import _native
     _native.LIB_PATH = os.path.abspath(lib)
+    import ctypes
+
+    class Tolerant(ctypes.CDLL):            # an older build lacks the newest entry points: bind a stub that is never called
+        def __getattr__(self, name):
+            try:
+                return super().__getattr__(name)
+            except AttributeError:
+                if not name.startswith("fv_"):
+                    raise
+                stub = ctypes.CFUNCTYPE(ctypes.c_int)(lambda: -1)
+                setattr(self, name, stub)
+                return stub
+    _native.ctypes.CDLL = Tolerant
     import bench
     dev = torch.device("cuda:0")
     model, cfg, sd = bench.build_model(model_name, dev, None, 0)

@@ -7,6 +7,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fastvocoder_amd import _native  # noqa: E402
+import _ablib  # noqa: E402
+_ablib.use_lib_from_env(_native)
 
 
 def bench(fn, reps=20):
