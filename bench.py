@@ -76,7 +76,9 @@ def load_conf(config):
 def utterance_mels(first, count):
     """[count, 80, T] forward-layout mels of the global utterances first .. first+count-1; utterance i is
     ``seeded_mel(T, seed=1+i)``: utterance 0 is the mel of tests/golden/full_hifigan_light.npz (seed 1)."""
-    return np.stack([seeded_mel(T_FRAMES, seed=1 + first + i).T for i in range(count)]).astype(np.float32)
+    # (C-contiguous: np.stack keeps the transposed views' memory order, and a strided mel would make every forward start with
+    # a copy kernel inside the timed region -- the workload is "mel resident in HBM", in the layout forward() takes)
+    return np.ascontiguousarray(np.stack([seeded_mel(T_FRAMES, seed=1 + first + i).T for i in range(count)]), dtype=np.float32)
 
 
 def check_against_golden(wav_row):

@@ -549,8 +549,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                  "s"(q.guard));
     // this block's items of each member: from the host's schedule (pair_schedule: few, unequal items per block), or its
     // contiguous share of the cost-weighted item sequence
-    const bool sched = p.sched_on != 0;
+    const bool sched = p.sched_on == 1, cut = p.sched_on == 2;      // 2: the contiguous cut as a table (pair_cut_schedule)
     int slo[3] = {0, 0, 0}, shi[3] = {0, 0, 0};
+    int g_lo = 0, g_hi = 0;
+    if (cut) {
+        const int share = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+        g_lo = (int)p.sched[share];
+        g_hi = share + 1 < q.nblk ? (int)p.sched[share + 1] : n_items[0] + (q.n_members > 1 ? n_items[1] : 0) + (q.n_members > 2 ? n_items[2] : 0);
+        asm volatile("" ::"s"(g_lo), "s"(g_hi));
+    }
     if (sched) {
         // two words of the kernel arguments per block: (lo : 11, count : 5) of member 0 | member 1 << 16, member 2
         const unsigned w0 = p.sched[2 * xcd_remap((int)blockIdx.x, (int)gridDim.x)], w1 = p.sched[2 * xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1];
@@ -560,9 +567,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("" ::"s"(slo[0]), "s"(shi[0]), "s"(slo[1]), "s"(shi[1]), "s"(slo[2]), "s"(shi[2]));
     }
     long long total = 0;
+    if (!sched && !cut) {
 #pragma unroll
-    for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_items[m] * cost[m] : 0;
+        for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_items[m] * cost[m] : 0;
+    }
     long long base = 0;
+    int off = 0;
     bool first = true;
     for (int m = 0; m < q.n_members; ++m) {
         const int n = m == 0 ? n_items[0] : m == 1 ? n_items[1] : n_items[2];
@@ -571,11 +581,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (sched) {
             lo = m == 0 ? slo[0] : m == 1 ? slo[1] : slo[2];
             hi = m == 0 ? shi[0] : m == 1 ? shi[1] : shi[2];
+        } else if (cut) {
+            lo = min(max(g_lo - off, 0), n);
+            hi = min(max(g_hi - off, 0), n);
+            off += n;
         } else {
             lo = pair_share(xcd_remap((int)blockIdx.x, (int)gridDim.x), total, base, cm, n, q.nblk);
             hi = pair_share(xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1, total, base, cm, n, q.nblk);
+            base += (long long)n * cm;
         }
-        base += (long long)n * cm;
         if (lo >= hi) continue;
         // ... and this member's pointers and sizes in one more
         PairMember mb;
@@ -616,7 +630,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                  "s"(q.trace), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.ups), "s"(q.pad_t), "s"(q.Tout), "s"(q.cout), "s"(mb.x), "s"(mb.w1),
                  "s"(mb.b1), "s"(mb.y), "s"(mb.y_act), "s"(mb.n_tiles), "s"(n_items), "s"(q.guard));
     // equal items: block b takes [b n / nblk, (b + 1) n / nblk)
-    const int lo = (int)((long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * n_items / q.nblk), hi = (int)((long long)(xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1) * n_items / q.nblk);
+    const int lo = equal_share(xcd_remap((int)blockIdx.x, (int)gridDim.x), n_items, q.nblk), hi = equal_share(xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1, n_items, q.nblk);
     if (lo < hi) convh_run_member<ConvHGeom<CG, 2, 2, 1, true>>(q, mb, lo, hi, smem, wave, lane, true);
 }
 
@@ -642,7 +656,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                  "s"(q.dbg), "s"(q.trace), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.guard), "s"(q.sub), "s"(q.sub_batched), "s"(mb.x), "s"(mb.x2), "s"(mb.w1),
                  "s"(mb.b1), "s"(mb.res), "s"(mb.y), "s"(mb.y_act), "s"(mb.n_tiles), "s"(n_items));
     // equal items: block b takes [b n / nblk, (b + 1) n / nblk) -- row tiles of one column tile stay together
-    const int lo = (int)((long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * n_items / q.nblk), hi = (int)((long long)(xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1) * n_items / q.nblk);
+    const int lo = equal_share(xcd_remap((int)blockIdx.x, (int)gridDim.x), n_items, q.nblk), hi = equal_share(xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1, n_items, q.nblk);
     if (lo < hi) convh_run_member<ConvHGeom<CG, 2, 1, 1, false, true>>(q, mb, lo, hi, smem, wave, lane, true);
 }
 

@@ -200,6 +200,11 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
     pair_schedule(p, p.nblk);
+    if (!p.sched_on) {                 // no per-block schedule: the kernels' contiguous cut, as a table instead of arithmetic
+        long long n[3] = {0, 0, 0};
+        for (int i = 0; i < p.n_members; ++i) n[i] = p.m[i].n_items;
+        pair_cut_schedule(p, p.nblk, n);
+    }
     p.dbg = tuning().pair_dbg;
     p.trace = reinterpret_cast<unsigned long long*>(tuning().trace_ptr);
     profile_begin(s);
@@ -369,6 +374,11 @@ static int prepare_convp(PairParams& p, int dil, size_t& lds_out, double& flops,
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
     pair_schedule(p, p.nblk);
+    if (!p.sched_on) {                 // no per-block schedule: the kernels' contiguous cut, as a table instead of arithmetic
+        long long n[3] = {0, 0, 0};
+        for (int i = 0; i < p.n_members; ++i) n[i] = p.m[i].n_items;
+        pair_cut_schedule(p, p.nblk, n);
+    }
     p.dbg = tuning().pair_dbg;
     p.trace = reinterpret_cast<unsigned long long*>(tuning().trace_ptr);
     lds_out = lds;
@@ -651,6 +661,11 @@ int launch_convq(PairParams p, int dil, hipStream_t s) {
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
     pair_schedule(p, p.nblk, true);
+    if (!p.sched_on) {                 // no per-block schedule: the kernels' contiguous cut, as a table instead of arithmetic
+        long long n[3] = {0, 0, 0};
+        for (int i = 0; i < p.n_members; ++i) n[i] = p.m[i].n_items;
+        pair_cut_schedule(p, p.nblk, n);
+    }
     p.dbg = tuning().pair_dbg;
     p.trace = nullptr;
     profile_begin(s);

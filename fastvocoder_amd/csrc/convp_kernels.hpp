@@ -356,8 +356,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                  "s"(n_items[0]), "s"(n_items[1]), "s"(n_items[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]), "s"(q.guard));
     // this block's items of each member: from the host's schedule (pair_schedule: few, unequal items per block), or its
     // contiguous share of the cost-weighted item sequence
-    const bool sched = p.sched_on != 0;
+    const bool sched = p.sched_on == 1, cut = p.sched_on == 2;      // 2: the contiguous cut as a table (pair_cut_schedule)
     int slo[3] = {0, 0, 0}, shi[3] = {0, 0, 0};
+    int g_lo = 0, g_hi = 0;
+    if (cut) {
+        const int share = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+        g_lo = (int)p.sched[share];
+        g_hi = share + 1 < q.nblk ? (int)p.sched[share + 1] : n_items[0] + (q.n_members > 1 ? n_items[1] : 0) + (q.n_members > 2 ? n_items[2] : 0);
+        asm volatile("" ::"s"(g_lo), "s"(g_hi));
+    }
     if (sched) {
         // two words of the kernel arguments per block: (lo : 11, count : 5) of member 0 | member 1 << 16, member 2
         const unsigned w0 = p.sched[2 * xcd_remap((int)blockIdx.x, (int)gridDim.x)], w1 = p.sched[2 * xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1];
@@ -367,9 +374,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("" ::"s"(slo[0]), "s"(shi[0]), "s"(slo[1]), "s"(shi[1]), "s"(slo[2]), "s"(shi[2]));
     }
     long long total = 0;
+    if (!sched && !cut) {
 #pragma unroll
-    for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_items[m] * cost[m] : 0;
+        for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_items[m] * cost[m] : 0;
+    }
     long long base = 0;
+    int off = 0;
     bool first = true;
     for (int m = 0; m < q.n_members; ++m) {
         const int n = m == 0 ? n_items[0] : m == 1 ? n_items[1] : n_items[2];
@@ -378,11 +388,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (sched) {
             lo = m == 0 ? slo[0] : m == 1 ? slo[1] : slo[2];
             hi = m == 0 ? shi[0] : m == 1 ? shi[1] : shi[2];
+        } else if (cut) {
+            lo = min(max(g_lo - off, 0), n);
+            hi = min(max(g_hi - off, 0), n);
+            off += n;
         } else {
             lo = pair_share(xcd_remap((int)blockIdx.x, (int)gridDim.x), total, base, cm, n, q.nblk);
             hi = pair_share(xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1, total, base, cm, n, q.nblk);
+            base += (long long)n * cm;
         }
-        base += (long long)n * cm;
         if (lo >= hi) continue;
         PairMember mb;
         mb.x = p.m[m].x; mb.w1 = p.m[m].w1; mb.w2 = p.m[m].w2; mb.b1 = p.m[m].b1; mb.b2 = p.m[m].b2; mb.add1 = p.m[m].add1;

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                  "s"(q.dbg), "s"(q.trace), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.guard), "s"(q.sub), "s"(q.sub_batched), "s"(mb.x), "s"(mb.x2), "s"(mb.w1),
                  "s"(mb.b1), "s"(mb.res), "s"(mb.y), "s"(mb.y_act), "s"(mb.n_tiles), "s"(n_items));
     // equal items: block b takes [b n / nblk, (b + 1) n / nblk) -- the row pairs of one column tile stay together
-    const int lo = (int)((long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * n_items / q.nblk), hi = (int)((long long)(xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1) * n_items / q.nblk);
+    const int lo = equal_share(xcd_remap((int)blockIdx.x, (int)gridDim.x), n_items, q.nblk), hi = equal_share(xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1, n_items, q.nblk);
     if (lo < hi) convr_run<ConvRGeom<1, 1, true>>(q, mb, lo, hi, smem, wave, lane, true);
 }
 
@@ -404,8 +404,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                  "s"(q.post), "s"(q.x_off), "s"(q.img_off), "s"(q.dbg), "s"(q.trace), "s"(n_items[0]), "s"(n_items[1]),
                  "s"(n_items[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.reflect),
                  "s"(q.guard));
-    const bool sched = p.sched_on != 0;
+    const bool sched = p.sched_on == 1, cut = p.sched_on == 2;      // 2: the contiguous cut as a table (pair_cut_schedule)
     int slo[3] = {0, 0, 0}, shi[3] = {0, 0, 0};
+    int g_lo = 0, g_hi = 0;
+    if (cut) {
+        const int share = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+        g_lo = (int)p.sched[share];
+        g_hi = share + 1 < q.nblk ? (int)p.sched[share + 1] : n_items[0] + (q.n_members > 1 ? n_items[1] : 0) + (q.n_members > 2 ? n_items[2] : 0);
+        asm volatile("" ::"s"(g_lo), "s"(g_hi));
+    }
     if (sched) {
         const unsigned w0 = p.sched[2 * xcd_remap((int)blockIdx.x, (int)gridDim.x)], w1 = p.sched[2 * xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1];
         slo[0] = (int)(w0 & 2047u);         shi[0] = slo[0] + (int)((w0 >> 11) & 31u);
@@ -414,9 +421,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("" ::"s"(slo[0]), "s"(shi[0]), "s"(slo[1]), "s"(shi[1]), "s"(slo[2]), "s"(shi[2]));
     }
     long long total = 0;
+    if (!sched && !cut) {
 #pragma unroll
-    for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_items[m] * cost[m] : 0;
+        for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_items[m] * cost[m] : 0;
+    }
     long long base = 0;
+    int off = 0;
     bool first = true;
     for (int m = 0; m < q.n_members; ++m) {
         const int n = m == 0 ? n_items[0] : m == 1 ? n_items[1] : n_items[2];
@@ -425,11 +435,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (sched) {
             lo = m == 0 ? slo[0] : m == 1 ? slo[1] : slo[2];
             hi = m == 0 ? shi[0] : m == 1 ? shi[1] : shi[2];
+        } else if (cut) {
+            lo = min(max(g_lo - off, 0), n);
+            hi = min(max(g_hi - off, 0), n);
+            off += n;
         } else {
             lo = pair_share(xcd_remap((int)blockIdx.x, (int)gridDim.x), total, base, cm, n, q.nblk);
             hi = pair_share(xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1, total, base, cm, n, q.nblk);
+            base += (long long)n * cm;
         }
-        base += (long long)n * cm;
         if (lo >= hi) continue;
         PairMember mb;
         mb.x = p.m[m].x; mb.x2 = nullptr; mb.w1 = p.m[m].w1; mb.b1 = p.m[m].b1; mb.res = p.m[m].res; mb.add1 = p.m[m].add1;
@@ -464,7 +478,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                  "s"(q.trace), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.ups), "s"(q.pad_t), "s"(q.Tout), "s"(q.cout), "s"(mb.x), "s"(mb.w1),
                  "s"(mb.b1), "s"(mb.y), "s"(mb.y_act), "s"(mb.n_tiles), "s"(n_items), "s"(q.guard));
     const int blk = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int lo = (int)((long long)blk * n_items / q.nblk), hi = (int)((long long)(blk + 1) * n_items / q.nblk);
+    const int lo = equal_share(blk, n_items, q.nblk), hi = equal_share(blk + 1, n_items, q.nblk);
     if (lo < hi) convr_run<ConvRGeom<2, 1, false, true>>(q, mb, lo, hi, smem, wave, lane, true);
 }
 

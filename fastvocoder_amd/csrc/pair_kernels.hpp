@@ -473,6 +473,12 @@ __device__ __forceinline__ int pair_share(long long blk, long long total, long l
     return j > n ? n : (int)j;
 }
 
+// equal items: block blk takes [blk n / nblk, (blk + 1) n / nblk) -- in 32 bits whenever the product fits (a 64-bit division
+// is a few hundred scalar instructions between kernel entry and the first load)
+__device__ __forceinline__ int equal_share(int blk, int n, int nblk) {
+    return n < (1 << 21) ? (int)((unsigned)blk * (unsigned)n / (unsigned)nblk) : (int)((long long)blk * n / nblk);
+}
+
 // 16 waves per CU (4 per SIMD: <= 128 VGPRs) whatever the block size
 #define FV_PAIR_WAVES __attribute__((amdgpu_waves_per_eu(4, 4)))
 
