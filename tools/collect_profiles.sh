@@ -2,11 +2,11 @@
 # Round profile collection on the GPU box (run from the repo root through gpurun):
 #   tools/collect_profiles.sh r02
 # writes gpurun_out/<tag>/...; turn it into the committed profiles/<tag>_* with tools/summarise_profiles.py <tag>
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$PWD
 mkdir -p $R/gpurun_out/$TAG
 export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --no-job --no-exact"
+B="python $R/bench.py --no-cpu-baseline --no-job --no-exact --no-others"
 # --- the headline bench (BASELINE config 2): kernel stats, HBM traffic (two PMC passes), matrix-pipe counters ---
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/stats -o bench -- $B --steps 20 --warmup 3 > $R/gpurun_out/$TAG/bench_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/$TAG/fetch -o bench -- $B --steps 5 --warmup 2 > $R/gpurun_out/$TAG/bench_fetch.log 2>&1
