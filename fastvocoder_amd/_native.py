@@ -149,6 +149,7 @@ def lib():
     L.fv_pack_conv_transpose1d_split_f16.argtypes = [vp, vp, i, i, i, i, vp, vp]
     L.fv_conv_transpose1d_split_f16.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, f, vp, vp]
     L.fv_plan_add_conv_transpose1d_split_f16.argtypes = [vp, i, i, i, vp, vp, i, i, i, i, i, i, f, f]
+    L.fv_plan_set_input_merge.argtypes = [vp, i, i, f]
     L.fv_pqmf_synthesis.argtypes = [vp, vp, vp, i, i, i, i, vp]
     L.fv_conv1d_2src_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, f, vp]
     L.fv_plan_add_conv1d_2src.argtypes = [vp, i, i, i, i, i, vp, vp, i, i, i, i, f]
@@ -717,13 +718,17 @@ class Plan:
                                                  float(act_slope)))
 
     def add_conv_transpose1d_split_f16(self, x, y, packed, bias, cin, cout, k, stride, pad, out_pad, pre_slope=1.0,
-                                       y_act=SLOT_NONE, act_slope=1.0):
+                                       y_act=SLOT_NONE, act_slope=1.0, merge=None):
+        """``merge = (add1_slot, add2_slot, div)``: the input is ((x + add1) + add2) / div, formed in the kernel's window
+        loader (fv_plan_set_input_merge: the MRF merge of hifigan.py:99-103 inside the upsampler behind the stage)."""
         self.keep(packed)
         if bias is not None:
             self.keep(bias)
         check(lib().fv_plan_add_conv_transpose1d_split_f16(self._h, x, y, y_act, _ptr(packed, "packed"),
                                                            _ptr(bias, "bias", True), cin, cout, k, stride, pad, out_pad,
                                                            float(pre_slope), float(act_slope)))
+        if merge is not None:
+            check(lib().fv_plan_set_input_merge(self._h, int(merge[0]), int(merge[1]), float(merge[2])))
 
     def add_conv1d_2src(self, x, x2, y, packed, bias, cin1, cin2, cout, res=SLOT_NONE, post=POST_NONE,
                         y_act=SLOT_NONE, act_slope=1.0):

@@ -402,6 +402,7 @@ struct Op {
     const float* pb2[3] = {nullptr, nullptr, nullptr};
     int pk[3] = {0, 0, 0};
     int prec = 0;             // FV_PAIR_F32 / FV_PAIR_SPLIT_F16
+    bool in_merge = false;    // fv_plan_set_input_merge (split-f16 transposed conv): the input is ((x + xb) + xc) / out_div
     // fv_plan_set_pair_output_conv: a 16 -> 1 channel, 7-tap conv folded into the pair; y is ITS output [B, 1, T]
     const float* fold_w = nullptr;
     const float* fold_b = nullptr;
@@ -477,6 +478,14 @@ static int infer(const fv_plan* plan, int B, int T, Shape* sh, int64_t* slot_ele
             if (aux[a] == FV_SLOT_NONE) continue;
             if (!sh[aux[a]].set || sh[aux[a]].C != Cout || sh[aux[a]].T != Tout)
                 return fail(FV_ERR_INVALID_ARG, "op %zu: residual/accumulator slot %d shape mismatch", n, aux[a]);
+        }
+        if (o.in_merge) {
+            const int extra[2] = {o.xb, o.xc};
+            for (int e = 0; e < 2; ++e)
+                if (extra[e] != FV_SLOT_NONE && (!sh[extra[e]].set || sh[extra[e]].C != o.Cin || sh[extra[e]].T != sh[o.x].T ||
+                                                 extra[e] == o.y || extra[e] == o.y2))
+                    return fail(FV_ERR_INVALID_ARG, "op %zu: merged input slot %d must be [%d, T] like the first and not the output",
+                                n, extra[e], o.Cin);
         }
         if (o.type == OP_MRFSUM) {
             const int extra[2] = {o.xb, o.xc};
@@ -627,6 +636,10 @@ static int run_op(const Op& o, const float* x, float* y, float* y2, const float*
         pp.m[0].b1 = o.bias;
         pp.m[0].y = y;
         pp.m[0].y_act = y2;
+        // fv_plan_set_input_merge: the input is ((x + acc) + acc2) / out_div, formed in the kernel's window loader
+        pp.m[0].add1 = acc;
+        pp.m[0].add2 = acc2;
+        pp.out_div = acc ? o.out_div : 1.f;
         return launch_convt(pp, o.Cin, o.Cout, o.stride, o.pad, (int)conv_out_len(o, Tin), s);
     }
     return launch_conv(make_params(o, x, y, y2, res, acc, acc2, B, Tin, x2, sub, sub_batched), s);
@@ -1267,6 +1280,22 @@ int fv_plan_add_conv_transpose1d_split_f16(fv_plan_t* plan, int x_slot, int y_sl
                                               out_pad, pre_slope, FV_POST_NONE, act_slope))
         return rc;
     plan->ops.back().prec = FV_PAIR_SPLIT_F16;
+    return 0;
+}
+
+int fv_plan_set_input_merge(fv_plan_t* plan, int add1_slot, int add2_slot, float div) {
+    if (!plan || plan->ops.empty()) return fail(FV_ERR_INVALID_ARG, "plan_set_input_merge: no op to attach to");
+    Op& o = plan->ops.back();
+    if (o.type != OP_CONVT || o.prec != FV_PAIR_SPLIT_F16)
+        return fail(FV_ERR_UNSUPPORTED, "plan_set_input_merge: the last op is not a split-f16 transposed conv");
+    if (add1_slot == FV_SLOT_NONE || add1_slot < 0 || add1_slot >= FV_MAX_SLOTS ||
+        (add2_slot != FV_SLOT_NONE && (add2_slot < 0 || add2_slot >= FV_MAX_SLOTS)))
+        return fail(FV_ERR_INVALID_ARG, "plan_set_input_merge: slots %d, %d", add1_slot, add2_slot);
+    if (!(div > 0.f)) return fail(FV_ERR_INVALID_ARG, "plan_set_input_merge: divisor %g", (double)div);
+    o.in_merge = true;
+    o.xb = add1_slot;
+    o.xc = add2_slot;
+    o.out_div = div;
     return 0;
 }
 
@@ -2015,6 +2044,10 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
         const float* res = o.res == FV_SLOT_NONE ? nullptr : base[o.res];
         const float* acc = o.acc == FV_SLOT_NONE ? nullptr : base[o.acc];
         const float* acc2 = o.acc2 == FV_SLOT_NONE ? nullptr : base[o.acc2];
+        if (o.type == OP_CONVT && o.in_merge) {        // merged INPUT (fv_plan_set_input_merge): xb, xc travel as acc, acc2
+            acc = base[o.xb];
+            acc2 = o.xc == FV_SLOT_NONE ? nullptr : base[o.xc];
+        }
         float* y2 = o.y2 == FV_SLOT_NONE ? nullptr : base[o.y2];
         if (int rc = run_op(o, base[o.x], base[o.y], y2, res, acc, acc2, B, Tin, s,
                             o.x2 == FV_SLOT_NONE ? nullptr : base[o.x2], o.sub == FV_SLOT_NONE ? nullptr : base[o.sub],

@@ -197,6 +197,31 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
         else return mb.x + bb * ustride + c * cstride;
     };
     auto chunk_slope = [&](int c) { return G::TWO && c >= nch / 2 ? 1.f : p.slope; };
+    // Transposed conv with a MERGED input (round 4): the upsampler behind an MRF stage reads the three ResBlocks' results
+    // r0 (member x), r1 (add1), r2 (add2) and forms x = ((r0 + r1) + r2) / out_div itself -- hifigan.py:99-103 in the
+    // reference's order -- so that the stage ends in ONE three-member pair launch instead of two launches (the second a
+    // single cheap member that waited for the other two: 18-24 us for ~9 us of work at batch 1).  The window of r0 is
+    // prefetched as before; r1 and r2 are fetched where the window is consumed (one L2 round trip per window, both in
+    // flight together: they were written by the launch before).  Every value of x is formed exactly as the stage's last
+    // launch formed it: same bits.
+    const bool merge = G::TR && mb.add1 != nullptr;
+    const float mrcp = div_rcp(p.out_div);
+    auto merge_window = [&](int c, int bb, int nt) {
+        ConvHRaw<G> t, u;
+        const size_t off = (size_t)bb * ustride + (size_t)c * cstride;
+        convh_load_raw<G>(t, mb.add1 + off, p.T, nt * G::NTC - G::P, tid, true, false, chunk_channels(c));
+        convh_load_raw<G>(u, mb.add2 ? mb.add2 + off : mb.add1 + off, p.T, nt * G::NTC - G::P, tid, mb.add2 != nullptr, false,
+                          chunk_channels(c));
+        pair_wait_vm0();
+#pragma unroll
+        for (int q = 0; q < G::XR; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = (raw.v[q][j] + t.v[q][j]) + u.v[q][j];       // (no add2: u is zeros, and v + 0 = v)
+                if (p.out_div != 1.f) v = mrcp != 0.f ? div_exact(v, p.out_div, mrcp) : v / p.out_div;
+                raw.v[q][j] = v;
+            }
+    };
     // Two stages per chunk (the two-source 1x1 conv; the transposed conv of 64 input channels): three stages ahead can be
     // two chunks -- or, with one chunk per item, two ITEMS -- on.  The stages of an item (all chunks of one row tile) are
     // contiguous in the packed image: stage number `lin` counted from the first stage of item `it`, wherever it falls
@@ -213,6 +238,9 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
     pair_stamp(p, 8, wave, lane, 7, 11);
     pair_wait_vm0();
     pair_stamp(p, 8, wave, lane, 7, 10);
+    if constexpr (G::TR) {
+        if (merge) merge_window(0, b, ntile);
+    }
     if (!(p.dbg & 2)) convh_convert<G>(raw, ximg, chunk_slope(0), tid, low, 0);
     pair_stamp(p, 8, wave, lane, 7, 13);                 // (tuning aid, -DFV_PAIR_TRACE) prologue done
     f32x4 hi[2][G::NFW], lo[2][G::NFW];                // live across the channel chunks of an item
@@ -381,6 +409,10 @@ __device__ __forceinline__ void convh_run_member(const PairParams& p, const Pair
         pair_stamp(p, 8, wave, lane, it, 3);
         wait_vm<0>();                                    // raw window, residual, the weight stages requested so far
         pair_stamp(p, 8, wave, lane, it, 4);
+        if constexpr (G::TR) {
+            // (before this tile's stores are issued: a wait behind them would take their whole round trip)
+            if (merge && new_win) merge_window(nchunk, nb, nnt);
+        }
         if constexpr (G::TR) {
             if (last) {
                 // y[co][ups u + phase - pad]: a lane's four rows are four consecutive phases -- inside one output channel
@@ -618,17 +650,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     PairParams q;
-    q.n_members = 1; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = 1.f;
+    // (out_div, add1, add2: the INPUT merge of an upsampler behind an MRF stage -- convh_run_member merge_window)
+    q.n_members = 1; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = p.out_div;
     q.act_slope = p.act_slope; q.post = 0; q.x_off = p.x_off; q.img_off = p.img_off; q.dbg = p.dbg; q.trace = p.trace;
     q.ctot = p.ctot; q.nch = p.nch; q.nmt = p.nmt; q.reflect = 0; q.ups = p.ups; q.pad_t = p.pad_t; q.Tout = p.Tout; q.cout = p.cout;
     q.guard = p.guard;
     PairMember mb;
-    mb.x = p.m[0].x; mb.w1 = p.m[0].w1; mb.b1 = p.m[0].b1; mb.res = nullptr; mb.add1 = nullptr; mb.add2 = nullptr;
+    mb.x = p.m[0].x; mb.w1 = p.m[0].w1; mb.b1 = p.m[0].b1; mb.res = nullptr; mb.add1 = p.m[0].add1; mb.add2 = p.m[0].add2;
     mb.y = p.m[0].y; mb.y_act = p.m[0].y_act; mb.k = 2; mb.n_tiles = p.m[0].n_tiles;
     const int n_items = p.m[0].n_items;
     asm volatile("" ::"s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.act_slope), "s"(q.x_off), "s"(q.img_off), "s"(q.dbg),
                  "s"(q.trace), "s"(q.ctot), "s"(q.nch), "s"(q.nmt), "s"(q.ups), "s"(q.pad_t), "s"(q.Tout), "s"(q.cout), "s"(mb.x), "s"(mb.w1),
-                 "s"(mb.b1), "s"(mb.y), "s"(mb.y_act), "s"(mb.n_tiles), "s"(n_items), "s"(q.guard));
+                 "s"(mb.b1), "s"(mb.y), "s"(mb.y_act), "s"(mb.n_tiles), "s"(n_items), "s"(q.guard), "s"(q.out_div), "s"(mb.add1), "s"(mb.add2));
     // equal items: block b takes [b n / nblk, (b + 1) n / nblk)
     const int lo = equal_share(xcd_remap((int)blockIdx.x, (int)gridDim.x), n_items, q.nblk), hi = equal_share(xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1, n_items, q.nblk);
     if (lo < hi) convh_run_member<ConvHGeom<CG, 2, 2, 1, true>>(q, mb, lo, hi, smem, wave, lane, true);

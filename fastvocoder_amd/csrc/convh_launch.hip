@@ -249,7 +249,12 @@ int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout,
     // 128 and more input channels: 128-row tiles (convu_kernel, convr_kernels.hpp) when that still gives the chip items
     // enough, as launch_convg / launch_convh; Tuning::convt_rows64
     const long long wide_items = (long long)mb.n_tiles * p.B * ((p.nmt + 1) / 2);
-    const bool wide = cc == 128 && (tuning().convt_rows64 < 0 ? wide_items * 10 >= 7LL * device_cu_count() : !tuning().convt_rows64);
+    // (a merged input -- mb.add1: the upsampler behind an MRF stage forms ((x + add1) + add2) / out_div in its window loader --
+    // exists on the 64-row kernel only: the 128-row one has no registers left for the second window)
+    const bool wide = cc == 128 && !mb.add1 &&
+                      (tuning().convt_rows64 < 0 ? wide_items * 10 >= 7LL * device_cu_count() : !tuning().convt_rows64);
+    if (!mb.add1) p.out_div = 1.f;
+    if (mb.add2 && !mb.add1) return fail(FV_ERR_INVALID_ARG, "split-f16 transposed conv: add2 without add1");
     mb.n_items = wide ? (int)wide_items : mb.n_tiles * p.B * p.nmt;
     mb.cost = 1;
     const int xrows = (NTC + 1 + 3) / 4 * 4;

@@ -254,23 +254,38 @@ class PlanBuilder:
                              channels=c1.in_channels, dil=c1.dilation[0], members=ms, out_div=float(out_div),
                              post=post))
 
-    def conv_transpose(self, convt, src, dst, pre_slope=1.0, post=POST_NONE, trim=0):
+    def conv_transpose_takes_merge(self, convt):
+        """Can this upsampler form its own input from the three ResBlock results of the stage in front of it
+        (``conv_transpose(..., merge=...)``)?  The split-f16 transposed-conv kernel can (csrc/convh_kernels.hpp
+        merge_window); the fp32 polyphase kernel and UpsampleLayer cannot."""
+        if not isinstance(convt, torch.nn.ConvTranspose1d) or convt.groups != 1 or convt.dilation[0] != 1:
+            return False
+        k, s = convt.kernel_size[0], convt.stride[0]
+        return (self.pair_precision(convt.in_channels) == _native.PAIR_SPLIT_F16
+                and _native.conv_transpose_split_supported(convt.in_channels, convt.out_channels, k, s, convt.padding[0],
+                                                           convt.output_padding[0]))
+
+    def conv_transpose(self, convt, src, dst, pre_slope=1.0, post=POST_NONE, trim=0, merge=None):
         """Record a torch.nn.ConvTranspose1d container (polyphase form); ``trim``: samples dropped from the end of
-        the output (CausalConvTranspose1d: its stride)."""
+        the output (CausalConvTranspose1d: its stride); ``merge = (slot_b, slot_c, div)``: the input is
+        ((src + slot_b) + slot_c) / div (conv_transpose_takes_merge must hold)."""
         if convt.groups != 1 or convt.dilation[0] != 1:
             raise _native.NativeError("only dense, undilated ConvTranspose1d layers exist on this path")
         k, s = convt.kernel_size[0], convt.stride[0]
         p, op = convt.padding[0], convt.output_padding[0]
         cin, cout = convt.in_channels, convt.out_channels
+        if merge is not None and not (post == POST_NONE and trim == 0 and self.conv_transpose_takes_merge(convt)):
+            raise _native.NativeError("conv_transpose: a merged input exists on the split-f16 kernel only")
         if (post == POST_NONE and self.pair_precision(cin) == _native.PAIR_SPLIT_F16
                 and _native.conv_transpose_split_supported(cin, cout, k, s, p, op - int(trim))):
             # kernel = 2 strides, 128+ input channels: split-f16 operands (csrc/convh_kernels.hpp convt_kernel)
             # (src is read raw, the activation is applied on chip: nothing is hoisted into its producer)
+            extra = {} if merge is None else dict(xb=merge[0], xc=merge[1], in_div=float(merge[2]))
             self.ops.append(dict(kind="convT", split=True, x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE,
                                  pre_slope=1.0, slope=float(pre_slope),
                                  packed=_native.pack_conv_transpose1d_split(effective_weight(convt), s, self.guard),
                                  bias=self._bias(convt), cin=cin, cout=cout, k=k, stride=s, pad=p,
-                                 out_pad=op - int(trim), post=post))
+                                 out_pad=op - int(trim), post=post, **extra))
             return
         self.ops.append(dict(kind="convT", x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE,
                              pre_slope=float(pre_slope),
@@ -479,7 +494,8 @@ class PlanBuilder:
                 self.plan.add_conv_transpose1d_split_f16(op["x"], op["y"], op["packed"], op["bias"], op["cin"],
                                                          op["cout"], op["k"], op["stride"], op["pad"], op["out_pad"],
                                                          pre_slope=op["slope"], y_act=op["y_act"],
-                                                         act_slope=op["act_slope"])
+                                                         act_slope=op["act_slope"],
+                                                         merge=(op["xb"], op["xc"], op["in_div"]) if "in_div" in op else None)
             elif op["kind"] == "convT":
                 self.plan.add_conv_transpose1d(op["x"], op["y"], op["packed"], op["bias"], op["cin"],
                                                op["cout"], op["k"], op["stride"], op["pad"],
@@ -549,12 +565,16 @@ class NativeModule(torch.nn.Module):
                      "off"  -- no check.
     ``fuse_pairs``   ResBlock1 pairs as fused launches (default) or conv by conv (round-1 path; A/B runs).
     ``fold_post``    HiFi-GAN's conv_post inside the last pair's launch (default) or as a launch of its own.
+    ``merge_in_upsampler``  the MRF merge ((r0 + r1) + r2) / 3 of a fused stage inside the split-f16 upsampler behind it
+                     (default: the stage ends in one three-member launch) or in the stage's own last launch (A/B runs;
+                     identical bits).
     """
 
     precision = "split"
     range_guard = "auto"
     fuse_pairs = True
     fold_post = True
+    merge_in_upsampler = True
 
     def __init__(self):
         super().__init__()
@@ -570,7 +590,7 @@ class NativeModule(torch.nn.Module):
         """The policy a plan is built under (part of every plan's cache key)."""
         prec = "f32" if (self.precision == "f32" or self._fv_overflow) else "split"
         # (the guard is part of the key: a plan built under range_guard = "off" carries no guard word)
-        return prec, bool(self.fuse_pairs), bool(self.fold_post), self.range_guard != "off"
+        return prec, bool(self.fuse_pairs), bool(self.fold_post), self.range_guard != "off", bool(self.merge_in_upsampler)
 
     def _fv_state(self):
         """(identity + in-place version of every tensor the plans bake in, policy in force).  The tensor list is
@@ -655,7 +675,7 @@ class NativeModule(torch.nn.Module):
         hit = self._fv_plans.get((name, state[1]))
         if hit is not None and hit[0] == state:
             return hit[1]
-        prec, _, fold, guarded = state[1]
+        prec, _, fold, guarded = state[1][:4]
         guard = self._guard_word() if (prec == "split" and guarded) else None
         with torch.no_grad():
             pb = PlanBuilder(in_channels, precision=prec, fold_post=fold, guard=guard)

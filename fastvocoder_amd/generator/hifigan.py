@@ -96,10 +96,14 @@ class _HiFiGANBase(NativeModule):
             flags.append(t > 0 and t % 4 == 0 and self._stage_fusable(i, precision))
         return tuple(flags)
 
-    def _emit_fused_stage(self, pb, blocks, up, x, scratch, parts, fold=None):
+    def _emit_fused_stage(self, pb, blocks, up, x, scratch, parts, fold=None, merge_next=False):
         """The three ResBlocks of a stage as fused pair launches: every pair position is ONE launch of
         three members; the last position also forms the MRF mean when the three weight sets fit in
-        LDS (16 channels), otherwise it runs conv by conv (grouped first convs + the merged last convs)."""
+        LDS (16 channels), otherwise it runs conv by conv (grouped first convs + the merged last convs).
+        ``merge_next`` (split-f16 stages in front of a split-f16 upsampler): the last position is an ordinary three-member
+        launch too -- block 0 stores r_0 in ``x``, blocks 1, 2 store r_1, r_2 in ``parts`` -- and the UPSAMPLER forms
+        ((r_0 + r_1) + r_2) / nk while it loads its window (PlanBuilder.conv_transpose(merge=...)): one launch less per
+        stage, the same bits."""
         nk = len(blocks)
         npairs = len(blocks[0].convs1)
         ch = blocks[0].channels
@@ -119,13 +123,13 @@ class _HiFiGANBase(NativeModule):
                 pb.end_group()
                 nxt = []
                 pb.begin_group()
-                for j in range(1 if last else 0, nk):
+                for j in range(1 if (last and not merge_next) else 0, nk):
                     ping, pong = scratch[j][1], scratch[j][2]
-                    d = parts[j - 1] if last else (ping if curs[j] != ping else pong)
+                    d = (x if j == 0 else parts[j - 1]) if last else (ping if curs[j] != ping else pong)
                     pb.conv_split(blocks[j].convs2[pi], scratch[j][0], d, LRELU_SLOPE, res=curs[j])
                     nxt.append(d)
                 pb.end_group()
-                if last:
+                if last and not merge_next:
                     pb.conv_split(blocks[0].convs2[pi], scratch[0][0], x, LRELU_SLOPE, res=curs[0],
                                   add1=parts[0], add2=parts[1] if nk > 2 else SLOT_NONE, out_div=float(nk))
                 curs = nxt
@@ -140,6 +144,13 @@ class _HiFiGANBase(NativeModule):
                 nxt.append(d)
             pb.end_group()
             curs = nxt
+        if prec == PAIR_SPLIT_F16 and merge_next:
+            pb.begin_group()
+            for j in range(nk):
+                pb.pair(blocks[j].convs1[-1], blocks[j].convs2[-1], curs[j], x if j == 0 else parts[j - 1], LRELU_SLOPE, prec,
+                        mid=scratch[j][0])
+            pb.end_group()
+            return
         if prec == PAIR_SPLIT_F16:
             # the 7- and 11-tap blocks' last pairs share a launch and store r_1, r_2; the first block's last pair
             # runs after them and forms ((r_0 + r_1) + r_2) / nk in its epilogue: the reference's order, bit for bit
@@ -200,18 +211,25 @@ class _HiFiGANBase(NativeModule):
         parts = [pb.tmp() for _ in range(nk - 1)]          # r_1 .. r_{nk-1}
         scratch = [[pb.tmp(), pb.tmp(), pb.tmp()] for _ in range(nk)]
         pb.conv(self.conv_pre, SLOT_IN, x)
+        merged = False        # the stage in front left r_0, r_1, r_2 in x, parts[0], parts[1]: this upsampler merges them
         for i in range(self.num_upsamples):
             if isinstance(self.ups[i], UpsampleLayer):
                 pb.upsample_conv(self.ups[i], x, up, pre_slope=LRELU_SLOPE)
             else:
-                pb.conv_transpose(self.ups[i], x, up, pre_slope=LRELU_SLOPE)
+                pb.conv_transpose(self.ups[i], x, up, pre_slope=LRELU_SLOPE,
+                                  merge=(parts[0], parts[1], float(nk)) if merged else None)
+            merged = False
             blocks = [self.resblocks[i * nk + j] for j in range(nk)]
             if fused is not None and fused[i]:
                 if fold_post and i == self.num_upsamples - 1:
                     self._emit_fused_stage(pb, blocks, up, x, scratch, parts,
                                            fold=(self.conv_post, DEFAULT_LRELU_SLOPE, POST_TANH, dst))
                     return
-                self._emit_fused_stage(pb, blocks, up, x, scratch, parts)
+                # the MRF merge inside the NEXT upsampler (engine.NativeModule.merge_in_upsampler)
+                merged = (self.merge_in_upsampler and nk == 3 and i + 1 < self.num_upsamples
+                          and pb.pair_precision(blocks[0].channels) == PAIR_SPLIT_F16
+                          and pb.conv_transpose_takes_merge(self.ups[i + 1]))
+                self._emit_fused_stage(pb, blocks, up, x, scratch, parts, merge_next=merged)
                 continue
             if nk <= 3:
                 steps = blocks[0].num_steps()

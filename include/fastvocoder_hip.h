@@ -450,6 +450,12 @@ int fv_plan_add_conv1d_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_
 int fv_plan_add_conv_transpose1d_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed,
                                            const float* bias, int Cin, int Cout, int k, int stride, int pad,
                                            int out_pad, float pre_slope, float act_slope);
+/* The input of the split-f16 transposed conv just added becomes ((x + add1) + add2) / div, formed on chip while its window
+ * is loaded (add2_slot may be FV_SLOT_NONE; slots shaped like x).  This is the MRF merge of reference hifigan.py:99-103 --
+ * xs = r0; xs += r1; xs += r2; x = xs / num_kernels, in that association -- moved from the end of a stage into the upsampler
+ * behind it, so that the stage's last pair position is ONE launch of its three ResBlocks (each storing its r_j) instead of
+ * two launches.  The values are formed exactly as the stage-end launch forms them: identical bits. */
+int fv_plan_set_input_merge(fv_plan_t* plan, int add1_slot, int add2_slot, float div);
 int fv_plan_add_mrf_sum(fv_plan_t* plan, const int* x_slots, int y_slot, int y_act_slot,
                         const float* const* packed1, const float* const* packed2, const float* const* bias1,
                         const float* const* bias2, int C, const int* k, int dil, float slope, float out_div,

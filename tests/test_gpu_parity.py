@@ -603,6 +603,55 @@ def test_shipped_configs_vs_aten_port_full_length(tag, name, path):
     assert _err(y, ref) <= TOL
 
 
+@pytest.mark.parametrize("name,path,T", [("hifigan", "conf/hifigan/light.yaml", 100), ("hifigan", "conf/hifigan/large.yaml", 40),
+                                         ("multiband-hifigan", "conf/multiband-hifigan/light.yaml", 64)],
+                         ids=["hifigan_light", "hifigan_large", "mb_light"])
+def test_mrf_merge_inside_the_upsampler_gives_the_same_bits(name, path, T):
+    """hifigan.py:99-103 -- xs = r0; xs += r1; xs += r2; x = xs / 3 -- at the end of every MRF stage but the last is formed by
+    the split-f16 upsampler BEHIND the stage while it loads its window (fv_plan_set_input_merge): the stage's last pair
+    position is one three-member launch instead of two launches.  Same association, same division: bit-identical to the
+    plan that merges in the stage's own last launch (`merge_in_upsampler = False`), single utterance and a batch, with
+    fewer launches."""
+    cfg = cases.load_conf(path)
+    m, _ = _model(name, cfg, seed=3)
+    x = torch.from_numpy(seeded_mel(T, seed=12, batch=3)).to(_dev())
+    def launches():
+        torch.cuda.synchronize()
+        _native.profile_collect(-1)
+        _native.profile_enable(True)
+        y = m(x).clone()
+        torch.cuda.synchronize()
+        _native.profile_enable(False)
+        return y, int(_native.profile_collect(-1)["launches"])
+    with torch.no_grad():
+        m(x)
+        a, n_merged = launches()
+        m.merge_in_upsampler = False
+        m(x)
+        b, n_plain = launches()
+        one = m(x[1:2].contiguous()).clone()
+        m.merge_in_upsampler = True
+        one_m = m(x[1:2].contiguous()).clone()
+    assert torch.equal(a, b) and torch.equal(one, a[1:2]) and torch.equal(one_m, one)
+    assert n_merged < n_plain, (n_merged, n_plain)     # (one launch less per stage whose upsampler is a split-f16 one)
+    assert not m.check_range()
+
+
+def test_headline_workload_full_tensor_at_T1000():
+    """BASELINE config 2 (HiFi-GAN light, 1000 frames -> 240 000 samples) against the validated ATen port on the host,
+    EVERY sample (the golden pins 1024 strided samples and the sums: a tile-boundary fault between two strides would have to
+    show in the sums); the same mel and weights as the golden, so the strided samples are checked in the same breath."""
+    cfg = cases.load_conf("conf/hifigan/light.yaml")
+    m, sd = _model("hifigan", cfg, seed=0)
+    mel = seeded_mel(1000, seed=1)
+    with torch.no_grad():
+        y = m.inference(mel)
+    ref = torch_port.inference("hifigan", mel, sd, cfg).numpy()
+    assert y.numel() == 240000 and _err(y, ref) <= TOL
+    g = np.load(os.path.join(cases.ROOT, "tests", "golden", "full_hifigan_light.npz"))
+    assert np.abs(y.cpu().numpy()[g["T1000_idx"]] - g["T1000_samples"]).max() <= TOL
+
+
 def test_batch_rows_are_independent_and_bit_identical():
     """Utterances never mix: row b of a batched forward equals the single-row call
     bit for bit (this is what makes N-GPU sharding exact)."""

@@ -3,6 +3,7 @@ its own subprocess, the runs interleaved (A B A B ...) so that clock / thermal d
 
     python tools/ab_lib.py [--batch B] [--rounds R] fastvocoder_amd/libfv_base_r3.so fastvocoder_amd/libfastvocoder_hip.so
 
+A library name followed by "@nomerge" runs with NativeModule.merge_in_upsampler = False.
 Prints per library the step time of every round, their median, and the per-family kernel times (profile hooks).
 The product never loads a library by path from the environment: this tool sets _native.LIB_PATH in its own child
 process, and does not go through bench.py's build-id check (an older build is the point)."""
@@ -17,12 +18,13 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def child(lib, batch, model_name):
+def child(lib, batch, model_name, nomerge=False):
     sys.path.insert(0, ROOT)
     import torch
     from fastvocoder_amd import _native
     _native.LIB_PATH = os.path.abspath(lib)
     import ctypes
+    has_merge = hasattr(ctypes.CDLL(_native.LIB_PATH), "fv_plan_set_input_merge")
 
     class Tolerant(ctypes.CDLL):            # an older build lacks the newest entry points: bind a stub that is never called
         def __getattr__(self, name):
@@ -36,6 +38,9 @@ def child(lib, batch, model_name):
                 return stub
     _native.ctypes.CDLL = Tolerant
     import bench
+    from fastvocoder_amd.generator.engine import NativeModule
+    if nomerge or not has_merge:
+        NativeModule.merge_in_upsampler = False          # (an older build has no merged upsampler input)
     dev = torch.device("cuda:0")
     model, cfg, sd = bench.build_model(model_name, dev, None, 0)
     mel = torch.from_numpy(bench.utterance_mels(0, batch)).to(dev)
@@ -72,7 +77,7 @@ def main():
     ap.add_argument("libs", nargs="*")
     a = ap.parse_args()
     if a.child:
-        return child(a.child, a.batch, a.model)
+        return child(a.child.split("@")[0], a.batch, a.model, nomerge=a.child.endswith("@nomerge"))
     res = {lib: [] for lib in a.libs}
     for _ in range(a.rounds):
         for lib in a.libs:
