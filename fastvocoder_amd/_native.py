@@ -340,7 +340,7 @@ def pack_conv_transpose1d(w, stride, pad):
 
 def conv_transpose_split_supported(cin, cout, k, stride, pad, out_pad):
     """Shapes of the split-f16 transposed conv (csrc/convh_launch.hip launch_convt)."""
-    return (cin in (64, 128, 256, 512) and 2 <= stride <= 16 and k == 2 * stride and cout * stride >= 64
+    return (cin in (32, 64, 128, 256, 512) and 2 <= stride <= 16 and k == 2 * stride and cout * stride >= 32
             and 0 <= pad <= stride and -stride <= out_pad < stride)
 
 

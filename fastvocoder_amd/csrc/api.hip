@@ -353,7 +353,7 @@ __global__ void pack_convg_kernel(const float* __restrict__ w1, const float* __r
 // m = co * s + phase, K = (tap, ci): tap 0 multiplies x[u - 1] (kernel index s + phase), tap 1 x[u] (kernel index phase)
 // (64 input channels: one chunk of 64 = two 32-channel groups per tap; otherwise chunks of 128)
 __global__ void pack_convth_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, const float* __restrict__ inv, int Cin, int Cout, int s_, int* range_flag) {
-    const int CC = Cin == 64 ? 64 : 128, NCH = (Cin + CC - 1) / CC, CG = CC / 32, NSTEP = 2 * CG, k = 2 * s_;
+    const int CC = Cin <= 64 ? 64 : 128, NCH = (Cin + CC - 1) / CC, CG = CC / 32, NSTEP = 2 * CG, k = 2 * s_;
     const int64_t total = (int64_t)((Cout * s_ + 63) / 64) * NCH * NSTEP * 4 * 2 * 64 * 8;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -963,22 +963,22 @@ int fv_generator_run(fv_plan_t* plan, int B, int T, const float* mel, float* out
 
 // ---- ConvTranspose1d with split-f16 operands (convt_kernel) ----
 static int check_convt_split_args(int Cin, int Cout, int k, int stride, int pad, int out_pad) {
-    if (Cin != 64 && Cin != 128 && Cin != 256 && Cin != 512)
-        return fail(FV_ERR_UNSUPPORTED, "conv_transpose1d_split_f16: Cin = %d (64, 128, 256 or 512)", Cin);
+    if (Cin != 32 && Cin != 64 && Cin != 128 && Cin != 256 && Cin != 512)
+        return fail(FV_ERR_UNSUPPORTED, "conv_transpose1d_split_f16: Cin = %d (32, 64, 128, 256 or 512)", Cin);
     if (stride < 2 || stride > 16 || k != 2 * stride)
         return fail(FV_ERR_UNSUPPORTED, "conv_transpose1d_split_f16: kernel %d, stride %d (kernel = 2 x stride, stride 2..16)", k, stride);
-    if (Cout <= 0 || Cout * stride < 64)
-        return fail(FV_ERR_UNSUPPORTED, "conv_transpose1d_split_f16: Cout * stride = %d (64 or more)", Cout * stride);
+    if (Cout <= 0 || Cout * stride < 32)
+        return fail(FV_ERR_UNSUPPORTED, "conv_transpose1d_split_f16: Cout * stride = %d (32 or more)", Cout * stride);
     if (pad < 0 || pad > stride || out_pad < -stride || out_pad >= stride)
         return fail(FV_ERR_INVALID_ARG, "conv_transpose1d_split_f16: pad=%d (0..stride) out_pad=%d", pad, out_pad);
     return 0;
 }
 
 int64_t fv_packed_conv_transpose1d_split_floats(int Cin, int Cout, int k, int stride) {
-    if ((Cin != 64 && Cin != 128 && Cin != 256 && Cin != 512) || stride < 2 || stride > 16 || k != 2 * stride ||
-        Cout <= 0 || Cout * stride < 64)
+    if ((Cin != 32 && Cin != 64 && Cin != 128 && Cin != 256 && Cin != 512) || stride < 2 || stride > 16 || k != 2 * stride ||
+        Cout <= 0 || Cout * stride < 32)
         return 0;
-    const int cc = Cin == 64 ? 64 : 128;                                             // input channels per chunk
+    const int cc = Cin <= 64 ? 64 : 128;                                             // input channels per chunk (32: half of one)
     const int64_t row_tiles = (Cout * stride + 63) / 64;
     // row tiles x chunks x K steps x 8 KB, then one float per (padded) row: the inverse of its power-of-two prescale
     return row_tiles * ((Cin + cc - 1) / cc) * (2 * cc / 32) * 2048 + row_tiles * 64;

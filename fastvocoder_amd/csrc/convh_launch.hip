@@ -217,10 +217,10 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
 // ---- ConvTranspose1d, kernel = 2 x stride (convt_kernel) -----------------------------------------------------------
 int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout, hipStream_t s) {
     if (p.B <= 0 || p.T <= 0 || Tout <= 0) return 0;
-    if (Cin != 64 && Cin != 128 && Cin != 256 && Cin != 512)
-        return fail(FV_ERR_UNSUPPORTED, "split-f16 transposed conv: Cin = %d (64, 128, 256 or 512)", Cin);
-    if (stride < 2 || stride > 16 || Cout <= 0 || Cout * stride < 64)
-        return fail(FV_ERR_UNSUPPORTED, "split-f16 transposed conv: stride %d (2..16), Cout * stride = %d (64 or more)",
+    if (Cin != 32 && Cin != 64 && Cin != 128 && Cin != 256 && Cin != 512)
+        return fail(FV_ERR_UNSUPPORTED, "split-f16 transposed conv: Cin = %d (32, 64, 128, 256 or 512)", Cin);
+    if (stride < 2 || stride > 16 || Cout <= 0 || Cout * stride < 32)
+        return fail(FV_ERR_UNSUPPORTED, "split-f16 transposed conv: stride %d (2..16), Cout * stride = %d (32 or more)",
                     stride, Cout * stride);
     if (pad < 0 || pad > stride) return fail(FV_ERR_UNSUPPORTED, "split-f16 transposed conv: padding %d (0..stride)", pad);
     if ((double)Cin * p.T * 4.0 >= 1073741824.0 || (double)Cout * Tout * 4.0 >= 1073741824.0)
@@ -234,7 +234,8 @@ int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout,
         return fail(FV_ERR_UNSUPPORTED, "split-f16 transposed conv: packed weights must be 16-byte aligned");
     p.n_members = 1;
     p.ctot = Cin;
-    const int cc = Cin == 64 ? 64 : 128;      // input channels per chunk (64 input channels: one chunk of 64, two K steps per tap)
+    const int cc = Cin <= 64 ? 64 : 128;      // input channels per chunk (64 input channels: one chunk of 64, two K steps per tap;
+                                              // 32: half of that chunk -- the missing channels read as zeros)
     p.nch = (Cin + cc - 1) / cc;
     p.nmt = (Cout * stride + 63) / 64;        // rows beyond Cout * stride: zero weights, stores dropped
     p.cout = Cout;

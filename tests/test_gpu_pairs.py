@@ -430,6 +430,8 @@ CONVT_CASES = [  # B, Cin, Cout, Tin, stride, pad, out_pad
     (2, 128, 16, 50, 4, 0, 0), (1, 128, 64, 33, 8, 8, -8), (1, 128, 64, 260, 16, 8, 0),
     # 64 input channels (half a chunk) and row counts that are not a multiple of the 64-row tile
     (1, 64, 32, 300, 3, 2, 1), (2, 64, 32, 129, 2, 1, 0), (1, 64, 40, 100, 5, 3, 1), (1, 128, 20, 64, 4, 2, 0),
+    # 32 input channels (a quarter of a 128-chunk's image: HiFi-GAN light's last upsampler, 32 -> 16 x 2) and 32 rows
+    (1, 32, 16, 1000, 2, 1, 0), (2, 32, 16, 131, 2, 1, 0), (1, 32, 24, 77, 4, 2, 0),
 ]
 
 
@@ -483,7 +485,7 @@ def test_conv_transpose1d_split_f16_vs_oracle(case, tuning):
 
 def test_conv_transpose1d_split_f16_rejects():
     with pytest.raises(_native.NativeError, match="not built"):
-        _native.pack_conv_transpose1d_split(torch.zeros((32, 32, 16), device=_dev()), 8)       # Cin = 32
+        _native.pack_conv_transpose1d_split(torch.zeros((48, 32, 16), device=_dev()), 8)       # Cin = 48
     with pytest.raises(_native.NativeError, match="not built"):
         _native.pack_conv_transpose1d_split(torch.zeros((128, 32, 17), device=_dev()), 8)      # k != 2 s
     P = _native.pack_conv_transpose1d_split(torch.zeros((128, 32, 16), device=_dev()), 8)

@@ -286,13 +286,19 @@ def test_plan_shape_inference_without_gpu():
     assert L.fv_packed_conv_transpose1d_split_floats(128, 64, 10, 5) == 5 * 1 * 8 * 2048 + 320     # (+ one float per padded row)
     assert L.fv_packed_conv_transpose1d_split_floats(256, 128, 16, 8) == 16 * 2 * 8 * 2048 + 1024
     assert L.fv_packed_conv_transpose1d_split_floats(64, 32, 6, 3) == 2 * 1 * 4 * 2048 + 128     # 96 rows -> 2 tiles; 64-channel chunks
-    assert L.fv_packed_conv_transpose1d_split_floats(32, 16, 4, 2) == 0
+    assert L.fv_packed_conv_transpose1d_split_floats(32, 16, 4, 2) == 1 * 1 * 4 * 2048 + 64       # 32 rows and 32 channels: half a tile, half a chunk
+    assert L.fv_packed_conv_transpose1d_split_floats(48, 16, 4, 2) == 0
     assert L.fv_packed_conv_transpose1d_split_floats(128, 64, 11, 5) == 0
     assert L.fv_plan_add_conv_transpose1d_split_f16(t, 0, 1, -1, dummy, None, 128, 64, 10, 5, 3, 1, 0.1, 1.0) == 0
     assert L.fv_plan_output_shape(t, 100, ctypes.byref(c), ctypes.byref(n)) == 0
     assert (c.value, n.value) == (64, 500)
-    assert L.fv_plan_add_conv_transpose1d_split_f16(t, 0, 1, -1, dummy, None, 32, 16, 4, 2, 1, 0, 0.1, 1.0) != 0
-    assert b"Cin = 32" in L.fv_last_error()
+    assert L.fv_plan_add_conv_transpose1d_split_f16(t, 0, 1, -1, dummy, None, 48, 16, 4, 2, 1, 0, 0.1, 1.0) != 0
+    assert b"Cin = 48" in L.fv_last_error()
+    # the MRF merge of the stage in front, inside this op's window loader: only on a split-f16 transposed conv
+    assert L.fv_plan_set_input_merge(t, 2, 3, 3.0) == 0
+    assert L.fv_plan_set_input_merge(t, -1, 3, 3.0) != 0 and L.fv_plan_set_input_merge(t, 2, 3, 0.0) != 0
+    assert L.fv_plan_output_shape(t, 100, ctypes.byref(c), ctypes.byref(n)) != 0     # slots 2, 3 are not set: caught by the shape walk
+    assert b"merged input" in L.fv_last_error()
     assert L.fv_plan_set_output_offset(t, 28, -1) != 0
     L.fv_plan_destroy(t)
 
