@@ -261,7 +261,10 @@ class PlanBuilder:
         if not isinstance(convt, torch.nn.ConvTranspose1d) or convt.groups != 1 or convt.dilation[0] != 1:
             return False
         k, s = convt.kernel_size[0], convt.stride[0]
-        return (convt.in_channels >= self.SPLIT_CONVT_MIN_CIN
+        # (up to 128 input channels: with 256 / 512 the merging kernel -- 64-row tiles only -- converts every chunk's window once
+        # per 64 rows where the 128-row kernel converts it once per 128: HiFi-GAN large, 64 utterances, 118.7 -> 121.8 ms
+        # with the merge in its 256-channel upsampler [measured, tools/bench_configs.py --no-merge])
+        return (self.SPLIT_CONVT_MIN_CIN <= convt.in_channels <= 128
                 and self.pair_precision(convt.in_channels) == _native.PAIR_SPLIT_F16
                 and _native.conv_transpose_split_supported(convt.in_channels, convt.out_channels, k, s, convt.padding[0],
                                                            convt.output_padding[0]))

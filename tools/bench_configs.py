@@ -29,7 +29,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--only", type=int, default=None, help="index into CONFIGS (0-based): run just that one")
     ap.add_argument("--tuning", default="", help='launcher switches "key=value,..." (fv_tuning_set) for an A/B')
+    ap.add_argument("--no-merge", action="store_true", help="A/B: the MRF merge in the stage's own last launch (merge_in_upsampler = False)")
     args = ap.parse_args()
+    if args.no_merge:
+        from fastvocoder_amd.generator.engine import NativeModule
+        NativeModule.merge_in_upsampler = False
     for kv in filter(None, args.tuning.split(",")):
         k, v = kv.split("=")
         _native.tuning_set(k, int(v))
