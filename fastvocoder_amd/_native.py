@@ -150,6 +150,7 @@ def lib():
     L.fv_conv_transpose1d_split_f16.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, f, vp, vp]
     L.fv_plan_add_conv_transpose1d_split_f16.argtypes = [vp, i, i, i, vp, vp, i, i, i, i, i, i, f, f]
     L.fv_plan_set_input_merge.argtypes = [vp, i, i, f]
+    L.fv_div_probe.argtypes = [ctypes.c_uint, i64, f, vp, vp]
     L.fv_pqmf_synthesis.argtypes = [vp, vp, vp, i, i, i, i, vp]
     L.fv_conv1d_2src_fused.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, f, vp]
     L.fv_plan_add_conv1d_2src.argtypes = [vp, i, i, i, i, i, vp, vp, i, i, i, i, f]

@@ -2088,6 +2088,11 @@ int fv_plan_check_range(fv_plan_t* plan, void* stream) {
                               "results of the last run are not valid; repeat it on an fp32-precision plan");
 }
 
+int fv_div_probe(unsigned first_bits, int64_t n, float d, unsigned long long* mismatches, void* stream) {
+    if (!mismatches || n <= 0) return fail(FV_ERR_INVALID_ARG, "div_probe: null counter / empty range");
+    return fv::launch_div_probe(first_bits, (long long)n, d, mismatches, (hipStream_t)stream);
+}
+
 int fv_tuning_set(const char* key, int value) {
     if (!key) return fail(FV_ERR_INVALID_ARG, "tuning_set: null key");
     (void)tuning();                         // the environment (FV_TUNING=1) is read first, once

@@ -394,6 +394,9 @@ int launch_encode16(float* x, int B, int64_t n, float rescale, short* out, unsig
 int launch_pqmf_analysis(const float* xin, const float* ha, float* x, int B, int S, int ntaps,
                          int64_t T, hipStream_t s);
 
+// self-check of pair_kernels.hpp div_exact against the device's division (fv_div_probe; pair_inst_c16.hip)
+int launch_div_probe(unsigned first, long long n, float d, unsigned long long* mismatches, hipStream_t s);
+
 // measurement hook
 void profile_begin(hipStream_t stream);
 void profile_end(hipStream_t stream, int kind, double flops, double bytes);

@@ -310,8 +310,8 @@ __device__ __forceinline__ void pair_conv1(const PairLane<G>& L, const float* bl
 // v / d for the divisors of the MRF mean (hifigan.py:103: xs / num_kernels, a small integer) in three instructions instead
 // of the ~11 of an IEEE division: q0 = v r, e = fma(-d, q0, v) (the exact residual), q = fma(e, r, q0) with r = RN(1 / d)
 // is the correctly rounded quotient for every finite v whose quotient is a normal number (Markstein; checked exhaustively
-// over all 2^24 significands for d = 1 .. 16 on the CPU, tests/test_split_precision.py, and on the GPU against the
-// hardware's own division, fv_div_probe).  Non-finite v: the range guard has fired anyway.
+// over all 2^24 significands for the integers up to 15 on the CPU, tests/test_split_precision.py, and on the GPU against the
+// hardware's own division, fv_div_probe / tests/test_gpu_parity.py).  Non-finite v: the range guard has fired anyway.
 // div_rcp: 1 / d where that holds, else 0 (-> IEEE division).
 __device__ __forceinline__ float div_rcp(float d) { return (d >= 1.f && d <= 16.f && d == truncf(d)) ? 1.f / d : 0.f; }
 __device__ __forceinline__ float div_exact(float v, float d, float r) {

@@ -517,6 +517,12 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
 int fv_generator_run(fv_plan_t* plan, int B, int T, const float* mel, float* out, void* workspace,
                      int64_t workspace_bytes, void* stream);
 
+/* Self-check (tests): the MRF mean's divisor is applied as q0 = v r, q = fma(fma(-d, q0, v), r, q0), r = RN(1 / d) for small
+ * integer d (csrc/pair_kernels.hpp div_exact) -- claimed to be the correctly rounded v / d.  Counts, over the fp32 values with
+ * bit patterns [first_bits, first_bits + n) and their negatives, where that differs from the device's IEEE division (values
+ * whose quotient is not a normal number are skipped); *mismatches (device memory, zeroed by the caller) receives the count. */
+int fv_div_probe(unsigned first_bits, int64_t n, float d, unsigned long long* mismatches, void* stream);
+
 /* number of kernel launches one fv_plan_run enqueues */
 int fv_plan_num_ops(fv_plan_t* plan);
 

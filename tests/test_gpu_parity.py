@@ -637,6 +637,18 @@ def test_mrf_merge_inside_the_upsampler_gives_the_same_bits(name, path, T):
     assert not m.check_range()
 
 
+def test_three_instruction_division_on_the_device():
+    """csrc/pair_kernels.hpp div_exact (the MRF mean's xs / 3, hifigan.py:103) against the device's own IEEE division: every
+    fp32 value of four binades (and the negatives), d = 3 -- and 2, 5, 7, 12 for the rule's other divisors: zero mismatches."""
+    cnt = torch.zeros(1, dtype=torch.int64, device=_dev())
+    L = _native.lib()
+    for d in (3.0, 2.0, 5.0, 7.0, 12.0):
+        for first in (0x3F800000, 0x00C00000, 0x7E000000, 0x42000000):          # 1.0, tiny, huge, 32.0: 2^23 values each
+            _native.check(L.fv_div_probe(first, 1 << 23, d, cnt.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == 0
+
+
 def test_headline_workload_full_tensor_at_T1000():
     """BASELINE config 2 (HiFi-GAN light, 1000 frames -> 240 000 samples) against the validated ATen port on the host,
     EVERY sample (the golden pins 1024 strided samples and the sums: a tile-boundary fault between two strides would have to

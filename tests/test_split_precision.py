@@ -143,3 +143,23 @@ def test_small_activations_inside_the_guarded_domain(aexp):
     assert esp <= 3.0 * e32 + 1e-7 * np.abs(ref).max(), esp / e32
     assert _low_guard(x * np.float32(0.25) if aexp == -9 else x * np.float32(2.0 ** (-11 - aexp)))
     assert not _low_guard(np.zeros(4, np.float32))
+
+
+@pytest.mark.parametrize("d", [3, 5, 6, 7, 9, 11, 12, 15])
+def test_three_instruction_division_is_correctly_rounded(d):
+    """csrc/pair_kernels.hpp div_exact -- q0 = v r; q = fma(fma(-d, q0, v), r, q0), r = RN(1 / d) -- for the MRF mean
+    (hifigan.py:103: xs / num_kernels): equal to the correctly rounded v / d for every significand (all 2^23 of a binade,
+    both signs, several binades: correct rounding does not depend on the exponent while the quotient is a normal number).
+    float64 emulates the fused multiply-adds exactly here: d q0 and e r are products of a <= 4-bit and a 24-bit, resp. two
+    24-bit significands.  (The GPU repeats the check against its own division: test_gpu_parity.py.)"""
+    d32 = np.float32(d)
+    r = np.float32(1.0) / d32
+    m = np.arange(2 ** 23, 2 ** 24, dtype=np.int64).astype(np.float64)
+    for e, sgn in ((-40, 1.0), (0, 1.0), (0, -1.0), (60, -1.0)):
+        if True:
+            v = (sgn * m * 2.0 ** (e - 23)).astype(np.float32)
+            q0 = (v * r).astype(np.float32)
+            res = (v.astype(np.float64) - np.float64(d) * q0.astype(np.float64)).astype(np.float32)     # fma(-d, q0, v): exact
+            q = (q0.astype(np.float64) + res.astype(np.float64) * np.float64(r)).astype(np.float32)
+            want = (v.astype(np.float64) / np.float64(d)).astype(np.float32)
+            assert np.array_equal(q, want), (d, e, sgn, int((q != want).sum()))
