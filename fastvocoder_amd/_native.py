@@ -19,10 +19,11 @@ _CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip", "wav_sink.hip", "conv_inst_narrow.hip",
            "pair_launch.hip", "pair_inst_c16.hip", "pair_inst_c32.hip", "pairh_inst_c16.hip", "pairh_inst_c32.hip",
            "convh_launch.hip", "convh_inst_c64.hip", "convh_inst_c128.hip", "convp_inst.hip", "convt_inst.hip",
-           "convg_inst.hip", "convq_inst.hip", "convp_chain_inst.hip", "convr_inst.hip"] + \
+           "convg_inst.hip", "convq_inst.hip", "convp_chain_inst.hip", "convr_inst.hip", "convtn_inst.hip"] + \
           [f"conv_inst_s{i}.hip" for i in range(6)]
 HEADERS = ["fv_internal.h", "conv_kernels.hpp", "pair_kernels.hpp", "pair_inst.hpp", "pairh_kernels.hpp",
-           "pairh_inst.hpp", "convh_kernels.hpp", "convh_inst.hpp", "convp_kernels.hpp", "convq_kernels.hpp", "convp_chain.hpp", "convr_kernels.hpp"]
+           "pairh_inst.hpp", "convh_kernels.hpp", "convh_inst.hpp", "convp_kernels.hpp", "convq_kernels.hpp", "convp_chain.hpp", "convr_kernels.hpp",
+           "convtn_kernels.hpp"]
 
 PAD_ZERO, PAD_REFLECT = 0, 1
 PAD_CAUSAL = 2      # flag: pad (k-1)*dil on both sides, keep the first Tin outputs (CausalConv1d)
@@ -341,8 +342,15 @@ def pack_conv_transpose1d(w, stride, pad):
 
 def conv_transpose_split_supported(cin, cout, k, stride, pad, out_pad):
     """Shapes of the split-f16 transposed conv (csrc/convh_launch.hip launch_convt)."""
+    if conv_transpose_small(cin, cout, k, stride):
+        return pad == 1 and out_pad == 0
     return (cin in (32, 64, 128, 256, 512) and 2 <= stride <= 16 and k == 2 * stride and cout * stride >= 32
             and 0 <= pad <= stride and -stride <= out_pad < stride)
+
+
+def conv_transpose_small(cin, cout, k, stride):
+    """The shape with a kernel of its own (csrc/convtn_kernels.hpp): HiFi-GAN light's last upsampler, 32 -> 16 channels x 2."""
+    return (cin, cout, k, stride) == (32, 16, 4, 2)
 
 
 def pack_conv_transpose1d_split(w, stride, flag=None):

@@ -640,6 +640,7 @@ static int run_op(const Op& o, const float* x, float* y, float* y2, const float*
         pp.m[0].add1 = acc;
         pp.m[0].add2 = acc2;
         pp.out_div = acc ? o.out_div : 1.f;
+        if (convtn_shape(o.Cin, o.Cout, o.k, o.stride)) return launch_convtn(pp, (int)conv_out_len(o, Tin), s);
         return launch_convt(pp, o.Cin, o.Cout, o.stride, o.pad, (int)conv_out_len(o, Tin), s);
     }
     return launch_conv(make_params(o, x, y, y2, res, acc, acc2, B, Tin, x2, sub, sub_batched), s);
@@ -971,6 +972,9 @@ static int check_convt_split_args(int Cin, int Cout, int k, int stride, int pad,
         return fail(FV_ERR_UNSUPPORTED, "conv_transpose1d_split_f16: Cout * stride = %d (32 or more)", Cout * stride);
     if (pad < 0 || pad > stride || out_pad < -stride || out_pad >= stride)
         return fail(FV_ERR_INVALID_ARG, "conv_transpose1d_split_f16: pad=%d (0..stride) out_pad=%d", pad, out_pad);
+    if (convtn_shape(Cin, Cout, k, stride) && (pad != 1 || out_pad != 0))
+        return fail(FV_ERR_UNSUPPORTED, "conv_transpose1d_split_f16: 32 -> 16 channels, kernel 4, stride 2 exists with pad=1, "
+                    "out_pad=0 only (got %d, %d)", pad, out_pad);
     return 0;
 }
 
@@ -978,6 +982,7 @@ int64_t fv_packed_conv_transpose1d_split_floats(int Cin, int Cout, int k, int st
     if ((Cin != 32 && Cin != 64 && Cin != 128 && Cin != 256 && Cin != 512) || stride < 2 || stride > 16 || k != 2 * stride ||
         Cout <= 0 || Cout * stride < 32)
         return 0;
+    if (convtn_shape(Cin, Cout, k, stride)) return kTnPackedFloats;                   // its own kernel and layout (convtn_kernels.hpp)
     const int cc = Cin <= 64 ? 64 : 128;                                             // input channels per chunk (32: half of one)
     const int64_t row_tiles = (Cout * stride + 63) / 64;
     // row tiles x chunks x K steps x 8 KB, then one float per (padded) row: the inverse of its power-of-two prescale
@@ -987,6 +992,11 @@ int64_t fv_packed_conv_transpose1d_split_floats(int Cin, int Cout, int k, int st
 int fv_pack_conv_transpose1d_split_f16(const float* w, float* packed, int Cin, int Cout, int k, int stride, int* range_flag,
                                        void* stream) {
     if (!w || !packed) return fail(FV_ERR_INVALID_ARG, "pack_conv_transpose1d_split_f16: null tensor");
+    if (convtn_shape(Cin, Cout, k, stride)) {
+        hipLaunchKernelGGL(row_scale_kernel, dim3(32), dim3(64), 0, (hipStream_t)stream, w, (const float*)nullptr,
+                           packed + (kTnPackedFloats - 32), 32, Cin, 2, Cout, stride);
+        return launch_pack_convtn(w, packed, packed + (kTnPackedFloats - 32), range_flag, (hipStream_t)stream);
+    }
     if (int rc = check_convt_split_args(Cin, Cout, k, stride, 0, 0)) return rc;
     const int rows = (Cout * stride + 63) / 64 * 64;
     const int64_t image = fv_packed_conv_transpose1d_split_floats(Cin, Cout, k, stride) - rows, total = image * 2;

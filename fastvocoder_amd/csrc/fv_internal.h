@@ -345,6 +345,13 @@ int launch_convh_geom(const PairParams& p, int dil, size_t lds, hipStream_t s);
 // convh_kernels.hpp): member 0 uses x, w1 (fv_pack_conv_transpose1d_split_f16 image), b1, y, y_act
 int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout, hipStream_t stream);
 int launch_convt_geom(const PairParams& p, int cg, size_t lds, hipStream_t s);
+// ... 32 -> 16 channels, kernel 4, stride 2, padding 1 (HiFi-GAN light's last upsampler): its own kernel (convtn_kernels.hpp),
+// its own packed layout (8 KB + 32 inverse row prescales); member 0 as launch_convt (add1 / add2: merged input)
+// (the packed layout follows from Cin, Cout, k, stride alone; the op then needs pad = 1, out_pad = 0)
+inline bool convtn_shape(int Cin, int Cout, int k, int stride) { return Cin == 32 && Cout == 16 && k == 4 && stride == 2; }
+constexpr int kTnPackedFloats = 2048 + 32;
+int launch_convtn(const PairParams& p, int Tout, hipStream_t s);
+int launch_pack_convtn(const float* w, float* packed, const float* inv, int* range_flag, hipStream_t s);
 // y = post(W1 lrelu(x, slope) + W2 x2 + bias + res), 1-tap convs C -> C with split-f16 operands (convg_kernel): member 0
 // uses x, x2, w1 (fv_pack_conv1x1_2src_split_f16 image), b1, res, y, y_act; C = 128, 256 or 512
 int launch_convg(PairParams p, int C, hipStream_t stream);

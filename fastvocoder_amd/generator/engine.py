@@ -264,15 +264,17 @@ class PlanBuilder:
         # (up to 128 input channels: with 256 / 512 the merging kernel -- 64-row tiles only -- converts every chunk's window once
         # per 64 rows where the 128-row kernel converts it once per 128: HiFi-GAN large, 64 utterances, 118.7 -> 121.8 ms
         # with the merge in its 256-channel upsampler [measured, tools/bench_configs.py --no-merge])
-        return (self.SPLIT_CONVT_MIN_CIN <= convt.in_channels <= 128
+        return ((self.SPLIT_CONVT_MIN_CIN <= convt.in_channels <= 128
+                 or _native.conv_transpose_small(convt.in_channels, convt.out_channels, k, s))
                 and self.pair_precision(convt.in_channels) == _native.PAIR_SPLIT_F16
                 and _native.conv_transpose_split_supported(convt.in_channels, convt.out_channels, k, s, convt.padding[0],
                                                            convt.output_padding[0]))
 
     # The split-f16 transposed conv exists from 32 input channels on (fv_conv_transpose1d_split_f16), but with 32 channels and
-    # 32 rows it pads both K and M to 64: HiFi-GAN light's last upsampler (32 -> 16 x 2) took 29 us on it against 18 us on the
-    # fp32-MFMA kernel, and although the 32-channel stage in front of it then ends in one launch (-13 us), the step did not
-    # gain at batch 1 and lost 1 % at batch 16 [measured, tools/ab_lib.py].  The plans use it from 64 channels on.
+    # 32 rows the GENERAL kernel pads both K and M to 64: HiFi-GAN light's last upsampler (32 -> 16 x 2) took 29 us on it against
+    # 18 us on the fp32-MFMA kernel, and although the 32-channel stage in front of it then ends in one launch (-13 us), the step
+    # did not gain at batch 1 and lost 1 % at batch 16 [measured, tools/ab_lib.py].  The plans use the general kernel from 64
+    # channels on -- and, for exactly that upsampler, the kernel written for it (csrc/convtn_kernels.hpp).
     SPLIT_CONVT_MIN_CIN = 64
 
     def conv_transpose(self, convt, src, dst, pre_slope=1.0, post=POST_NONE, trim=0, merge=None):
@@ -286,7 +288,8 @@ class PlanBuilder:
         cin, cout = convt.in_channels, convt.out_channels
         if merge is not None and not (post == POST_NONE and trim == 0 and self.conv_transpose_takes_merge(convt)):
             raise _native.NativeError("conv_transpose: a merged input exists on the split-f16 kernel only")
-        if (post == POST_NONE and cin >= self.SPLIT_CONVT_MIN_CIN and self.pair_precision(cin) == _native.PAIR_SPLIT_F16
+        if (post == POST_NONE and (cin >= self.SPLIT_CONVT_MIN_CIN or _native.conv_transpose_small(cin, cout, k, s))
+                and self.pair_precision(cin) == _native.PAIR_SPLIT_F16
                 and _native.conv_transpose_split_supported(cin, cout, k, s, p, op - int(trim))):
             # kernel = 2 strides, 128+ input channels: split-f16 operands (csrc/convh_kernels.hpp convt_kernel)
             # (src is read raw, the activation is applied on chip: nothing is hoisted into its producer)

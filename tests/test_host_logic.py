@@ -286,7 +286,8 @@ def test_plan_shape_inference_without_gpu():
     assert L.fv_packed_conv_transpose1d_split_floats(128, 64, 10, 5) == 5 * 1 * 8 * 2048 + 320     # (+ one float per padded row)
     assert L.fv_packed_conv_transpose1d_split_floats(256, 128, 16, 8) == 16 * 2 * 8 * 2048 + 1024
     assert L.fv_packed_conv_transpose1d_split_floats(64, 32, 6, 3) == 2 * 1 * 4 * 2048 + 128     # 96 rows -> 2 tiles; 64-channel chunks
-    assert L.fv_packed_conv_transpose1d_split_floats(32, 16, 4, 2) == 1 * 1 * 4 * 2048 + 64       # 32 rows and 32 channels: half a tile, half a chunk
+    assert L.fv_packed_conv_transpose1d_split_floats(32, 16, 4, 2) == 2048 + 32                # its own kernel: 8 KB of A operands + 32 row scales
+    assert L.fv_packed_conv_transpose1d_split_floats(32, 24, 8, 4) == 2 * 1 * 4 * 2048 + 128     # 32 channels on the general kernel: half a chunk
     assert L.fv_packed_conv_transpose1d_split_floats(48, 16, 4, 2) == 0
     assert L.fv_packed_conv_transpose1d_split_floats(128, 64, 11, 5) == 0
     assert L.fv_plan_add_conv_transpose1d_split_f16(t, 0, 1, -1, dummy, None, 128, 64, 10, 5, 3, 1, 0.1, 1.0) == 0
