@@ -19,18 +19,18 @@ _CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip", "wav_sink.hip", "conv_inst_narrow.hip",
            "pair_launch.hip", "pair_inst_c16.hip", "pair_inst_c32.hip", "pairh_inst_c16.hip", "pairh_inst_c32.hip",
            "convh_launch.hip", "convh_inst_c64.hip", "convh_inst_c128.hip", "convp_inst.hip", "convt_inst.hip",
-           "convg_inst.hip", "convq_inst.hip", "convp_chain_inst.hip", "convr_inst.hip", "convtn_inst.hip"] + \
+           "convg_inst.hip", "convq_inst.hip", "convp_chain_inst.hip", "convr_inst.hip", "convtn_inst.hip", "convk_inst.hip"] + \
           [f"conv_inst_s{i}.hip" for i in range(6)]
 HEADERS = ["fv_internal.h", "conv_kernels.hpp", "pair_kernels.hpp", "pair_inst.hpp", "pairh_kernels.hpp",
            "pairh_inst.hpp", "convh_kernels.hpp", "convh_inst.hpp", "convp_kernels.hpp", "convq_kernels.hpp", "convp_chain.hpp", "convr_kernels.hpp",
-           "convtn_kernels.hpp"]
+           "convtn_kernels.hpp", "convk_kernels.hpp"]
 
 PAD_ZERO, PAD_REFLECT = 0, 1
 PAD_CAUSAL = 2      # flag: pad (k-1)*dil on both sides, keep the first Tin outputs (CausalConv1d)
 POST_NONE, POST_TANH, POST_RELU = 0, 1, 2
 SLOT_NONE, SLOT_IN, SLOT_OUT, SLOT_TMP0, MAX_SLOTS = -1, 0, 1, 2, 32
 SLOT_AUX_IN0, SLOT_AUX_IN1, SLOT_OUT2 = 28, 29, 30    # caller-provided tensors of Plan.run(aux=..., out2=...)
-ABI_VERSION = 9
+ABI_VERSION = 10
 PAIR_F32, PAIR_SPLIT_F16 = 0, 1   # arithmetic of the fused ResBlock-pair kernels (fastvocoder_hip.h)
 
 
@@ -160,6 +160,11 @@ def lib():
     L.fv_pack_conv1x1_2src_split_f16.argtypes = [vp, vp, vp, i, vp, vp]
     L.fv_conv1x1_2src_split_f16.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, f, i, f, vp, vp]
     L.fv_plan_add_conv1x1_2src_split_f16.argtypes = [vp, i, i, i, i, i, vp, vp, i, f, i, f]
+    L.fv_packed_residual_stack_floats.argtypes = [i, i]
+    L.fv_packed_residual_stack_floats.restype = i64
+    L.fv_pack_residual_stack_split_f16.argtypes = [vp, vp, vp, vp, i, i, vp, vp]
+    L.fv_residual_stack_split_f16.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, i, f, vp, vp]
+    L.fv_plan_add_residual_stack_split_f16.argtypes = [vp, i, i, i, vp, vp, vp, i, i, i, f, i, f]
     L.fv_conv_post_pqmf.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, f, i, i, vp]
     L.fv_plan_add_conv_post_pqmf.argtypes = [vp, i, i, vp, vp, i, i, i, i, f, i, vp, i]
     L.fv_plan_set_sum_order.argtypes = [vp, i]
@@ -385,6 +390,42 @@ def pack_conv1x1_2src_split(w1, w2, flag=None):
     out = torch.empty(n, dtype=torch.float32, device=w1.device)
     with _on(w1, w2) as stream:
         check(lib().fv_pack_conv1x1_2src_split_f16(_ptr(w1, "w1"), _ptr(w2, "w2"), _ptr(out), c, _flag_ptr(flag), stream))
+    return out
+
+
+def residual_stack_split_supported(channels, k, dil):
+    """Shapes of the one-launch MelGAN ResidualStack (csrc/convk_kernels.hpp)."""
+    return channels in (32, 64, 128) and k == 3 and dil in (1, 3, 9)
+
+
+def pack_residual_stack_split(w_dilated, w_pointwise, w_skip, flag=None):
+    """The three Conv1d weights of a ResidualStack ([C,C,3] dilated, [C,C,1] stack[4], [C,C,1] skip_layer) -> the
+    split-f16 stage image of convk_kernel (flat tensor)."""
+    ws = [w.detach().contiguous().float() for w in (w_dilated, w_pointwise, w_skip)]
+    c, k = ws[0].shape[0], ws[0].shape[2]
+    if tuple(ws[0].shape) != (c, c, k) or tuple(ws[1].shape) != (c, c, 1) or tuple(ws[2].shape) != (c, c, 1):
+        raise NativeError(f"pack_residual_stack_split: [C,C,k], [C,C,1], [C,C,1] expected, got {[tuple(w.shape) for w in ws]}")
+    n = lib().fv_packed_residual_stack_floats(c, k)
+    if n <= 0:
+        raise NativeError(f"pack_residual_stack_split: C={c}, k={k} is not built (32 / 64 / 128 channels, 3 taps)")
+    out = torch.empty(n, dtype=torch.float32, device=ws[0].device)
+    with _on(*ws) as stream:
+        check(lib().fv_pack_residual_stack_split_f16(_ptr(ws[0], "w_dilated"), _ptr(ws[1], "w_pointwise"), _ptr(ws[2], "w_skip"),
+                                                     _ptr(out), c, k, _flag_ptr(flag), stream))
+    return out
+
+
+def residual_stack_split_f16(x, packed, bias_dilated, bias_out, k, dil, slope, pad_mode=PAD_REFLECT, out=None, out_act=None,
+                             act_slope=1.0, guard=None):
+    """MelGAN ResidualStack as one launch (fv_residual_stack_split_f16); packed = pack_residual_stack_split(...),
+    bias_out = stack[4].bias + skip_layer.bias."""
+    B, c, T = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    with _on(x, packed, bias_dilated, bias_out, out, out_act) as stream:
+        check(lib().fv_residual_stack_split_f16(_ptr(x, "x"), _ptr(packed, "packed"), _ptr(bias_dilated, "bias_dilated", True),
+                                                _ptr(bias_out, "bias_out", True), _ptr(out, "out"), _ptr(out_act, "out_act", True),
+                                                B, c, T, k, dil, float(slope), pad_mode, float(act_slope), _guard_ptr(guard), stream))
     return out
 
 
@@ -757,6 +798,16 @@ class Plan:
                                                        _ptr(bias, "bias", True), channels, float(pre_slope), post,
                                                        float(act_slope)))
 
+    def add_residual_stack_split_f16(self, x, y, packed, bias_dilated, bias_out, channels, k, dil, slope, pad_mode=PAD_REFLECT,
+                                     y_act=SLOT_NONE, act_slope=1.0):
+        self.keep(packed)
+        for b in (bias_dilated, bias_out):
+            if b is not None:
+                self.keep(b)
+        check(lib().fv_plan_add_residual_stack_split_f16(self._h, x, y, y_act, _ptr(packed, "packed"),
+                                                         _ptr(bias_dilated, "bias_dilated", True), _ptr(bias_out, "bias_out", True),
+                                                         channels, k, dil, float(slope), pad_mode, float(act_slope)))
+
     def add_upsample_conv1d(self, x, y, packed, bias, cin, cout, k, rate, pad, pre_slope=1.0,
                             post=POST_NONE, y_act=SLOT_NONE, act_slope=1.0):
         self.keep(packed)
@@ -942,6 +993,7 @@ def profile_enable(on):
 
 KERNEL_CONV_MFMA32, KERNEL_CONV_MFMA16, KERNEL_CONV_NARROW, KERNEL_PAIR16, KERNEL_PAIR32 = 0, 1, 2, 3, 4
 KERNEL_PAIRH16, KERNEL_PAIRH32, KERNEL_CONVH64, KERNEL_CONVH128, KERNEL_CONVT, KERNEL_CONVG = 5, 6, 7, 8, 9, 10
+KERNEL_STACK = 11
 
 
 def profile_bracket_cost(n=200):

@@ -372,7 +372,7 @@ __global__ void pack_convth_kernel(const float* __restrict__ w, _Float16* __rest
 // ---------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------
-enum OpType { OP_CONV = 0, OP_CONVT = 1, OP_PQMF = 2, OP_UPCONV = 3, OP_PAIR = 4, OP_MRFSUM = 5, OP_CONVH = 6, OP_CONVG = 7 };
+enum OpType { OP_CONV = 0, OP_CONVT = 1, OP_PQMF = 2, OP_UPCONV = 3, OP_PAIR = 4, OP_MRFSUM = 5, OP_CONVH = 6, OP_CONVG = 7, OP_STACK = 8 };
 
 struct Op {
     int type;
@@ -380,6 +380,7 @@ struct Op {
     int group;     // ops with the same non-zero id are mutually independent: one grouped launch
     const float* wp;
     const float* bias;
+    const float* bias2 = nullptr;   // OP_STACK: bias of the 1x1 pair (stack[4] + skip_layer); `bias` is the dilated conv's
     int Cin, Cout, k, dil, pad, pad_mode, stride, out_pad;
     float pre_slope, out_div, act_slope;
     int post;
@@ -439,7 +440,7 @@ struct fv_plan {
 namespace fv {
 
 static int64_t conv_out_len(const Op& o, int64_t Tin) {
-    if (o.type == OP_PAIR || o.type == OP_MRFSUM || o.type == OP_CONVH || o.type == OP_CONVG) return Tin;
+    if (o.type == OP_PAIR || o.type == OP_MRFSUM || o.type == OP_CONVH || o.type == OP_CONVG || o.type == OP_STACK) return Tin;
     if (o.type == OP_CONV) {
         const int64_t t = (o.pad_mode & FV_PAD_CAUSAL) ? Tin : Tin + 2LL * o.pad - (int64_t)o.dil * (o.k - 1);
         return o.pq_h ? t * o.Cout : t;      // (conv_post + pqmf: the S sub-bands interleave into S * T' samples)
@@ -622,6 +623,23 @@ static int run_op(const Op& o, const float* x, float* y, float* y2, const float*
         pp.m[0].y = y;
         pp.m[0].y_act = y2;
         return launch_convg(pp, o.Cout, s);
+    }
+    if (o.type == OP_STACK) {
+        PairParams pp = {};
+        pp.B = B;
+        pp.T = (int)Tin;
+        pp.slope = o.pre_slope;
+        pp.act_slope = o.act_slope;
+        pp.prec = FV_PAIR_SPLIT_F16;
+        pp.guard = guard;
+        pp.reflect = (o.pad_mode & FV_PAD_REFLECT) ? 1 : 0;
+        pp.m[0].x = x;
+        pp.m[0].w1 = o.wp;
+        pp.m[0].b1 = o.bias;
+        pp.m[0].b2 = o.bias2;
+        pp.m[0].y = y;
+        pp.m[0].y_act = y2;
+        return launch_convk(pp, o.Cout, o.dil, s);
     }
     if (o.type == OP_CONVT && o.prec == FV_PAIR_SPLIT_F16) {
         PairParams pp = {};
@@ -1245,6 +1263,96 @@ int fv_plan_add_conv1x1_2src_split_f16(fv_plan_t* plan, int x_slot, int x2_slot,
     return 0;
 }
 
+// ---- MelGAN ResidualStack as one launch (convk_kernel) ----
+int64_t fv_packed_residual_stack_floats(int C, int k) {
+    if (!convk_shape(C, k, 1)) return 0;
+    return (int64_t)5 * (C / 32) * C * 32 + 2 * C;       // 5 C / 32 stages of C x 128 bytes, + the rows' inverse prescales (conv1's, the 1x1 pair's)
+}
+
+int fv_pack_residual_stack_split_f16(const float* w_dilated, const float* w_pointwise, const float* w_skip, float* packed,
+                                     int C, int k, int* range_flag, void* stream) {
+    if (!w_dilated || !w_pointwise || !w_skip || !packed) return fail(FV_ERR_INVALID_ARG, "pack_residual_stack_split_f16: null tensor");
+    const int64_t n = fv_packed_residual_stack_floats(C, k);
+    if (n <= 0) return fail(FV_ERR_UNSUPPORTED, "pack_residual_stack_split_f16: C = %d, k = %d (32 / 64 / 128 channels, 3 taps)", C, k);
+    float* inv = packed + (n - 2 * C);
+    // the same row prescales as the two-launch form: conv1's rows over their 3 C weights, the 1x1 pair's over [W2 | Ws]
+    hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)C), dim3(64), 0, (hipStream_t)stream, w_dilated, (const float*)nullptr,
+                       inv, C, 3 * C, 0, 0, 0);
+    hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)C), dim3(64), 0, (hipStream_t)stream, w_pointwise, w_skip, inv + C, C, C,
+                       1, 0, 0);
+    return launch_pack_convk(w_dilated, w_pointwise, w_skip, packed, C, range_flag, (hipStream_t)stream);
+}
+
+static int check_stack_args(int C, int k, int dil, int pad_mode, float slope, float act_slope) {
+    if (!convk_shape(C, k, dil))
+        return fail(FV_ERR_UNSUPPORTED, "residual_stack_split_f16: C = %d, k = %d, dilation %d (32 / 64 / 128 channels, 3 taps, "
+                    "dilation 1, 3 or 9)", C, k, dil);
+    if (pad_mode != FV_PAD_ZERO && pad_mode != FV_PAD_REFLECT)
+        return fail(FV_ERR_UNSUPPORTED, "residual_stack_split_f16: pad_mode %d (zero or reflection padding of the 'same' conv)", pad_mode);
+    if (slope < 0.f || slope > 1.f || act_slope < 0.f || act_slope > 1.f)
+        return fail(FV_ERR_INVALID_ARG, "residual_stack_split_f16: activation slope outside [0, 1]");
+    return 0;
+}
+
+int fv_residual_stack_split_f16(const float* x, const float* packed, const float* bias_dilated, const float* bias_out, float* y,
+                                float* y_act, int B, int C, int T, int k, int dil, float slope, int pad_mode, float act_slope,
+                                int* guard, void* stream) {
+    if (!x || !packed || !y) return fail(FV_ERR_INVALID_ARG, "residual_stack_split_f16: null tensor");
+    if (x == y || x == y_act || (y_act && y_act == y))
+        return fail(FV_ERR_INVALID_ARG, "residual_stack_split_f16: y / y_act must not alias x or each other");
+    if (B < 0 || T < 0) return fail(FV_ERR_INVALID_ARG, "residual_stack_split_f16: B=%d T=%d", B, T);
+    if (int rc = check_stack_args(C, k, dil, pad_mode, slope, act_slope)) return rc;
+    Op o = {};
+    o.type = OP_STACK;
+    o.prec = FV_PAIR_SPLIT_F16;
+    o.wp = packed;
+    o.bias = bias_dilated;
+    o.bias2 = bias_out;
+    o.Cin = o.Cout = C;
+    o.k = k;
+    o.dil = dil;
+    o.pad = dil * (k - 1) / 2;
+    o.pad_mode = pad_mode;
+    o.pre_slope = slope;
+    o.out_div = 1.f;
+    o.act_slope = act_slope;
+    return run_op(o, x, y, y_act, nullptr, nullptr, nullptr, B, T, (hipStream_t)stream, nullptr, nullptr, 0, guard);
+}
+
+int fv_plan_add_residual_stack_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed,
+                                         const float* bias_dilated, const float* bias_out, int C, int k, int dil, float slope,
+                                         int pad_mode, float act_slope) {
+    if (!plan || !packed) return fail(FV_ERR_INVALID_ARG, "plan_add_residual_stack_split_f16: null");
+    if (int rc = check_stack_args(C, k, dil, pad_mode, slope, act_slope)) return rc;
+    if (int rc = check_slot(x_slot, false)) return rc;
+    if (int rc = check_slot(y_slot, false)) return rc;
+    if (int rc = check_slot(y_act_slot, true)) return rc;
+    if (y_slot == FV_SLOT_IN || y_act_slot == FV_SLOT_IN) return fail(FV_ERR_INVALID_ARG, "plan: the input slot is read-only");
+    Op o = {};
+    o.type = OP_STACK;
+    o.prec = FV_PAIR_SPLIT_F16;
+    o.x = x_slot;
+    o.y = y_slot;
+    o.y2 = y_act_slot;
+    o.res = o.acc = o.acc2 = FV_SLOT_NONE;
+    o.group = 0;
+    o.wp = packed;
+    o.bias = bias_dilated;
+    o.bias2 = bias_out;
+    o.Cin = o.Cout = C;
+    o.k = k;
+    o.dil = dil;
+    o.pad = dil * (k - 1) / 2;
+    o.pad_mode = pad_mode;
+    o.stride = 1;
+    o.pre_slope = slope;
+    o.out_div = 1.f;
+    o.post = FV_POST_NONE;
+    o.act_slope = act_slope;
+    plan->ops.push_back(o);
+    return 0;
+}
+
 int fv_plan_add_conv_transpose1d(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot,
                                  const float* packed, const float* bias, int Cin, int Cout, int k,
                                  int stride, int pad, int out_pad, float pre_slope, int post,
@@ -1721,7 +1829,7 @@ int fv_plan_set_output_offset(fv_plan_t* plan, int aux_slot, int y2_slot) {
         return fail(FV_ERR_INVALID_ARG, "plan_set_output_offset: slot %d is not an auxiliary input", aux_slot);
     if (int rc = check_slot(y2_slot, true)) return rc;
     Op& o = plan->ops.back();
-    if (o.type == OP_PAIR || o.type == OP_MRFSUM || o.type == OP_CONVH || o.sum3 || o.group != 0 ||
+    if (o.type == OP_PAIR || o.type == OP_MRFSUM || o.type == OP_CONVH || o.type == OP_STACK || o.sum3 || o.group != 0 ||
         (o.type == OP_CONVT && o.prec == FV_PAIR_SPLIT_F16))   // (a pair with a folded output conv included)
         return fail(FV_ERR_UNSUPPORTED, "plan_set_output_offset: only plain conv / transposed conv / two-source 1x1 / pqmf ops carry an offset");
     if (y2_slot != FV_SLOT_NONE) {

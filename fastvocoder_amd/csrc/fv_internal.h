@@ -352,6 +352,11 @@ inline bool convtn_shape(int Cin, int Cout, int k, int stride) { return Cin == 3
 constexpr int kTnPackedFloats = 2048 + 32;
 int launch_convtn(const PairParams& p, int Tout, hipStream_t s);
 int launch_pack_convtn(const float* w, float* packed, const float* inv, int* range_flag, hipStream_t s);
+// MelGAN ResidualStack as one launch (convk_kernels.hpp): member 0 uses x, w1 (fv_pack_residual_stack_split_f16 image),
+// b1 (the dilated conv's bias), b2 (stack[4]'s + the skip layer's), y, y_act; p.reflect: ReflectionPad1d
+inline bool convk_shape(int C, int k, int dil) { return (C == 32 || C == 64 || C == 128) && k == 3 && (dil == 1 || dil == 3 || dil == 9); }
+int launch_convk(const PairParams& p, int C, int dil, hipStream_t s);
+int launch_pack_convk(const float* w1, const float* w2, const float* ws, float* packed, int C, int* range_flag, hipStream_t s);
 // y = post(W1 lrelu(x, slope) + W2 x2 + bias + res), 1-tap convs C -> C with split-f16 operands (convg_kernel): member 0
 // uses x, x2, w1 (fv_pack_conv1x1_2src_split_f16 image), b1, res, y, y_act; C = 128, 256 or 512
 int launch_convg(PairParams p, int C, hipStream_t stream);

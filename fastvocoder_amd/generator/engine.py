@@ -242,6 +242,31 @@ class PlanBuilder:
                              packed=_native.pack_pair(effective_weight(conv), _native.PAIR_SPLIT_F16, self.guard),
                              bias=self._bias(conv), out_div=float(out_div), post=post))
 
+    def residual_stack_supported(self, dilated, pointwise, skip, pad, pad_mode=PAD_ZERO):
+        """Can this MelGAN ResidualStack -- ``dilated`` (k taps, 'same' padding ``pad`` applied in front of it, zero or
+        reflected), ``pointwise`` and ``skip`` (1x1) -- run as ONE launch (csrc/convk_kernels.hpp), and is split-f16
+        arithmetic in force for its channel count?"""
+        c, k, d = dilated.in_channels, dilated.kernel_size[0], dilated.dilation[0]
+        return (self.precision != "f32" and dilated.stride[0] == 1 and dilated.groups == 1 and dilated.out_channels == c
+                and dilated.padding[0] == 0 and pad == d * (k - 1) // 2 and pad_mode in (PAD_ZERO, PAD_REFLECT)
+                and all(cv.kernel_size[0] == 1 and cv.stride[0] == 1 and cv.groups == 1 and cv.padding[0] == 0
+                        and cv.in_channels == c and cv.out_channels == c for cv in (pointwise, skip))
+                and _native.residual_stack_split_supported(c, k, d))
+
+    def residual_stack(self, dilated, pointwise, skip, src, dst, slope, pad_mode=PAD_ZERO):
+        """dst = pointwise(lrelu(dilated(pad(lrelu(src))))) + skip(src), reference modules.py:351-382, as one launch
+        (fv_plan_add_residual_stack_split_f16).  ``src`` is read raw; nothing is hoisted into its producer."""
+        c, k, d = dilated.in_channels, dilated.kernel_size[0], dilated.dilation[0]
+        if not self.residual_stack_supported(dilated, pointwise, skip, d * (k - 1) // 2, pad_mode):
+            raise _native.NativeError("residual_stack: shape not built into the one-launch kernel")
+        ba, bb = self._bias(pointwise), self._bias(skip)
+        bias_out = ba if bb is None else (bb if ba is None else (ba + bb).contiguous())
+        self.ops.append(dict(kind="stack", x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE, pre_slope=1.0, slope=float(slope),
+                             split=True, channels=c, k=k, dil=d, pad_mode=pad_mode,
+                             packed=_native.pack_residual_stack_split(effective_weight(dilated), effective_weight(pointwise),
+                                                                      effective_weight(skip), self.guard),
+                             bias=self._bias(dilated), bias_out=bias_out, post=POST_NONE))
+
     def mrf_sum(self, pairs, srcs, dst, slope, out_div, post=POST_NONE):
         """dst = post(sum_j pair_j(srcs[j]) / out_div): the last pairs of the three ResBlocks of an MRF stage
         and the mean, one launch (fv_plan_add_mrf_sum)."""
@@ -426,7 +451,7 @@ class PlanBuilder:
                 own, rate = max(op["ks"]) // 2, 1
             elif op["kind"] in ("conv2", "conv2h"):
                 own, rate = 0, 1
-            elif op["kind"] == "convh":
+            elif op["kind"] in ("convh", "stack"):
                 own, rate = (op["k"] - 1) // 2 * op["dil"], 1
             elif op["kind"] == "pair":
                 own, rate = (op["k"] - 1) // 2 * (op["dil"] + 1) + (3 if "fold_w" in op else 0), 1
@@ -503,6 +528,10 @@ class PlanBuilder:
                 self.plan.add_conv1x1_2src_split_f16(op["x"], op["x2"], op["y"], op["packed"], op["bias"], op["channels"],
                                                      pre_slope=op["slope"], res=op["res"], post=op["post"],
                                                      y_act=op["y_act"], act_slope=op["act_slope"])
+            elif op["kind"] == "stack":
+                self.plan.add_residual_stack_split_f16(op["x"], op["y"], op["packed"], op["bias"], op["bias_out"],
+                                                       op["channels"], op["k"], op["dil"], op["slope"],
+                                                       pad_mode=op["pad_mode"], y_act=op["y_act"], act_slope=op["act_slope"])
             elif op["kind"] == "convT" and op.get("split"):
                 self.plan.add_conv_transpose1d_split_f16(op["x"], op["y"], op["packed"], op["bias"], op["cin"],
                                                          op["cout"], op["k"], op["stride"], op["pad"], op["out_pad"],

@@ -72,7 +72,7 @@ class _MelGANTrunk(NativeModule):
             elif isinstance(m, torch.nn.ConvTranspose1d):
                 pb.conv_transpose(m, cur, nxt, pre_slope=pending_slope, post=post)
             elif isinstance(m, ResidualStack):
-                m.emit(pb, cur, nxt, scratch, post=post)
+                m.emit(pb, cur, nxt, scratch, post=post, last=is_last)
             elif isinstance(m, LastLayer):
                 m.emit(pb, cur, nxt, post=post)
             elif isinstance(m, UpsampleLayer):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FV_ABI_VERSION 9
+#define FV_ABI_VERSION 10
 
 #define FV_ERR_INVALID_ARG (-1)
 #define FV_ERR_UNSUPPORTED (-2)
@@ -284,6 +284,27 @@ int fv_conv1x1_2src_split_f16(const float* x, const float* x2, const float* pack
                               int* guard, void* stream);
 
 /*
+ * MelGAN's ResidualStack (modules.py:351-382) as ONE launch, C = 32, 64 or 128 channels, 3 taps, dilation 1, 3 or 9,
+ * split-f16 operands (arithmetic and domain: FV_PAIR_SPLIT_F16 above):
+ *
+ *     y = W2 * lrelu( conv1d( pad( lrelu(x, slope) ); w_dilated, dil ) + bias_dilated, slope ) + Ws * x + bias_out
+ *
+ * stack = [act, pad, Conv1d(C, C, 3, dilation), act, Conv1d(C, C, 1)] (modules.py:362-366), skip_layer = Conv1d(C, C, 1)
+ * of the raw input (:377, :382); bias_out = stack[4].bias + skip_layer.bias or NULL; pad_mode FV_PAD_ZERO or
+ * FV_PAD_REFLECT (`dil` samples on either side: the 'same' padding of the dilated conv).  The hidden tensor never
+ * leaves the CU (csrc/convk_kernels.hpp); at 128 channels the result is bit-identical to fv_conv1d_split_f16 followed
+ * by fv_conv1x1_2src_split_f16.  y_act (or NULL): lrelu(y, act_slope); without y_act and act_slope != 1, y itself is
+ * stored activated.  packed: fv_pack_residual_stack_split_f16 of the three weights [C, C, 3], [C, C, 1], [C, C, 1]
+ * (fv_packed_residual_stack_floats floats; 0 = shape not built).
+ */
+int64_t fv_packed_residual_stack_floats(int C, int k);
+int fv_pack_residual_stack_split_f16(const float* w_dilated, const float* w_pointwise, const float* w_skip, float* packed,
+                                     int C, int k, int* range_flag, void* stream);
+int fv_residual_stack_split_f16(const float* x, const float* packed, const float* bias_dilated, const float* bias_out, float* y,
+                                float* y_act, int B, int C, int T, int k, int dil, float slope, int pad_mode, float act_slope,
+                                int* guard, void* stream);
+
+/*
  * y = post( conv_transpose1d(lrelu(x, pre_slope); w, stride, pad, out_pad) + bias )
  *
  * Replaces F.leaky_relu + torch.nn.ConvTranspose1d at hifigan.py:95-96,
@@ -406,6 +427,9 @@ int fv_plan_add_conv1d_2src(fv_plan_t* plan, int x_slot, int x2_slot, int y_slot
 int fv_plan_add_conv1x1_2src_split_f16(fv_plan_t* plan, int x_slot, int x2_slot, int y_slot, int y_act_slot, int res_slot,
                                        const float* packed, const float* bias, int C, float pre_slope, int post,
                                        float act_slope);
+int fv_plan_add_residual_stack_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed,
+                                         const float* bias_dilated, const float* bias_out, int C, int k, int dil, float slope,
+                                         int pad_mode, float act_slope);
 /*
  * y = act( ( sum_{j<3} ( conv1d(x_j; w_j, k_j taps, 'same' zero padding) + res_j ) + bias_sum ) / out_div )
  *
@@ -567,6 +591,7 @@ int fv_tuning_set(const char* key, int value);
 #define FV_KERNEL_CONVH128 8    /* ... C = 128 */
 #define FV_KERNEL_CONVT 9       /* transposed conv (kernel = 2 strides) with split-f16 operands (convt_kernel) */
 #define FV_KERNEL_CONVG 10      /* two-source 1x1 conv (ResidualStack tail) with split-f16 operands (convg_kernel) */
+#define FV_KERNEL_STACK 11      /* MelGAN ResidualStack as one launch, 32 / 64 / 128 channels, split-f16 operands (convk_kernel) */
 int fv_profile_enable(int on);
 /* what the measurement adds to a launch (subtract it per launch): a launch's duration is measured completion to
  * completion on its stream, from the end event of the launch before it to its own (its dispatch latency included, as

@@ -30,7 +30,11 @@ def main():
     ap.add_argument("--only", type=int, default=None, help="index into CONFIGS (0-based): run just that one")
     ap.add_argument("--tuning", default="", help='launcher switches "key=value,..." (fv_tuning_set) for an A/B')
     ap.add_argument("--no-merge", action="store_true", help="A/B: the MRF merge in the stage's own last launch (merge_in_upsampler = False)")
+    ap.add_argument("--no-stack", action="store_true", help="A/B: MelGAN's ResidualStacks as two launches each (fuse_stack = False)")
     args = ap.parse_args()
+    if args.no_stack:
+        from fastvocoder_amd.generator.modules import ResidualStack
+        ResidualStack.fuse_stack = False
     if args.no_merge:
         from fastvocoder_amd.generator.engine import NativeModule
         NativeModule.merge_in_upsampler = False
