@@ -313,8 +313,13 @@ def test_fused_skip_equals_unfused_residual_stack():
     torch.manual_seed(1)
     rs = modules.ResidualStack(kernel_size=3, channels=64, dilation=3).to(_dev())
     x = torch.randn(2, 64, 500, device=_dev())
+    one = rs(x).cpu().numpy()
+    assert _plans(rs)["forward"].num_ops() == 1          # the whole stack as one launch (csrc/convk_kernels.hpp)
+    rs.fuse_stack = False
+    rs.invalidate_plans()
     fused = rs(x).cpu().numpy()
     assert _plans(rs)["forward"].num_ops() == 2
+    assert np.abs(one - fused).max() <= 1e-5 * max(1.0, np.abs(fused).max())
     rs.fuse_skip = False
     rs.invalidate_plans()
     plain = rs(x).cpu().numpy()
