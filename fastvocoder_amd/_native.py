@@ -165,6 +165,7 @@ def lib():
     L.fv_pack_residual_stack_split_f16.argtypes = [vp, vp, vp, vp, i, i, vp, vp]
     L.fv_residual_stack_split_f16.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, i, f, vp, vp]
     L.fv_plan_add_residual_stack_split_f16.argtypes = [vp, i, i, i, vp, vp, vp, i, i, i, f, i, f]
+    L.fv_plan_set_stack_two_launch.argtypes = [vp, i, vp, vp]
     L.fv_conv_post_pqmf.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, f, i, i, vp]
     L.fv_plan_add_conv_post_pqmf.argtypes = [vp, i, i, vp, vp, i, i, i, i, f, i, vp, i]
     L.fv_plan_set_sum_order.argtypes = [vp, i]
@@ -395,7 +396,7 @@ def pack_conv1x1_2src_split(w1, w2, flag=None):
 
 def residual_stack_split_supported(channels, k, dil):
     """Shapes of the one-launch MelGAN ResidualStack (csrc/convk_kernels.hpp)."""
-    return channels in (32, 64, 128) and k == 3 and dil in (1, 3, 9)
+    return channels in (32, 64, 128, 256) and k == 3 and dil in (1, 3, 9)
 
 
 def pack_residual_stack_split(w_dilated, w_pointwise, w_skip, flag=None):
@@ -407,7 +408,7 @@ def pack_residual_stack_split(w_dilated, w_pointwise, w_skip, flag=None):
         raise NativeError(f"pack_residual_stack_split: [C,C,k], [C,C,1], [C,C,1] expected, got {[tuple(w.shape) for w in ws]}")
     n = lib().fv_packed_residual_stack_floats(c, k)
     if n <= 0:
-        raise NativeError(f"pack_residual_stack_split: C={c}, k={k} is not built (32 / 64 / 128 channels, 3 taps)")
+        raise NativeError(f"pack_residual_stack_split: C={c}, k={k} is not built (32 / 64 / 128 / 256 channels, 3 taps)")
     out = torch.empty(n, dtype=torch.float32, device=ws[0].device)
     with _on(*ws) as stream:
         check(lib().fv_pack_residual_stack_split_f16(_ptr(ws[0], "w_dilated"), _ptr(ws[1], "w_pointwise"), _ptr(ws[2], "w_skip"),
@@ -799,7 +800,9 @@ class Plan:
                                                        float(act_slope)))
 
     def add_residual_stack_split_f16(self, x, y, packed, bias_dilated, bias_out, channels, k, dil, slope, pad_mode=PAD_REFLECT,
-                                     y_act=SLOT_NONE, act_slope=1.0):
+                                     y_act=SLOT_NONE, act_slope=1.0, two_launch=None):
+        """``two_launch`` = (hidden slot, pack_pair image of the dilated conv, pack_conv1x1_2src_split image of the 1x1 pair):
+        the form a run with many tiles takes instead (fv_plan_set_stack_two_launch; 256 channels)."""
         self.keep(packed)
         for b in (bias_dilated, bias_out):
             if b is not None:
@@ -807,6 +810,11 @@ class Plan:
         check(lib().fv_plan_add_residual_stack_split_f16(self._h, x, y, y_act, _ptr(packed, "packed"),
                                                          _ptr(bias_dilated, "bias_dilated", True), _ptr(bias_out, "bias_out", True),
                                                          channels, k, dil, float(slope), pad_mode, float(act_slope)))
+        if two_launch is not None:
+            hidden, pd, pp = two_launch
+            self.keep(pd)
+            self.keep(pp)
+            check(lib().fv_plan_set_stack_two_launch(self._h, hidden, _ptr(pd, "packed_dilated"), _ptr(pp, "packed_pair")))
 
     def add_upsample_conv1d(self, x, y, packed, bias, cin, cout, k, rate, pad, pre_slope=1.0,
                             post=POST_NONE, y_act=SLOT_NONE, act_slope=1.0):

@@ -381,6 +381,11 @@ struct Op {
     const float* wp;
     const float* bias;
     const float* bias2 = nullptr;   // OP_STACK: bias of the 1x1 pair (stack[4] + skip_layer); `bias` is the dilated conv's
+    // OP_STACK at 256 channels (fv_plan_set_stack_two_launch): the two-launch form for runs with many tiles -- the dilated
+    // conv's fv_pack_pair_weight_ex image, the 1x1 pair's fv_pack_conv1x1_2src_split_f16 image, the hidden tensor's slot
+    const float* alt_w1 = nullptr;
+    const float* alt_w2 = nullptr;
+    int alt_mid = FV_SLOT_NONE;
     int Cin, Cout, k, dil, pad, pad_mode, stride, out_pad;
     float pre_slope, out_div, act_slope;
     int post;
@@ -514,6 +519,13 @@ static int infer(const fv_plan* plan, int B, int T, Shape* sh, int64_t* slot_ele
                 const int64_t es = (int64_t)B * o.Cout * sh[o.x].T;
                 if (es > slot_elems[t2[e]]) slot_elems[t2[e]] = es;
             }
+        }
+        if (o.type == OP_STACK && o.alt_mid != FV_SLOT_NONE) {   // hidden tensor of the two-launch form
+            if (o.alt_mid == o.x || o.alt_mid == o.y || o.alt_mid == o.y2 || o.alt_mid == FV_SLOT_IN)
+                return fail(FV_ERR_INVALID_ARG, "op %zu: stack scratch slot %d aliases an operand", n, o.alt_mid);
+            sh[o.alt_mid] = {o.Cout, sh[o.x].T, true};
+            const int64_t es = (int64_t)B * o.Cout * sh[o.x].T;
+            if (es > slot_elems[o.alt_mid]) slot_elems[o.alt_mid] = es;
         }
         if (o.type == OP_PAIR && o.tmpb != FV_SLOT_NONE) {   // intermediate of a two-launch (C >= 64) pair
             if (o.tmpb == o.x || o.tmpb == o.y || o.tmpb == o.y2 || o.tmpb == o.acc || o.tmpb == o.acc2 || o.tmpb == FV_SLOT_IN)
@@ -720,7 +732,7 @@ static const TuningEntry kTuningTable[] = {
     {"pair_dbg", &Tuning::pair_dbg},       {"dbg", &Tuning::conv_dbg},           {"sched", &Tuning::sched},
     {"sched_switch", &Tuning::sched_switch}, {"convh_skel", &Tuning::convh_skel}, {"convp_skel", &Tuning::convp_skel},
     {"convq_skel", &Tuning::convq_skel},   {"pair128_unfused", &Tuning::pair128_unfused},
-    {"chain", &Tuning::chain},             {"chain_spin", &Tuning::chain_spin},  {"convg_rows64", &Tuning::convg_rows64},
+    {"chain", &Tuning::chain},             {"chain_spin", &Tuning::chain_spin},  {"convg_rows64", &Tuning::convg_rows64}, {"stack_items", &Tuning::stack_items},
     {"convh_rows64", &Tuning::convh_rows64},  {"convt_rows64", &Tuning::convt_rows64},
     {"pairh_skel", &Tuning::pairh_skel},   {"pair_skel", &Tuning::pair_skel},    {"convh_blocks", &Tuning::convh_blocks},
     {"pair_blocks", &Tuning::pair_blocks}, {"sum3_min", &Tuning::sum3_min},      {"lds_budget", &Tuning::lds_budget},
@@ -1273,7 +1285,7 @@ int fv_pack_residual_stack_split_f16(const float* w_dilated, const float* w_poin
                                      int C, int k, int* range_flag, void* stream) {
     if (!w_dilated || !w_pointwise || !w_skip || !packed) return fail(FV_ERR_INVALID_ARG, "pack_residual_stack_split_f16: null tensor");
     const int64_t n = fv_packed_residual_stack_floats(C, k);
-    if (n <= 0) return fail(FV_ERR_UNSUPPORTED, "pack_residual_stack_split_f16: C = %d, k = %d (32 / 64 / 128 channels, 3 taps)", C, k);
+    if (n <= 0) return fail(FV_ERR_UNSUPPORTED, "pack_residual_stack_split_f16: C = %d, k = %d (32 / 64 / 128 / 256 channels, 3 taps)", C, k);
     float* inv = packed + (n - 2 * C);
     // the same row prescales as the two-launch form: conv1's rows over their 3 C weights, the 1x1 pair's over [W2 | Ws]
     hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)C), dim3(64), 0, (hipStream_t)stream, w_dilated, (const float*)nullptr,
@@ -1283,9 +1295,20 @@ int fv_pack_residual_stack_split_f16(const float* w_dilated, const float* w_poin
     return launch_pack_convk(w_dilated, w_pointwise, w_skip, packed, C, range_flag, (hipStream_t)stream);
 }
 
+// A residual stack that carries its two-launch form (256 channels): one launch up to Tuning::stack_items tiles per CU (in
+// tenths), else two launches on 128-row x 128-column tiles.  [measured, Basis-MelGAN light, 1000 frames, batch 1 / 4 / 16 /
+// 64, tools/bench_configs.py --only 3 --batch B --tuning stack_items=0 against the default] 0.385 -> 0.304, 1.03 -> 0.94,
+// 3.55 -> 3.35, 13.0 -> 12.45 ms: the one-launch kernel wins at every size, so the default limit is "none"; the switch
+// stays for A/B runs and the bit-identity tests
+static bool stack_two_launch(int C, int B, int64_t T) {
+    const int nm = convk_tile_columns(C);
+    const int64_t items = (int64_t)B * ((T + nm - 1) / nm);
+    return items * 10 > (int64_t)tuning().stack_items * device_cu_count();
+}
+
 static int check_stack_args(int C, int k, int dil, int pad_mode, float slope, float act_slope) {
     if (!convk_shape(C, k, dil))
-        return fail(FV_ERR_UNSUPPORTED, "residual_stack_split_f16: C = %d, k = %d, dilation %d (32 / 64 / 128 channels, 3 taps, "
+        return fail(FV_ERR_UNSUPPORTED, "residual_stack_split_f16: C = %d, k = %d, dilation %d (32 / 64 / 128 / 256 channels, 3 taps, "
                     "dilation 1, 3 or 9)", C, k, dil);
     if (pad_mode != FV_PAD_ZERO && pad_mode != FV_PAD_REFLECT)
         return fail(FV_ERR_UNSUPPORTED, "residual_stack_split_f16: pad_mode %d (zero or reflection padding of the 'same' conv)", pad_mode);
@@ -1350,6 +1373,21 @@ int fv_plan_add_residual_stack_split_f16(fv_plan_t* plan, int x_slot, int y_slot
     o.post = FV_POST_NONE;
     o.act_slope = act_slope;
     plan->ops.push_back(o);
+    return 0;
+}
+
+int fv_plan_set_stack_two_launch(fv_plan_t* plan, int hidden_slot, const float* packed_dilated, const float* packed_pair) {
+    if (!plan || plan->ops.empty() || !packed_dilated || !packed_pair)
+        return fail(FV_ERR_INVALID_ARG, "plan_set_stack_two_launch: no op / null weights");
+    if (int rc = check_slot(hidden_slot, false)) return rc;
+    Op& o = plan->ops.back();
+    if (o.type != OP_STACK || fv_packed_conv1x1_2src_split_floats(o.Cout) <= 0 || o.Cout < 128)
+        return fail(FV_ERR_UNSUPPORTED, "plan_set_stack_two_launch: the last op must be a residual stack of 128 or 256 channels");
+    if (hidden_slot == FV_SLOT_IN || hidden_slot == o.x || hidden_slot == o.y || hidden_slot == o.y2)
+        return fail(FV_ERR_INVALID_ARG, "plan_set_stack_two_launch: the scratch slot aliases an operand");
+    o.alt_w1 = packed_dilated;
+    o.alt_w2 = packed_pair;
+    o.alt_mid = hidden_slot;
     return 0;
 }
 
@@ -2154,6 +2192,42 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             }
             if (rc3) return rc3;
             sh[o.y] = {o.Cout, conv_out_len(o, sh[o.x].T), true};
+            if (o.y2 != FV_SLOT_NONE) sh[o.y2] = sh[o.y];
+            continue;
+        }
+        if (o.type == OP_STACK && o.alt_w1 && stack_two_launch(o.Cout, B, sh[o.x].T)) {
+            // many tiles: dilated conv into the scratch slot (convs_kernel), then the K-concatenated 1x1 pair (convr_kernel)
+            PairParams pp = {};
+            pp.B = B;
+            pp.T = (int)sh[o.x].T;
+            pp.slope = o.pre_slope;
+            pp.act_slope = 1.f;
+            pp.out_div = 1.f;
+            pp.prec = FV_PAIR_SPLIT_F16;
+            pp.guard = plan->guard_dev;
+            pp.reflect = o.pad_mode == FV_PAD_REFLECT;
+            pp.n_members = 1;
+            pp.m[0].x = base[o.x];
+            pp.m[0].w1 = o.alt_w1;
+            pp.m[0].b1 = o.bias;
+            pp.m[0].k = o.k;
+            pp.m[0].y = base[o.alt_mid];
+            if (int rc = launch_convh(pp, o.Cin, o.dil, s)) return rc;
+            PairParams pg = {};
+            pg.B = B;
+            pg.T = (int)sh[o.x].T;
+            pg.slope = o.pre_slope;
+            pg.act_slope = o.act_slope;
+            pg.prec = FV_PAIR_SPLIT_F16;
+            pg.guard = plan->guard_dev;
+            pg.m[0].x = base[o.alt_mid];
+            pg.m[0].x2 = base[o.x];
+            pg.m[0].w1 = o.alt_w2;
+            pg.m[0].b1 = o.bias2;
+            pg.m[0].y = base[o.y];
+            pg.m[0].y_act = o.y2 == FV_SLOT_NONE ? nullptr : base[o.y2];
+            if (int rc = launch_convg(pg, o.Cout, s)) return rc;
+            sh[o.y] = {o.Cout, sh[o.x].T, true};
             if (o.y2 != FV_SLOT_NONE) sh[o.y2] = sh[o.y];
             continue;
         }

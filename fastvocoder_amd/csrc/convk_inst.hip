@@ -31,9 +31,41 @@ __global__ void pack_convk_kernel(const float* __restrict__ w1, const float* __r
     }
 }
 
+// 256 channels (convk2_kernel): [stage = 2 K step + split half][row sixteenth 16][lane][8 halves]; K steps: conv1's in
+// chunks of 128 input channels, tap-major inside a chunk (convs_kernel's order), then W2's eight groups, then the skip layer's
+__global__ void pack_convk2_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ ws,
+                                   _Float16* __restrict__ wp, const float* __restrict__ inv1, const float* __restrict__ inv2,
+                                   int* range_flag) {
+    constexpr int C = 256, NK1 = 24, NST = 80;
+    const int total = NST * 8192;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i & 7, lane = (i >> 3) & 63, r16 = (i >> 9) & 15, st = i >> 13;
+        const int ks = st >> 1, half = st & 1;
+        const int co = 16 * r16 + (lane & 15), kb = lane >> 4;
+        float v;
+        if (ks < NK1) {
+            const int chunk = ks / 12, tap = (ks % 12) / 4, ci = 32 * (4 * chunk + ks % 4) + 8 * kb + j;
+            v = w1[((size_t)co * C + ci) * 3 + tap] * (1.f / inv1[co]);
+        } else if (ks < NK1 + 8) {
+            v = w2[(size_t)co * C + 32 * (ks - NK1) + 8 * kb + j] * (1.f / inv2[co]);
+        } else {
+            v = ws[(size_t)co * C + 32 * (ks - NK1 - 8) + 8 * kb + j] * (1.f / inv2[co]);
+        }
+        const _Float16 h1 = (_Float16)v;
+        if (range_flag && !(fabsf(v) < 65520.f)) *range_flag = 1;
+        wp[i] = half == 0 ? h1 : (_Float16)((v - (float)h1) * 2048.f);
+    }
+}
+
 int launch_pack_convk(const float* w1, const float* w2, const float* ws, float* packed, int C, int* range_flag, hipStream_t s) {
     const int image = 5 * (C / 32) * C * 32;             // floats
     const int total = image * 2;
+    if (C == 256) {
+        hipLaunchKernelGGL(pack_convk2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w1, w2, ws,
+                           reinterpret_cast<_Float16*>(packed), packed + image, packed + image + C, range_flag);
+        FV_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(pack_convk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w1, w2, ws,
                        reinterpret_cast<_Float16*>(packed), packed + image, packed + image + C, C, range_flag);
     FV_HIP(hipGetLastError());
@@ -48,6 +80,14 @@ static int launch_one(const ConvKParams& p, hipStream_t s) {
     FV_HIP(hipGetLastError());
     return 0;
 }
+template <int DIL>
+static int launch_256(const ConvKParams& p, hipStream_t s) {
+    typedef ConvK2Geom<DIL> G;
+    if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(convk2_kernel<DIL>), (size_t)G::LDS_BYTES)) return rc;
+    hipLaunchKernelGGL((convk2_kernel<DIL>), dim3(p.nblk), dim3(512), (size_t)G::LDS_BYTES, s, p);
+    FV_HIP(hipGetLastError());
+    return 0;
+}
 template <int CG>
 static int launch_cg(const ConvKParams& p, int dil, hipStream_t s) {
     return dil == 1 ? launch_one<CG, 1>(p, s) : dil == 3 ? launch_one<CG, 3>(p, s) : launch_one<CG, 9>(p, s);
@@ -55,7 +95,7 @@ static int launch_cg(const ConvKParams& p, int dil, hipStream_t s) {
 
 int launch_convk(const PairParams& pp, int C, int dil, hipStream_t s) {
     const PairMember& mb = pp.m[0];
-    if (!convk_shape(C, 3, dil)) return fail(FV_ERR_UNSUPPORTED, "residual stack: C = %d, dilation %d (32 / 64 / 128 channels, 3 taps, dilation 1, 3 or 9)", C, dil);
+    if (!convk_shape(C, 3, dil)) return fail(FV_ERR_UNSUPPORTED, "residual stack: C = %d, dilation %d (32 / 64 / 128 / 256 channels, 3 taps, dilation 1, 3 or 9)", C, dil);
     if (!mb.x || !mb.w1 || !mb.y) return fail(FV_ERR_INVALID_ARG, "residual stack: null tensor");
     if (reinterpret_cast<uintptr_t>(mb.w1) & 15) return fail(FV_ERR_UNSUPPORTED, "residual stack: packed weights must be 16-byte aligned");
     if (pp.B <= 0 || pp.T <= 0) return 0;
@@ -74,7 +114,7 @@ int launch_convk(const PairParams& pp, int C, int dil, hipStream_t s) {
     p.y_act = mb.y_act;
     p.B = pp.B;
     p.T = pp.T;
-    const int nm = 256 / (C / 32);
+    const int nm = convk_tile_columns(C);
     p.n_tiles = (pp.T + nm - 1) / nm;
     const long long items = (long long)p.n_tiles * pp.B;
     if (items >= (1LL << 31)) return fail(FV_ERR_UNSUPPORTED, "residual stack: too many tiles");
@@ -87,7 +127,8 @@ int launch_convk(const PairParams& pp, int C, int dil, hipStream_t s) {
     p.reflect = pp.reflect;
     p.guard = pp.guard;
     profile_begin(s);
-    const int rc = C == 32 ? launch_cg<1>(p, dil, s) : C == 64 ? launch_cg<2>(p, dil, s) : launch_cg<4>(p, dil, s);
+    const int rc = C == 32 ? launch_cg<1>(p, dil, s) : C == 64 ? launch_cg<2>(p, dil, s) : C == 128 ? launch_cg<4>(p, dil, s)
+                 : dil == 1 ? launch_256<1>(p, s) : dil == 3 ? launch_256<3>(p, s) : launch_256<9>(p, s);
     // conv1 (3 taps) + the two 1x1 convs; x in, y (and its twin) out, the weights once
     profile_end(s, FV_KERNEL_STACK, 2.0 * pp.B * (double)C * C * 5 * pp.T,
                 4.0 * (5.0 * C * C + (double)pp.B * C * pp.T * (mb.y_act ? 3 : 2)));

@@ -317,4 +317,258 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ---- 256 channels ---------------------------------------------------------------------------------------------------
+// A block holds all 256 rows of a 32-COLUMN tile (8 waves = 8 row slabs of 32, the same 32 x 32 wave tile): window image
+// <= 52 KB, hidden tile 32 KB.  A K step of all 256 rows is 32 KB of A operands -- a ring of three such stages would not
+// fit -- so a weight stage is one SPLIT HALF of a K step (16 KB: the h1 parts of all rows, then the h2 parts), ring of
+// four, three stages ahead.  Of a K step's 12 MFMAs per wave the 8 that multiply h1 (hi += a1 b1, lo += a1 b2) run when
+// the first stage has landed, the 4 that multiply h2 (lo += a2 b1) one stage entry later: the order of every other split
+// kernel, hence the bits of convs_kernel + convr_kernel (the two-launch form at 256 channels, whose K order -- chunks of
+// 128 input channels, tap-major inside a chunk -- the stage sequence follows).
+// 32-column tiles: 50 of them for MelGAN's first stage at batch 1 (1 600 columns), each a chain of 80 stage entries --
+// the form for launches that are latency-bound anyway; with more tiles than ~2 per CU the two-launch form on 128-row x
+// 128-column tiles is the faster one (the launcher decides: launch_convk).
+template <int DIL_>
+struct ConvK2Geom {
+    static constexpr int DIL = DIL_, KT = 3, C = 256, CG = 8, CB = 32, NFW = 2, NT = 512;
+    static constexpr int NM = 32, P = DIL;
+    static constexpr int XROWS = (NM + 2 * DIL + 3) / 4 * 4;
+    static constexpr int XRP = XROWS;                    // (B reads stay below row 31 + 2 DIL: no padding rows needed)
+    static constexpr int XHALF = CB * XRP * 16;
+    static constexpr int XR = (XROWS * CB + NT - 1) / NT;
+    static constexpr int MRP = NM, MHALF = CB * MRP * 16;
+    static constexpr int NK1 = KT * CG, NK2 = 2 * CG;    // K steps of conv1 / of the 1x1 pair
+    static constexpr int NS1 = 2 * NK1, NST = 2 * (NK1 + NK2);      // stages: two per K step
+    static constexpr int STAGE_BYTES = 16384, RING = 4, AHEAD = 3, NDMA = 2;
+    static constexpr int NRAW = XR * 8;
+    static constexpr int WBYTES = NST * STAGE_BYTES;
+    static constexpr int RING_BYTES = RING * STAGE_BYTES;
+    static constexpr int LDS_BYTES = RING_BYTES + 2 * XHALF + 2 * MHALF + (4 * C + 16) * 4;
+    static_assert(NST % RING == 0, "ring slot = stage & 3");
+    static_assert(2 * MHALF <= 2 * XHALF && LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(((CG - 1) * 4 * XRP + (KT - 1) * DIL + 16) * 16 + 16 < 65536, "ds_read immediate range");
+};
+
+template <int DIL>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void convk2_kernel(ConvKParams p) {
+    typedef ConvK2Geom<DIL> G;
+    typedef __attribute__((address_space(3))) const f16x8 LdsH8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
+    asm volatile("" : "+v"(lane));
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int share = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    int item = equal_share(share, p.n_items, p.nblk);
+    const int hi_item = equal_share(share + 1, p.n_items, p.nblk);
+    if (item >= hi_item) return;
+
+    float* const ring = smem;
+    char* const ximg = reinterpret_cast<char*>(smem) + G::RING_BYTES;
+    char* const mimg = ximg + 2 * G::XHALF;
+    float* const bl = reinterpret_cast<float*>(mimg + 2 * G::MHALF);
+    const int n = lane & 15, kb = lane >> 4;
+    const int ws = wave;                                 // row slab of 32; one column group of 32
+    const int col0 = n;
+    const char* const bptr = ximg + (kb * G::XRP + col0) * 16;
+    const char* const mptr = mimg + (kb * G::MRP + col0) * 16;
+    const char* const rptr = ximg + (kb * G::MRP + col0) * 16;
+    const float* const aptr = ring + (2 * ws) * 256 + lane * 4;    // + slot stage + h * 256 floats (one split half per stage)
+    const int row0 = 32 * ws + 4 * kb;
+    char* const mw = mimg + ((4 * ws + (kb >> 1)) * G::MRP + col0) * 16 + 8 * (kb & 1);
+
+    const size_t ustride = (size_t)G::C * (size_t)p.T;
+    const unsigned ubytes = (unsigned)G::C * (unsigned)p.T * 4u;
+    const unsigned t4 = (unsigned)p.T * 4u;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (unsigned)G::WBYTES);
+    auto dma_stage = [&](int slot, unsigned stage_off) {
+        float* dst = ring + slot * (G::STAGE_BYTES / 4) + wave * 512;
+        const unsigned o = stage_off == kOutOfRange ? kOutOfRange : stage_off + (unsigned)(wave * 2048 + lane * 16);
+        dma16(rw, dst, o);
+        dma16(rw, dst + 256, o == kOutOfRange ? kOutOfRange : o + 1024u);
+    };
+    int b = item / p.n_tiles, tile = item - b * p.n_tiles;
+    LowGuard low;
+    f32x2 bad2 = {0.f, 0.f};
+    ConvHRaw<G> raw;
+    convh_load_raw<G>(raw, p.x + b * ustride, p.T, tile * G::NM - G::P, tid, true, p.reflect != 0);
+#pragma unroll
+    for (int st = 0; st < G::AHEAD; ++st) dma_stage(st, (unsigned)(st * G::STAGE_BYTES));
+    if (tid < G::C) {
+        bl[tid] = p.b1 ? p.b1[tid] : 0.f;
+        bl[G::C + tid] = p.b2 ? p.b2[tid] : 0.f;
+        bl[2 * G::C + tid] = p.w[G::WBYTES / 4 + tid];
+        bl[3 * G::C + tid] = p.w[G::WBYTES / 4 + G::C + tid];
+    }
+    pair_wait_vm0();
+    convh_convert<G>(raw, ximg, p.slope, tid, low, 0);
+    for (;;) {
+        const int t0 = tile * G::NM;
+        const int nitem = item + 1;
+        const bool more = nitem < hi_item;
+        int nb = b, ntile = tile + 1;
+        if (ntile == p.n_tiles) {
+            ntile = 0;
+            ++nb;
+        }
+        f32x4 hi[2][2], lo[2][2];
+        f16x8 a1[2], a2[2], bbuf[2][2][2];
+
+        // stage entry: as convk_kernel's, three stages ahead in a ring of four (NST % 4 == 0: slot = stage & 3)
+        auto entry = [&](auto GC) {
+            constexpr int GS = decltype(GC)::value;
+            constexpr bool raw_between = GS >= G::NS1 + 1 && GS <= G::NS1 + G::AHEAD;
+            if constexpr (GS >= G::AHEAD) wait_vm<G::NDMA * (G::AHEAD - 1) + (raw_between ? G::NRAW : 0)>();
+            pair_barrier();
+            constexpr int NS = GS + G::AHEAD;
+            if constexpr (NS < G::NST) dma_stage(NS & 3, (unsigned)(NS * G::STAGE_BYTES));
+            else dma_stage(NS & 3, more ? (unsigned)((NS - G::NST) * G::STAGE_BYTES) : kOutOfRange);
+        };
+        auto fetch_a = [&](auto SC, f16x8 (&dst)[2]) {   // the stage's split half of this wave's two row sixteenths
+            constexpr int S = decltype(SC)::value;
+            LdsCF* a = lds_opaque(aptr + (S & 3) * (G::STAGE_BYTES / 4));
+            dst[0] = *reinterpret_cast<LdsH8*>(a);
+            dst[1] = *reinterpret_cast<LdsH8*>(a + 256);
+        };
+        LdsCF* const bb = lds_opaque(reinterpret_cast<const float*>(bptr));
+        LdsCF* const bb2 = lds_opaque(reinterpret_cast<const float*>(bptr + G::XHALF));
+        LdsCF* const mb1 = lds_opaque(reinterpret_cast<const float*>(mptr));
+        LdsCF* const mb2 = lds_opaque(reinterpret_cast<const float*>(mptr + G::MHALF));
+        LdsCF* const rb1 = lds_opaque(reinterpret_cast<const float*>(rptr));
+        LdsCF* const rb2 = lds_opaque(reinterpret_cast<const float*>(rptr + G::MHALF));
+        // B operands of K step KS: conv1 -- chunk of 128 channels, tap, 32-channel group inside the chunk (the order of
+        // convs_kernel's packed image); then the hidden tile's eight groups, then the raw centre's
+        auto fetch_b = [&](auto KC, f16x8 (&dst)[2][2]) {
+            constexpr int KS = decltype(KC)::value;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if constexpr (KS < G::NK1) {
+                    constexpr int chunk = KS / 12, tap = (KS % 12) / 4, cg = 4 * chunk + KS % 4;
+                    constexpr int off = (cg * 4 * G::XRP + tap * G::DIL) * 4;
+                    dst[e][0] = *reinterpret_cast<LdsH8*>(bb + off + e * 64);
+                    dst[e][1] = *reinterpret_cast<LdsH8*>(bb2 + off + e * 64);
+                } else if constexpr (KS < G::NK1 + G::CG) {
+                    constexpr int off = ((KS - G::NK1) * 4 * G::MRP) * 4;
+                    dst[e][0] = *reinterpret_cast<LdsH8*>(mb1 + off + e * 64);
+                    dst[e][1] = *reinterpret_cast<LdsH8*>(mb2 + off + e * 64);
+                } else {
+                    constexpr int off = ((KS - G::NK1 - G::CG) * 4 * G::MRP) * 4;
+                    dst[e][0] = *reinterpret_cast<LdsH8*>(rb1 + off + e * 64);
+                    dst[e][1] = *reinterpret_cast<LdsH8*>(rb2 + off + e * 64);
+                }
+            }
+        };
+        // stages [S0, S1) (whole K steps): h1 stage -> 8 MFMAs, h2 stage -> 4
+        auto run = [&](auto S0C, auto S1C) {
+            constexpr int S0 = decltype(S0C)::value, S1 = decltype(S1C)::value;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+            fetch_a(IntC<S0>{}, a1);
+            fetch_b(IntC<S0 / 2>{}, bbuf[(S0 / 2) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<S0, S1>([&](auto SC) {
+                constexpr int S = decltype(SC)::value, SN = S + 1, KS = S / 2;
+                if constexpr (SN < G::NST) entry(IntC<SN>{});
+                if constexpr (S % 2 == 0) {
+                    fetch_a(IntC<SN>{}, a2);             // the K step's h2 parts: needed one entry from now
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            hi[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[h], bbuf[KS & 1][e][0], hi[h][e], 0, 0, 0);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            lo[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[h], bbuf[KS & 1][e][1], lo[h][e], 0, 0, 0);
+                } else {
+                    if constexpr (SN < S1) {
+                        fetch_a(IntC<SN>{}, a1);         // the next K step's h1 parts and B operands
+                        fetch_b(IntC<KS + 1>{}, bbuf[(KS + 1) & 1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            lo[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[h], bbuf[KS & 1][e][0], lo[h][e], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+
+        entry(IntC<0>{});
+        run(IntC<0>{}, IntC<G::NS1>{});
+        {
+            float lowm = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x2* const b2 = reinterpret_cast<const f32x2*>(bl + row0 + 16 * h);
+                const f32x2* const s2 = reinterpret_cast<const f32x2*>(bl + 2 * G::C + row0 + 16 * h);
+                const f32x2 b01 = b2[0], b23 = b2[1], s01 = s2[0], s23 = s2[1];
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    f16x4 h1, h2;
+                    split_mid4<false>(hi[h][f], lo[h][f], s01, s23, b01, b23, p.slope, true, h1, h2, lowm);
+                    *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16)) = h1;
+                    *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16) + G::MHALF) = h2;
+                }
+            }
+            low_note(low, 1, lowm);
+        }
+        pair_barrier();                                  // the hidden tile is complete, nobody reads the window image any more
+        convk_convert_centre<G>(raw, ximg, tid);
+        convh_load_raw<G>(raw, p.x + nb * ustride, p.T, ntile * G::NM - G::P, tid, more, p.reflect != 0);
+        run(IntC<G::NS1>{}, IntC<G::NST>{});
+        pair_barrier();                                  // every wave is done with the hidden tile and the raw centre
+        pair_wait_vm0();
+        {
+            const size_t boff = (size_t)b * ustride;
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y + boff, ubytes);
+            const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.y_act ? p.y_act + boff : p.y, p.y_act ? ubytes : 0u);
+            const float zero[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x2* const b2 = reinterpret_cast<const f32x2*>(bl + G::C + row0 + 16 * h);
+                const f32x2* const s2 = reinterpret_cast<const f32x2*>(bl + 3 * G::C + row0 + 16 * h);
+                const f32x2 b01 = b2[0], b23 = b2[1], s01 = s2[0], s23 = s2[1];
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    combine4(hi[h][f], lo[h][f], s01, s23, b01, b23, zero);
+                    range_note4p(bad2, hi[h][f]);
+                    const int t = t0 + col0 + f * 16;
+                    const unsigned voff = t < p.T ? (unsigned)((row0 + 16 * h) * p.T + t) * 4u : kOutOfRange;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = hi[h][f][i], a = p.act_slope != 1.f ? act(v, p.act_slope) : v;
+                        buffer_store1s(ry, voff, (unsigned)i * t4, p.y_act ? v : a);
+                        if (p.y_act) buffer_store1s(ra, voff, (unsigned)i * t4, a);
+                    }
+                }
+            }
+        }
+        if (!more) break;
+        convh_convert<G>(raw, ximg, p.slope, tid, low, 0);
+        item = nitem;
+        b = nb;
+        tile = ntile;
+    }
+    pair_wait_vm0();
+    if (p.guard) {
+        const float bad = bad2.x + bad2.y;
+        if (bad != bad) *p.guard = 1;
+        unsigned* const su = reinterpret_cast<unsigned*>(bl + 4 * G::C);
+        if (lane == 0) su[wave] = low.bits;
+        pair_barrier();
+        if (tid == 0) {
+            unsigned all = 0;
+            for (int w = 0; w < 8; ++w) all |= su[w];
+            if (((all & 2u) && !(all & 1u)) || ((all & 8u) && !(all & 4u))) *p.guard = 4;
+        }
+    }
+}
+
 }  // namespace fv

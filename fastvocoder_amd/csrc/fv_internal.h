@@ -147,6 +147,8 @@ struct Tuning {
     int pair128_unfused = 0; // 1: 128-channel ResBlock pairs as two conv launches (convh) instead of the fused convq kernel (A/B, bit-identity tests)
     int convh_rows64 = -1;    // the split-f16 convs at 128+ channels on 64-row tiles (1: convh_kernel) or 128-row ones (0: convs_kernel); -1: by size
     int convt_rows64 = -1;    // the split-f16 transposed conv (128+ input channels) on 64-row tiles (1) or 128-row ones (0); -1: by size
+    int stack_items = 1 << 20;   // residual stacks of 256 channels: tiles per CU (in tenths) up to which the one-launch kernel runs
+                                 // (api.hip stack_two_launch; measured: it wins at every size -- 0 forces the two launches, A/B)
     int convg_rows64 = -1;    // the two-source 1x1 conv on 64-row tiles (1: convg_kernel) or 128-row ones (0: convr_kernel); -1: by size
     int chain = 0;            // 1: the dependent pair launches of a 64-channel MRF stage as one chained launch (PairChain;
                               // measured no faster at batch 1, convh_launch.hip chain_schedule: off)
@@ -354,7 +356,8 @@ int launch_convtn(const PairParams& p, int Tout, hipStream_t s);
 int launch_pack_convtn(const float* w, float* packed, const float* inv, int* range_flag, hipStream_t s);
 // MelGAN ResidualStack as one launch (convk_kernels.hpp): member 0 uses x, w1 (fv_pack_residual_stack_split_f16 image),
 // b1 (the dilated conv's bias), b2 (stack[4]'s + the skip layer's), y, y_act; p.reflect: ReflectionPad1d
-inline bool convk_shape(int C, int k, int dil) { return (C == 32 || C == 64 || C == 128) && k == 3 && (dil == 1 || dil == 3 || dil == 9); }
+inline bool convk_shape(int C, int k, int dil) { return (C == 32 || C == 64 || C == 128 || C == 256) && k == 3 && (dil == 1 || dil == 3 || dil == 9); }
+inline int convk_tile_columns(int C) { return C == 256 ? 32 : 256 / (C / 32); }   // a block holds every row of a column tile
 int launch_convk(const PairParams& p, int C, int dil, hipStream_t s);
 int launch_pack_convk(const float* w1, const float* w2, const float* ws, float* packed, int C, int* range_flag, hipStream_t s);
 // y = post(W1 lrelu(x, slope) + W2 x2 + bias + res), 1-tap convs C -> C with split-f16 operands (convg_kernel): member 0

@@ -253,19 +253,27 @@ class PlanBuilder:
                         and cv.in_channels == c and cv.out_channels == c for cv in (pointwise, skip))
                 and _native.residual_stack_split_supported(c, k, d))
 
-    def residual_stack(self, dilated, pointwise, skip, src, dst, slope, pad_mode=PAD_ZERO):
+    def residual_stack(self, dilated, pointwise, skip, src, dst, slope, pad_mode=PAD_ZERO, hidden=SLOT_NONE):
         """dst = pointwise(lrelu(dilated(pad(lrelu(src))))) + skip(src), reference modules.py:351-382, as one launch
-        (fv_plan_add_residual_stack_split_f16).  ``src`` is read raw; nothing is hoisted into its producer."""
+        (fv_plan_add_residual_stack_split_f16).  ``src`` is read raw; nothing is hoisted into its producer.
+        256 channels: the op also carries the two-launch form (scratch slot ``hidden``), and every run picks by its size
+        (fv_plan_set_stack_two_launch) -- the one-launch kernel's 32-column tiles suit latency-bound runs only."""
         c, k, d = dilated.in_channels, dilated.kernel_size[0], dilated.dilation[0]
         if not self.residual_stack_supported(dilated, pointwise, skip, d * (k - 1) // 2, pad_mode):
             raise _native.NativeError("residual_stack: shape not built into the one-launch kernel")
         ba, bb = self._bias(pointwise), self._bias(skip)
         bias_out = ba if bb is None else (bb if ba is None else (ba + bb).contiguous())
-        self.ops.append(dict(kind="stack", x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE, pre_slope=1.0, slope=float(slope),
-                             split=True, channels=c, k=k, dil=d, pad_mode=pad_mode,
-                             packed=_native.pack_residual_stack_split(effective_weight(dilated), effective_weight(pointwise),
-                                                                      effective_weight(skip), self.guard),
-                             bias=self._bias(dilated), bias_out=bias_out, post=POST_NONE))
+        w1, w2, ws = effective_weight(dilated), effective_weight(pointwise), effective_weight(skip)
+        op = dict(kind="stack", x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE, pre_slope=1.0, slope=float(slope),
+                  split=True, channels=c, k=k, dil=d, pad_mode=pad_mode,
+                  packed=_native.pack_residual_stack_split(w1, w2, ws, self.guard),
+                  bias=self._bias(dilated), bias_out=bias_out, post=POST_NONE)
+        if c >= 256:
+            if hidden == SLOT_NONE:
+                raise _native.NativeError("residual_stack: a scratch slot (hidden) is needed at 256 channels")
+            op.update(tmps=[hidden], two_launch=(hidden, _native.pack_pair(w1, _native.PAIR_SPLIT_F16, self.guard),
+                                                 _native.pack_conv1x1_2src_split(w2, ws, self.guard)))
+        self.ops.append(op)
 
     def mrf_sum(self, pairs, srcs, dst, slope, out_div, post=POST_NONE):
         """dst = post(sum_j pair_j(srcs[j]) / out_div): the last pairs of the three ResBlocks of an MRF stage
@@ -531,7 +539,8 @@ class PlanBuilder:
             elif op["kind"] == "stack":
                 self.plan.add_residual_stack_split_f16(op["x"], op["y"], op["packed"], op["bias"], op["bias_out"],
                                                        op["channels"], op["k"], op["dil"], op["slope"],
-                                                       pad_mode=op["pad_mode"], y_act=op["y_act"], act_slope=op["act_slope"])
+                                                       pad_mode=op["pad_mode"], y_act=op["y_act"], act_slope=op["act_slope"],
+                                                       two_launch=op.get("two_launch"))
             elif op["kind"] == "convT" and op.get("split"):
                 self.plan.add_conv_transpose1d_split_f16(op["x"], op["y"], op["packed"], op["bias"], op["cin"],
                                                          op["cout"], op["k"], op["stride"], op["pad"], op["out_pad"],

@@ -200,7 +200,7 @@ class ResidualStack(_Block):
     ``use_causal_conv``, a CausalConv1d at .1 (keys ``stack.1.conv.*``) and the 1x1 at .3."""
 
     fuse_skip = True      # stack[4] + skip_layer as ONE GEMM over the concatenated K range (False: three launches; A/B)
-    fuse_stack = True     # the whole stack as ONE launch where that kernel exists (32 / 64 / 128 channels; False: A/B)
+    fuse_stack = True     # the whole stack as ONE launch where that kernel exists (32 ... 256 channels; False: A/B)
 
     def __init__(self, kernel_size=3, channels=32, dilation=1, bias=True,
                  nonlinear_activation="LeakyReLU",
@@ -245,9 +245,9 @@ class ResidualStack(_Block):
         dilated = getattr(dilated, "conv", dilated)               # CausalConv1d wraps its conv
         if (self.fuse_stack and post == POST_NONE and not last
                 and pb.residual_stack_supported(dilated, pointwise, self.skip_layer, self._pad, self._pad_mode)):
-            # 32 / 64 / 128 channels: dilated conv, activation, 1x1 conv and skip branch in ONE launch, the hidden
-            # tile stays in LDS (csrc/convk_kernels.hpp)
-            pb.residual_stack(dilated, pointwise, self.skip_layer, src, dst, self._slope, pad_mode=self._pad_mode)
+            # 32 ... 256 channels: dilated conv, activation, 1x1 conv and skip branch in ONE launch, the hidden
+            # tile stays in LDS (csrc/convk_kernels.hpp; 256 channels: only for runs of few tiles, else the two launches below)
+            pb.residual_stack(dilated, pointwise, self.skip_layer, src, dst, self._slope, pad_mode=self._pad_mode, hidden=hidden)
             return
         if pb.conv_split_supported(dilated, self._pad, self._pad_mode):
             # 64 ... 512 channels: the dilated conv with split-f16 operands (csrc/convh_kernels.hpp), the

@@ -284,7 +284,7 @@ int fv_conv1x1_2src_split_f16(const float* x, const float* x2, const float* pack
                               int* guard, void* stream);
 
 /*
- * MelGAN's ResidualStack (modules.py:351-382) as ONE launch, C = 32, 64 or 128 channels, 3 taps, dilation 1, 3 or 9,
+ * MelGAN's ResidualStack (modules.py:351-382) as ONE launch, C = 32, 64, 128 or 256 channels, 3 taps, dilation 1, 3 or 9,
  * split-f16 operands (arithmetic and domain: FV_PAIR_SPLIT_F16 above):
  *
  *     y = W2 * lrelu( conv1d( pad( lrelu(x, slope) ); w_dilated, dil ) + bias_dilated, slope ) + Ws * x + bias_out
@@ -292,7 +292,7 @@ int fv_conv1x1_2src_split_f16(const float* x, const float* x2, const float* pack
  * stack = [act, pad, Conv1d(C, C, 3, dilation), act, Conv1d(C, C, 1)] (modules.py:362-366), skip_layer = Conv1d(C, C, 1)
  * of the raw input (:377, :382); bias_out = stack[4].bias + skip_layer.bias or NULL; pad_mode FV_PAD_ZERO or
  * FV_PAD_REFLECT (`dil` samples on either side: the 'same' padding of the dilated conv).  The hidden tensor never
- * leaves the CU (csrc/convk_kernels.hpp); at 128 channels the result is bit-identical to fv_conv1d_split_f16 followed
+ * leaves the CU (csrc/convk_kernels.hpp); at 128 and 256 channels the result is bit-identical to fv_conv1d_split_f16 followed
  * by fv_conv1x1_2src_split_f16.  y_act (or NULL): lrelu(y, act_slope); without y_act and act_slope != 1, y itself is
  * stored activated.  packed: fv_pack_residual_stack_split_f16 of the three weights [C, C, 3], [C, C, 1], [C, C, 1]
  * (fv_packed_residual_stack_floats floats; 0 = shape not built).
@@ -430,6 +430,12 @@ int fv_plan_add_conv1x1_2src_split_f16(fv_plan_t* plan, int x_slot, int x2_slot,
 int fv_plan_add_residual_stack_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed,
                                          const float* bias_dilated, const float* bias_out, int C, int k, int dil, float slope,
                                          int pad_mode, float act_slope);
+/* The residual stack recorded last (256 channels) also carries its two-launch form -- packed_dilated: fv_pack_pair_weight_ex
+ * (FV_PAIR_SPLIT_F16) of the dilated conv, packed_pair: fv_pack_conv1x1_2src_split_f16 of (stack[4], skip_layer), hidden_slot:
+ * scratch for the hidden tensor -- and a run picks by size (fv_tuning_set "stack_items": tiles per CU, in tenths, up to
+ * which the one-launch kernel runs; default: always -- it measured faster at every batch size; 0: never).  Identical bits
+ * either way: the switch exists for A/B runs and tests. */
+int fv_plan_set_stack_two_launch(fv_plan_t* plan, int hidden_slot, const float* packed_dilated, const float* packed_pair);
 /*
  * y = act( ( sum_{j<3} ( conv1d(x_j; w_j, k_j taps, 'same' zero padding) + res_j ) + bias_sum ) / out_div )
  *

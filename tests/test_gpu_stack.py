@@ -58,7 +58,7 @@ def _run(x, w1, b1, w2, b2, ws, bs, dil, slope, pad_mode, **kw):
 
 @pytest.fixture
 def tuning():
-    defaults = {"convh_blocks": 0, "convg_rows64": -1, "convh_rows64": -1}
+    defaults = {"convh_blocks": 0, "convg_rows64": -1, "convh_rows64": -1, "stack_items": 1 << 20}
     yield _native.tuning_set
     for k, v in defaults.items():
         _native.tuning_set(k, v)
@@ -79,6 +79,11 @@ STACK_CASES = [
     (1, 128, 130, 9, True, False),
     (1, 128, 64, 9, False, True),
     (2, 128, 1, 1, False, True),            # a single sample
+    (1, 256, 1600, 1, True, True),          # MelGAN's first stage: 50 tiles of 32 columns (convk2_kernel)
+    (2, 256, 257, 3, True, True),
+    (1, 256, 130, 9, True, False),
+    (3, 256, 33, 9, False, True),
+    (1, 256, 10, 9, True, True),
 ]
 
 
@@ -110,11 +115,12 @@ def test_residual_stack_vs_oracle(case, tuning):
         assert torch.equal(one, y[1:2])
 
 
-@pytest.mark.parametrize("case", [(1, 128, 1600, 1), (2, 128, 300, 3), (1, 128, 203, 9), (1, 128, 12, 9)],
+@pytest.mark.parametrize("case", [(1, 128, 1600, 1), (2, 128, 300, 3), (1, 128, 203, 9), (1, 128, 12, 9),
+                                  (1, 256, 1600, 9), (2, 256, 300, 1), (1, 256, 77, 3)],
                          ids=lambda c: "x".join(str(v) for v in c))
 def test_residual_stack_is_the_two_launch_form_bit_for_bit(case):
-    """At 128 channels the two-launch form runs on the same arithmetic (convh_kernel, then convg_kernel / convr_kernel):
-    same K order, same split of the hidden tensor, same epilogue -- identical bits."""
+    """At 128 and 256 channels the two-launch form runs on the same arithmetic (convh_kernel / convs_kernel, then convg_kernel
+    / convr_kernel): same K order, same split of the hidden tensor, same epilogue -- identical bits."""
     B, C, T, dil = case
     rng = np.random.RandomState(C + T + dil)
     x, w1, b1, w2, b2, ws, bs = _stack(rng, B, C, T)
@@ -125,7 +131,7 @@ def test_residual_stack_is_the_two_launch_form_bit_for_bit(case):
     assert torch.equal(fused, two)
 
 
-@pytest.mark.parametrize("C", [32, 64, 128])
+@pytest.mark.parametrize("C", [32, 64, 128, 256])
 def test_residual_stack_at_weight_and_activation_scales(C):
     """The split-f16 domain: weights of any magnitude (row prescale at pack time), activations
     over the f16 range; the error stays within three times the fp32 chain's."""
@@ -193,6 +199,18 @@ def test_melgan_module_runs_its_stacks_fused():
         assert float((fused - plain).abs().max()) <= 4e-6 * max(1.0, float(plain.abs().max()))
         if C == 128:
             assert torch.equal(fused, plain)
+    # 256 channels: the op carries both forms and a run picks by its size -- identical bits
+    rs = M.ResidualStack(kernel_size=3, channels=256, dilation=3).to(_dev())
+    for T in (500, 40000):
+        x = torch.randn(1, 256, T, device=_dev())
+        picked = rs(x)                                     # one launch (the default at every size)
+        assert {k[0]: v[1].num_ops() for k, v in rs._fv_plans.items()}["forward"] == 1
+        _native.tuning_set("stack_items", 0)               # the two launches the same op carries
+        try:
+            other = rs(x)
+        finally:
+            _native.tuning_set("stack_items", 1 << 20)
+        assert torch.equal(picked, other)
     g = MelGANGenerator().to(_dev()).eval()
     mel = torch.randn(1, 80, 50, device=_dev())
 
@@ -214,4 +232,4 @@ def test_melgan_module_runs_its_stacks_fused():
         M.ResidualStack.fuse_stack = True
         g.invalidate_plans()
     assert float((y - y2).abs().max()) <= 1e-5
-    assert n_plain - n_fused == 9 and n_fused <= 25       # three stacks in each of the 128-, 64- and 32-channel stages
+    assert n_plain - n_fused == 12 and n_fused <= 18      # three stacks in each of the four stages

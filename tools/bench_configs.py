@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--only", type=int, default=None, help="index into CONFIGS (0-based): run just that one")
     ap.add_argument("--tuning", default="", help='launcher switches "key=value,..." (fv_tuning_set) for an A/B')
     ap.add_argument("--no-merge", action="store_true", help="A/B: the MRF merge in the stage's own last launch (merge_in_upsampler = False)")
+    ap.add_argument("--batch", type=int, default=None, help="override the batch size of the selected configs")
     ap.add_argument("--no-stack", action="store_true", help="A/B: MelGAN's ResidualStacks as two launches each (fuse_stack = False)")
     args = ap.parse_args()
     if args.no_stack:
@@ -45,6 +46,8 @@ def main():
     for idx, (label, name, path, B, T) in enumerate(CONFIGS):
         if args.only is not None and idx != args.only:
             continue
+        if args.batch is not None:
+            B, label = args.batch, f"{label} [B={args.batch}]"
         cfg = yaml.safe_load(open(path))
         m = build_generator(name, cfg)
         m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(name, cfg).items()})
