@@ -163,8 +163,8 @@ def lib():
     L.fv_packed_residual_stack_floats.argtypes = [i, i]
     L.fv_packed_residual_stack_floats.restype = i64
     L.fv_pack_residual_stack_split_f16.argtypes = [vp, vp, vp, vp, i, i, vp, vp]
-    L.fv_residual_stack_split_f16.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, i, f, vp, vp]
-    L.fv_plan_add_residual_stack_split_f16.argtypes = [vp, i, i, i, vp, vp, vp, i, i, i, f, i, f]
+    L.fv_residual_stack_split_f16.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, i, i, f, vp, vp]
+    L.fv_plan_add_residual_stack_split_f16.argtypes = [vp, i, i, i, vp, vp, vp, i, i, i, f, i, i, f]
     L.fv_plan_set_stack_two_launch.argtypes = [vp, i, vp, vp]
     L.fv_conv_post_pqmf.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, f, i, i, vp]
     L.fv_plan_add_conv_post_pqmf.argtypes = [vp, i, i, vp, vp, i, i, i, i, f, i, vp, i]
@@ -417,7 +417,7 @@ def pack_residual_stack_split(w_dilated, w_pointwise, w_skip, flag=None):
 
 
 def residual_stack_split_f16(x, packed, bias_dilated, bias_out, k, dil, slope, pad_mode=PAD_REFLECT, out=None, out_act=None,
-                             act_slope=1.0, guard=None):
+                             act_slope=1.0, guard=None, post=POST_NONE):
     """MelGAN ResidualStack as one launch (fv_residual_stack_split_f16); packed = pack_residual_stack_split(...),
     bias_out = stack[4].bias + skip_layer.bias."""
     B, c, T = x.shape
@@ -426,7 +426,7 @@ def residual_stack_split_f16(x, packed, bias_dilated, bias_out, k, dil, slope, p
     with _on(x, packed, bias_dilated, bias_out, out, out_act) as stream:
         check(lib().fv_residual_stack_split_f16(_ptr(x, "x"), _ptr(packed, "packed"), _ptr(bias_dilated, "bias_dilated", True),
                                                 _ptr(bias_out, "bias_out", True), _ptr(out, "out"), _ptr(out_act, "out_act", True),
-                                                B, c, T, k, dil, float(slope), pad_mode, float(act_slope), _guard_ptr(guard), stream))
+                                                B, c, T, k, dil, float(slope), pad_mode, post, float(act_slope), _guard_ptr(guard), stream))
     return out
 
 
@@ -800,7 +800,7 @@ class Plan:
                                                        float(act_slope)))
 
     def add_residual_stack_split_f16(self, x, y, packed, bias_dilated, bias_out, channels, k, dil, slope, pad_mode=PAD_REFLECT,
-                                     y_act=SLOT_NONE, act_slope=1.0, two_launch=None):
+                                     y_act=SLOT_NONE, act_slope=1.0, two_launch=None, post=POST_NONE):
         """``two_launch`` = (hidden slot, pack_pair image of the dilated conv, pack_conv1x1_2src_split image of the 1x1 pair):
         the form a run with many tiles takes instead (fv_plan_set_stack_two_launch; 256 channels)."""
         self.keep(packed)
@@ -809,7 +809,7 @@ class Plan:
                 self.keep(b)
         check(lib().fv_plan_add_residual_stack_split_f16(self._h, x, y, y_act, _ptr(packed, "packed"),
                                                          _ptr(bias_dilated, "bias_dilated", True), _ptr(bias_out, "bias_out", True),
-                                                         channels, k, dil, float(slope), pad_mode, float(act_slope)))
+                                                         channels, k, dil, float(slope), pad_mode, post, float(act_slope)))
         if two_launch is not None:
             hidden, pd, pp = two_launch
             self.keep(pd)

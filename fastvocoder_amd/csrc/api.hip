@@ -645,6 +645,7 @@ static int run_op(const Op& o, const float* x, float* y, float* y2, const float*
         pp.prec = FV_PAIR_SPLIT_F16;
         pp.guard = guard;
         pp.reflect = (o.pad_mode & FV_PAD_REFLECT) ? 1 : 0;
+        pp.post = o.post;
         pp.m[0].x = x;
         pp.m[0].w1 = o.wp;
         pp.m[0].b1 = o.bias;
@@ -1306,7 +1307,9 @@ static bool stack_two_launch(int C, int B, int64_t T) {
     return items * 10 > (int64_t)tuning().stack_items * device_cu_count();
 }
 
-static int check_stack_args(int C, int k, int dil, int pad_mode, float slope, float act_slope) {
+static int check_stack_args(int C, int k, int dil, int pad_mode, float slope, float act_slope, int post = FV_POST_NONE) {
+    if (post != FV_POST_NONE && post != FV_POST_TANH && post != FV_POST_RELU)
+        return fail(FV_ERR_INVALID_ARG, "residual_stack_split_f16: post op %d", post);
     if (!convk_shape(C, k, dil))
         return fail(FV_ERR_UNSUPPORTED, "residual_stack_split_f16: C = %d, k = %d, dilation %d (32 / 64 / 128 / 256 channels, 3 taps, "
                     "dilation 1, 3 or 9)", C, k, dil);
@@ -1318,13 +1321,13 @@ static int check_stack_args(int C, int k, int dil, int pad_mode, float slope, fl
 }
 
 int fv_residual_stack_split_f16(const float* x, const float* packed, const float* bias_dilated, const float* bias_out, float* y,
-                                float* y_act, int B, int C, int T, int k, int dil, float slope, int pad_mode, float act_slope,
-                                int* guard, void* stream) {
+                                float* y_act, int B, int C, int T, int k, int dil, float slope, int pad_mode, int post,
+                                float act_slope, int* guard, void* stream) {
     if (!x || !packed || !y) return fail(FV_ERR_INVALID_ARG, "residual_stack_split_f16: null tensor");
     if (x == y || x == y_act || (y_act && y_act == y))
         return fail(FV_ERR_INVALID_ARG, "residual_stack_split_f16: y / y_act must not alias x or each other");
     if (B < 0 || T < 0) return fail(FV_ERR_INVALID_ARG, "residual_stack_split_f16: B=%d T=%d", B, T);
-    if (int rc = check_stack_args(C, k, dil, pad_mode, slope, act_slope)) return rc;
+    if (int rc = check_stack_args(C, k, dil, pad_mode, slope, act_slope, post)) return rc;
     Op o = {};
     o.type = OP_STACK;
     o.prec = FV_PAIR_SPLIT_F16;
@@ -1338,15 +1341,16 @@ int fv_residual_stack_split_f16(const float* x, const float* packed, const float
     o.pad_mode = pad_mode;
     o.pre_slope = slope;
     o.out_div = 1.f;
+    o.post = post;
     o.act_slope = act_slope;
     return run_op(o, x, y, y_act, nullptr, nullptr, nullptr, B, T, (hipStream_t)stream, nullptr, nullptr, 0, guard);
 }
 
 int fv_plan_add_residual_stack_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed,
                                          const float* bias_dilated, const float* bias_out, int C, int k, int dil, float slope,
-                                         int pad_mode, float act_slope) {
+                                         int pad_mode, int post, float act_slope) {
     if (!plan || !packed) return fail(FV_ERR_INVALID_ARG, "plan_add_residual_stack_split_f16: null");
-    if (int rc = check_stack_args(C, k, dil, pad_mode, slope, act_slope)) return rc;
+    if (int rc = check_stack_args(C, k, dil, pad_mode, slope, act_slope, post)) return rc;
     if (int rc = check_slot(x_slot, false)) return rc;
     if (int rc = check_slot(y_slot, false)) return rc;
     if (int rc = check_slot(y_act_slot, true)) return rc;
@@ -1370,7 +1374,7 @@ int fv_plan_add_residual_stack_split_f16(fv_plan_t* plan, int x_slot, int y_slot
     o.stride = 1;
     o.pre_slope = slope;
     o.out_div = 1.f;
-    o.post = FV_POST_NONE;
+    o.post = post;
     o.act_slope = act_slope;
     plan->ops.push_back(o);
     return 0;
@@ -2218,6 +2222,7 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             pg.T = (int)sh[o.x].T;
             pg.slope = o.pre_slope;
             pg.act_slope = o.act_slope;
+            pg.post = o.post;
             pg.prec = FV_PAIR_SPLIT_F16;
             pg.guard = plan->guard_dev;
             pg.m[0].x = base[o.alt_mid];

@@ -124,6 +124,7 @@ int launch_convk(const PairParams& pp, int C, int dil, hipStream_t s) {
     p.nblk = (int)nblk;
     p.slope = pp.slope;
     p.act_slope = pp.act_slope;
+    p.post = pp.post;
     p.reflect = pp.reflect;
     p.guard = pp.guard;
     profile_begin(s);

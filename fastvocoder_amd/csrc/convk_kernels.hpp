@@ -35,6 +35,7 @@ struct ConvKParams {
     float* y_act;        // optional activated twin lrelu(y, act_slope), or null (then act_slope != 1: y is stored activated)
     int B, T, n_tiles, n_items, nblk;
     float slope, act_slope;
+    int post;            // FV_POST_* applied to y (the graph's last stack: Basis-MelGAN's final ReLU)
     int reflect;         // rows outside [0, T): mirrored samples (ReflectionPad1d) instead of zeros
     int* guard;
 };
@@ -287,7 +288,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const unsigned voff = t < p.T ? (unsigned)((row0 + 16 * h) * p.T + t) * 4u : kOutOfRange;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float v = hi[h][f][i], a = p.act_slope != 1.f ? act(v, p.act_slope) : v;
+                        float v = hi[h][f][i];
+                        if (p.post == FV_POST_TANH) v = tanhf(v);
+                        else if (p.post == FV_POST_RELU) v = fmaxf(v, 0.f);
+                        const float a = p.act_slope != 1.f ? act(v, p.act_slope) : v;
                         buffer_store1s(ry, voff, (unsigned)i * t4, p.y_act ? v : a);
                         if (p.y_act) buffer_store1s(ra, voff, (unsigned)i * t4, a);
                     }
@@ -543,7 +547,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const unsigned voff = t < p.T ? (unsigned)((row0 + 16 * h) * p.T + t) * 4u : kOutOfRange;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float v = hi[h][f][i], a = p.act_slope != 1.f ? act(v, p.act_slope) : v;
+                        float v = hi[h][f][i];
+                        if (p.post == FV_POST_TANH) v = tanhf(v);
+                        else if (p.post == FV_POST_RELU) v = fmaxf(v, 0.f);
+                        const float a = p.act_slope != 1.f ? act(v, p.act_slope) : v;
                         buffer_store1s(ry, voff, (unsigned)i * t4, p.y_act ? v : a);
                         if (p.y_act) buffer_store1s(ra, voff, (unsigned)i * t4, a);
                     }

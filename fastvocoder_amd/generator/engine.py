@@ -253,11 +253,13 @@ class PlanBuilder:
                         and cv.in_channels == c and cv.out_channels == c for cv in (pointwise, skip))
                 and _native.residual_stack_split_supported(c, k, d))
 
-    def residual_stack(self, dilated, pointwise, skip, src, dst, slope, pad_mode=PAD_ZERO, hidden=SLOT_NONE):
+    def residual_stack(self, dilated, pointwise, skip, src, dst, slope, pad_mode=PAD_ZERO, hidden=SLOT_NONE, post=POST_NONE,
+                       carry_two_launch=False):
         """dst = pointwise(lrelu(dilated(pad(lrelu(src))))) + skip(src), reference modules.py:351-382, as one launch
         (fv_plan_add_residual_stack_split_f16).  ``src`` is read raw; nothing is hoisted into its producer.
-        256 channels: the op also carries the two-launch form (scratch slot ``hidden``), and every run picks by its size
-        (fv_plan_set_stack_two_launch) -- the one-launch kernel's 32-column tiles suit latency-bound runs only."""
+        256 channels (and ``carry_two_launch``, 128+ channels: the graph's last stack, which may get an output offset
+        attached -- :meth:`subtract_output` then falls back on that form): the op also carries the two-launch form
+        (scratch slot ``hidden``; fv_plan_set_stack_two_launch, ``Tuning::stack_items`` for A/B runs)."""
         c, k, d = dilated.in_channels, dilated.kernel_size[0], dilated.dilation[0]
         if not self.residual_stack_supported(dilated, pointwise, skip, d * (k - 1) // 2, pad_mode):
             raise _native.NativeError("residual_stack: shape not built into the one-launch kernel")
@@ -267,8 +269,10 @@ class PlanBuilder:
         op = dict(kind="stack", x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE, pre_slope=1.0, slope=float(slope),
                   split=True, channels=c, k=k, dil=d, pad_mode=pad_mode,
                   packed=_native.pack_residual_stack_split(w1, w2, ws, self.guard),
-                  bias=self._bias(dilated), bias_out=bias_out, post=POST_NONE)
-        if c >= 256:
+                  bias=self._bias(dilated), bias_out=bias_out, post=post)
+        if c >= 256 or carry_two_launch:
+            if not _native.conv1x1_2src_split_supported(c):
+                raise _native.NativeError("residual_stack: the two-launch form exists at 128+ channels only")
             if hidden == SLOT_NONE:
                 raise _native.NativeError("residual_stack: a scratch slot (hidden) is needed at 256 channels")
             op.update(tmps=[hidden], two_launch=(hidden, _native.pack_pair(w1, _native.PAIR_SPLIT_F16, self.guard),
@@ -367,6 +371,16 @@ class PlanBuilder:
         Bias removal without a separate elementwise pass (reference bin/synthesize.py:74-80,
         basis_melgan.py:147-159, bin/test.py:82-91)."""
         op = self.ops[-1]
+        if op["kind"] == "stack" and "two_launch" in op:
+            # the one-launch stack kernel has no offset epilogue: its two-launch form (the op carries it) does
+            hidden, pd, pp = op["two_launch"]
+            self.ops[-1:] = [
+                dict(kind="convh", group=0, x=op["x"], y=hidden, res=SLOT_NONE, acc=SLOT_NONE, acc2=SLOT_NONE, pre_slope=1.0,
+                     slope=op["slope"], channels=op["channels"], k=op["k"], dil=op["dil"], pad_mode=op["pad_mode"], packed=pd,
+                     bias=op["bias"], out_div=1.0, post=POST_NONE),
+                dict(kind="conv2h", x=hidden, x2=op["x"], y=op["y"], res=SLOT_NONE, acc=SLOT_NONE, pre_slope=1.0,
+                     slope=op["slope"], split=True, packed=pp, bias=op["bias_out"], channels=op["channels"], post=op["post"])]
+            op = self.ops[-1]
         if (op["kind"] not in ("conv", "conv2", "conv2h", "convT", "upconv", "pqmf", "postpqmf") or op.get("group", 0)
                 or (op.get("split") and op["kind"] != "conv2h")):
             raise _native.NativeError("subtract_output: the last op must be a plain conv / transposed conv / two-source "
@@ -540,7 +554,7 @@ class PlanBuilder:
                 self.plan.add_residual_stack_split_f16(op["x"], op["y"], op["packed"], op["bias"], op["bias_out"],
                                                        op["channels"], op["k"], op["dil"], op["slope"],
                                                        pad_mode=op["pad_mode"], y_act=op["y_act"], act_slope=op["act_slope"],
-                                                       two_launch=op.get("two_launch"))
+                                                       two_launch=op.get("two_launch"), post=op["post"])
             elif op["kind"] == "convT" and op.get("split"):
                 self.plan.add_conv_transpose1d_split_f16(op["x"], op["y"], op["packed"], op["bias"], op["cin"],
                                                          op["cout"], op["k"], op["stride"], op["pad"], op["out_pad"],

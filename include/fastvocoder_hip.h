@@ -287,7 +287,7 @@ int fv_conv1x1_2src_split_f16(const float* x, const float* x2, const float* pack
  * MelGAN's ResidualStack (modules.py:351-382) as ONE launch, C = 32, 64, 128 or 256 channels, 3 taps, dilation 1, 3 or 9,
  * split-f16 operands (arithmetic and domain: FV_PAIR_SPLIT_F16 above):
  *
- *     y = W2 * lrelu( conv1d( pad( lrelu(x, slope) ); w_dilated, dil ) + bias_dilated, slope ) + Ws * x + bias_out
+ *     y = post( W2 * lrelu( conv1d( pad( lrelu(x, slope) ); w_dilated, dil ) + bias_dilated, slope ) + Ws * x + bias_out )
  *
  * stack = [act, pad, Conv1d(C, C, 3, dilation), act, Conv1d(C, C, 1)] (modules.py:362-366), skip_layer = Conv1d(C, C, 1)
  * of the raw input (:377, :382); bias_out = stack[4].bias + skip_layer.bias or NULL; pad_mode FV_PAD_ZERO or
@@ -301,8 +301,8 @@ int64_t fv_packed_residual_stack_floats(int C, int k);
 int fv_pack_residual_stack_split_f16(const float* w_dilated, const float* w_pointwise, const float* w_skip, float* packed,
                                      int C, int k, int* range_flag, void* stream);
 int fv_residual_stack_split_f16(const float* x, const float* packed, const float* bias_dilated, const float* bias_out, float* y,
-                                float* y_act, int B, int C, int T, int k, int dil, float slope, int pad_mode, float act_slope,
-                                int* guard, void* stream);
+                                float* y_act, int B, int C, int T, int k, int dil, float slope, int pad_mode, int post,
+                                float act_slope, int* guard, void* stream);
 
 /*
  * y = post( conv_transpose1d(lrelu(x, pre_slope); w, stride, pad, out_pad) + bias )
@@ -429,7 +429,7 @@ int fv_plan_add_conv1x1_2src_split_f16(fv_plan_t* plan, int x_slot, int x2_slot,
                                        float act_slope);
 int fv_plan_add_residual_stack_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed,
                                          const float* bias_dilated, const float* bias_out, int C, int k, int dil, float slope,
-                                         int pad_mode, float act_slope);
+                                         int pad_mode, int post, float act_slope);
 /* The residual stack recorded last (256 channels) also carries its two-launch form -- packed_dilated: fv_pack_pair_weight_ex
  * (FV_PAIR_SPLIT_F16) of the dilated conv, packed_pair: fv_pack_conv1x1_2src_split_f16 of (stack[4], skip_layer), hidden_slot:
  * scratch for the hidden tensor -- and a run picks by size (fv_tuning_set "stack_items": tiles per CU, in tenths, up to

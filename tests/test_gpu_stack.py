@@ -105,6 +105,9 @@ def test_residual_stack_vs_oracle(case, tuning):
     assert torch.equal(y2, y) and _rel(twin, oo.lrelu(ref, 0.1)) <= 4e-6
     y3 = _run(*m, dil, 0.2, nmode, act_slope=0.1)
     assert torch.equal(y3, twin)
+    # the graph's last stack carries the generator's final activation (Basis-MelGAN's ReLU, basis_melgan.py:99-100)
+    y4 = _run(*m, dil, 0.2, nmode, post=_native.POST_RELU)
+    assert torch.equal(y4, torch.clamp(y, min=0.0))
     # a few persistent blocks walking many tiles each (ring and window hand-over between tiles): the same bits
     tuning("convh_blocks", 3)
     few = _run(*m, dil, 0.2, nmode)

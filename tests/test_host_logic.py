@@ -307,20 +307,20 @@ def test_plan_shape_inference_without_gpu():
         [5 * 1 * 32 * 32 + 64, 5 * 2 * 64 * 32 + 128, 5 * 4 * 128 * 32 + 256, 80 * 4096 + 512, 0, 0]
     assert L.fv_packed_residual_stack_floats(64, 7) == 0
     r = L.fv_plan_create(64)
-    assert L.fv_plan_add_residual_stack_split_f16(r, 0, 1, -1, dummy, None, None, 64, 3, 9, 0.2, _native.PAD_REFLECT, 1.0) == 0
+    assert L.fv_plan_add_residual_stack_split_f16(r, 0, 1, -1, dummy, None, None, 64, 3, 9, 0.2, _native.PAD_REFLECT, 0, 1.0) == 0
     assert L.fv_plan_output_shape(r, 321, ctypes.byref(c), ctypes.byref(n)) == 0 and (c.value, n.value) == (64, 321)
     assert L.fv_plan_set_output_offset(r, 28, -1) != 0                      # no output offset on this op (two-launch form)
-    assert L.fv_plan_add_residual_stack_split_f16(r, 0, 1, -1, dummy, None, None, 64, 3, 5, 0.2, 0, 1.0) != 0
+    assert L.fv_plan_add_residual_stack_split_f16(r, 0, 1, -1, dummy, None, None, 64, 3, 5, 0.2, 0, 0, 1.0) != 0
     assert b"dilation 5" in L.fv_last_error()
-    assert L.fv_plan_add_residual_stack_split_f16(r, 0, 1, -1, dummy, None, None, 512, 3, 1, 0.2, 0, 1.0) != 0
+    assert L.fv_plan_add_residual_stack_split_f16(r, 0, 1, -1, dummy, None, None, 512, 3, 1, 0.2, 0, 0, 1.0) != 0
     assert L.fv_plan_set_stack_two_launch(r, 2, dummy, dummy) != 0          # 64 channels: no two-launch form to carry
-    assert L.fv_plan_add_residual_stack_split_f16(r, 0, 1, -1, dummy, None, None, 64, 3, 1, 0.2, _native.PAD_CAUSAL, 1.0) != 0
+    assert L.fv_plan_add_residual_stack_split_f16(r, 0, 1, -1, dummy, None, None, 64, 3, 1, 0.2, _native.PAD_CAUSAL, 0, 1.0) != 0
     assert b"pad_mode" in L.fv_last_error()
-    assert L.fv_plan_add_residual_stack_split_f16(r, 0, 1, -1, dummy, None, None, 64, 3, 1, 1.5, 0, 1.0) != 0
+    assert L.fv_plan_add_residual_stack_split_f16(r, 0, 1, -1, dummy, None, None, 64, 3, 1, 1.5, 0, 0, 1.0) != 0
     assert L.fv_plan_num_ops(r) == 1
     L.fv_plan_destroy(r)
     r = L.fv_plan_create(256)
-    assert L.fv_plan_add_residual_stack_split_f16(r, 0, 1, -1, dummy, None, None, 256, 3, 3, 0.2, _native.PAD_REFLECT, 1.0) == 0
+    assert L.fv_plan_add_residual_stack_split_f16(r, 0, 1, -1, dummy, None, None, 256, 3, 3, 0.2, _native.PAD_REFLECT, _native.POST_RELU, 1.0) == 0
     assert L.fv_plan_set_stack_two_launch(r, 1, dummy, dummy) != 0 and b"aliases" in L.fv_last_error()
     assert L.fv_plan_set_stack_two_launch(r, 2, dummy, dummy) == 0
     assert L.fv_plan_output_shape(r, 100, ctypes.byref(c), ctypes.byref(n)) == 0 and (c.value, n.value) == (256, 100)

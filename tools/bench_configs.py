@@ -31,8 +31,12 @@ def main():
     ap.add_argument("--tuning", default="", help='launcher switches "key=value,..." (fv_tuning_set) for an A/B')
     ap.add_argument("--no-merge", action="store_true", help="A/B: the MRF merge in the stage's own last launch (merge_in_upsampler = False)")
     ap.add_argument("--batch", type=int, default=None, help="override the batch size of the selected configs")
+    ap.add_argument("--no-last-stack", action="store_true", help="A/B: the graph's last ResidualStack as two launches (fuse_last = False)")
     ap.add_argument("--no-stack", action="store_true", help="A/B: MelGAN's ResidualStacks as two launches each (fuse_stack = False)")
     args = ap.parse_args()
+    if args.no_last_stack:
+        from fastvocoder_amd.generator.modules import ResidualStack
+        ResidualStack.fuse_last = False
     if args.no_stack:
         from fastvocoder_amd.generator.modules import ResidualStack
         ResidualStack.fuse_stack = False
