@@ -277,6 +277,19 @@ int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout,
     return rc;
 }
 
+// Long runs of the fused 64- / 128-channel pairs (convp / convq: many tiles per block) are mostly WARM tiles -- NM outputs
+// for the work a cold tile spends on NM - (k - 1) (convq_kernels.hpp) -- so an ITEM (NM - (k - 1) columns) of an 11-tap
+// member costs 84 % of a tile there, one of a 3-tap member 97 %: the members' partition weights follow, or the blocks that
+// walk the 3-tap member finish last [measured, 128 channels, 16 x 64 000 columns, three members: 4.76 ms with equal
+// tile costs whatever the tiling, against 3.50 vs 3.87 ms for the two-member launch]
+#ifndef FV_WARM_TILES
+#define FV_WARM_TILES 1
+#endif
+static void warm_run_costs(PairParams& p, long long items, int nm) {
+    if (!FV_WARM_TILES || items < 8LL * p.nblk) return;
+    for (int i = 0; i < p.n_members; ++i) p.m[i].cost *= nm - (p.m[i].k - 1);
+}
+
 // ---- two-source 1x1 conv (convg_kernel) -----------------------------------------------------------------------------
 int launch_convg(PairParams p, int C, hipStream_t s) {
     if (p.B <= 0 || p.T <= 0) return 0;
@@ -381,6 +394,7 @@ static int prepare_convp(PairParams& p, int dil, size_t& lds_out, double& flops,
     p.nblk = (int)nblk;
     pair_schedule(p, p.nblk);
     if (!p.sched_on) {                 // no per-block schedule: the kernels' contiguous cut, as a table instead of arithmetic
+        warm_run_costs(p, items, 128);
         long long n[3] = {0, 0, 0};
         for (int i = 0; i < p.n_members; ++i) n[i] = p.m[i].n_items;
         pair_cut_schedule(p, p.nblk, n);
@@ -668,6 +682,7 @@ int launch_convq(PairParams p, int dil, hipStream_t s) {
     p.nblk = (int)nblk;
     pair_schedule(p, p.nblk, true);
     if (!p.sched_on) {                 // no per-block schedule: the kernels' contiguous cut, as a table instead of arithmetic
+        warm_run_costs(p, items, NM);
         long long n[3] = {0, 0, 0};
         for (int i = 0; i < p.n_members; ++i) n[i] = p.m[i].n_items;
         pair_cut_schedule(p, p.nblk, n);

@@ -11,6 +11,9 @@
 // the two images alone would be 172 KB: those pairs stay two launches.
 #pragma once
 #include "convh_kernels.hpp"
+#ifndef FV_WARM_TILES
+#define FV_WARM_TILES 1             // 0: every tile cold (A/B builds, tools/build_variant.py)
+#endif
 
 namespace fv {
 
@@ -76,6 +79,15 @@ __device__ __forceinline__ void convp_run_member(const PairCore& p, const PairMe
     int item = item0;
     int g0 = 0;
     int b = item / mb.n_tiles, tile = item - b * mb.n_tiles;
+    // Runs of consecutive tiles inside one utterance: the first tile is cold (NOUT outputs, KT - 1 intermediate columns
+    // recomputed), the others warm -- the last KT - 1 intermediate columns of the tile before move to the front of the image,
+    // conv1 produces NM new ones, conv2 NM outputs (convq_kernels.hpp; not in chained launches, whose flags count cold tiles)
+    constexpr bool WARM = !CHAIN;                        // (the run logic; FV_WARM_TILES = 0 keeps every tile of a run cold)
+    const int b_last = (hi_item - 1) / mb.n_tiles;
+    const int c_last = min(((hi_item - 1) - b_last * mb.n_tiles + 1) * G::NOUT, p.T);
+    int tout = tile * G::NOUT;
+    int c_end = !WARM || b != b_last ? p.T : c_last;
+    bool warm = false;
     if (!first) pair_barrier();
     pair_stamp(p, 8, wave, lane, 7, 12);                 // (tuning aid, -DFV_PAIR_TRACE: tools/convp_trace.py) run start
     LowGuard low;                                        // low side of the range guard (pairh_kernels.hpp)
@@ -106,9 +118,8 @@ __device__ __forceinline__ void convp_run_member(const PairCore& p, const PairMe
     pair_stamp(p, 8, wave, lane, 7, 13);
     for (int it = 0;; ++it) {
         pair_stamp(p, 8, wave, lane, it, 0);
-        const int t0 = tile * G::NOUT;
+        const int t0 = WARM ? tout : tile * G::NOUT;
         const int nitem = item + dir;
-        const bool more = nitem != hi_item;
         int nb = b, ntile = tile + dir;
         if (ntile == mb.n_tiles) {
             ntile = 0;
@@ -120,6 +131,14 @@ __device__ __forceinline__ void convp_run_member(const PairCore& p, const PairMe
                 --nb;
             }
         }
+        const int r0 = WARM && warm ? G::KT - 1 : 0;     // image row of the first NEW intermediate column
+        const int n_out = WARM && warm ? G::NM : G::NOUT;
+        const bool cont = WARM && t0 + n_out < c_end;    // the next tile continues this run
+        const bool nwarm = FV_WARM_TILES && cont;
+        const bool more = WARM ? (cont || b < b_last) : nitem != hi_item;
+        if constexpr (WARM) nb = cont ? b : b + 1;
+        const int ntout = cont ? t0 + n_out : 0;
+        const int nwin = WARM ? ntout - G::P1 - G::P2 + (nwarm ? G::KT - 1 : 0) : ntile * G::NOUT - G::P1 - G::P2;
         f32x4 hi[2][G::NFW], lo[2][G::NFW];
         float res[2][G::NFW][4];
         unsigned voff[G::NFW];
@@ -157,14 +176,14 @@ __device__ __forceinline__ void convp_run_member(const PairCore& p, const PairMe
                 if constexpr (CHAIN) {
                     if (!(p.dbg & 64) && !chain_ready(*cc, fo, fv)) chain_spin(*cc, fo, lane);
                 }
-                convh_load_raw<H, AUX>(raw, mb.x + nb * ustride, p.T, ntile * G::NOUT - G::P1 - G::P2, tid, more && !(p.dbg & 1));
+                convh_load_raw<H, AUX>(raw, mb.x + nb * ustride, p.T, nwin, tid, more && !(p.dbg & 1));
             }
             if constexpr (GS == G::RESST) {
                 const __amdgpu_buffer_rsrc_t rr = make_rsrc(mb.x + b * ustride, ubytes);     // the residual is x itself
 #pragma unroll
                 for (int f = 0; f < G::NFW; ++f) {
                     const int col = col0 + f * 16, t = t0 + col;
-                    voff[f] = col < G::NOUT && t < p.T ? (unsigned)(row0 * p.T + t) * 4u : kOutOfRange;
+                    voff[f] = col < n_out && t < c_end ? (unsigned)(row0 * p.T + t) * 4u : kOutOfRange;
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -249,8 +268,9 @@ __device__ __forceinline__ void convp_run_member(const PairCore& p, const PairMe
         {
             // conv1 -> intermediate image: column u of the tile is time t0 - P2 + u; conv2's zero padding applies to
             // the intermediate: columns outside [0, T) are zero, not conv1 of the padded input
-            const int tm = t0 - G::P2;
+            const int tm = t0 - G::P2 + r0;              // time of the first new column
             const bool inside = tm >= 0 && tm + G::NM <= p.T;     // (uniform) no column of this tile needs the mask
+            char* const mwr = mw + r0 * 16;
             float lowm = 0.f;                            // largest magnitude of this tile's intermediate in this lane
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -263,8 +283,8 @@ __device__ __forceinline__ void convp_run_member(const PairCore& p, const PairMe
                     f16x4 h1, h2;
                     if (inside) split_mid4<false>(hi[h][f], lo[h][f], s01, s23, b01, b23, p.slope, true, h1, h2, lowm);
                     else split_mid4<true>(hi[h][f], lo[h][f], s01, s23, b01, b23, p.slope, t >= 0 && t < p.T, h1, h2, lowm);
-                    *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16)) = h1;
-                    *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16) + G::MHALF) = h2;
+                    *reinterpret_cast<f16x4*>(mwr + f * 256 + h * (2 * G::MRP * 16)) = h1;
+                    *reinterpret_cast<f16x4*>(mwr + f * 256 + h * (2 * G::MRP * 16) + G::MHALF) = h2;
                 }
             }
             low_note(low, 1, lowm);
@@ -276,6 +296,16 @@ __device__ __forceinline__ void convp_run_member(const PairCore& p, const PairMe
         pair_stamp(p, 8, wave, lane, it, 3);
         // ---- epilogue: outputs, then the image of the next window ----------------------------------------------
         pair_barrier();                                  // every wave is done with the intermediate
+        if (nwarm) {
+            // the last KT - 1 valid columns -> the front of the image, for the warm tile that follows
+            constexpr int NC = 2 * (G::C / 8) * (G::KT - 1);
+            if (tid < NC) {
+                const int row = tid % (G::KT - 1), hb = tid / (G::KT - 1);      // hb: (split half, 8-channel block)
+                char* const base = mimg + (hb / (G::C / 8)) * G::MHALF + ((hb % (G::C / 8)) * G::MRP) * 16;
+                *reinterpret_cast<f16x8*>(base + row * 16) =
+                    *reinterpret_cast<const f16x8*>(base + (r0 + G::NM - (G::KT - 1) + row) * 16);
+            }
+        }
         wait_vm<0>();                                    // raw window, residual, the next tile's first three weight stages
         pair_stamp(p, 8, wave, lane, it, 4);
         const bool fin = mb.add1 != nullptr;
@@ -317,16 +347,19 @@ __device__ __forceinline__ void convp_run_member(const PairCore& p, const PairMe
                 const int col = col0 + f * 16;
                 range_note4p(bad2, hi[h][f]);         // (every column is computed from real, zero-padded data)
                 pair_store<AUX>(p, mb.y, mb.y_act, G::C, b, row0 + 16 * h, t0 + col,
-                           col < G::NOUT && t0 + col < p.T && !(p.dbg & 8), v, fin, rcp);
+                           col < n_out && t0 + col < c_end && !(p.dbg & 8), v, fin, rcp);
             }
         pair_stamp(p, 8, wave, lane, it, 5);
         if (more && !(p.dbg & 2)) convh_convert<H>(raw, ximg, p.slope, tid, low);
         pair_stamp(p, 8, wave, lane, it, 6);
         if (!more) break;
         g0 += G::NST;
+        if (WARM && !cont) c_end = nb == b_last ? c_last : p.T;
         item = nitem;
         b = nb;
         tile = ntile;
+        tout = ntout;
+        warm = nwarm;
     }
     pair_wait_vm0();
     if constexpr (CHAIN) {

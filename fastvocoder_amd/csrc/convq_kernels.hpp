@@ -15,6 +15,9 @@
 // two-launch form: identical bits.
 #pragma once
 #include "convh_kernels.hpp"
+#ifndef FV_WARM_TILES
+#define FV_WARM_TILES 1             // 0: every tile cold (A/B builds, tools/build_variant.py)
+#endif
 
 namespace fv {
 
@@ -30,7 +33,7 @@ struct ConvQGeom {
     static constexpr int XRP = (XROWS + 15) / 16 * 16;   // image: [split half][8-channel block][XRP rows][8 halves]
     static constexpr int XHALF = CB * XRP * 16;
     static constexpr int XR = (XROWS * CB + NT - 1) / NT, XRM = XR;
-    static constexpr int MRP = NM + 16;                  // rows of the intermediate image (>= NM + KT - 1, multiple of 16)
+    static constexpr int MRP = NM + 16;                  // rows of the intermediate image (>= NM + KT - 1: a warm tile's, multiple of 16)
     static constexpr int MHALF = CB * MRP * 16;
     // (a ring of four stages fits at dilation 1 and 3 -- smaller x image -- and was measured: no difference)
     static constexpr int STAGE_BYTES = 16384, RING = 3, AHEAD = RING - 1;
@@ -94,13 +97,24 @@ __device__ __forceinline__ void convq_run_member(const PairParams& p, const Pair
         int s = g0 + g % G::RING;
         return s >= G::RING ? s - G::RING : s;
     };
-    int b = item / mb.n_tiles, tile = item - b * mb.n_tiles;
+    // A block's items are consecutive tiles: inside one utterance they form a RUN of columns [tout, c_end).  Its first tile
+    // is "cold" -- conv1 produces the 64 intermediate columns conv2 needs for NOUT = 64 - (KT - 1) outputs, the first KT - 1
+    // of them a recomputation of what the tile before (another block's) had.  Every further tile of the run is "warm": the
+    // last KT - 1 intermediate columns of the tile before are still in LDS -- they are moved to the front of the image
+    // (5 KB) -- conv1 produces 64 NEW columns behind them and conv2 64 outputs: no recomputation inside a run (18 % more
+    // outputs per tile at 11 taps).  Every output is formed exactly as before: same bits whatever the tiling.
+    const int b_last = (hi_item - 1) / mb.n_tiles;
+    const int c_last = min(((hi_item - 1) - b_last * mb.n_tiles + 1) * G::NOUT, p.T);     // end of the run in the last utterance
+    int b = item / mb.n_tiles;
+    int tout = (item - b * mb.n_tiles) * G::NOUT;        // first output column of the tile
+    int c_end = b == b_last ? c_last : p.T;
+    bool warm = false;
     if (!first) pair_barrier();
     LowGuard low;                                        // low side of the range guard (pairh_kernels.hpp)
     f32x2 bad2 = {0.f, 0.f};                             // range guard (pairh_kernels.hpp range_note4p)
     const float rcp = div_rcp(p.out_div);                // the MRF mean's divisor (pair_kernels.hpp div_exact)
     ConvHRaw<G> raw;
-    convh_load_raw<G>(raw, mb.x + b * ustride, p.T, tile * G::NOUT - G::P1 - G::P2, tid, true);
+    convh_load_raw<G>(raw, mb.x + b * ustride, p.T, tout - G::P1 - G::P2, tid, true);
 #pragma unroll
     for (int st = 0; st < G::AHEAD; ++st) convq_dma_stage<G>(rw1, ring, st, (unsigned)(st * 8192), wave, lane);
     if (tid < G::C) {
@@ -115,14 +129,16 @@ __device__ __forceinline__ void convq_run_member(const PairParams& p, const Pair
     pair_wait_vm0();
     if (!(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid, low);
     for (;;) {
-        const int t0 = tile * G::NOUT;
-        const int nitem = item + 1;
-        const bool more = nitem < hi_item;
-        int nb = b, ntile = tile + 1;
-        if (ntile == mb.n_tiles) {
-            ntile = 0;
-            ++nb;
-        }
+        const int t0 = tout;
+        const int r0 = warm ? G::KT - 1 : 0;             // image row of the first NEW intermediate column (row r = time t0 - P2 + r)
+        const int n_out = warm ? G::NM : G::NOUT;        // outputs of this tile
+        // the next tile: warm in this run, or cold at the start of the next utterance's
+        const bool cont = t0 + n_out < c_end;            // the run goes on
+        const bool nwarm = FV_WARM_TILES && cont;
+        const bool more = cont || b < b_last;
+        const int nb = cont ? b : b + 1;
+        const int ntout = cont ? t0 + n_out : 0;
+        const int nwin = ntout - G::P2 - G::P1 + (nwarm ? G::KT - 1 : 0);      // first window row of the next tile
         f32x4 hi[2][G::NFW], lo[2][G::NFW];
         float res[2][G::NFW][4];
         unsigned voff[G::NFW];
@@ -150,7 +166,7 @@ __device__ __forceinline__ void convq_run_member(const PairParams& p, const Pair
             else
                 convq_dma_stage<G>(rw1, ring, slot_of(NS), more ? (unsigned)((NS - G::NST) * 8192) : kOutOfRange, wave, lane);
             if constexpr (GS == G::RAWST)
-                convh_load_raw<G>(raw, mb.x + nb * ustride, p.T, ntile * G::NOUT - G::P1 - G::P2, tid, more && !(p.dbg & 1));
+                convh_load_raw<G>(raw, mb.x + nb * ustride, p.T, nwin, tid, more && !(p.dbg & 1));
         };
         auto fetch_a = [&](auto SC, f16x8 (&dst)[2][2]) {        // SC: stage of the tile (= step of its 2 x NSTEP sequence)
             constexpr int S = decltype(SC)::value;
@@ -229,8 +245,9 @@ __device__ __forceinline__ void convq_run_member(const PairParams& p, const Pair
         {
             // conv1 -> intermediate image: column u of the tile is time t0 - P2 + u; conv2's zero padding applies to
             // the intermediate: columns outside [0, T) are zero, not conv1 of the padded input
-            const int tm = t0 - G::P2;
+            const int tm = t0 - G::P2 + r0;              // time of the first new column
             const bool inside = tm >= 0 && tm + G::NM <= p.T;     // (uniform) no column of this tile needs the mask
+            char* const mwr = mw + r0 * 16;
             float lowm = 0.f;                            // largest magnitude of this tile's intermediate in this lane
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -243,8 +260,8 @@ __device__ __forceinline__ void convq_run_member(const PairParams& p, const Pair
                     f16x4 h1, h2;
                     if (inside) split_mid4<false>(hi[h][f], lo[h][f], s01, s23, b01, b23, p.slope, true, h1, h2, lowm);
                     else split_mid4<true>(hi[h][f], lo[h][f], s01, s23, b01, b23, p.slope, t >= 0 && t < p.T, h1, h2, lowm);
-                    *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16)) = h1;
-                    *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16) + G::MHALF) = h2;
+                    *reinterpret_cast<f16x4*>(mwr + f * 256 + h * (2 * G::MRP * 16)) = h1;
+                    *reinterpret_cast<f16x4*>(mwr + f * 256 + h * (2 * G::MRP * 16) + G::MHALF) = h2;
                 }
             }
             low_note(low, 1, lowm);
@@ -253,12 +270,23 @@ __device__ __forceinline__ void convq_run_member(const PairParams& p, const Pair
         conv(IntC<1>{});
         // ---- epilogue: outputs, then the image of the next window ----------------------------------------------
         pair_barrier();                                  // every wave is done with the intermediate
+        if (nwarm) {
+            // the last KT - 1 valid columns -> the front of the image (rows [r0 + NM - (KT - 1), r0 + NM) -> [0, KT - 1));
+            // the next tile's conv1 writes rows [KT - 1, KT - 1 + NM) many barriers from here, conv2 reads after its own
+            constexpr int NC = 2 * G::CB * (G::KT - 1);
+            if (tid < NC) {
+                const int row = tid % (G::KT - 1), hb = tid / (G::KT - 1);      // hb: (split half, 8-channel block)
+                char* const base = mimg + (hb / G::CB) * G::MHALF + ((hb % G::CB) * G::MRP) * 16;
+                *reinterpret_cast<f16x8*>(base + row * 16) =
+                    *reinterpret_cast<const f16x8*>(base + (r0 + G::NM - (G::KT - 1) + row) * 16);
+            }
+        }
         {
             const __amdgpu_buffer_rsrc_t rr = make_rsrc(mb.x + b * ustride, ubytes);     // the residual is x itself
 #pragma unroll
             for (int f = 0; f < G::NFW; ++f) {
                 const int col = col0 + f * 16, t = t0 + col;
-                voff[f] = col < G::NOUT && t < p.T ? (unsigned)(row0 * p.T + t) * 4u : kOutOfRange;
+                voff[f] = col < n_out && t < c_end ? (unsigned)(row0 * p.T + t) * 4u : kOutOfRange;
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -305,14 +333,15 @@ __device__ __forceinline__ void convq_run_member(const PairParams& p, const Pair
                 const int col = col0 + f * 16;
                 range_note4p(bad2, hi[h][f]);         // (every column is computed from real, zero-padded data)
                 pair_store(p, mb.y, mb.y_act, G::C, b, row0 + 16 * h, t0 + col,
-                           col < G::NOUT && t0 + col < p.T && !(p.dbg & 8), v, fin, rcp);
+                           col < n_out && t0 + col < c_end && !(p.dbg & 8), v, fin, rcp);
             }
         if (more && !(p.dbg & 2)) convh_convert<G>(raw, ximg, p.slope, tid, low);
         if (!more) break;
         g0 = slot_of(G::NST);
-        item = nitem;
+        if (!cont) c_end = nb == b_last ? c_last : p.T;
         b = nb;
-        tile = ntile;
+        tout = ntout;
+        warm = nwarm;
     }
     pair_wait_vm0();
     range_flag(p, bad2.x + bad2.y);

@@ -11,6 +11,8 @@ import yaml
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fastvocoder_amd import _native  # noqa: E402
+import _ablib  # noqa: E402
+_ablib.use_lib_from_env(_native)       # FV_AB_LIB=<a library build>: A/B of two builds (tools/build_variant.py)
 from fastvocoder_amd.bin.synthesize import build_generator  # noqa: E402
 from fastvocoder_amd.synthetic import seeded_mel, seeded_state_dict  # noqa: E402
 
