@@ -31,7 +31,7 @@ __global__ void pack_convk_kernel(const float* __restrict__ w1, const float* __r
     }
 }
 
-// 256 channels (convk2_kernel): [stage = 2 K step + split half][row sixteenth 16][lane][8 halves]; K steps: conv1's in
+// 256 channels (convk2_kernel): [K step][split half][row sixteenth 16][lane][8 halves]; K steps: conv1's in
 // chunks of 128 input channels, tap-major inside a chunk (convs_kernel's order), then W2's eight groups, then the skip layer's
 __global__ void pack_convk2_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ ws,
                                    _Float16* __restrict__ wp, const float* __restrict__ inv1, const float* __restrict__ inv2,

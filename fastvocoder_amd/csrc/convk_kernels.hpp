@@ -322,16 +322,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ---- 256 channels ---------------------------------------------------------------------------------------------------
-// A block holds all 256 rows of a 32-COLUMN tile (8 waves = 8 row slabs of 32, the same 32 x 32 wave tile): window image
-// <= 52 KB, hidden tile 32 KB.  A K step of all 256 rows is 32 KB of A operands -- a ring of three such stages would not
-// fit -- so a weight stage is one SPLIT HALF of a K step (16 KB: the h1 parts of all rows, then the h2 parts), ring of
-// four, three stages ahead.  Of a K step's 12 MFMAs per wave the 8 that multiply h1 (hi += a1 b1, lo += a1 b2) run when
-// the first stage has landed, the 4 that multiply h2 (lo += a2 b1) one stage entry later: the order of every other split
-// kernel, hence the bits of convs_kernel + convr_kernel (the two-launch form at 256 channels, whose K order -- chunks of
-// 128 input channels, tap-major inside a chunk -- the stage sequence follows).
-// 32-column tiles: 50 of them for MelGAN's first stage at batch 1 (1 600 columns), each a chain of 80 stage entries --
-// the form for launches that are latency-bound anyway; with more tiles than ~2 per CU the two-launch form on 128-row x
-// 128-column tiles is the faster one (the launcher decides: launch_convk).
+// A block holds all 256 rows of a 32-COLUMN tile: 8 waves = 8 row slabs of 32, ONE column group -- the same 32 x 32 wave
+// tile, window image <= 52 KB, hidden tile 32 KB.  With one column group no two waves share a row of weights, so there is
+// nothing for an LDS ring to share: every wave loads the A operands of ITS 32 rows straight from L2 into registers
+// (4 x 16 bytes per lane and K step, three K steps ahead) and the K loops have NO barrier -- four per tile instead of one
+// per weight stage.  (First built with a ring of 16 KB half-K-step stages, 80 stage entries per tile: 1350 cycles per K
+// step against 384 of MFMA issue; the packed image [K step][split half][row sixteenth][lane][8 halves] is that form's.)
+// The MFMA order of every split kernel -- hi += a1 b1, lo += a1 b2, lo += a2 b1 -- and convs_kernel's K order (chunks of
+// 128 input channels, tap-major inside a chunk; then the hidden tile's eight groups, then the raw centre's): the bits of
+// convs_kernel + convr_kernel, the two-launch form at 256 channels.
 template <int DIL_>
 struct ConvK2Geom {
     static constexpr int DIL = DIL_, KT = 3, C = 256, CG = 8, CB = 32, NFW = 2, NT = 512;
@@ -341,22 +340,23 @@ struct ConvK2Geom {
     static constexpr int XHALF = CB * XRP * 16;
     static constexpr int XR = (XROWS * CB + NT - 1) / NT;
     static constexpr int MRP = NM, MHALF = CB * MRP * 16;
-    static constexpr int NK1 = KT * CG, NK2 = 2 * CG;    // K steps of conv1 / of the 1x1 pair
-    static constexpr int NS1 = 2 * NK1, NST = 2 * (NK1 + NK2);      // stages: two per K step
-    static constexpr int STAGE_BYTES = 16384, RING = 4, AHEAD = 3, NDMA = 2;
+    static constexpr int NK1 = KT * CG, NK2 = 2 * CG, NK = NK1 + NK2;     // K steps of conv1 / of the 1x1 pair
+    static constexpr int STEP_BYTES = 2 * 16384;         // packed: [K step][split half: 16 KB]
+    static constexpr int QD = 3;                         // A operands this many K steps ahead of their MFMAs (queue of QD + 1 slots)
+    static constexpr int NA = 4;                         // loads per wave and K step
     static constexpr int NRAW = XR * 8;
-    static constexpr int WBYTES = NST * STAGE_BYTES;
-    static constexpr int RING_BYTES = RING * STAGE_BYTES;
-    static constexpr int LDS_BYTES = RING_BYTES + 2 * XHALF + 2 * MHALF + (4 * C + 16) * 4;
-    static_assert(NST % RING == 0, "ring slot = stage & 3");
+    static constexpr int WBYTES = NK * STEP_BYTES;
+    static constexpr int LDS_BYTES = 2 * XHALF + 2 * MHALF + (4 * C + 16) * 4;
     static_assert(2 * MHALF <= 2 * XHALF && LDS_BYTES <= 160 * 1024, "LDS");
     static_assert(((CG - 1) * 4 * XRP + (KT - 1) * DIL + 16) * 16 + 16 < 65536, "ds_read immediate range");
+    static_assert(NK % (QD + 1) == 0, "the A queue runs on from tile to tile: slot = K step % (QD + 1)");
 };
 
 template <int DIL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void convk2_kernel(ConvKParams p) {
     typedef ConvK2Geom<DIL> G;
     typedef __attribute__((address_space(3))) const f16x8 LdsH8;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     int lane = tid & 63;
@@ -367,8 +367,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int hi_item = equal_share(share + 1, p.n_items, p.nblk);
     if (item >= hi_item) return;
 
-    float* const ring = smem;
-    char* const ximg = reinterpret_cast<char*>(smem) + G::RING_BYTES;
+    char* const ximg = reinterpret_cast<char*>(smem);
     char* const mimg = ximg + 2 * G::XHALF;
     float* const bl = reinterpret_cast<float*>(mimg + 2 * G::MHALF);
     const int n = lane & 15, kb = lane >> 4;
@@ -377,7 +376,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const char* const bptr = ximg + (kb * G::XRP + col0) * 16;
     const char* const mptr = mimg + (kb * G::MRP + col0) * 16;
     const char* const rptr = ximg + (kb * G::MRP + col0) * 16;
-    const float* const aptr = ring + (2 * ws) * 256 + lane * 4;    // + slot stage + h * 256 floats (one split half per stage)
     const int row0 = 32 * ws + 4 * kb;
     char* const mw = mimg + ((4 * ws + (kb >> 1)) * G::MRP + col0) * 16 + 8 * (kb & 1);
 
@@ -385,25 +383,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned ubytes = (unsigned)G::C * (unsigned)p.T * 4u;
     const unsigned t4 = (unsigned)p.T * 4u;
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (unsigned)G::WBYTES);
-    auto dma_stage = [&](int slot, unsigned stage_off) {
-        float* dst = ring + slot * (G::STAGE_BYTES / 4) + wave * 512;
-        const unsigned o = stage_off == kOutOfRange ? kOutOfRange : stage_off + (unsigned)(wave * 2048 + lane * 16);
-        dma16(rw, dst, o);
-        dma16(rw, dst + 256, o == kOutOfRange ? kOutOfRange : o + 1024u);
+    const unsigned aoff = (unsigned)((2 * ws) * 1024 + lane * 16);        // this wave's two row sixteenths inside a 16 KB half
+    // A operands of K step KS (compile time, modulo the tile's NK: the queue runs on into the next tile): [h][split half]
+    auto load_a = [&](auto KC, f16x8 (&dst)[2][2]) {
+        constexpr int KS = decltype(KC)::value % G::NK;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                dst[h][e] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                    rw, (int)(aoff + (unsigned)(h * 1024)), KS * G::STEP_BYTES + e * 16384, 0));
     };
     int b = item / p.n_tiles, tile = item - b * p.n_tiles;
     LowGuard low;
     f32x2 bad2 = {0.f, 0.f};
     ConvHRaw<G> raw;
     convh_load_raw<G>(raw, p.x + b * ustride, p.T, tile * G::NM - G::P, tid, true, p.reflect != 0);
-#pragma unroll
-    for (int st = 0; st < G::AHEAD; ++st) dma_stage(st, (unsigned)(st * G::STAGE_BYTES));
     if (tid < G::C) {
         bl[tid] = p.b1 ? p.b1[tid] : 0.f;
         bl[G::C + tid] = p.b2 ? p.b2[tid] : 0.f;
         bl[2 * G::C + tid] = p.w[G::WBYTES / 4 + tid];
         bl[3 * G::C + tid] = p.w[G::WBYTES / 4 + G::C + tid];
     }
+    f16x8 aq[G::QD + 1][2][2];                           // K step KS sits in aq[KS % (QD + 1)]
+    static_for<0, G::QD>([&](auto QC) { load_a(QC, aq[decltype(QC)::value]); });
     pair_wait_vm0();
     convh_convert<G>(raw, ximg, p.slope, tid, low, 0);
     for (;;) {
@@ -416,32 +419,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             ++nb;
         }
         f32x4 hi[2][2], lo[2][2];
-        f16x8 a1[2], a2[2], bbuf[2][2][2];
+        f16x8 bbuf[2][2][2];
 
-        // stage entry: as convk_kernel's, three stages ahead in a ring of four (NST % 4 == 0: slot = stage & 3)
-        auto entry = [&](auto GC) {
-            constexpr int GS = decltype(GC)::value;
-            constexpr bool raw_between = GS >= G::NS1 + 1 && GS <= G::NS1 + G::AHEAD;
-            if constexpr (GS >= G::AHEAD) wait_vm<G::NDMA * (G::AHEAD - 1) + (raw_between ? G::NRAW : 0)>();
-            pair_barrier();
-            constexpr int NS = GS + G::AHEAD;
-            if constexpr (NS < G::NST) dma_stage(NS & 3, (unsigned)(NS * G::STAGE_BYTES));
-            else dma_stage(NS & 3, more ? (unsigned)((NS - G::NST) * G::STAGE_BYTES) : kOutOfRange);
-        };
-        auto fetch_a = [&](auto SC, f16x8 (&dst)[2]) {   // the stage's split half of this wave's two row sixteenths
-            constexpr int S = decltype(SC)::value;
-            LdsCF* a = lds_opaque(aptr + (S & 3) * (G::STAGE_BYTES / 4));
-            dst[0] = *reinterpret_cast<LdsH8*>(a);
-            dst[1] = *reinterpret_cast<LdsH8*>(a + 256);
-        };
         LdsCF* const bb = lds_opaque(reinterpret_cast<const float*>(bptr));
         LdsCF* const bb2 = lds_opaque(reinterpret_cast<const float*>(bptr + G::XHALF));
         LdsCF* const mb1 = lds_opaque(reinterpret_cast<const float*>(mptr));
         LdsCF* const mb2 = lds_opaque(reinterpret_cast<const float*>(mptr + G::MHALF));
         LdsCF* const rb1 = lds_opaque(reinterpret_cast<const float*>(rptr));
         LdsCF* const rb2 = lds_opaque(reinterpret_cast<const float*>(rptr + G::MHALF));
-        // B operands of K step KS: conv1 -- chunk of 128 channels, tap, 32-channel group inside the chunk (the order of
-        // convs_kernel's packed image); then the hidden tile's eight groups, then the raw centre's
         auto fetch_b = [&](auto KC, f16x8 (&dst)[2][2]) {
             constexpr int KS = decltype(KC)::value;
 #pragma unroll
@@ -462,50 +447,49 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         };
-        // stages [S0, S1) (whole K steps): h1 stage -> 8 MFMAs, h2 stage -> 4
-        auto run = [&](auto S0C, auto S1C) {
-            constexpr int S0 = decltype(S0C)::value, S1 = decltype(S1C)::value;
+        // K steps [K0, K1): the A queue runs QD steps ahead (loads return in order: K step KS has landed once at most the
+        // loads issued after it are outstanding -- QD steps' worth, plus the next tile's raw window where that was requested
+        // in between: RAWK = first K step issued after it); B operands one step ahead, from the images
+        auto run = [&](auto K0C, auto K1C, auto RAWKC) {
+            constexpr int K0 = decltype(K0C)::value, K1 = decltype(K1C)::value, RAWK = decltype(RAWKC)::value;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int f = 0; f < 2; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-            fetch_a(IntC<S0>{}, a1);
-            fetch_b(IntC<S0 / 2>{}, bbuf[(S0 / 2) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<S0, S1>([&](auto SC) {
-                constexpr int S = decltype(SC)::value, SN = S + 1, KS = S / 2;
-                if constexpr (SN < G::NST) entry(IntC<SN>{});
-                if constexpr (S % 2 == 0) {
-                    fetch_a(IntC<SN>{}, a2);             // the K step's h2 parts: needed one entry from now
-                    __builtin_amdgcn_sched_barrier(0);
+            fetch_b(IntC<K0>{}, bbuf[K0 & 1]);
+            static_for<K0, K1>([&](auto KC) {
+                constexpr int KS = decltype(KC)::value;
+                load_a(IntC<KS + G::QD>{}, aq[(KS + G::QD) % (G::QD + 1)]);
+                if constexpr (KS + 1 < K1) fetch_b(IntC<KS + 1>{}, bbuf[(KS + 1) & 1]);
+                // outstanding after K step KS's loads: steps KS + 1 .. KS + QD, and the raw window if it was requested after
+                // step KS's loads and before step KS + QD's (RAWK in (KS, KS + QD])
+                constexpr bool raw_after = RAWK > KS && RAWK <= KS + G::QD;
+                // (a tile's first QD steps were waited for in the epilogue of the tile before, ahead of its stores: a count
+                // here would wait for those stores)
+                if constexpr (KS >= G::QD) wait_vm<G::NA * G::QD + (raw_after ? G::NRAW : 0)>();
+                __builtin_amdgcn_sched_barrier(0);
+                f16x8 (&a)[2][2] = aq[KS % (G::QD + 1)];
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                        for (int e = 0; e < 2; ++e)
-                            hi[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[h], bbuf[KS & 1][e][0], hi[h][e], 0, 0, 0);
+                    for (int e = 0; e < 2; ++e)
+                        hi[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[h][0], bbuf[KS & 1][e][0], hi[h][e], 0, 0, 0);
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                        for (int e = 0; e < 2; ++e)
-                            lo[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[h], bbuf[KS & 1][e][1], lo[h][e], 0, 0, 0);
-                } else {
-                    if constexpr (SN < S1) {
-                        fetch_a(IntC<SN>{}, a1);         // the next K step's h1 parts and B operands
-                        fetch_b(IntC<KS + 1>{}, bbuf[(KS + 1) & 1]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int e = 0; e < 2; ++e)
+                        lo[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[h][0], bbuf[KS & 1][e][1], lo[h][e], 0, 0, 0);
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                        for (int e = 0; e < 2; ++e)
-                            lo[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[h], bbuf[KS & 1][e][0], lo[h][e], 0, 0, 0);
-                }
+                    for (int e = 0; e < 2; ++e)
+                        lo[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[h][1], bbuf[KS & 1][e][0], lo[h][e], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
 
-        entry(IntC<0>{});
-        run(IntC<0>{}, IntC<G::NS1>{});
+        pair_barrier();                                  // the window image is complete
+        run(IntC<0>{}, IntC<G::NK1>{}, IntC<-1>{});
         {
             float lowm = 0.f;
 #pragma unroll
@@ -525,10 +509,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         pair_barrier();                                  // the hidden tile is complete, nobody reads the window image any more
         convk_convert_centre<G>(raw, ximg, tid);
+        // the next tile's window: requested after the loads of K steps NK1, NK1 + 1 (issued during conv1's last two steps)
         convh_load_raw<G>(raw, p.x + nb * ustride, p.T, ntile * G::NM - G::P, tid, more, p.reflect != 0);
-        run(IntC<G::NS1>{}, IntC<G::NST>{});
+        pair_barrier();                                  // the raw centre's image is complete
+        run(IntC<G::NK1>{}, IntC<G::NK>{}, IntC<G::NK1 + G::QD>{});
         pair_barrier();                                  // every wave is done with the hidden tile and the raw centre
-        pair_wait_vm0();
         {
             const size_t boff = (size_t)b * ustride;
             const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y + boff, ubytes);
@@ -558,6 +543,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         if (!more) break;
+        // the window (requested before conv2) and the A operands of the next tile's first steps are all older than this
+        // tile's stores (16 per lane, 32 with the activated twin): wait for the loads only
+        if (p.y_act) wait_vm<32>();
+        else wait_vm<16>();
         convh_convert<G>(raw, ximg, p.slope, tid, low, 0);
         item = nitem;
         b = nb;
