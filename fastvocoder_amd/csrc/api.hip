@@ -646,6 +646,8 @@ static int run_op(const Op& o, const float* x, float* y, float* y2, const float*
         pp.guard = guard;
         pp.reflect = (o.pad_mode & FV_PAD_REFLECT) ? 1 : 0;
         pp.post = o.post;
+        pp.sub = sub;
+        pp.sub_batched = sub_batched;
         pp.m[0].x = x;
         pp.m[0].w1 = o.wp;
         pp.m[0].b1 = o.bias;
@@ -733,7 +735,7 @@ static const TuningEntry kTuningTable[] = {
     {"pair_dbg", &Tuning::pair_dbg},       {"dbg", &Tuning::conv_dbg},           {"sched", &Tuning::sched},
     {"sched_switch", &Tuning::sched_switch}, {"convh_skel", &Tuning::convh_skel}, {"convp_skel", &Tuning::convp_skel},
     {"convq_skel", &Tuning::convq_skel},   {"pair128_unfused", &Tuning::pair128_unfused},
-    {"chain", &Tuning::chain},             {"chain_spin", &Tuning::chain_spin},  {"convg_rows64", &Tuning::convg_rows64}, {"stack_items", &Tuning::stack_items},
+    {"chain", &Tuning::chain},             {"chain_spin", &Tuning::chain_spin},  {"convg_rows64", &Tuning::convg_rows64}, {"stack_items", &Tuning::stack_items}, {"stack_wide", &Tuning::stack_wide},
     {"convh_rows64", &Tuning::convh_rows64},  {"convt_rows64", &Tuning::convt_rows64},
     {"pairh_skel", &Tuning::pairh_skel},   {"pair_skel", &Tuning::pair_skel},    {"convh_blocks", &Tuning::convh_blocks},
     {"pair_blocks", &Tuning::pair_blocks}, {"sum3_min", &Tuning::sum3_min},      {"lds_budget", &Tuning::lds_budget},
@@ -1871,9 +1873,9 @@ int fv_plan_set_output_offset(fv_plan_t* plan, int aux_slot, int y2_slot) {
         return fail(FV_ERR_INVALID_ARG, "plan_set_output_offset: slot %d is not an auxiliary input", aux_slot);
     if (int rc = check_slot(y2_slot, true)) return rc;
     Op& o = plan->ops.back();
-    if (o.type == OP_PAIR || o.type == OP_MRFSUM || o.type == OP_CONVH || o.type == OP_STACK || o.sum3 || o.group != 0 ||
+    if (o.type == OP_PAIR || o.type == OP_MRFSUM || o.type == OP_CONVH || o.sum3 || o.group != 0 ||
         (o.type == OP_CONVT && o.prec == FV_PAIR_SPLIT_F16))   // (a pair with a folded output conv included)
-        return fail(FV_ERR_UNSUPPORTED, "plan_set_output_offset: only plain conv / transposed conv / two-source 1x1 / pqmf ops carry an offset");
+        return fail(FV_ERR_UNSUPPORTED, "plan_set_output_offset: only plain conv / transposed conv / two-source 1x1 / residual stack / pqmf ops carry an offset");
     if (y2_slot != FV_SLOT_NONE) {
         if (o.y2 != FV_SLOT_NONE) return fail(FV_ERR_INVALID_ARG, "plan_set_output_offset: the op already has a second output");
         if (y2_slot == o.y || y2_slot == o.x || y2_slot == FV_SLOT_IN) return fail(FV_ERR_INVALID_ARG, "plan_set_output_offset: y2 aliases");
@@ -2231,6 +2233,8 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             pg.m[0].b1 = o.bias2;
             pg.m[0].y = base[o.y];
             pg.m[0].y_act = o.y2 == FV_SLOT_NONE ? nullptr : base[o.y2];
+            pg.sub = o.sub == FV_SLOT_NONE ? nullptr : base[o.sub];
+            pg.sub_batched = o.sub == FV_SLOT_NONE ? 0 : aux_b[o.sub - FV_SLOT_AUX_IN0];
             if (int rc = launch_convg(pg, o.Cout, s)) return rc;
             sh[o.y] = {o.Cout, sh[o.x].T, true};
             if (o.y2 != FV_SLOT_NONE) sh[o.y2] = sh[o.y];

@@ -80,13 +80,17 @@ static int launch_one(const ConvKParams& p, hipStream_t s) {
     FV_HIP(hipGetLastError());
     return 0;
 }
-template <int DIL>
+template <int DIL, int NM>
 static int launch_256(const ConvKParams& p, hipStream_t s) {
-    typedef ConvK2Geom<DIL> G;
-    if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(convk2_kernel<DIL>), (size_t)G::LDS_BYTES)) return rc;
-    hipLaunchKernelGGL((convk2_kernel<DIL>), dim3(p.nblk), dim3(512), (size_t)G::LDS_BYTES, s, p);
+    typedef ConvK2Geom<DIL, NM> G;
+    if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(convk2_kernel<DIL, NM>), (size_t)G::LDS_BYTES)) return rc;
+    hipLaunchKernelGGL((convk2_kernel<DIL, NM>), dim3(p.nblk), dim3(512), (size_t)G::LDS_BYTES, s, p);
     FV_HIP(hipGetLastError());
     return 0;
+}
+template <int NM>
+static int launch_256_dil(const ConvKParams& p, int dil, hipStream_t s) {
+    return dil == 1 ? launch_256<1, NM>(p, s) : dil == 3 ? launch_256<3, NM>(p, s) : launch_256<9, NM>(p, s);
 }
 template <int CG>
 static int launch_cg(const ConvKParams& p, int dil, hipStream_t s) {
@@ -114,7 +118,10 @@ int launch_convk(const PairParams& pp, int C, int dil, hipStream_t s) {
     p.y_act = mb.y_act;
     p.B = pp.B;
     p.T = pp.T;
-    const int nm = convk_tile_columns(C);
+    // 256 channels: 64-column tiles (half the weight traffic per column, 24 MFMAs per K step and wave) once there are
+    // Tuning::stack_wide tenths of a tile per CU that way; 32-column tiles for the latency-bound runs below that
+    const bool wide = C == 256 && (long long)pp.B * ((pp.T + 63) / 64) * 10 >= (long long)tuning().stack_wide * device_cu_count();
+    const int nm = wide ? 64 : convk_tile_columns(C);
     p.n_tiles = (pp.T + nm - 1) / nm;
     const long long items = (long long)p.n_tiles * pp.B;
     if (items >= (1LL << 31)) return fail(FV_ERR_UNSUPPORTED, "residual stack: too many tiles");
@@ -125,11 +132,13 @@ int launch_convk(const PairParams& pp, int C, int dil, hipStream_t s) {
     p.slope = pp.slope;
     p.act_slope = pp.act_slope;
     p.post = pp.post;
+    p.sub = pp.sub;
+    p.sub_batched = pp.sub_batched;
     p.reflect = pp.reflect;
     p.guard = pp.guard;
     profile_begin(s);
     const int rc = C == 32 ? launch_cg<1>(p, dil, s) : C == 64 ? launch_cg<2>(p, dil, s) : C == 128 ? launch_cg<4>(p, dil, s)
-                 : dil == 1 ? launch_256<1>(p, s) : dil == 3 ? launch_256<3>(p, s) : launch_256<9>(p, s);
+                 : wide ? launch_256_dil<64>(p, dil, s) : launch_256_dil<32>(p, dil, s);
     // conv1 (3 taps) + the two 1x1 convs; x in, y (and its twin) out, the weights once
     profile_end(s, FV_KERNEL_STACK, 2.0 * pp.B * (double)C * C * 5 * pp.T,
                 4.0 * (5.0 * C * C + (double)pp.B * C * pp.T * (mb.y_act ? 3 : 2)));

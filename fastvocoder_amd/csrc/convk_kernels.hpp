@@ -36,6 +36,8 @@ struct ConvKParams {
     int B, T, n_tiles, n_items, nblk;
     float slope, act_slope;
     int post;            // FV_POST_* applied to y (the graph's last stack: Basis-MelGAN's final ReLU)
+    const float* sub;    // optional output offset (fv_plan_set_output_offset): y2 = act(post(y)) - sub, or y itself when there
+    int sub_batched;     //   is no second output (convh_kernels.hpp's rule); [C, T] or (sub_batched) [B, C, T]
     int reflect;         // rows outside [0, T): mirrored samples (ReflectionPad1d) instead of zeros
     int* guard;
 };
@@ -275,6 +277,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y + boff, ubytes);
             const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.y_act ? p.y_act + boff : p.y, p.y_act ? ubytes : 0u);
             const float zero[4] = {0.f, 0.f, 0.f, 0.f};
+            float off[2][2][4] = {};                     // the output offset of the bias-removal flows (the graph's last op only)
+            if (p.sub) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.sub + (p.sub_batched ? boff : 0), ubytes);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const int t = t0 + col0 + f * 16;
+                        const unsigned vo = t < p.T ? (unsigned)((row0 + 16 * h) * p.T + t) * 4u : kOutOfRange;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) off[h][f][i] = buffer_load1s(rs, vo, (unsigned)i * t4);
+                    }
+                pair_wait_vm0();
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const f32x2* const b2 = reinterpret_cast<const f32x2*>(bl + G::C + row0 + 16 * h);
@@ -291,7 +307,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         float v = hi[h][f][i];
                         if (p.post == FV_POST_TANH) v = tanhf(v);
                         else if (p.post == FV_POST_RELU) v = fmaxf(v, 0.f);
-                        const float a = p.act_slope != 1.f ? act(v, p.act_slope) : v;
+                        const float a = (p.act_slope != 1.f ? act(v, p.act_slope) : v) - off[h][f][i];
                         buffer_store1s(ry, voff, (unsigned)i * t4, p.y_act ? v : a);
                         if (p.y_act) buffer_store1s(ra, voff, (unsigned)i * t4, a);
                     }
@@ -331,30 +347,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // The MFMA order of every split kernel -- hi += a1 b1, lo += a1 b2, lo += a2 b1 -- and convs_kernel's K order (chunks of
 // 128 input channels, tap-major inside a chunk; then the hidden tile's eight groups, then the raw centre's): the bits of
 // convs_kernel + convr_kernel, the two-launch form at 256 channels.
-template <int DIL_>
+// NM_: columns per tile -- 32 (50 tiles for MelGAN's first stage at batch 1: the latency-bound form), or 64 for runs with
+// tiles to spare: a 32 x 64 wave tile (24 MFMAs per 4 A loads and 8 B reads), half the weight traffic per column -- at 32
+// columns every tile pulls the stack's 1.3 MB of weights through L2, 20 TB/s over the chip at batch 64 -- and 150 KB of LDS
+template <int DIL_, int NM_>
 struct ConvK2Geom {
-    static constexpr int DIL = DIL_, KT = 3, C = 256, CG = 8, CB = 32, NFW = 2, NT = 512;
-    static constexpr int NM = 32, P = DIL;
+    static constexpr int DIL = DIL_, KT = 3, C = 256, CG = 8, CB = 32, NM = NM_, NFW = NM / 16, NT = 512;
+    static constexpr int P = DIL;
     static constexpr int XROWS = (NM + 2 * DIL + 3) / 4 * 4;
-    static constexpr int XRP = XROWS;                    // (B reads stay below row 31 + 2 DIL: no padding rows needed)
+    static constexpr int XRP = XROWS;                    // (B reads stay below row NM - 1 + 2 DIL: no padding rows needed)
     static constexpr int XHALF = CB * XRP * 16;
     static constexpr int XR = (XROWS * CB + NT - 1) / NT;
     static constexpr int MRP = NM, MHALF = CB * MRP * 16;
     static constexpr int NK1 = KT * CG, NK2 = 2 * CG, NK = NK1 + NK2;     // K steps of conv1 / of the 1x1 pair
     static constexpr int STEP_BYTES = 2 * 16384;         // packed: [K step][split half: 16 KB]
-    static constexpr int QD = 3;                         // A operands this many K steps ahead of their MFMAs (queue of QD + 1 slots)
+    static constexpr int QD = NM >= 64 ? 1 : 3;          // A operands this many K steps ahead of their MFMAs (queue of QD + 1 slots;
+                                                         // a K step of the wide tile is 768 matrix cycles per SIMD: one ahead is enough)
     static constexpr int NA = 4;                         // loads per wave and K step
     static constexpr int NRAW = XR * 8;
     static constexpr int WBYTES = NK * STEP_BYTES;
     static constexpr int LDS_BYTES = 2 * XHALF + 2 * MHALF + (4 * C + 16) * 4;
     static_assert(2 * MHALF <= 2 * XHALF && LDS_BYTES <= 160 * 1024, "LDS");
-    static_assert(((CG - 1) * 4 * XRP + (KT - 1) * DIL + 16) * 16 + 16 < 65536, "ds_read immediate range");
+    static_assert(((CG - 1) * 4 * XRP + (KT - 1) * DIL + 16 * (NFW - 1)) * 16 + 16 < 65536, "ds_read immediate range");
     static_assert(NK % (QD + 1) == 0, "the A queue runs on from tile to tile: slot = K step % (QD + 1)");
 };
 
-template <int DIL>
+template <int DIL, int NM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void convk2_kernel(ConvKParams p) {
-    typedef ConvK2Geom<DIL> G;
+    typedef ConvK2Geom<DIL, NM> G;
     typedef __attribute__((address_space(3))) const f16x8 LdsH8;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -371,7 +391,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     char* const mimg = ximg + 2 * G::XHALF;
     float* const bl = reinterpret_cast<float*>(mimg + 2 * G::MHALF);
     const int n = lane & 15, kb = lane >> 4;
-    const int ws = wave;                                 // row slab of 32; one column group of 32
+    const int ws = wave;                                 // row slab of 32; one column group of NM
     const int col0 = n;
     const char* const bptr = ximg + (kb * G::XRP + col0) * 16;
     const char* const mptr = mimg + (kb * G::MRP + col0) * 16;
@@ -418,8 +438,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             ntile = 0;
             ++nb;
         }
-        f32x4 hi[2][2], lo[2][2];
-        f16x8 bbuf[2][2][2];
+        f32x4 hi[2][G::NFW], lo[2][G::NFW];
+        f16x8 bbuf[2][G::NFW][2];
 
         LdsCF* const bb = lds_opaque(reinterpret_cast<const float*>(bptr));
         LdsCF* const bb2 = lds_opaque(reinterpret_cast<const float*>(bptr + G::XHALF));
@@ -427,10 +447,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         LdsCF* const mb2 = lds_opaque(reinterpret_cast<const float*>(mptr + G::MHALF));
         LdsCF* const rb1 = lds_opaque(reinterpret_cast<const float*>(rptr));
         LdsCF* const rb2 = lds_opaque(reinterpret_cast<const float*>(rptr + G::MHALF));
-        auto fetch_b = [&](auto KC, f16x8 (&dst)[2][2]) {
+        auto fetch_b = [&](auto KC, f16x8 (&dst)[G::NFW][2]) {
             constexpr int KS = decltype(KC)::value;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
+            for (int e = 0; e < G::NFW; ++e) {
                 if constexpr (KS < G::NK1) {
                     constexpr int chunk = KS / 12, tap = (KS % 12) / 4, cg = 4 * chunk + KS % 4;
                     constexpr int off = (cg * 4 * G::XRP + tap * G::DIL) * 4;
@@ -455,7 +475,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int f = 0; f < 2; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int f = 0; f < G::NFW; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
             fetch_b(IntC<K0>{}, bbuf[K0 & 1]);
             static_for<K0, K1>([&](auto KC) {
                 constexpr int KS = decltype(KC)::value;
@@ -472,17 +492,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int e = 0; e < 2; ++e)
+                    for (int e = 0; e < G::NFW; ++e)
                         hi[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[h][0], bbuf[KS & 1][e][0], hi[h][e], 0, 0, 0);
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int e = 0; e < 2; ++e)
+                    for (int e = 0; e < G::NFW; ++e)
                         lo[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[h][0], bbuf[KS & 1][e][1], lo[h][e], 0, 0, 0);
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int e = 0; e < 2; ++e)
+                    for (int e = 0; e < G::NFW; ++e)
                         lo[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[h][1], bbuf[KS & 1][e][0], lo[h][e], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -498,7 +518,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const f32x2* const s2 = reinterpret_cast<const f32x2*>(bl + 2 * G::C + row0 + 16 * h);
                 const f32x2 b01 = b2[0], b23 = b2[1], s01 = s2[0], s23 = s2[1];
 #pragma unroll
-                for (int f = 0; f < 2; ++f) {
+                for (int f = 0; f < G::NFW; ++f) {
                     f16x4 h1, h2;
                     split_mid4<false>(hi[h][f], lo[h][f], s01, s23, b01, b23, p.slope, true, h1, h2, lowm);
                     *reinterpret_cast<f16x4*>(mw + f * 256 + h * (2 * G::MRP * 16)) = h1;
@@ -519,13 +539,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y + boff, ubytes);
             const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.y_act ? p.y_act + boff : p.y, p.y_act ? ubytes : 0u);
             const float zero[4] = {0.f, 0.f, 0.f, 0.f};
+            float off[2][G::NFW][4] = {};                // the output offset of the bias-removal flows (the graph's last op only)
+            if (p.sub) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.sub + (p.sub_batched ? boff : 0), ubytes);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int f = 0; f < G::NFW; ++f) {
+                        const int t = t0 + col0 + f * 16;
+                        const unsigned vo = t < p.T ? (unsigned)((row0 + 16 * h) * p.T + t) * 4u : kOutOfRange;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) off[h][f][i] = buffer_load1s(rs, vo, (unsigned)i * t4);
+                    }
+                pair_wait_vm0();
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const f32x2* const b2 = reinterpret_cast<const f32x2*>(bl + G::C + row0 + 16 * h);
                 const f32x2* const s2 = reinterpret_cast<const f32x2*>(bl + 3 * G::C + row0 + 16 * h);
                 const f32x2 b01 = b2[0], b23 = b2[1], s01 = s2[0], s23 = s2[1];
 #pragma unroll
-                for (int f = 0; f < 2; ++f) {
+                for (int f = 0; f < G::NFW; ++f) {
                     combine4(hi[h][f], lo[h][f], s01, s23, b01, b23, zero);
                     range_note4p(bad2, hi[h][f]);
                     const int t = t0 + col0 + f * 16;
@@ -535,7 +569,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         float v = hi[h][f][i];
                         if (p.post == FV_POST_TANH) v = tanhf(v);
                         else if (p.post == FV_POST_RELU) v = fmaxf(v, 0.f);
-                        const float a = p.act_slope != 1.f ? act(v, p.act_slope) : v;
+                        const float a = (p.act_slope != 1.f ? act(v, p.act_slope) : v) - off[h][f][i];
                         buffer_store1s(ry, voff, (unsigned)i * t4, p.y_act ? v : a);
                         if (p.y_act) buffer_store1s(ra, voff, (unsigned)i * t4, a);
                     }
@@ -544,9 +578,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         if (!more) break;
         // the window (requested before conv2) and the A operands of the next tile's first steps are all older than this
-        // tile's stores (16 per lane, 32 with the activated twin): wait for the loads only
-        if (p.y_act) wait_vm<32>();
-        else wait_vm<16>();
+        // tile's stores (8 NFW per lane, twice that with the activated twin): wait for the loads only
+        if (p.y_act) wait_vm<16 * G::NFW>();
+        else wait_vm<8 * G::NFW>();
         convh_convert<G>(raw, ximg, p.slope, tid, low, 0);
         item = nitem;
         b = nb;

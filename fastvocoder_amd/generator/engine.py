@@ -257,9 +257,8 @@ class PlanBuilder:
                        carry_two_launch=False):
         """dst = pointwise(lrelu(dilated(pad(lrelu(src))))) + skip(src), reference modules.py:351-382, as one launch
         (fv_plan_add_residual_stack_split_f16).  ``src`` is read raw; nothing is hoisted into its producer.
-        256 channels (and ``carry_two_launch``, 128+ channels: the graph's last stack, which may get an output offset
-        attached -- :meth:`subtract_output` then falls back on that form): the op also carries the two-launch form
-        (scratch slot ``hidden``; fv_plan_set_stack_two_launch, ``Tuning::stack_items`` for A/B runs)."""
+        256 channels (or ``carry_two_launch``, 128+): the op also carries the two-launch form (scratch slot ``hidden``;
+        fv_plan_set_stack_two_launch, ``Tuning::stack_items``) for A/B runs and the bit-identity tests."""
         c, k, d = dilated.in_channels, dilated.kernel_size[0], dilated.dilation[0]
         if not self.residual_stack_supported(dilated, pointwise, skip, d * (k - 1) // 2, pad_mode):
             raise _native.NativeError("residual_stack: shape not built into the one-launch kernel")
@@ -371,20 +370,10 @@ class PlanBuilder:
         Bias removal without a separate elementwise pass (reference bin/synthesize.py:74-80,
         basis_melgan.py:147-159, bin/test.py:82-91)."""
         op = self.ops[-1]
-        if op["kind"] == "stack" and "two_launch" in op:
-            # the one-launch stack kernel has no offset epilogue: its two-launch form (the op carries it) does
-            hidden, pd, pp = op["two_launch"]
-            self.ops[-1:] = [
-                dict(kind="convh", group=0, x=op["x"], y=hidden, res=SLOT_NONE, acc=SLOT_NONE, acc2=SLOT_NONE, pre_slope=1.0,
-                     slope=op["slope"], channels=op["channels"], k=op["k"], dil=op["dil"], pad_mode=op["pad_mode"], packed=pd,
-                     bias=op["bias"], out_div=1.0, post=POST_NONE),
-                dict(kind="conv2h", x=hidden, x2=op["x"], y=op["y"], res=SLOT_NONE, acc=SLOT_NONE, pre_slope=1.0,
-                     slope=op["slope"], split=True, packed=pp, bias=op["bias_out"], channels=op["channels"], post=op["post"])]
-            op = self.ops[-1]
-        if (op["kind"] not in ("conv", "conv2", "conv2h", "convT", "upconv", "pqmf", "postpqmf") or op.get("group", 0)
-                or (op.get("split") and op["kind"] != "conv2h")):
+        if (op["kind"] not in ("conv", "conv2", "conv2h", "stack", "convT", "upconv", "pqmf", "postpqmf") or op.get("group", 0)
+                or (op.get("split") and op["kind"] not in ("conv2h", "stack"))):
             raise _native.NativeError("subtract_output: the last op must be a plain conv / transposed conv / two-source "
-                                      "1x1 conv / pqmf")
+                                      "1x1 conv / residual stack / pqmf")
         op["sub"] = SLOT_AUX_IN0 + int(aux)
         op["sub_y2"] = SLOT_OUT2 if second else SLOT_NONE
 

@@ -201,7 +201,7 @@ class ResidualStack(_Block):
 
     fuse_skip = True      # stack[4] + skip_layer as ONE GEMM over the concatenated K range (False: three launches; A/B)
     fuse_stack = True     # the whole stack as ONE launch where that kernel exists (32 ... 256 channels; False: A/B)
-    fuse_last = True      # ... also the graph's last stack (128+ channels; False: A/B)
+    fuse_last = True      # ... also the graph's last stack (False: A/B)
 
     def __init__(self, kernel_size=3, channels=32, dilation=1, bias=True,
                  nonlinear_activation="LeakyReLU",
@@ -240,17 +240,17 @@ class ResidualStack(_Block):
         return 2
 
     def emit(self, pb, src, dst, scratch, post=POST_NONE, last=False):
-        """``last``: this stack produces the graph's output -- it may get an output offset attached, which only the
-        two-launch form has: fused at 128+ channels only, where the op can carry that form (PlanBuilder.subtract_output)."""
+        """``last``: this stack produces the graph's output (final activation and, in the bias-removal flows, an output
+        offset in its epilogue; ``fuse_last = False``: the two-launch form, A/B)."""
         hidden, skip = scratch[:2]
         dilated, pointwise = (self.stack[i] for i in self._conv_at)
         dilated = getattr(dilated, "conv", dilated)               # CausalConv1d wraps its conv
-        if (self.fuse_stack and (not last or (self.fuse_last and self.channels >= 128))
+        if (self.fuse_stack and (not last or self.fuse_last)
                 and pb.residual_stack_supported(dilated, pointwise, self.skip_layer, self._pad, self._pad_mode)):
             # 32 ... 256 channels: dilated conv, activation, 1x1 conv and skip branch in ONE launch, the hidden
             # tile stays in LDS (csrc/convk_kernels.hpp; 256 channels: only for runs of few tiles, else the two launches below)
             pb.residual_stack(dilated, pointwise, self.skip_layer, src, dst, self._slope, pad_mode=self._pad_mode, hidden=hidden,
-                              post=post, carry_two_launch=last)
+                              post=post)
             return
         if pb.conv_split_supported(dilated, self._pad, self._pad_mode):
             # 64 ... 512 channels: the dilated conv with split-f16 operands (csrc/convh_kernels.hpp), the

@@ -58,7 +58,7 @@ def _run(x, w1, b1, w2, b2, ws, bs, dil, slope, pad_mode, **kw):
 
 @pytest.fixture
 def tuning():
-    defaults = {"convh_blocks": 0, "convg_rows64": -1, "convh_rows64": -1, "stack_items": 1 << 20}
+    defaults = {"convh_blocks": 0, "convg_rows64": -1, "convh_rows64": -1, "stack_items": 1 << 20, "stack_wide": 20}
     yield _native.tuning_set
     for k, v in defaults.items():
         _native.tuning_set(k, v)
@@ -116,18 +116,30 @@ def test_residual_stack_vs_oracle(case, tuning):
     if B > 1:                                # utterances are independent
         one = _run(m[0][1:2], *m[1:], dil, 0.2, nmode)
         assert torch.equal(one, y[1:2])
+    if C == 256:                             # 32- and 64-column tiles (convk2_kernel<DIL, NM>; the launcher picks by size)
+        for wide in (0, 1 << 20):
+            tuning("stack_wide", wide)
+            for blocks in (0, 2):
+                tuning("convh_blocks", blocks)
+                assert torch.equal(_run(*m, dil, 0.2, nmode), y)
+        tuning("convh_blocks", 0)
+        tuning("stack_wide", 20)
 
 
 @pytest.mark.parametrize("case", [(1, 128, 1600, 1), (2, 128, 300, 3), (1, 128, 203, 9), (1, 128, 12, 9),
                                   (1, 256, 1600, 9), (2, 256, 300, 1), (1, 256, 77, 3)],
                          ids=lambda c: "x".join(str(v) for v in c))
-def test_residual_stack_is_the_two_launch_form_bit_for_bit(case):
+def test_residual_stack_is_the_two_launch_form_bit_for_bit(case, tuning):
     """At 128 and 256 channels the two-launch form runs on the same arithmetic (convh_kernel / convs_kernel, then convg_kernel
     / convr_kernel): same K order, same split of the hidden tensor, same epilogue -- identical bits."""
     B, C, T, dil = case
     rng = np.random.RandomState(C + T + dil)
     x, w1, b1, w2, b2, ws, bs = _stack(rng, B, C, T)
     fused = _run(x, w1, b1, w2, b2, ws, bs, dil, 0.2, _native.PAD_REFLECT)
+    tuning("stack_wide", 0)                  # (256 channels: the 64-column tile; elsewhere no effect)
+    wide = _run(x, w1, b1, w2, b2, ws, bs, dil, 0.2, _native.PAD_REFLECT)
+    tuning("stack_wide", 20)
+    assert torch.equal(wide, fused)
     hid = _native.conv1d_split_f16([_t(x)], [_native.pack_pair(_t(w1), SPLIT)], [_t(b1)], [3], dil, pre_slope=0.2,
                                    pad_mode=_native.PAD_REFLECT)[0]
     two = _native.conv1x1_2src_split_f16(hid, _t(x), _native.pack_conv1x1_2src_split(_t(w2), _t(ws)), _t(b2 + bs), pre_slope=0.2)

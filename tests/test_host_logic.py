@@ -309,7 +309,7 @@ def test_plan_shape_inference_without_gpu():
     r = L.fv_plan_create(64)
     assert L.fv_plan_add_residual_stack_split_f16(r, 0, 1, -1, dummy, None, None, 64, 3, 9, 0.2, _native.PAD_REFLECT, 0, 1.0) == 0
     assert L.fv_plan_output_shape(r, 321, ctypes.byref(c), ctypes.byref(n)) == 0 and (c.value, n.value) == (64, 321)
-    assert L.fv_plan_set_output_offset(r, 28, -1) != 0                      # no output offset on this op (two-launch form)
+    assert L.fv_plan_set_output_offset(r, 28, -1) == 0                      # (the bias-removal flows' offset rides in its epilogue)
     assert L.fv_plan_add_residual_stack_split_f16(r, 0, 1, -1, dummy, None, None, 64, 3, 5, 0.2, 0, 0, 1.0) != 0
     assert b"dilation 5" in L.fv_last_error()
     assert L.fv_plan_add_residual_stack_split_f16(r, 0, 1, -1, dummy, None, None, 512, 3, 1, 0.2, 0, 0, 1.0) != 0
