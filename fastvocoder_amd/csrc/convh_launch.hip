@@ -339,12 +339,20 @@ int launch_convg(PairParams p, int C, hipStream_t s) {
 }
 
 // ---- fused pair at C = 64 (convp_kernels.hpp) --------------------------------------------------------------------
+template <int DIL, int C>
+int launch_convq2_dil(const PairParams& p, size_t lds, hipStream_t s);      // convq2_inst.hip: the pairs without the weight ring
+extern template int launch_convq2_dil<1, 128>(const PairParams&, size_t, hipStream_t);
+extern template int launch_convq2_dil<3, 128>(const PairParams&, size_t, hipStream_t);
+extern template int launch_convq2_dil<5, 128>(const PairParams&, size_t, hipStream_t);
+extern template int launch_convq2_dil<1, 64>(const PairParams&, size_t, hipStream_t);
+extern template int launch_convq2_dil<3, 64>(const PairParams&, size_t, hipStream_t);
+extern template int launch_convq2_dil<5, 64>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convp_dil<1>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convp_dil<3>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convp_dil<5>(const PairParams&, size_t, hipStream_t);
 
 // everything launch_convp does in front of the launch: validation, member order, tile counts, LDS layout, block schedule
-static int prepare_convp(PairParams& p, int dil, size_t& lds_out, double& flops, double& bytes) {
+static int prepare_convp(PairParams& p, int dil, size_t& lds_out, double& flops, double& bytes, bool noring = false) {
     const int C = 64;
     if (dil != 1 && dil != 3 && dil != 5) return fail(FV_ERR_UNSUPPORTED, "resblock pair: dilation %d (1, 3 or 5)", dil);
     if (p.n_members < 1 || p.n_members > 3) return fail(FV_ERR_INVALID_ARG, "resblock pair: %d members", p.n_members);
@@ -380,7 +388,7 @@ static int prepare_convp(PairParams& p, int dil, size_t& lds_out, double& flops,
     }
     size_t floats = 0;
     p.x_off = 0;                       // ring of 4 weight stages
-    floats += 4 * 16384 / 4;
+    if (!noring) floats += 4 * 16384 / 4;
     p.img_off = (int)floats;
     floats += (size_t)img_bytes / 4;
     p.mid_off = (int)floats;
@@ -409,9 +417,13 @@ int launch_convp(PairParams p, int dil, hipStream_t s) {
     if (p.B <= 0 || p.T <= 0) return 0;
     size_t lds;
     double flops, bytes;
-    if (int rc = prepare_convp(p, dil, lds, flops, bytes)) return rc;
+    // convq2_kernels.hpp at 64 channels (A operands from L2 into registers, no ring) measured the same as convp_kernel at batch
+    // 1 (55.2 vs 54.4-56.2 us per three-member launch) and at 8 x 128 000 columns (1162 vs 1163 us): the ring form stays
+    const bool noring = tuning().convp2 != 0;
+    if (int rc = prepare_convp(p, dil, lds, flops, bytes, noring)) return rc;
     profile_begin(s);
-    const int rc = dil == 1 ? launch_convp_dil<1>(p, lds, s) : dil == 3 ? launch_convp_dil<3>(p, lds, s) : launch_convp_dil<5>(p, lds, s);
+    const int rc = noring ? (dil == 1 ? launch_convq2_dil<1, 64>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, 64>(p, lds, s) : launch_convq2_dil<5, 64>(p, lds, s))
+                          : (dil == 1 ? launch_convp_dil<1>(p, lds, s) : dil == 3 ? launch_convp_dil<3>(p, lds, s) : launch_convp_dil<5>(p, lds, s));
     profile_end(s, FV_KERNEL_CONVH64, flops, bytes);
     return rc;
 }
@@ -667,8 +679,9 @@ int launch_convq(PairParams p, int dil, hipStream_t s) {
         bytes += 4.0 * (2.0 * C * C * mb.k + (double)p.B * C * p.T * ((mb.y_act ? 3 : 2) + (mb.add1 ? 1 : 0) + (mb.add2 ? 1 : 0)));
     }
     size_t floats = 0;
+    const bool noring = tuning().convq2 != 0;      // convq2_kernels.hpp: A operands from L2 into registers, no ring
     p.x_off = 0;                       // ring of 3 weight stages (one K step of all 128 rows each)
-    floats += 3 * 16384 / 4;
+    if (!noring) floats += 3 * 16384 / 4;
     p.img_off = (int)floats;
     floats += (size_t)img_bytes / 4;
     p.mid_off = (int)floats;
@@ -690,7 +703,8 @@ int launch_convq(PairParams p, int dil, hipStream_t s) {
     p.dbg = tuning().pair_dbg;
     p.trace = nullptr;
     profile_begin(s);
-    const int rc = dil == 1 ? launch_convq_dil<1>(p, lds, s) : dil == 3 ? launch_convq_dil<3>(p, lds, s) : launch_convq_dil<5>(p, lds, s);
+    const int rc = noring ? (dil == 1 ? launch_convq2_dil<1, 128>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, 128>(p, lds, s) : launch_convq2_dil<5, 128>(p, lds, s))
+                          : (dil == 1 ? launch_convq_dil<1>(p, lds, s) : dil == 3 ? launch_convq_dil<3>(p, lds, s) : launch_convq_dil<5>(p, lds, s));
     profile_end(s, FV_KERNEL_CONVH128, flops, bytes);
     return rc;
 }

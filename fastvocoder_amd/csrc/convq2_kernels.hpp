@@ -1,0 +1,337 @@
+// Fused ResBlock1 pair at 128 channels WITHOUT the weight ring (round 4; the ring form: convq_kernels.hpp).
+//
+// Same tile (all 128 rows x 64 intermediate columns), same images, same K order, same warm tiles -- a different wave
+// layout: 8 waves = 8 row slabs of SIXTEEN rows x ONE column group of 64 columns (a 16 x 64 wave tile: per K step
+// 1 row sixteenth x 4 fragments x 3 split terms = the same 12 MFMAs, 8 B-operand ds_read_b128 -- what the 32 x 32 tile
+// read as 4 A + 4 B).  With one column group no two waves share a row of weights, so every wave loads the A operands of
+// its own 16 rows straight from L2 into registers (2 x 16 bytes per lane and K step, three K steps ahead in a queue that
+// runs on from conv1 to conv2 to the next tile) -- the L2 traffic of the ring form, no LDS-DMA, no ring slot to hand
+// over: the K loops have NO barrier (the ring form: one per K step, 88 per 11-tap tile); three per tile remain (window
+// image complete, intermediate complete, intermediate free).  Identical bits: the same MFMA order per output.
+#pragma once
+#include "convq_kernels.hpp"
+#include "convp_kernels.hpp"
+
+namespace fv {
+
+// C = 128: the geometry of convq_kernel (64 intermediate columns); C = 64: that of convp_kernel (128 columns: two column
+// groups of 64 -- two waves do share a row sixteenth there and load it twice, 5.6 KB of weights per column instead of
+// 2.8: the 64-channel weights are a quarter of the 128-channel ones and the tile is twice as wide)
+template <int KT_, int DIL_, int C_>
+struct ConvQ2Geom;
+template <int KT_, int DIL_>
+struct ConvQ2Geom<KT_, DIL_, 128> : ConvQGeom<KT_, DIL_> {
+    typedef ConvQGeom<KT_, DIL_> IMG;                    // window loader / converter geometry
+    static constexpr int WN = 1;                         // column groups of 64
+    static constexpr int WBYTES = 2 * IMG::WTILE;        // packed bytes of one conv
+};
+template <int KT_, int DIL_>
+struct ConvQ2Geom<KT_, DIL_, 64> : ConvPGeom<KT_, DIL_> {
+    typedef typename ConvPGeom<KT_, DIL_>::H IMG;
+    static constexpr int WN = 2;
+    static constexpr int CG = 2, CB = 8, NT = 512;
+    static constexpr int NSTEP = IMG::NSTEP, XRP = IMG::XRP, XHALF = IMG::XHALF, WTILE = IMG::WTILE, NRAW = IMG::NRAW;
+    static constexpr int WBYTES = IMG::WTILE;
+};
+template <int KT_, int DIL_, int C_>
+struct ConvQ2Run : ConvQ2Geom<KT_, DIL_, C_> {
+    typedef ConvQ2Geom<KT_, DIL_, C_> B;
+    static constexpr int NFW = 4;                        // fragments per wave: 64 columns
+    static constexpr int QD = 3;                         // A operands this many K steps ahead (queue of QD + 1 slots)
+    static constexpr int NA = 2;                         // loads per wave and K step
+    static constexpr int NSEQ = 2 * B::NSTEP;            // K steps per tile: conv1's, then conv2's
+    static constexpr int RAWK = NSEQ - QD;               // K step at which the next tile's window is requested: no A operand of
+                                                         // THIS tile is issued after it, so nothing here waits for it
+    static_assert(NSEQ % (QD + 1) == 0, "the A queue runs on from tile to tile: slot = K step % (QD + 1)");
+    static_assert(B::NM == 64 * B::WN, "column groups of 64");
+};
+
+template <class G>
+__device__ __forceinline__ void convq2_run_member(const PairParams& p, const PairMember& mb, int item0, int hi_item,
+                                                  float* smem, int wave, int lane_in, bool first) {
+    typedef __attribute__((address_space(3))) const f16x8 LdsH8;
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int tid = wave * 64 + lane;
+    char* const ximg = reinterpret_cast<char*>(smem + p.img_off);
+    char* const mimg = reinterpret_cast<char*>(smem + p.mid_off);
+    float* const bl = smem + p.bias_off;                 // [b1[128] | b2[128] | inverse row prescales 1 | 2 | guard scratch]
+    const int n = lane & 15, kb = lane >> 4;
+    const int ws = G::WN == 1 ? wave : wave & 3;         // row slab of 16 = row sixteenth ws
+    const int col0 = (G::WN == 1 ? 0 : (wave >> 2) * 64) + n;
+    const char* const bptr = ximg + (kb * G::XRP + col0) * 16;
+    const char* const mptr = mimg + (kb * G::MRP + col0) * 16;
+    const int row0 = 16 * ws + 4 * kb;                   // + i
+    // D fragment -> intermediate image: channels row0 + i = half of the 8-channel block 2 ws + (kb >> 1)
+    char* const mw = mimg + ((2 * ws + (kb >> 1)) * G::MRP + col0) * 16 + 8 * (kb & 1);
+
+    const size_t ustride = (size_t)G::C * (size_t)p.T;
+    const unsigned ubytes = (unsigned)G::C * (unsigned)p.T * 4u;
+    const unsigned t4 = (unsigned)p.T * 4u;
+    const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(mb.w1, (unsigned)G::WBYTES);
+    const __amdgpu_buffer_rsrc_t rw2 = make_rsrc(mb.w2, (unsigned)G::WBYTES);
+    // packed image (fv_pack_pair_weight_ex): [64-row tile][K step][row sixteenth 4][split half][lane][8 halves]
+    const unsigned aoff = (unsigned)((ws >> 2) * G::WTILE + (ws & 3) * 2048 + lane * 16);       // (64 channels: one row tile)
+    // A operands of K step S of the tile's sequence (compile time; beyond the tile: the next tile's): [split half]
+    auto load_a = [&](auto SC, f16x8 (&dst)[2]) {
+        constexpr int S = decltype(SC)::value % G::NSEQ;
+        constexpr int step = S % G::NSTEP;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            dst[e] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(S < G::NSTEP ? rw1 : rw2, (int)aoff,
+                                                                                     step * 8192 + e * 1024, 0));
+    };
+    const int b_last = (hi_item - 1) / mb.n_tiles;
+    const int c_last = min(((hi_item - 1) - b_last * mb.n_tiles + 1) * G::NOUT, p.T);     // end of the run in the last utterance
+    int b = item0 / mb.n_tiles;
+    int tout = (item0 - b * mb.n_tiles) * G::NOUT;       // first output column of the tile
+    int c_end = b == b_last ? c_last : p.T;
+    bool warm = false;                                   // (cold / warm tiles of a run: convq_kernels.hpp)
+    if (!first) pair_barrier();
+    LowGuard low;
+    f32x2 bad2 = {0.f, 0.f};
+    const float rcp = div_rcp(p.out_div);
+    typedef typename G::IMG IMG;
+    ConvHRaw<IMG> raw;
+    convh_load_raw<IMG>(raw, mb.x + b * ustride, p.T, tout - G::P1 - G::P2, tid, true);
+    f16x8 aq[G::QD + 1][2];                              // K step S sits in aq[S % (QD + 1)]
+    static_for<0, G::QD>([&](auto QC) { load_a(QC, aq[decltype(QC)::value]); });
+    if (tid < G::C) {
+        bl[tid] = mb.b1 ? mb.b1[tid] : 0.f;
+        bl[G::C + tid] = mb.b2 ? mb.b2[tid] : 0.f;
+        bl[2 * G::C + tid] = mb.w1[G::WBYTES / 4 + tid];      // the rows' inverse weight prescales: behind the packed images
+        bl[3 * G::C + tid] = mb.w2[G::WBYTES / 4 + tid];
+    }
+    // rows [NM, MRP) of the intermediate feed only discarded columns: finite values once
+    for (int idx = tid; idx < 2 * G::CB * 64; idx += G::NT)
+        reinterpret_cast<float*>(mimg + ((idx >> 6) * G::MRP + G::NM) * 16)[idx & 63] = 0.f;
+    pair_wait_vm0();
+    if (!(p.dbg & 2)) convh_convert<IMG>(raw, ximg, p.slope, tid, low);
+    for (;;) {
+        const int t0 = tout;
+        const int r0 = warm ? G::KT - 1 : 0;             // image row of the first NEW intermediate column
+        const int n_out = warm ? G::NM : G::NOUT;
+        const bool cont = t0 + n_out < c_end;            // the run goes on
+        const bool nwarm = FV_WARM_TILES && cont;
+        const bool more = cont || b < b_last;
+        const int nb = cont ? b : b + 1;
+        const int ntout = cont ? t0 + n_out : 0;
+        const int nwin = ntout - G::P2 - G::P1 + (nwarm ? G::KT - 1 : 0);
+        f32x4 hi[G::NFW], lo[G::NFW];
+        f16x8 bbuf[2][G::NFW][2];
+
+        LdsCF* const bb = lds_opaque(reinterpret_cast<const float*>(bptr));
+        LdsCF* const bb2 = lds_opaque(reinterpret_cast<const float*>(bptr + G::XHALF));
+        LdsCF* const mb1 = lds_opaque(reinterpret_cast<const float*>(mptr));
+        LdsCF* const mb2 = lds_opaque(reinterpret_cast<const float*>(mptr + G::MHALF));
+        // B operands of K step S: conv1 from the x image (tap stride DIL), conv2 from the intermediate (stride 1)
+        auto fetch_b = [&](auto SC, f16x8 (&dst)[G::NFW][2]) {
+            constexpr int S = decltype(SC)::value, step = S % G::NSTEP;
+            constexpr int tap = step / G::CG, cg = step % G::CG;
+#pragma unroll
+            for (int e = 0; e < G::NFW; ++e) {
+                if constexpr (S < G::NSTEP) {
+                    constexpr int off = (cg * 4 * G::XRP + tap * G::DIL) * 4;
+                    dst[e][0] = *reinterpret_cast<LdsH8*>(bb + off + e * 64);
+                    dst[e][1] = *reinterpret_cast<LdsH8*>(bb2 + off + e * 64);
+                } else {
+                    constexpr int off = (cg * 4 * G::MRP + tap) * 4;
+                    dst[e][0] = *reinterpret_cast<LdsH8*>(mb1 + off + e * 64);
+                    dst[e][1] = *reinterpret_cast<LdsH8*>(mb2 + off + e * 64);
+                }
+            }
+        };
+        // K steps [S0, S1) of the tile's sequence.  Loads return in order: step S's operands have landed once at most the
+        // loads issued after them are outstanding -- QD steps' worth, plus the next window where it was requested in between
+        auto run = [&](auto S0C, auto S1C) {
+            constexpr int S0 = decltype(S0C)::value, S1 = decltype(S1C)::value;
+#pragma unroll
+            for (int f = 0; f < G::NFW; ++f) hi[f] = lo[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+            fetch_b(IntC<S0>{}, bbuf[S0 & 1]);
+            static_for<S0, S1>([&](auto SC) {
+                constexpr int S = decltype(SC)::value;
+                if constexpr (S == G::RAWK)
+                    convh_load_raw<IMG>(raw, mb.x + nb * ustride, p.T, nwin, tid, more && !(p.dbg & 1));
+                load_a(IntC<S + G::QD>{}, aq[(S + G::QD) % (G::QD + 1)]);
+                if constexpr (S + 1 < S1) fetch_b(IntC<S + 1>{}, bbuf[(S + 1) & 1]);
+                constexpr bool raw_after = G::RAWK > S - G::QD && G::RAWK <= S;     // requested after step S's loads were
+                // (a tile's first QD steps were waited for in the epilogue of the tile before)
+                if constexpr (S >= G::QD) wait_vm<G::NA * G::QD + (raw_after ? G::NRAW : 0)>();
+                __builtin_amdgcn_sched_barrier(0);
+                f16x8 (&a)[2] = aq[S % (G::QD + 1)];
+#pragma unroll
+                for (int e = 0; e < G::NFW; ++e)
+                    hi[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], bbuf[S & 1][e][0], hi[e], 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < G::NFW; ++e)
+                    lo[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], bbuf[S & 1][e][1], lo[e], 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < G::NFW; ++e)
+                    lo[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], bbuf[S & 1][e][0], lo[e], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+
+        pair_barrier();                                  // the window image is complete
+        run(IntC<0>{}, IntC<G::NSTEP>{});
+        {
+            // conv1 -> intermediate image: row r is time t0 - P2 + r; conv2's zero padding applies to the intermediate
+            const int tm = t0 - G::P2 + r0;              // time of the first new column
+            const bool inside = tm >= 0 && tm + G::NM <= p.T;
+            char* const mwr = mw + r0 * 16;
+            float lowm = 0.f;
+            const f32x2* const b2 = reinterpret_cast<const f32x2*>(bl + row0);
+            const f32x2* const s2 = reinterpret_cast<const f32x2*>(bl + 2 * G::C + row0);
+            const f32x2 b01 = b2[0], b23 = b2[1], s01 = s2[0], s23 = s2[1];
+#pragma unroll
+            for (int f = 0; f < G::NFW; ++f) {
+                const int t = tm + col0 + f * 16;
+                f16x4 h1, h2;
+                if (inside) split_mid4<false>(hi[f], lo[f], s01, s23, b01, b23, p.slope, true, h1, h2, lowm);
+                else split_mid4<true>(hi[f], lo[f], s01, s23, b01, b23, p.slope, t >= 0 && t < p.T, h1, h2, lowm);
+                *reinterpret_cast<f16x4*>(mwr + f * 256) = h1;
+                *reinterpret_cast<f16x4*>(mwr + f * 256 + G::MHALF) = h2;
+            }
+            low_note(low, 1, lowm);
+        }
+        pair_barrier();                                  // the intermediate is complete (and nobody reads the x image any more)
+        run(IntC<G::NSTEP>{}, IntC<G::NSEQ>{});
+        pair_barrier();                                  // every wave is done with the intermediate
+        if (nwarm) {
+            // the last KT - 1 valid columns -> the front of the image (convq_kernels.hpp)
+            constexpr int NC = 2 * G::CB * (G::KT - 1);
+            if (tid < NC) {
+                const int row = tid % (G::KT - 1), hb = tid / (G::KT - 1);
+                char* const base = mimg + (hb / G::CB) * G::MHALF + ((hb % G::CB) * G::MRP) * 16;
+                *reinterpret_cast<f16x8*>(base + row * 16) =
+                    *reinterpret_cast<const f16x8*>(base + (r0 + G::NM - (G::KT - 1) + row) * 16);
+            }
+        }
+        float res[G::NFW][4];
+        unsigned voff[G::NFW];
+        {
+            const __amdgpu_buffer_rsrc_t rr = make_rsrc(mb.x + b * ustride, ubytes);     // the residual is x itself
+#pragma unroll
+            for (int f = 0; f < G::NFW; ++f) {
+                const int col = col0 + f * 16, t = t0 + col;
+                voff[f] = col < n_out && t < c_end ? (unsigned)(row0 * p.T + t) * 4u : kOutOfRange;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) res[f][i] = buffer_load1s(rr, voff[f], (unsigned)i * t4);
+            }
+        }
+        pair_wait_vm0();                                 // the next window, the residual, the next tile's first A operands
+        const bool fin = mb.add1 != nullptr;
+        {
+            const f32x2* const b2 = reinterpret_cast<const f32x2*>(bl + G::C + row0);
+            const f32x2* const s2 = reinterpret_cast<const f32x2*>(bl + 3 * G::C + row0);
+            const f32x2 b01 = b2[0], b23 = b2[1], s01 = s2[0], s23 = s2[1];
+#pragma unroll
+            for (int f = 0; f < G::NFW; ++f) combine4(hi[f], lo[f], s01, s23, b01, b23, res[f]);
+        }
+        if (fin) {
+            const __amdgpu_buffer_rsrc_t r1 = make_rsrc(mb.add1 + b * ustride, ubytes);
+            const __amdgpu_buffer_rsrc_t r2 = make_rsrc(mb.add2 ? mb.add2 + b * ustride : mb.add1, mb.add2 ? ubytes : 0u);
+#pragma unroll
+            for (int f = 0; f < G::NFW; ++f)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    lo[f][i] = buffer_load1s(r1, voff[f], (unsigned)i * t4);
+                    res[f][i] = buffer_load1s(r2, voff[f], (unsigned)i * t4);
+                }
+            pair_wait_vm0();
+#pragma unroll
+            for (int f = 0; f < G::NFW; ++f)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hi[f][i] = (hi[f][i] + lo[f][i]) + res[f][i];
+        }
+#pragma unroll
+        for (int f = 0; f < G::NFW; ++f) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = hi[f][i];
+            const int col = col0 + f * 16;
+            range_note4p(bad2, hi[f]);
+            pair_store(p, mb.y, mb.y_act, G::C, b, row0, t0 + col, col < n_out && t0 + col < c_end && !(p.dbg & 8), v, fin, rcp);
+        }
+        if (more && !(p.dbg & 2)) convh_convert<IMG>(raw, ximg, p.slope, tid, low);
+        if (!more) break;
+        if (!cont) c_end = nb == b_last ? c_last : p.T;
+        b = nb;
+        tout = ntout;
+        warm = nwarm;
+    }
+    pair_wait_vm0();
+    range_flag(p, bad2.x + bad2.y);
+    low_flag(p, low, bl + 4 * G::C, wave, lane, 8);
+}
+
+// one 8-wave block per CU, 2 waves per SIMD
+template <int DIL, int C>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void convq2_kernel(PairParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    PairParams q;
+    q.n_members = p.n_members; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = p.out_div;
+    q.act_slope = p.act_slope; q.post = p.post; q.x_off = p.x_off; q.img_off = p.img_off; q.mid_off = p.mid_off;
+    q.bias_off = p.bias_off; q.dbg = p.dbg; q.trace = p.trace; q.guard = p.guard;
+    int n_items[3], cost[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { n_items[m] = p.m[m].n_items; cost[m] = p.m[m].cost; }
+    asm volatile("" ::"s"(q.n_members), "s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.out_div), "s"(q.act_slope),
+                 "s"(q.post), "s"(q.x_off), "s"(q.img_off), "s"(q.mid_off), "s"(q.bias_off), "s"(q.dbg), "s"(q.trace),
+                 "s"(n_items[0]), "s"(n_items[1]), "s"(n_items[2]), "s"(cost[0]), "s"(cost[1]), "s"(cost[2]), "s"(q.guard));
+    const bool sched = p.sched_on == 1, cut = p.sched_on == 2;
+    int slo[3] = {0, 0, 0}, shi[3] = {0, 0, 0};
+    int g_lo = 0, g_hi = 0;
+    if (cut) {
+        const int share = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+        g_lo = (int)p.sched[share];
+        g_hi = share + 1 < q.nblk ? (int)p.sched[share + 1] : n_items[0] + (q.n_members > 1 ? n_items[1] : 0) + (q.n_members > 2 ? n_items[2] : 0);
+        asm volatile("" ::"s"(g_lo), "s"(g_hi));
+    }
+    if (sched) {
+        const unsigned w0 = p.sched[2 * xcd_remap((int)blockIdx.x, (int)gridDim.x)], w1 = p.sched[2 * xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1];
+        slo[0] = (int)(w0 & 2047u);         shi[0] = slo[0] + (int)((w0 >> 11) & 31u);
+        slo[1] = (int)((w0 >> 16) & 2047u); shi[1] = slo[1] + (int)(w0 >> 27);
+        slo[2] = (int)(w1 & 2047u);         shi[2] = slo[2] + (int)((w1 >> 11) & 31u);
+        asm volatile("" ::"s"(slo[0]), "s"(shi[0]), "s"(slo[1]), "s"(shi[1]), "s"(slo[2]), "s"(shi[2]));
+    }
+    long long total = 0;
+    if (!sched && !cut) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) total += m < q.n_members ? (long long)n_items[m] * cost[m] : 0;
+    }
+    long long base = 0;
+    int off = 0;
+    bool first = true;
+    for (int m = 0; m < q.n_members; ++m) {
+        const int n = m == 0 ? n_items[0] : m == 1 ? n_items[1] : n_items[2];
+        const int cm = m == 0 ? cost[0] : m == 1 ? cost[1] : cost[2];
+        int lo, hi;
+        if (sched) {
+            lo = m == 0 ? slo[0] : m == 1 ? slo[1] : slo[2];
+            hi = m == 0 ? shi[0] : m == 1 ? shi[1] : shi[2];
+        } else if (cut) {
+            lo = min(max(g_lo - off, 0), n);
+            hi = min(max(g_hi - off, 0), n);
+            off += n;
+        } else {
+            lo = pair_share(xcd_remap((int)blockIdx.x, (int)gridDim.x), total, base, cm, n, q.nblk);
+            hi = pair_share(xcd_remap((int)blockIdx.x, (int)gridDim.x) + 1, total, base, cm, n, q.nblk);
+            base += (long long)n * cm;
+        }
+        if (lo >= hi) continue;
+        PairMember mb;
+        mb.x = p.m[m].x; mb.w1 = p.m[m].w1; mb.w2 = p.m[m].w2; mb.b1 = p.m[m].b1; mb.b2 = p.m[m].b2; mb.add1 = p.m[m].add1;
+        mb.add2 = p.m[m].add2; mb.y = p.m[m].y; mb.y_act = p.m[m].y_act; mb.k = p.m[m].k; mb.n_tiles = p.m[m].n_tiles;
+        asm volatile("" ::"s"(mb.x), "s"(mb.w1), "s"(mb.w2), "s"(mb.b1), "s"(mb.b2), "s"(mb.add1), "s"(mb.add2), "s"(mb.y),
+                     "s"(mb.y_act), "s"(mb.k), "s"(mb.n_tiles));
+        if (mb.k == 11) convq2_run_member<ConvQ2Run<11, DIL, C>>(q, mb, lo, hi, smem, wave, lane, first);
+        else if (mb.k == 7) convq2_run_member<ConvQ2Run<7, DIL, C>>(q, mb, lo, hi, smem, wave, lane, first);
+        else convq2_run_member<ConvQ2Run<3, DIL, C>>(q, mb, lo, hi, smem, wave, lane, first);
+        first = false;
+    }
+}
+
+}  // namespace fv
