@@ -470,8 +470,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // K steps [K0, K1): the A queue runs QD steps ahead (loads return in order: K step KS has landed once at most the
         // loads issued after it are outstanding -- QD steps' worth, plus the next tile's raw window where that was requested
         // in between: RAWK = first K step issued after it); B operands one step ahead, from the images
-        auto run = [&](auto K0C, auto K1C, auto RAWKC) {
-            constexpr int K0 = decltype(K0C)::value, K1 = decltype(K1C)::value, RAWK = decltype(RAWKC)::value;
+        auto run = [&](auto K0C, auto K1C) {
+            constexpr int K0 = decltype(K0C)::value, K1 = decltype(K1C)::value;
+            // the next tile's window is requested QD steps before the tile ends: no A operand of THIS tile is issued after it,
+            // so no count here waits for it (requested at the start of the second GEMM it had one to three K steps to land)
+            constexpr int RAWK = G::NK - G::QD;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -479,11 +482,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             fetch_b(IntC<K0>{}, bbuf[K0 & 1]);
             static_for<K0, K1>([&](auto KC) {
                 constexpr int KS = decltype(KC)::value;
+                if constexpr (KS == RAWK)
+                    convh_load_raw<G>(raw, p.x + nb * ustride, p.T, ntile * G::NM - G::P, tid, more, p.reflect != 0);
                 load_a(IntC<KS + G::QD>{}, aq[(KS + G::QD) % (G::QD + 1)]);
                 if constexpr (KS + 1 < K1) fetch_b(IntC<KS + 1>{}, bbuf[(KS + 1) & 1]);
-                // outstanding after K step KS's loads: steps KS + 1 .. KS + QD, and the raw window if it was requested after
-                // step KS's loads and before step KS + QD's (RAWK in (KS, KS + QD])
-                constexpr bool raw_after = RAWK > KS && RAWK <= KS + G::QD;
+                // outstanding after K step KS's loads: steps KS + 1 .. KS + QD, and the window if it was requested after them
+                constexpr bool raw_after = RAWK > KS - G::QD && RAWK <= KS;
                 // (a tile's first QD steps were waited for in the epilogue of the tile before, ahead of its stores: a count
                 // here would wait for those stores)
                 if constexpr (KS >= G::QD) wait_vm<G::NA * G::QD + (raw_after ? G::NRAW : 0)>();
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         };
 
         pair_barrier();                                  // the window image is complete
-        run(IntC<0>{}, IntC<G::NK1>{}, IntC<-1>{});
+        run(IntC<0>{}, IntC<G::NK1>{});
         {
             float lowm = 0.f;
 #pragma unroll
@@ -529,10 +533,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         pair_barrier();                                  // the hidden tile is complete, nobody reads the window image any more
         convk_convert_centre<G>(raw, ximg, tid);
-        // the next tile's window: requested after the loads of K steps NK1, NK1 + 1 (issued during conv1's last two steps)
-        convh_load_raw<G>(raw, p.x + nb * ustride, p.T, ntile * G::NM - G::P, tid, more, p.reflect != 0);
         pair_barrier();                                  // the raw centre's image is complete
-        run(IntC<G::NK1>{}, IntC<G::NK>{}, IntC<G::NK1 + G::QD>{});
+        run(IntC<G::NK1>{}, IntC<G::NK>{});
         pair_barrier();                                  // every wave is done with the hidden tile and the raw centre
         {
             const size_t boff = (size_t)b * ustride;
