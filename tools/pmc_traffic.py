@@ -30,7 +30,7 @@ def main():
     out = {"unit": "bytes per launch", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": {}}
     fam_bytes, fam_n = 0.0, 0
     split = {"16": [0.0, 0], "32": [0.0, 0]}          # fv::pairh_kernel<MH = 1 | 2, ...>: C = 16 | 32
-    wide = [0.0, 0]                                   # fv::convh_kernel / convp_kernel / convq_kernel: the 128- / 64-channel stages
+    wide = [0.0, 0]                                   # fv::convh_kernel / convp_kernel / convq_kernel / convq2_kernel: the 128- / 64-channel stages
     for k in sorted(fetch, key=lambda k: -fetch[k]):
         if k not in write or "fv::" not in k:
             continue
@@ -41,7 +41,7 @@ def main():
                                 "pair_sum_kernel")):
             fam_bytes += (fb + wb) * nf[k]
             fam_n += nf[k]
-        if "convh_kernel<" in k or "convp_kernel<" in k or "convq_kernel<" in k:
+        if "convh_kernel<" in k or "convp_kernel<" in k or "convq_kernel<" in k or "convq2_kernel<" in k:
             wide[0] += (fb + wb) * nf[k]
             wide[1] += nf[k]
         if "pairh_kernel<" in k:

@@ -26,7 +26,7 @@ with open(f"{dst}/{tag}_mfma_counters.txt", "w") as f:
     f.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY\n"
             "#   SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace -- python bench.py --steps 5 --warmup 2\n"
             "# MI355X, HiFi-GAN light B=1 T=1000; per-dispatch averages; GRBM_GUI_ACTIVE is summed over the 8 XCDs\n")
-    fams = {"split-f16 convs with streamed weights (convh_kernel, convp_kernel, convq_kernel)": ("convh_kernel", "convp_kernel", "convq_kernel"), "split-f16 fused pairs (pairh_kernel)": ("pairh_kernel",),
+    fams = {"split-f16 convs with streamed weights (convh_kernel, convp_kernel, convq_kernel, convq2_kernel)": ("convh_kernel", "convp_kernel", "convq_kernel", "convq2_kernel"), "split-f16 fused pairs (pairh_kernel)": ("pairh_kernel",),
             "split-f16 transposed convs (convt_kernel)": ("convt_kernel",),
             "fp32-MFMA convs (conv_mfma_kernel + conv_group3_kernel + conv_sum3_kernel + pair_kernel + pair_sum_kernel)":
                 ("conv_mfma_kernel", "conv_group3_kernel", "conv_sum3_kernel", "fv::pair_kernel", "pair_sum_kernel")}
