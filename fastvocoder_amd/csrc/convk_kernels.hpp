@@ -376,7 +376,6 @@ template <int DIL, int NM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void convk2_kernel(ConvKParams p) {
     typedef ConvK2Geom<DIL, NM> G;
     typedef __attribute__((address_space(3))) const f16x8 LdsH8;
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     int lane = tid & 63;
