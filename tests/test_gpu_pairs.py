@@ -537,7 +537,9 @@ def test_pairs_without_the_weight_ring_give_the_same_bits(tuning):
     so identical bits, on full and three-block grids (long runs of warm tiles), two utterances, every tap count, with the MRF sum."""
     rng = np.random.RandomState(123)
     ks = (11, 3, 7)
-    for C, T, dil in ((128, 520, 1), (128, 1100, 5), (64, 1030, 3), (64, 300, 5)):
+    # (the last four: shorter than a tile / than the halo, exactly one cold tile, one column into the first warm tile)
+    for C, T, dil in ((128, 520, 1), (128, 1100, 5), (64, 1030, 3), (64, 300, 5), (128, 5, 5), (128, 54, 3), (128, 55, 1),
+                      (64, 7, 3)):
         ms = [_member(rng, 2, C, T, k, True) for k in ks]
         xs = [_t(m[0]) for m in ms]
         h1, h2 = [_native.pack_pair(_t(m[1]), SPLIT) for m in ms], [_native.pack_pair(_t(m[3]), SPLIT) for m in ms]
