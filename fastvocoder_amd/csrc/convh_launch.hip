@@ -347,13 +347,20 @@ extern template int launch_convq2_dil<5, 128>(const PairParams&, size_t, hipStre
 extern template int launch_convq2_dil<1, 64>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convq2_dil<3, 64>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convq2_dil<5, 64>(const PairParams&, size_t, hipStream_t);
+extern template int launch_convq2_dil<1, 65>(const PairParams&, size_t, hipStream_t);      // 65: 64 channels on 256-column tiles
+extern template int launch_convq2_dil<3, 65>(const PairParams&, size_t, hipStream_t);
+extern template int launch_convq2_dil<5, 65>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convp_dil<1>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convp_dil<3>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convp_dil<5>(const PairParams&, size_t, hipStream_t);
 
 // everything launch_convp does in front of the launch: validation, member order, tile counts, LDS layout, block schedule
-static int prepare_convp(PairParams& p, int dil, size_t& lds_out, double& flops, double& bytes, bool noring = false) {
+// (form: 0 convp_kernel -- the LDS weight ring; 1 convq2_kernel<DIL, 64> -- no ring, 128-column tiles; 2 convq2_kernel<DIL, 65>
+// -- no ring, 256-column tiles)
+static int prepare_convp(PairParams& p, int dil, size_t& lds_out, double& flops, double& bytes, int form = 0) {
     const int C = 64;
+    const bool noring = form != 0;
+    const int NMc = form == 2 ? 256 : 128;           // intermediate columns per tile
     if (dil != 1 && dil != 3 && dil != 5) return fail(FV_ERR_UNSUPPORTED, "resblock pair: dilation %d (1, 3 or 5)", dil);
     if (p.n_members < 1 || p.n_members > 3) return fail(FV_ERR_INVALID_ARG, "resblock pair: %d members", p.n_members);
     if ((double)C * p.T * 4.0 >= 1073741824.0)
@@ -377,11 +384,13 @@ static int prepare_convp(PairParams& p, int dil, size_t& lds_out, double& flops,
         mb.flag_off = -1;
         for (auto& d : mb.dep) d = {-1, 1, 0, 0};
         const ConvHShape g = convh_shape(C, mb.k, dil);
-        const int nout = g.NTC - (mb.k - 1);
+        const int nout = NMc - (mb.k - 1);
         mb.n_tiles = (p.T + nout - 1) / nout;
         mb.n_items = mb.n_tiles * p.B;
         mb.cost = 2 * g.NST + tuning().convp_skel;
-        if (g.XIMG > img_bytes) img_bytes = g.XIMG;
+        const int xrows = (NMc + (mb.k - 1) * dil + 3) / 4 * 4;
+        const int ximg = form == 2 ? 2 * (C / 8) * ((xrows + 15) / 16 * 16) * 16 : g.XIMG;
+        if (ximg > img_bytes) img_bytes = ximg;
         items += mb.n_items;
         flops += 2.0 * 2.0 * p.B * (double)C * C * mb.k * p.T;
         bytes += 4.0 * (2.0 * C * C * mb.k + (double)p.B * C * p.T * ((mb.y_act ? 3 : 2) + (mb.add1 ? 1 : 0) + (mb.add2 ? 1 : 0)));
@@ -392,7 +401,7 @@ static int prepare_convp(PairParams& p, int dil, size_t& lds_out, double& flops,
     p.img_off = (int)floats;
     floats += (size_t)img_bytes / 4;
     p.mid_off = (int)floats;
-    floats += (size_t)4 * C * (128 + 16) / 4;
+    floats += (size_t)4 * C * (NMc + 16) / 4;
     p.bias_off = (int)floats;
     floats += 4 * (size_t)C + 16;      // [b1 | b2 | inverse row prescales of conv1 | conv2 | scratch of the low-range guard]
     const size_t lds = floats * 4;
@@ -402,7 +411,7 @@ static int prepare_convp(PairParams& p, int dil, size_t& lds_out, double& flops,
     p.nblk = (int)nblk;
     pair_schedule(p, p.nblk);
     if (!p.sched_on) {                 // no per-block schedule: the kernels' contiguous cut, as a table instead of arithmetic
-        warm_run_costs(p, items, 128);
+        warm_run_costs(p, items, NMc);
         long long n[3] = {0, 0, 0};
         for (int i = 0; i < p.n_members; ++i) n[i] = p.m[i].n_items;
         pair_cut_schedule(p, p.nblk, n);
@@ -419,11 +428,15 @@ int launch_convp(PairParams p, int dil, hipStream_t s) {
     double flops, bytes;
     // convq2_kernels.hpp at 64 channels (A operands from L2 into registers, no ring) measured the same as convp_kernel at batch
     // 1 (55.2 vs 54.4-56.2 us per three-member launch) and at 8 x 128 000 columns (1162 vs 1163 us): the ring form stays
-    const bool noring = tuning().convp2 != 0;
-    if (int rc = prepare_convp(p, dil, lds, flops, bytes, noring)) return rc;
+    // ... and on 256-column tiles (32 x 64 wave tiles) from Tuning::convp_wide tenths of such a tile per CU up
+    long long wide_items = 0;
+    for (int i = 0; i < p.n_members; ++i) wide_items += (long long)p.B * ((p.T + 256 - p.m[i].k) / (257 - p.m[i].k));
+    const int form = wide_items * 10 >= (long long)tuning().convp_wide * device_cu_count() ? 2 : tuning().convp2 != 0 ? 1 : 0;
+    if (int rc = prepare_convp(p, dil, lds, flops, bytes, form)) return rc;
     profile_begin(s);
-    const int rc = noring ? (dil == 1 ? launch_convq2_dil<1, 64>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, 64>(p, lds, s) : launch_convq2_dil<5, 64>(p, lds, s))
-                          : (dil == 1 ? launch_convp_dil<1>(p, lds, s) : dil == 3 ? launch_convp_dil<3>(p, lds, s) : launch_convp_dil<5>(p, lds, s));
+    const int rc = form == 2 ? (dil == 1 ? launch_convq2_dil<1, 65>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, 65>(p, lds, s) : launch_convq2_dil<5, 65>(p, lds, s))
+                 : form == 1 ? (dil == 1 ? launch_convq2_dil<1, 64>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, 64>(p, lds, s) : launch_convq2_dil<5, 64>(p, lds, s))
+                             : (dil == 1 ? launch_convp_dil<1>(p, lds, s) : dil == 3 ? launch_convp_dil<3>(p, lds, s) : launch_convp_dil<5>(p, lds, s));
     profile_end(s, FV_KERNEL_CONVH64, flops, bytes);
     return rc;
 }

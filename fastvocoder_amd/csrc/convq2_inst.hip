@@ -14,4 +14,7 @@ template int launch_convq2_dil<5, 128>(const PairParams&, size_t, hipStream_t);
 template int launch_convq2_dil<1, 64>(const PairParams&, size_t, hipStream_t);
 template int launch_convq2_dil<3, 64>(const PairParams&, size_t, hipStream_t);
 template int launch_convq2_dil<5, 64>(const PairParams&, size_t, hipStream_t);
+template int launch_convq2_dil<1, 65>(const PairParams&, size_t, hipStream_t);
+template int launch_convq2_dil<3, 65>(const PairParams&, size_t, hipStream_t);
+template int launch_convq2_dil<5, 65>(const PairParams&, size_t, hipStream_t);
 }  // namespace fv

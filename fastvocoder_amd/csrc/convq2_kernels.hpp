@@ -33,17 +33,45 @@ struct ConvQ2Geom<KT_, DIL_, 64> : ConvPGeom<KT_, DIL_> {
     static constexpr int NSTEP = IMG::NSTEP, XRP = IMG::XRP, XHALF = IMG::XHALF, WTILE = IMG::WTILE, NRAW = IMG::NRAW;
     static constexpr int WBYTES = IMG::WTILE;
 };
+// C_ = 65 (a tag, not a channel count): 64 channels on 256-column tiles -- 8 waves = 2 row slabs of 32 x 4 column groups of
+// 64 (a 32 x 64 wave tile: 24 MFMAs per K step for 8 B reads and 4 A loads; the LDS operand traffic per MFMA of the 32 x 32
+// tile halved, k - 1 of 256 intermediate columns recomputed by a cold tile instead of k - 1 of 128).  Without a ring the
+// two images fit: (256 + 50) x 64 channels = 80 KB + 70 KB.  For launches with tiles to spare (the launcher decides).
+template <int KT_, int DIL_>
+struct ConvWideImg {                                     // window loader / converter geometry of the 256-column tile
+    static constexpr int C = 64, CB = 8, NT = 512;
+    static constexpr int XROWS = (256 + (KT_ - 1) * DIL_ + 3) / 4 * 4;
+    static constexpr int XRP = (XROWS + 15) / 16 * 16;
+    static constexpr int XHALF = CB * XRP * 16;
+    static constexpr int XR = (XROWS * CB + NT - 1) / NT;
+    static constexpr int NRAW = XR * 8;
+};
+template <int KT_, int DIL_>
+struct ConvQ2Geom<KT_, DIL_, 65> {
+    typedef ConvWideImg<KT_, DIL_> IMG;
+    static constexpr int KT = KT_, DIL = DIL_, C = 64, CG = 2, CB = 8, NT = 512, WN = 4;
+    static constexpr int NM = 256, NOUT = NM - (KT - 1);
+    static constexpr int P1 = (KT - 1) * DIL / 2, P2 = (KT - 1) / 2;
+    static constexpr int NSTEP = KT * CG;
+    static constexpr int XRP = IMG::XRP, XHALF = IMG::XHALF, NRAW = IMG::NRAW;
+    static constexpr int MRP = NM + 16, MHALF = CB * MRP * 16;
+    static constexpr int WTILE = NSTEP * 8192, WBYTES = WTILE;
+    static_assert(((CG - 1) * 4 * XRP + (KT - 1) * DIL + 16 * 3) * 16 + 16 < 65536, "ds_read immediate range");
+};
 template <int KT_, int DIL_, int C_>
 struct ConvQ2Run : ConvQ2Geom<KT_, DIL_, C_> {
     typedef ConvQ2Geom<KT_, DIL_, C_> B;
     static constexpr int NFW = 4;                        // fragments per wave: 64 columns
-    static constexpr int QD = 3;                         // A operands this many K steps ahead (queue of QD + 1 slots)
-    static constexpr int NA = 2;                         // loads per wave and K step
+    static constexpr int NH = C_ == 65 ? 2 : 1;          // row sixteenths per wave
+    static constexpr int NSLAB = B::C / (16 * NH);       // row slabs = waves per column group
+    static constexpr int QD = C_ == 65 ? 1 : 3;          // A operands this many K steps ahead (queue of QD + 1 slots; a K step of
+                                                         // the 32 x 64 tile is 768 matrix cycles per SIMD: one ahead is enough)
+    static constexpr int NA = 2 * NH;                    // loads per wave and K step
     static constexpr int NSEQ = 2 * B::NSTEP;            // K steps per tile: conv1's, then conv2's
     static constexpr int RAWK = NSEQ - QD;               // K step at which the next tile's window is requested: no A operand of
                                                          // THIS tile is issued after it, so nothing here waits for it
     static_assert(NSEQ % (QD + 1) == 0, "the A queue runs on from tile to tile: slot = K step % (QD + 1)");
-    static_assert(B::NM == 64 * B::WN, "column groups of 64");
+    static_assert(B::NM == 64 * B::WN && NSLAB * B::WN == 8, "8 waves: row slabs x column groups of 64");
 };
 
 template <class G>
@@ -57,13 +85,13 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
     char* const mimg = reinterpret_cast<char*>(smem + p.mid_off);
     float* const bl = smem + p.bias_off;                 // [b1[128] | b2[128] | inverse row prescales 1 | 2 | guard scratch]
     const int n = lane & 15, kb = lane >> 4;
-    const int ws = G::WN == 1 ? wave : wave & 3;         // row slab of 16 = row sixteenth ws
-    const int col0 = (G::WN == 1 ? 0 : (wave >> 2) * 64) + n;
+    const int ws = wave % G::NSLAB;                      // row slab of 16 NH rows: sixteenths NH ws ...
+    const int col0 = (wave / G::NSLAB) * 64 + n;
     const char* const bptr = ximg + (kb * G::XRP + col0) * 16;
     const char* const mptr = mimg + (kb * G::MRP + col0) * 16;
-    const int row0 = 16 * ws + 4 * kb;                   // + i
-    // D fragment -> intermediate image: channels row0 + i = half of the 8-channel block 2 ws + (kb >> 1)
-    char* const mw = mimg + ((2 * ws + (kb >> 1)) * G::MRP + col0) * 16 + 8 * (kb & 1);
+    const int row0 = 16 * G::NH * ws + 4 * kb;           // + 16 h + i
+    // D fragment -> intermediate image: channels row0 + 16 h + i = half of the 8-channel block 2 (NH ws + h) + (kb >> 1)
+    char* const mw = mimg + ((2 * G::NH * ws + (kb >> 1)) * G::MRP + col0) * 16 + 8 * (kb & 1);
 
     const size_t ustride = (size_t)G::C * (size_t)p.T;
     const unsigned ubytes = (unsigned)G::C * (unsigned)p.T * 4u;
@@ -71,15 +99,18 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
     const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(mb.w1, (unsigned)G::WBYTES);
     const __amdgpu_buffer_rsrc_t rw2 = make_rsrc(mb.w2, (unsigned)G::WBYTES);
     // packed image (fv_pack_pair_weight_ex): [64-row tile][K step][row sixteenth 4][split half][lane][8 halves]
-    const unsigned aoff = (unsigned)((ws >> 2) * G::WTILE + (ws & 3) * 2048 + lane * 16);       // (64 channels: one row tile)
+    const int s16 = G::NH * ws;                          // first row sixteenth of this wave (64 channels: one row tile)
+    const unsigned aoff = (unsigned)((s16 >> 2) * G::WTILE + (s16 & 3) * 2048 + lane * 16);
     // A operands of K step S of the tile's sequence (compile time; beyond the tile: the next tile's): [split half]
-    auto load_a = [&](auto SC, f16x8 (&dst)[2]) {
+    auto load_a = [&](auto SC, f16x8 (&dst)[G::NH][2]) {
         constexpr int S = decltype(SC)::value % G::NSEQ;
         constexpr int step = S % G::NSTEP;
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
-            dst[e] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(S < G::NSTEP ? rw1 : rw2, (int)aoff,
-                                                                                     step * 8192 + e * 1024, 0));
+        for (int h = 0; h < G::NH; ++h)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                dst[h][e] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                    S < G::NSTEP ? rw1 : rw2, (int)aoff, step * 8192 + h * 2048 + e * 1024, 0));
     };
     const int b_last = (hi_item - 1) / mb.n_tiles;
     const int c_last = min(((hi_item - 1) - b_last * mb.n_tiles + 1) * G::NOUT, p.T);     // end of the run in the last utterance
@@ -94,7 +125,7 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
     typedef typename G::IMG IMG;
     ConvHRaw<IMG> raw;
     convh_load_raw<IMG>(raw, mb.x + b * ustride, p.T, tout - G::P1 - G::P2, tid, true);
-    f16x8 aq[G::QD + 1][2];                              // K step S sits in aq[S % (QD + 1)]
+    f16x8 aq[G::QD + 1][G::NH][2];                       // K step S sits in aq[S % (QD + 1)]
     static_for<0, G::QD>([&](auto QC) { load_a(QC, aq[decltype(QC)::value]); });
     if (tid < G::C) {
         bl[tid] = mb.b1 ? mb.b1[tid] : 0.f;
@@ -117,7 +148,7 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
         const int nb = cont ? b : b + 1;
         const int ntout = cont ? t0 + n_out : 0;
         const int nwin = ntout - G::P2 - G::P1 + (nwarm ? G::KT - 1 : 0);
-        f32x4 hi[G::NFW], lo[G::NFW];
+        f32x4 hi[G::NH][G::NFW], lo[G::NH][G::NFW];
         f16x8 bbuf[2][G::NFW][2];
 
         LdsCF* const bb = lds_opaque(reinterpret_cast<const float*>(bptr));
@@ -146,7 +177,9 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
         auto run = [&](auto S0C, auto S1C) {
             constexpr int S0 = decltype(S0C)::value, S1 = decltype(S1C)::value;
 #pragma unroll
-            for (int f = 0; f < G::NFW; ++f) hi[f] = lo[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int h = 0; h < G::NH; ++h)
+#pragma unroll
+                for (int f = 0; f < G::NFW; ++f) hi[h][f] = lo[h][f] = f32x4{0.f, 0.f, 0.f, 0.f};
             fetch_b(IntC<S0>{}, bbuf[S0 & 1]);
             static_for<S0, S1>([&](auto SC) {
                 constexpr int S = decltype(SC)::value;
@@ -158,16 +191,22 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
                 // (a tile's first QD steps were waited for in the epilogue of the tile before)
                 if constexpr (S >= G::QD) wait_vm<G::NA * G::QD + (raw_after ? G::NRAW : 0)>();
                 __builtin_amdgcn_sched_barrier(0);
-                f16x8 (&a)[2] = aq[S % (G::QD + 1)];
+                f16x8 (&a)[G::NH][2] = aq[S % (G::QD + 1)];
 #pragma unroll
-                for (int e = 0; e < G::NFW; ++e)
-                    hi[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], bbuf[S & 1][e][0], hi[e], 0, 0, 0);
+                for (int h = 0; h < G::NH; ++h)
 #pragma unroll
-                for (int e = 0; e < G::NFW; ++e)
-                    lo[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], bbuf[S & 1][e][1], lo[e], 0, 0, 0);
+                    for (int e = 0; e < G::NFW; ++e)
+                        hi[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[h][0], bbuf[S & 1][e][0], hi[h][e], 0, 0, 0);
 #pragma unroll
-                for (int e = 0; e < G::NFW; ++e)
-                    lo[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], bbuf[S & 1][e][0], lo[e], 0, 0, 0);
+                for (int h = 0; h < G::NH; ++h)
+#pragma unroll
+                    for (int e = 0; e < G::NFW; ++e)
+                        lo[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[h][0], bbuf[S & 1][e][1], lo[h][e], 0, 0, 0);
+#pragma unroll
+                for (int h = 0; h < G::NH; ++h)
+#pragma unroll
+                    for (int e = 0; e < G::NFW; ++e)
+                        lo[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[h][1], bbuf[S & 1][e][0], lo[h][e], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
@@ -180,17 +219,20 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
             const bool inside = tm >= 0 && tm + G::NM <= p.T;
             char* const mwr = mw + r0 * 16;
             float lowm = 0.f;
-            const f32x2* const b2 = reinterpret_cast<const f32x2*>(bl + row0);
-            const f32x2* const s2 = reinterpret_cast<const f32x2*>(bl + 2 * G::C + row0);
-            const f32x2 b01 = b2[0], b23 = b2[1], s01 = s2[0], s23 = s2[1];
 #pragma unroll
-            for (int f = 0; f < G::NFW; ++f) {
-                const int t = tm + col0 + f * 16;
-                f16x4 h1, h2;
-                if (inside) split_mid4<false>(hi[f], lo[f], s01, s23, b01, b23, p.slope, true, h1, h2, lowm);
-                else split_mid4<true>(hi[f], lo[f], s01, s23, b01, b23, p.slope, t >= 0 && t < p.T, h1, h2, lowm);
-                *reinterpret_cast<f16x4*>(mwr + f * 256) = h1;
-                *reinterpret_cast<f16x4*>(mwr + f * 256 + G::MHALF) = h2;
+            for (int h = 0; h < G::NH; ++h) {
+                const f32x2* const b2 = reinterpret_cast<const f32x2*>(bl + row0 + 16 * h);
+                const f32x2* const s2 = reinterpret_cast<const f32x2*>(bl + 2 * G::C + row0 + 16 * h);
+                const f32x2 b01 = b2[0], b23 = b2[1], s01 = s2[0], s23 = s2[1];
+#pragma unroll
+                for (int f = 0; f < G::NFW; ++f) {
+                    const int t = tm + col0 + f * 16;
+                    f16x4 h1, h2;
+                    if (inside) split_mid4<false>(hi[h][f], lo[h][f], s01, s23, b01, b23, p.slope, true, h1, h2, lowm);
+                    else split_mid4<true>(hi[h][f], lo[h][f], s01, s23, b01, b23, p.slope, t >= 0 && t < p.T, h1, h2, lowm);
+                    *reinterpret_cast<f16x4*>(mwr + f * 256 + h * (2 * G::MRP * 16)) = h1;
+                    *reinterpret_cast<f16x4*>(mwr + f * 256 + h * (2 * G::MRP * 16) + G::MHALF) = h2;
+                }
             }
             low_note(low, 1, lowm);
         }
@@ -207,7 +249,7 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
                     *reinterpret_cast<const f16x8*>(base + (r0 + G::NM - (G::KT - 1) + row) * 16);
             }
         }
-        float res[G::NFW][4];
+        float res[G::NH][G::NFW][4];
         unsigned voff[G::NFW];
         {
             const __amdgpu_buffer_rsrc_t rr = make_rsrc(mb.x + b * ustride, ubytes);     // the residual is x itself
@@ -216,43 +258,53 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
                 const int col = col0 + f * 16, t = t0 + col;
                 voff[f] = col < n_out && t < c_end ? (unsigned)(row0 * p.T + t) * 4u : kOutOfRange;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) res[f][i] = buffer_load1s(rr, voff[f], (unsigned)i * t4);
+                for (int h = 0; h < G::NH; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) res[h][f][i] = buffer_load1s(rr, voff[f], (unsigned)(16 * h + i) * t4);
             }
         }
         pair_wait_vm0();                                 // the next window, the residual, the next tile's first A operands
         const bool fin = mb.add1 != nullptr;
-        {
-            const f32x2* const b2 = reinterpret_cast<const f32x2*>(bl + G::C + row0);
-            const f32x2* const s2 = reinterpret_cast<const f32x2*>(bl + 3 * G::C + row0);
+#pragma unroll
+        for (int h = 0; h < G::NH; ++h) {
+            const f32x2* const b2 = reinterpret_cast<const f32x2*>(bl + G::C + row0 + 16 * h);
+            const f32x2* const s2 = reinterpret_cast<const f32x2*>(bl + 3 * G::C + row0 + 16 * h);
             const f32x2 b01 = b2[0], b23 = b2[1], s01 = s2[0], s23 = s2[1];
 #pragma unroll
-            for (int f = 0; f < G::NFW; ++f) combine4(hi[f], lo[f], s01, s23, b01, b23, res[f]);
+            for (int f = 0; f < G::NFW; ++f) combine4(hi[h][f], lo[h][f], s01, s23, b01, b23, res[h][f]);
         }
         if (fin) {
             const __amdgpu_buffer_rsrc_t r1 = make_rsrc(mb.add1 + b * ustride, ubytes);
             const __amdgpu_buffer_rsrc_t r2 = make_rsrc(mb.add2 ? mb.add2 + b * ustride : mb.add1, mb.add2 ? ubytes : 0u);
 #pragma unroll
-            for (int f = 0; f < G::NFW; ++f)
+            for (int h = 0; h < G::NH; ++h)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    lo[f][i] = buffer_load1s(r1, voff[f], (unsigned)i * t4);
-                    res[f][i] = buffer_load1s(r2, voff[f], (unsigned)i * t4);
-                }
+                for (int f = 0; f < G::NFW; ++f)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        lo[h][f][i] = buffer_load1s(r1, voff[f], (unsigned)(16 * h + i) * t4);
+                        res[h][f][i] = buffer_load1s(r2, voff[f], (unsigned)(16 * h + i) * t4);
+                    }
             pair_wait_vm0();
 #pragma unroll
-            for (int f = 0; f < G::NFW; ++f)
+            for (int h = 0; h < G::NH; ++h)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) hi[f][i] = (hi[f][i] + lo[f][i]) + res[f][i];
+                for (int f = 0; f < G::NFW; ++f)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hi[h][f][i] = (hi[h][f][i] + lo[h][f][i]) + res[h][f][i];
         }
 #pragma unroll
-        for (int f = 0; f < G::NFW; ++f) {
-            float v[4];
+        for (int h = 0; h < G::NH; ++h)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = hi[f][i];
-            const int col = col0 + f * 16;
-            range_note4p(bad2, hi[f]);
-            pair_store(p, mb.y, mb.y_act, G::C, b, row0, t0 + col, col < n_out && t0 + col < c_end && !(p.dbg & 8), v, fin, rcp);
-        }
+            for (int f = 0; f < G::NFW; ++f) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = hi[h][f][i];
+                const int col = col0 + f * 16;
+                range_note4p(bad2, hi[h][f]);
+                pair_store(p, mb.y, mb.y_act, G::C, b, row0 + 16 * h, t0 + col, col < n_out && t0 + col < c_end && !(p.dbg & 8), v, fin,
+                           rcp);
+            }
         if (more && !(p.dbg & 2)) convh_convert<IMG>(raw, ximg, p.slope, tid, low);
         if (!more) break;
         if (!cont) c_end = nb == b_last ? c_last : p.T;
@@ -266,6 +318,7 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
 }
 
 // one 8-wave block per CU, 2 waves per SIMD
+// C: 128, 64, or the tag 65 (64 channels on 256-column tiles)
 template <int DIL, int C>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void convq2_kernel(PairParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
