@@ -150,7 +150,9 @@ struct Tuning {
     int convq2 = 1;              // fused 128-channel pairs: 1 convq2_kernel (A operands from L2 into registers, no ring), 0 convq_kernel
     int convp_wide = 20;         // fused 64-channel pairs: 256-column tiles per CU (in tenths) from which the wide no-ring form runs
     int convp2 = 0;              // ... 64-channel pairs: 1 the same kernel at 64 channels, 0 convp_kernel (measured equal: convh_launch.hip)
-    int stack_wide = 20;         // residual stacks of 256 channels: tiles of 64 columns per CU (in tenths) from which the wide tile runs
+    int stack_wide = 10;         // residual stacks of 256 channels: tiles of 64 columns per CU (in tenths) from which the wide tile runs
+                                 // (Basis-MelGAN, 1000 frames: batch 1 -- 250 such tiles in its second stage -- 0.238 narrow / 0.248 wide,
+                                 // batch 2 0.384 / 0.359, batch 3 0.624 / 0.534)
     int stack_items = 1 << 20;   // residual stacks of 256 channels: tiles per CU (in tenths) up to which the one-launch kernel runs
                                  // (api.hip stack_two_launch; measured: it wins at every size -- 0 forces the two launches, A/B)
     int convg_rows64 = -1;    // the two-source 1x1 conv on 64-row tiles (1: convg_kernel) or 128-row ones (0: convr_kernel); -1: by size

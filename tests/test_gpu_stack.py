@@ -58,7 +58,7 @@ def _run(x, w1, b1, w2, b2, ws, bs, dil, slope, pad_mode, **kw):
 
 @pytest.fixture
 def tuning():
-    defaults = {"convh_blocks": 0, "convg_rows64": -1, "convh_rows64": -1, "stack_items": 1 << 20, "stack_wide": 20}
+    defaults = {"convh_blocks": 0, "convg_rows64": -1, "convh_rows64": -1, "stack_items": 1 << 20, "stack_wide": 10}
     yield _native.tuning_set
     for k, v in defaults.items():
         _native.tuning_set(k, v)
@@ -123,7 +123,7 @@ def test_residual_stack_vs_oracle(case, tuning):
                 tuning("convh_blocks", blocks)
                 assert torch.equal(_run(*m, dil, 0.2, nmode), y)
         tuning("convh_blocks", 0)
-        tuning("stack_wide", 20)
+        tuning("stack_wide", 10)
 
 
 @pytest.mark.parametrize("case", [(1, 128, 1600, 1), (2, 128, 300, 3), (1, 128, 203, 9), (1, 128, 12, 9),
@@ -138,7 +138,7 @@ def test_residual_stack_is_the_two_launch_form_bit_for_bit(case, tuning):
     fused = _run(x, w1, b1, w2, b2, ws, bs, dil, 0.2, _native.PAD_REFLECT)
     tuning("stack_wide", 0)                  # (256 channels: the 64-column tile; elsewhere no effect)
     wide = _run(x, w1, b1, w2, b2, ws, bs, dil, 0.2, _native.PAD_REFLECT)
-    tuning("stack_wide", 20)
+    tuning("stack_wide", 10)
     assert torch.equal(wide, fused)
     hid = _native.conv1d_split_f16([_t(x)], [_native.pack_pair(_t(w1), SPLIT)], [_t(b1)], [3], dil, pre_slope=0.2,
                                    pad_mode=_native.PAD_REFLECT)[0]
