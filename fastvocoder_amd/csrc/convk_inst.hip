@@ -72,29 +72,17 @@ int launch_pack_convk(const float* w1, const float* w2, const float* ws, float* 
     return 0;
 }
 
-template <int CG, int DIL>
-static int launch_one(const ConvKParams& p, hipStream_t s) {
-    typedef ConvKGeom<CG, DIL> G;
-    if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(convk_kernel<CG, DIL>), (size_t)G::LDS_BYTES)) return rc;
-    hipLaunchKernelGGL((convk_kernel<CG, DIL>), dim3(p.nblk), dim3(512), (size_t)G::LDS_BYTES, s, p);
+template <int C, int DIL, int NM>
+static int launch_k2(const ConvKParams& p, hipStream_t s) {
+    typedef ConvK2Geom<C, DIL, NM> G;
+    if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(convk2_kernel<C, DIL, NM>), (size_t)G::LDS_BYTES)) return rc;
+    hipLaunchKernelGGL((convk2_kernel<C, DIL, NM>), dim3(p.nblk), dim3(512), (size_t)G::LDS_BYTES, s, p);
     FV_HIP(hipGetLastError());
     return 0;
 }
-template <int DIL, int NM>
-static int launch_256(const ConvKParams& p, hipStream_t s) {
-    typedef ConvK2Geom<DIL, NM> G;
-    if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(convk2_kernel<DIL, NM>), (size_t)G::LDS_BYTES)) return rc;
-    hipLaunchKernelGGL((convk2_kernel<DIL, NM>), dim3(p.nblk), dim3(512), (size_t)G::LDS_BYTES, s, p);
-    FV_HIP(hipGetLastError());
-    return 0;
-}
-template <int NM>
-static int launch_256_dil(const ConvKParams& p, int dil, hipStream_t s) {
-    return dil == 1 ? launch_256<1, NM>(p, s) : dil == 3 ? launch_256<3, NM>(p, s) : launch_256<9, NM>(p, s);
-}
-template <int CG>
-static int launch_cg(const ConvKParams& p, int dil, hipStream_t s) {
-    return dil == 1 ? launch_one<CG, 1>(p, s) : dil == 3 ? launch_one<CG, 3>(p, s) : launch_one<CG, 9>(p, s);
+template <int C, int NM>
+static int launch_k2_dil(const ConvKParams& p, int dil, hipStream_t s) {
+    return dil == 1 ? launch_k2<C, 1, NM>(p, s) : dil == 3 ? launch_k2<C, 3, NM>(p, s) : launch_k2<C, 9, NM>(p, s);
 }
 
 int launch_convk(const PairParams& pp, int C, int dil, hipStream_t s) {
@@ -137,8 +125,8 @@ int launch_convk(const PairParams& pp, int C, int dil, hipStream_t s) {
     p.reflect = pp.reflect;
     p.guard = pp.guard;
     profile_begin(s);
-    const int rc = C == 32 ? launch_cg<1>(p, dil, s) : C == 64 ? launch_cg<2>(p, dil, s) : C == 128 ? launch_cg<4>(p, dil, s)
-                 : wide ? launch_256_dil<64>(p, dil, s) : launch_256_dil<32>(p, dil, s);
+    const int rc = C == 256 ? (wide ? launch_k2_dil<256, 64>(p, dil, s) : launch_k2_dil<256, 32>(p, dil, s))
+                 : C == 32 ? launch_k2_dil<32, 256>(p, dil, s) : C == 64 ? launch_k2_dil<64, 128>(p, dil, s) : launch_k2_dil<128, 64>(p, dil, s);
     // conv1 (3 taps) + the two 1x1 convs; x in, y (and its twin) out, the weights once
     profile_end(s, FV_KERNEL_STACK, 2.0 * pp.B * (double)C * C * 5 * pp.T,
                 4.0 * (5.0 * C * C + (double)pp.B * C * pp.T * (mb.y_act ? 3 : 2)));

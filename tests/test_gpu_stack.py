@@ -116,7 +116,7 @@ def test_residual_stack_vs_oracle(case, tuning):
     if B > 1:                                # utterances are independent
         one = _run(m[0][1:2], *m[1:], dil, 0.2, nmode)
         assert torch.equal(one, y[1:2])
-    if C == 256:                             # 32- and 64-column tiles (convk2_kernel<DIL, NM>; the launcher picks by size)
+    if C == 256:                             # 32- and 64-column tiles (convk2_kernel<C, DIL, NM>; the launcher picks by size)
         for wide in (0, 1 << 20):
             tuning("stack_wide", wide)
             for blocks in (0, 2):
