@@ -350,6 +350,8 @@ extern template int launch_convq2_dil<5, 64>(const PairParams&, size_t, hipStrea
 extern template int launch_convq2_dil<1, 65>(const PairParams&, size_t, hipStream_t);      // 65: 64 channels on 256-column tiles
 extern template int launch_convq2_dil<3, 65>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convq2_dil<5, 65>(const PairParams&, size_t, hipStream_t);
+extern template int launch_convq2_dil<1, 129>(const PairParams&, size_t, hipStream_t);     // 129: 128 channels on 128-column tiles
+extern template int launch_convq2_dil<3, 129>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convp_dil<1>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convp_dil<3>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convp_dil<5>(const PairParams&, size_t, hipStream_t);
@@ -658,7 +660,13 @@ extern template int launch_convq_dil<3>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convq_dil<5>(const PairParams&, size_t, hipStream_t);
 
 int launch_convq(PairParams p, int dil, hipStream_t s) {
-    const int C = 128, NM = 64;
+    const int C = 128;
+    // 128-column tiles (convq2_kernel<DIL, 129>: 32 x 64 wave tiles) where both images fit without the ring -- dilation 1 and
+    // 3 -- from Tuning::convq_wide tenths of such a tile per CU up
+    long long wide_items = 0;
+    for (int i = 0; i < p.n_members && i < 3; ++i) wide_items += (long long)p.B * ((p.T + 128 - p.m[i].k) / (129 - p.m[i].k));
+    const bool wide = tuning().convq2 != 0 && dil <= 3 && wide_items * 10 >= (long long)tuning().convq_wide * device_cu_count();
+    const int NM = wide ? 128 : 64;
     if (p.B <= 0 || p.T <= 0) return 0;
     if (dil != 1 && dil != 3 && dil != 5) return fail(FV_ERR_UNSUPPORTED, "resblock pair: dilation %d (1, 3 or 5)", dil);
     if (p.n_members < 1 || p.n_members > 3) return fail(FV_ERR_INVALID_ARG, "resblock pair: %d members", p.n_members);
@@ -693,6 +701,7 @@ int launch_convq(PairParams p, int dil, hipStream_t s) {
     }
     size_t floats = 0;
     const bool noring = tuning().convq2 != 0;      // convq2_kernels.hpp: A operands from L2 into registers, no ring
+    (void)wide_items;
     p.x_off = 0;                       // ring of 3 weight stages (one K step of all 128 rows each)
     if (!noring) floats += 3 * 16384 / 4;
     p.img_off = (int)floats;
@@ -716,7 +725,8 @@ int launch_convq(PairParams p, int dil, hipStream_t s) {
     p.dbg = tuning().pair_dbg;
     p.trace = nullptr;
     profile_begin(s);
-    const int rc = noring ? (dil == 1 ? launch_convq2_dil<1, 128>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, 128>(p, lds, s) : launch_convq2_dil<5, 128>(p, lds, s))
+    const int rc = wide ? (dil == 1 ? launch_convq2_dil<1, 129>(p, lds, s) : launch_convq2_dil<3, 129>(p, lds, s))
+                 : noring ? (dil == 1 ? launch_convq2_dil<1, 128>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, 128>(p, lds, s) : launch_convq2_dil<5, 128>(p, lds, s))
                           : (dil == 1 ? launch_convq_dil<1>(p, lds, s) : dil == 3 ? launch_convq_dil<3>(p, lds, s) : launch_convq_dil<5>(p, lds, s));
     profile_end(s, FV_KERNEL_CONVH128, flops, bytes);
     return rc;

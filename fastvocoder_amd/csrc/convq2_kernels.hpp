@@ -58,13 +58,37 @@ struct ConvQ2Geom<KT_, DIL_, 65> {
     static constexpr int WTILE = NSTEP * 8192, WBYTES = WTILE;
     static_assert(((CG - 1) * 4 * XRP + (KT - 1) * DIL + 16 * 3) * 16 + 16 < 65536, "ds_read immediate range");
 };
+// C_ = 129 (a tag): 128 channels on 128-column tiles, 8 waves = 4 row slabs of 32 x 2 column groups of 64 -- the two images fit
+// without the ring at dilation 1 and 3 (80 + 72 KB at 11 taps x dilation 3), not at 5
+template <int KT_, int DIL_>
+struct ConvWideImg128 {
+    static constexpr int C = 128, CB = 16, NT = 512;
+    static constexpr int XROWS = (128 + (KT_ - 1) * DIL_ + 3) / 4 * 4;
+    static constexpr int XRP = (XROWS + 15) / 16 * 16;
+    static constexpr int XHALF = CB * XRP * 16;
+    static constexpr int XR = (XROWS * CB + NT - 1) / NT;
+    static constexpr int NRAW = XR * 8;
+};
+template <int KT_, int DIL_>
+struct ConvQ2Geom<KT_, DIL_, 129> {
+    typedef ConvWideImg128<KT_, DIL_> IMG;
+    static constexpr int KT = KT_, DIL = DIL_, C = 128, CG = 4, CB = 16, NT = 512, WN = 2;
+    static constexpr int NM = 128, NOUT = NM - (KT - 1);
+    static constexpr int P1 = (KT - 1) * DIL / 2, P2 = (KT - 1) / 2;
+    static constexpr int NSTEP = KT * CG;
+    static constexpr int XRP = IMG::XRP, XHALF = IMG::XHALF, NRAW = IMG::NRAW;
+    static constexpr int MRP = NM + 16, MHALF = CB * MRP * 16;
+    static constexpr int WTILE = NSTEP * 8192, WBYTES = 2 * WTILE;
+    static_assert(((CG - 1) * 4 * XRP + (KT - 1) * DIL + 16 * 3) * 16 + 16 < 65536, "ds_read immediate range");
+    static_assert(2 * XHALF + 2 * MHALF + (4 * C + 16) * 4 <= 160 * 1024, "LDS: dilation 1 and 3 only");
+};
 template <int KT_, int DIL_, int C_>
 struct ConvQ2Run : ConvQ2Geom<KT_, DIL_, C_> {
     typedef ConvQ2Geom<KT_, DIL_, C_> B;
     static constexpr int NFW = 4;                        // fragments per wave: 64 columns
-    static constexpr int NH = C_ == 65 ? 2 : 1;          // row sixteenths per wave
+    static constexpr int NH = C_ == 65 || C_ == 129 ? 2 : 1;    // row sixteenths per wave
     static constexpr int NSLAB = B::C / (16 * NH);       // row slabs = waves per column group
-    static constexpr int QD = C_ == 65 ? 1 : 3;          // A operands this many K steps ahead (queue of QD + 1 slots; a K step of
+    static constexpr int QD = NH == 2 ? 1 : 3;           // A operands this many K steps ahead (queue of QD + 1 slots; a K step of
                                                          // the 32 x 64 tile is 768 matrix cycles per SIMD: one ahead is enough)
     static constexpr int NA = 2 * NH;                    // loads per wave and K step
     static constexpr int NSEQ = 2 * B::NSTEP;            // K steps per tile: conv1's, then conv2's
@@ -318,7 +342,7 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
 }
 
 // one 8-wave block per CU, 2 waves per SIMD
-// C: 128, 64, or the tag 65 (64 channels on 256-column tiles)
+// C: 128, 64, or a tag: 65 (64 channels on 256-column tiles), 129 (128 channels on 128-column tiles; dilation 1 and 3)
 template <int DIL, int C>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void convq2_kernel(PairParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -148,6 +148,7 @@ struct Tuning {
     int convh_rows64 = -1;    // the split-f16 convs at 128+ channels on 64-row tiles (1: convh_kernel) or 128-row ones (0: convs_kernel); -1: by size
     int convt_rows64 = -1;    // the split-f16 transposed conv (128+ input channels) on 64-row tiles (1) or 128-row ones (0); -1: by size
     int convq2 = 1;              // fused 128-channel pairs: 1 convq2_kernel (A operands from L2 into registers, no ring), 0 convq_kernel
+    int convq_wide = 20;         // fused 128-channel pairs, dilation 1 / 3: 128-column tiles per CU (in tenths) from which the wide form runs
     int convp_wide = 20;         // fused 64-channel pairs: 256-column tiles per CU (in tenths) from which the wide no-ring form runs
     int convp2 = 0;              // ... 64-channel pairs: 1 the same kernel at 64 channels, 0 convp_kernel (measured equal: convh_launch.hip)
     int stack_wide = 10;         // residual stacks of 256 channels: tiles of 64 columns per CU (in tenths) from which the wide tile runs

@@ -362,7 +362,7 @@ def test_conv1d_split_f16_reflection_rejects():
 def tuning():
     """fv_tuning_set for the duration of a test (process-wide switches of the launchers: restored afterwards)."""
     defaults = {"sched": 1, "sched_switch": 4, "convh_blocks": 0, "pair_blocks": 0, "pair128_unfused": 0, "convg_rows64": -1,
-                "convh_rows64": -1, "convt_rows64": -1, "chain": 0, "convq2": 1, "convp2": 0, "convp_wide": 20}
+                "convh_rows64": -1, "convt_rows64": -1, "chain": 0, "convq2": 1, "convp2": 0, "convp_wide": 20, "convq_wide": 20}
     yield _native.tuning_set
     for k, v in defaults.items():
         _native.tuning_set(k, v)
@@ -539,7 +539,7 @@ def test_pairs_without_the_weight_ring_give_the_same_bits(tuning):
     ks = (11, 3, 7)
     # (the last four: shorter than a tile / than the halo, exactly one cold tile, one column into the first warm tile)
     for C, T, dil in ((128, 520, 1), (128, 1100, 5), (64, 1030, 3), (64, 300, 5), (128, 5, 5), (128, 54, 3), (128, 55, 1),
-                      (64, 7, 3), (64, 2100, 1), (64, 247, 5)):
+                      (64, 7, 3), (64, 2100, 1), (64, 247, 5), (128, 1500, 3), (128, 119, 1)):
         ms = [_member(rng, 2, C, T, k, True) for k in ks]
         xs = [_t(m[0]) for m in ms]
         h1, h2 = [_native.pack_pair(_t(m[1]), SPLIT) for m in ms], [_native.pack_pair(_t(m[3]), SPLIT) for m in ms]
@@ -551,6 +551,7 @@ def test_pairs_without_the_weight_ring_give_the_same_bits(tuning):
             tuning("convq2", noring)
             tuning("convp2", noring)
             tuning("convp_wide", wide)
+            tuning("convq_wide", wide)       # (128 channels: 128-column tiles at dilation 1 and 3)
             for blocks in (0, 3):
                 tuning("convh_blocks", blocks)
                 ys = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, prec=SPLIT)
@@ -562,6 +563,7 @@ def test_pairs_without_the_weight_ring_give_the_same_bits(tuning):
         tuning("convq2", 1)
         tuning("convp2", 0)
         tuning("convp_wide", 20)
+        tuning("convq_wide", 20)
         base = outs[(0, 1 << 20, 0)]
         for y, ref in zip(base[:3], refs):
             assert _rel(y, ref) <= 4e-6
