@@ -952,6 +952,44 @@ def test_generator_beyond_the_f16_range_repeats_on_fp32():
         assert torch.equal(strict(x)[0], want)
 
 
+def _scaled_melgan(gain, seed=0):
+    """MelGAN original whose first conv (an fp32 kernel) is `gain` times too loud and whose last layer undoes it: every
+    upsampler and ResidualStack (one-launch split-f16 kernels, csrc/convk_kernels.hpp) then works at `gain` times its usual
+    scale with its weights untouched."""
+    cfg = cases.load_conf("conf/melgan/original.yaml")
+    m, _ = _model("melgan", cfg, seed=seed)
+    m.remove_weight_norm()
+    from fastvocoder_amd.generator.modules import LastLayer
+    first = next(mod for mod in m.melgan if isinstance(mod, torch.nn.Conv1d))
+    last = next(mod for mod in m.melgan if isinstance(mod, LastLayer)).conv
+    with torch.no_grad():
+        first.weight.mul_(gain)
+        first.bias.mul_(gain)
+        last.weight.mul_(1.0 / gain)
+    return m
+
+
+@pytest.mark.parametrize("gain", [1e7, 1e-7])
+def test_melgan_outside_the_split_domain_repeats_on_fp32(gain):
+    """Both sides of the split-f16 domain through the one-launch ResidualStack kernels: activations beyond the f16 range (the
+    kernels' range guard, value 1) and tensors that are tiny as a whole (the low-side guard, value 4) send `inference` to
+    the exact-fp32 kernels -- the two-launch fp32 form of every stack -- and the result is the fp32 model's, bit for bit."""
+    mel = seeded_mel(40, seed=5)
+    exact = _scaled_melgan(gain)
+    exact.precision = "f32"
+    with torch.no_grad():
+        want = exact.inference(mel)
+    assert bool(torch.isfinite(want).all()) and float(want.abs().max()) > 1e-4
+    m = _scaled_melgan(gain)
+    with pytest.warns(RuntimeWarning, match="split-f16 range"), torch.no_grad():
+        got = m.inference(mel)
+    assert torch.equal(got, want) and m._fv_policy()[0] == "f32"
+    ok = _scaled_melgan(30.0 if gain > 1 else 1.0 / 30.0)          # inside the domain: stays on the split kernels
+    with torch.no_grad():
+        y = ok.inference(mel)
+    assert ok._fv_policy()[0] == "split" and not ok.check_range() and bool(torch.isfinite(y).all())
+
+
 def test_weights_of_any_magnitude_stay_on_the_split_kernels():
     """Weights far outside the f16 range inside a generator (round 3: a weight beyond 65504 meant an fp32 plan, one below
     6e-5 lost bits silently).  Every ResBlock's first convs 2^10 times too large and its second convs 2^-10 times too small
