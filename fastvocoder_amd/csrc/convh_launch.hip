@@ -339,6 +339,7 @@ int launch_convg(PairParams p, int C, hipStream_t s) {
 }
 
 // ---- fused pair at C = 64 (convp_kernels.hpp) --------------------------------------------------------------------
+constexpr int kPair64Wide = 65, kPair128Wide = 129;     // (convq2_kernels.hpp: the wide forms of the ring-free pair kernel)
 template <int DIL, int C>
 int launch_convq2_dil(const PairParams& p, size_t lds, hipStream_t s);      // convq2_inst.hip: the pairs without the weight ring
 extern template int launch_convq2_dil<1, 128>(const PairParams&, size_t, hipStream_t);
@@ -347,11 +348,11 @@ extern template int launch_convq2_dil<5, 128>(const PairParams&, size_t, hipStre
 extern template int launch_convq2_dil<1, 64>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convq2_dil<3, 64>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convq2_dil<5, 64>(const PairParams&, size_t, hipStream_t);
-extern template int launch_convq2_dil<1, 65>(const PairParams&, size_t, hipStream_t);      // 65: 64 channels on 256-column tiles
-extern template int launch_convq2_dil<3, 65>(const PairParams&, size_t, hipStream_t);
-extern template int launch_convq2_dil<5, 65>(const PairParams&, size_t, hipStream_t);
-extern template int launch_convq2_dil<1, 129>(const PairParams&, size_t, hipStream_t);     // 129: 128 channels on 128-column tiles
-extern template int launch_convq2_dil<3, 129>(const PairParams&, size_t, hipStream_t);
+extern template int launch_convq2_dil<1, kPair64Wide>(const PairParams&, size_t, hipStream_t);
+extern template int launch_convq2_dil<3, kPair64Wide>(const PairParams&, size_t, hipStream_t);
+extern template int launch_convq2_dil<5, kPair64Wide>(const PairParams&, size_t, hipStream_t);
+extern template int launch_convq2_dil<1, kPair128Wide>(const PairParams&, size_t, hipStream_t);
+extern template int launch_convq2_dil<3, kPair128Wide>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convp_dil<1>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convp_dil<3>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convp_dil<5>(const PairParams&, size_t, hipStream_t);
@@ -436,7 +437,7 @@ int launch_convp(PairParams p, int dil, hipStream_t s) {
     const int form = wide_items * 10 >= (long long)tuning().convp_wide * device_cu_count() ? 2 : tuning().convp2 != 0 ? 1 : 0;
     if (int rc = prepare_convp(p, dil, lds, flops, bytes, form)) return rc;
     profile_begin(s);
-    const int rc = form == 2 ? (dil == 1 ? launch_convq2_dil<1, 65>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, 65>(p, lds, s) : launch_convq2_dil<5, 65>(p, lds, s))
+    const int rc = form == 2 ? (dil == 1 ? launch_convq2_dil<1, kPair64Wide>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, kPair64Wide>(p, lds, s) : launch_convq2_dil<5, kPair64Wide>(p, lds, s))
                  : form == 1 ? (dil == 1 ? launch_convq2_dil<1, 64>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, 64>(p, lds, s) : launch_convq2_dil<5, 64>(p, lds, s))
                              : (dil == 1 ? launch_convp_dil<1>(p, lds, s) : dil == 3 ? launch_convp_dil<3>(p, lds, s) : launch_convp_dil<5>(p, lds, s));
     profile_end(s, FV_KERNEL_CONVH64, flops, bytes);
@@ -701,7 +702,6 @@ int launch_convq(PairParams p, int dil, hipStream_t s) {
     }
     size_t floats = 0;
     const bool noring = tuning().convq2 != 0;      // convq2_kernels.hpp: A operands from L2 into registers, no ring
-    (void)wide_items;
     p.x_off = 0;                       // ring of 3 weight stages (one K step of all 128 rows each)
     if (!noring) floats += 3 * 16384 / 4;
     p.img_off = (int)floats;
@@ -725,7 +725,7 @@ int launch_convq(PairParams p, int dil, hipStream_t s) {
     p.dbg = tuning().pair_dbg;
     p.trace = nullptr;
     profile_begin(s);
-    const int rc = wide ? (dil == 1 ? launch_convq2_dil<1, 129>(p, lds, s) : launch_convq2_dil<3, 129>(p, lds, s))
+    const int rc = wide ? (dil == 1 ? launch_convq2_dil<1, kPair128Wide>(p, lds, s) : launch_convq2_dil<3, kPair128Wide>(p, lds, s))
                  : noring ? (dil == 1 ? launch_convq2_dil<1, 128>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, 128>(p, lds, s) : launch_convq2_dil<5, 128>(p, lds, s))
                           : (dil == 1 ? launch_convq_dil<1>(p, lds, s) : dil == 3 ? launch_convq_dil<3>(p, lds, s) : launch_convq_dil<5>(p, lds, s));
     profile_end(s, FV_KERNEL_CONVH128, flops, bytes);

@@ -14,9 +14,9 @@ template int launch_convq2_dil<5, 128>(const PairParams&, size_t, hipStream_t);
 template int launch_convq2_dil<1, 64>(const PairParams&, size_t, hipStream_t);
 template int launch_convq2_dil<3, 64>(const PairParams&, size_t, hipStream_t);
 template int launch_convq2_dil<5, 64>(const PairParams&, size_t, hipStream_t);
-template int launch_convq2_dil<1, 65>(const PairParams&, size_t, hipStream_t);
-template int launch_convq2_dil<3, 65>(const PairParams&, size_t, hipStream_t);
-template int launch_convq2_dil<5, 65>(const PairParams&, size_t, hipStream_t);
-template int launch_convq2_dil<1, 129>(const PairParams&, size_t, hipStream_t);
-template int launch_convq2_dil<3, 129>(const PairParams&, size_t, hipStream_t);
+template int launch_convq2_dil<1, kPair64Wide>(const PairParams&, size_t, hipStream_t);
+template int launch_convq2_dil<3, kPair64Wide>(const PairParams&, size_t, hipStream_t);
+template int launch_convq2_dil<5, kPair64Wide>(const PairParams&, size_t, hipStream_t);
+template int launch_convq2_dil<1, kPair128Wide>(const PairParams&, size_t, hipStream_t);
+template int launch_convq2_dil<3, kPair128Wide>(const PairParams&, size_t, hipStream_t);
 }  // namespace fv

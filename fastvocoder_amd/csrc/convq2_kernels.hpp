@@ -17,6 +17,9 @@ namespace fv {
 // C = 128: the geometry of convq_kernel (64 intermediate columns); C = 64: that of convp_kernel (128 columns: two column
 // groups of 64 -- two waves do share a row sixteenth there and load it twice, 5.6 KB of weights per column instead of
 // 2.8: the 64-channel weights are a quarter of the 128-channel ones and the tile is twice as wide)
+// The kernel's second template argument: a channel count on its ordinary tile (128 / 64), or one of the wide forms below
+constexpr int kPair64Wide = 65;      // 64 channels on 256-column tiles
+constexpr int kPair128Wide = 129;    // 128 channels on 128-column tiles (dilation 1 and 3)
 template <int KT_, int DIL_, int C_>
 struct ConvQ2Geom;
 template <int KT_, int DIL_>
@@ -33,7 +36,7 @@ struct ConvQ2Geom<KT_, DIL_, 64> : ConvPGeom<KT_, DIL_> {
     static constexpr int NSTEP = IMG::NSTEP, XRP = IMG::XRP, XHALF = IMG::XHALF, WTILE = IMG::WTILE, NRAW = IMG::NRAW;
     static constexpr int WBYTES = IMG::WTILE;
 };
-// C_ = 65 (a tag, not a channel count): 64 channels on 256-column tiles -- 8 waves = 2 row slabs of 32 x 4 column groups of
+// kPair64Wide: 64 channels on 256-column tiles -- 8 waves = 2 row slabs of 32 x 4 column groups of
 // 64 (a 32 x 64 wave tile: 24 MFMAs per K step for 8 B reads and 4 A loads; the LDS operand traffic per MFMA of the 32 x 32
 // tile halved, k - 1 of 256 intermediate columns recomputed by a cold tile instead of k - 1 of 128).  Without a ring the
 // two images fit: (256 + 50) x 64 channels = 80 KB + 70 KB.  For launches with tiles to spare (the launcher decides).
@@ -47,7 +50,7 @@ struct ConvWideImg {                                     // window loader / conv
     static constexpr int NRAW = XR * 8;
 };
 template <int KT_, int DIL_>
-struct ConvQ2Geom<KT_, DIL_, 65> {
+struct ConvQ2Geom<KT_, DIL_, kPair64Wide> {
     typedef ConvWideImg<KT_, DIL_> IMG;
     static constexpr int KT = KT_, DIL = DIL_, C = 64, CG = 2, CB = 8, NT = 512, WN = 4;
     static constexpr int NM = 256, NOUT = NM - (KT - 1);
@@ -58,7 +61,7 @@ struct ConvQ2Geom<KT_, DIL_, 65> {
     static constexpr int WTILE = NSTEP * 8192, WBYTES = WTILE;
     static_assert(((CG - 1) * 4 * XRP + (KT - 1) * DIL + 16 * 3) * 16 + 16 < 65536, "ds_read immediate range");
 };
-// C_ = 129 (a tag): 128 channels on 128-column tiles, 8 waves = 4 row slabs of 32 x 2 column groups of 64 -- the two images fit
+// kPair128Wide: 128 channels on 128-column tiles, 8 waves = 4 row slabs of 32 x 2 column groups of 64 -- the two images fit
 // without the ring at dilation 1 and 3 (80 + 72 KB at 11 taps x dilation 3), not at 5
 template <int KT_, int DIL_>
 struct ConvWideImg128 {
@@ -70,7 +73,7 @@ struct ConvWideImg128 {
     static constexpr int NRAW = XR * 8;
 };
 template <int KT_, int DIL_>
-struct ConvQ2Geom<KT_, DIL_, 129> {
+struct ConvQ2Geom<KT_, DIL_, kPair128Wide> {
     typedef ConvWideImg128<KT_, DIL_> IMG;
     static constexpr int KT = KT_, DIL = DIL_, C = 128, CG = 4, CB = 16, NT = 512, WN = 2;
     static constexpr int NM = 128, NOUT = NM - (KT - 1);
@@ -86,7 +89,7 @@ template <int KT_, int DIL_, int C_>
 struct ConvQ2Run : ConvQ2Geom<KT_, DIL_, C_> {
     typedef ConvQ2Geom<KT_, DIL_, C_> B;
     static constexpr int NFW = 4;                        // fragments per wave: 64 columns
-    static constexpr int NH = C_ == 65 || C_ == 129 ? 2 : 1;    // row sixteenths per wave
+    static constexpr int NH = C_ == kPair64Wide || C_ == kPair128Wide ? 2 : 1;     // row sixteenths per wave
     static constexpr int NSLAB = B::C / (16 * NH);       // row slabs = waves per column group
     static constexpr int QD = NH == 2 ? 1 : 3;           // A operands this many K steps ahead (queue of QD + 1 slots; a K step of
                                                          // the 32 x 64 tile is 768 matrix cycles per SIMD: one ahead is enough)
@@ -342,7 +345,7 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
 }
 
 // one 8-wave block per CU, 2 waves per SIMD
-// C: 128, 64, or a tag: 65 (64 channels on 256-column tiles), 129 (128 channels on 128-column tiles; dilation 1 and 3)
+// C: 128, 64, kPair64Wide or kPair128Wide
 template <int DIL, int C>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void convq2_kernel(PairParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -253,12 +253,11 @@ class PlanBuilder:
                         and cv.in_channels == c and cv.out_channels == c for cv in (pointwise, skip))
                 and _native.residual_stack_split_supported(c, k, d))
 
-    def residual_stack(self, dilated, pointwise, skip, src, dst, slope, pad_mode=PAD_ZERO, hidden=SLOT_NONE, post=POST_NONE,
-                       carry_two_launch=False):
+    def residual_stack(self, dilated, pointwise, skip, src, dst, slope, pad_mode=PAD_ZERO, hidden=SLOT_NONE, post=POST_NONE):
         """dst = pointwise(lrelu(dilated(pad(lrelu(src))))) + skip(src), reference modules.py:351-382, as one launch
         (fv_plan_add_residual_stack_split_f16).  ``src`` is read raw; nothing is hoisted into its producer.
-        256 channels (or ``carry_two_launch``, 128+): the op also carries the two-launch form (scratch slot ``hidden``;
-        fv_plan_set_stack_two_launch, ``Tuning::stack_items``) for A/B runs and the bit-identity tests."""
+        256 channels: the op also carries the two-launch form (scratch slot ``hidden``; fv_plan_set_stack_two_launch,
+        ``Tuning::stack_items``) for A/B runs and the bit-identity tests."""
         c, k, d = dilated.in_channels, dilated.kernel_size[0], dilated.dilation[0]
         if not self.residual_stack_supported(dilated, pointwise, skip, d * (k - 1) // 2, pad_mode):
             raise _native.NativeError("residual_stack: shape not built into the one-launch kernel")
@@ -269,9 +268,7 @@ class PlanBuilder:
                   split=True, channels=c, k=k, dil=d, pad_mode=pad_mode,
                   packed=_native.pack_residual_stack_split(w1, w2, ws, self.guard),
                   bias=self._bias(dilated), bias_out=bias_out, post=post)
-        if c >= 256 or carry_two_launch:
-            if not _native.conv1x1_2src_split_supported(c):
-                raise _native.NativeError("residual_stack: the two-launch form exists at 128+ channels only")
+        if c >= 256:
             if hidden == SLOT_NONE:
                 raise _native.NativeError("residual_stack: a scratch slot (hidden) is needed at 256 channels")
             op.update(tmps=[hidden], two_launch=(hidden, _native.pack_pair(w1, _native.PAIR_SPLIT_F16, self.guard),
