@@ -723,7 +723,7 @@ int launch_convq(PairParams p, int dil, hipStream_t s) {
         pair_cut_schedule(p, p.nblk, n);
     }
     p.dbg = tuning().pair_dbg;
-    p.trace = nullptr;
+    p.trace = reinterpret_cast<unsigned long long*>(tuning().trace_ptr);
     profile_begin(s);
     const int rc = wide ? (dil == 1 ? launch_convq2_dil<1, kPair128Wide>(p, lds, s) : launch_convq2_dil<3, kPair128Wide>(p, lds, s))
                  : noring ? (dil == 1 ? launch_convq2_dil<1, 128>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, 128>(p, lds, s) : launch_convq2_dil<5, 128>(p, lds, s))

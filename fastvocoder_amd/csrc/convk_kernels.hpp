@@ -75,6 +75,9 @@ __device__ __forceinline__ void convk_convert_centre(const ConvHRaw<G>& r, char*
 // tap-major.  (Its first form streamed the weights through an LDS ring of three K-step stages, one barrier per stage: equal
 // within 1-2 % at every batch size -- MelGAN batch 1 / 8 / 64: 0.254 vs 0.256, 0.797 vs 0.813, 5.85 vs 5.79 ms -- and gone.)  At 32 and 64 channels the queue holds the whole stack's A operands (5 / 10 K steps of 8 registers):
 // they are loaded once per tile and would not have to be -- L2 hits either way.
+#ifndef FV_K2_ILV
+#define FV_K2_ILV 1
+#endif
 template <int C_, int DIL_, int NM_>
 struct ConvK2Geom {
     static constexpr int DIL = DIL_, KT = 3, C = C_, CG = C / 32, CB = C / 8, NM = NM_, NT = 512;
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // the next tile's window is requested QD steps before the tile ends: no A operand of THIS tile is issued after it,
             // so no count here waits for it (requested at the start of the second GEMM it had one to three K steps to land)
             constexpr int RAWK = G::RES ? G::NK1 : G::NK - G::QD;
+            constexpr bool ILV = FV_K2_ILV && G::NH == 1;
             static_assert(RAWK >= G::NK1, "the window registers are read after conv1 (the raw centre)");
 #pragma unroll
             for (int h = 0; h < G::NH; ++h)
@@ -219,14 +223,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 constexpr int KS = decltype(KC)::value;
                 if constexpr (KS == RAWK)
                     convh_load_raw<G>(raw, p.x + nb * ustride, p.T, ntile * G::NM - G::P, tid, more, p.reflect != 0);
-                if constexpr (!G::RES) load_a(IntC<KS + G::QD>{}, aq[(KS + G::QD) % (G::QD + 1)]);
-                if constexpr (KS + 1 < K1) fetch_b(IntC<KS + 1>{}, bbuf[(KS + 1) & 1]);
                 // outstanding after K step KS's loads: steps KS + 1 .. KS + QD, and the window if it was requested after them
                 constexpr bool raw_after = RAWK > KS - G::QD && RAWK <= KS;
                 // (a tile's first QD steps were waited for in the epilogue of the tile before, ahead of its stores: a count
                 // here would wait for those stores)
-                if constexpr (!G::RES && KS >= G::QD) wait_vm<G::NA * G::QD + (raw_after ? G::NRAW : 0)>();
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ILV) {                     // the loads of this step go one per MFMA gap (below): wait first
+                    if constexpr (!G::RES && KS >= G::QD) wait_vm<G::NA * (G::QD - 1) + (raw_after ? G::NRAW : 0)>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (!G::RES) load_a(IntC<KS + G::QD>{}, aq[(KS + G::QD) % (G::QD + 1)]);
+                    if constexpr (KS + 1 < K1) fetch_b(IntC<KS + 1>{}, bbuf[(KS + 1) & 1]);
+                } else {
+                    if constexpr (!G::RES) load_a(IntC<KS + G::QD>{}, aq[(KS + G::QD) % (G::QD + 1)]);
+                    if constexpr (KS + 1 < K1) fetch_b(IntC<KS + 1>{}, bbuf[(KS + 1) & 1]);
+                    if constexpr (!G::RES && KS >= G::QD) wait_vm<G::NA * G::QD + (raw_after ? G::NRAW : 0)>();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 f16x8 (&a)[G::NH][2] = aq[KS % (G::QD + 1)];
 #pragma unroll
                 for (int h = 0; h < G::NH; ++h)
@@ -243,6 +254,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int e = 0; e < G::NFW; ++e)
                         lo[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[h][1], bbuf[KS & 1][e][0], lo[h][e], 0, 0, 0);
+                if constexpr (ILV) {                     // (convq2_kernels.hpp: one load per MFMA gap on the 16 x 64 wave tiles)
+                    constexpr int NV = G::RES ? 0 : G::NA, ND = KS + 1 < K1 ? 2 * G::NFW : 0;
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < ND; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * G::NH * G::NFW - NV - ND, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
         };

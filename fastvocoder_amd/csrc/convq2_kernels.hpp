@@ -85,6 +85,9 @@ struct ConvQ2Geom<KT_, DIL_, kPair128Wide> {
     static_assert(((CG - 1) * 4 * XRP + (KT - 1) * DIL + 16 * 3) * 16 + 16 < 65536, "ds_read immediate range");
     static_assert(2 * XHALF + 2 * MHALF + (4 * C + 16) * 4 <= 160 * 1024, "LDS: dilation 1 and 3 only");
 };
+#ifndef FV_Q2_ILV
+#define FV_Q2_ILV 1
+#endif
 template <int KT_, int DIL_, int C_>
 struct ConvQ2Run : ConvQ2Geom<KT_, DIL_, C_> {
     typedef ConvQ2Geom<KT_, DIL_, C_> B;
@@ -94,6 +97,7 @@ struct ConvQ2Run : ConvQ2Geom<KT_, DIL_, C_> {
     static constexpr int QD = NH == 2 ? 1 : 3;           // A operands this many K steps ahead (queue of QD + 1 slots; a K step of
                                                          // the 32 x 64 tile is 768 matrix cycles per SIMD: one ahead is enough)
     static constexpr int NA = 2 * NH;                    // loads per wave and K step
+    static constexpr bool ILV = FV_Q2_ILV && NH == 1;    // the step's loads one per MFMA gap (below)
     static constexpr int NSEQ = 2 * B::NSTEP;            // K steps per tile: conv1's, then conv2's
     static constexpr int RAWK = NSEQ - QD;               // K step at which the next tile's window is requested: no A operand of
                                                          // THIS tile is issued after it, so nothing here waits for it
@@ -146,6 +150,7 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
     int c_end = b == b_last ? c_last : p.T;
     bool warm = false;                                   // (cold / warm tiles of a run: convq_kernels.hpp)
     if (!first) pair_barrier();
+    pair_stamp(p, 8, wave, lane, 7, 12);                 // (tuning aid, -DFV_PAIR_TRACE: tools/convq2_trace.py) run start
     LowGuard low;
     f32x2 bad2 = {0.f, 0.f};
     const float rcp = div_rcp(p.out_div);
@@ -164,8 +169,11 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
     for (int idx = tid; idx < 2 * G::CB * 64; idx += G::NT)
         reinterpret_cast<float*>(mimg + ((idx >> 6) * G::MRP + G::NM) * 16)[idx & 63] = 0.f;
     pair_wait_vm0();
+    pair_stamp(p, 8, wave, lane, 7, 10);
     if (!(p.dbg & 2)) convh_convert<IMG>(raw, ximg, p.slope, tid, low);
-    for (;;) {
+    pair_stamp(p, 8, wave, lane, 7, 13);
+    for (int it = 0;; ++it) {
+        pair_stamp(p, 8, wave, lane, it, 0);
         const int t0 = tout;
         const int r0 = warm ? G::KT - 1 : 0;             // image row of the first NEW intermediate column
         const int n_out = warm ? G::NM : G::NOUT;
@@ -212,12 +220,19 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
                 constexpr int S = decltype(SC)::value;
                 if constexpr (S == G::RAWK)
                     convh_load_raw<IMG>(raw, mb.x + nb * ustride, p.T, nwin, tid, more && !(p.dbg & 1));
-                load_a(IntC<S + G::QD>{}, aq[(S + G::QD) % (G::QD + 1)]);
-                if constexpr (S + 1 < S1) fetch_b(IntC<S + 1>{}, bbuf[(S + 1) & 1]);
                 constexpr bool raw_after = G::RAWK > S - G::QD && G::RAWK <= S;     // requested after step S's loads were
                 // (a tile's first QD steps were waited for in the epilogue of the tile before)
-                if constexpr (S >= G::QD) wait_vm<G::NA * G::QD + (raw_after ? G::NRAW : 0)>();
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (G::ILV) {
+                    if constexpr (S >= G::QD) wait_vm<G::NA * (G::QD - 1) + (raw_after ? G::NRAW : 0)>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_a(IntC<S + G::QD>{}, aq[(S + G::QD) % (G::QD + 1)]);
+                    if constexpr (S + 1 < S1) fetch_b(IntC<S + 1>{}, bbuf[(S + 1) & 1]);
+                } else {
+                    load_a(IntC<S + G::QD>{}, aq[(S + G::QD) % (G::QD + 1)]);
+                    if constexpr (S + 1 < S1) fetch_b(IntC<S + 1>{}, bbuf[(S + 1) & 1]);
+                    if constexpr (S >= G::QD) wait_vm<G::NA * G::QD + (raw_after ? G::NRAW : 0)>();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 f16x8 (&a)[G::NH][2] = aq[S % (G::QD + 1)];
 #pragma unroll
                 for (int h = 0; h < G::NH; ++h)
@@ -234,12 +249,33 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
 #pragma unroll
                     for (int e = 0; e < G::NFW; ++e)
                         lo[h][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[h][1], bbuf[S & 1][e][0], lo[h][e], 0, 0, 0);
+                if constexpr (G::ILV) {
+                    // the 16 x 64 wave tiles: one load per MFMA gap instead of a burst of NA + 2 NFW between two steps -- the
+                    // wave's own stream keeps the matrix pipe fed while it issues them [measured, batch 1: 47.6 -> 46.0 us
+                    // at 128 channels, 54.5 -> 52.8 at 64; nothing on the 32 x 64 tiles, whose steps are twice as long]
+#pragma unroll
+                    for (int i = 0; i < G::NA; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // buffer load
+                    }
+                    if constexpr (S + 1 < S1) {
+#pragma unroll
+                        for (int i = 0; i < 2 * G::NFW; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // LDS read
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3 * G::NH * G::NFW - G::NA - 2 * G::NFW, 0);
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3 * G::NH * G::NFW - G::NA, 0);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
 
         pair_barrier();                                  // the window image is complete
         run(IntC<0>{}, IntC<G::NSTEP>{});
+        pair_stamp(p, 8, wave, lane, it, 1);
         {
             // conv1 -> intermediate image: row r is time t0 - P2 + r; conv2's zero padding applies to the intermediate
             const int tm = t0 - G::P2 + r0;              // time of the first new column
@@ -264,7 +300,9 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
             low_note(low, 1, lowm);
         }
         pair_barrier();                                  // the intermediate is complete (and nobody reads the x image any more)
+        pair_stamp(p, 8, wave, lane, it, 2);
         run(IntC<G::NSTEP>{}, IntC<G::NSEQ>{});
+        pair_stamp(p, 8, wave, lane, it, 3);
         pair_barrier();                                  // every wave is done with the intermediate
         if (nwarm) {
             // the last KT - 1 valid columns -> the front of the image (convq_kernels.hpp)
@@ -291,6 +329,7 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
             }
         }
         pair_wait_vm0();                                 // the next window, the residual, the next tile's first A operands
+        pair_stamp(p, 8, wave, lane, it, 4);
         const bool fin = mb.add1 != nullptr;
 #pragma unroll
         for (int h = 0; h < G::NH; ++h) {
@@ -332,7 +371,9 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
                 pair_store(p, mb.y, mb.y_act, G::C, b, row0 + 16 * h, t0 + col, col < n_out && t0 + col < c_end && !(p.dbg & 8), v, fin,
                            rcp);
             }
+        pair_stamp(p, 8, wave, lane, it, 5);
         if (more && !(p.dbg & 2)) convh_convert<IMG>(raw, ximg, p.slope, tid, low);
+        pair_stamp(p, 8, wave, lane, it, 6);
         if (!more) break;
         if (!cont) c_end = nb == b_last ? c_last : p.T;
         b = nb;

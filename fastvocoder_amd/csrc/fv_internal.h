@@ -150,7 +150,7 @@ struct Tuning {
     int convq2 = 1;              // fused 128-channel pairs: 1 convq2_kernel (A operands from L2 into registers, no ring), 0 convq_kernel
     int convq_wide = 20;         // fused 128-channel pairs, dilation 1 / 3: 128-column tiles per CU (in tenths) from which the wide form runs
     int convp_wide = 20;         // fused 64-channel pairs: 256-column tiles per CU (in tenths) from which the wide no-ring form runs
-    int convp2 = 0;              // ... 64-channel pairs: 1 the same kernel at 64 channels, 0 convp_kernel (measured equal: convh_launch.hip)
+    int convp2 = 1;              // ... 64-channel pairs: 1 the same kernel at 64 channels, 0 convp_kernel (the ring form: 1.5 us per batch-1 launch behind)
     int stack_wide = 10;         // residual stacks of 256 channels: tiles of 64 columns per CU (in tenths) from which the wide tile runs
                                  // (Basis-MelGAN, 1000 frames: batch 1 -- 250 such tiles in its second stage -- 0.238 narrow / 0.248 wide,
                                  // batch 2 0.384 / 0.359, batch 3 0.624 / 0.534)

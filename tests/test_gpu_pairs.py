@@ -362,7 +362,7 @@ def test_conv1d_split_f16_reflection_rejects():
 def tuning():
     """fv_tuning_set for the duration of a test (process-wide switches of the launchers: restored afterwards)."""
     defaults = {"sched": 1, "sched_switch": 4, "convh_blocks": 0, "pair_blocks": 0, "pair128_unfused": 0, "convg_rows64": -1,
-                "convh_rows64": -1, "convt_rows64": -1, "chain": 0, "convq2": 1, "convp2": 0, "convp_wide": 20, "convq_wide": 20}
+                "convh_rows64": -1, "convt_rows64": -1, "chain": 0, "convq2": 1, "convp2": 1, "convp_wide": 20, "convq_wide": 20}
     yield _native.tuning_set
     for k, v in defaults.items():
         _native.tuning_set(k, v)
@@ -561,7 +561,7 @@ def test_pairs_without_the_weight_ring_give_the_same_bits(tuning):
                 outs[(noring, wide, blocks)] = ys + [merged]
         tuning("convh_blocks", 0)
         tuning("convq2", 1)
-        tuning("convp2", 0)
+        tuning("convp2", 1)
         tuning("convp_wide", 20)
         tuning("convq_wide", 20)
         base = outs[(0, 1 << 20, 0)]
