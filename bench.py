@@ -339,10 +339,10 @@ def roofline_report(model, mel, ms_per_step, reps=5):
     if wide["ms"] >= fp32["ms"]:
         dom, peak = wide, PEAK_F16_MFMA_TFLOPS / 3.0
         roofline = {
-            "kernel": "fv::convq2_kernel (fused ResBlock pair, 128 channels; csrc/convq2_kernels.hpp) + fv::convp_kernel (fused "
-                      "ResBlock pair, 64 channels; csrc/convp_kernels.hpp): the 128- and 64-channel MRF stages (36 of the 78 convs, "
+            "kernel": "fv::convq2_kernel<dilation, 128> and <dilation, 64> (fused ResBlock pairs; csrc/convq2_kernels.hpp): the "
+                      "128- and 64-channel MRF stages (36 of the 78 convs, "
                       "%.0f %% of the step's kernel time) with split-f16 operands -- every fp32 product is three "
-                      "v_mfma_f32_16x16x32_f16 terms (a1 b1 + (a1 b2 + a2 b1) / 2048, fp32 accumulate), weights streamed from L2 (into registers at 128 channels, through an LDS ring at 64)"
+                      "v_mfma_f32_16x16x32_f16 terms (a1 b1 + (a1 b2 + a2 b1) / 2048, fp32 accumulate), weights streamed from L2 into registers"
                       % (100.0 * wide["ms"] / max(all_ms * reps, 1e-9)),
             "bound": "mfma", "achieved": rate(dom), "peak": peak, "unit": "TFLOP/s",
             "frac": rate(dom) / peak,
