@@ -268,7 +268,7 @@ int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout,
     p.nblk = (int)nblk;
     p.sched_on = 0;
     p.dbg = tuning().pair_dbg;
-    p.trace = nullptr;
+    p.trace = reinterpret_cast<unsigned long long*>(tuning().trace_ptr);
     profile_begin(s);
     const int rc = wide ? launch_convu_geom(p, lds, s) : launch_convt_geom(p, cc / 32, lds, s);
     // MACs of a ConvTranspose1d = Tin * Cin * Cout * k
