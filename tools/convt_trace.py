@@ -37,7 +37,7 @@ e1.record()
 torch.cuda.synchronize()
 print(f"ConvTranspose1d {cin} -> {cout} x{s}, T = {T}, B = {B}: launch (events) {e0.elapsed_time(e1) * 1e3:.1f} us, out {tuple(y.shape)}")
 tr = trace.cpu().numpy()[:8 * nw * 8 * 16].reshape(8, nw, 8, 16)
-names = ["kloop", "bar", "vmwait", "convert", "epi+stores", "to next"]
+names = ["entry", "kloop", "barrier", "vmwait", "merge+epilogue+stores", "convert next"]
 for blk in range(8):
     ent, stg, ext = tr[blk, 0, 7, 15], tr[blk, 0, 7, 13], tr[blk, 0, 7, 14]
     t12, t11, t10 = tr[blk, 0, 7, 12], tr[blk, 0, 7, 11], tr[blk, 0, 7, 10]
