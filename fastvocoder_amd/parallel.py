@@ -19,7 +19,21 @@ import torch
 import torch.distributed as dist
 
 
-_DTYPES = [torch.float32, torch.int16, torch.float64, torch.float16]      # what a forward_fn may return (wire code = index)
+# what a forward_fn may return (wire code = index; new entries go to the END: the codes travel between ranks)
+_DTYPES = [torch.float32, torch.int16, torch.float64, torch.float16, torch.bfloat16, torch.int32, torch.int64,
+           torch.uint8, torch.int8]
+_ALIGN = 16      # byte alignment of every tensor inside the flat broadcast buffer (>= the largest element size)
+
+
+def _dtype_code(dtype):
+    """Wire code of ``dtype``, or -2: not a dtype the gather can carry.  Never raises -- a rank that raised BEFORE a
+    collective would leave the others waiting in it; the code travels and every rank raises after the collective."""
+    return _DTYPES.index(dtype) if dtype in _DTYPES else -2
+
+
+def _wire_bytes(t):
+    """``t`` as its bytes (RCCL / gloo lack some element types -- int16, bf16 under gloo: everything travels as uint8)."""
+    return t.contiguous().reshape(-1).view(torch.uint8)
 
 
 def shard_range(n_items, world_size, rank):
@@ -44,18 +58,22 @@ def broadcast_weights(model, src=0, group=None):
         with torch.no_grad():
             dev = tensors[0].device
             staged = _staged(group, *tensors)
+            # every tensor starts on a 16-byte boundary of the flat buffer: `.view(dtype)` of a byte range needs an
+            # offset that is a multiple of the element size (a module with mixed dtypes -- BatchNorm's int64
+            # num_batches_tracked behind an odd count of fp32 elements, bool / fp16 buffers -- would otherwise raise on
+            # every rank)
             sizes = [t.numel() * t.element_size() for t in tensors]
-            flat = torch.empty(sum(sizes), dtype=torch.uint8, device="cpu" if staged else dev)
+            offs, total = [], 0
+            for n in sizes:
+                offs.append(total)
+                total += (n + _ALIGN - 1) // _ALIGN * _ALIGN
+            flat = torch.zeros(total, dtype=torch.uint8, device="cpu" if staged else dev)
             if dist.get_rank(group) == src:
-                off = 0
-                for t, n in zip(tensors, sizes):
-                    flat[off:off + n].copy_(t.data.contiguous().reshape(-1).view(torch.uint8))
-                    off += n
+                for t, off, n in zip(tensors, offs, sizes):
+                    flat[off:off + n].copy_(_wire_bytes(t.data))
             dist.broadcast(flat, src=src, group=group)
-            off = 0
-            for t, n in zip(tensors, sizes):
+            for t, off, n in zip(tensors, offs, sizes):
                 t.data.copy_(flat[off:off + n].view(t.dtype).reshape(t.shape))
-                off += n
     if hasattr(model, "invalidate_plans"):
         for m in model.modules():
             if hasattr(m, "invalidate_plans"):
@@ -95,12 +113,20 @@ def synthesize_ragged(forward_fn, mels, world_size=None, rank=None, dst=0, group
     meta = torch.zeros(slots, dtype=torch.int64, device=wire_dev)
     for j, o in enumerate(outs):
         meta[j] = o.numel()
-    meta[slots - 1] = _DTYPES.index(outs[0].dtype) if outs else -1
+    code = _dtype_code(outs[0].dtype) if outs else -1
+    meta[slots - 1] = code
     metas = [torch.empty_like(meta) for _ in range(world_size)] if rank == dst else None
     dist.gather(meta, gather_list=metas, dst=dst, group=group)
-    total = torch.tensor([sum(o.numel() * o.element_size() for o in outs)], dtype=torch.int64, device=wire_dev)
+    # [this rank's byte total, 1 if its forward_fn returned a dtype the wire cannot carry] -> MAX over ranks: every rank
+    # learns of the error inside the collective and raises after it, none is left waiting in the gather below
+    total = torch.tensor([sum(o.numel() * o.element_size() for o in outs), 1 if code == -2 else 0], dtype=torch.int64,
+                         device=wire_dev)
     dist.all_reduce(total, op=dist.ReduceOp.MAX, group=group)
-    wire = torch.zeros(max(int(total.item()), 1), dtype=torch.uint8, device=wire_dev)
+    if int(total[1]):
+        raise ValueError("synthesize_ragged: forward_fn returned a dtype the gather cannot carry"
+                         + (f" ({outs[0].dtype})" if code == -2 else " (on another rank)")
+                         + f"; supported: {', '.join(str(d) for d in _DTYPES)}")
+    wire = torch.zeros(max(int(total[0]), 1), dtype=torch.uint8, device=wire_dev)
     off = 0
     for o in outs:
         b = o.reshape(-1).view(torch.uint8).to(wire_dev)
@@ -215,17 +241,27 @@ def synthesize_sharded(forward_fn, mels, world_size=None, rank=None, dst=0, grou
     # Only this rank's REAL rows go through the generator (the filler rows of a ragged batch exist on the wire only:
     # scatter and gather want equal blocks); a rank without rows learns the row shape from the root.
     rows_here = hi - lo
+    if B == 0:                           # nothing to do on any rank (every rank knows B): no collective, an empty result
+        return torch.zeros((0, 0), dtype=torch.float32, device=block.device) if rank == dst else None
     wav = forward_fn(block[:rows_here].contiguous()).contiguous() if rows_here > 0 else None
-    if B < world_size:                   # some rank has nothing to run: the root tells everybody (samples per row, dtype)
-        info = torch.tensor([wav.shape[1], _DTYPES.index(wav.dtype)] if rank == dst else [0, 0], dtype=torch.int64,
-                            device="cpu" if dist.get_backend(group) == "gloo" else block.device)
-        dist.broadcast(info, src=dst, group=group)
+    if B < world_size:
+        # Some rank has nothing to run and cannot know the row shape / dtype.  The ranks that DID run something tell the
+        # others -- MAX over ranks of [samples per row, dtype code + 1, error flag]; a rank without rows contributes
+        # zeros.  (Not a broadcast from dst: dst itself may be a rank without rows.)
+        code = _dtype_code(wav.dtype) if wav is not None else -1
+        info = torch.tensor([wav.shape[1] if wav is not None else 0, max(code, -1) + 1, 1 if code == -2 else 0],
+                            dtype=torch.int64, device="cpu" if dist.get_backend(group) == "gloo" else block.device)
+        dist.all_reduce(info, op=dist.ReduceOp.MAX, group=group)
+        if int(info[2]):
+            raise ValueError("synthesize_sharded: forward_fn returned a dtype the gather cannot carry"
+                             + (f" ({wav.dtype})" if code == -2 else " (on another rank)")
+                             + f"; supported: {', '.join(str(d) for d in _DTYPES)}")
         if wav is None:
-            wav = torch.zeros((0, int(info[0])), dtype=_DTYPES[int(info[1])], device=block.device)
+            wav = torch.zeros((0, int(info[0])), dtype=_DTYPES[int(info[1]) - 1], device=block.device)
     if wav.shape[0] < per:
         wav = torch.cat([wav, torch.zeros((per - wav.shape[0], wav.shape[1]), dtype=wav.dtype, device=wav.device)], dim=0)
-    # RCCL / gloo have no 16-bit integer type: int16 PCM travels as its bytes
-    wire = wav.view(torch.uint8) if wav.dtype == torch.int16 else wav
+    # RCCL / gloo have no 16-bit integer type (and gloo no bf16): anything but fp32 / fp64 / fp16 travels as its bytes
+    wire = wav if wav.dtype in (torch.float32, torch.float64, torch.float16) else wav.view(torch.uint8)
     if staged:
         wire = wire.cpu()
     bufs = [torch.empty_like(wire) for _ in range(world_size)] if rank == dst else None

@@ -150,6 +150,63 @@ def _worker_job(rank, world, port, B, T):
         dist.destroy_process_group()
 
 
+def _worker_edges(rank, world, port):
+    """The corners round 4's review found: a root without rows, an empty batch, a module whose tensors do not pack to
+    aligned offsets, and a forward_fn whose dtype the wire cannot carry (every rank must raise, none may hang)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mels = torch.rand(1, 5, 7, generator=torch.Generator().manual_seed(5))
+        # B < world with dst = the rank that has NO rows (shard_range gives the only row to rank 0)
+        for dst in range(world):
+            out = parallel.synthesize_sharded(_fake_generator, mels, dst=dst)
+            assert (torch.equal(out, _fake_generator(mels)) if rank == dst else out is None), (rank, dst)
+            out = parallel.synthesize_sharded(lambda b: (_fake_generator(b) * 9).to(torch.int16),
+                                              mels if rank == dst else None, dst=dst, scatter=True, device=torch.device("cpu"))
+            assert (out.dtype == torch.int16 and out.shape == (1, 21)) if rank == dst else out is None
+        # an empty batch: an empty result on the root, no collective left half-entered
+        out = parallel.synthesize_sharded(_fake_generator, mels[:0])
+        assert (out.shape[0] == 0) if rank == 0 else out is None
+        dist.barrier()
+        # mixed dtypes at unaligned byte offsets: 13 fp32 (52 bytes), then int64, bool, fp16, fp64
+        class Odd(torch.nn.Module):
+            def __init__(self, seed):
+                super().__init__()
+                g = torch.Generator().manual_seed(seed)
+                self.a = torch.nn.Parameter(torch.rand(13, generator=g))
+                self.register_buffer("n", torch.randint(0, 1 << 40, (3,), generator=g))
+                self.register_buffer("m", torch.rand(5, generator=g) > 0.5)
+                self.register_buffer("h", torch.rand(3, generator=g).to(torch.float16))
+                self.register_buffer("d", torch.rand(2, generator=g).to(torch.float64))
+        net, ref = Odd(rank + 1), Odd(1)
+        parallel.broadcast_weights(net, src=0)
+        for (ka, a), (kb, b) in zip(sorted(net.state_dict().items()), sorted(ref.state_dict().items())):
+            assert ka == kb and a.dtype == b.dtype and torch.equal(a, b), ka
+        # more wire dtypes: bf16 and int32 come back as they were produced
+        for dt in (torch.bfloat16, torch.int32):
+            fn = lambda b, dt=dt: (_fake_generator(b) * 64).to(dt)
+            m3 = torch.rand(3, 5, 7, generator=torch.Generator().manual_seed(6))
+            out = parallel.synthesize_sharded(fn, m3)
+            assert (out.dtype == dt and torch.equal(out, fn(m3))) if rank == 0 else out is None
+            res = parallel.synthesize_ragged(fn, [m3[0], m3[1][:, :4], m3[2][:, :6]])
+            assert (res[1].dtype == dt and torch.equal(res[1], fn(m3[1][None, :, :4])[0])) if rank == 0 else res is None
+        # a dtype outside the wire's list: ValueError on EVERY rank, after the collective (nobody hangs)
+        bad = lambda b: torch.complex(_fake_generator(b), _fake_generator(b))
+        with pytest.raises(ValueError, match="dtype"):
+            parallel.synthesize_ragged(bad, [mels[0]])          # one utterance: only rank 0 runs forward_fn
+        with pytest.raises(ValueError, match="dtype"):
+            parallel.synthesize_sharded(bad, mels)              # B < world: only rank 0 has a row
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharding_edge_cases_gloo(world):
+    mp.spawn(_worker_edges, args=(world, _free_port()), nprocs=world, join=True)
+
+
 def test_job_of_512_utterances_over_8_ranks_gloo():
     """BASELINE.json configs[4]'s control flow at full utterance count and world size (tiny T), on CPU."""
     mp.spawn(_worker_job, args=(8, _free_port(), 512, 4), nprocs=8, join=True)
