@@ -154,6 +154,11 @@ def cpu_baseline(cfg, sd, mel):
 
 # The other single-GPU BASELINE.json configs (parity-test cases; the headline stays configs[1]): label, model name, yaml,
 # batch, frames, golden fixture, timed steps.  Utterance 0 of every batch is the mel its golden was made from.
+# The timed steps are pipelined (stream-ordered) forwards: the range guard is the explicit opt-in "lazy" -- the guard word
+# is read by check_range() AFTER the steps (asserted clean) instead of by a stream drain inside every step.  The default
+# policy ("auto" = checked before every call returns) is timed beside it: range_guard.ms_per_step_sync_checked.
+BENCH_RANGE_GUARD = "lazy"
+
 OTHER_CONFIGS = [
     ("config1_melgan_T200_B1", "melgan", "conf/melgan/original.yaml", 1, 200, "synthesize_melgan.npz", 50),
     ("config3_mb_hifigan_light_pqmf_B32", "multiband-hifigan", "conf/multiband-hifigan/light.yaml", 32, 1000, "full_mb_light.npz", 4),
@@ -173,6 +178,7 @@ def other_configs(dev):
         m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(name, cfg, seed=0).items()})
         m = m.to(dev).eval()
         m.remove_weight_norm()
+        m.range_guard = BENCH_RANGE_GUARD                 # checked after the timed steps (m.check_range() below)
         g = np.load(os.path.join(ROOT, "tests", "golden", golden))
         if name == "melgan":
             first = np.random.RandomState(0).rand(80, T).astype(np.float32)      # config 1's mel (make_golden.py)
@@ -445,6 +451,7 @@ def build_model(config, dev, dist, rank, precision="split"):
     cfg = load_conf(config)
     model = build_generator(MODEL, cfg)
     model.precision = precision
+    model.range_guard = BENCH_RANGE_GUARD                 # every timed region below ends in model.check_range()
     sd = seeded_state_dict(MODEL, cfg, seed=0) if rank == 0 else None
     if rank == 0:
         model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -505,6 +512,27 @@ def run_job(args, dev, dist, world, rank, steps, warmup):
     return elapsed, samples_per_utt, total_utt, workload, extra
 
 
+def world_error(gpus, world, local_rank, visible, one_gpu=False):
+    """Why this launch cannot run as asked, or None.  `--gpus N` must be the world torch.distributed.run started and every
+    rank needs a device of its own: a run that silently fell back to fewer GPUs (ranks sharing a device, or N > 1
+    started as one process) would report an N-GPU figure that is not one."""
+    if gpus < 1:
+        return f"--gpus {gpus}: need at least one GPU"
+    if gpus > 1 and world == 1:
+        return ("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if gpus != world:
+        return f"--gpus {gpus} but WORLD_SIZE = {world}: launch exactly one rank per GPU asked for"
+    if one_gpu:                      # FV_BENCH_ONE_GPU=1 (tests): every rank on device 0, declared as such
+        return None if visible >= 1 else "no GPU visible"
+    if world > visible:
+        return (f"--gpus {gpus} needs {world} visible devices, this node shows {visible} "
+                "(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?): refusing to run ranks on shared devices")
+    if local_rank >= visible:
+        return f"LOCAL_RANK {local_rank} has no device (visible: {visible})"
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -528,12 +556,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        sys.exit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                 "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     # FV_BENCH_ONE_GPU=1 (tests): every rank on device 0 -- world_size > 1 through the real generator on a 1-GPU box
-    if os.environ.get("FV_BENCH_ONE_GPU", "0") == "1":
+    one_gpu = os.environ.get("FV_BENCH_ONE_GPU", "0") == "1"
+    err = world_error(args.gpus, world, local_rank, torch.cuda.device_count(), one_gpu)
+    if err:
+        sys.exit("bench.py: " + err)
+    if one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -581,7 +610,7 @@ def main():
         use_gather = gather is not None and not args.no_gather
         step, done = make_step(model, use_gather)
         elapsed, wav = timed_steps(step, steps, warmup, dist, dev, after=done)
-        # the timed forwards ran stream-ordered (range_guard "auto": forward's check is deferred): the check, now
+        # the timed forwards ran stream-ordered (range_guard "lazy", set explicitly: the check is deferred): the check, now
         guard_clean = not model.check_range()
         assert guard_clean, "a timed forward left the split-f16 range: its output is not the reference's"
         if use_gather:
@@ -663,14 +692,16 @@ def main():
             enq = (time.perf_counter() - t0) / 10
             torch.cuda.synchronize()
             out["host_enqueue_ms_per_forward"] = 1e3 * enq
-            # the range guard (engine.NativeModule.range_guard): forward checks lazily under the default policy; the
-            # same steps with a synchronous check per call (what `inference` does) beside them
-            model.range_guard = "sync"
+            # the range guard (engine.NativeModule.range_guard): the timed steps ran under the explicit "lazy" opt-in; the
+            # same steps under the DEFAULT policy ("auto": every call checked before it returns) beside them
+            model.range_guard = "auto"
             stepg, doneg = make_step(model, False)
             eg, _ = timed_steps(stepg, min(steps, 20), 2, None, dev, after=doneg)
-            model.range_guard = "auto"
-            out["range_guard"] = {"policy": "auto: forward checks at the next call / check_range(), inference before it "
-                                            "returns", "timed_steps_clean": guard_clean,
+            model.range_guard = BENCH_RANGE_GUARD
+            out["range_guard"] = {"policy": "timed steps: range_guard = 'lazy' (explicit opt-in: stream-ordered forwards, "
+                                            "model.check_range() after the steps -- asserted clean); the module default "
+                                            "'auto' checks every call before it returns: ms_per_step_sync_checked",
+                                  "timed_under": BENCH_RANGE_GUARD, "timed_steps_clean": guard_clean,
                                   "ms_per_step_sync_checked": 1e3 * eg / min(steps, 20)}
             # PCIe-inclusive rate of the drop-in boundary (never `value`): Generator.inference takes a
             # HOST mel [T,80] and the caller wants a HOST waveform -- pageable numpy in, numpy out,

@@ -606,13 +606,15 @@ class NativeModule(torch.nn.Module):
                      "sync" -- every call waits for its kernels and reads the guard word they raise; an out-of-range
                          call is repeated on the fp32 kernels before it returns, and the module stays on them (one
                          warning).  Results are always the reference's; calls are synchronous.
-                     "lazy" -- calls stay stream-ordered (asynchronous); the word is looked at when the NEXT call
-                         starts (and by ``check_range()``): the module then switches to the fp32 kernels with a
-                         warning, but the call that overflowed has already returned non-finite values.
-                     "auto" (default) -- "sync" for the calls whose result is bound for the host (``inference``,
-                         ``inference_minus``, the Synthesizer flows: the reference's drop-in surface -- the caller's
-                         ``.cpu()`` waits for the stream anyway), "lazy" for ``forward`` and the standalone blocks
-                         (tensor in, tensor out, pipelined by the caller; ``check_range()`` is the explicit barrier).
+                     "auto" (default) -- the same as "sync", for EVERY entry (``forward``, the standalone blocks,
+                         ``inference``, ``inference_minus``, the Synthesizer flows): whatever a call returns is the
+                         reference's result.  (Until round 5 ``forward`` checked lazily under "auto"; a tensor-in /
+                         tensor-out call could then return non-finite values and only the next call noticed.)
+                     "lazy" -- an explicit opt-in for pipelined callers: calls stay stream-ordered (asynchronous); the
+                         word is looked at when the NEXT call starts (and by ``check_range()``, the explicit barrier):
+                         the module then switches to the fp32 kernels with a warning, but the call that overflowed has
+                         already returned non-finite values.  ``bench.py`` times its steps under "lazy" (and says so),
+                         calls ``check_range()`` after them, and reports the "sync" figure beside.
                      "off"  -- no check.
     ``fuse_pairs``   ResBlock1 pairs as fused launches (default) or conv by conv (round-1 path; A/B runs).
     ``fold_post``    HiFi-GAN's conv_post inside the last pair's launch (default) or as a launch of its own.
@@ -744,11 +746,13 @@ class NativeModule(torch.nn.Module):
 
     def _exec(self, plan_for, x, sync=False, **run_kw):
         """``plan_for(T).run(x, **run_kw)`` under the module's range guard (class docstring); ``sync``: the result is
-        bound for the host ("auto" checks it before returning).  ``plan_for`` must resolve the plan through
+        bound for the host (informational since round 5: "auto" checks every call before returning).  ``plan_for`` must resolve the plan through
         :meth:`_plan` every time it is called: after an overflow it returns the fp32 plan."""
         mode = self.range_guard
-        if mode == "auto":
-            mode = "sync" if sync else "lazy"
+        if mode == "auto":              # safe by default: every call is checked before it returns (class docstring)
+            mode = "sync"
+        elif mode not in ("sync", "lazy", "off"):
+            raise ValueError(f"range_guard = {mode!r}: 'auto', 'sync', 'lazy' or 'off'")
         if mode == "lazy" and not self._fv_overflow and self._fv_guard is not None and self._fv_guard.peek(0):
             self._fv_guard.clear(0)
             self._went_out_of_range("an EARLIER call met an activation (its output holds non-finite values)")

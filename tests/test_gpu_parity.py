@@ -909,9 +909,10 @@ def _scaled_hifigan(gain, seed=0):
 
 
 def test_generator_beyond_the_f16_range_repeats_on_fp32():
-    """Activations beyond 65504 inside the generator: `inference` (range_guard "auto" = synchronous) notices, repeats
-    the call on the exact-fp32 kernels and returns what a precision = "f32" model returns, bit for bit; the module
-    then stays on the fp32 kernels.  `forward` (deferred check) reports at the next call / check_range()."""
+    """Activations beyond 65504 inside the generator: every entry under the default policy (range_guard "auto" =
+    checked before the call returns) -- `inference` AND `forward` -- notices, repeats the call on the exact-fp32 kernels
+    and returns what a precision = "f32" model returns, bit for bit; the module then stays on the fp32 kernels.  The
+    explicit opt-in "lazy" defers the check to the next call / check_range()."""
     mel = seeded_mel(64, seed=31)
     exact = _scaled_hifigan(1e6)
     exact.precision = "f32"
@@ -930,9 +931,19 @@ def test_generator_beyond_the_f16_range_repeats_on_fp32():
     sd = {k: v.detach().cpu().numpy() for k, v in exact.state_dict().items()}
     ref = torch_port.inference("hifigan", mel, sd, cases.load_conf("conf/hifigan/light.yaml")).numpy()
     assert _err(want, ref) <= TOL
-    # forward: stream-ordered, the check is deferred
-    lazy = _scaled_hifigan(1e6)
+    # forward under the DEFAULT policy: checked before it returns, with or without torch.no_grad()
     x = torch.from_numpy(np.ascontiguousarray(mel.T[None])).to(_dev())      # the same mel, forward layout [1, 80, T]
+    dflt = _scaled_hifigan(1e6)
+    assert dflt.range_guard == "auto"
+    with pytest.warns(RuntimeWarning, match="split-f16 range"), torch.no_grad():
+        assert torch.equal(dflt(x)[0], want)
+    assert dflt._fv_policy()[0] == "f32"
+    dflt2 = _scaled_hifigan(1e6)
+    with pytest.warns(RuntimeWarning, match="split-f16 range"):
+        assert torch.equal(dflt2(x)[0], want)
+    # forward under the explicit opt-in "lazy": stream-ordered, the check is deferred
+    lazy = _scaled_hifigan(1e6)
+    lazy.range_guard = "lazy"
     with torch.no_grad():
         first = lazy(x)
         with pytest.warns(RuntimeWarning, match="split-f16 range"):

@@ -378,3 +378,20 @@ def test_checkpoint_loader_is_restricted_unless_asked(tmp_path):
     with pytest.raises(pickle.UnpicklingError):
         load_checkpoint(str(bad), "cpu")
     assert load_checkpoint(str(bad), "cpu", unsafe=True)["extra"] == os.path.join("never", "called")
+
+
+def test_bench_refuses_worlds_it_cannot_place():
+    """bench.py --gpus N: N must be the world torch.distributed.run started and every rank needs its own device --
+    the driver's first 8-GPU run cannot silently fall back to fewer devices."""
+    import bench
+    assert bench.world_error(1, 1, 0, 1) is None
+    assert bench.world_error(8, 8, 7, 8) is None
+    assert "torch.distributed.run" in bench.world_error(8, 1, 0, 8)          # N > 1 started as one process
+    assert "visible devices" in bench.world_error(8, 8, 0, 1)                # 8 ranks, one GPU
+    assert "visible devices" in bench.world_error(2, 2, 1, 1)
+    assert "WORLD_SIZE" in bench.world_error(4, 8, 0, 8)                      # flag and launcher disagree
+    assert "WORLD_SIZE" in bench.world_error(1, 2, 0, 2)
+    assert bench.world_error(2, 2, 5, 4) is not None                          # a local rank without a device
+    assert bench.world_error(0, 1, 0, 1) is not None
+    # the declared test mode: ranks share device 0 (tests/test_gpu_multi.py), never the default
+    assert bench.world_error(2, 2, 1, 1, one_gpu=True) is None
