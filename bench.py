@@ -292,7 +292,7 @@ def roofline_report(model, mel, ms_per_step, reps=5):
              "pair16": _native.KERNEL_PAIR16, "pair32": _native.KERNEL_PAIR32,
              "pairh16": _native.KERNEL_PAIRH16, "pairh32": _native.KERNEL_PAIRH32,
              "convh64": _native.KERNEL_CONVH64, "convh128": _native.KERNEL_CONVH128,
-             "convt": _native.KERNEL_CONVT, "narrow": _native.KERNEL_CONV_NARROW}
+             "convt": _native.KERNEL_CONVT, "narrow": _native.KERNEL_CONV_NARROW, "mrf16": _native.KERNEL_MRF16}
     rec = {k: _native.profile_collect(v) for k, v in kinds.items()}
     # What an event record costs between two kernels of this forward: the replay with events against the timed step
     # without them, per launch.  (Between two NULL kernels a record costs `bracket_ms`, ~5 us; next to a real kernel
@@ -310,7 +310,8 @@ def roofline_report(model, mel, ms_per_step, reps=5):
 
     fp32 = fam("conv32", "conv16", "pair16", "pair32")       # fp32 matrix cores (csrc/conv_kernels.hpp, pair_kernels.hpp)
     wide = fam("convh64", "convh128")                        # split-f16 convs with streamed weights (convh_kernels.hpp)
-    pairs = fam("pairh16", "pairh32")                        # split-f16 fused pairs (pairh_kernels.hpp)
+    pairs = fam("pairh16", "pairh32", "mrf16")               # split-f16 fused pairs (pairh_kernels.hpp) and the one-launch
+                                                             # 16-channel stage (mrfh_kernels.hpp)
     ups = fam("convt")                                       # split-f16 transposed convs (convt_kernel)
     all_ms = (fp32["ms"] + wide["ms"] + pairs["ms"] + ups["ms"] + rec["narrow"]["ms"]) / reps
     all_flops = fp32["flops"] + wide["flops"] + pairs["flops"] + ups["flops"]
@@ -392,8 +393,9 @@ def roofline_report(model, mel, ms_per_step, reps=5):
             "tflops": rate(fp32), "frac_of_fp32_mfma_peak": rate(fp32) / PEAK_FP32_MFMA_TFLOPS,
         },
         "split_f16_pairs": {
-            "kernel": "fv::pairh_kernel (fused ResBlock1 pairs of the 32- and 16-channel stages, split-f16 operands, "
-                      "intermediate in LDS; csrc/pairh_kernels.hpp)",
+            "kernel": "fv::pairh_kernel (fused ResBlock1 pairs of the 32-channel stage, split-f16 operands, intermediate in "
+                      "LDS; csrc/pairh_kernels.hpp) + fv::mrfh_kernel (the whole 16-channel stage and conv_post as ONE "
+                      "launch; csrc/mrfh_kernels.hpp)",
             "ms_per_step": pairs["ms"] / reps, "launches_per_step": pairs["launches"] // reps,
             "fp32_equivalent_tflops": rate(pairs),
             "external_gbs": pairs["bytes"] / (pairs["ms"] * 1e-3) / 1e9 if pairs["ms"] > 0 else 0.0,
@@ -412,7 +414,8 @@ def roofline_report(model, mel, ms_per_step, reps=5):
     })
     # The HBM-bound members (north star: "memory roofline on the dilated-conv kernels"): the 16-channel stage,
     # 12-44 FLOP/B, with SURVEY.md section 8(d)'s layer-by-layer bytes over the time of its launches
-    stage = rec["pairh16"] if rec["pairh16"]["launches"] else rec["pair16"] if rec["pair16"]["launches"] else rec["conv16"]
+    stage = (rec["mrf16"] if rec["mrf16"]["launches"] else rec["pairh16"] if rec["pairh16"]["launches"]
+             else rec["pair16"] if rec["pair16"]["launches"] else rec["conv16"])
     B = mel.shape[0]
     t_stage = T_FRAMES
     for up in model.ups:
@@ -421,7 +424,9 @@ def roofline_report(model, mel, ms_per_step, reps=5):
     st_ms = stage["ms"] / reps
     hbm = {
         "kernel": "the C = 16 stage of the generator (18 dilated / plain 16-channel convs on 240 000 samples): "
-                  + ("3 fused-pair launches (two of three members, the stage end of two) + the first block's last "
+                  + ("ONE launch -- nine fused pairs, the MRF mean and conv_post + tanh on LDS-resident tiles, the running x "
+                     "in registers (fv::mrfh_kernel, split-f16 operands, csrc/mrfh_kernels.hpp)" if rec["mrf16"]["launches"]
+                     else "3 fused-pair launches (two of three members, the stage end of two) + the first block's last "
                      "pair with the MRF merge (fv::pairh_kernel, split-f16 operands)" if rec["pairh16"]["launches"]
                      else "2 fused-pair launches + the fused MRF stage end (fv::pair_kernel, fv::pair_sum_kernel)"
                      if rec["pair16"]["launches"] else "16x16x4-MFMA conv launches"),
@@ -441,6 +446,20 @@ def roofline_report(model, mel, ms_per_step, reps=5):
         "tflops": stage["flops"] / (stage["ms"] * 1e-3) / 1e12 if stage["ms"] > 0 else 0.0,
         "measured": "per-launch HIP events, completion to completion (event cost subtracted); HBM traffic by PMC: profiles/",
     }
+    if rec["mrf16"]["launches"] and st_ms > 0:
+        # One launch moves the stage's input once and 4 bytes per sample out: the external bytes are 1/18 of round 4's, and
+        # what bounds the launch is no longer HBM but the matrix cores -- three f16 MFMA FLOP per algorithmic FLOP, the
+        # zero tap that pads an odd tap count to whole K steps of 32, and the window columns a tile recomputes.
+        alg = stage["flops"] / reps
+        hbm["bound_now"] = {
+            "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F16_MFMA_TFLOPS / 3.0,
+            "achieved": alg / (st_ms * 1e-3) / 1e12, "frac": alg / (st_ms * 1e-3) / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3.0),
+            "algorithmic_gflop": alg / 1e9,
+            "floor_us_at_the_matrix_peak": 1e6 * alg * 3.0 / (PEAK_F16_MFMA_TFLOPS * 1e12),
+            "floor_us_at_the_hbm_peak": 1e6 * stage["bytes"] / reps / (PEAK_HBM_GBS * 1e9),
+            "what": "the one-launch stage against its own two floors: 3 x algorithmic FLOP at the dense f16 MFMA peak, and its "
+                    "external bytes (input once, one float per sample out, weights) at 8 TB/s -- `frac` above is those bytes "
+                    "over the launch's time, a number that fusion makes SMALL; `effective` is the comparable one"}
     return roofline, hbm
 
 

@@ -19,18 +19,19 @@ _CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip", "wav_sink.hip", "conv_inst_narrow.hip",
            "pair_launch.hip", "pair_inst_c16.hip", "pair_inst_c32.hip", "pairh_inst_c16.hip", "pairh_inst_c32.hip",
            "convh_launch.hip", "convh_inst_c64.hip", "convh_inst_c128.hip", "convp_inst.hip", "convt_inst.hip",
-           "convg_inst.hip", "convq_inst.hip", "convp_chain_inst.hip", "convr_inst.hip", "convtn_inst.hip", "convk_inst.hip", "convq2_inst.hip"] + \
+           "convg_inst.hip", "convq_inst.hip", "convp_chain_inst.hip", "convr_inst.hip", "convtn_inst.hip", "convk_inst.hip", "convq2_inst.hip",
+           "mrfh_launch.hip", "mrfh_inst_a.hip", "mrfh_inst_b.hip"] + \
           [f"conv_inst_s{i}.hip" for i in range(6)]
 HEADERS = ["fv_internal.h", "conv_kernels.hpp", "pair_kernels.hpp", "pair_inst.hpp", "pairh_kernels.hpp",
            "pairh_inst.hpp", "convh_kernels.hpp", "convh_inst.hpp", "convp_kernels.hpp", "convq_kernels.hpp", "convp_chain.hpp", "convr_kernels.hpp",
-           "convtn_kernels.hpp", "convk_kernels.hpp", "convq2_kernels.hpp"]
+           "convtn_kernels.hpp", "convk_kernels.hpp", "convq2_kernels.hpp", "mrfh_kernels.hpp", "mrfh_inst.hpp"]
 
 PAD_ZERO, PAD_REFLECT = 0, 1
 PAD_CAUSAL = 2      # flag: pad (k-1)*dil on both sides, keep the first Tin outputs (CausalConv1d)
 POST_NONE, POST_TANH, POST_RELU = 0, 1, 2
 SLOT_NONE, SLOT_IN, SLOT_OUT, SLOT_TMP0, MAX_SLOTS = -1, 0, 1, 2, 32
 SLOT_AUX_IN0, SLOT_AUX_IN1, SLOT_OUT2 = 28, 29, 30    # caller-provided tensors of Plan.run(aux=..., out2=...)
-ABI_VERSION = 10
+ABI_VERSION = 11
 PAIR_F32, PAIR_SPLIT_F16 = 0, 1   # arithmetic of the fused ResBlock-pair kernels (fastvocoder_hip.h)
 
 
@@ -195,6 +196,12 @@ def lib():
     L.fv_plan_add_resblock_pair_ex.argtypes = [vp, i, i, i, i, i, i, vp, vp, vp, vp, i, i, i, f, f, i, f, i]
     L.fv_conv1d_split_f16.argtypes = [i, pp, pp, pp, pp, pp, pp, pp, pp, ctypes.POINTER(i), i, i, i, i, i, f, f, i, f, vp, vp]
     L.fv_plan_set_pair_output_conv.argtypes = [vp, vp, vp, i, f, i]
+    L.fv_packed_mrf_stage_floats.argtypes = [i, ctypes.POINTER(i)]
+    L.fv_packed_mrf_stage_floats.restype = i64
+    L.fv_pack_mrf_stage_split_f16.argtypes = [pp, pp, pp, pp, vp, i, ctypes.POINTER(i), vp, vp]
+    L.fv_mrf_stage_split_f16.argtypes = [vp, vp, vp, vp, i, i, i, ctypes.POINTER(i), ctypes.POINTER(i), f, f, i, f, vp, vp, vp,
+                                         vp, vp]
+    L.fv_plan_add_mrf_stage_split_f16.argtypes = [vp, i, i, i, vp, i, ctypes.POINTER(i), ctypes.POINTER(i), f, f, i, f]
     L.fv_plan_add_conv1d_split_f16.argtypes = [vp, i, i, i, i, i, i, vp, vp, i, i, i, i, f, f, i, f]
     L.fv_plan_add_mrf_sum.argtypes = [vp, ctypes.POINTER(i), i, i, pp, pp, pp, pp, i, ctypes.POINTER(i), i, f, f, i, f]
     L.fv_plan_create.argtypes = [i]
@@ -541,6 +548,66 @@ def conv1d_split_f16(xs, packed, biases, ks, dil, pre_slope=1.0, res=None, add1=
     return outs
 
 
+MRF_STAGE_DILATIONS = (1, 3, 5)
+
+
+def mrf_stage_supported(channels, ks, dils):
+    """Shapes the one-launch MRF stage kernel is built for (csrc/mrfh_launch.hip): 16 channels, three ResBlocks with
+    3 / 7 / 11 taps (any order), pair dilations (1, 3, 5)."""
+    return channels == 16 and len(ks) == 3 and all(k in (3, 7, 11) for k in ks) and tuple(dils) == MRF_STAGE_DILATIONS
+
+
+def pack_mrf_stage(w1s, w2s, b1s, b2s, ks, flag=None):
+    """The 18 convs of a 16-channel MRF stage -> the packed stage of fv_mrf_stage_split_f16 (flat tensor).  w1s / w2s:
+    nine [16, 16, k_j] weights in the order pair p of ResBlock j at index 3 j + p; b1s / b2s: nine [16] biases or None;
+    ks: the three ResBlocks' taps.  ``flag``: raised for a non-finite weight (as pack_pair)."""
+    w1s = [w.detach().contiguous().float() for w in w1s]
+    w2s = [w.detach().contiguous().float() for w in w2s]
+    b1s = [None if b is None else b.detach().contiguous().float() for b in b1s]
+    b2s = [None if b is None else b.detach().contiguous().float() for b in b2s]
+    if not (len(w1s) == len(w2s) == len(b1s) == len(b2s) == 9 and len(ks) == 3):
+        raise NativeError("pack_mrf_stage: nine pairs (three ResBlocks x three positions) expected")
+    c = w1s[0].shape[0]
+    for i, w in enumerate(w1s + w2s):
+        if tuple(w.shape) != (c, c, ks[(i % 9) // 3]):
+            raise NativeError(f"pack_mrf_stage: weight {i} has shape {tuple(w.shape)}, expected {(c, c, ks[(i % 9) // 3])}")
+    karr = (ctypes.c_int * 3)(*ks)
+    nfl = lib().fv_packed_mrf_stage_floats(c, karr)
+    if nfl <= 0:
+        raise NativeError(f"pack_mrf_stage: no packed layout for C={c} taps={list(ks)}")
+    out = torch.empty(nfl, dtype=torch.float32, device=w1s[0].device)
+    with _on(*w1s, *w2s, *b1s, *b2s, out) as stream:
+        check(lib().fv_pack_mrf_stage_split_f16(_vp_array(w1s, "w1"), _vp_array(w2s, "w2"), _vp_array(b1s, "b1", True),
+                                                _vp_array(b2s, "b2", True), _ptr(out), c, karr, _flag_ptr(flag), stream))
+    return out
+
+
+def mrf_stage_split_f16(x, packed, ks, dils=MRF_STAGE_DILATIONS, slope=0.1, out_div=3.0, post=POST_NONE, act_slope=1.0,
+                        out=None, out_act=None, fold=None, guard=None):
+    """A whole 16-channel MRF stage in one launch (fv_mrf_stage_split_f16): y = post(((r0 + r1) + r2) / out_div) with
+    r_j = ResBlock1_j(x); ``packed`` from pack_mrf_stage.  ``fold`` = (w [16, 7], bias [1] or None): returns
+    post(conv1d(lrelu(y, act_slope); w, padding 3) + bias), [B, 1, T], instead of y."""
+    B, C, T = x.shape
+    karr, darr = (ctypes.c_int * 3)(*ks), (ctypes.c_int * 3)(*dils)
+    if fold is not None:
+        fw, fb = fold
+        fw = fw.detach().contiguous().float()
+        fb = None if fb is None else fb.detach().contiguous().float()
+        res = torch.empty((B, 1, T), dtype=torch.float32, device=x.device)
+        with _on(x, packed, fw, fb, res) as stream:
+            check(lib().fv_mrf_stage_split_f16(_ptr(x, "x"), _ptr(packed, "packed"), None, None, B, C, T, karr, darr,
+                                               float(slope), float(out_div), post, float(act_slope), _ptr(fw, "fold_w"),
+                                               _ptr(fb, "fold_b", True), _ptr(res), _guard_ptr(guard), stream))
+        return res
+    if out is None:
+        out = torch.empty_like(x)
+    with _on(x, packed, out, out_act) as stream:
+        check(lib().fv_mrf_stage_split_f16(_ptr(x, "x"), _ptr(packed, "packed"), _ptr(out, "y"), _ptr(out_act, "y_act", True),
+                                           B, C, T, karr, darr, float(slope), float(out_div), post, float(act_slope), None,
+                                           None, None, _guard_ptr(guard), stream))
+    return out
+
+
 def mrf_stage(xs, w1s, w2s, b1s, b2s, ks, dil, slope, out_div=3.0, post=POST_NONE, act_slope=1.0, out=None,
               out_act=None):
     """y = post(sum_j pair_j(x_j) / out_div): the last pairs of three ResBlocks + the MRF mean (fv_mrf_stage)."""
@@ -850,6 +917,14 @@ class Plan:
                                                  _ptr(bias2, "bias2", True), channels, k, dil, float(slope),
                                                  float(out_div), post, float(act_slope), prec))
 
+    def add_mrf_stage(self, x, y, packed, channels, ks, dils, slope, out_div=3.0, post=POST_NONE, y_act=SLOT_NONE,
+                      act_slope=1.0):
+        """A whole 16-channel MRF stage as one op / one launch (fv_plan_add_mrf_stage_split_f16)."""
+        self.keep(packed)
+        check(lib().fv_plan_add_mrf_stage_split_f16(self._h, x, y, y_act, _ptr(packed, "packed"), channels,
+                                                    (ctypes.c_int * 3)(*ks), (ctypes.c_int * 3)(*dils), float(slope),
+                                                    float(out_div), post, float(act_slope)))
+
     def set_pair_output_conv(self, w, bias, y, act_slope, post=POST_NONE):
         """Fold a 16 -> 1 channel, 7-tap conv into the resblock pair appended last (fv_plan_set_pair_output_conv):
         ``y`` becomes post(conv(lrelu(pair result, act_slope)) + bias), [B, 1, T]."""
@@ -1002,6 +1077,7 @@ def profile_enable(on):
 KERNEL_CONV_MFMA32, KERNEL_CONV_MFMA16, KERNEL_CONV_NARROW, KERNEL_PAIR16, KERNEL_PAIR32 = 0, 1, 2, 3, 4
 KERNEL_PAIRH16, KERNEL_PAIRH32, KERNEL_CONVH64, KERNEL_CONVH128, KERNEL_CONVT, KERNEL_CONVG = 5, 6, 7, 8, 9, 10
 KERNEL_STACK = 11
+KERNEL_MRF16 = 12     # a whole 16-channel MRF stage as one launch (mrfh_kernel)
 
 
 def profile_bracket_cost(n=200):

@@ -372,7 +372,7 @@ __global__ void pack_convth_kernel(const float* __restrict__ w, _Float16* __rest
 // ---------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------
-enum OpType { OP_CONV = 0, OP_CONVT = 1, OP_PQMF = 2, OP_UPCONV = 3, OP_PAIR = 4, OP_MRFSUM = 5, OP_CONVH = 6, OP_CONVG = 7, OP_STACK = 8 };
+enum OpType { OP_CONV = 0, OP_CONVT = 1, OP_PQMF = 2, OP_UPCONV = 3, OP_PAIR = 4, OP_MRFSUM = 5, OP_CONVH = 6, OP_CONVG = 7, OP_STACK = 8, OP_STAGE = 9 };
 
 struct Op {
     int type;
@@ -407,6 +407,7 @@ struct Op {
     const float* pb1[3] = {nullptr, nullptr, nullptr};
     const float* pb2[3] = {nullptr, nullptr, nullptr};
     int pk[3] = {0, 0, 0};
+    int sdil[3] = {0, 0, 0};  // OP_STAGE: dilations of the three pair positions (pk: taps of the three ResBlocks; wp: the packed stage)
     int prec = 0;             // FV_PAIR_F32 / FV_PAIR_SPLIT_F16
     bool in_merge = false;    // fv_plan_set_input_merge (split-f16 transposed conv): the input is ((x + xb) + xc) / out_div
     // fv_plan_set_pair_output_conv: a 16 -> 1 channel, 7-tap conv folded into the pair; y is ITS output [B, 1, T]
@@ -445,7 +446,9 @@ struct fv_plan {
 namespace fv {
 
 static int64_t conv_out_len(const Op& o, int64_t Tin) {
-    if (o.type == OP_PAIR || o.type == OP_MRFSUM || o.type == OP_CONVH || o.type == OP_CONVG || o.type == OP_STACK) return Tin;
+    if (o.type == OP_PAIR || o.type == OP_MRFSUM || o.type == OP_CONVH || o.type == OP_CONVG || o.type == OP_STACK ||
+        o.type == OP_STAGE)
+        return Tin;
     if (o.type == OP_CONV) {
         const int64_t t = (o.pad_mode & FV_PAD_CAUSAL) ? Tin : Tin + 2LL * o.pad - (int64_t)o.dil * (o.k - 1);
         return o.pq_h ? t * o.Cout : t;      // (conv_post + pqmf: the S sub-bands interleave into S * T' samples)
@@ -741,7 +744,7 @@ static const TuningEntry kTuningTable[] = {
     {"pair_blocks", &Tuning::pair_blocks}, {"sum3_min", &Tuning::sum3_min},      {"lds_budget", &Tuning::lds_budget},
     {"units", &Tuning::units},             {"shape16", &Tuning::shape16},        {"shape32", &Tuning::shape32},
     {"shape64", &Tuning::shape64},         {"krows", &Tuning::krows},            {"grid_cap", &Tuning::grid_cap},
-    {"no_group", &Tuning::no_group},
+    {"no_group", &Tuning::no_group},       {"mrf_blocks", &Tuning::mrf_blocks},  {"mrf_shape", &Tuning::mrf_shape},
 };
 static void tuning_from_env() {
     const char* on = getenv("FV_TUNING");
@@ -1683,6 +1686,113 @@ int fv_mrf_stage(const float* const* x, const float* const* w1, const float* con
     return launch_pairs(pp, C, dil, (hipStream_t)stream);
 }
 
+// ---- a whole 16-channel MRF stage as one launch (csrc/mrfh_kernels.hpp) ----------------------------------------------
+int64_t fv_packed_mrf_stage_floats(int C, const int* k) {
+    const int dil[3] = {1, 3, 5};
+    if (!k || !mrf_stage_shape(C, k, dil)) return 0;
+    int64_t bytes = 0;
+    for (int j = 0; j < 3; ++j) bytes += 3LL * mrf_block_bytes(C, k[j]);
+    return bytes / 4;
+}
+
+int fv_pack_mrf_stage_split_f16(const float* const* w1, const float* const* w2, const float* const* b1,
+                                const float* const* b2, float* packed, int C, const int* k, int* range_flag, void* stream) {
+    const int64_t floats = fv_packed_mrf_stage_floats(C, k);
+    if (floats == 0) return fail(FV_ERR_UNSUPPORTED, "pack_mrf_stage: shape not built (16 channels, taps 3 / 7 / 11)");
+    if (!w1 || !w2 || !packed) return fail(FV_ERR_INVALID_ARG, "pack_mrf_stage: null tensor");
+    hipStream_t const s = (hipStream_t)stream;
+    FV_HIP(hipMemsetAsync(packed, 0, (size_t)floats * 4, s));          // absent biases and the blocks' padding: zeros
+    char* at = reinterpret_cast<char*>(packed);
+    for (int j = 0; j < 3; ++j)
+        for (int q = 0; q < 3; ++q) {
+            const int i = 3 * j + q;
+            if (!w1[i] || !w2[i]) return fail(FV_ERR_INVALID_ARG, "pack_mrf_stage: null weight (pair %d)", i);
+            const int wb = (mrf_block_bytes(C, k[j]) - 1024) / 2;       // bytes of one conv's image
+            float* const tail = reinterpret_cast<float*>(at + 2 * wb);  // [b1 | b2 | s1 | s2]
+            const float* const ws[2] = {w1[i], w2[i]};
+            for (int c = 0; c < 2; ++c) {
+                float* const inv = tail + (2 + c) * C;
+                hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)C), dim3(64), 0, s, ws[c], (const float*)nullptr, inv, C,
+                                   C * k[j], 0, 0, 0);
+                const int64_t total = (int64_t)wb / 2;                  // halves of the image
+                hipLaunchKernelGGL(pack_pairh_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws[c],
+                                   reinterpret_cast<_Float16*>(at + c * wb), inv, C, k[j], range_flag);
+            }
+            if (b1 && b1[i]) FV_HIP(hipMemcpyAsync(tail, b1[i], (size_t)C * 4, hipMemcpyDeviceToDevice, s));
+            if (b2 && b2[i]) FV_HIP(hipMemcpyAsync(tail + C, b2[i], (size_t)C * 4, hipMemcpyDeviceToDevice, s));
+            at += mrf_block_bytes(C, k[j]);
+        }
+    FV_HIP(hipGetLastError());
+    return 0;
+}
+
+static int check_stage_args(int C, const int* k, const int* dil, float slope, float act_slope, int post) {
+    if (!k || !dil) return fail(FV_ERR_INVALID_ARG, "mrf stage: null taps / dilations");
+    if (!mrf_stage_shape(C, k, dil))
+        return fail(FV_ERR_UNSUPPORTED, "mrf stage: C = %d, taps (%d, %d, %d), dilations (%d, %d, %d): built for 16 channels, "
+                    "taps 3 / 7 / 11, dilations (1, 3, 5)", C, k[0], k[1], k[2], dil[0], dil[1], dil[2]);
+    if (slope < 0.f || slope > 1.f || act_slope < 0.f || act_slope > 1.f)
+        return fail(FV_ERR_INVALID_ARG, "mrf stage: activation slope outside [0, 1]");
+    if (post != FV_POST_NONE && post != FV_POST_TANH && post != FV_POST_RELU) return fail(FV_ERR_INVALID_ARG, "mrf stage: post %d", post);
+    return 0;
+}
+
+int fv_mrf_stage_split_f16(const float* x, const float* packed, float* y, float* y_act, int B, int C, int T, const int* k,
+                           const int* dil, float slope, float out_div, int post, float act_slope, const float* fold_w,
+                           const float* fold_b, float* fold_y, int* guard, void* stream) {
+    if (int rc = check_stage_args(C, k, dil, slope, act_slope, post)) return rc;
+    if (B < 0 || T < 0) return fail(FV_ERR_INVALID_ARG, "mrf stage: B=%d T=%d", B, T);
+    MrfParams p = {};
+    p.x = x;
+    p.y = y;
+    p.y_act = y_act;
+    p.blob = packed;
+    for (int j = 0; j < 3; ++j) p.k[j] = k[j];
+    p.B = B;
+    p.T = T;
+    p.slope = slope;
+    p.out_div = out_div;
+    p.act_slope = act_slope;
+    p.post = post;
+    p.fold_w = fold_w;
+    p.fold_b = fold_b;
+    p.fold_y = fold_y;
+    p.guard = guard;
+    return launch_mrfh(p, C, dil, (hipStream_t)stream);
+}
+
+int fv_plan_add_mrf_stage_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed, int C,
+                                    const int* k, const int* dil, float slope, float out_div, int post, float act_slope) {
+    if (!plan || !packed) return fail(FV_ERR_INVALID_ARG, "plan_add_mrf_stage: null");
+    if (int rc = check_stage_args(C, k, dil, slope, act_slope, post)) return rc;
+    if (int rc = check_slot(x_slot, false)) return rc;
+    if (int rc = check_slot(y_slot, false)) return rc;
+    if (int rc = check_slot(y_act_slot, true)) return rc;
+    if (y_slot == FV_SLOT_IN || y_act_slot == FV_SLOT_IN) return fail(FV_ERR_INVALID_ARG, "plan: the input slot is read-only");
+    Op o = {};
+    o.type = OP_STAGE;
+    o.x = x_slot;
+    o.y = y_slot;
+    o.y2 = y_act_slot;
+    o.res = o.acc = o.acc2 = FV_SLOT_NONE;
+    o.group = 0;
+    o.Cin = o.Cout = C;
+    o.k = k[0];
+    o.dil = dil[0];
+    for (int j = 0; j < 3; ++j) {
+        o.pk[j] = k[j];
+        o.sdil[j] = dil[j];
+    }
+    o.wp = packed;
+    o.pre_slope = slope;
+    o.act_slope = act_slope;
+    o.out_div = out_div;
+    o.post = post;
+    o.prec = FV_PAIR_SPLIT_F16;
+    plan->ops.push_back(o);
+    return 0;
+}
+
 int fv_plan_add_resblock_pair(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed1,
                               const float* packed2, const float* bias1, const float* bias2, int C, int k, int dil,
                               float slope, float act_slope) {
@@ -1890,10 +2000,10 @@ int fv_plan_set_pair_output_conv(fv_plan_t* plan, const float* w, const float* b
     if (!plan || plan->ops.empty() || !w) return fail(FV_ERR_INVALID_ARG, "plan_set_pair_output_conv: no op / null weights");
     if (int rc = check_slot(y_slot, false)) return rc;
     Op& o = plan->ops.back();
-    if (o.type != OP_PAIR || o.prec != FV_PAIR_SPLIT_F16 || o.Cin != 16 || o.group != 0 || o.y2 != FV_SLOT_NONE ||
-        o.post != FV_POST_NONE || o.fold_w)
+    if ((o.type != OP_PAIR && o.type != OP_STAGE) || o.prec != FV_PAIR_SPLIT_F16 || o.Cin != 16 || o.group != 0 ||
+        o.y2 != FV_SLOT_NONE || o.post != FV_POST_NONE || o.fold_w)
         return fail(FV_ERR_UNSUPPORTED, "plan_set_pair_output_conv: the last op must be an ungrouped 16-channel split-f16 "
-                    "resblock pair without an activated twin or a post op of its own");
+                    "resblock pair (or a one-launch MRF stage) without an activated twin or a post op of its own");
     if (y_slot == FV_SLOT_IN || y_slot == o.x || y_slot == o.acc || y_slot == o.acc2 || y_slot == o.tmpb)
         return fail(FV_ERR_INVALID_ARG, "plan_set_pair_output_conv: the output slot aliases an operand");
     if (act_slope < 0.f || act_slope > 1.f) return fail(FV_ERR_INVALID_ARG, "plan_set_pair_output_conv: slope outside [0, 1]");
@@ -2023,6 +2133,32 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
                 if (qo.y2 != FV_SLOT_NONE) sh[qo.y2] = sh[qo.y];
             }
             n = m - 1;
+            continue;
+        }
+        // ---- a whole 16-channel MRF stage: one launch ----
+        if (o.type == OP_STAGE) {
+            MrfParams mp = {};
+            mp.x = base[o.x];
+            mp.blob = o.wp;
+            for (int j = 0; j < 3; ++j) mp.k[j] = o.pk[j];
+            mp.B = B;
+            mp.T = (int)sh[o.x].T;
+            mp.slope = o.pre_slope;
+            mp.out_div = o.out_div;
+            mp.act_slope = o.act_slope;
+            mp.post = o.post;
+            mp.guard = plan->guard_dev;
+            if (o.fold_w) {
+                mp.fold_w = o.fold_w;
+                mp.fold_b = o.fold_b;
+                mp.fold_y = base[o.y];
+            } else {
+                mp.y = base[o.y];
+                mp.y_act = o.y2 == FV_SLOT_NONE ? nullptr : base[o.y2];
+            }
+            if (int rc = launch_mrfh(mp, o.Cin, o.sdil, s)) return rc;
+            sh[o.y] = {o.fold_w ? 1 : o.Cout, sh[o.x].T, true};
+            if (o.y2 != FV_SLOT_NONE) sh[o.y2] = sh[o.y];
             continue;
         }
         // ---- fused ResBlock pairs: the members of a group (the three ResBlocks of an MRF stage) in one launch ----

@@ -164,6 +164,8 @@ struct Tuning {
     int pair_skel = -1;      // (-1: 4 at 16 channels, 3 at 32)
     int convh_blocks = 0;    // > 0: persistent blocks of the convh / convp / convt launches (default: one per CU)
     int pair_blocks = 0;     // > 0: ... of the pair launches
+    int mrf_blocks = 0;      // > 0: ... of the one-launch MRF stage (mrfh_kernel)
+    int mrf_shape = 0;       // one-launch MRF stage: 0 -- 12 waves x 3 fragments (576-column windows), 1 -- 16 waves x 2 (512)
     int sum3_min = 800;      // fewest tiles for which the three last convs of an MRF stage run as ONE fp32 launch
     int lds_budget = 39;     // fp32 conv kernels: KiB of LDS per block
     int units = 500;
@@ -380,6 +382,55 @@ template <int MH, int NF, int NG>
 int launch_pair_geom(const PairParams& p, int dil, size_t lds, hipStream_t s);
 template <int MH, int NF, int NG>
 int launch_pairh_geom(const PairParams& p, int dil, size_t lds, hipStream_t s);
+
+// ---- a whole 16-channel MRF stage as one launch (mrfh_kernels.hpp / mrfh_launch.hip) -------------------------------------
+struct MrfParams {
+    const float* x;          // [B, 16, T] stage input (the upsampler's raw output)
+    float* y;                // [B, 16, T] stage output, or null with fold_*
+    float* y_act;            // optional activated twin lrelu(y, act_slope), or null
+    const float* blob;       // fv_pack_mrf_stage_split_f16 image
+    unsigned blob_bytes;
+    unsigned blk_off[9];     // byte offset of pair q = 3 j + p inside the blob
+    int k[3];                // taps of ResBlock j
+    int B, T;
+    int halo;                // columns a run's first tile starts early (sum of reaches of the longest ResBlock)
+    int ol;                  // FOLD: 3 (the 7-tap output conv's reach), else 0
+    float slope;             // leaky slope inside the ResBlocks
+    float out_div;           // 3
+    float act_slope;         // y_act / FOLD: slope of the activation in front of the output conv; 1 = none
+    int post;                // FV_POST_* (FOLD: applied to the output conv's result)
+    const float* fold_w;     // [16][7] or null
+    const float* fold_b;     // [1] or null
+    float* fold_y;           // [B, 1, T]
+    int* guard;
+    int nblk;
+    long long total;         // B * T output columns
+    unsigned long long* trace;
+};
+
+// packed stage (fv_pack_mrf_stage_split_f16): pair q = 3 j + p of ResBlock j is the block [conv1 image | conv2 image |
+// b1[C] | b2[C] | 1 / row prescale of conv1 [C] | of conv2 [C] | padding to a whole KB]; images: fv_pack_pair_weight_ex's
+inline int mrf_block_bytes(int C, int k) { return 2 * ((k + (32 / C) - 1) / (32 / C)) * (C / 16) * 2048 + 1024; }
+inline bool mrf_stage_shape(int C, const int* k, const int* dil) {
+    if (C != 16 || !k || !dil || dil[0] != 1 || dil[1] != 3 || dil[2] != 5) return false;
+    for (int j = 0; j < 3; ++j)
+        if (k[j] != 3 && k[j] != 7 && k[j] != 11) return false;
+    return true;
+}
+// columns a run's first tile starts early: the reaches of the longest ResBlock's six convs
+inline int mrf_halo(const int* k, const int* dil) {
+    int h = 0;
+    for (int j = 0; j < 3; ++j) {
+        int r = 0;
+        for (int q = 0; q < 3; ++q) r += (k[j] - 1) * dil[q] / 2 + (k[j] - 1) / 2;
+        if (r > h) h = r;
+    }
+    return h;
+}
+// p: x, y / y_act or fold_*, blob, k, B, T, slopes, out_div, post, guard filled in; the rest is set here
+int launch_mrfh(MrfParams p, int C, const int* dil, hipStream_t stream);
+template <int NF, int NG>
+int launch_mrfh_geom(const MrfParams& p, hipStream_t s);
 
 // Shared between the host launcher (conv_mfma.hip) and the kernels (conv_kernels.hpp):
 #ifndef FV_RING

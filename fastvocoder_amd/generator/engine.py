@@ -215,6 +215,42 @@ class PlanBuilder:
                              out_div=float(out_div), post=post, mid=mid if wide else SLOT_NONE,
                              tmps=[mid] if wide else [], **m))
 
+    def mrf_stage_supported(self, blocks):
+        """Can these three ResBlock1s run as ONE launch (fv_mrf_stage_split_f16, csrc/mrfh_kernels.hpp)?  16 channels,
+        split-f16 arithmetic in force, 3 / 7 / 11 taps, pair dilations (1, 3, 5), every pair fusable."""
+        if len(blocks) != 3 or self.pair_precision(blocks[0].channels) != _native.PAIR_SPLIT_F16:
+            return False
+        if any(len(b.convs1) != 3 or len(b.convs2) != 3 for b in blocks):
+            return False
+        ks = [b.convs1[0].kernel_size[0] for b in blocks]
+        dils = [c.dilation[0] for c in blocks[0].convs1]
+        return (_native.mrf_stage_supported(blocks[0].channels, ks, dils)
+                and all([c.dilation[0] for c in b.convs1] == dils for b in blocks)
+                and all(self.pair_fusable(c1, c2, _native.PAIR_SPLIT_F16) for b in blocks for c1, c2 in zip(b.convs1, b.convs2)))
+
+    def mrf_stage(self, blocks, src, dst, slope, out_div, fold=None):
+        """dst = ((r0 + r1) + r2) / out_div, r_j = blocks[j](src): a whole MRF stage (hifigan.py:97-103) as ONE op.
+        ``fold`` = (out_conv, slope, post): the stage's result is not stored; dst = post(out_conv(lrelu(result, slope))),
+        a [B, 1, T] tensor (pair_fold_supported)."""
+        if not self.mrf_stage_supported(blocks):
+            raise _native.NativeError("mrf stage: shape not built into the one-launch kernel")
+        ks = [b.convs1[0].kernel_size[0] for b in blocks]
+        dils = [c.dilation[0] for c in blocks[0].convs1]
+        c1s = [c for b in blocks for c in b.convs1]
+        c2s = [c for b in blocks for c in b.convs2]
+        packed = _native.pack_mrf_stage([effective_weight(c) for c in c1s], [effective_weight(c) for c in c2s],
+                                        [self._bias(c) for c in c1s], [self._bias(c) for c in c2s], ks, self.guard)
+        op = dict(kind="stage", group=0, x=src, y=dst, res=SLOT_NONE, acc=SLOT_NONE, acc2=SLOT_NONE, pre_slope=1.0,
+                  slope=float(slope), channels=blocks[0].channels, ks=ks, dils=dils, packed=packed, out_div=float(out_div),
+                  post=POST_NONE, prec=_native.PAIR_SPLIT_F16)
+        if fold is not None:
+            out_conv, fslope, fpost = fold
+            if not self.pair_fold_supported(blocks[0].convs1[0], out_conv, _native.PAIR_SPLIT_F16):
+                raise _native.NativeError("mrf stage: this output conv cannot be folded into the stage")
+            op.update(fold_w=effective_weight(out_conv).detach().float().reshape(16, 7).contiguous(),
+                      fold_b=self._bias(out_conv), fold_post=fpost, act_slope=float(fslope))
+        self.ops.append(op)
+
     def conv_split_supported(self, conv, pad, pad_mode=PAD_ZERO):
         """Is this a 'same' conv (zero or reflection padding ``pad`` applied in front of it) the split-f16 conv kernels
         are built for, and is that arithmetic in force?"""
@@ -465,6 +501,9 @@ class PlanBuilder:
                 own, rate = (op["k"] - 1) // 2 * (op["dil"] + 1) + (3 if "fold_w" in op else 0), 1
             elif op["kind"] == "mrfsum":
                 own, rate = max((m["k"] - 1) // 2 * (op["dil"] + 1) for m in op["members"]), 1
+            elif op["kind"] == "stage":
+                own = max(sum((k - 1) // 2 * (d + 1) for d in op["dils"]) for k in op["ks"]) + (3 if "fold_w" in op else 0)
+                rate = 1
             elif op["kind"] == "convT":
                 own, rate = -(-op["k"] // op["stride"]) + 1, op["stride"]
             elif op["kind"] == "upconv":
@@ -511,6 +550,11 @@ class PlanBuilder:
                                             y_act=op["y_act"], act_slope=op["act_slope"], prec=op["prec"],
                                             add1=op["acc"], add2=op["acc2"], out_div=op["out_div"],
                                             post=op["post"], mid=op["mid"])
+                if "fold_w" in op:
+                    self.plan.set_pair_output_conv(op["fold_w"], op["fold_b"], op["y"], op["act_slope"], op["fold_post"])
+            elif op["kind"] == "stage":
+                self.plan.add_mrf_stage(op["x"], op["y"], op["packed"], op["channels"], op["ks"], op["dils"], op["slope"],
+                                        out_div=op["out_div"], y_act=op["y_act"], act_slope=op["act_slope"])
                 if "fold_w" in op:
                     self.plan.set_pair_output_conv(op["fold_w"], op["fold_b"], op["y"], op["act_slope"], op["fold_post"])
             elif op["kind"] == "convh":
@@ -617,7 +661,9 @@ class NativeModule(torch.nn.Module):
                          calls ``check_range()`` after them, and reports the "sync" figure beside.
                      "off"  -- no check.
     ``fuse_pairs``   ResBlock1 pairs as fused launches (default) or conv by conv (round-1 path; A/B runs).
-    ``fold_post``    HiFi-GAN's conv_post inside the last pair's launch (default) or as a launch of its own.
+    ``fuse_stage``   a 16-channel MRF stage (three ResBlock1s of three pairs + the mean) as ONE launch (default,
+                     csrc/mrfh_kernels.hpp) or as four fused-pair launches (A/B runs; identical bits).
+    ``fold_post``    HiFi-GAN's conv_post inside the last pair's / the last stage's launch (default) or as a launch of its own.
     ``merge_in_upsampler``  the MRF merge ((r0 + r1) + r2) / 3 of a fused stage inside the split-f16 upsampler behind it
                      (default: the stage ends in one three-member launch) or in the stage's own last launch (A/B runs;
                      identical bits).
@@ -626,6 +672,7 @@ class NativeModule(torch.nn.Module):
     precision = "split"
     range_guard = "auto"
     fuse_pairs = True
+    fuse_stage = True
     fold_post = True
     merge_in_upsampler = True
 
@@ -643,7 +690,8 @@ class NativeModule(torch.nn.Module):
         """The policy a plan is built under (part of every plan's cache key)."""
         prec = "f32" if (self.precision == "f32" or self._fv_overflow) else "split"
         # (the guard is part of the key: a plan built under range_guard = "off" carries no guard word)
-        return prec, bool(self.fuse_pairs), bool(self.fold_post), self.range_guard != "off", bool(self.merge_in_upsampler)
+        return (prec, bool(self.fuse_pairs), bool(self.fold_post), self.range_guard != "off", bool(self.merge_in_upsampler),
+                bool(self.fuse_stage))
 
     def _fv_state(self):
         """(identity + in-place version of every tensor the plans bake in, policy in force).  The tensor list is

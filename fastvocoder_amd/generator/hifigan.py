@@ -109,6 +109,14 @@ class _HiFiGANBase(NativeModule):
         ch = blocks[0].channels
         curs = [up] * nk
         prec = pb.pair_precision(ch)
+        if self.fuse_stage and pb.mrf_stage_supported(blocks):
+            # 16 channels: the whole stage -- nine pairs, the mean, and conv_post when it folds -- is ONE launch
+            # (csrc/mrfh_kernels.hpp): the stage's tensor is read once and written once (or not at all)
+            if fold is not None:
+                pb.mrf_stage(blocks, up, fold[3], LRELU_SLOPE, float(nk), fold=fold[:3])
+            else:
+                pb.mrf_stage(blocks, up, x, LRELU_SLOPE, float(nk))
+            return
         if prec == PAIR_SPLIT_F16 and ch > 128:
             # 256 / 512 channels (HiFi-GAN large): a pair is two launches of the split-f16 conv kernel
             # (csrc/convh_kernels.hpp); 64 and 128 channels run fused (csrc/convp_kernels.hpp, convq_kernels.hpp)
@@ -228,7 +236,8 @@ class _HiFiGANBase(NativeModule):
                 # the MRF merge inside the NEXT upsampler (engine.NativeModule.merge_in_upsampler)
                 merged = (self.merge_in_upsampler and nk == 3 and i + 1 < self.num_upsamples
                           and pb.pair_precision(blocks[0].channels) == PAIR_SPLIT_F16
-                          and pb.conv_transpose_takes_merge(self.ups[i + 1]))
+                          and pb.conv_transpose_takes_merge(self.ups[i + 1])
+                          and not (self.fuse_stage and pb.mrf_stage_supported(blocks)))
                 self._emit_fused_stage(pb, blocks, up, x, scratch, parts, merge_next=merged)
                 continue
             if nk <= 3:

@@ -642,6 +642,41 @@ def test_mrf_merge_inside_the_upsampler_gives_the_same_bits(name, path, T):
     assert not m.check_range()
 
 
+def test_one_launch_stage_gives_the_same_bits():
+    """HiFi-GAN light's 16-channel MRF stage (hifigan.py:97-106) as ONE launch -- nine fused pairs, the mean, conv_post + tanh
+    (csrc/mrfh_kernels.hpp) -- against the four pair launches of round 4 (`fuse_stage = False`): the same arithmetic per
+    element, so identical bits; a single utterance at the headline length, a ragged batch, `inference` and the bias-removal
+    plan (whose conv_post stays a launch of its own), with three launches fewer per forward."""
+    cfg = cases.load_conf("conf/hifigan/light.yaml")
+    one, _ = _model("hifigan", cfg, seed=3)
+    four, _ = _model("hifigan", cfg, seed=3)
+    four.fuse_stage = False
+    with torch.no_grad():
+        for T, batch in ((1000, 1), (77, 3), (9, 2)):
+            x = torch.from_numpy(seeded_mel(T, seed=15, batch=batch)).to(_dev())
+            a, b = one(x), four(x)
+            assert torch.equal(a, b), (T, batch)
+            assert torch.equal(one(x[:1].contiguous())[0], a[0])
+        mel = seeded_mel(123, seed=16)
+        assert torch.equal(one.inference(mel), four.inference(mel))
+        bias = four.inference(np.zeros_like(mel))
+        (e1, r1), (e2, r2) = one.inference_minus(mel, bias), four.inference_minus(mel, bias)
+        assert torch.equal(e1, e2) and torch.equal(r1, r2)
+    def launches(m, x):
+        torch.cuda.synchronize()
+        _native.profile_collect(-1)
+        _native.profile_enable(True)
+        with torch.no_grad():
+            m(x)
+        torch.cuda.synchronize()
+        _native.profile_enable(False)
+        return int(_native.profile_collect(-1)["launches"])
+    x = torch.from_numpy(seeded_mel(77, seed=15, batch=1)).to(_dev())
+    n1, n4 = launches(one, x), launches(four, x)
+    assert n1 == n4 - 3, (n1, n4)                      # four launches of the last stage -> one
+    assert not one.check_range() and not four.check_range()
+
+
 def test_three_instruction_division_on_the_device():
     """csrc/pair_kernels.hpp div_exact (the MRF mean's xs / 3, hifigan.py:103) against the device's own IEEE division: every
     fp32 value of four binades (and the negatives), d = 3 -- and 2, 5, 7, 12 for the rule's other divisors: zero mismatches."""
