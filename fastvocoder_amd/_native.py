@@ -18,12 +18,12 @@ _CSRC = os.path.join(_HERE, "csrc")
 # so that the ~170 kernel variants compile in parallel
 SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip", "wav_sink.hip", "conv_inst_narrow.hip",
            "pair_launch.hip", "pair_inst_c16.hip", "pair_inst_c32.hip", "pairh_inst_c16.hip", "pairh_inst_c32.hip",
-           "convh_launch.hip", "convh_inst_c64.hip", "convh_inst_c128.hip", "convp_inst.hip", "convt_inst.hip",
-           "convg_inst.hip", "convq_inst.hip", "convp_chain_inst.hip", "convr_inst.hip", "convtn_inst.hip", "convk_inst.hip", "convq2_inst.hip",
+           "convh_launch.hip", "convh_inst_c64.hip", "convh_inst_c128.hip", "convt_inst.hip",
+           "convg_inst.hip", "convr_inst.hip", "convtn_inst.hip", "convk_inst.hip", "convq2_inst.hip",
            "mrfh_launch.hip", "mrfh_inst_a.hip", "mrfh_inst_b.hip"] + \
           [f"conv_inst_s{i}.hip" for i in range(6)]
 HEADERS = ["fv_internal.h", "conv_kernels.hpp", "pair_kernels.hpp", "pair_inst.hpp", "pairh_kernels.hpp",
-           "pairh_inst.hpp", "convh_kernels.hpp", "convh_inst.hpp", "convp_kernels.hpp", "convq_kernels.hpp", "convp_chain.hpp", "convr_kernels.hpp",
+           "pairh_inst.hpp", "convh_kernels.hpp", "convh_inst.hpp", "convr_kernels.hpp",
            "convtn_kernels.hpp", "convk_kernels.hpp", "convq2_kernels.hpp", "mrfh_kernels.hpp", "mrfh_inst.hpp"]
 
 PAD_ZERO, PAD_REFLECT = 0, 1
@@ -79,36 +79,75 @@ def built_id():
     return data[at + 12:end].decode(errors="replace") if 0 < end - at - 12 <= 64 else None
 
 
+def _local_includes(path, seen=None):
+    """Transitive closure of the `#include "..."` files of a source (paths relative to the including file)."""
+    import re
+    seen = set() if seen is None else seen
+    with open(path) as f:
+        text = f.read()
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+        dep = os.path.normpath(os.path.join(os.path.dirname(path), inc))
+        if dep not in seen and os.path.exists(dep):
+            seen.add(dep)
+            _local_includes(dep, seen)
+    return seen
+
+
+def _object_stamp(src, flags):
+    """Hash of everything an object file depends on: its source, the headers it includes (transitively), the flags."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in [src] + sorted(_local_includes(src)):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(flags).encode())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
     """hipcc the kernels for gfx950 into fastvocoder_amd/libfastvocoder_hip.so
     (cross-compiles without a GPU): one object per source, compiled in parallel, then linked.
-    Up to date <=> the library's embedded build id equals the hash of the sources."""
+    Up to date <=> the library's embedded build id equals the hash of the sources.  Objects are rebuilt only when their
+    own source, a header they include or the flags changed (a stamp file next to each object); the build id is compiled
+    into api.hip alone."""
     srcs = [os.path.join(_CSRC, s) for s in SOURCES]
     want = source_hash()
     if not force and built_id() == want:
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f'-DFV_BUILD_ID="{want}"',
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
              "-Wno-unused-value", "-Wno-comment", "-Wno-pass-failed",
              # MFMA results straight in VGPRs (unified register file on gfx950): no
              # v_accvgpr_read/write pairs around every stage -- VALU work costs MFMA time
              "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + os.environ.get("FV_HIPCC_FLAGS", "").split()
     objdir = os.path.join(_HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    jobs = []
+    jobs, objs = [], []
     for src in srcs:
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        objs.append(obj)
+        own = flags + ([f'-DFV_BUILD_ID="{want}"'] if os.path.basename(src) == "api.hip" else [])
+        stamp, stamp_path = _object_stamp(src, own), obj + ".stamp"
+        if not force and os.path.exists(obj) and os.path.exists(stamp_path):
+            with open(stamp_path) as f:
+                if f.read() == stamp:
+                    continue
+        cmd = [hipcc] + own + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        jobs.append((cmd, obj, subprocess.Popen(cmd)))
-    for cmd, obj, proc in jobs:
+        if os.path.exists(stamp_path):
+            os.remove(stamp_path)
+        jobs.append((cmd, stamp_path, stamp, subprocess.Popen(cmd)))
+    for cmd, stamp_path, stamp, proc in jobs:
         if proc.wait() != 0:
-            for _, _, other in jobs:
+            for _, _, _, other in jobs:
                 if other.poll() is None:
                     other.kill()
             raise subprocess.CalledProcessError(proc.returncode, cmd)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj for _, obj, _ in jobs] + ["-o", LIB_PATH]
+        with open(stamp_path, "w") as f:
+            f.write(stamp)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)

@@ -437,10 +437,6 @@ struct fv_plan {
     // memory -- the host's and the device's view of it
     int* guard_host = nullptr;
     int* guard_dev = nullptr;
-    // chained launches (fv_internal.h PairChain): flags and schedule tables on the device, chains launched so far in
-    // the current run
-    fv::ChainBuffers chain;
-    int chain_count = 0;
 };
 
 namespace fv {
@@ -738,13 +734,15 @@ static const TuningEntry kTuningTable[] = {
     {"pair_dbg", &Tuning::pair_dbg},       {"dbg", &Tuning::conv_dbg},           {"sched", &Tuning::sched},
     {"sched_switch", &Tuning::sched_switch}, {"convh_skel", &Tuning::convh_skel}, {"convp_skel", &Tuning::convp_skel},
     {"convq_skel", &Tuning::convq_skel},   {"pair128_unfused", &Tuning::pair128_unfused},
-    {"chain", &Tuning::chain},             {"chain_spin", &Tuning::chain_spin},  {"convg_rows64", &Tuning::convg_rows64}, {"stack_items", &Tuning::stack_items}, {"stack_wide", &Tuning::stack_wide}, {"convq2", &Tuning::convq2}, {"convp2", &Tuning::convp2}, {"convp_wide", &Tuning::convp_wide}, {"convq_wide", &Tuning::convq_wide},
+    {"convg_rows64", &Tuning::convg_rows64}, {"stack_items", &Tuning::stack_items}, {"stack_wide", &Tuning::stack_wide},
+    {"convp_wide", &Tuning::convp_wide},   {"convq_wide", &Tuning::convq_wide},
     {"convh_rows64", &Tuning::convh_rows64},  {"convt_rows64", &Tuning::convt_rows64},
     {"pairh_skel", &Tuning::pairh_skel},   {"pair_skel", &Tuning::pair_skel},    {"convh_blocks", &Tuning::convh_blocks},
     {"pair_blocks", &Tuning::pair_blocks}, {"sum3_min", &Tuning::sum3_min},      {"lds_budget", &Tuning::lds_budget},
     {"units", &Tuning::units},             {"shape16", &Tuning::shape16},        {"shape32", &Tuning::shape32},
     {"shape64", &Tuning::shape64},         {"krows", &Tuning::krows},            {"grid_cap", &Tuning::grid_cap},
     {"no_group", &Tuning::no_group},       {"mrf_blocks", &Tuning::mrf_blocks},  {"mrf_shape", &Tuning::mrf_shape},
+    {"mrf_prio", &Tuning::mrf_prio},
 };
 static void tuning_from_env() {
     const char* on = getenv("FV_TUNING");
@@ -1100,7 +1098,6 @@ fv_plan_t* fv_plan_create(int in_channels) {
 }
 
 void fv_plan_destroy(fv_plan_t* plan) {
-    if (plan) plan->chain.release();
     delete plan;
 }
 
@@ -2086,7 +2083,6 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
     base[FV_SLOT_IN] = const_cast<float*>(in);
     base[FV_SLOT_OUT] = out;
     hipStream_t const s = (hipStream_t)stream;
-    plan->chain_count = 0;
     // shapes again, op by op (a slot may change shape when it is reused)
     for (int i = 0; i < FV_MAX_SLOTS; ++i) sh[i].set = false;
     sh[FV_SLOT_IN] = {plan->in_channels, T, true};
@@ -2233,32 +2229,6 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             };
             PairParams pp;
             const size_t m = gather(n, (int)sh[o.x].T, pp);
-            // the launches of an MRF stage that follow (same channels, samples, arithmetic): one chained launch
-            if (o.type == OP_PAIR && o.Cin == 64 && o.prec == FV_PAIR_SPLIT_F16 && !o.fold_w && plan->guard_dev && tuning().chain) {
-                PairParams cph[kChainPhases];
-                int cdil[kChainPhases];
-                size_t cend[kChainPhases];
-                int np = 0;
-                size_t at = n;
-                while (np < kChainPhases && at < plan->ops.size()) {
-                    const Op& f = plan->ops[at];
-                    if (f.type != OP_PAIR || f.Cin != o.Cin || f.prec != o.prec || f.fold_w) break;
-                    cend[np] = gather(at, (int)sh[o.x].T, cph[np]);
-                    cdil[np] = f.dil;
-                    at = cend[np];
-                    ++np;
-                }
-                if (np >= 2) {
-                    const int rc = launch_convp_chain(cph, cdil, np, plan->chain, plan->chain_count, s);
-                    if (rc < 0) return rc;
-                    if (rc == 0) {
-                        ++plan->chain_count;
-                        set_shapes(n, cend[np - 1]);
-                        n = cend[np - 1] - 1;
-                        continue;
-                    }
-                }
-            }
             if (o.Cin == 64 && o.prec == FV_PAIR_SPLIT_F16) {
                 if (int rc = launch_convp(pp, o.dil, s)) return rc;
             } else if (o.Cin == 128 && o.prec == FV_PAIR_SPLIT_F16 && !tuning().pair128_unfused) {

@@ -126,7 +126,7 @@ __device__ __forceinline__ void buffer_store1(__amdgpu_buffer_rsrc_t r, unsigned
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)byte_off, 0, 0);
 }
 // ... with cache-policy bits (AUX: 0 plain, kAuxAgent = sc1: the access is coherent device-wide -- stores write through
-// the XCD's L2, loads do not hit in it; what tensors that cross the phases of a chained launch need, fv_internal.h PairChain)
+// the XCD's L2, loads do not hit in it; what tensors handed between blocks INSIDE a launch would need)
 constexpr int kAuxAgent = 16;
 template <int AUX>
 __device__ __forceinline__ float buffer_load1s_aux(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned s_off) {

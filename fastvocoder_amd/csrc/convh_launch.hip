@@ -338,7 +338,7 @@ int launch_convg(PairParams p, int C, hipStream_t s) {
     return rc;
 }
 
-// ---- fused pair at C = 64 (convp_kernels.hpp) --------------------------------------------------------------------
+// ---- fused pair at C = 64 (convq2_kernels.hpp) -------------------------------------------------------------------
 constexpr int kPair64Wide = 65, kPair128Wide = 129;     // (convq2_kernels.hpp: the wide forms of the ring-free pair kernel)
 template <int DIL, int C>
 int launch_convq2_dil(const PairParams& p, size_t lds, hipStream_t s);      // convq2_inst.hip: the pairs without the weight ring
@@ -353,16 +353,11 @@ extern template int launch_convq2_dil<3, kPair64Wide>(const PairParams&, size_t,
 extern template int launch_convq2_dil<5, kPair64Wide>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convq2_dil<1, kPair128Wide>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convq2_dil<3, kPair128Wide>(const PairParams&, size_t, hipStream_t);
-extern template int launch_convp_dil<1>(const PairParams&, size_t, hipStream_t);
-extern template int launch_convp_dil<3>(const PairParams&, size_t, hipStream_t);
-extern template int launch_convp_dil<5>(const PairParams&, size_t, hipStream_t);
 
 // everything launch_convp does in front of the launch: validation, member order, tile counts, LDS layout, block schedule
-// (form: 0 convp_kernel -- the LDS weight ring; 1 convq2_kernel<DIL, 64> -- no ring, 128-column tiles; 2 convq2_kernel<DIL, 65>
-// -- no ring, 256-column tiles)
-static int prepare_convp(PairParams& p, int dil, size_t& lds_out, double& flops, double& bytes, int form = 0) {
+// (form: 1 convq2_kernel<DIL, 64> -- 128-column tiles; 2 convq2_kernel<DIL, 65> -- 256-column tiles)
+static int prepare_convp(PairParams& p, int dil, size_t& lds_out, double& flops, double& bytes, int form) {
     const int C = 64;
-    const bool noring = form != 0;
     const int NMc = form == 2 ? 256 : 128;           // intermediate columns per tile
     if (dil != 1 && dil != 3 && dil != 5) return fail(FV_ERR_UNSUPPORTED, "resblock pair: dilation %d (1, 3 or 5)", dil);
     if (p.n_members < 1 || p.n_members > 3) return fail(FV_ERR_INVALID_ARG, "resblock pair: %d members", p.n_members);
@@ -384,8 +379,6 @@ static int prepare_convp(PairParams& p, int dil, size_t& lds_out, double& flops,
         if (mb.add2 && !mb.add1) return fail(FV_ERR_INVALID_ARG, "resblock pair: add2 without add1 (member %d)", i);
         if ((reinterpret_cast<uintptr_t>(mb.w1) | reinterpret_cast<uintptr_t>(mb.w2)) & 15)
             return fail(FV_ERR_UNSUPPORTED, "resblock pair: packed weights must be 16-byte aligned");
-        mb.flag_off = -1;
-        for (auto& d : mb.dep) d = {-1, 1, 0, 0};
         const ConvHShape g = convh_shape(C, mb.k, dil);
         const int nout = NMc - (mb.k - 1);
         mb.n_tiles = (p.T + nout - 1) / nout;
@@ -399,8 +392,7 @@ static int prepare_convp(PairParams& p, int dil, size_t& lds_out, double& flops,
         bytes += 4.0 * (2.0 * C * C * mb.k + (double)p.B * C * p.T * ((mb.y_act ? 3 : 2) + (mb.add1 ? 1 : 0) + (mb.add2 ? 1 : 0)));
     }
     size_t floats = 0;
-    p.x_off = 0;                       // ring of 4 weight stages
-    if (!noring) floats += 4 * 16384 / 4;
+    p.x_off = 0;
     p.img_off = (int)floats;
     floats += (size_t)img_bytes / 4;
     p.mid_off = (int)floats;
@@ -429,236 +421,20 @@ int launch_convp(PairParams p, int dil, hipStream_t s) {
     if (p.B <= 0 || p.T <= 0) return 0;
     size_t lds;
     double flops, bytes;
-    // convq2_kernels.hpp at 64 channels (A operands from L2 into registers, no ring) measured the same as convp_kernel at batch
-    // 1 (55.2 vs 54.4-56.2 us per three-member launch) and at 8 x 128 000 columns (1162 vs 1163 us): the ring form stays
-    // ... and on 256-column tiles (32 x 64 wave tiles) from Tuning::convp_wide tenths of such a tile per CU up
+    // convq2_kernels.hpp at 64 channels (A operands from L2 into registers) on 128-column tiles, and on 256-column tiles
+    // (32 x 64 wave tiles) from Tuning::convp_wide tenths of such a tile per CU up
     long long wide_items = 0;
     for (int i = 0; i < p.n_members; ++i) wide_items += (long long)p.B * ((p.T + 256 - p.m[i].k) / (257 - p.m[i].k));
-    const int form = wide_items * 10 >= (long long)tuning().convp_wide * device_cu_count() ? 2 : tuning().convp2 != 0 ? 1 : 0;
+    const int form = wide_items * 10 >= (long long)tuning().convp_wide * device_cu_count() ? 2 : 1;
     if (int rc = prepare_convp(p, dil, lds, flops, bytes, form)) return rc;
     profile_begin(s);
     const int rc = form == 2 ? (dil == 1 ? launch_convq2_dil<1, kPair64Wide>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, kPair64Wide>(p, lds, s) : launch_convq2_dil<5, kPair64Wide>(p, lds, s))
-                 : form == 1 ? (dil == 1 ? launch_convq2_dil<1, 64>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, 64>(p, lds, s) : launch_convq2_dil<5, 64>(p, lds, s))
-                             : (dil == 1 ? launch_convp_dil<1>(p, lds, s) : dil == 3 ? launch_convp_dil<3>(p, lds, s) : launch_convp_dil<5>(p, lds, s));
+                             : (dil == 1 ? launch_convq2_dil<1, 64>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, 64>(p, lds, s) : launch_convq2_dil<5, 64>(p, lds, s));
     profile_end(s, FV_KERNEL_CONVH64, flops, bytes);
     return rc;
 }
 
-// ---- chained launches (fv_internal.h PairChain) ------------------------------------------------------------------
-void ChainBuffers::release() {
-    if (flags) (void)hipFree(flags);
-    for (Table& t : tables)
-        if (t.dev) (void)hipFree(t.dev);
-    flags = nullptr;
-    flag_words = 0;
-    tables.clear();
-}
-
-// Flag offsets and dependency descriptors of n prepared phases (n_tiles / n_items set); nout[i][m], halo[i][m]: output
-// samples per tile and window halo of phase i's member m.  false: the phases cannot share a launch.
-static bool chain_link(PairParams* ph, int n, const int (*nout)[3], const int (*halo)[3], size_t& flag_words) {
-    size_t at = 16;                                      // kChainFlagBase (pairh_kernels.hpp): word 0 is the abort word
-    for (int i = 0; i < n; ++i)
-        for (int m = 0; m < ph[i].n_members; ++m) {
-            ph[i].m[m].flag_off = (int)at;
-            at += (size_t)ph[i].m[m].n_items;
-            if (at > (1u << 28)) return false;
-        }
-    flag_words = at;
-    for (int i = 0; i < n; ++i)
-        for (int m = 0; m < ph[i].n_members; ++m) {
-            PairMember& mb = ph[i].m[m];
-            const float* outs[2] = {mb.y, mb.y_act};
-            for (const float* o : outs) {
-                if (!o) continue;
-                // written twice, or read by this or an earlier phase (whose blocks may still be at it): no chain
-                for (int j = 0; j <= i; ++j)
-                    for (int q = 0; q < ph[j].n_members; ++q) {
-                        const PairMember& e = ph[j].m[q];
-                        if (e.x == o || e.add1 == o || e.add2 == o) return false;
-                        if ((j < i || q < m) && (e.y == o || e.y_act == o)) return false;
-                    }
-            }
-            const float* ins[3] = {mb.x, mb.add1, mb.add2};
-            for (int g = 0; g < 3; ++g) {
-                mb.dep[g] = {-1, 1, 0, 0};
-                if (!ins[g]) continue;
-                for (int j = i - 1; j >= 0 && mb.dep[g].off < 0; --j)
-                    for (int q = 0; q < ph[j].n_members; ++q) {
-                        const PairMember& e = ph[j].m[q];
-                        if (e.y != ins[g] && e.y_act != ins[g]) continue;
-                        const int h = g == 0 ? halo[i][m] : 0;
-                        if ((nout[i][m] + 2 * h) / nout[j][q] + 2 > 8) return false;      // eight flags per input
-                        mb.dep[g] = {e.flag_off, nout[j][q], e.n_tiles, h};
-                        break;
-                    }
-            }
-        }
-    return true;
-}
-
-// Block schedule of a chain: per phase and block the item range of every member, [phase][block][4 words] (word m:
-// lo | count << 20; word 3 bit 0: the phase runs downwards).  Phase by phase the cost-weighted item sequence (members in
-// launch order, items ascending: a block mostly stays with one member) is cut into contiguous shares -- not equal ones:
-// block b's share is what brings its CUMULATIVE load to the common level F (water filling over the loads the earlier
-// phases left), rounded to whole items, so the rounding of one phase is made up for in the next.  Shares stay in block
-// order along the sequence, so between phases with the same members a block reads tiles it produced itself or that its
-// neighbours produced; the direction alternates from phase to phase, so that the neighbour tiles a block needs FIRST in
-// a phase are the ones the neighbour finished first in the phase before.
-// [measured, MI355X, HiFi-GAN light B = 1, 64 channels, tools/chain_trace.py] blocks end between 120 and 166 us (median
-// 143): items are 7.8 / 12.1 / 15.6 us (3 / 7 / 11 taps) and a block gets 1.2 - 3.9 of them per phase, the phases with
-// two and one member do not line up with the three-member ones (waiting for flags: median 6 us per block, up to 30),
-// and a late block makes the blocks late that read its tiles.  Interleaving the members along time instead (every share
-// a time window of all members: local dependencies in every phase) costs three member switches per phase and block
-// (~4 us each): 186 - 201 us.
-static bool chain_schedule(const PairParams* ph, int n, int nblk, std::vector<unsigned>& table) {
-    table.assign((size_t)kChainPhases * nblk * 4, 0u);
-    std::vector<double> a((size_t)nblk, 0.0), cap((size_t)nblk), sorted((size_t)nblk);
-    const double sw = tuning().sched_switch;
-    for (int p = 0; p < n; ++p) {
-        double W = 0;
-        for (int m = 0; m < ph[p].n_members; ++m) {
-            if (ph[p].m[m].n_items >= (1 << 20)) return false;
-            W += (double)ph[p].m[m].n_items * ph[p].m[m].cost;
-        }
-        sorted = a;
-        std::sort(sorted.begin(), sorted.end());
-        double F = 0, prefix = 0;
-        for (int k = 1; k <= nblk; ++k) {
-            prefix += sorted[(size_t)k - 1];
-            F = (W + prefix) / k;
-            if (k == nblk || F <= sorted[(size_t)k]) break;
-        }
-        for (int b = 0; b < nblk; ++b) cap[(size_t)b] = F > a[(size_t)b] ? F - a[(size_t)b] : 0.0;
-        unsigned* const t = table.data() + (size_t)p * nblk * 4;
-        int b = 0;
-        double cum = cap[0], pos = 0;
-        for (int m = 0; m < ph[p].n_members; ++m) {
-            const double c = ph[p].m[m].cost;
-            for (int i = 0; i < ph[p].m[m].n_items; ++i, pos += c) {
-                while (b < nblk - 1 && pos + 0.5 * c > cum) cum += cap[(size_t)++b];
-                unsigned& w = t[(size_t)b * 4 + m];
-                if ((w >> 20) == 0) w = (unsigned)i;
-                if ((w >> 20) == 4095u) return false;
-                w += 1u << 20;
-                a[(size_t)b] += c;
-            }
-        }
-        for (int bb = 0; bb < nblk; ++bb) {
-            for (int m = 0; m < ph[p].n_members; ++m)
-                if (t[(size_t)bb * 4 + m] >> 20) a[(size_t)bb] += sw;
-            t[(size_t)bb * 4 + 3] = (unsigned)(p & 1);
-        }
-    }
-    return true;
-}
-
-// the chain's flags and schedule table on the device; ok = false: not possible right now (stream capture with
-// something to allocate or copy)
-static int chain_buffers(ChainBuffers& cb, int chain_index, size_t flag_words, const std::vector<unsigned>& table, hipStream_t s,
-                         const unsigned** sched_dev, bool& ok) {
-    ok = false;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(s, &cap);
-    const bool capturing = cap != hipStreamCaptureStatusNone;
-    if (cb.flag_words < flag_words) {
-        if (capturing) return 0;
-        if (cb.flags) FV_HIP(hipFree(cb.flags));         // (synchronises: no launch still polls the old words)
-        cb.flags = nullptr;
-        cb.flag_words = 0;
-        const size_t words = flag_words + flag_words / 2;
-        FV_HIP(hipMalloc(reinterpret_cast<void**>(&cb.flags), words * 4));
-        FV_HIP(hipMemset(cb.flags, 0, words * 4));
-        cb.flag_words = words;
-        cb.epoch = 0;
-    }
-    if ((int)cb.tables.size() <= chain_index) cb.tables.resize((size_t)chain_index + 1);
-    ChainBuffers::Table& t = cb.tables[(size_t)chain_index];
-    if (t.dev && t.host.size() != table.size()) {
-        if (capturing) return 0;
-        FV_HIP(hipFree(t.dev));
-        t.dev = nullptr;
-        t.host.clear();
-    }
-    if (!t.dev) {
-        if (capturing) return 0;
-        FV_HIP(hipMalloc(reinterpret_cast<void**>(&t.dev), table.size() * 4));
-    }
-    if (t.host != table) {
-        if (capturing) return 0;
-        FV_HIP(hipStreamSynchronize(s));                 // (a launch in flight may read the table: once per shape)
-        FV_HIP(hipMemcpy(t.dev, table.data(), table.size() * 4, hipMemcpyHostToDevice));
-        t.host = table;
-    }
-    *sched_dev = t.dev;
-    ok = true;
-    return 0;
-}
-
-int launch_convp_chain(PairParams* ph, const int* dil, int n, ChainBuffers& cb, int chain_index, hipStream_t s) {
-    if (n < 2 || n > kChainPhases || !tuning().chain) return 1;
-    if (ph[0].B <= 0 || ph[0].T <= 0) return 1;
-    size_t lds = 0;
-    double flops = 0, bytes = 0;
-    int nout[kChainPhases][3], halo[kChainPhases][3], nblk = 0;
-    for (int i = 0; i < n; ++i) {
-        if (!ph[i].guard || ph[i].guard != ph[0].guard || ph[i].B != ph[0].B || ph[i].T != ph[0].T) return 1;
-        size_t l;
-        double f, by;
-        if (int rc = prepare_convp(ph[i], dil[i], l, f, by)) return rc;
-        lds = l > lds ? l : lds;
-        flops += f;
-        bytes += by;
-        nblk = ph[i].nblk > nblk ? ph[i].nblk : nblk;
-        for (int m = 0; m < ph[i].n_members; ++m) {
-            const int k = ph[i].m[m].k;
-            nout[i][m] = 128 - (k - 1);
-            halo[i][m] = (k - 1) * dil[i] / 2 + (k - 1) / 2;
-        }
-    }
-    size_t flag_words;
-    if (!chain_link(ph, n, nout, halo, flag_words)) return 1;
-    nblk = tuning().convh_blocks > 0 ? tuning().convh_blocks : device_cu_count();
-    // (the schedule depends on the shapes only: kept with the chain's table, recomputed when the key changes)
-    std::vector<int> key = {n, nblk, tuning().sched_switch};
-    for (int i = 0; i < n; ++i)
-        for (int m = 0; m < 3; ++m) {
-            key.push_back(m < ph[i].n_members ? ph[i].m[m].n_items : 0);
-            key.push_back(m < ph[i].n_members ? ph[i].m[m].cost : 0);
-        }
-    if ((int)cb.tables.size() <= chain_index) cb.tables.resize((size_t)chain_index + 1);
-    ChainBuffers::Table& tb = cb.tables[(size_t)chain_index];
-    if (tb.key != key) {
-        if (!chain_schedule(ph, n, nblk, tb.sched)) return 1;
-        tb.key = key;
-    }
-    const unsigned* sched_dev;
-    bool ok;
-    if (int rc = chain_buffers(cb, chain_index, flag_words, tb.sched, s, &sched_dev, ok)) return rc;
-    if (!ok) return 1;
-    PairChain c = {};
-    ++cb.epoch;
-    for (int i = 0; i < n; ++i) {
-        c.ph[i] = ph[i];                                 // (the PairCore part)
-        c.ph[i].flags = cb.flags;
-        c.ph[i].flag_bytes = (unsigned)(cb.flag_words * 4);
-        c.ph[i].epoch = cb.epoch;
-        c.ph[i].trace = reinterpret_cast<unsigned long long*>(tuning().trace_ptr);
-        c.dil[i] = dil[i];
-    }
-    c.n_phases = n;
-    c.sched = sched_dev;
-    c.spin_limit = tuning().chain_spin;
-    profile_begin(s);
-    const int rc = launch_convp_chain_kernel(c, nblk, lds, s);
-    profile_end(s, FV_KERNEL_CONVH64, flops, bytes);
-    return rc;
-}
-
-// ---- fused pair at C = 128 (convq_kernels.hpp) -------------------------------------------------------------------
-extern template int launch_convq_dil<1>(const PairParams&, size_t, hipStream_t);
-extern template int launch_convq_dil<3>(const PairParams&, size_t, hipStream_t);
-extern template int launch_convq_dil<5>(const PairParams&, size_t, hipStream_t);
+// ---- fused pair at C = 128 (convq2_kernels.hpp) ------------------------------------------------------------------
 
 int launch_convq(PairParams p, int dil, hipStream_t s) {
     const int C = 128;
@@ -666,7 +442,7 @@ int launch_convq(PairParams p, int dil, hipStream_t s) {
     // 3 -- from Tuning::convq_wide tenths of such a tile per CU up
     long long wide_items = 0;
     for (int i = 0; i < p.n_members && i < 3; ++i) wide_items += (long long)p.B * ((p.T + 128 - p.m[i].k) / (129 - p.m[i].k));
-    const bool wide = tuning().convq2 != 0 && dil <= 3 && wide_items * 10 >= (long long)tuning().convq_wide * device_cu_count();
+    const bool wide = dil <= 3 && wide_items * 10 >= (long long)tuning().convq_wide * device_cu_count();
     const int NM = wide ? 128 : 64;
     if (p.B <= 0 || p.T <= 0) return 0;
     if (dil != 1 && dil != 3 && dil != 5) return fail(FV_ERR_UNSUPPORTED, "resblock pair: dilation %d (1, 3 or 5)", dil);
@@ -701,9 +477,7 @@ int launch_convq(PairParams p, int dil, hipStream_t s) {
         bytes += 4.0 * (2.0 * C * C * mb.k + (double)p.B * C * p.T * ((mb.y_act ? 3 : 2) + (mb.add1 ? 1 : 0) + (mb.add2 ? 1 : 0)));
     }
     size_t floats = 0;
-    const bool noring = tuning().convq2 != 0;      // convq2_kernels.hpp: A operands from L2 into registers, no ring
-    p.x_off = 0;                       // ring of 3 weight stages (one K step of all 128 rows each)
-    if (!noring) floats += 3 * 16384 / 4;
+    p.x_off = 0;
     p.img_off = (int)floats;
     floats += (size_t)img_bytes / 4;
     p.mid_off = (int)floats;
@@ -726,8 +500,7 @@ int launch_convq(PairParams p, int dil, hipStream_t s) {
     p.trace = reinterpret_cast<unsigned long long*>(tuning().trace_ptr);
     profile_begin(s);
     const int rc = wide ? (dil == 1 ? launch_convq2_dil<1, kPair128Wide>(p, lds, s) : launch_convq2_dil<3, kPair128Wide>(p, lds, s))
-                 : noring ? (dil == 1 ? launch_convq2_dil<1, 128>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, 128>(p, lds, s) : launch_convq2_dil<5, 128>(p, lds, s))
-                          : (dil == 1 ? launch_convq_dil<1>(p, lds, s) : dil == 3 ? launch_convq_dil<3>(p, lds, s) : launch_convq_dil<5>(p, lds, s));
+                      : (dil == 1 ? launch_convq2_dil<1, 128>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, 128>(p, lds, s) : launch_convq2_dil<5, 128>(p, lds, s));
     profile_end(s, FV_KERNEL_CONVH128, flops, bytes);
     return rc;
 }

@@ -1,4 +1,9 @@
-// Fused ResBlock1 pair at 128 channels WITHOUT the weight ring (round 4; the ring form: convq_kernels.hpp).
+// Fused ResBlock1 pair at 128 / 64 channels, split-f16 operands, weights from L2 straight into registers:
+//
+//     x' = x + conv2( lrelu( conv1( lrelu(x) ) + b1 ) ) + b2          (reference model/generator/modules.py:223-230)
+//
+// (Rounds 3 / 4 streamed the weights through an LDS ring -- convq_kernel at 128 channels, convp_kernel at 64; this form
+// measured faster or equal everywhere and bit-identical, and the ring forms were removed in round 5: docs/history/.)
 //
 // Same tile (all 128 rows x 64 intermediate columns), same images, same K order, same warm tiles -- a different wave
 // layout: 8 waves = 8 row slabs of SIXTEEN rows x ONE column group of 64 columns (a 16 x 64 wave tile: per K step
@@ -9,10 +14,62 @@
 // over: the K loops have NO barrier (the ring form: one per K step, 88 per 11-tap tile); three per tile remain (window
 // image complete, intermediate complete, intermediate free).  Identical bits: the same MFMA order per output.
 #pragma once
-#include "convq_kernels.hpp"
-#include "convp_kernels.hpp"
+#include "convh_kernels.hpp"
+#ifndef FV_WARM_TILES
+#define FV_WARM_TILES 1             // 0: every tile cold (A/B builds, tools/build_variant.py)
+#endif
 
 namespace fv {
+
+// ---- tile geometry at 128 channels: a block owns ALL 128 rows of a 64-column tile (conv2 needs every channel of the
+// intermediate); x image 64 + (KT - 1) DIL columns, intermediate 64 + 16 columns
+template <int KT_, int DIL_>
+struct ConvQGeom {
+    static constexpr int KT = KT_, DIL = DIL_, C = 128, CG = 4, CB = 16, NFW = 2, NT = 512;
+    static constexpr int NM = 64;                        // intermediate columns per tile
+    static constexpr int NOUT = NM - (KT - 1);           // output columns per tile
+    static constexpr int P1 = (KT - 1) * DIL / 2, P2 = (KT - 1) / 2;
+    static constexpr int NSTEP = KT * CG;                // K steps of 32 per conv = weight stages per conv
+    static constexpr int NST = 2 * NSTEP;                // stages per tile: conv1's, then conv2's
+    static constexpr int XROWS = (NM + (KT - 1) * DIL + 3) / 4 * 4;
+    static constexpr int XRP = (XROWS + 15) / 16 * 16;   // image: [split half][8-channel block][XRP rows][8 halves]
+    static constexpr int XHALF = CB * XRP * 16;
+    static constexpr int XR = (XROWS * CB + NT - 1) / NT, XRM = XR;
+    static constexpr int MRP = NM + 16;                  // rows of the intermediate image (>= NM + KT - 1: a warm tile's, multiple of 16)
+    static constexpr int MHALF = CB * MRP * 16;
+    // (a ring of four stages fits at dilation 1 and 3 -- smaller x image -- and was measured: no difference)
+    static constexpr int STAGE_BYTES = 16384, RING = 3, AHEAD = RING - 1;
+    static constexpr int WTILE = NSTEP * 8192;           // packed bytes of one 64-row tile of a conv ([tile][step][8 KB])
+    static constexpr int RAWST = NST - 8;                // stage at which the next tile's raw window is requested
+    // (the residual is NOT prefetched during the last stages as in convh / convp: its 16 registers would be live together
+    // with the raw window, both operand queues and the accumulators -- the kernel is at the 256-register limit -- so it
+    // is loaded in the epilogue, an L2 round trip per 22-27 us tile)
+#ifndef FV_CONVQ_BDEPTH
+#define FV_CONVQ_BDEPTH 2
+#endif
+    static constexpr int BD = FV_CONVQ_BDEPTH;           // B operands BD - 1 steps ahead of their MFMAs (register budget)
+    static constexpr int NRAW = XRM * 8;
+    static_assert(KT - 1 <= 16 && NSTEP >= 8, "taps");
+    static_assert(((CG - 1) * 4 * XRP + (KT - 1) * DIL + 16 * (NFW - 1)) * 16 + 16 < 65536, "ds_read immediate range");
+};
+
+// ---- tile geometry at 64 channels: 128 intermediate columns per tile, the image / wave layout of convh_kernel<2, 2>
+template <int KT_, int DIL_>
+struct ConvPGeom {
+    typedef ConvHGeom<2, 2, KT_, DIL_> H;                // the conv1 side: same image, ring, wave layout
+    static constexpr int KT = KT_, DIL = DIL_, C = 64, NFW = 2;
+    static constexpr int NM = H::NTC;                    // 128 intermediate columns per tile
+    static constexpr int NOUT = NM - (KT - 1);           // output columns per tile
+    static constexpr int P1 = (KT - 1) * DIL / 2, P2 = (KT - 1) / 2;
+    static constexpr int NST1 = H::NST, NST = 2 * NST1;  // weight stages per tile: conv1's, then conv2's
+    static constexpr int NUNIT1 = H::NUNIT;              // MFMA groups per conv
+    static constexpr int MRP = NM + 16;                  // rows of the intermediate image (>= NM + KT - 1, multiple of 16)
+    static constexpr int MHALF = (C / 8) * MRP * 16;
+    static constexpr int RAWST = NST - 4, RESST = NST - 2;
+    static constexpr int NRAW = H::NRAW, NRES = 8 * NFW;
+    static_assert(KT - 1 <= 16 && NST1 >= 3, "taps");
+};
+
 
 // C = 128: the geometry of convq_kernel (64 intermediate columns); C = 64: that of convp_kernel (128 columns: two column
 // groups of 64 -- two waves do share a row sixteenth there and load it twice, 5.6 KB of weights per column instead of

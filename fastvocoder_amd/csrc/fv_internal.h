@@ -147,25 +147,21 @@ struct Tuning {
     int pair128_unfused = 0; // 1: 128-channel ResBlock pairs as two conv launches (convh) instead of the fused convq kernel (A/B, bit-identity tests)
     int convh_rows64 = -1;    // the split-f16 convs at 128+ channels on 64-row tiles (1: convh_kernel) or 128-row ones (0: convs_kernel); -1: by size
     int convt_rows64 = -1;    // the split-f16 transposed conv (128+ input channels) on 64-row tiles (1) or 128-row ones (0); -1: by size
-    int convq2 = 1;              // fused 128-channel pairs: 1 convq2_kernel (A operands from L2 into registers, no ring), 0 convq_kernel
     int convq_wide = 20;         // fused 128-channel pairs, dilation 1 / 3: 128-column tiles per CU (in tenths) from which the wide form runs
     int convp_wide = 20;         // fused 64-channel pairs: 256-column tiles per CU (in tenths) from which the wide no-ring form runs
-    int convp2 = 1;              // ... 64-channel pairs: 1 the same kernel at 64 channels, 0 convp_kernel (the ring form: 1.5 us per batch-1 launch behind)
     int stack_wide = 10;         // residual stacks of 256 channels: tiles of 64 columns per CU (in tenths) from which the wide tile runs
                                  // (Basis-MelGAN, 1000 frames: batch 1 -- 250 such tiles in its second stage -- 0.238 narrow / 0.248 wide,
                                  // batch 2 0.384 / 0.359, batch 3 0.624 / 0.534)
     int stack_items = 1 << 20;   // residual stacks of 256 channels: tiles per CU (in tenths) up to which the one-launch kernel runs
                                  // (api.hip stack_two_launch; measured: it wins at every size -- 0 forces the two launches, A/B)
     int convg_rows64 = -1;    // the two-source 1x1 conv on 64-row tiles (1: convg_kernel) or 128-row ones (0: convr_kernel); -1: by size
-    int chain = 0;            // 1: the dependent pair launches of a 64-channel MRF stage as one chained launch (PairChain;
-                              // measured no faster at batch 1, convh_launch.hip chain_schedule: off)
-    int chain_spin = 1 << 19; // polls a chained block waits for a flag before it gives up
     int pairh_skel = -1;     // (-1: 8 at 16 channels, 6 at 32)
     int pair_skel = -1;      // (-1: 4 at 16 channels, 3 at 32)
     int convh_blocks = 0;    // > 0: persistent blocks of the convh / convp / convt launches (default: one per CU)
     int pair_blocks = 0;     // > 0: ... of the pair launches
     int mrf_blocks = 0;      // > 0: ... of the one-launch MRF stage (mrfh_kernel)
     int mrf_shape = 0;       // one-launch MRF stage: 0 -- 12 waves x 3 fragments (576-column windows), 1 -- 16 waves x 2 (512)
+    int mrf_prio = 1;        // ... s_setprio inside the K loops (0: none; 1: level 1; 2 / 3: later waves higher -- mrfh_kernels.hpp)
     int sum3_min = 800;      // fewest tiles for which the three last convs of an MRF stage run as ONE fp32 launch
     int lds_budget = 39;     // fp32 conv kernels: KiB of LDS per block
     int units = 500;
@@ -196,15 +192,6 @@ struct PairMember {
     int cost;            // relative cost of one tile of this member (partition weights): taps + per-tile overhead
     int n_tiles;         // tiles per utterance
     int w_off;           // float offset of this member's two weight images in dynamic LDS
-    // chained launches (PairChain below): where this member's tiles raise their flags, and the flags its inputs
-    // x / add1 / add2 wait for when an earlier phase of the same launch produces them
-    int flag_off;        // first flag of this member's items (item = utterance * n_tiles + tile), or -1
-    struct Dep {
-        int off;         // first flag of the producing member's items, or -1: the input was complete before the launch
-        int nout;        // output samples per tile of the producer
-        int n_tiles;     // its tiles per utterance
-        int halo;        // samples needed on either side of the consumer's tile
-    } dep[3];
 };
 
 constexpr int kSchedBlocks = 256;     // blocks a launch's schedule can describe (one per CU)
@@ -242,11 +229,6 @@ struct PairCore {
     int dbg;             // ablation switches (Tuning::pair_dbg, timing experiments only -- results are wrong):
                          // 1 no x DMA after a block's first tile, 2 no activation pass, 4 no MFMA,
                          // 8 no stores, 16 no residual loads
-    // chained launches: flags[] (device memory, one word per item of every phase) holds `epoch` once the item's
-    // outputs are visible device-wide; null: an ordinary launch
-    unsigned* flags;
-    unsigned flag_bytes;
-    unsigned epoch;
 };
 
 struct PairParams : PairCore {
@@ -254,20 +236,6 @@ struct PairParams : PairCore {
     // lo (11 bits) | count (5 bits): word 0 = member 0 | member 1 << 16, word 1 = member 2.  Part of the kernel
     // arguments: no device table, no copy, legal under stream capture.
     unsigned sched[2 * kSchedBlocks];
-};
-
-// The dependent launches of an MRF stage (pair positions 1, 2, 3 of the three ResBlocks: four launches) as ONE
-// persistent launch: every block runs its share of phase 0, then of phase 1, ...; a tile of a later phase waits for the
-// flags of the tiles it reads (its own window + halo in the producing member, the summands of the stage's last
-// launch) instead of for a kernel boundary.  Tensors that cross phases are written and read with agent-scope (sc1)
-// accesses: the XCDs' L2s are not coherent with each other inside a launch (tools/flag_probe.hip).
-constexpr int kChainPhases = 4;
-struct PairChain {
-    PairCore ph[kChainPhases];
-    int dil[kChainPhases];
-    int n_phases;
-    const unsigned* sched;       // device memory: the block schedule [phase][block][4] (chain_schedule, convh_launch.hip)
-    int spin_limit;              // polls before a waiting block gives up (raises guard word 2 and goes on)
 };
 
 // tile geometry of the pair kernels, the run-time mirror of PairGeom<> (pair_kernels.hpp)
@@ -319,37 +287,12 @@ void pair_schedule(PairParams& p, int nblk, bool three_members = false);
 // (members concatenated) share i starts at, i = 0 .. nblk - 1 (nblk <= 2 kSchedBlocks entries), p.sched_on = 2; n[m]: items
 // of member m.  Left alone (sched_on unchanged) when the table does not fit.
 void pair_cut_schedule(PairParams& p, int nblk, const long long* n);
-// fused ResBlock pair at C = 64 with split-f16 operands and streamed weights (convp_kernels.hpp): members use x, w1, w2
+// fused ResBlock pair at C = 64 with split-f16 operands (convq2_kernels.hpp): members use x, w1, w2
 // (fv_pack_pair_weight_ex images), b1, b2, add1 / add2, y, y_act, k
 int launch_convp(PairParams p, int dil, hipStream_t stream);
-template <int DIL>
-int launch_convp_dil(const PairParams& p, size_t lds, hipStream_t s);
-// Device-side state of a plan's chained launches (PairChain): the item flags (shared by the plan's chains: every launch
-// has its own epoch), one block-schedule table per chain of the run, their host mirrors.
-struct ChainBuffers {
-    unsigned* flags = nullptr;
-    size_t flag_words = 0;
-    unsigned epoch = 0;
-    struct Table {
-        unsigned* dev = nullptr;
-        std::vector<unsigned> host;      // what dev holds
-        std::vector<int> key;            // shapes the schedule below was computed for
-        std::vector<unsigned> sched;
-    };
-    std::vector<Table> tables;
-    void release();
-};
-// n (2 .. kChainPhases) dependent pair launches at 64 channels as one chained launch (convp_chain.hpp); ph[i] / dil[i] as
-// launch_convp would get them, in launch order.  Returns 0 (launched), < 0 (error) or 1: not chained (a phase reads what a
-// later one overwrites, a tile spans too many producer tiles, the stream is being captured before the tables are on
-// the device, ...) -- nothing was launched, the caller launches the phases one by one.
-int launch_convp_chain(PairParams* ph, const int* dil, int n, ChainBuffers& cb, int chain_index, hipStream_t stream);
-int launch_convp_chain_kernel(const PairChain& c, int nblk, size_t lds, hipStream_t s);
-// fused ResBlock pair at C = 128 (convq_kernels.hpp): 128-row x 64-column tiles, one K step per weight stage; members as
-// launch_convp (w1 / w2: the fv_pack_pair_weight_ex images of the conv kernel, [row tile][step][8 KB])
+// fused ResBlock pair at C = 128 (convq2_kernels.hpp): 128-row x 64-column tiles; members as launch_convp (w1 / w2: the
+// fv_pack_pair_weight_ex images of the conv kernel, [row tile][step][8 KB])
 int launch_convq(PairParams p, int dil, hipStream_t stream);
-template <int DIL>
-int launch_convq_dil(const PairParams& p, size_t lds, hipStream_t s);
 template <int CG, int NFW>
 int launch_convh_geom(const PairParams& p, int dil, size_t lds, hipStream_t s);
 // ConvTranspose1d with split-f16 operands, k = 2 stride, Cin = 64 or a multiple of 128 (convt_kernel in
@@ -405,6 +348,7 @@ struct MrfParams {
     int* guard;
     int nblk;
     long long total;         // B * T output columns
+    int prio;                // s_setprio inside the K loops (Tuning::mrf_prio)
     unsigned long long* trace;
 };
 

@@ -49,9 +49,11 @@ struct MrfTile {
     static constexpr int WSLOT = 2 * 6 * 2048 + 1024;   // bytes of a weight slot: the 11-tap pair + its bias block
     static constexpr int HSLOT = (4 * 25 + 4 * 5) * 16; // history of one pair: conv1's <= 25 rows, conv2's <= 5 rows
     static constexpr int HX = 0, HM = 4 * 25 * 16;
-    static constexpr int SBW = W + 8;                   // FOLD: row stride (floats) of the activated fp32 tile
+    static constexpr int SBW = W + 4;                   // FOLD: row stride (floats) of the activated fp32 tile (4 SBW = 16 mod 32:
+                                                        // the four channel groups of a D fragment write disjoint banks)
     static constexpr int OFF_W = 0, OFF_X = 2 * WSLOT, OFF_M = OFF_X + IMG, OFF_H = OFF_M + IMG, OFF_S = OFF_H + 9 * HSLOT;
-    static constexpr int LDS = OFF_S + 256;
+    static constexpr int OFF_F = OFF_S + 256;           // FOLD: the output conv's weights [16][8] (7 taps + pad) and bias
+    static constexpr int LDS = OFF_F + 576;
     static_assert(RP % 16 == 0, "whole bank rows");
     static_assert(C * SBW * 4 <= IMG, "the folded output conv's tile lies over the intermediate image");
     static_assert(LDS <= 160 * 1024, "LDS");
@@ -69,8 +71,8 @@ struct MrfGeom {
 
 __device__ __forceinline__ void mrf_stamp(const MrfParams& p, int nw, int wave, int lane, int it, int ev) {
 #ifdef FV_PAIR_TRACE
-    if (p.trace && (blockIdx.x & 63) == 0 && blockIdx.x < 512 && it < 2 && lane == 0)
-        p.trace[(((size_t)(blockIdx.x >> 6) * nw + wave) * 2 + it) * 64 + ev] = __builtin_amdgcn_s_memtime();
+    if (p.trace && (blockIdx.x & 63) == 0 && blockIdx.x < 256 && it < 3 && lane == 0)
+        p.trace[(((size_t)(blockIdx.x >> 6) * nw + wave) * 3 + it) * 64 + ev] = __builtin_amdgcn_s_memtime();
 #endif
 }
 
@@ -85,6 +87,8 @@ struct MrfLane {
     int tap16;               // 16 x its tap inside a K step (0 / 16)
     int rdoff;               // B operand: byte offset of row FM + colw of its channel block inside an image
     int wroff;               // D fragment: byte offset of its half block entry of row FM + colw inside an image
+    int cpslot;              // history copies: 16 x entry u = tid & 127 (u = 4 row + part, part = 2 split half + channel block)
+    int cpimg;               // ... byte offset of (row, part) inside an image, relative to row 0
     char* sm;                // dynamic LDS
 };
 
@@ -144,19 +148,12 @@ __device__ __forceinline__ void mrf_mma(const float* wl, const char* img, f32x4 
     }
 }
 
-// ---- history copies: rows [r0, r0 + P) of an image (both split halves, both channel blocks) <-> a slot ------------------
-// entry u = 4 row + part, part = 2 half + channel block; the threads [64 W0, 64 W0 + 4 P) each move 16 bytes.  The read
-// is issued where this is called, the write by the caller later (two-step so that the LDS latency hides behind the phase).
-template <int W0>
-__device__ __forceinline__ bool mrf_copy_mine(int tid, int P) {
-    return tid >= 64 * W0 && tid < 64 * W0 + 4 * P;
-}
-template <class TL, int W0>
-__device__ __forceinline__ int mrf_img_off(int tid, int r0) {
-    const int u = tid - 64 * W0, part = u & 3, row = u >> 2;
-    return (part >> 1) * TL::HALF + (part & 1) * (TL::RP * 16) + (r0 + row) * 16;
-}
-
+// ---- history copies: rows [r0, r0 + P) of an image (both split halves, both channel blocks) <-> a slot, 16 bytes per
+// entry u = 4 row + part.  Four copies per pair, each the job of one or two waves (wave-uniform branches: the other waves
+// skip them with a scalar jump), entry u = tid & 127 on every site so that the per-thread offsets are computed once per
+// kernel: phase 1 -- waves 0, 1 save the x image's rows in front of the next window's column 0, wave 2 fetches the
+// intermediate's rows of the previous window; phase 2 -- wave 4 saves the intermediate's, waves 6, 7 fetch the next pair's x
+// rows.  The read is issued in front of the epilogue, the write behind it (the LDS latency hides behind the epilogue).
 // the activated, split image entry of four consecutive channels of one column, from fp32 values
 __device__ __forceinline__ void split_x4(const float (&v)[4], float slope, f16x4& h1, f16x4& h2, float& lowm) {
     const f32x2 a01 = split_act2(f32x2{v[0], v[1]}, slope);
@@ -183,6 +180,22 @@ __device__ __forceinline__ void mrf_write_x(char* xwr, const float (&v)[TL::NF][
     low_note(low, 0, lowm);
 }
 
+// A wave inside its K loop outranks one that is in its epilogue (s_setprio): the waves of a SIMD finish a conv phase one
+// after the other (the arbiter prefers the oldest), the early ones then run their epilogues under the late ones' MFMAs --
+// and have slack until the phase's barrier, which the late ones do not [measured, tools/stage_bench.py: 84 -> 77 us at batch
+// 1, 546 -> 513 at batch 8].  prio 2: the last third of the waves (the arbiter's losers) one step higher still.
+__device__ __forceinline__ void mrf_prio_up(const MrfParams& p, int wave) {
+    if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p.prio == 2) {
+        if (wave >= 8) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(1);
+    } else if (p.prio == 3) {
+        if (wave >= 8) __builtin_amdgcn_s_setprio(3);
+        else if (wave >= 4) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(1);
+    }
+}
+
 // ---- one pair:  xr <- xr + conv2(lrelu(conv1(x image) + b1)) + b2 ------------------------------------------------------
 // On entry the x image holds lrelu(xr) split (complete for every wave, history rows in front), `wl` the pair's block.
 // NEXT: what the x image holds when the pair returns (behind its last barrier): 0 -- lrelu(new xr) (the next pair of the
@@ -193,68 +206,99 @@ template <class TL, class G, int DIL, int NEXT>
 __device__ __forceinline__ void mrf_pair(const MrfParams& p, const MrfLane<TL>& L, const float* wl, float (&xr)[TL::NF][4],
                                          const float (&x0)[TL::NF][4], bool write_next, int tw, bool inside, int adv,
                                          char* hq, char* hq_next, int pnext, LowGuard& low, __amdgpu_buffer_rsrc_t rb,
-                                         float* dma_dst, unsigned dma_off, int dma_pieces) {
+                                         float* dma_dst, unsigned dma_off, int dma_pieces, int tile_no, int q) {
     constexpr int NF = TL::NF;
     constexpr int P1 = (G::KT - 1) * DIL / 2, P2 = G::P2;
-    int tid = L.tid, rdoff = L.rdoff, wroff = L.wroff, tap16 = L.tap16, colw = L.colw, row0 = L.row0;
-    asm volatile("" : "+v"(tid), "+v"(rdoff), "+v"(wroff), "+v"(tap16), "+v"(colw), "+v"(row0));
+    int rdoff = L.rdoff, wroff = L.wroff, tap16 = L.tap16, colw = L.colw, row0 = L.row0, cpslot = L.cpslot, cpimg = L.cpimg;
+    asm volatile("" : "+v"(rdoff), "+v"(wroff), "+v"(tap16), "+v"(colw), "+v"(row0), "+v"(cpslot), "+v"(cpimg));
     char* const ximg = L.sm + TL::OFF_X;
     char* const mimg = L.sm + TL::OFF_M;
     const float* const bl = wl + 2 * G::WB / 4;          // [b1 | b2 | s1 | s2]
+    const int wv = L.wave;
     // the block of the pair after this one: its slot was last read before the barrier this pair started behind
+    mrf_stamp(p, TL::NG, L.wave, L.lane, tile_no, 7 * q);
     mrf_dma<TL::NG>(rb, dma_dst, dma_off, dma_pieces, L.wave, L.lane);
     f32x4 hi[NF], lo[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) hi[f] = lo[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mrf_prio_up(p, wv);
     mrf_mma<G, 2 * DIL * 16, TL::HALF>(wl, ximg + (rdoff + tap16 * DIL - P1 * 16), hi, lo, L.lane);
+    if (p.prio) __builtin_amdgcn_s_setprio(0);
+    mrf_stamp(p, TL::NG, L.wave, L.lane, tile_no, 7 * q + 1);
     {
-        // -- history, first half (a few lanes of waves 0-2; reads here, writes behind the epilogue: the operand queues of
-        // the K loop are dead, the LDS latency hides behind the epilogue): save the x image's rows in front of the next
-        // tile's column 0; fetch the intermediate's
-        f16x8 hs_x = {}, hr_m = {};
-        const bool c_sx = mrf_copy_mine<0>(tid, P1), c_rm = mrf_copy_mine<2>(tid, P2);
-        if (c_sx) hs_x = *reinterpret_cast<const f16x8*>(ximg + mrf_img_off<TL, 0>(tid, TL::FM + adv - P1));
-        if (c_rm) hr_m = *reinterpret_cast<const f16x8*>(hq + TL::HM + (tid - 128) * 16);
+        f16x8 hv = {};
+        if (wv < 2) {
+            if (cpslot < 64 * P1) hv = *reinterpret_cast<const f16x8*>(ximg + cpimg + (TL::FM + adv - P1) * 16);
+        } else if (wv == 2) {
+            if (cpslot < 64 * P2) hv = *reinterpret_cast<const f16x8*>(hq + TL::HM + cpslot);
+        }
         char* const mwr = mimg + wroff;
         const f32x2* const b2 = reinterpret_cast<const f32x2*>(bl + row0);
         const f32x2* const s2 = reinterpret_cast<const f32x2*>(bl + 32 + row0);
         const f32x2 b01 = b2[0], b23 = b2[1], s01 = s2[0], s23 = s2[1];
         float lowm = 0.f;
+        if (inside) {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            const int t = tw + colw + f * 16;
-            f16x4 h1, h2;
-            if (inside) split_mid4<false>(hi[f], lo[f], s01, s23, b01, b23, p.slope, true, h1, h2, lowm);
-            else split_mid4<true>(hi[f], lo[f], s01, s23, b01, b23, p.slope, t >= 0 && t < p.T, h1, h2, lowm);
-            *reinterpret_cast<f16x4*>(mwr + f * 256) = h1;
-            *reinterpret_cast<f16x4*>(mwr + f * 256 + TL::HALF) = h2;
+            for (int f = 0; f < NF; ++f) {
+                f16x4 h1, h2;
+                split_mid4<false>(hi[f], lo[f], s01, s23, b01, b23, p.slope, true, h1, h2, lowm);
+                *reinterpret_cast<f16x4*>(mwr + f * 256) = h1;
+                *reinterpret_cast<f16x4*>(mwr + f * 256 + TL::HALF) = h2;
+            }
+        } else {
+            // conv2's zero padding applies to the intermediate: nothing exists outside [0, T)
+            int cm = colw;
+            asm volatile("" : "+v"(cm));                 // (the compares stay on this side of the branch)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int t = tw + cm + f * 16;
+                f16x4 h1, h2;
+                split_mid4<true>(hi[f], lo[f], s01, s23, b01, b23, p.slope, t >= 0 && t < p.T, h1, h2, lowm);
+                *reinterpret_cast<f16x4*>(mwr + f * 256) = h1;
+                *reinterpret_cast<f16x4*>(mwr + f * 256 + TL::HALF) = h2;
+            }
         }
         low_note(low, 1, lowm);
-        if (c_sx) *reinterpret_cast<f16x8*>(hq + TL::HX + tid * 16) = hs_x;
-        if (c_rm) *reinterpret_cast<f16x8*>(mimg + mrf_img_off<TL, 2>(tid, TL::FM - P2)) = hr_m;
+        if (wv < 2) {
+            if (cpslot < 64 * P1) *reinterpret_cast<f16x8*>(hq + TL::HX + cpslot) = hv;
+        } else if (wv == 2) {
+            if (cpslot < 64 * P2) *reinterpret_cast<f16x8*>(mimg + cpimg + (TL::FM - P2) * 16) = hv;
+        }
     }
+    mrf_stamp(p, TL::NG, L.wave, L.lane, tile_no, 7 * q + 2);
     pair_barrier();                                      // (C) intermediate complete (history rows included), x image free
+    mrf_stamp(p, TL::NG, L.wave, L.lane, tile_no, 7 * q + 3);
 #pragma unroll
     for (int f = 0; f < NF; ++f) hi[f] = lo[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mrf_prio_up(p, wv);
     mrf_mma<G, 2 * 16, TL::HALF>(wl + G::WB / 4, mimg + (rdoff + tap16 - P2 * 16), hi, lo, L.lane);
+    if (p.prio) __builtin_amdgcn_s_setprio(0);
+    mrf_stamp(p, TL::NG, L.wave, L.lane, tile_no, 7 * q + 4);
     {
-        // -- history, second half (waves 3-5): save the intermediate's rows; fetch the NEXT pair's x rows
-        f16x8 hs_m = {}, hr_x = {};
-        const bool c_sm = mrf_copy_mine<3>(tid, P2), c_rx = mrf_copy_mine<4>(tid, pnext);
-        if (c_sm) hs_m = *reinterpret_cast<const f16x8*>(mimg + mrf_img_off<TL, 3>(tid, TL::FM + adv - P2));
-        if (c_rx) hr_x = *reinterpret_cast<const f16x8*>(hq_next + TL::HX + (tid - 256) * 16);
+        f16x8 hv = {};
+        if (wv == 4) {
+            if (cpslot < 64 * P2) hv = *reinterpret_cast<const f16x8*>(mimg + cpimg + (TL::FM + adv - P2) * 16);
+        } else if ((wv >> 1) == 3) {
+            if (cpslot < 64 * pnext) hv = *reinterpret_cast<const f16x8*>(hq_next + TL::HX + cpslot);
+        }
         const f32x2* const b2 = reinterpret_cast<const f32x2*>(bl + 16 + row0);
         const f32x2* const s2 = reinterpret_cast<const f32x2*>(bl + 48 + row0);
         const f32x2 b01 = b2[0], b23 = b2[1], s01 = s2[0], s23 = s2[1];
+        if (inside) {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            combine4(hi[f], lo[f], s01, s23, b01, b23, xr[f]);
-            if (inside) {
+            for (int f = 0; f < NF; ++f) {
+                combine4(hi[f], lo[f], s01, s23, b01, b23, xr[f]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xr[f][i] = hi[f][i];
-            } else {
-                // the next conv's zero padding applies to x: nothing exists outside [0, T)
-                const int t = tw + colw + f * 16;
+            }
+        } else {
+            // the next conv's zero padding applies to x: nothing exists outside [0, T)
+            int cm = colw;
+            asm volatile("" : "+v"(cm));
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                combine4(hi[f], lo[f], s01, s23, b01, b23, xr[f]);
+                const int t = tw + cm + f * 16;
                 const bool ok = t >= 0 && t < p.T;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xr[f][i] = ok ? hi[f][i] : 0.f;
@@ -262,10 +306,15 @@ __device__ __forceinline__ void mrf_pair(const MrfParams& p, const MrfLane<TL>& 
         }
         if constexpr (NEXT == 0) mrf_write_x<TL>(ximg + wroff, xr, p.slope, low);
         else if (write_next) mrf_write_x<TL>(ximg + wroff, x0, p.slope, low);
-        if (c_sm) *reinterpret_cast<f16x8*>(hq + TL::HM + (tid - 192) * 16) = hs_m;
-        if (c_rx) *reinterpret_cast<f16x8*>(ximg + mrf_img_off<TL, 4>(tid, TL::FM - pnext)) = hr_x;
+        if (wv == 4) {
+            if (cpslot < 64 * P2) *reinterpret_cast<f16x8*>(hq + TL::HM + cpslot) = hv;
+        } else if ((wv >> 1) == 3) {
+            if (cpslot < 64 * pnext) *reinterpret_cast<f16x8*>(ximg + cpimg + (TL::FM - pnext) * 16) = hv;
+        }
     }
+    mrf_stamp(p, TL::NG, L.wave, L.lane, tile_no, 7 * q + 5);
     pair_wait_vm0();                                     // this wave's pieces of the next block have landed
+    mrf_stamp(p, TL::NG, L.wave, L.lane, tile_no, 7 * q + 6);
     pair_barrier();                                      // (A) next x image complete, intermediate free, next block visible
 }
 
@@ -276,7 +325,7 @@ template <class TL, int KT, int D0, int D1, int D2>
 __device__ __forceinline__ void mrf_block_run(const MrfParams& p, const MrfLane<TL>& L, float* wbuf, int j, int par, int pnext,
                                               float (&xr)[TL::NF][4], const float (&x0)[TL::NF][4], bool write_next, int tw,
                                               bool inside, int adv, LowGuard& low, __amdgpu_buffer_rsrc_t rb,
-                                              unsigned off_next_block, int pieces_next_block) {
+                                              unsigned off_next_block, int pieces_next_block, int tile_no) {
     typedef MrfGeom<TL::NF, KT> G;
     constexpr int PIECES = (2 * G::WB + 1024) / 1024;
     const int q0 = 3 * j;
@@ -287,19 +336,21 @@ __device__ __forceinline__ void mrf_block_run(const MrfParams& p, const MrfLane<
     char* const h1 = hist + (q0 + 1) * TL::HSLOT;
     char* const h2 = hist + (q0 + 2) * TL::HSLOT;
     char* const hn = hist + (j == 2 ? 0 : q0 + 3) * TL::HSLOT;
-    mrf_pair<TL, G, D0, 0>(p, L, w0, xr, x0, true, tw, inside, adv, h0, h1, (KT - 1) * D1 / 2, low, rb, w1, p.blk_off[q0 + 1], PIECES);
-    mrf_pair<TL, G, D1, 0>(p, L, w1, xr, x0, true, tw, inside, adv, h1, h2, (KT - 1) * D2 / 2, low, rb, w0, p.blk_off[q0 + 2], PIECES);
-    mrf_pair<TL, G, D2, 1>(p, L, w0, xr, x0, write_next, tw, inside, adv, h2, hn, pnext, low, rb, w1, off_next_block, pieces_next_block);
+    mrf_pair<TL, G, D0, 0>(p, L, w0, xr, x0, true, tw, inside, adv, h0, h1, (KT - 1) * D1 / 2, low, rb, w1, p.blk_off[q0 + 1], PIECES, tile_no, q0);
+    mrf_pair<TL, G, D1, 0>(p, L, w1, xr, x0, true, tw, inside, adv, h1, h2, (KT - 1) * D2 / 2, low, rb, w0, p.blk_off[q0 + 2], PIECES, tile_no, q0 + 1);
+    mrf_pair<TL, G, D2, 1>(p, L, w0, xr, x0, write_next, tw, inside, adv, h2, hn, pnext, low, rb, w1, off_next_block, pieces_next_block,
+                           tile_no, q0 + 2);
 }
 
 template <class TL, int D0, int D1, int D2>
 __device__ __forceinline__ void mrf_block(const MrfParams& p, const MrfLane<TL>& L, float* wbuf, int j, int par, int k, int knext,
                                           float (&xr)[TL::NF][4], const float (&x0)[TL::NF][4], bool write_next, int tw, bool inside,
-                                          int adv, LowGuard& low, __amdgpu_buffer_rsrc_t rb, unsigned off_next, int pieces_next) {
+                                          int adv, LowGuard& low, __amdgpu_buffer_rsrc_t rb, unsigned off_next, int pieces_next,
+                                          int tile_no) {
     const int pnext = (knext - 1) * D0 / 2;
-    if (k == 11) mrf_block_run<TL, 11, D0, D1, D2>(p, L, wbuf, j, par, pnext, xr, x0, write_next, tw, inside, adv, low, rb, off_next, pieces_next);
-    else if (k == 7) mrf_block_run<TL, 7, D0, D1, D2>(p, L, wbuf, j, par, pnext, xr, x0, write_next, tw, inside, adv, low, rb, off_next, pieces_next);
-    else mrf_block_run<TL, 3, D0, D1, D2>(p, L, wbuf, j, par, pnext, xr, x0, write_next, tw, inside, adv, low, rb, off_next, pieces_next);
+    if (k == 11) mrf_block_run<TL, 11, D0, D1, D2>(p, L, wbuf, j, par, pnext, xr, x0, write_next, tw, inside, adv, low, rb, off_next, pieces_next, tile_no);
+    else if (k == 7) mrf_block_run<TL, 7, D0, D1, D2>(p, L, wbuf, j, par, pnext, xr, x0, write_next, tw, inside, adv, low, rb, off_next, pieces_next, tile_no);
+    else mrf_block_run<TL, 3, D0, D1, D2>(p, L, wbuf, j, par, pnext, xr, x0, write_next, tw, inside, adv, low, rb, off_next, pieces_next, tile_no);
 }
 
 __device__ __forceinline__ int mrf_pieces(int k) { return (2 * ((k + 1) / 2) * 2048 + 1024) / 1024; }
@@ -352,7 +403,11 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3
         L.tap16 = 16 * (g >> 1);
         L.rdoff = ((g & 1) * TL::RP + TL::FM + L.colw) * 16;
         L.wroff = ((g >> 1) * TL::RP + TL::FM + L.colw) * 16 + 8 * (g & 1);
+        const int u = L.tid & 127, part = u & 3, row = u >> 2;
+        L.cpslot = u * 16;
+        L.cpimg = (part >> 1) * TL::HALF + (part & 1) * (TL::RP * 16) + row * 16;
     }
+    static_assert(NG >= 8, "the history copies are the job of waves 0 ... 7");
     char* const ximg0 = sm + TL::OFF_X;
     char* const mimg0 = sm + TL::OFF_M;
     float* const wbuf = smem + TL::OFF_W / 4;
@@ -396,10 +451,17 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3
         reinterpret_cast<float*>(img + (part >> 1) * TL::HALF + (part & 1) * (TL::RP * 16) + ((fb ? TL::FM + TL::W : 0) + row) * 16)[dw] = 0.f;
     }
     for (int idx = L.tid; idx < 9 * TL::HSLOT / 4; idx += TL::NT) reinterpret_cast<float*>(sm + TL::OFF_H)[idx] = 0.f;
+    if constexpr (FOLD) {
+        float* const fw = reinterpret_cast<float*>(sm + TL::OFF_F);
+        if (L.tid < 128) fw[L.tid] = (L.tid & 7) < 7 ? p.fold_w[(L.tid >> 3) * 7 + (L.tid & 7)] : 0.f;
+        if (L.tid == 128) fw[128] = p.fold_b ? p.fold_b[0] : 0.f;
+    }
     LowGuard low;
     float bad = 0.f;
     const float rcp = div_rcp(p.out_div);
+    mrf_stamp(p, NG, L.wave, L.lane, 2, 0);              // (stamps of "tile 2": kernel entry, prologue)
     pair_wait_vm0();
+    mrf_stamp(p, NG, L.wave, L.lane, 2, 1);
     mrf_write_x<TL>(ximg0 + L.wroff, x0, p.slope, low);
     pair_barrier();
     int tile_no = 0, par = 0;
@@ -407,7 +469,6 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3
         const MrfIter cur = it;
         const bool more = mrf_next(it, g_hi, T, halo, ol, vcols, adv);
         const bool inside = cur.tw >= 0 && cur.tw + TL::W <= T;
-        mrf_stamp(p, NG, L.wave, L.lane, tile_no, 0);
         // ---- the three ResBlocks, one after the other on the same window (a loop, not three copies of the code: a
         // block body is ~12 KB of instructions per tap count) ----
 #pragma unroll 1
@@ -421,8 +482,7 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3
                 for (int i = 0; i < 4; ++i) xr[f][i] = x0[f][i];
             // x0 is free once the last ResBlock has its copy: the next tile's window travels during that block
             if (j == 2 && more) load_x0(it);
-            mrf_block<TL, D0, D1, D2>(p, L, wbuf, j, par, kj, kn, xr, x0, j < 2 || more, cur.tw, inside, adv, low, rb, offn, pcn);
-            mrf_stamp(p, NG, L.wave, L.lane, tile_no, 1 + j);
+            mrf_block<TL, D0, D1, D2>(p, L, wbuf, j, par, kj, kn, xr, x0, j < 2 || more, cur.tw, inside, adv, low, rb, offn, pcn, tile_no);
             if (j < 2) {
 #pragma unroll
                 for (int f = 0; f < NF; ++f)
@@ -431,14 +491,24 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3
             }
         }
         // ---- ((r0 + r1) + r2) / 3 and the stores (behind the tile's last barrier: they drain under the next tile) ----
+        if (tile_no == 0) mrf_stamp(p, NG, L.wave, L.lane, 2, 2);
         float out[NF][4];
 #pragma unroll
         for (int f = 0; f < NF; ++f)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float v = sum[f][i] + xr[f][i];
-                out[f][i] = p.out_div == 1.f ? v : rcp != 0.f ? div_exact(v, p.out_div, rcp) : v / p.out_div;
-            }
+            for (int i = 0; i < 4; ++i) out[f][i] = sum[f][i] + xr[f][i];
+        // (one wave-uniform branch around all twelve values: with the choice inside the loops hipcc branches per value)
+        if (rcp != 0.f) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) out[f][i] = div_exact(out[f][i], p.out_div, rcp);
+        } else if (p.out_div != 1.f) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) out[f][i] = out[f][i] / p.out_div;
+        }
         if constexpr (FOLD) {
             // the activated tile -> LDS (over the intermediate image, free since the last barrier), zero outside [0, T);
             // then one output sample per thread: conv_narrow_kernel's arithmetic (channel-major FMA chain from zero, bias
@@ -452,21 +522,60 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sb[(L.row0 + i) * TL::SBW + col] = ok ? act(out[f][i], p.act_slope) : 0.f;
             }
+            if (tile_no == 0) mrf_stamp(p, NG, L.wave, L.lane, 2, 3);
             pair_barrier();
+            if (tile_no == 0) mrf_stamp(p, NG, L.wave, L.lane, 2, 4);
+            const float* const fw = reinterpret_cast<const float*>(sm + TL::OFF_F);
             for (int c0 = L.tid; c0 < vcols - 2 * ol; c0 += TL::NT) {
-                // output column: the first final one of a warm tile is `ol`; a cold tile's lie further right (time mask)
+                // output column: the first final one of a warm tile is `ol`; a cold tile's lie further right (time mask).
+                // 112 dependent FMAs: the next channel's operands are requested BEFORE this channel's seven FMAs (pinned:
+                // left alone hipcc waits for every pair of LDS operands right behind its load -- 64 round trips, 6 900 cycles
+                // [measured, tools/mrf_trace.py])
                 const int col = c0 + ol, t = cur.tw + col;
+                const float* const sr = sb + col - 3;
                 float o = 0.f;
-#pragma unroll 2
-                for (int c = 0; c < TL::C; ++c)
+                float va[7], vb[7];
+                f32x4 wa0, wb0;
+                f32x2 wa1, wb1;
+                float wa2, wb2;
+                // (exactly seven weight registers per channel: with a spare lane in a wider load hipcc parks a temporary in
+                // it and waits for the load first)
+                auto fetch = [&](int c, float (&v)[7], f32x4& w0, f32x2& w1, float& w2) {
+                    w0 = *reinterpret_cast<const f32x4*>(fw + 8 * c);
+                    w1 = *reinterpret_cast<const f32x2*>(fw + 8 * c + 4);
+                    w2 = fw[8 * c + 6];
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) o = fmaf(p.fold_w[c * 7 + j], sb[c * TL::SBW + col - 3 + j], o);
-                o = o + (p.fold_b ? p.fold_b[0] : 0.f);
+                    for (int j = 0; j < 7; ++j) v[j] = sr[c * TL::SBW + j];
+                };
+                auto chain = [&](const float (&v)[7], const f32x4& w0, const f32x2& w1, float w2) {
+                    o = fmaf(w0[0], v[0], o);
+                    o = fmaf(w0[1], v[1], o);
+                    o = fmaf(w0[2], v[2], o);
+                    o = fmaf(w0[3], v[3], o);
+                    o = fmaf(w1[0], v[4], o);
+                    o = fmaf(w1[1], v[5], o);
+                    o = fmaf(w2, v[6], o);
+                };
+                fetch(0, va, wa0, wa1, wa2);
+#pragma unroll 1
+                for (int c = 0; c < TL::C; c += 2) {
+                    fetch(c + 1, vb, wb0, wb1, wb2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    chain(va, wa0, wa1, wa2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fetch(c + 2 < TL::C ? c + 2 : c, va, wa0, wa1, wa2);      // (the last round fetches a row again: unused)
+                    __builtin_amdgcn_sched_barrier(0);
+                    chain(vb, wb0, wb1, wb2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                o = o + fw[128];
                 if (p.post == FV_POST_TANH) o = tanhf(o);
                 else if (p.post == FV_POST_RELU) o = fmaxf(o, 0.f);
                 if (t >= cur.lo && t < cur.hi) p.fold_y[(size_t)cur.b * T + t] = o;
             }
+            if (tile_no == 0) mrf_stamp(p, NG, L.wave, L.lane, 2, 5);
             pair_barrier();
+            if (tile_no == 0) mrf_stamp(p, NG, L.wave, L.lane, 2, 6);
             // The tile lay over the rows BEHIND the intermediate's window too: they feed discarded columns and, through
             // the zero pad tap, final ones -- finite values again (zeros).  (The rows in FRONT of the window are only ever
             // read as far as a pair's history copy has just rewritten them.)  No barrier: nobody else writes these rows,
@@ -502,7 +611,7 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3
                 }
             }
         }
-        mrf_stamp(p, NG, L.wave, L.lane, tile_no, 4);
+        mrf_stamp(p, NG, L.wave, L.lane, tile_no, 63);
         if (!more) break;
         ++tile_no;
         par ^= 1;

@@ -44,6 +44,7 @@ int launch_mrfh(MrfParams p, int C, const int* dil, hipStream_t s) {
     if (nblk > most) nblk = most;
     if (nblk < 1) nblk = 1;
     p.nblk = (int)nblk;
+    p.prio = tuning().mrf_prio;
     p.trace = reinterpret_cast<unsigned long long*>(tuning().trace_ptr);
     double bytes = 4.0 * ((double)p.B * C * p.T * (fold ? 1.0 : (p.y_act ? 3.0 : 2.0)) + (fold ? (double)p.B * p.T : 0.0)) + off;
     if (fold) flops += 2.0 * p.B * (double)C * 7 * p.T;

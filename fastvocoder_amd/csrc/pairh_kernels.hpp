@@ -198,71 +198,6 @@ __device__ __forceinline__ void range_note4p(f32x2& bad2, const f32x4& v) {
     bad2 = fma2(f32x2{v[2], v[3]}, z, bad2);
 }
 
-// ---- chained launches (fv_internal.h PairChain): per-item flags instead of kernel boundaries -----------------------
-// flags[0] is the launch's abort word (a block that waited spin_limit polls raises it, and the guard word, and every
-// block stops waiting: the host repeats the call unchained); item flags start at kChainFlagBase.  A flag holds the
-// launch's epoch once the item's outputs are acknowledged (sc1 stores, vmcnt(0) in every wave, barrier).
-constexpr int kChainFlagBase = 16;
-
-struct ChainCtx {
-    __amdgpu_buffer_rsrc_t rf;     // over flags[]
-    unsigned epoch;
-    int spin_limit;
-    int* guard;
-    unsigned long long* stall;     // tuning aid (-DFV_PAIR_TRACE): where the ticks spent in chain_spin are added up, or null
-};
-
-// lane -> byte offset in flags[] of ONE flag that the item (utterance b, output samples [t0, t0 + nout)) waits for, or
-// kOutOfRange: lanes 8 g .. 8 g + 7 take the producer tiles of input g (0: x with its halo, 1: add1, 2: add2)
-__device__ __forceinline__ unsigned chain_dep_offset(const PairMember::Dep* dep, int b, int t0, int nout, int T, int lane) {
-    const int g = lane >> 3, i = lane & 7;
-    const int gg = g < 3 ? g : 0;
-    const int off = dep[gg].off, dn = dep[gg].nout, dt = dep[gg].n_tiles, halo = dep[gg].halo;
-    int lo_t = t0 - halo, hi_t = t0 + nout - 1 + halo;
-    lo_t = lo_t < 0 ? 0 : lo_t;
-    hi_t = hi_t > T - 1 ? T - 1 : hi_t;
-    const int lo = lo_t / dn, hi = hi_t / dn;
-    const int idx = lo + i;
-    return g < 3 && off >= 0 && idx <= hi ? (unsigned)(off + b * dt + idx) * 4u : kOutOfRange;
-}
-__device__ __forceinline__ unsigned chain_load(const ChainCtx& c, unsigned voff) {
-    return __builtin_amdgcn_raw_buffer_load_b32(c.rf, (int)voff, 0, kAuxAgent);
-}
-__device__ __forceinline__ bool chain_ready(const ChainCtx& c, unsigned voff, unsigned v) {
-    return __builtin_amdgcn_ballot_w64(voff != kOutOfRange && v != c.epoch) == 0;
-}
-// the slow path: poll until every flag of this wave's lanes holds the epoch (lane 63 watches the abort word)
-__device__ __forceinline__ void chain_spin(const ChainCtx& c, unsigned voff, int lane) {
-    const unsigned vo = lane == 63 ? 0u : voff;
-#ifdef FV_PAIR_TRACE
-    const unsigned long long t_in = __builtin_amdgcn_s_memtime();
-#endif
-    for (int spin = 0;; ++spin) {
-        const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(c.rf, (int)vo, 0, kAuxAgent);
-        const bool pending = __builtin_amdgcn_ballot_w64(lane != 63 && vo != kOutOfRange && v != c.epoch) != 0;
-        const bool aborted = __builtin_amdgcn_ballot_w64(lane == 63 && v == c.epoch) != 0;
-        if (!pending || aborted) break;
-        if (spin >= c.spin_limit) {
-            if (lane == 0) {
-                __builtin_amdgcn_raw_buffer_store_b32(c.epoch, c.rf, 0, 0, kAuxAgent);
-                if (c.guard) *c.guard = 2;
-            }
-            break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-    }
-#ifdef FV_PAIR_TRACE
-    if (c.stall && lane == 0) {
-        atomicAdd(c.stall, __builtin_amdgcn_s_memtime() - t_in);
-        atomicAdd(c.stall + 1, 1ull);
-    }
-#endif
-}
-// one lane, after the block's stores are acknowledged: the item is complete
-__device__ __forceinline__ void chain_signal(const ChainCtx& c, int flag_index) {
-    __builtin_amdgcn_raw_buffer_store_b32(c.epoch, c.rf, flag_index * 4, 0, kAuxAgent);
-}
-
 template <int MH_, int NF_, int NG_, int KT_, int DIL_>
 struct PairHGeom {
     static constexpr int MH = MH_, NF = NF_, NG = NG_, KT = KT_, DIL = DIL_;

@@ -362,7 +362,7 @@ def test_conv1d_split_f16_reflection_rejects():
 def tuning():
     """fv_tuning_set for the duration of a test (process-wide switches of the launchers: restored afterwards)."""
     defaults = {"sched": 1, "sched_switch": 4, "convh_blocks": 0, "pair_blocks": 0, "pair128_unfused": 0, "convg_rows64": -1,
-                "convh_rows64": -1, "convt_rows64": -1, "chain": 0, "convq2": 1, "convp2": 1, "convp_wide": 20, "convq_wide": 20}
+                "convh_rows64": -1, "convt_rows64": -1, "convp_wide": 20, "convq_wide": 20}
     yield _native.tuning_set
     for k, v in defaults.items():
         _native.tuning_set(k, v)
@@ -531,10 +531,13 @@ def test_persistent_blocks_walk_many_tiles_and_cross_members(tuning, blocks):
                 assert _rel(y, ref) <= 2e-5
 
 
-def test_pairs_without_the_weight_ring_give_the_same_bits(tuning):
-    """convq2_kernel (csrc/convq2_kernels.hpp: 16 x 64 wave tiles, A operands from L2 straight into registers, no barrier in the
-    K loops -- the default at 128 channels) against the ring forms convq_kernel / convp_kernel: the same MFMA order per output,
-    so identical bits, on full and three-block grids (long runs of warm tiles), two utterances, every tap count, with the MRF sum."""
+def test_pair_tile_forms_give_the_same_bits(tuning):
+    """convq2_kernel (csrc/convq2_kernels.hpp: A operands from L2 straight into registers, no barrier in the K loops) on its
+    narrow tiles (16 x 64 wave tiles) and on the wide ones (32 x 64: 256 columns at 64 channels, 128 at 128 channels with
+    dilation 1 / 3), on full and three-block grids (long runs of warm tiles), two utterances, every tap count, with the MRF sum:
+    the same MFMA order per output, so identical bits -- and the bits of the two conv launches (convh_kernel) a fused pair
+    replaces.  (Until round 4 this test also ran the LDS-ring forms convq_kernel / convp_kernel, which gave the same bits and
+    were removed in round 5.)"""
     rng = np.random.RandomState(123)
     ks = (11, 3, 7)
     # (the last four: shorter than a tile / than the halo, exactly one cold tile, one column into the first warm tile)
@@ -546,30 +549,29 @@ def test_pairs_without_the_weight_ring_give_the_same_bits(tuning):
         b1s, b2s = [_t(m[2]) for m in ms], [_t(m[4]) for m in ms]
         refs = [_pair_ref(x, w1, b1, w2, b2, dil, 0.1) for x, w1, b1, w2, b2 in ms]
         outs = {}
-        # (ring forms; no ring; no ring and, at 64 channels, the 256-column tiles of the 32 x 64 wave tile)
-        for noring, wide in ((0, 1 << 20), (1, 1 << 20), (1, 0)):
-            tuning("convq2", noring)
-            tuning("convp2", noring)
+        for wide in (1 << 20, 0):            # narrow tiles only; wide tiles wherever they exist
             tuning("convp_wide", wide)
-            tuning("convq_wide", wide)       # (128 channels: 128-column tiles at dilation 1 and 3)
+            tuning("convq_wide", wide)
             for blocks in (0, 3):
                 tuning("convh_blocks", blocks)
                 ys = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, prec=SPLIT)
                 merged = torch.empty_like(xs[0])
                 _native.resblock1_fused([xs[1]], [h1[1]], [h2[1]], [b1s[1]], [b2s[1]], [3], dil, 0.1, outs=[merged], prec=SPLIT,
                                         add1=[ys[0]], add2=[ys[2]], out_div=3.0, act_slope=0.1)
-                outs[(noring, wide, blocks)] = ys + [merged]
+                outs[(wide, blocks)] = ys + [merged]
         tuning("convh_blocks", 0)
-        tuning("convq2", 1)
-        tuning("convp2", 1)
         tuning("convp_wide", 20)
         tuning("convq_wide", 20)
-        base = outs[(0, 1 << 20, 0)]
+        base = outs[(1 << 20, 0)]
         for y, ref in zip(base[:3], refs):
             assert _rel(y, ref) <= 4e-6
         for key, ys in outs.items():
             for y, yb in zip(ys, base):
                 assert torch.equal(y, yb), key
+        mids = _native.conv1d_split_f16(xs, h1, b1s, list(ks), dil, pre_slope=0.1)
+        two = _native.conv1d_split_f16(mids, h2, b2s, list(ks), 1, pre_slope=0.1, res=xs)
+        for yf, yt in zip(base[:3], two):
+            assert torch.equal(yf, yt)
 
 
 def test_pair_results_do_not_depend_on_the_batch():

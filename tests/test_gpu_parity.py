@@ -1101,30 +1101,6 @@ def test_conv_post_and_pqmf_in_one_launch_give_the_same_bits(path):
     assert all(n_f[k].num_ops() == n_p[k].num_ops() - 1 for k in n_f)
 
 
-def test_chained_stage_launch_gives_the_same_bits():
-    """The four pair launches of HiFi-GAN light's 64-channel MRF stage as ONE chained launch (fv_tuning_set "chain":
-    csrc/convp_chain.hpp -- per-tile flags and agent-scope accesses instead of kernel boundaries, a block schedule that
-    balances the blocks' cumulative load and alternates the direction from phase to phase) against the four launches:
-    the same tiles with the same arithmetic, so identical bits -- batch 1 at full length (few tiles per block), a ragged
-    batch, repeated calls (the flags carry an epoch: nothing is cleared in between), and no spin time-outs (the guard
-    word stays clear)."""
-    cfg = cases.load_conf("conf/hifigan/light.yaml")
-    m, _ = _model("hifigan", cfg, seed=0)
-    mel1 = torch.from_numpy(seeded_mel(1000, seed=5, batch=1)).to(_dev())
-    mel3 = torch.from_numpy(seeded_mel(157, seed=6, batch=3)).to(_dev())
-    try:
-        with torch.no_grad():
-            _native.tuning_set("chain", 0)
-            ref1, ref3 = m(mel1).clone(), m(mel3).clone()
-            _native.tuning_set("chain", 1)
-            for _ in range(3):
-                assert torch.equal(m(mel1), ref1)
-                assert torch.equal(m(mel3), ref3)
-            assert not m.check_range() and not m._fv_overflow
-    finally:
-        _native.tuning_set("chain", 0)
-
-
 @pytest.mark.parametrize("name,path", [("basis-melgan", "conf/basis-melgan/light.yaml"), ("melgan", "conf/melgan/original.yaml"),
                                        ("hifigan", "conf/hifigan/large.yaml")], ids=["basis", "melgan", "hifigan-large"])
 def test_128_row_tiles_give_the_same_waveform_bits(name, path):

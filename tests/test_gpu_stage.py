@@ -34,7 +34,7 @@ def _rel(a, b):
 @pytest.fixture
 def tuning():
     yield _native.tuning_set
-    for k, v in {"mrf_blocks": 0, "mrf_shape": 0}.items():
+    for k, v in {"mrf_blocks": 0, "mrf_shape": 0, "mrf_prio": 1}.items():
         _native.tuning_set(k, v)
 
 

@@ -67,6 +67,12 @@ def main():
             t_fold = timed(lambda: _native.mrf_stage_split_f16(x, P, KS, fold=(fw, fb), act_slope=0.01, post=_native.POST_TANH))
             line += f" | shape {shape}: one launch {t_one:8.1f} us, with conv_post {t_fold:8.1f} us"
         _native.tuning_set("mrf_shape", 0)
+        for prio in (0, 2, 3):
+            _native.tuning_set("mrf_prio", prio)
+            t_one = timed(lambda: _native.mrf_stage_split_f16(x, P, KS, out=y))
+            t_fold = timed(lambda: _native.mrf_stage_split_f16(x, P, KS, fold=(fw, fb), act_slope=0.01, post=_native.POST_TANH))
+            line += f" | shape 0, prio {prio}: {t_one:8.1f} us, with conv_post {t_fold:8.1f} us"
+        _native.tuning_set("mrf_prio", 1)
         print(line, flush=True)
 
 
