@@ -35,7 +35,10 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="override the batch size of the selected configs")
     ap.add_argument("--no-last-stack", action="store_true", help="A/B: the graph's last ResidualStack as two launches (fuse_last = False)")
     ap.add_argument("--no-stack", action="store_true", help="A/B: MelGAN's ResidualStacks as two launches each (fuse_stack = False)")
+    ap.add_argument("--families-json", default=None, help="write {family: {launches, algorithmic flops}} of ONE forward of each "
+                    "selected config to this file (the matrix-cycle accounting of tools/summarise_profiles.py)")
     args = ap.parse_args()
+    fam_out = {}
     if args.no_last_stack:
         from fastvocoder_amd.generator.modules import ResidualStack
         ResidualStack.fuse_last = False
@@ -59,6 +62,7 @@ def main():
         m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(name, cfg).items()})
         m = m.to(dev).eval()
         m.remove_weight_norm()
+        m.range_guard = "lazy"           # stream-ordered steps (the module default checks every call before it returns)
         if "pair_dbg" in args.tuning:
             m.range_guard = "off"        # (ablation switches give wrong values: timing only)
         mel = torch.from_numpy(seeded_mel(T, seed=1, batch=B)).to(dev)
@@ -75,7 +79,15 @@ def main():
             fn()
             torch.cuda.synchronize()
             _native.profile_enable(False)
-            prof = _native.profile_collect(-1)
+            if args.families_json:
+                kinds = {"conv32": _native.KERNEL_CONV_MFMA32, "conv16": _native.KERNEL_CONV_MFMA16, "pairh16": _native.KERNEL_PAIRH16,
+                         "pairh32": _native.KERNEL_PAIRH32, "convh64": _native.KERNEL_CONVH64, "convh128": _native.KERNEL_CONVH128,
+                         "convt": _native.KERNEL_CONVT, "convg": _native.KERNEL_CONVG, "stack": _native.KERNEL_STACK,
+                         "mrf16": _native.KERNEL_MRF16}
+                rec = {k: _native.profile_collect(v) for k, v in kinds.items()}
+                fam_out[label] = {"batch": B, "frames": T,
+                                  "families": {k: {"launches": int(r["launches"]), "flops": r["flops"]} for k, r in rec.items() if r["launches"]}}
+            prof = _native.profile_collect(-1) if not args.families_json else {"flops": sum(r["flops"] for r in rec.values())}
             t0 = time.perf_counter()
             steps = args.steps * (20 if B * T <= 2000 else 1)      # (a 0.3 ms step: 5 of them time the host's wake-up)
             for _ in range(steps):
@@ -87,6 +99,10 @@ def main():
               f"{prof['flops']/dt/1e12:6.1f} TFLOP/s algorithmic", flush=True)
         del m, mel, y
         torch.cuda.empty_cache()
+    if args.families_json:
+        import json
+        with open(args.families_json, "w") as f:
+            json.dump(fam_out, f, indent=1)
 
 
 if __name__ == "__main__":

@@ -2,7 +2,7 @@
 # Round profile collection on the GPU box (run from the repo root through gpurun):
 #   tools/collect_profiles.sh r02
 # writes gpurun_out/<tag>/...; turn it into the committed profiles/<tag>_* with tools/summarise_profiles.py <tag>
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$PWD
 mkdir -p $R/gpurun_out/$TAG
 export TMPDIR=/tmp
@@ -18,4 +18,10 @@ for i in 0 2 3 4; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/cfg$i -o cfg -- python $R/tools/bench_configs.py --only $i --steps 3 > $R/gpurun_out/$TAG/cfg$i.log 2>&1
 done
 python $R/tools/bench_configs.py --steps 5 > $R/gpurun_out/$TAG/configs.log 2>&1
+# --- matrix-cycle accounting at saturation: HiFi-GAN light B = 16 (index 5) and configs 3, 4, 5 -- executed MFMA
+#     instructions (SQ_INSTS_MFMA) next to the algorithmic FLOP of the same forward (the library's measurement hook) ---
+PMC="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA"
+for i in 5 2 3 4; do
+  rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $R/gpurun_out/$TAG/sat$i -o sat -- python $R/tools/bench_configs.py --only $i --steps 1 --families-json $R/gpurun_out/$TAG/sat${i}_families.json > $R/gpurun_out/$TAG/sat$i.log 2>&1
+done
 tail -c 300 $R/gpurun_out/$TAG/bench.json; cat $R/gpurun_out/$TAG/configs.log

@@ -30,7 +30,8 @@ def main():
     out = {"unit": "bytes per launch", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": {}}
     fam_bytes, fam_n = 0.0, 0
     split = {"16": [0.0, 0], "32": [0.0, 0]}          # fv::pairh_kernel<MH = 1 | 2, ...>: C = 16 | 32
-    wide = [0.0, 0]                                   # fv::convh_kernel / convp_kernel / convq_kernel / convq2_kernel: the 128- / 64-channel stages
+    wide = [0.0, 0]                                   # fv::convh_kernel / convq2_kernel: the 128- / 64-channel stages
+    stage16 = [0.0, 0]                                # fv::mrfh_kernel: the 16-channel stage as one launch
     for k in sorted(fetch, key=lambda k: -fetch[k]):
         if k not in write or "fv::" not in k:
             continue
@@ -44,6 +45,9 @@ def main():
         if "convh_kernel<" in k or "convp_kernel<" in k or "convq_kernel<" in k or "convq2_kernel<" in k:
             wide[0] += (fb + wb) * nf[k]
             wide[1] += nf[k]
+        if "mrfh_kernel<" in k:
+            stage16[0] += (fb + wb) * nf[k]
+            stage16[1] += nf[k]
         if "pairh_kernel<" in k:
             c = "16" if "pairh_kernel<1," in k else "32"
             split[c][0] += (fb + wb) * nf[k]
@@ -52,6 +56,8 @@ def main():
     out["conv_mfma_family"] = {"launches": fam_n, "hbm_bytes_per_launch": fam_bytes / max(fam_n, 1)}
     if wide[1]:
         out["split_f16_convs"] = {"launches": wide[1], "hbm_bytes_per_launch": wide[0] / wide[1]}
+    if stage16[1]:
+        out["split_f16_stage_c16"] = {"launches": stage16[1], "hbm_bytes_per_launch": stage16[0] / stage16[1]}
     for c, (b, n) in split.items():
         if n:
             out["split_f16_pairs_c" + c] = {"launches": n, "hbm_bytes_per_launch": b / n}

@@ -59,21 +59,26 @@ def main():
                                     DILS[2], 0.1, prec=SPLIT, outs=parts)
             _native.resblock1_fused(cur[:1], [P1[2]], [P2[2]], [b1[2]], [b2[2]], [KS[0]], DILS[2], 0.1, prec=SPLIT,
                                     add1=[parts[0]], add2=[parts[1]], out_div=3.0, outs=[y])
-        t_pairs = timed(pairs)
-        line = f"B={B} T={T}: four pair launches {t_pairs:8.1f} us"
+        # variants interleaved over several rounds, the minimum of each (the first timings of a process run 5-8 % slower
+        # than the later ones -- clocks, caches: a single pass in a fixed order compares the order, not the variants)
+        variants = {"four pair launches": (None, None, pairs)}
         for shape in (0, 1):
-            _native.tuning_set("mrf_shape", shape)
-            t_one = timed(lambda: _native.mrf_stage_split_f16(x, P, KS, out=y))
-            t_fold = timed(lambda: _native.mrf_stage_split_f16(x, P, KS, fold=(fw, fb), act_slope=0.01, post=_native.POST_TANH))
-            line += f" | shape {shape}: one launch {t_one:8.1f} us, with conv_post {t_fold:8.1f} us"
+            for prio in ((0, 1, 3) if shape == 0 else (1,)):
+                variants[f"one launch, shape {shape}, prio {prio}"] = (shape, prio, lambda: _native.mrf_stage_split_f16(x, P, KS, out=y))
+                variants[f"  ... with conv_post, shape {shape}, prio {prio}"] = (shape, prio, lambda: _native.mrf_stage_split_f16(
+                    x, P, KS, fold=(fw, fb), act_slope=0.01, post=_native.POST_TANH))
+        best = {k: [] for k in variants}
+        for rnd in range(5):
+            for name, (shape, prio, fn) in variants.items():
+                if shape is not None:
+                    _native.tuning_set("mrf_shape", shape)
+                    _native.tuning_set("mrf_prio", prio)
+                best[name].append(timed(fn, reps=20, warm=3))
         _native.tuning_set("mrf_shape", 0)
-        for prio in (0, 2, 3):
-            _native.tuning_set("mrf_prio", prio)
-            t_one = timed(lambda: _native.mrf_stage_split_f16(x, P, KS, out=y))
-            t_fold = timed(lambda: _native.mrf_stage_split_f16(x, P, KS, fold=(fw, fb), act_slope=0.01, post=_native.POST_TANH))
-            line += f" | shape 0, prio {prio}: {t_one:8.1f} us, with conv_post {t_fold:8.1f} us"
         _native.tuning_set("mrf_prio", 1)
-        print(line, flush=True)
+        print(f"B={B} T={T}  (us per call: min / median of 5 interleaved rounds)")
+        for name, ts in best.items():
+            print(f"   {name:48s} {min(ts):8.1f} {sorted(ts)[len(ts) // 2]:8.1f}", flush=True)
 
 
 if __name__ == "__main__":

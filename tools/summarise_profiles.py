@@ -26,7 +26,9 @@ with open(f"{dst}/{tag}_mfma_counters.txt", "w") as f:
     f.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY\n"
             "#   SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace -- python bench.py --steps 5 --warmup 2\n"
             "# MI355X, HiFi-GAN light B=1 T=1000; per-dispatch averages; GRBM_GUI_ACTIVE is summed over the 8 XCDs\n")
-    fams = {"split-f16 convs with streamed weights (convh_kernel, convp_kernel, convq_kernel, convq2_kernel)": ("convh_kernel", "convp_kernel", "convq_kernel", "convq2_kernel"), "split-f16 fused pairs (pairh_kernel)": ("pairh_kernel",),
+    fams = {"split-f16 convs / fused pairs at 64+ channels (convh_kernel, convs_kernel, convq2_kernel)": ("convh_kernel", "convs_kernel", "convq2_kernel"),
+            "split-f16 fused pairs at 32 channels (pairh_kernel)": ("pairh_kernel",),
+            "split-f16 one-launch 16-channel MRF stage (mrfh_kernel)": ("mrfh_kernel",),
             "split-f16 transposed convs (convt_kernel)": ("convt_kernel",),
             "fp32-MFMA convs (conv_mfma_kernel + conv_group3_kernel + conv_sum3_kernel + pair_kernel + pair_sum_kernel)":
                 ("conv_mfma_kernel", "conv_group3_kernel", "conv_sum3_kernel", "fv::pair_kernel", "pair_sum_kernel")}
@@ -75,3 +77,60 @@ with open(f"{dst}/{tag}_configs.md", "w") as f:
                     f"{100 * float(r['TotalDurationNs']) / total:.1f} % |\n")
         f.write("\n")
 print(open(f"{dst}/{tag}_configs.md").read()[:1500])
+
+# ---- matrix-cycle accounting at saturation: per kernel family, executed MFMA FLOP (SQ_INSTS_MFMA x the
+# FLOP of one v_mfma_f32_16x16x32_f16: 16 384) next to 3 x the algorithmic FLOP of the same forward, and MFMA-busy ----
+import json  # noqa: E402
+
+FAMILY_OF = [("mrfh_kernel", "mrf16"), ("pairh_kernel<1,", "pairh16"), ("pairh_kernel<2,", "pairh32"),
+             ("convq2_kernel<1, 64>", "convh64"), ("convq2_kernel<3, 64>", "convh64"), ("convq2_kernel<5, 64>", "convh64"),
+             ("convq2_kernel<1, 65>", "convh64"), ("convq2_kernel<3, 65>", "convh64"), ("convq2_kernel<5, 65>", "convh64"),
+             ("convq2_kernel", "convh128"), ("convh_kernel<2,", "convh64"), ("convh_kernel", "convh128"), ("convs_kernel", "convh128"),
+             ("convt_kernel", "convt"), ("convtn_kernel", "convt"), ("convu_kernel", "convt"), ("convg_kernel", "convg"),
+             ("convr_kernel", "convg"), ("convk2_kernel", "stack"), ("convk_kernel", "stack")]
+titles = {5: "HiFi-GAN light, 16 utterances of 1000 frames", 2: "config 3: MB-HiFi-GAN light + PQMF, batch 32",
+          3: "config 4: Basis-MelGAN light, batch 64", 4: "config 5 (one GPU's share): HiFi-GAN large, batch 64"}
+out_path = f"{dst}/{tag}_saturated_counters.txt"
+with open(out_path, "w") as f:
+    f.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA\n"
+            "#   --kernel-trace -- python tools/bench_configs.py --only i --steps 1 --families-json ...   (tools/collect_profiles.sh)\n"
+            "# executed = SQ_INSTS_MFMA x 16 384 FLOP (one v_mfma_f32_16x16x32_f16 per wave), all dispatches of the family in the run;\n"
+            "# algorithmic = the library's measurement hook for ONE forward (2 B Cout Cin k T per conv) x forwards in the run;\n"
+            "# a split-f16 kernel executes THREE f16 FLOP per algorithmic FLOP by construction: executed / (3 x algorithmic) = 1 is ideal,\n"
+            "# the excess is recomputed halo columns, the zero tap that pads an odd tap count, padded rows / chunks.\n")
+    for i, title in titles.items():
+        cpath, jpath = f"{src}/sat{i}/sat_counter_collection.csv", f"{src}/sat{i}_families.json"
+        if not (os.path.exists(cpath) and os.path.exists(jpath)):
+            continue
+        fams = list(json.load(open(jpath)).values())[0]["families"]
+        ktot = defaultdict(lambda: defaultdict(float))
+        kn = defaultdict(int)
+        for row in csv.DictReader(open(cpath)):
+            k = row["Kernel_Name"]
+            if "fv::" not in k or "pack" in k or "fold" in k or "row_scale" in k:
+                continue
+            ktot[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            if row["Counter_Name"] == "SQ_INSTS_MFMA":
+                kn[k] += 1
+        ftot, fdisp = defaultdict(lambda: defaultdict(float)), defaultdict(int)
+        f.write(f"\n## {title}\n")
+        for k in sorted(ktot, key=lambda k: -ktot[k].get("GRBM_GUI_ACTIVE", 0)):
+            d = ktot[k]
+            fam = next((fm for pat, fm in FAMILY_OF if pat in k), None)
+            if d.get("GRBM_GUI_ACTIVE") and d.get("SQ_INSTS_MFMA"):
+                f.write(f"{k[:84]:84s} n={kn[k]:3d}  MFMA-busy {d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f}  "
+                        f"VALU per MFMA {d['SQ_INSTS_VALU'] / d['SQ_INSTS_MFMA']:.2f}  executed {d['SQ_INSTS_MFMA'] * 16384 / 1e9 / max(kn[k], 1):9.1f} GFLOP / dispatch"
+                        f"  [{fam}]\n")
+            if fam:
+                for cn, v in d.items():
+                    ftot[fam][cn] += v
+                fdisp[fam] += kn[k]
+        f.write("family      dispatches  forwards  executed f16 GFLOP   3 x algorithmic   executed / (3 x alg)   MFMA-busy   VALU per MFMA\n")
+        for fam, d in ftot.items():
+            if fam not in fams or not d.get("SQ_INSTS_MFMA"):
+                continue
+            forwards = fdisp[fam] / max(fams[fam]["launches"], 1)
+            ex, alg3 = d["SQ_INSTS_MFMA"] * 16384 / 1e9, 3 * fams[fam]["flops"] * forwards / 1e9
+            f.write(f"{fam:10s} {fdisp[fam]:10d} {forwards:9.1f} {ex:18.1f} {alg3:17.1f} {ex / alg3:22.3f} "
+                    f"{d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] / 8 * 1024):11.3f} {d['SQ_INSTS_VALU'] / d['SQ_INSTS_MFMA']:15.2f}\n")
+print(open(out_path).read()[:3000])
