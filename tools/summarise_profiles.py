@@ -113,6 +113,12 @@ with open(out_path, "w") as f:
             if row["Counter_Name"] == "SQ_INSTS_MFMA":
                 kn[k] += 1
         ftot, fdisp = defaultdict(lambda: defaultdict(float)), defaultdict(int)
+        kdur, kdn = defaultdict(float), defaultdict(int)
+        tpath = f"{src}/sat{i}/sat_kernel_trace.csv"
+        if os.path.exists(tpath):
+            for row in csv.DictReader(open(tpath)):
+                kdur[row["Kernel_Name"]] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                kdn[row["Kernel_Name"]] += 1
         f.write(f"\n## {title}\n")
         for k in sorted(ktot, key=lambda k: -ktot[k].get("GRBM_GUI_ACTIVE", 0)):
             d = ktot[k]
@@ -120,17 +126,29 @@ with open(out_path, "w") as f:
             if d.get("GRBM_GUI_ACTIVE") and d.get("SQ_INSTS_MFMA"):
                 f.write(f"{k[:84]:84s} n={kn[k]:3d}  MFMA-busy {d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f}  "
                         f"VALU per MFMA {d['SQ_INSTS_VALU'] / d['SQ_INSTS_MFMA']:.2f}  executed {d['SQ_INSTS_MFMA'] * 16384 / 1e9 / max(kn[k], 1):9.1f} GFLOP / dispatch"
-                        f"  [{fam}]\n")
+                        f"  busy cycles per MFMA {d['SQ_VALU_MFMA_BUSY_CYCLES'] / d['SQ_INSTS_MFMA']:.1f}"
+                        + (f"  clock {(d['GRBM_GUI_ACTIVE'] / 8 / kn[k]) / (kdur[k] / kdn[k]):.2f} GHz" if kdn.get(k) else "")
+                        + f"  [{fam}]\n")
+                if fam and kdn.get(k):
+                    ftot[fam]["_ns"] += kdur[k]
             if fam:
                 for cn, v in d.items():
                     ftot[fam][cn] += v
                 fdisp[fam] += kn[k]
-        f.write("family      dispatches  forwards  executed f16 GFLOP   3 x algorithmic   executed / (3 x alg)   MFMA-busy   VALU per MFMA\n")
+        f.write("family      dispatches  forwards  executed f16 GFLOP   3 x algorithmic   executed / (3 x alg)   MFMA-busy   VALU per MFMA   clock GHz   executed / peak at 2.4 GHz\n")
         for fam, d in ftot.items():
             if fam not in fams or not d.get("SQ_INSTS_MFMA"):
                 continue
             forwards = fdisp[fam] / max(fams[fam]["launches"], 1)
             ex, alg3 = d["SQ_INSTS_MFMA"] * 16384 / 1e9, 3 * fams[fam]["flops"] * forwards / 1e9
             f.write(f"{fam:10s} {fdisp[fam]:10d} {forwards:9.1f} {ex:18.1f} {alg3:17.1f} {ex / alg3:22.3f} "
-                    f"{d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] / 8 * 1024):11.3f} {d['SQ_INSTS_VALU'] / d['SQ_INSTS_MFMA']:15.2f}\n")
+                    f"{d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] / 8 * 1024):11.3f} {d['SQ_INSTS_VALU'] / d['SQ_INSTS_MFMA']:15.2f}"
+                    + (f" {d['GRBM_GUI_ACTIVE'] / 8 / d['_ns']:11.2f} {ex * 1e9 / (d['_ns'] * 1e-9) / 2.5e15:18.3f}" if d.get("_ns") else "") + "\n")
+    f.write("\n# Reading (VERDICT r4 item 3: MFMA-busy 0.60 against 0.42 of the peak in algorithmic FLOP at 128 channels).  The counter\n"
+            "# charges exactly 16 busy cycles per v_mfma_f32_16x16x32_f16, and executed / (3 x algorithmic) is 1.03-1.06 for the 64- / 128-channel\n"
+            "# pairs: the busy matrix cycles ARE the algorithmic FLOP (plus 3-6 % halo columns / zero taps).  What separates 0.60 from 0.42 is\n"
+            "# the CLOCK: under these MFMA-dense launches the chip runs at 1.8-1.9 GHz (GRBM_GUI_ACTIVE / dispatch duration, column above),\n"
+            "# while the 2.5 PFLOP/s peak the fraction is priced against is the 2.4 GHz figure: 0.60 busy x 1.87 / 2.4 = 0.47 of that peak\n"
+            "# executed = 0.44 algorithmic x 1.06.  (MI355X_MICROARCH.md, DVFS give-back: denser bodies clock lower; profiled passes\n"
+            "# run another 2-3 % below un-profiled ones.)\n")
 print(open(out_path).read()[:3000])
