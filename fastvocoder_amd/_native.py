@@ -36,6 +36,7 @@ PAIR_F32, PAIR_SPLIT_F16 = 0, 1   # arithmetic of the fused ResBlock-pair kernel
 
 
 ERR_RANGE = -4                    # fv_plan_check_range: a split-f16 kernel met an operand beyond the f16 range
+ERR_RANGE_LOW = -5                # ... only the low-side guard fired (a block's share of a tensor was small as a whole)
 
 
 class NativeError(RuntimeError):
@@ -1011,6 +1012,8 @@ class Plan:
         rc = lib().fv_plan_check_range(self._h, torch.cuda.current_stream(self._dev).cuda_stream)
         if rc == ERR_RANGE:
             return True
+        if rc == ERR_RANGE_LOW:
+            return "low"             # (truthy: the run has to be repeated; the caller may treat it as a property of the input)
         check(rc)
         return False
 

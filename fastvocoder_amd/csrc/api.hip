@@ -2388,8 +2388,12 @@ int fv_plan_check_range(fv_plan_t* plan, void* stream) {
     if (!plan->guard_host) return 0;
     FV_HIP(hipStreamSynchronize((hipStream_t)stream));
     volatile int* w = plan->guard_host;
-    if (*w == 0) return 0;
+    const int seen = *w;
+    if (seen == 0) return 0;
     *w = 0;
+    if (seen == 4)
+        return fail(FV_ERR_RANGE_LOW, "a split-f16 kernel met operands that were smaller than 2^-10 throughout a block's share of a "
+                                      "tensor (not all zero): the last run may carry fewer than 22 bits; repeat it on an fp32-precision plan");
     return fail(FV_ERR_RANGE, "a split-f16 kernel met an operand outside its domain (|v| >= 65520 or a non-finite value; "
                               "or operands that were smaller than 2^-10 throughout a block's share of a tensor): the "
                               "results of the last run are not valid; repeat it on an fp32-precision plan");

@@ -660,6 +660,10 @@ class NativeModule(torch.nn.Module):
                          already returned non-finite values.  ``bench.py`` times its steps under "lazy" (and says so),
                          calls ``check_range()`` after them, and reports the "sync" figure beside.
                      "off"  -- no check.
+                     The two sides of the domain are told apart (under "sync" / "auto"): an overflow (or a non-finite value)
+                     moves the module to fp32 at once; the LOW side alone -- a block's share of a tensor that is small as a
+                     whole, e.g. a quiet stretch of an utterance; the test is per block, not per tensor -- only repeats THAT
+                     call on fp32, and moves the module after ``low_range_patience`` such calls in a row.
     ``fuse_pairs``   ResBlock1 pairs as fused launches (default) or conv by conv (round-1 path; A/B runs).
     ``fuse_stage``   a 16-channel MRF stage (three ResBlock1s of three pairs + the mean) as ONE launch (default,
                      csrc/mrfh_kernels.hpp) or as four fused-pair launches (A/B runs; identical bits).
@@ -671,6 +675,7 @@ class NativeModule(torch.nn.Module):
 
     precision = "split"
     range_guard = "auto"
+    low_range_patience = 3        # consecutive low-side alarms answered call by call before the module moves to fp32 for good
     fuse_pairs = True
     fuse_stage = True
     fold_post = True
@@ -684,11 +689,13 @@ class NativeModule(torch.nn.Module):
         self._fv_key = None
         self._fv_guard = None
         self._fv_overflow = False
+        self._fv_low_hits = 0
+        self._fv_force_f32 = False
 
     # -- cache bookkeeping -------------------------------------------------
     def _fv_policy(self):
         """The policy a plan is built under (part of every plan's cache key)."""
-        prec = "f32" if (self.precision == "f32" or self._fv_overflow) else "split"
+        prec = "f32" if (self.precision == "f32" or self._fv_overflow or getattr(self, "_fv_force_f32", False)) else "split"
         # (the guard is part of the key: a plan built under range_guard = "off" carries no guard word)
         return (prec, bool(self.fuse_pairs), bool(self.fold_post), self.range_guard != "off", bool(self.merge_in_upsampler),
                 bool(self.fuse_stage))
@@ -720,6 +727,7 @@ class NativeModule(torch.nn.Module):
         self._fv_plans = {}
         self._fv_tensors = None
         self._fv_overflow = False         # new weights: the split-f16 path gets its chance again
+        self._fv_low_hits = 0
         self.__dict__.pop("_fv_zero", None)
         self.__dict__.pop("_zero_cache", None)
 
@@ -806,9 +814,23 @@ class NativeModule(torch.nn.Module):
             self._went_out_of_range("an EARLIER call met an activation (its output holds non-finite values)")
         plan = plan_for(x.shape[2])
         out = plan.run(x, **run_kw)
-        if mode == "sync" and plan.guarded and plan.check_range():
-            self._went_out_of_range("an activation lies")
-            out = plan_for(x.shape[2]).run(x, **run_kw)
+        if mode == "sync" and plan.guarded:
+            seen = plan.check_range()
+            if seen == "low" and getattr(self, "_fv_low_hits", 0) < self.low_range_patience:
+                # The LOW side alone: some block's share of a tensor was small as a whole -- a property of THIS input (a quiet
+                # stretch), not of the model.  This call is repeated on the exact-fp32 kernels; the module stays on the split
+                # kernels (until it has happened `low_range_patience` times in a row: then it is the model).
+                self._fv_low_hits = getattr(self, "_fv_low_hits", 0) + 1
+                self._fv_force_f32 = True
+                try:
+                    out = plan_for(x.shape[2]).run(x, **run_kw)
+                finally:
+                    self._fv_force_f32 = False
+            elif seen:
+                self._went_out_of_range("an activation lies")
+                out = plan_for(x.shape[2]).run(x, **run_kw)
+            else:
+                self._fv_low_hits = 0
         return out
 
     def check_range(self):

@@ -38,6 +38,10 @@ extern "C" {
 /* a split-f16 kernel met an operand beyond the f16 range or a non-finite value (fv_plan_check_range): the run's results
  * are not valid; the caller repeats it with FV_PAIR_F32 arithmetic */
 #define FV_ERR_RANGE (-4)
+/* ... the same for the LOW side of the domain only (operands that were smaller than 2^-10 throughout a block's share of a
+ * tensor): the run's results may carry fewer than 22 bits; repeating THIS run with FV_PAIR_F32 is enough -- the condition is
+ * a property of the input, not of the model */
+#define FV_ERR_RANGE_LOW (-5)
 
 /* padding of a conv's input: zero "same" padding (torch.nn.Conv1d padding=,
  * model/generator/modules.py:193-221) or reflection padding + valid conv
@@ -595,7 +599,7 @@ int fv_plan_num_ops(fv_plan_t* plan);
  *   the caller and zero-initialised; every split-f16 kernel the plan launches sets it to 1 when one of its final values
  *   is not finite.  NULL removes the guard.
  * fv_plan_check_range: waits for `stream` (the stream of the plan's last run) to drain, then returns 0 when the word is
- *   clear; otherwise clears it and returns FV_ERR_RANGE: the outputs of the run(s) since the last check are not valid
+ *   clear; otherwise clears it and returns FV_ERR_RANGE (FV_ERR_RANGE_LOW when only the low-side guard fired): the outputs of the run(s) since the last check are not valid
  *   (inf / NaN where the fp32 reference is finite) and must be recomputed on a plan built with FV_PAIR_F32 arithmetic --
  *   fastvocoder_amd/generator/engine.py does that automatically (NativeModule.range_guard).
  */

@@ -1027,6 +1027,11 @@ def test_melgan_outside_the_split_domain_repeats_on_fp32(gain):
         want = exact.inference(mel)
     assert bool(torch.isfinite(want).all()) and float(want.abs().max()) > 1e-4
     m = _scaled_melgan(gain)
+    if gain < 1:
+        # the low side alone is first taken for a property of the input: the call is repeated on fp32, the module stays
+        with torch.no_grad():
+            for _ in range(m.low_range_patience):
+                assert torch.equal(m.inference(mel), want) and m._fv_policy()[0] == "split"
     with pytest.warns(RuntimeWarning, match="split-f16 range"), torch.no_grad():
         got = m.inference(mel)
     assert torch.equal(got, want) and m._fv_policy()[0] == "f32"
@@ -1062,13 +1067,17 @@ def test_weights_of_any_magnitude_stay_on_the_split_kernels():
 def test_generator_below_the_low_side_repeats_on_fp32():
     """The low side of the domain end to end: conv_pre 2^-20 times too quiet (conv_post undoes it) -- the first split-f16
     layer sees a tensor that is small as a whole, the guard fires (4), `inference` repeats the call on the exact-fp32
-    kernels and returns the fp32 model's output bit for bit; at 2^-6 the model stays on the split kernels."""
+    kernels and returns the fp32 model's output bit for bit -- call by call at first (a quiet input is not the model's
+    fault), for good after `low_range_patience` such calls in a row; at 2^-6 the model stays on the split kernels."""
     mel = seeded_mel(64, seed=31)
     exact = _scaled_hifigan(2.0 ** -20)
     exact.precision = "f32"
     with torch.no_grad():
         want = exact.inference(mel)
     m = _scaled_hifigan(2.0 ** -20)
+    with torch.no_grad():
+        for _ in range(m.low_range_patience):
+            assert torch.equal(m.inference(mel), want) and m._fv_policy()[0] == "split" and not m._fv_overflow
     with pytest.warns(RuntimeWarning, match="split-f16 range"), torch.no_grad():
         got = m.inference(mel)
     assert torch.equal(got, want) and m._fv_policy()[0] == "f32"
