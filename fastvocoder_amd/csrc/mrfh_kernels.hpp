@@ -49,13 +49,12 @@ struct MrfTile {
     static constexpr int WSLOT = 2 * 6 * 2048 + 1024;   // bytes of a weight slot: the 11-tap pair + its bias block
     static constexpr int HSLOT = (4 * 25 + 4 * 5) * 16; // history of one pair: conv1's <= 25 rows, conv2's <= 5 rows
     static constexpr int HX = 0, HM = 4 * 25 * 16;
-    static constexpr int SBW = W + 4;                   // FOLD: row stride (floats) of the activated fp32 tile (4 SBW = 16 mod 32:
-                                                        // the four channel groups of a D fragment write disjoint banks)
+    static constexpr int SBW = 16;                      // FOLD: the activated fp32 tile is [column][16 channels], channel-minor
     static constexpr int OFF_W = 0, OFF_X = 2 * WSLOT, OFF_M = OFF_X + IMG, OFF_H = OFF_M + IMG, OFF_S = OFF_H + 9 * HSLOT;
     static constexpr int OFF_F = OFF_S + 256;           // FOLD: the output conv's weights [16][8] (7 taps + pad) and bias
     static constexpr int LDS = OFF_F + 576;
     static_assert(RP % 16 == 0, "whole bank rows");
-    static_assert(C * SBW * 4 <= IMG, "the folded output conv's tile lies over the intermediate image");
+    static_assert(W * SBW * 4 <= IMG, "the folded output conv's tile lies over the intermediate image");
     static_assert(LDS <= 160 * 1024, "LDS");
 };
 
@@ -452,9 +451,14 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3
     }
     for (int idx = L.tid; idx < 9 * TL::HSLOT / 4; idx += TL::NT) reinterpret_cast<float*>(sm + TL::OFF_H)[idx] = 0.f;
     if constexpr (FOLD) {
+        // the output conv's weights as [4 channels' group q][tap j][4 channels] (the group's seven taps are seven 16-byte
+        // entries: one uniform ds_read_b128 each), the bias behind them
         float* const fw = reinterpret_cast<float*>(sm + TL::OFF_F);
-        if (L.tid < 128) fw[L.tid] = (L.tid & 7) < 7 ? p.fold_w[(L.tid >> 3) * 7 + (L.tid & 7)] : 0.f;
-        if (L.tid == 128) fw[128] = p.fold_b ? p.fold_b[0] : 0.f;
+        if (L.tid < 112) {
+            const int q = L.tid / 28, j = (L.tid % 28) / 4, cc = L.tid & 3;
+            fw[L.tid] = p.fold_w[(4 * q + cc) * 7 + j];
+        }
+        if (L.tid == 112) fw[112] = p.fold_b ? p.fold_b[0] : 0.f;
     }
     LowGuard low;
     float bad = 0.f;
@@ -510,17 +514,23 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3
                 for (int i = 0; i < 4; ++i) out[f][i] = out[f][i] / p.out_div;
         }
         if constexpr (FOLD) {
-            // the activated tile -> LDS (over the intermediate image, free since the last barrier), zero outside [0, T);
-            // then one output sample per thread: conv_narrow_kernel's arithmetic (channel-major FMA chain from zero, bias
-            // last), so plans that keep the output conv as a launch of its own give the same bits
-            float* const sb = reinterpret_cast<float*>(mimg0);             // [16][SBW]
+            // The activated tile -> LDS (over the intermediate image, free since the last barrier), zero outside [0, T), as
+            // [column][16 channels]: the four channels of a D fragment are ONE 16-byte entry, and one output sample reads a
+            // group of four channels of a tap as one ds_read_b128.  The four entries of a column are rotated by column / 4
+            // (entry q of column c sits in slot (q + (c >> 2)) & 3): the lane groups a b128 access is served in -- quads
+            // of four consecutive columns, 4 or 12 apart -- then cover all sixteen 16-byte slots of a bank row, reads and
+            // writes alike.  Then one output sample per thread: conv_narrow_kernel's arithmetic (channel-major FMA chain
+            // from zero, bias last), so plans that keep the output conv as a launch of its own give the same bits.
+            char* const sb = mimg0;
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 const int col = L.colw + f * 16, t = cur.tw + col;
                 const bool ok = t >= 0 && t < T;
                 range_note4(bad, out[f][0], out[f][1], out[f][2], out[f][3], t >= cur.lo - ol && t < cur.hi + ol && ok);
+                f32x4 v;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) sb[(L.row0 + i) * TL::SBW + col] = ok ? act(out[f][i], p.act_slope) : 0.f;
+                for (int i = 0; i < 4; ++i) v[i] = ok ? act(out[f][i], p.act_slope) : 0.f;
+                *reinterpret_cast<f32x4*>(sb + col * 64 + ((((L.row0 >> 2) + (col >> 2)) & 3) << 4)) = v;
             }
             if (tile_no == 0) mrf_stamp(p, NG, L.wave, L.lane, 2, 3);
             pair_barrier();
@@ -528,47 +538,28 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3
             const float* const fw = reinterpret_cast<const float*>(sm + TL::OFF_F);
             for (int c0 = L.tid; c0 < vcols - 2 * ol; c0 += TL::NT) {
                 // output column: the first final one of a warm tile is `ol`; a cold tile's lie further right (time mask).
-                // 112 dependent FMAs: the next channel's operands are requested BEFORE this channel's seven FMAs (pinned:
-                // left alone hipcc waits for every pair of LDS operands right behind its load -- 64 round trips, 6 900 cycles
-                // [measured, tools/mrf_trace.py])
+                // 112 dependent FMAs in four rounds of 28 (a group of four channels, seven taps).  [measured, tools/mrf_trace.py]
+                // the channel-major tile of b32 operands: 6 900 cycles per tile as hipcc scheduled it (a wait behind every
+                // operand pair), 5 300 with the next channel's operands requested ahead of this channel's FMAs
                 const int col = c0 + ol, t = cur.tw + col;
-                const float* const sr = sb + col - 3;
                 float o = 0.f;
-                float va[7], vb[7];
-                f32x4 wa0, wb0;
-                f32x2 wa1, wb1;
-                float wa2, wb2;
-                // (exactly seven weight registers per channel: with a spare lane in a wider load hipcc parks a temporary in
-                // it and waits for the load first)
-                auto fetch = [&](int c, float (&v)[7], f32x4& w0, f32x2& w1, float& w2) {
-                    w0 = *reinterpret_cast<const f32x4*>(fw + 8 * c);
-                    w1 = *reinterpret_cast<const f32x2*>(fw + 8 * c + 4);
-                    w2 = fw[8 * c + 6];
-#pragma unroll
-                    for (int j = 0; j < 7; ++j) v[j] = sr[c * TL::SBW + j];
-                };
-                auto chain = [&](const float (&v)[7], const f32x4& w0, const f32x2& w1, float w2) {
-                    o = fmaf(w0[0], v[0], o);
-                    o = fmaf(w0[1], v[1], o);
-                    o = fmaf(w0[2], v[2], o);
-                    o = fmaf(w0[3], v[3], o);
-                    o = fmaf(w1[0], v[4], o);
-                    o = fmaf(w1[1], v[5], o);
-                    o = fmaf(w2, v[6], o);
-                };
-                fetch(0, va, wa0, wa1, wa2);
+                // (four rounds of 14 loads + 28 FMAs, no software pipeline: two operand sets in flight need 112 registers and
+                // hipcc spills 180 for them; a round's LDS round trip is ~150 cycles, four of them per tile)
 #pragma unroll 1
-                for (int c = 0; c < TL::C; c += 2) {
-                    fetch(c + 1, vb, wb0, wb1, wb2);
-                    __builtin_amdgcn_sched_barrier(0);
-                    chain(va, wa0, wa1, wa2);
-                    __builtin_amdgcn_sched_barrier(0);
-                    fetch(c + 2 < TL::C ? c + 2 : c, va, wa0, wa1, wa2);      // (the last round fetches a row again: unused)
-                    __builtin_amdgcn_sched_barrier(0);
-                    chain(vb, wb0, wb1, wb2);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 d[7], w[7];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) {
+                        const int row = col - 3 + j;
+                        d[j] = *reinterpret_cast<const f32x4*>(sb + row * 64 + (((q + (row >> 2)) & 3) << 4));
+                        w[j] = *reinterpret_cast<const f32x4*>(fw + (q * 7 + j) * 4);
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) o = fmaf(w[j][cc], d[j][cc], o);
                 }
-                o = o + fw[128];
+                o = o + fw[112];
                 if (p.post == FV_POST_TANH) o = tanhf(o);
                 else if (p.post == FV_POST_RELU) o = fmaxf(o, 0.f);
                 if (t >= cur.lo && t < cur.hi) p.fold_y[(size_t)cur.b * T + t] = o;
