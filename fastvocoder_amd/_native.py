@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libfastvocoder_hip.so")
 _CSRC = os.path.join(_HERE, "csrc")
 # conv_inst_s*.hip instantiate the conv kernel templates (conv_kernels.hpp) one tile shape each,
 # so that the ~170 kernel variants compile in parallel
-SOURCES = ["conv_mfma.hip", "api.hip", "pqmf.hip", "wav_sink.hip", "conv_inst_narrow.hip",
+SOURCES = ["conv_mfma.hip", "api.hip", "pack.hip", "pqmf.hip", "wav_sink.hip", "conv_inst_narrow.hip",
            "pair_launch.hip", "pair_inst_c16.hip", "pair_inst_c32.hip", "pairh_inst_c16.hip", "pairh_inst_c32.hip",
            "convh_launch.hip", "convh_inst_c64.hip", "convh_inst_c128.hip", "convt_inst.hip",
            "convg_inst.hip", "convr_inst.hip", "convtn_inst.hip", "convk_inst.hip", "convq2_inst.hip",

@@ -20,6 +20,10 @@ int fail(int code, const char* fmt, ...);
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// argument checks shared by the operator entries (api.hip) and the pack entries (pack.hip)
+int check_conv_args(int Cin, int Cout, int k, int dil);
+int check_convt_split_args(int Cin, int Cout, int k, int stride, int pad, int out_pad);
+
 // Rows of the packed weight image are padded so that every M tile is full.
 static inline int pad_rows(int M) { return M <= 16 ? 16 : round_up(M, 32); }
 
