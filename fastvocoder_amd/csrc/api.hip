@@ -482,7 +482,7 @@ static const TuningEntry kTuningTable[] = {
     {"units", &Tuning::units},             {"shape16", &Tuning::shape16},        {"shape32", &Tuning::shape32},
     {"shape64", &Tuning::shape64},         {"krows", &Tuning::krows},            {"grid_cap", &Tuning::grid_cap},
     {"no_group", &Tuning::no_group},       {"mrf_blocks", &Tuning::mrf_blocks},  {"mrf_shape", &Tuning::mrf_shape},
-    {"mrf_prio", &Tuning::mrf_prio},
+    {"mrf_prio", &Tuning::mrf_prio},       {"convt_lean", &Tuning::convt_lean},
 };
 static void tuning_from_env() {
     const char* on = getenv("FV_TUNING");

@@ -243,9 +243,36 @@ int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout,
     p.pad_t = pad;
     p.Tout = Tout;
     p.reflect = 0;
-    const int NTC = 128;
     const int ncols = (Tout + pad + stride - 1) / stride;          // u = (n + pad) / stride of the last sample, + 1
     mb.k = 2;
+    // Few items: the lean kernel (convtl_kernels.hpp: 64-column tiles, A operands L2 -> registers, no ring) -- a launch of a
+    // handful of tiles per CU is all prologue on the ring pipeline below.  Tuning::convt_lean: (64 x 64 item, chunk) units per CU
+    // (in tenths) up to which it runs; 0: never (A/B, bit-identity tests).  [measured, tools/convt_lean_bench.py, hot loop]
+    // 256 -> 128 x 8 at 1000 frames (2 units per CU): 10.6 against 15.6 us; 512 -> 256 x 8 at 200 frames (2): 15.2 / 23.6;
+    // 64 -> 32 x 3 at 40 000 (4.9): 17.5 / 19.6; 128 -> 64 x 5 at 8000 (2.5): 15.9 / 17.0; at 3.3 units the two are equal, from
+    // ~8 up the ring pipeline wins (batch 16: 74 against 107 us) -- its weights reach all eight waves through LDS once.
+    {
+        const long long lean_items = (long long)((ncols + 63) / 64) * p.B * p.nmt;
+        if (tuning().convt_lean > 0 && lean_items * p.nch * 10 <= (long long)tuning().convt_lean * device_cu_count()) {
+            if (!mb.add1) p.out_div = 1.f;
+            if (mb.add2 && !mb.add1) return fail(FV_ERR_INVALID_ARG, "split-f16 transposed conv: add2 without add1");
+            mb.n_tiles = (ncols + 63) / 64;
+            mb.n_items = (int)lean_items;
+            mb.cost = 1;
+            long long nb = tuning().convh_blocks > 0 ? tuning().convh_blocks : device_cu_count();
+            if (nb > lean_items) nb = lean_items;
+            p.nblk = (int)nb;
+            p.sched_on = 0;
+            p.dbg = 0;
+            p.trace = nullptr;
+            profile_begin(s);
+            const int rc = launch_convtl_geom(p, cc / 32, s);
+            profile_end(s, FV_KERNEL_CONVT, 2.0 * p.B * (double)p.T * Cin * Cout * 2 * stride,
+                        4.0 * ((double)Cin * Cout * 2 * stride + (double)p.B * ((double)Cin * p.T + (double)Cout * Tout * (mb.y_act ? 2 : 1))));
+            return rc;
+        }
+    }
+    const int NTC = 128;
     mb.n_tiles = (ncols + NTC - 1) / NTC;
     // 128 and more input channels: 128-row tiles (convu_kernel, convr_kernels.hpp) when that still gives the chip items
     // enough, as launch_convg / launch_convh; Tuning::convt_rows64

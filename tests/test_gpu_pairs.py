@@ -362,7 +362,7 @@ def test_conv1d_split_f16_reflection_rejects():
 def tuning():
     """fv_tuning_set for the duration of a test (process-wide switches of the launchers: restored afterwards)."""
     defaults = {"sched": 1, "sched_switch": 4, "convh_blocks": 0, "pair_blocks": 0, "pair128_unfused": 0, "convg_rows64": -1,
-                "convh_rows64": -1, "convt_rows64": -1, "convp_wide": 20, "convq_wide": 20}
+                "convh_rows64": -1, "convt_rows64": -1, "convp_wide": 20, "convq_wide": 20, "convt_lean": 50}
     yield _native.tuning_set
     for k, v in defaults.items():
         _native.tuning_set(k, v)
@@ -462,6 +462,17 @@ def test_conv_transpose1d_split_f16_vs_oracle(case, tuning):
     few = _native.conv_transpose1d_split_f16(X, P, Bi, cout, k, s, pad, op, pre_slope=0.1)
     tuning("convh_blocks", 0)
     assert torch.equal(few, y)
+    # these launches have few items per CU: they ran on the lean kernel (csrc/convtl_kernels.hpp: 64-column tiles, A operands
+    # L2 -> registers).  The ring pipeline (convt_kernel: 128-column tiles, weights through LDS) gives the same bits -- and
+    # is what the rest of this test forces
+    tuning("convt_lean", 0)
+    ring = _native.conv_transpose1d_split_f16(X, P, Bi, cout, k, s, pad, op, pre_slope=0.1)
+    tw_r = torch.empty_like(y)
+    ring2 = _native.conv_transpose1d_split_f16(X, P, None, cout, k, s, pad, op, pre_slope=0.1, out_act=tw_r, act_slope=0.2)
+    assert torch.equal(ring, y) and torch.equal(ring2, y2) and torch.equal(tw_r, twin)
+    tuning("convh_blocks", 3)
+    assert torch.equal(_native.conv_transpose1d_split_f16(X, P, Bi, cout, k, s, pad, op, pre_slope=0.1), y)
+    tuning("convh_blocks", 0)
     if B > 1:                                      # an utterance alone and inside the batch: same bits
         one = _native.conv_transpose1d_split_f16(X[1:2].contiguous(), P, Bi, cout, k, s, pad, op, pre_slope=0.1)
         assert torch.equal(one, y[1:2])
@@ -479,6 +490,7 @@ def test_conv_transpose1d_split_f16_vs_oracle(case, tuning):
             outs.append((_native.conv_transpose1d_split_f16(X, P, Bi, cout, k, s, pad, op, pre_slope=0.1).clone(),))
             tuning("convh_blocks", 0)
         tuning("convt_rows64", -1)
+        tuning("convt_lean", 50)
         assert torch.equal(outs[0][0], y) and all(torch.equal(a, b) for a, b in zip(outs[0], outs[2]))
         assert torch.equal(outs[1][0], y) and torch.equal(outs[3][0], y)
 

@@ -677,6 +677,28 @@ def test_one_launch_stage_gives_the_same_bits():
     assert not one.check_range() and not four.check_range()
 
 
+@pytest.mark.parametrize("name,path,T", [("hifigan", "conf/hifigan/light.yaml", 1000), ("hifigan", "conf/hifigan/large.yaml", 60),
+                                         ("melgan", "conf/melgan/original.yaml", 200), ("multiband-hifigan", "conf/multiband-hifigan/light.yaml", 90)],
+                         ids=["hifigan_light", "hifigan_large", "melgan", "mb_light"])
+def test_lean_upsamplers_give_the_same_bits(name, path, T):
+    """The transposed-conv upsamplers of a small batch run on the lean kernel (csrc/convtl_kernels.hpp: 64-column tiles, A
+    operands from L2 straight into registers, no weight ring); `fv_tuning_set("convt_lean", 0)` sends them through the ring
+    pipeline (convt_kernel / convu_kernel) instead.  Same GEMM, same K order per output, the MRF merge formed the same way
+    while the window loads: whole generators give identical bits -- one utterance and a ragged batch."""
+    cfg = cases.load_conf(path)
+    m, _ = _model(name, cfg, seed=2)
+    xs = [torch.from_numpy(seeded_mel(T, seed=21, batch=1)).to(_dev()), torch.from_numpy(seeded_mel(37, seed=22, batch=3)).to(_dev())]
+    try:
+        with torch.no_grad():
+            lean = [m(x).clone() for x in xs]
+            _native.tuning_set("convt_lean", 0)
+            ring = [m(x).clone() for x in xs]
+    finally:
+        _native.tuning_set("convt_lean", 50)
+    assert all(torch.equal(a, b) for a, b in zip(lean, ring))
+    assert not m.check_range()
+
+
 def test_three_instruction_division_on_the_device():
     """csrc/pair_kernels.hpp div_exact (the MRF mean's xs / 3, hifigan.py:103) against the device's own IEEE division: every
     fp32 value of four binades (and the negatives), d = 3 -- and 2, 5, 7, 12 for the rule's other divisors: zero mismatches."""
