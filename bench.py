@@ -292,7 +292,8 @@ def roofline_report(model, mel, ms_per_step, reps=5):
              "pair16": _native.KERNEL_PAIR16, "pair32": _native.KERNEL_PAIR32,
              "pairh16": _native.KERNEL_PAIRH16, "pairh32": _native.KERNEL_PAIRH32,
              "convh64": _native.KERNEL_CONVH64, "convh128": _native.KERNEL_CONVH128,
-             "convt": _native.KERNEL_CONVT, "narrow": _native.KERNEL_CONV_NARROW, "mrf16": _native.KERNEL_MRF16}
+             "convt": _native.KERNEL_CONVT, "narrow": _native.KERNEL_CONV_NARROW, "mrf16": _native.KERNEL_MRF16,
+             "mrf32": _native.KERNEL_MRF32}
     rec = {k: _native.profile_collect(v) for k, v in kinds.items()}
     # What an event record costs between two kernels of this forward: the replay with events against the timed step
     # without them, per launch.  (Between two NULL kernels a record costs `bracket_ms`, ~5 us; next to a real kernel
@@ -310,8 +311,8 @@ def roofline_report(model, mel, ms_per_step, reps=5):
 
     fp32 = fam("conv32", "conv16", "pair16", "pair32")       # fp32 matrix cores (csrc/conv_kernels.hpp, pair_kernels.hpp)
     wide = fam("convh64", "convh128")                        # split-f16 convs with streamed weights (convh_kernels.hpp)
-    pairs = fam("pairh16", "pairh32", "mrf16")               # split-f16 fused pairs (pairh_kernels.hpp) and the one-launch
-                                                             # 16-channel stage (mrfh_kernels.hpp)
+    pairs = fam("pairh16", "pairh32", "mrf16", "mrf32")      # split-f16 fused pairs (pairh_kernels.hpp) and the one-launch
+                                                             # 16- / 32-channel stages (mrfh_kernels.hpp, mrfw_kernels.hpp)
     ups = fam("convt")                                       # split-f16 transposed convs (convt_kernel)
     all_ms = (fp32["ms"] + wide["ms"] + pairs["ms"] + ups["ms"] + rec["narrow"]["ms"]) / reps
     all_flops = fp32["flops"] + wide["flops"] + pairs["flops"] + ups["flops"]
@@ -393,13 +394,13 @@ def roofline_report(model, mel, ms_per_step, reps=5):
             "tflops": rate(fp32), "frac_of_fp32_mfma_peak": rate(fp32) / PEAK_FP32_MFMA_TFLOPS,
         },
         "split_f16_pairs": {
-            "kernel": "fv::pairh_kernel (fused ResBlock1 pairs of the 32-channel stage, split-f16 operands, intermediate in "
-                      "LDS; csrc/pairh_kernels.hpp) + fv::mrfh_kernel (the whole 16-channel stage and conv_post as ONE "
-                      "launch; csrc/mrfh_kernels.hpp)",
+            "kernel": "fv::mrfw_kernel (the whole 32-channel MRF stage as ONE launch; csrc/mrfw_kernels.hpp) + fv::mrfh_kernel "
+                      "(the whole 16-channel stage and conv_post as ONE launch; csrc/mrfh_kernels.hpp); fv::pairh_kernel "
+                      "(fused ResBlock1 pairs, csrc/pairh_kernels.hpp) where a stage is not fused",
             "ms_per_step": pairs["ms"] / reps, "launches_per_step": pairs["launches"] // reps,
             "fp32_equivalent_tflops": rate(pairs),
             "external_gbs": pairs["bytes"] / (pairs["ms"] * 1e-3) / 1e9 if pairs["ms"] > 0 else 0.0,
-            "bound": "hbm / lds (DESIGN.md section 3.7)",
+            "bound": "matrix + LDS + VALU phases that add up (DESIGN.md section 4)",
         },
         "split_f16_transposed_convs": {
             "kernel": "fv::convt_kernel (the upsamplers with 64+ input channels: kernel = 2 strides as one GEMM with rows "
@@ -471,6 +472,9 @@ def build_model(config, dev, dist, rank, precision="split"):
     model = build_generator(MODEL, cfg)
     model.precision = precision
     model.range_guard = BENCH_RANGE_GUARD                 # every timed region below ends in model.check_range()
+    if os.environ.get("BENCH_FUSE_STAGE"):                # A/B runs: "16" / "16,32" / "0" 
+        widths = tuple(int(v) for v in os.environ["BENCH_FUSE_STAGE"].split(","))
+        model.fuse_stage = False if widths == (0,) else widths
     sd = seeded_state_dict(MODEL, cfg, seed=0) if rank == 0 else None
     if rank == 0:
         model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})

@@ -20,21 +20,22 @@ SOURCES = ["conv_mfma.hip", "api.hip", "pack.hip", "pqmf.hip", "wav_sink.hip", "
            "pair_launch.hip", "pair_inst_c16.hip", "pair_inst_c32.hip", "pairh_inst_c16.hip", "pairh_inst_c32.hip",
            "convh_launch.hip", "convh_inst_c64.hip", "convh_inst_c128.hip", "convt_inst.hip",
            "convg_inst.hip", "convr_inst.hip", "convtn_inst.hip", "convk_inst.hip", "convq2_inst.hip",
-           "mrfh_launch.hip", "mrfh_inst_a.hip", "mrfh_inst_b.hip", "convtl_inst.hip"] + \
+           "mrfh_launch.hip", "mrfh_inst_a.hip", "mrfh_inst_b.hip", "mrfw_inst.hip", "convtl_inst.hip"] + \
           [f"conv_inst_s{i}.hip" for i in range(6)]
 HEADERS = ["fv_internal.h", "conv_kernels.hpp", "pair_kernels.hpp", "pair_inst.hpp", "pairh_kernels.hpp",
            "pairh_inst.hpp", "convh_kernels.hpp", "convh_inst.hpp", "convr_kernels.hpp",
-           "convtn_kernels.hpp", "convk_kernels.hpp", "convq2_kernels.hpp", "mrfh_kernels.hpp", "mrfh_inst.hpp", "convtl_kernels.hpp"]
+           "convtn_kernels.hpp", "convk_kernels.hpp", "convq2_kernels.hpp", "mrfh_kernels.hpp", "mrfh_inst.hpp", "mrfw_kernels.hpp", "convtl_kernels.hpp"]
 
 PAD_ZERO, PAD_REFLECT = 0, 1
 PAD_CAUSAL = 2      # flag: pad (k-1)*dil on both sides, keep the first Tin outputs (CausalConv1d)
 POST_NONE, POST_TANH, POST_RELU = 0, 1, 2
 SLOT_NONE, SLOT_IN, SLOT_OUT, SLOT_TMP0, MAX_SLOTS = -1, 0, 1, 2, 32
 SLOT_AUX_IN0, SLOT_AUX_IN1, SLOT_OUT2 = 28, 29, 30    # caller-provided tensors of Plan.run(aux=..., out2=...)
-ABI_VERSION = 11
+ABI_VERSION = 12
 PAIR_F32, PAIR_SPLIT_F16 = 0, 1   # arithmetic of the fused ResBlock-pair kernels (fastvocoder_hip.h)
 
 
+ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE = -1, -2, -3
 ERR_RANGE = -4                    # fv_plan_check_range: a split-f16 kernel met an operand beyond the f16 range
 ERR_RANGE_LOW = -5                # ... only the low-side guard fired (a block's share of a tensor was small as a whole)
 
@@ -239,9 +240,11 @@ def lib():
     L.fv_packed_mrf_stage_floats.argtypes = [i, ctypes.POINTER(i)]
     L.fv_packed_mrf_stage_floats.restype = i64
     L.fv_pack_mrf_stage_split_f16.argtypes = [pp, pp, pp, pp, vp, i, ctypes.POINTER(i), vp, vp]
+    L.fv_mrf_stage_workspace_bytes.argtypes = [i]
+    L.fv_mrf_stage_workspace_bytes.restype = i64
     L.fv_mrf_stage_split_f16.argtypes = [vp, vp, vp, vp, i, i, i, ctypes.POINTER(i), ctypes.POINTER(i), f, f, i, f, vp, vp, vp,
-                                         vp, vp]
-    L.fv_plan_add_mrf_stage_split_f16.argtypes = [vp, i, i, i, vp, i, ctypes.POINTER(i), ctypes.POINTER(i), f, f, i, f]
+                                         vp, i64, vp, vp]
+    L.fv_plan_add_mrf_stage_split_f16.argtypes = [vp, i, i, i, vp, i, ctypes.POINTER(i), ctypes.POINTER(i), f, f, i, f, vp, i64]
     L.fv_plan_add_conv1d_split_f16.argtypes = [vp, i, i, i, i, i, i, vp, vp, i, i, i, i, f, f, i, f]
     L.fv_plan_add_mrf_sum.argtypes = [vp, ctypes.POINTER(i), i, i, pp, pp, pp, pp, i, ctypes.POINTER(i), i, f, f, i, f]
     L.fv_plan_create.argtypes = [i]
@@ -592,9 +595,21 @@ MRF_STAGE_DILATIONS = (1, 3, 5)
 
 
 def mrf_stage_supported(channels, ks, dils):
-    """Shapes the one-launch MRF stage kernel is built for (csrc/mrfh_launch.hip): 16 channels, three ResBlocks with
-    3 / 7 / 11 taps (any order), pair dilations (1, 3, 5)."""
-    return channels == 16 and len(ks) == 3 and all(k in (3, 7, 11) for k in ks) and tuple(dils) == MRF_STAGE_DILATIONS
+    """Shapes the one-launch MRF stage kernels are built for (csrc/mrfh_launch.hip): 16 or 32 channels, three ResBlocks
+    with 3 / 7 / 11 taps (any order), pair dilations (1, 3, 5)."""
+    return (channels in (16, 32) and len(ks) == 3 and all(k in (3, 7, 11) for k in ks)
+            and tuple(dils) == MRF_STAGE_DILATIONS)
+
+
+def mrf_stage_workspace(channels, device):
+    """The scratch a one-launch MRF stage needs next to its tensors (fv_mrf_stage_workspace_bytes: the 32-channel
+    kernel's columns of history; nothing at 16 channels -> None).  One per launch in flight; contents don't matter."""
+    n = lib().fv_mrf_stage_workspace_bytes(int(channels))
+    return torch.empty((n + 3) // 4, dtype=torch.float32, device=device) if n > 0 else None
+
+
+def _work_args(work):
+    return (_ptr(work, "workspace", True), 0 if work is None else work.numel() * 4)
 
 
 def pack_mrf_stage(w1s, w2s, b1s, b2s, ks, flag=None):
@@ -624,11 +639,13 @@ def pack_mrf_stage(w1s, w2s, b1s, b2s, ks, flag=None):
 
 def mrf_stage_split_f16(x, packed, ks, dils=MRF_STAGE_DILATIONS, slope=0.1, out_div=3.0, post=POST_NONE, act_slope=1.0,
                         out=None, out_act=None, fold=None, guard=None):
-    """A whole 16-channel MRF stage in one launch (fv_mrf_stage_split_f16): y = post(((r0 + r1) + r2) / out_div) with
-    r_j = ResBlock1_j(x); ``packed`` from pack_mrf_stage.  ``fold`` = (w [16, 7], bias [1] or None): returns
-    post(conv1d(lrelu(y, act_slope); w, padding 3) + bias), [B, 1, T], instead of y."""
+    """A whole 16- or 32-channel MRF stage in one launch (fv_mrf_stage_split_f16): y = post(((r0 + r1) + r2) / out_div)
+    with r_j = ResBlock1_j(x); ``packed`` from pack_mrf_stage.  ``fold`` (16 channels) = (w [16, 7], bias [1] or None):
+    returns post(conv1d(lrelu(y, act_slope); w, padding 3) + bias), [B, 1, T], instead of y.  The 32-channel kernel's
+    scratch is allocated here, per call (stream-ordered by the caching allocator)."""
     B, C, T = x.shape
     karr, darr = (ctypes.c_int * 3)(*ks), (ctypes.c_int * 3)(*dils)
+    work = mrf_stage_workspace(C, x.device)
     if fold is not None:
         fw, fb = fold
         fw = fw.detach().contiguous().float()
@@ -637,14 +654,14 @@ def mrf_stage_split_f16(x, packed, ks, dils=MRF_STAGE_DILATIONS, slope=0.1, out_
         with _on(x, packed, fw, fb, res) as stream:
             check(lib().fv_mrf_stage_split_f16(_ptr(x, "x"), _ptr(packed, "packed"), None, None, B, C, T, karr, darr,
                                                float(slope), float(out_div), post, float(act_slope), _ptr(fw, "fold_w"),
-                                               _ptr(fb, "fold_b", True), _ptr(res), _guard_ptr(guard), stream))
+                                               _ptr(fb, "fold_b", True), _ptr(res), *_work_args(work), _guard_ptr(guard), stream))
         return res
     if out is None:
         out = torch.empty_like(x)
-    with _on(x, packed, out, out_act) as stream:
+    with _on(x, packed, out, out_act, work) as stream:
         check(lib().fv_mrf_stage_split_f16(_ptr(x, "x"), _ptr(packed, "packed"), _ptr(out, "y"), _ptr(out_act, "y_act", True),
                                            B, C, T, karr, darr, float(slope), float(out_div), post, float(act_slope), None,
-                                           None, None, _guard_ptr(guard), stream))
+                                           None, None, *_work_args(work), _guard_ptr(guard), stream))
     return out
 
 
@@ -959,11 +976,15 @@ class Plan:
 
     def add_mrf_stage(self, x, y, packed, channels, ks, dils, slope, out_div=3.0, post=POST_NONE, y_act=SLOT_NONE,
                       act_slope=1.0):
-        """A whole 16-channel MRF stage as one op / one launch (fv_plan_add_mrf_stage_split_f16)."""
+        """A whole 16- / 32-channel MRF stage as one op / one launch (fv_plan_add_mrf_stage_split_f16); the 32-channel
+        kernel's scratch belongs to the op (a plan runs its ops in order on one stream)."""
         self.keep(packed)
+        work = mrf_stage_workspace(channels, packed.device)
+        if work is not None:
+            self.keep(work)
         check(lib().fv_plan_add_mrf_stage_split_f16(self._h, x, y, y_act, _ptr(packed, "packed"), channels,
                                                     (ctypes.c_int * 3)(*ks), (ctypes.c_int * 3)(*dils), float(slope),
-                                                    float(out_div), post, float(act_slope)))
+                                                    float(out_div), post, float(act_slope), *_work_args(work)))
 
     def set_pair_output_conv(self, w, bias, y, act_slope, post=POST_NONE):
         """Fold a 16 -> 1 channel, 7-tap conv into the resblock pair appended last (fv_plan_set_pair_output_conv):
@@ -1120,6 +1141,7 @@ KERNEL_CONV_MFMA32, KERNEL_CONV_MFMA16, KERNEL_CONV_NARROW, KERNEL_PAIR16, KERNE
 KERNEL_PAIRH16, KERNEL_PAIRH32, KERNEL_CONVH64, KERNEL_CONVH128, KERNEL_CONVT, KERNEL_CONVG = 5, 6, 7, 8, 9, 10
 KERNEL_STACK = 11
 KERNEL_MRF16 = 12     # a whole 16-channel MRF stage as one launch (mrfh_kernel)
+KERNEL_MRF32 = 13     # ... 32-channel (mrfw_kernel)
 
 
 def profile_bracket_cost(n=200):

@@ -132,6 +132,8 @@ struct Op {
     const float* pb2[3] = {nullptr, nullptr, nullptr};
     int pk[3] = {0, 0, 0};
     int sdil[3] = {0, 0, 0};  // OP_STAGE: dilations of the three pair positions (pk: taps of the three ResBlocks; wp: the packed stage)
+    void* work = nullptr;     // OP_STAGE, 32 channels: the launch's history slots (caller-owned)
+    int64_t work_bytes = 0;
     int prec = 0;             // FV_PAIR_F32 / FV_PAIR_SPLIT_F16
     bool in_merge = false;    // fv_plan_set_input_merge (split-f16 transposed conv): the input is ((x + xb) + xc) / out_div
     // fv_plan_set_pair_output_conv: a 16 -> 1 channel, 7-tap conv folded into the pair; y is ITS output [B, 1, T]
@@ -1195,7 +1197,7 @@ int fv_mrf_stage(const float* const* x, const float* const* w1, const float* con
 static int check_stage_args(int C, const int* k, const int* dil, float slope, float act_slope, int post) {
     if (!k || !dil) return fail(FV_ERR_INVALID_ARG, "mrf stage: null taps / dilations");
     if (!mrf_stage_shape(C, k, dil))
-        return fail(FV_ERR_UNSUPPORTED, "mrf stage: C = %d, taps (%d, %d, %d), dilations (%d, %d, %d): built for 16 channels, "
+        return fail(FV_ERR_UNSUPPORTED, "mrf stage: C = %d, taps (%d, %d, %d), dilations (%d, %d, %d): built for 16 / 32 channels, "
                     "taps 3 / 7 / 11, dilations (1, 3, 5)", C, k[0], k[1], k[2], dil[0], dil[1], dil[2]);
     if (slope < 0.f || slope > 1.f || act_slope < 0.f || act_slope > 1.f)
         return fail(FV_ERR_INVALID_ARG, "mrf stage: activation slope outside [0, 1]");
@@ -1203,9 +1205,12 @@ static int check_stage_args(int C, const int* k, const int* dil, float slope, fl
     return 0;
 }
 
+int64_t fv_mrf_stage_workspace_bytes(int C) { return mrf_workspace_bytes(C); }
+
 int fv_mrf_stage_split_f16(const float* x, const float* packed, float* y, float* y_act, int B, int C, int T, const int* k,
                            const int* dil, float slope, float out_div, int post, float act_slope, const float* fold_w,
-                           const float* fold_b, float* fold_y, int* guard, void* stream) {
+                           const float* fold_b, float* fold_y, void* workspace, int64_t workspace_bytes, int* guard,
+                           void* stream) {
     if (int rc = check_stage_args(C, k, dil, slope, act_slope, post)) return rc;
     if (B < 0 || T < 0) return fail(FV_ERR_INVALID_ARG, "mrf stage: B=%d T=%d", B, T);
     MrfParams p = {};
@@ -1223,14 +1228,20 @@ int fv_mrf_stage_split_f16(const float* x, const float* packed, float* y, float*
     p.fold_w = fold_w;
     p.fold_b = fold_b;
     p.fold_y = fold_y;
+    p.hist = static_cast<float*>(workspace);
+    p.hist_bytes = workspace_bytes;
     p.guard = guard;
     return launch_mrfh(p, C, dil, (hipStream_t)stream);
 }
 
 int fv_plan_add_mrf_stage_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed, int C,
-                                    const int* k, const int* dil, float slope, float out_div, int post, float act_slope) {
+                                    const int* k, const int* dil, float slope, float out_div, int post, float act_slope,
+                                    void* workspace, int64_t workspace_bytes) {
     if (!plan || !packed) return fail(FV_ERR_INVALID_ARG, "plan_add_mrf_stage: null");
     if (int rc = check_stage_args(C, k, dil, slope, act_slope, post)) return rc;
+    if (workspace_bytes < mrf_workspace_bytes(C) || (mrf_workspace_bytes(C) > 0 && !workspace))
+        return fail(FV_ERR_WORKSPACE, "plan_add_mrf_stage: C = %d needs a workspace of %lld bytes (fv_mrf_stage_workspace_bytes)", C,
+                    (long long)mrf_workspace_bytes(C));
     if (int rc = check_slot(x_slot, false)) return rc;
     if (int rc = check_slot(y_slot, false)) return rc;
     if (int rc = check_slot(y_act_slot, true)) return rc;
@@ -1250,6 +1261,8 @@ int fv_plan_add_mrf_stage_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int
         o.sdil[j] = dil[j];
     }
     o.wp = packed;
+    o.work = workspace;
+    o.work_bytes = workspace_bytes;
     o.pre_slope = slope;
     o.act_slope = act_slope;
     o.out_div = out_div;
@@ -1613,6 +1626,8 @@ int fv_plan_run_aux(fv_plan_t* plan, int B, int T, const float* in, float* out, 
             mp.act_slope = o.act_slope;
             mp.post = o.post;
             mp.guard = plan->guard_dev;
+            mp.hist = static_cast<float*>(o.work);
+            mp.hist_bytes = o.work_bytes;
             if (o.fold_w) {
                 mp.fold_w = o.fold_w;
                 mp.fold_b = o.fold_b;

@@ -356,13 +356,15 @@ struct MrfParams {
     long long total;         // B * T output columns
     int prio;                // s_setprio inside the K loops (Tuning::mrf_prio)
     unsigned long long* trace;
+    float* hist;             // 32 channels: the blocks' history slots (mrf_workspace_bytes), else null
+    long long hist_bytes;
 };
 
 // packed stage (fv_pack_mrf_stage_split_f16): pair q = 3 j + p of ResBlock j is the block [conv1 image | conv2 image |
 // b1[C] | b2[C] | 1 / row prescale of conv1 [C] | of conv2 [C] | padding to a whole KB]; images: fv_pack_pair_weight_ex's
 inline int mrf_block_bytes(int C, int k) { return 2 * ((k + (32 / C) - 1) / (32 / C)) * (C / 16) * 2048 + 1024; }
 inline bool mrf_stage_shape(int C, const int* k, const int* dil) {
-    if (C != 16 || !k || !dil || dil[0] != 1 || dil[1] != 3 || dil[2] != 5) return false;
+    if ((C != 16 && C != 32) || !k || !dil || dil[0] != 1 || dil[1] != 3 || dil[2] != 5) return false;
     for (int j = 0; j < 3; ++j)
         if (k[j] != 3 && k[j] != 7 && k[j] != 11) return false;
     return true;
@@ -381,6 +383,10 @@ inline int mrf_halo(const int* k, const int* dil) {
 int launch_mrfh(MrfParams p, int C, const int* dil, hipStream_t stream);
 template <int NF, int NG>
 int launch_mrfh_geom(const MrfParams& p, hipStream_t s);
+// 32 channels (mrfw_kernels.hpp): bytes of history a launch of at most `blocks` blocks needs, and the launch
+constexpr int kMrfwHistBytes = 9 * 30 * 128;
+long long mrf_workspace_bytes(int C);
+int launch_mrfw_geom(const MrfParams& p, hipStream_t s);
 
 // Shared between the host launcher (conv_mfma.hip) and the kernels (conv_kernels.hpp):
 #ifndef FV_RING

@@ -665,8 +665,10 @@ class NativeModule(torch.nn.Module):
                      whole, e.g. a quiet stretch of an utterance; the test is per block, not per tensor -- only repeats THAT
                      call on fp32, and moves the module after ``low_range_patience`` such calls in a row.
     ``fuse_pairs``   ResBlock1 pairs as fused launches (default) or conv by conv (round-1 path; A/B runs).
-    ``fuse_stage``   a 16-channel MRF stage (three ResBlock1s of three pairs + the mean) as ONE launch (default,
-                     csrc/mrfh_kernels.hpp) or as four fused-pair launches (A/B runs; identical bits).
+    ``fuse_stage``   a 16- or 32-channel MRF stage (three ResBlock1s of three pairs + the mean) as ONE launch
+                     (csrc/mrfh_kernels.hpp, mrfw_kernels.hpp) or as fused-pair launches.  True (default): 16 channels always,
+                     32 channels where one window per block covers the batch (hifigan._stage_one_launch); a tuple of channel
+                     counts -- e.g. (16,) or (16, 32) -- fuses exactly those stages; False: none (A/B runs, identical bits).
     ``fold_post``    HiFi-GAN's conv_post inside the last pair's / the last stage's launch (default) or as a launch of its own.
     ``merge_in_upsampler``  the MRF merge ((r0 + r1) + r2) / 3 of a fused stage inside the split-f16 upsampler behind it
                      (default: the stage ends in one three-member launch) or in the stage's own last launch (A/B runs;
@@ -698,7 +700,7 @@ class NativeModule(torch.nn.Module):
         prec = "f32" if (self.precision == "f32" or self._fv_overflow or getattr(self, "_fv_force_f32", False)) else "split"
         # (the guard is part of the key: a plan built under range_guard = "off" carries no guard word)
         return (prec, bool(self.fuse_pairs), bool(self.fold_post), self.range_guard != "off", bool(self.merge_in_upsampler),
-                bool(self.fuse_stage))
+                self.fuse_stage if isinstance(self.fuse_stage, tuple) else bool(self.fuse_stage))
 
     def _fv_state(self):
         """(identity + in-place version of every tensor the plans bake in, policy in force).  The tensor list is
@@ -812,6 +814,7 @@ class NativeModule(torch.nn.Module):
         if mode == "lazy" and not self._fv_overflow and self._fv_guard is not None and self._fv_guard.peek(0):
             self._fv_guard.clear(0)
             self._went_out_of_range("an EARLIER call met an activation (its output holds non-finite values)")
+        self._fv_batch = int(x.shape[0])  # (graphs whose shape depends on the batch: hifigan._stage_one_launch)
         plan = plan_for(x.shape[2])
         out = plan.run(x, **run_kw)
         if mode == "sync" and plan.guarded:

@@ -93,10 +93,35 @@ class _HiFiGANBase(NativeModule):
                 t = t * up.upsample_rate + 2 * up.conv.padding[0] - (up.conv.kernel_size[0] - 1)
             else:
                 t = (t - 1) * up.stride[0] - 2 * up.padding[0] + up.kernel_size[0] + up.output_padding[0]
-            flags.append(t > 0 and t % 4 == 0 and self._stage_fusable(i, precision))
+            fusable = t > 0 and t % 4 == 0 and self._stage_fusable(i, precision)
+            ch = self.resblocks[i * self.num_kernels].channels
+            flags.append("s" if fusable and self._stage_one_launch(ch, t) else bool(fusable))
         return tuple(flags)
 
-    def _emit_fused_stage(self, pb, blocks, up, x, scratch, parts, fold=None, merge_next=False):
+    def _stage_one_launch(self, channels, t):
+        """A fused stage of ``t`` samples as ONE launch (csrc/mrfh_kernels.hpp, mrfw_kernels.hpp) rather than as pair
+        launches?  ``fuse_stage`` = a tuple of widths: exactly those; False: none; True (default): 16 channels always; 32
+        channels when the kernel's fixed 384-column windows fit the work -- a block's share of the batch's columns takes
+        one run-in window (264 final columns) plus whole windows of 324, and the pair launches, whose tiles are cut to the
+        share, win when much of the last window is empty.  Measured on whole forwards (tools/stage_policy_bench.py, us,
+        pairs / one launch): batch 1, 560 frames (share 263 of one window: 0.68) 457 / 440; 1000 frames (469 of two: 0.61)
+        603 / 619; 700 frames (0.43) 494 / 537; batch 4, 1000 frames (1875 of six: 0.81) 1938 / 1850; 500 frames (0.61)
+        1093 / 1120; 700 frames (0.68) 1407 / 1403 -- one launch from 0.65 up."""
+        fs = self.fuse_stage
+        if isinstance(fs, (tuple, list)):
+            return channels in fs
+        if not fs or channels == 16:
+            return bool(fs)
+        if channels != 32:
+            return False
+        cols = getattr(self, "_fv_batch", 1) * int(t)
+        cus = torch.cuda.get_device_properties(self._device()).multi_processor_count
+        nblk = max(1, min(cus, -(-cols // 128)))
+        share = -(-cols // nblk)
+        windows = 1 if share <= 264 else 1 + -(-(share - 264) // 324)
+        return share >= 0.65 * 384 * windows
+
+    def _emit_fused_stage(self, pb, blocks, up, x, scratch, parts, fold=None, merge_next=False, one_launch=False):
         """The three ResBlocks of a stage as fused pair launches: every pair position is ONE launch of
         three members; the last position also forms the MRF mean when the three weight sets fit in
         LDS (16 channels), otherwise it runs conv by conv (grouped first convs + the merged last convs).
@@ -109,9 +134,9 @@ class _HiFiGANBase(NativeModule):
         ch = blocks[0].channels
         curs = [up] * nk
         prec = pb.pair_precision(ch)
-        if self.fuse_stage and pb.mrf_stage_supported(blocks):
-            # 16 channels: the whole stage -- nine pairs, the mean, and conv_post when it folds -- is ONE launch
-            # (csrc/mrfh_kernels.hpp): the stage's tensor is read once and written once (or not at all)
+        if one_launch and pb.mrf_stage_supported(blocks):
+            # 16 / 32 channels: the whole stage -- nine pairs, the mean, and conv_post when it folds -- is ONE launch
+            # (csrc/mrfh_kernels.hpp, mrfw_kernels.hpp): the stage's tensor is read once and written once (or not at all)
             if fold is not None:
                 pb.mrf_stage(blocks, up, fold[3], LRELU_SLOPE, float(nk), fold=fold[:3])
             else:
@@ -230,15 +255,15 @@ class _HiFiGANBase(NativeModule):
             blocks = [self.resblocks[i * nk + j] for j in range(nk)]
             if fused is not None and fused[i]:
                 if fold_post and i == self.num_upsamples - 1:
-                    self._emit_fused_stage(pb, blocks, up, x, scratch, parts,
+                    self._emit_fused_stage(pb, blocks, up, x, scratch, parts, one_launch=fused[i] == "s",
                                            fold=(self.conv_post, DEFAULT_LRELU_SLOPE, POST_TANH, dst))
                     return
                 # the MRF merge inside the NEXT upsampler (engine.NativeModule.merge_in_upsampler)
                 merged = (self.merge_in_upsampler and nk == 3 and i + 1 < self.num_upsamples
                           and pb.pair_precision(blocks[0].channels) == PAIR_SPLIT_F16
                           and pb.conv_transpose_takes_merge(self.ups[i + 1])
-                          and not (self.fuse_stage and pb.mrf_stage_supported(blocks)))
-                self._emit_fused_stage(pb, blocks, up, x, scratch, parts, merge_next=merged)
+                          and not (fused[i] == "s" and pb.mrf_stage_supported(blocks)))
+                self._emit_fused_stage(pb, blocks, up, x, scratch, parts, merge_next=merged, one_launch=fused[i] == "s")
                 continue
             if nk <= 3:
                 steps = blocks[0].num_steps()
@@ -285,7 +310,7 @@ class _HiFiGANBase(NativeModule):
             pb.conv(self.conv_post, x, dst, pre_slope=DEFAULT_LRELU_SLOPE, post=POST_TANH)
 
     def _flag_tag(self, T):
-        return "".join("f" if f else "-" for f in self._fused_flags(T))
+        return "".join("s" if f == "s" else "f" if f else "-" for f in self._fused_flags(T))
 
     # (which stages run fused depends on the policy in force -- after a range overflow the fp32 pair kernels exist at 16 /
     # 32 channels only -- so plan names and emit functions evaluate _fused_flags when they are used, not here)

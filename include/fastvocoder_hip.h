@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FV_ABI_VERSION 11
+#define FV_ABI_VERSION 12
 
 #define FV_ERR_INVALID_ARG (-1)
 #define FV_ERR_UNSUPPORTED (-2)
@@ -213,21 +213,26 @@ int fv_resblock1_fused_ex(int n, const float* const* x, const float* const* w1, 
  * writes the stage's tensor, is here one pass: a tile's columns stay on the CU through all 18 convs (running x in
  * registers, operand images and a few columns of history per conv in LDS, csrc/mrfh_kernels.hpp), x is read once and y
  * written once.  Bit-identical to the pair launches.
- *   x, y, y_act [B, 16, T] (y_act or NULL; without it and act_slope != 1, y itself is stored activated); any T.
- *   k[3]: taps of the three ResBlocks, each 3, 7 or 11; dil[3] = {1, 3, 5}; C = 16.  Anything else: FV_ERR_UNSUPPORTED.
- *   packed: fv_pack_mrf_stage_split_f16 of the 18 Conv1d weights and biases -- w1[3 j + p], w2[3 j + p]: [16, 16, k_j];
- *   b1 / b2: arrays of 9 pointers to [16] (entries, or the arrays, may be NULL); fv_packed_mrf_stage_floats floats
+ *   x, y, y_act [B, C, T] (y_act or NULL; without it and act_slope != 1, y itself is stored activated); any T.
+ *   k[3]: taps of the three ResBlocks, each 3, 7 or 11; dil[3] = {1, 3, 5}; C = 16 or 32.  Anything else: FV_ERR_UNSUPPORTED.
+ *   C = 32 (csrc/mrfw_kernels.hpp: weights stream through LDS in pieces of four taps, the columns of history live in
+ *   `workspace`): workspace = fv_mrf_stage_workspace_bytes(32) bytes of device memory, 16-byte aligned, that no other launch
+ *   in flight uses (contents: don't care, before and after); C = 16: workspace may be NULL.
+ *   packed: fv_pack_mrf_stage_split_f16 of the 18 Conv1d weights and biases -- w1[3 j + p], w2[3 j + p]: [C, C, k_j];
+ *   b1 / b2: arrays of 9 pointers to [C] (entries, or the arrays, may be NULL); fv_packed_mrf_stage_floats floats
  *   (0 = shape not built).  Per pair: [conv1 image | conv2 image | b1 | b2 | 1 / row prescale of conv1 | of conv2].
- *   fold_w [16, 7] != NULL (HiFi-GAN's conv_post, hifigan.py:104-106, inside the launch; needs y = y_act = NULL):
+ *   fold_w [16, 7] != NULL (HiFi-GAN's conv_post, hifigan.py:104-106, inside the launch; C = 16, needs y = y_act = NULL):
  *       fold_y[B, 1, T] = post( conv1d( lrelu(((r_0 + r_1) + r_2) / out_div, act_slope); fold_w, zero padding 3 ) + fold_b )
  *   -- the same arithmetic, bit for bit, as fv_conv1d_fused on a stored y.
  */
 int64_t fv_packed_mrf_stage_floats(int C, const int* k);
 int fv_pack_mrf_stage_split_f16(const float* const* w1, const float* const* w2, const float* const* b1,
                                 const float* const* b2, float* packed, int C, const int* k, int* range_flag, void* stream);
+int64_t fv_mrf_stage_workspace_bytes(int C);
 int fv_mrf_stage_split_f16(const float* x, const float* packed, float* y, float* y_act, int B, int C, int T, const int* k,
                            const int* dil, float slope, float out_div, int post, float act_slope, const float* fold_w,
-                           const float* fold_b, float* fold_y, int* guard, void* stream);
+                           const float* fold_b, float* fold_y, void* workspace, int64_t workspace_bytes, int* guard,
+                           void* stream);
 
 /*
  * Conv1d of the wide ResBlock stages with split-f16 operands (arithmetic: FV_PAIR_SPLIT_F16 above), n = 1..3
@@ -504,10 +509,12 @@ int fv_plan_add_resblock_pair_ex(fv_plan_t* plan, int x_slot, int y_slot, int y_
  * computed on the activated tile in LDS (tiles overlap by the conv's 3-sample halo).  One launch and a [B,16,T]
  * round trip less than the pair followed by fv_conv1d_fused. */
 int fv_plan_set_pair_output_conv(fv_plan_t* plan, const float* w, const float* bias, int y_slot, float act_slope, int post);
-/* fv_mrf_stage_split_f16 as a plan op (y_act_slot may be FV_SLOT_NONE).  fv_plan_set_pair_output_conv also applies to this
+/* fv_mrf_stage_split_f16 as a plan op (y_act_slot may be FV_SLOT_NONE; workspace: as there, owned by the caller for the
+ * plan's lifetime, one per op).  fv_plan_set_pair_output_conv also applies to this
  * op when it was appended last (the stage's own y is then not stored; y_slot receives the folded conv's [B, 1, T]). */
 int fv_plan_add_mrf_stage_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed, int C,
-                                    const int* k, const int* dil, float slope, float out_div, int post, float act_slope);
+                                    const int* k, const int* dil, float slope, float out_div, int post, float act_slope,
+                                    void* workspace, int64_t workspace_bytes);
 /* fv_conv1d_split_f16 as a plan op; consecutive ops under one non-zero group id with equal C, dilation, padding
  * mode, slopes, out_div and post run as ONE launch */
 int fv_plan_add_conv1d_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, int res_slot, int add1_slot,
@@ -636,6 +643,7 @@ int fv_tuning_set(const char* key, int value);
 #define FV_KERNEL_CONVG 10      /* two-source 1x1 conv (ResidualStack tail) with split-f16 operands (convg_kernel) */
 #define FV_KERNEL_STACK 11      /* MelGAN ResidualStack as one launch, 32 / 64 / 128 channels, split-f16 operands (convk_kernel) */
 #define FV_KERNEL_MRF16 12      /* a whole 16-channel MRF stage as one launch, split-f16 operands (mrfh_kernel) */
+#define FV_KERNEL_MRF32 13      /* ... 32-channel (mrfw_kernel) */
 int fv_profile_enable(int on);
 /* what the measurement adds to a launch (subtract it per launch): a launch's duration is measured completion to
  * completion on its stream, from the end event of the launch before it to its own (its dispatch latency included, as

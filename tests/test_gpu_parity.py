@@ -643,20 +643,29 @@ def test_mrf_merge_inside_the_upsampler_gives_the_same_bits(name, path, T):
 
 
 def test_one_launch_stage_gives_the_same_bits():
-    """HiFi-GAN light's 16-channel MRF stage (hifigan.py:97-106) as ONE launch -- nine fused pairs, the mean, conv_post + tanh
-    (csrc/mrfh_kernels.hpp) -- against the four pair launches of round 4 (`fuse_stage = False`): the same arithmetic per
-    element, so identical bits; a single utterance at the headline length, a ragged batch, `inference` and the bias-removal
-    plan (whose conv_post stays a launch of its own), with three launches fewer per forward."""
+    """HiFi-GAN light's 32- and 16-channel MRF stages (hifigan.py:97-106) as ONE launch each -- nine fused pairs, the mean,
+    and at 16 channels conv_post + tanh (csrc/mrfw_kernels.hpp, mrfh_kernels.hpp) -- against the pair launches of round 4
+    (`fuse_stage = False`; `(16,)`: only the last stage fused): the same arithmetic per element, so identical bits; a single
+    utterance at the headline length, a ragged batch, `inference` and the bias-removal plan (whose conv_post stays a launch
+    of its own), with five launches fewer per forward."""
     cfg = cases.load_conf("conf/hifigan/light.yaml")
     one, _ = _model("hifigan", cfg, seed=3)
+    one.fuse_stage = (16, 32)
     four, _ = _model("hifigan", cfg, seed=3)
     four.fuse_stage = False
+    last, _ = _model("hifigan", cfg, seed=3)
+    last.fuse_stage = (16,)
+    auto, _ = _model("hifigan", cfg, seed=3)          # the default: per call, by the shape (hifigan._stage_one_launch)
+    assert auto.fuse_stage is True
     with torch.no_grad():
-        for T, batch in ((1000, 1), (77, 3), (9, 2)):
+        for T, batch in ((1000, 1), (560, 1), (77, 3), (9, 2)):
             x = torch.from_numpy(seeded_mel(T, seed=15, batch=batch)).to(_dev())
             a, b = one(x), four(x)
-            assert torch.equal(a, b), (T, batch)
+            assert torch.equal(a, b) and torch.equal(last(x), a) and torch.equal(auto(x), a), (T, batch)
             assert torch.equal(one(x[:1].contiguous())[0], a[0])
+        # 560 frames are 67 200 columns at 32 channels: one window per block -> one launch; 1000 frames: two -> pair launches
+        auto._fv_batch = 1
+        assert auto._flag_tag(560) == "ffss" and auto._flag_tag(1000) == "fffs" and one._flag_tag(1000) == "ffss"
         mel = seeded_mel(123, seed=16)
         assert torch.equal(one.inference(mel), four.inference(mel))
         bias = four.inference(np.zeros_like(mel))
@@ -672,9 +681,10 @@ def test_one_launch_stage_gives_the_same_bits():
         _native.profile_enable(False)
         return int(_native.profile_collect(-1)["launches"])
     x = torch.from_numpy(seeded_mel(77, seed=15, batch=1)).to(_dev())
-    n1, n4 = launches(one, x), launches(four, x)
-    assert n1 == n4 - 3, (n1, n4)                      # four launches of the last stage -> one
-    assert not one.check_range() and not four.check_range()
+    n1, n4, nl = launches(one, x), launches(four, x), launches(last, x)
+    assert nl == n4 - 3, (nl, n4)                      # four launches of the last stage -> one
+    assert n1 == n4 - 5, (n1, n4)                      # ... and three of the 32-channel stage -> one
+    assert not one.check_range() and not four.check_range() and not last.check_range()
 
 
 @pytest.mark.parametrize("name,path,T", [("hifigan", "conf/hifigan/light.yaml", 1000), ("hifigan", "conf/hifigan/large.yaml", 60),

@@ -1,4 +1,4 @@
-"""GPU parity of the one-launch MRF stage (csrc/mrfh_kernels.hpp) through the C ABI (fv_mrf_stage_split_f16 and its plan
+"""GPU parity of the one-launch MRF stage (csrc/mrfh_kernels.hpp; 32 channels: csrc/mrfw_kernels.hpp) through the C ABI (fv_mrf_stage_split_f16 and its plan
 op): against the C oracle's convs on the same seeded inputs (4e-6 of the tensor's scale, the split-f16 kernels' bar), and
 BIT FOR BIT against the pair launches it replaces (fv_resblock1_fused_ex) -- over windows, runs and shares of every shape:
 one tile, tiles with history, runs that start inside an utterance, shares that cross utterance ends, both block shapes.
@@ -213,5 +213,119 @@ def test_mrf_stage_refuses_what_it_is_not_built_for():
         _native.mrf_stage_split_f16(x, P, ks, dils=(1, 3, 9))
     with pytest.raises(_native.NativeError):
         _native.mrf_stage_split_f16(x, P, (3, 5, 11))
-    assert not _native.mrf_stage_supported(32, ks, DILS) and not _native.mrf_stage_supported(16, (3, 7), DILS)
-    assert _native.mrf_stage_supported(16, (11, 11, 3), DILS)
+    assert not _native.mrf_stage_supported(64, ks, DILS) and not _native.mrf_stage_supported(16, (3, 7), DILS)
+    assert _native.mrf_stage_supported(16, (11, 11, 3), DILS) and _native.mrf_stage_supported(32, (7, 3, 11), DILS)
+
+
+# ---- 32 channels (csrc/mrfw_kernels.hpp): 384-column windows, weights in pieces of four taps, history in the workspace ----
+STAGE32_CASES = [
+    # B, T, taps of the three ResBlocks, bias, blocks (0: one per CU / per 128 columns)
+    (1, 40, (3, 7, 11), True, 0),           # shorter than the halo: one cold tile, both sequence ends inside
+    (2, 200, (3, 7, 11), True, 0),          # a share per 128 columns: every tile cold, runs start inside the utterance
+    (1, 264, (3, 7, 11), True, 1),          # exactly one cold window's final columns
+    (1, 1500, (3, 7, 11), True, 1),         # one block: a cold tile, then four tiles on history (324 columns each)
+    (3, 1201, (11, 3, 7), False, 2),        # two blocks over three utterances: shares cross utterance ends, no bias
+    (2, 2000, (7, 7, 3), True, 3),          # repeated tap counts, blocks that end inside a window
+    (1, 4003, (3, 7, 11), True, 5),         # odd length
+    (2, 1100, (11, 11, 11), True, 1),       # three pieces per conv throughout
+    (2, 1100, (3, 3, 3), True, 1),          # one piece per conv throughout
+    (1, 5, (3, 7, 11), True, 0),
+]
+
+
+@pytest.mark.parametrize("case", STAGE32_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_mrf_stage32_vs_oracle_and_pair_launches(case, tuning):
+    B, T, ks, bias, blocks = case
+    rng = np.random.RandomState(abs(hash(case)) % (2 ** 31))
+    x = rng.randn(B, 32, T).astype(np.float32)
+    ws = _stage_weights(rng, ks, bias, C=32)
+    ref = _oracle_stage(x, ws, ks)
+    tuning("mrf_blocks", blocks)
+    X, P = _t(x), _pack(ws, ks)
+    guard = torch.zeros(1, dtype=torch.int32, device=_dev())
+    y = _native.mrf_stage_split_f16(X, P, ks, guard=guard)
+    assert _rel(y, ref) <= 4e-6
+    assert int(guard.item()) == 0
+    if T % 4 == 0:
+        assert torch.equal(y, _pairs_stage(X, ws, ks)), "one launch and the four pair launches differ"
+    twin = torch.empty_like(y)
+    y2 = _native.mrf_stage_split_f16(X, P, ks, out_act=twin, act_slope=0.1)
+    assert torch.equal(y2, y) and _rel(twin, oo.lrelu(ref, 0.1)) <= 4e-6
+    assert torch.equal(_native.mrf_stage_split_f16(X, P, ks, act_slope=0.1), twin)
+
+
+def test_mrf_stage32_does_not_depend_on_blocks_or_batch(tuning):
+    rng = np.random.RandomState(6)
+    ks = (3, 7, 11)
+    x = rng.randn(3, 32, 2600).astype(np.float32)
+    ws = _stage_weights(rng, ks, C=32)
+    X, P = _t(x), _pack(ws, ks)
+    want = _native.mrf_stage_split_f16(X, P, ks)
+    for blocks in (1, 2, 7, 61):
+        tuning("mrf_blocks", blocks)
+        assert torch.equal(_native.mrf_stage_split_f16(X, P, ks), want), blocks
+        for b in range(3):
+            assert torch.equal(_native.mrf_stage_split_f16(X[b:b + 1].contiguous(), P, ks)[0], want[b]), (blocks, b)
+
+
+def test_mrf_stage32_history_survives_a_dirty_workspace(tuning):
+    """The workspace's contents do not matter: a run's first tile reads zeros, later tiles what the tile before them
+    wrote -- NaNs left in it by whoever had the memory before change nothing."""
+    rng = np.random.RandomState(8)
+    ks = (11, 7, 3)
+    x = rng.randn(2, 32, 1800).astype(np.float32)
+    ws = _stage_weights(rng, ks, C=32)
+    X, P = _t(x), _pack(ws, ks)
+    tuning("mrf_blocks", 3)
+    want = _native.mrf_stage_split_f16(X, P, ks)
+    n = _native.lib().fv_mrf_stage_workspace_bytes(32)
+    assert n > 0 and _native.lib().fv_mrf_stage_workspace_bytes(16) == 0
+    work = torch.full((n // 4,), float("nan"), device=_dev())
+    out = torch.empty_like(X)
+    import ctypes
+    karr, darr = (ctypes.c_int * 3)(*ks), (ctypes.c_int * 3)(*DILS)
+    rc = _native.lib().fv_mrf_stage_split_f16(X.data_ptr(), P.data_ptr(), out.data_ptr(), None, 2, 32, 1800, karr, darr, 0.1, 3.0,
+                                              _native.POST_NONE, 1.0, None, None, None, work.data_ptr(), n, None, None)
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(out, want)
+    # no workspace, or one that is too small: refused, nothing launched
+    rc = _native.lib().fv_mrf_stage_split_f16(X.data_ptr(), P.data_ptr(), out.data_ptr(), None, 2, 32, 1800, karr, darr, 0.1, 3.0,
+                                              _native.POST_NONE, 1.0, None, None, None, None, 0, None, None)
+    assert rc == _native.ERR_WORKSPACE
+    rc = _native.lib().fv_mrf_stage_split_f16(X.data_ptr(), P.data_ptr(), out.data_ptr(), None, 2, 32, 1800, karr, darr, 0.1, 3.0,
+                                              _native.POST_NONE, 1.0, None, None, None, work.data_ptr(), 1000, None, None)
+    assert rc == _native.ERR_WORKSPACE
+
+
+def test_mrf_stage32_guards_and_refusals():
+    rng = np.random.RandomState(12)
+    ks = (3, 7, 11)
+    ws = _stage_weights(rng, ks, C=32)
+    P = _pack(ws, ks)
+    guard = torch.zeros(1, dtype=torch.int32, device=_dev())
+    x = rng.randn(2, 32, 900).astype(np.float32)
+    big = x.copy()
+    big[1, 19, 450] = 1.0e6
+    y = _native.mrf_stage_split_f16(_t(big), P, ks, guard=guard)
+    assert int(guard.item()) == 1 and not bool(torch.isfinite(y).all())
+    guard.zero_()
+    nob = _stage_weights(rng, ks, bias=False, C=32)
+    _native.mrf_stage_split_f16(_t(x * np.float32(2.0 ** -14)), _pack(nob, ks), ks, guard=guard)
+    assert int(guard.item()) == 4
+    guard.zero_()
+    y = _native.mrf_stage_split_f16(_t(np.zeros_like(x)), _pack(nob, ks), ks, guard=guard)
+    assert int(guard.item()) == 0 and float(y.abs().max()) == 0.0
+    # the folded output conv is a 16-channel affair
+    with pytest.raises(_native.NativeError, match="16 channels"):
+        _native.mrf_stage_split_f16(_t(x), P, ks, fold=(_t(rng.randn(16, 7).astype(np.float32)), None))
+
+
+def test_mrf_stage32_plan_op():
+    rng = np.random.RandomState(13)
+    ks = (3, 7, 11)
+    x = rng.randn(2, 32, 1000).astype(np.float32)
+    ws = _stage_weights(rng, ks, C=32)
+    X, P = _t(x), _pack(ws, ks)
+    plan = _native.Plan(32)
+    plan.add_mrf_stage(_native.SLOT_IN, _native.SLOT_OUT, P, 32, ks, DILS, 0.1)
+    assert torch.equal(plan.run(X), _native.mrf_stage_split_f16(X, P, ks))

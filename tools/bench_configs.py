@@ -83,7 +83,7 @@ def main():
                 kinds = {"conv32": _native.KERNEL_CONV_MFMA32, "conv16": _native.KERNEL_CONV_MFMA16, "pairh16": _native.KERNEL_PAIRH16,
                          "pairh32": _native.KERNEL_PAIRH32, "convh64": _native.KERNEL_CONVH64, "convh128": _native.KERNEL_CONVH128,
                          "convt": _native.KERNEL_CONVT, "convg": _native.KERNEL_CONVG, "stack": _native.KERNEL_STACK,
-                         "mrf16": _native.KERNEL_MRF16}
+                         "mrf16": _native.KERNEL_MRF16, "mrf32": _native.KERNEL_MRF32}
                 rec = {k: _native.profile_collect(v) for k, v in kinds.items()}
                 fam_out[label] = {"batch": B, "frames": T,
                                   "families": {k: {"launches": int(r["launches"]), "flops": r["flops"]} for k, r in rec.items() if r["launches"]}}

@@ -2,7 +2,7 @@
 tools/build_variant.py trace "-DFV_PAIR_TRACE" -- loaded through FV_AB_LIB).  Per traced block (every 64th), per wave and
 tile: shader-clock ticks (s_memtime) between the stamps of mrf_pair -- conv1, epilogue 1, barrier C, conv2, epilogue 2,
 vmcnt(0), barrier A -- for the nine pairs of a tile.
-    FV_AB_LIB=fastvocoder_amd/libfv_trace.so python tools/mrf_trace.py [B] [fold 0/1] [shape 0/1]"""
+    FV_AB_LIB=fastvocoder_amd/libfv_trace.so python tools/mrf_trace.py [B] [fold 0/1] [shape 0/1] [channels 16/32]"""
 import os
 import sys
 
@@ -12,8 +12,11 @@ import torch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 fold = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 shape = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+C = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+if C == 32:
+    fold = 0
 dev = torch.device("cuda:0")
-nw = 16 if shape else 12
+nw = 8 if C == 32 else 16 if shape else 12
 trace = torch.zeros(4 * nw * 3 * 64 + 4096, dtype=torch.int64, device=dev)
 os.environ["FV_TUNING"] = "1"
 os.environ["FV_PAIR_TRACE_PTR"] = hex(trace.data_ptr())
@@ -24,13 +27,13 @@ from fastvocoder_amd import _native  # noqa: E402
 import _ablib  # noqa: E402
 _ablib.use_lib_from_env(_native)
 
-T, KS = 240000, (3, 7, 11)
+T, KS = (120000 if C == 32 else 240000), (3, 7, 11)
 g = torch.Generator().manual_seed(0)
-w1 = [(torch.randn((16, 16, KS[q // 3]), generator=g) / (16 * KS[q // 3]) ** 0.5).to(dev) for q in range(9)]
-w2 = [(torch.randn((16, 16, KS[q // 3]), generator=g) / (16 * KS[q // 3]) ** 0.5).to(dev) for q in range(9)]
-bs = [torch.randn(16, generator=g).to(dev) * 0.1 for _ in range(9)]
+w1 = [(torch.randn((C, C, KS[q // 3]), generator=g) / (C * KS[q // 3]) ** 0.5).to(dev) for q in range(9)]
+w2 = [(torch.randn((C, C, KS[q // 3]), generator=g) / (C * KS[q // 3]) ** 0.5).to(dev) for q in range(9)]
+bs = [torch.randn(C, generator=g).to(dev) * 0.1 for _ in range(9)]
 P = _native.pack_mrf_stage(w1, w2, bs, bs, list(KS))
-x = torch.randn((B, 16, T), generator=g).to(dev)
+x = torch.randn((B, C, T), generator=g).to(dev)
 y = torch.empty_like(x)
 fw, fb = (torch.randn((16, 7), generator=g) / 10).to(dev), torch.zeros(1, device=dev)
 if fold:
@@ -46,7 +49,7 @@ e0.record()
 run()
 e1.record()
 torch.cuda.synchronize()
-print(f"B={B} fold={fold} shape={shape}: launch (events) {e0.elapsed_time(e1) * 1e3:.1f} us")
+print(f"B={B} C={C} fold={fold} shape={shape}: launch (events) {e0.elapsed_time(e1) * 1e3:.1f} us")
 tr = trace.cpu().numpy()[:4 * nw * 3 * 64].reshape(4, nw, 3, 64).astype(np.int64)
 names = ["conv1", "epi1", "barC", "conv2", "epi2", "vm0", "barA"]
 for blk in range(4):

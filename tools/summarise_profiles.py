@@ -82,7 +82,7 @@ print(open(f"{dst}/{tag}_configs.md").read()[:1500])
 # FLOP of one v_mfma_f32_16x16x32_f16: 16 384) next to 3 x the algorithmic FLOP of the same forward, and MFMA-busy ----
 import json  # noqa: E402
 
-FAMILY_OF = [("mrfh_kernel", "mrf16"), ("pairh_kernel<1,", "pairh16"), ("pairh_kernel<2,", "pairh32"),
+FAMILY_OF = [("mrfh_kernel", "mrf16"), ("mrfw_kernel", "mrf32"), ("pairh_kernel<1,", "pairh16"), ("pairh_kernel<2,", "pairh32"),
              ("convq2_kernel<1, 64>", "convh64"), ("convq2_kernel<3, 64>", "convh64"), ("convq2_kernel<5, 64>", "convh64"),
              ("convq2_kernel<1, 65>", "convh64"), ("convq2_kernel<3, 65>", "convh64"), ("convq2_kernel<5, 65>", "convh64"),
              ("convq2_kernel", "convh128"), ("convh_kernel<2,", "convh64"), ("convh_kernel", "convh128"), ("convs_kernel", "convh128"),
