@@ -13,9 +13,10 @@
 //   * 8 waves = 4 row sixteenths x 2 column groups of 32: each wave loads the A operands of its OWN sixteen rows straight from
 //     L2 into registers -- all K steps of a chunk up front (64 registers), in flight while the chunk's window is converted --
 //     so the K loop has no barrier, no ring and no LDS-DMA: B operands from the LDS image one step ahead, six MFMAs per step;
-//   * per chunk: window global -> registers (the NEXT chunk's, requested behind this chunk's A operands), merge (an upsampler
-//     behind an MRF stage forms ((r0 + r1) + r2) / 3 itself: convt_kernel's merge_window), lrelu + split -> LDS image,
-//     barrier, K loop, barrier.  One block per CU, 2 waves per SIMD (<= 256 VGPRs).
+//   * per chunk: window global -> registers (the NEXT chunk's -- all three tensors of a merged window -- requested behind
+//     this chunk's A operands), merge (an upsampler behind an MRF stage forms ((r0 + r1) + r2) / 3 itself: convt_kernel's
+//     merge_window), lrelu + split -> LDS image, barrier, K loop, barrier; consecutive row tiles of one window skip all of
+//     that but the K loop.  One block per CU, 2 waves per SIMD (<= 256 VGPRs).
 // The launcher (launch_convt) picks this kernel when the launch has few 64-column items per CU (Tuning::convt_lean).
 #pragma once
 #include "convh_kernels.hpp"
@@ -68,10 +69,24 @@ __device__ __forceinline__ void convtl_run(const PairParams& p, const PairMember
     const float mrcp = div_rcp(p.out_div);
     float bad = 0.f;
     LowGuard low;
-    ConvHRaw<G> raw;
+    // The window of a chunk is up to three tensors (an upsampler behind an MRF stage forms ((r0 + r1) + r2) / 3 itself): all of
+    // them are requested a chunk ahead, behind the barrier that completes the current image, and land during the K loop, the
+    // epilogue and the stores [round 5, first form: only x travelled ahead; the two addends were requested where they were
+    // needed, a full memory latency per item].
+    ConvHRaw<G> raw, rt, ru;
+    auto load_window = [&](int bb, int cc, int nt_) {
+        const size_t off = (size_t)bb * ustride + (size_t)cc * cstride;
+        convh_load_raw<G>(raw, mb.x + off, p.T, nt_ * G::NTC - G::P, tid, true, false, chunk_channels(cc));
+        if (merge) {
+            convh_load_raw<G>(rt, mb.add1 + off, p.T, nt_ * G::NTC - G::P, tid, true, false, chunk_channels(cc));
+            convh_load_raw<G>(ru, mb.add2 ? mb.add2 + off : mb.add1 + off, p.T, nt_ * G::NTC - G::P, tid, mb.add2 != nullptr, false,
+                              chunk_channels(cc));
+        }
+    };
     int item = item0, chunk = 0, b, ntile, mtile;
     decode(item, b, ntile, mtile);
-    convh_load_raw<G>(raw, mb.x + b * ustride, p.T, ntile * G::NTC - G::P, tid, true, false, chunk_channels(0));
+    load_window(b, 0, ntile);
+    bool fresh = true;                                   // the image has to be built from the window in the registers
     f32x4 hi[2], lo[2];
     float bv[4], sv[4];
     for (;;) {
@@ -107,29 +122,25 @@ __device__ __forceinline__ void convtl_run(const PairParams& p, const PairMember
 #pragma unroll
             for (int i = 0; i < 4; ++i) sv[i] = buffer_load1(rs, (unsigned)(64 * mtile + row0 + i) * 4u);
         }
-        // ---- the window: merge (an upsampler behind an MRF stage), lrelu, split -> image
-        if (merge) {
-            ConvHRaw<G> t, u;
-            const size_t off = (size_t)b * ustride + (size_t)chunk * cstride;
-            convh_load_raw<G>(t, mb.add1 + off, p.T, ntile * G::NTC - G::P, tid, true, false, chunk_channels(chunk));
-            convh_load_raw<G>(u, mb.add2 ? mb.add2 + off : mb.add1 + off, p.T, ntile * G::NTC - G::P, tid, mb.add2 != nullptr, false,
-                              chunk_channels(chunk));
+        // ---- the window: merge (an upsampler behind an MRF stage), lrelu, split -> image.  Consecutive items of a block are
+        // row tiles of the SAME window more often than not (row tile fastest in the item order): a one-chunk window then stays
+        // where it is -- no loads, no conversion, no barriers.
+        if (fresh) {
+            if (merge) {
 #pragma unroll
-            for (int q = 0; q < G::XR; ++q)
+                for (int q = 0; q < G::XR; ++q)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float v = (raw.v[q][j] + t.v[q][j]) + u.v[q][j];       // (no add2: u is zeros, and v + 0 = v)
-                    if (p.out_div != 1.f) v = mrcp != 0.f ? div_exact(v, p.out_div, mrcp) : v / p.out_div;
-                    raw.v[q][j] = v;
-                }
+                    for (int j = 0; j < 8; ++j) {
+                        float v = (raw.v[q][j] + rt.v[q][j]) + ru.v[q][j];   // (no add2: ru is zeros, and v + 0 = v)
+                        if (p.out_div != 1.f) v = mrcp != 0.f ? div_exact(v, p.out_div, mrcp) : v / p.out_div;
+                        raw.v[q][j] = v;
+                    }
+            }
+            convh_convert<G>(raw, ximg, p.slope, tid, low, 0);
+            pair_barrier();                              // image complete
         }
-        convh_convert<G>(raw, ximg, p.slope, tid, low, 0);
-        pair_barrier();                                  // image complete
-        // the NEXT window (next chunk of this item, or chunk 0 of the next item): requested behind this chunk's A operands,
-        // in flight during the K loop, the epilogue and the stores
-        if (more || !last)
-            convh_load_raw<G>(raw, mb.x + (last ? nb : b) * ustride + (last ? 0 : nchunk) * cstride, p.T, (last ? nnt : ntile) * G::NTC - G::P,
-                              tid, true, false, chunk_channels(last ? 0 : nchunk));
+        const bool reuse = more && last && nch == 1 && nb == b && nnt == ntile;
+        if ((more || !last) && !reuse) load_window(last ? nb : b, last ? 0 : nchunk, last ? nnt : ntile);
         // ---- K loop: no barrier, B operands one step ahead
         {
             LdsCF* const bb = lds_opaque(reinterpret_cast<const float*>(bptr));
@@ -201,7 +212,8 @@ __device__ __forceinline__ void convtl_run(const PairParams& p, const PairMember
             }
         }
         if (!more && last) break;
-        pair_barrier();                                  // every wave is done with the image: the next window may overwrite it
+        if (!reuse) pair_barrier();                      // every wave is done with the image: the next window may overwrite it
+        fresh = !reuse;
         item = nitem;
         chunk = nchunk;
         b = nb;
