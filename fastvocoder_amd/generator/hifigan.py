@@ -24,6 +24,20 @@ from .pqmf import PQMF
 DEFAULT_LRELU_SLOPE = 0.01  # F.leaky_relu's default, used before conv_post (hifigan.py:104)
 
 
+def stage32_windows_fit(cols, cus, fill=0.65):
+    """Do the 32-channel one-launch kernel's fixed windows fit ``cols`` columns (batch x samples of the stage) on ``cus``
+    CUs?  The launcher (csrc/mrfh_launch.hip) gives every block -- one per CU, at most one per 128 columns -- an equal share;
+    a share takes one run-in window of 384 columns (264 of them final) plus whole windows of 324 final columns.  True when
+    at least ``fill`` of the windows' columns are the share's (measured crossover: _HiFiGANBase._stage_one_launch)."""
+    cols = int(cols)
+    if cols <= 0:
+        return False
+    nblk = max(1, min(int(cus), -(-cols // 128)))
+    share = -(-cols // nblk)
+    windows = 1 if share <= 264 else 1 + -(-(share - 264) // 324)
+    return share >= fill * 384 * windows
+
+
 class _HiFiGANBase(NativeModule):
     _post_channels = 1
     fuse_pqmf = True      # Multiband: conv_post + tanh + PQMF synthesis as one launch (False: two; A/B and bit-identity tests)
@@ -114,12 +128,8 @@ class _HiFiGANBase(NativeModule):
             return bool(fs)
         if channels != 32:
             return False
-        cols = getattr(self, "_fv_batch", 1) * int(t)
         cus = torch.cuda.get_device_properties(self._device()).multi_processor_count
-        nblk = max(1, min(cus, -(-cols // 128)))
-        share = -(-cols // nblk)
-        windows = 1 if share <= 264 else 1 + -(-(share - 264) // 324)
-        return share >= 0.65 * 384 * windows
+        return stage32_windows_fit(getattr(self, "_fv_batch", 1) * int(t), cus)
 
     def _emit_fused_stage(self, pb, blocks, up, x, scratch, parts, fold=None, merge_next=False, one_launch=False):
         """The three ResBlocks of a stage as fused pair launches: every pair position is ONE launch of

@@ -395,3 +395,21 @@ def test_bench_refuses_worlds_it_cannot_place():
     assert bench.world_error(0, 1, 0, 1) is not None
     # the declared test mode: ranks share device 0 (tests/test_gpu_multi.py), never the default
     assert bench.world_error(2, 2, 1, 1, one_gpu=True) is None
+
+
+def test_stage32_policy_follows_the_window_arithmetic():
+    """hifigan.stage32_windows_fit: the 32-channel one-launch stage kernel is used where its fixed 384-column windows are at
+    least 65 % full -- the shapes measured in DESIGN.md section 4.3 fall on the sides they were measured on."""
+    from fastvocoder_amd.generator.hifigan import stage32_windows_fit as fit
+    cus = 256
+    # HiFi-GAN light's 32-channel stage has 120 samples per mel frame
+    assert fit(1 * 560 * 120, cus)           # 263 columns per block: one run-in window (264 final columns)
+    assert not fit(1 * 1000 * 120, cus)      # 469: a second window, 63 % empty  -> pair launches
+    assert not fit(1 * 700 * 120, cus)       # 329: the second window holds 65 columns
+    assert not fit(1 * 250 * 120, cus)       # 235 blocks of 128 columns: a third of a window each
+    assert fit(4 * 1000 * 120, cus)          # 1875 = 264 + 5 x 324 - 9: six full windows
+    assert not fit(4 * 500 * 120, cus)       # 938: four windows for 2.6
+    assert fit(16 * 1000 * 120, cus) and fit(64 * 1000 * 120, cus)
+    assert not fit(0, cus) and fit(264, 1) and not fit(265, 1)
+    # the limit for many windows: 324 / 384 of every further window is final
+    assert fit(10 ** 7, cus)
