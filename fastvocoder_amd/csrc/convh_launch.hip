@@ -164,6 +164,17 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
         for (int i = 0; i < p.n_members; ++i) w += (long long)((p.T + 127) / 128) * p.B * (C / 128);
         wide = tuning().convh_rows64 < 0 ? w * 10 >= 7LL * cus : !tuning().convh_rows64;
     }
+    // 256 / 512 channels with items enough: the ring-free form (convs2_kernels.hpp: 128 rows x 64 columns, every wave loads the A
+    // operands of its own sixteen rows L2 -> registers; no reflection padding, dilations 1 / 3 / 5) -- Tuning::convs_ringfree
+    const bool ringfree = wide && C >= 256 && !p.reflect && dil <= 5 && tuning().convs_ringfree != 0;
+    int rf_nh = 1;                     // 128-column tiles (32 x 64 wave tiles) when they still give every CU four items
+    if (ringfree) {
+        long long w = 0;
+        for (int i = 0; i < p.n_members; ++i) w += (long long)((p.T + 127) / 128) * p.B * (C / 128);
+        rf_nh = tuning().convs_ringfree > 0 ? tuning().convs_ringfree : (w >= 4LL * cus ? 2 : 1);
+        if (rf_nh != 1 && rf_nh != 2) rf_nh = 1;
+    }
+    const int rf_cols = 64 * rf_nh;
     for (int i = 0; i < p.n_members; ++i) {
         PairMember& mb = p.m[i];
         if (mb.k != 11 && mb.k != 7 && mb.k != 3) return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: %d taps (3, 7 or 11)", mb.k);
@@ -175,14 +186,18 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
         if (reinterpret_cast<uintptr_t>(mb.w1) & 15)
             return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: packed weights must be 16-byte aligned");
         const ConvHShape g = convh_shape(C, mb.k, dil);
-        mb.n_tiles = (p.T + g.NTC - 1) / g.NTC;
+        mb.n_tiles = ringfree ? (p.T + rf_cols - 1) / rf_cols : (p.T + g.NTC - 1) / g.NTC;
         mb.n_items = mb.n_tiles * p.B * (wide ? g.NMT / 2 : g.NMT);
         p.ctot = C;
         p.nch = g.NCH;
         p.nmt = g.NMT;
         // a tile costs its stages (LDS / matrix time) plus loads, conversion, epilogue
         mb.cost = g.NST * g.NCH + (tuning().convh_skel >= 0 ? tuning().convh_skel : (C == 64 ? 5 : 2));
-        if (g.XIMG > img_bytes) img_bytes = g.XIMG;
+        if (ringfree) {
+            const int xrows = (rf_cols + (mb.k - 1) * dil + 3) / 4 * 4;
+            const int ximg = 4 * 128 * ((xrows + 15) / 16 * 16);
+            if (ximg > img_bytes) img_bytes = ximg;
+        } else if (g.XIMG > img_bytes) img_bytes = g.XIMG;
         items += mb.n_items;
         flops += 2.0 * p.B * (double)C * C * mb.k * p.T;
         bytes += 4.0 * ((double)C * C * mb.k + (double)p.B * C * p.T *
@@ -190,16 +205,18 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     }
     size_t floats = 0;
     p.x_off = 0;                       // ring of 4 weight stages
-    floats += 4 * 16384 / 4;
+    if (!ringfree) floats += 4 * 16384 / 4;
     p.img_off = (int)floats;
     floats += (size_t)img_bytes / 4;
     p.bias_off = 0;                    // (biases are read from global memory in the epilogue)
+    if (ringfree) floats += 64;        // the low-side guard's scratch
     const size_t lds = floats * 4;
     if (lds > 160 * 1024) return fail(FV_ERR_UNSUPPORTED, "split-f16 conv: %zu bytes of LDS", lds);
     long long nblk = tuning().convh_blocks > 0 ? tuning().convh_blocks : cus;     // one 8-wave block per CU
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
-    pair_schedule(p, p.nblk);
+    if (ringfree) p.sched_on = 0;
+    else pair_schedule(p, p.nblk);
     if (!p.sched_on) {                 // no per-block schedule: the kernels' contiguous cut, as a table instead of arithmetic
         long long n[3] = {0, 0, 0};
         for (int i = 0; i < p.n_members; ++i) n[i] = p.m[i].n_items;
@@ -208,7 +225,7 @@ int launch_convh(PairParams p, int C, int dil, hipStream_t s) {
     p.dbg = tuning().pair_dbg;
     p.trace = reinterpret_cast<unsigned long long*>(tuning().trace_ptr);
     profile_begin(s);
-    const int rc = wide ? launch_convs_geom(p, dil, lds, s)
+    const int rc = ringfree ? launch_convs2_geom(p, dil, rf_nh, lds, s) : wide ? launch_convs_geom(p, dil, lds, s)
                  : C >= 128 ? launch_convh_geom<4, 2>(p, dil, lds, s) : launch_convh_geom<2, 2>(p, dil, lds, s);
     profile_end(s, C == 64 ? FV_KERNEL_CONVH64 : FV_KERNEL_CONVH128, flops, bytes);
     return rc;

@@ -151,6 +151,8 @@ struct Tuning {
     int pair128_unfused = 0; // 1: 128-channel ResBlock pairs as two conv launches (convh) instead of the fused convq kernel (A/B, bit-identity tests)
     int convh_rows64 = -1;    // the split-f16 convs at 128+ channels on 64-row tiles (1: convh_kernel) or 128-row ones (0: convs_kernel); -1: by size
     int convt_rows64 = -1;    // the split-f16 transposed conv (128+ input channels) on 64-row tiles (1) or 128-row ones (0); -1: by size
+    int convs_ringfree = -1;  // 256 / 512-channel convs with many items: convs2_kernel (A operands L2 -> registers, no ring) on 64-column (1) or
+                              // 128-column tiles (2; -1: by the number of items) instead of convs_kernel (0)
     int convt_lean = 50;      // ... on the lean kernel (convtl_kernels.hpp) up to this many (64 x 64 item, chunk) units per CU, in tenths; 0: never
     int convq_wide = 20;         // fused 128-channel pairs, dilation 1 / 3: 128-column tiles per CU (in tenths) from which the wide form runs
     int convp_wide = 20;         // fused 64-channel pairs: 256-column tiles per CU (in tenths) from which the wide no-ring form runs
@@ -304,6 +306,7 @@ int launch_convh_geom(const PairParams& p, int dil, size_t lds, hipStream_t s);
 // convh_kernels.hpp): member 0 uses x, w1 (fv_pack_conv_transpose1d_split_f16 image), b1, y, y_act
 int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout, hipStream_t stream);
 int launch_convt_geom(const PairParams& p, int cg, size_t lds, hipStream_t s);
+int launch_convs2_geom(const PairParams& p, int dil, int nh, size_t lds, hipStream_t s);
 int launch_convtl_geom(const PairParams& p, int cg, hipStream_t s);     // the lean form for launches with few items (convtl_kernels.hpp)
 // ... 32 -> 16 channels, kernel 4, stride 2, padding 1 (HiFi-GAN light's last upsampler): its own kernel (convtn_kernels.hpp),
 // its own packed layout (8 KB + 32 inverse row prescales); member 0 as launch_convt (add1 / add2: merged input)

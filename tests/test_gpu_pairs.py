@@ -278,12 +278,15 @@ def test_conv1d_split_f16_vs_oracle(case):
 
 
 @pytest.mark.parametrize("case", [(1, 128, 260, 5, (11, 7, 3)), (3, 128, 129, 1, (11,)), (1, 256, 300, 5, (11, 3)), (2, 512, 140, 3, (7,)),
-                                  (2, 256, 1000, 9, (3,)), (1, 512, 257, 1, (3, 7, 11)), (1, 128, 1, 3, (3,))],
+                                  (2, 256, 1000, 9, (3,)), (1, 512, 257, 1, (3, 7, 11)), (1, 128, 1, 3, (3,)),
+                                  (2, 256, 1000, 5, (11, 7, 3)), (1, 512, 700, 3, (3, 11)), (3, 256, 64, 1, (7,))],
                          ids=lambda c: "x".join(str(v) for v in c))
 def test_conv1d_split_f16_on_128_row_tiles_gives_the_same_bits(case, tuning):
     """The split-f16 convs at 128 channels and more on 128-row tiles (csrc/convr_kernels.hpp convs_kernel: a chunk's window
-    is converted once for both 64-row tiles) against the 64-row tiles of convh_kernel: the same K order per output, so
-    identical bits -- zero and reflection padding, every epilogue form, few persistent blocks, and the oracle."""
+    is converted once for both 64-row tiles; at 256 / 512 channels without reflection padding the ring-free convs2_kernel of
+    csrc/convs2_kernels.hpp, and convs_kernel under `convs_ringfree = 0`) against the 64-row tiles of convh_kernel: the same K
+    order per output, so identical bits -- zero and reflection padding, every epilogue form, few persistent blocks, and the
+    oracle."""
     B, C, T, dil, ks = case
     rng = np.random.RandomState(7 * T + C + dil)
     n = len(ks)
@@ -311,10 +314,19 @@ def test_conv1d_split_f16_on_128_row_tiles_gives_the_same_bits(case, tuning):
     narrow = forms()
     tuning("convh_rows64", 0)
     wide = forms()
+    tuning("convs_ringfree", 0)
+    ring = forms()
+    tuning("convs_ringfree", 1)
+    rf64 = forms()
+    tuning("convs_ringfree", 2)
+    rf128 = forms()
+    tuning("convs_ringfree", -1)
     tuning("convh_blocks", 3)
     few = forms()
     tuning("convh_blocks", 0)
     assert all(torch.equal(a, b) for a, b in zip(narrow, wide)) and all(torch.equal(a, b) for a, b in zip(wide, few))
+    assert all(torch.equal(a, b) for a, b in zip(wide, ring))
+    assert all(torch.equal(a, b) for a, b in zip(wide, rf64)) and all(torch.equal(a, b) for a, b in zip(wide, rf128))
     for y, x, w, b, k in zip(wide[:n], xs, ws, Bi, ks):
         assert _rel(y, oo.conv1d(x, w, b.cpu().numpy(), dil=dil, pad=(k - 1) * dil // 2, pre_slope=0.1)) <= 4e-6
 
@@ -362,7 +374,7 @@ def test_conv1d_split_f16_reflection_rejects():
 def tuning():
     """fv_tuning_set for the duration of a test (process-wide switches of the launchers: restored afterwards)."""
     defaults = {"sched": 1, "sched_switch": 4, "convh_blocks": 0, "pair_blocks": 0, "pair128_unfused": 0, "convg_rows64": -1,
-                "convh_rows64": -1, "convt_rows64": -1, "convp_wide": 20, "convq_wide": 20, "convt_lean": 50}
+                "convh_rows64": -1, "convt_rows64": -1, "convp_wide": 20, "convq_wide": 20, "convt_lean": 50, "convs_ringfree": -1}
     yield _native.tuning_set
     for k, v in defaults.items():
         _native.tuning_set(k, v)
