@@ -321,7 +321,7 @@ static const TuningEntry kTuningTable[] = {
     {"shape64", &Tuning::shape64},         {"krows", &Tuning::krows},            {"grid_cap", &Tuning::grid_cap},
     {"no_group", &Tuning::no_group},       {"mrf_blocks", &Tuning::mrf_blocks},  {"mrf_shape", &Tuning::mrf_shape},
     {"mrf_prio", &Tuning::mrf_prio},       {"convt_lean", &Tuning::convt_lean},
-    {"convs_ringfree", &Tuning::convs_ringfree},
+    {"convs_ringfree", &Tuning::convs_ringfree}, {"convu_resident", &Tuning::convu_resident},
 };
 static void tuning_from_env() {
     const char* on = getenv("FV_TUNING");

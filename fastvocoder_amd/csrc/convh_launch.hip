@@ -291,6 +291,28 @@ int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout,
     }
     const int NTC = 128;
     mb.n_tiles = (ncols + NTC - 1) / NTC;
+    // Many items, 128 / 256 input channels, no merged input: an item is a column tile with ALL its rows on resident images
+    // (convu2_kernels.hpp) -- convu_kernel below converts every window once per PAIR of 64-row tiles.  Tuning::convu_resident
+    {
+        const long long items = (long long)mb.n_tiles * p.B;
+        const int mode = tuning().convu_resident;
+        if (cc == 128 && p.nch <= 2 && p.nmt * 64 <= 1024 && !mb.add1 && mode != 0 && (mode == 2 || items >= 2LL * device_cu_count())) {
+            p.out_div = 1.f;
+            mb.n_items = (int)items;
+            mb.cost = 1;
+            long long nb = tuning().convh_blocks > 0 ? tuning().convh_blocks : device_cu_count();
+            if (nb > items) nb = items;
+            p.nblk = (int)nb;
+            p.sched_on = 0;
+            p.dbg = 0;
+            p.trace = nullptr;
+            profile_begin(s);
+            const int rc = launch_convu2_geom(p, p.nch, s);
+            profile_end(s, FV_KERNEL_CONVT, 2.0 * p.B * (double)p.T * Cin * Cout * 2 * stride,
+                        4.0 * ((double)Cin * Cout * 2 * stride + (double)p.B * ((double)Cin * p.T + (double)Cout * Tout * (mb.y_act ? 2 : 1))));
+            return rc;
+        }
+    }
     // 128 and more input channels: 128-row tiles (convu_kernel, convr_kernels.hpp) when that still gives the chip items
     // enough, as launch_convg / launch_convh; Tuning::convt_rows64
     const long long wide_items = (long long)mb.n_tiles * p.B * ((p.nmt + 1) / 2);

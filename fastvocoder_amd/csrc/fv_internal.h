@@ -153,6 +153,8 @@ struct Tuning {
     int convt_rows64 = -1;    // the split-f16 transposed conv (128+ input channels) on 64-row tiles (1) or 128-row ones (0); -1: by size
     int convs_ringfree = -1;  // 256 / 512-channel convs with many items: convs2_kernel (A operands L2 -> registers, no ring) on 64-column (1) or
                               // 128-column tiles (2; -1: by the number of items) instead of convs_kernel (0)
+    int convu_resident = 1;   // transposed convs of 128 / 256 input channels with >= 2 column tiles per CU: convu2_kernel (all rows of a column
+                              // tile on resident images, A operands L2 -> registers) instead of convu_kernel (0); 2: whenever the shape allows
     int convt_lean = 50;      // ... on the lean kernel (convtl_kernels.hpp) up to this many (64 x 64 item, chunk) units per CU, in tenths; 0: never
     int convq_wide = 20;         // fused 128-channel pairs, dilation 1 / 3: 128-column tiles per CU (in tenths) from which the wide form runs
     int convp_wide = 20;         // fused 64-channel pairs: 256-column tiles per CU (in tenths) from which the wide no-ring form runs
@@ -307,6 +309,7 @@ int launch_convh_geom(const PairParams& p, int dil, size_t lds, hipStream_t s);
 int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout, hipStream_t stream);
 int launch_convt_geom(const PairParams& p, int cg, size_t lds, hipStream_t s);
 int launch_convs2_geom(const PairParams& p, int dil, int nh, size_t lds, hipStream_t s);
+int launch_convu2_geom(const PairParams& p, int nch, hipStream_t s);
 int launch_convtl_geom(const PairParams& p, int cg, hipStream_t s);     // the lean form for launches with few items (convtl_kernels.hpp)
 // ... 32 -> 16 channels, kernel 4, stride 2, padding 1 (HiFi-GAN light's last upsampler): its own kernel (convtn_kernels.hpp),
 // its own packed layout (8 KB + 32 inverse row prescales); member 0 as launch_convt (add1 / add2: merged input)

@@ -374,7 +374,7 @@ def test_conv1d_split_f16_reflection_rejects():
 def tuning():
     """fv_tuning_set for the duration of a test (process-wide switches of the launchers: restored afterwards)."""
     defaults = {"sched": 1, "sched_switch": 4, "convh_blocks": 0, "pair_blocks": 0, "pair128_unfused": 0, "convg_rows64": -1,
-                "convh_rows64": -1, "convt_rows64": -1, "convp_wide": 20, "convq_wide": 20, "convt_lean": 50, "convs_ringfree": -1}
+                "convh_rows64": -1, "convt_rows64": -1, "convp_wide": 20, "convq_wide": 20, "convt_lean": 50, "convs_ringfree": -1, "convu_resident": 1}
     yield _native.tuning_set
     for k, v in defaults.items():
         _native.tuning_set(k, v)
@@ -440,6 +440,7 @@ CONVT_CASES = [  # B, Cin, Cout, Tin, stride, pad, out_pad
     (1, 256, 128, 300, 8, 4, 0), (2, 128, 64, 257, 5, 3, 1), (1, 128, 32, 129, 2, 1, 0), (1, 512, 256, 40, 8, 4, 0),
     (3, 128, 64, 1, 10, 5, 0), (2, 256, 64, 127, 6, 3, 0), (1, 128, 64, 128, 3, 2, 1), (1, 256, 256, 200, 4, 2, 0),
     (2, 128, 16, 50, 4, 0, 0), (1, 128, 64, 33, 8, 8, -8), (1, 128, 64, 260, 16, 8, 0),
+    (4, 256, 256, 500, 4, 2, 0), (2, 128, 64, 700, 8, 4, 0),
     # 64 input channels (half a chunk) and row counts that are not a multiple of the 64-row tile
     (1, 64, 32, 300, 3, 2, 1), (2, 64, 32, 129, 2, 1, 0), (1, 64, 40, 100, 5, 3, 1), (1, 128, 20, 64, 4, 2, 0),
     # 32 input channels (a quarter of a 128-chunk's image: HiFi-GAN light's last upsampler, 32 -> 16 x 2) and 32 rows
@@ -488,6 +489,18 @@ def test_conv_transpose1d_split_f16_vs_oracle(case, tuning):
     if B > 1:                                      # an utterance alone and inside the batch: same bits
         one = _native.conv_transpose1d_split_f16(X[1:2].contiguous(), P, Bi, cout, k, s, pad, op, pre_slope=0.1)
         assert torch.equal(one, y[1:2])
+    if cin in (128, 256) and (cout * s + 63) // 64 * 64 <= 1024:
+        # launches with many column tiles run a column tile with ALL its rows on resident images (csrc/convu2_kernels.hpp: A
+        # operands L2 -> registers, the window converted once per column tile); forced here: same bits
+        tuning("convu_resident", 2)
+        tw_u = torch.empty_like(y)
+        u1 = _native.conv_transpose1d_split_f16(X, P, Bi, cout, k, s, pad, op, pre_slope=0.1)
+        u2 = _native.conv_transpose1d_split_f16(X, P, None, cout, k, s, pad, op, pre_slope=0.1, out_act=tw_u, act_slope=0.2)
+        tuning("convh_blocks", 3)
+        u3 = _native.conv_transpose1d_split_f16(X, P, Bi, cout, k, s, pad, op, pre_slope=0.1)
+        tuning("convh_blocks", 0)
+        tuning("convu_resident", 1)
+        assert torch.equal(u1, y) and torch.equal(u2, y2) and torch.equal(tw_u, twin) and torch.equal(u3, y)
     if cin >= 128:
         # 128-row tiles (csrc/convr_kernels.hpp convu_kernel: the window of a chunk converted once for two 64-row tiles,
         # an odd count of row tiles leaves the last pair half empty) against 64-row tiles: the same K order, same bits
