@@ -85,7 +85,7 @@ import json  # noqa: E402
 FAMILY_OF = [("mrfh_kernel", "mrf16"), ("mrfw_kernel", "mrf32"), ("pairh_kernel<1,", "pairh16"), ("pairh_kernel<2,", "pairh32"),
              ("convq2_kernel<1, 64>", "convh64"), ("convq2_kernel<3, 64>", "convh64"), ("convq2_kernel<5, 64>", "convh64"),
              ("convq2_kernel<1, 65>", "convh64"), ("convq2_kernel<3, 65>", "convh64"), ("convq2_kernel<5, 65>", "convh64"),
-             ("convq2_kernel", "convh128"), ("convh_kernel<2,", "convh64"), ("convh_kernel", "convh128"), ("convs_kernel", "convh128"), ("convs2_kernel", "convh128"), ("convtl_kernel", "convt"),
+             ("convq2_kernel", "convh128"), ("convh_kernel<2,", "convh64"), ("convh_kernel", "convh128"), ("convs_kernel", "convh128"), ("convs2_kernel", "convh128"), ("convtl_kernel", "convt"), ("convu2_kernel", "convt"),
              ("convt_kernel", "convt"), ("convtn_kernel", "convt"), ("convu_kernel", "convt"), ("convg_kernel", "convg"),
              ("convr_kernel", "convg"), ("convk2_kernel", "stack"), ("convk_kernel", "stack")]
 titles = {5: "HiFi-GAN light, 16 utterances of 1000 frames", 2: "config 3: MB-HiFi-GAN light + PQMF, batch 32",
