@@ -17,7 +17,11 @@ CONFIGS = [("melgan", "conf/melgan/original.yaml", 1, 200), ("hifigan", "conf/hi
            ("hifigan", "conf/hifigan/large.yaml", 2, 400),
            # (batches large enough for the wide tiles: 256-column pairs at 64 channels, 128-column ones at 128, 64-column stacks)
            ("hifigan", "conf/hifigan/light.yaml", 16, 1000), ("basis-melgan", "conf/basis-melgan/light.yaml", 8, 1000),
-           ("multiband-hifigan", "conf/multiband-hifigan/light.yaml", 16, 1000), ("hifigan", "conf/hifigan/large.yaml", 8, 600)]
+           ("multiband-hifigan", "conf/multiband-hifigan/light.yaml", 16, 1000), ("hifigan", "conf/hifigan/large.yaml", 8, 600),
+           # (round 5: the 32-channel one-launch stage with history -- 560 frames: one window per block, batch 4: six; the
+           # transposed conv on resident images and the ring-free 256-channel convs at their batch sizes)
+           ("hifigan", "conf/hifigan/light.yaml", 1, 560), ("hifigan", "conf/hifigan/light.yaml", 4, 1000),
+           ("basis-melgan", "conf/basis-melgan/light.yaml", 32, 1000), ("hifigan", "conf/hifigan/large.yaml", 32, 1000)]
 bad = 0
 for name, path, B, T in CONFIGS:
     cfg = yaml.safe_load(open(path))
