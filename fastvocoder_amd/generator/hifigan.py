@@ -24,6 +24,9 @@ from .pqmf import PQMF
 DEFAULT_LRELU_SLOPE = 0.01  # F.leaky_relu's default, used before conv_post (hifigan.py:104)
 
 
+_CU_COUNT = {}      # device -> compute units (asked once per device: the policy below runs on every forward)
+
+
 def stage32_windows_fit(cols, cus, fill=0.65):
     """Do the 32-channel one-launch kernel's fixed windows fit ``cols`` columns (batch x samples of the stage) on ``cus``
     CUs?  The launcher (csrc/mrfh_launch.hip) gives every block -- one per CU, at most one per 128 columns -- an equal share;
@@ -128,7 +131,10 @@ class _HiFiGANBase(NativeModule):
             return bool(fs)
         if channels != 32:
             return False
-        cus = torch.cuda.get_device_properties(self._device()).multi_processor_count
+        dev = self._device()
+        cus = _CU_COUNT.get(dev)
+        if cus is None:
+            cus = _CU_COUNT[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
         return stage32_windows_fit(getattr(self, "_fv_batch", 1) * int(t), cus)
 
     def _emit_fused_stage(self, pb, blocks, up, x, scratch, parts, fold=None, merge_next=False, one_launch=False):
