@@ -391,9 +391,10 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3
     // ---- prologue: margins zero (finite), the nine pairs' bias blocks, first window, first piece ----
     // L2 warm-up.  Every block walks the same 36 pieces in step, one piece ahead of its K loops (~1 us): inside a forward the
     // packed stage (306 KB) is in nobody's L2 when the launch starts, and a piece that every block of an XCD asks for at the
-    // same moment is a miss for all of them -- 36 exposed misses per tile [measured: 159 us inside the step where the hot
-    // loop takes 76].  So the blocks of an XCD (blockIdx % 8) read one slice of the stage each, up front, into registers
-    // that nobody uses: by the time the third piece is due the whole stage sits in the XCD's L2.
+    // same moment is a miss for all of them.  So the blocks of an XCD (blockIdx % 8) read one slice of the stage each, up
+    // front, into registers that nobody uses: by the time the third piece is due the whole stage sits in the XCD's L2.
+    // [Measured inside the step: no difference -- the misses it removes were not what the launch waited for; it costs two
+    // loads per thread and stays.]
     u32x4 warm0, warm1;
     {
         const unsigned per_xcd = gridDim.x >= 8 ? gridDim.x >> 3 : 1u;
