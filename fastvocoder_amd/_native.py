@@ -647,7 +647,7 @@ def pack_mrf_stage(w1s, w2s, b1s, b2s, ks, flag=None):
 def mrf_stage_split_f16(x, packed, ks, dils=MRF_STAGE_DILATIONS, slope=0.1, out_div=3.0, post=POST_NONE, act_slope=1.0,
                         out=None, out_act=None, fold=None, guard=None):
     """A whole 16- or 32-channel MRF stage in one launch (fv_mrf_stage_split_f16): y = post(((r0 + r1) + r2) / out_div)
-    with r_j = ResBlock1_j(x); ``packed`` from pack_mrf_stage.  ``fold`` (16 channels) = (w [16, 7], bias [1] or None):
+    with r_j = ResBlock1_j(x); ``packed`` from pack_mrf_stage.  ``fold`` = (w [C, 7], bias [1] or None):
     returns post(conv1d(lrelu(y, act_slope); w, padding 3) + bias), [B, 1, T], instead of y.  The 32-channel kernel's
     scratch is allocated here, per call (stream-ordered by the caching allocator)."""
     B, C, T = x.shape

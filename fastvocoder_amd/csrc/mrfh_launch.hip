@@ -19,7 +19,6 @@ int launch_mrfh(MrfParams p, int C, const int* dil, hipStream_t s) {
         return fail(FV_ERR_UNSUPPORTED, "mrf stage: C = %d, taps (%d, %d, %d), dilations (%d, %d, %d): built for 16 / 32 channels, taps "
                     "3 / 7 / 11, dilations (1, 3, 5)", C, p.k[0], p.k[1], p.k[2], dil ? dil[0] : 0, dil ? dil[1] : 0, dil ? dil[2] : 0);
     const bool fold = p.fold_w != nullptr;
-    if (fold && C != 16) return fail(FV_ERR_UNSUPPORTED, "mrf stage: the folded output conv is built for 16 channels (C = %d)", C);
     if (!p.x || !p.blob || (!fold && !p.y) || (fold && (!p.fold_y || p.y || p.y_act)))
         return fail(FV_ERR_INVALID_ARG, "mrf stage: null tensor (or both an output tensor and a folded output conv)");
     if ((reinterpret_cast<uintptr_t>(p.blob) & 15) != 0) return fail(FV_ERR_UNSUPPORTED, "mrf stage: the packed stage must be 16-byte aligned");
@@ -62,7 +61,7 @@ int launch_mrfh(MrfParams p, int C, const int* dil, hipStream_t s) {
     p.prio = tuning().mrf_prio;
     p.trace = reinterpret_cast<unsigned long long*>(tuning().trace_ptr);
     double bytes = 4.0 * ((double)p.B * C * p.T * (fold ? 1.0 : (p.y_act ? 3.0 : 2.0)) + (fold ? (double)p.B * p.T : 0.0)) + off;
-    if (fold) flops += 2.0 * p.B * (double)C * 7 * p.T;
+    if (fold) flops += 2.0 * p.B * (double)C * 7 * p.T;   // (the folded output conv: C -> 1 channels, 7 taps)
     profile_begin(s);
     const int rc = C == 32 ? launch_mrfw_geom(p, s) : shape == 1 ? launch_mrfh_geom<2, 16>(p, s) : launch_mrfh_geom<3, 12>(p, s);
     profile_end(s, C == 32 ? FV_KERNEL_MRF32 : FV_KERNEL_MRF16, flops, bytes);

@@ -42,7 +42,9 @@ struct MrfwTile {
     static constexpr int HROW = 128;                    // history: bytes per image row (2 split halves x 4 blocks x 16)
     static constexpr int HX = 0, HM = 25 * HROW, HSLOT = 30 * HROW;
     static constexpr int OFF_W = 0, OFF_X = 2 * PIECE, OFF_M = OFF_X + IMG, OFF_B = OFF_M + IMG, OFF_S = OFF_B + 9 * TAIL;
-    static constexpr int LDS = OFF_S + 256;
+    static constexpr int OFF_F = OFF_S + 256;           // FOLD: the output conv's weights [8 groups][7 taps][4] and bias
+    static constexpr int LDS = OFF_F + 1024;
+    static_assert(W * 128 <= IMG, "FOLD: the activated fp32 tile [column][32 channels] lies over the intermediate image");
     static_assert(RP % 16 == 0, "whole bank rows");
     static_assert(NG >= 5 && NG <= 8, "history copies: waves 0 ... 4; a piece is at most two LDS-DMA instructions per wave");
     static_assert(LDS <= 160 * 1024, "LDS");
@@ -334,7 +336,7 @@ __device__ __forceinline__ void mrfw_block_run(const MrfParams& p, const MrfwLan
                              rh, o2, next_off, next_kb, tile_no, q0 + 2);
 }
 
-template <int NF, int NG, int D0, int D1, int D2>
+template <int NF, int NG, int D0, int D1, int D2, bool FOLD>
 __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3) / 4, (NG + 3) / 4))) void mrfw_kernel(MrfParams p) {
     typedef MrfwTile<NF, NG> TL;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -358,12 +360,12 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3
     char* const mimg0 = sm + TL::OFF_M;
     float* const wbuf = smem + TL::OFF_W / 4;
     float* const scratch = smem + TL::OFF_S / 4;
-    const int T = p.T, halo = p.halo;
-    const int vcols = TL::W - halo;
-    const int adv = vcols;
+    const int T = p.T, halo = p.halo, ol = p.ol;
+    const int vcols = TL::W - halo;                      // columns of a window that are final for the pairs (given history)
+    const int adv = vcols - 2 * ol;                      // window advance inside a run (FOLD: the output conv's reach either side)
     const int k0 = p.k[0], k1 = p.k[1], k2 = p.k[2];
     const unsigned off0 = p.blk_off[0], off3 = p.blk_off[3], off6 = p.blk_off[6];
-    asm volatile("" ::"s"(T), "s"(halo), "s"(k0), "s"(k1), "s"(k2), "s"(off0), "s"(off3), "s"(off6));
+    asm volatile("" ::"s"(T), "s"(halo), "s"(ol), "s"(k0), "s"(k1), "s"(k2), "s"(off0), "s"(off3), "s"(off6));
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.blob, p.blob_bytes);
     const __amdgpu_buffer_rsrc_t rh = make_rsrc(p.hist + (size_t)blockIdx.x * (9 * TL::HSLOT / 4), p.hist ? 9 * TL::HSLOT : 0);
 
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3
     const long long g_lo = p.total * share / p.nblk, g_hi = p.total * (share + 1) / p.nblk;
     if (g_lo >= g_hi) return;
     MrfIter it;
-    mrf_first(it, g_lo, g_hi, T, halo, 0, vcols);
+    mrf_first(it, g_lo, g_hi, T, halo, ol, vcols);
 
     const unsigned t4 = (unsigned)T * 4u, ubytes = (unsigned)TL::C * (unsigned)T * 4u;
     const size_t ustride = (size_t)TL::C * (size_t)T;
@@ -423,6 +425,16 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3
         const unsigned base = (j == 0 ? off0 : j == 1 ? off3 : off6) + (unsigned)((q - 3 * j) * (2 * kj * TL::STEP + 1024));
         reinterpret_cast<float*>(sm + TL::OFF_B)[idx] = p.blob[(base + 2u * (unsigned)kj * TL::STEP) / 4 + e];
     }
+    if constexpr (FOLD) {
+        // the output conv's weights as [4 channels' group q][tap j][4 channels] (a group's seven taps are seven 16-byte entries:
+        // one uniform ds_read_b128 each), the bias behind them
+        float* const fw = reinterpret_cast<float*>(sm + TL::OFF_F);
+        if (L.tid < 224) {
+            const int q = L.tid / 28, j = (L.tid % 28) / 4, cc = L.tid & 3;
+            fw[L.tid] = p.fold_w[(4 * q + cc) * 7 + j];
+        }
+        if (L.tid == 224) fw[224] = p.fold_b ? p.fold_b[0] : 0.f;
+    }
     LowGuard low;
     float bad = 0.f;
     const float rcp = div_rcp(p.out_div);
@@ -435,7 +447,7 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3
     int tile_no = 0, par = 0;
     for (;;) {
         const MrfIter cur = it;
-        const bool more = mrf_next(it, g_hi, T, halo, 0, vcols, adv);
+        const bool more = mrf_next(it, g_hi, T, halo, ol, vcols, adv);
         MrfwWhen wh;
         wh.tw = cur.tw;
         wh.inside = cur.tw >= 0 && cur.tw + TL::W <= T;
@@ -471,47 +483,116 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3
         }
         // ---- ((r0 + r1) + r2) / 3 and the stores (behind the tile's last barrier: they drain under the next tile) ----
         if (tile_no == 0) mrf_stamp(p, NG, L.wave, L.lane, 2, 2);
-        const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y + cur.b * ustride, ubytes);
-        const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.y_act ? p.y_act + cur.b * ustride : p.y, p.y_act ? ubytes : 0u);
+        if constexpr (FOLD) {
+            // mrfh_kernel's fold at 32 channels.  The activated tile -> LDS over the intermediate image (free since the last
+            // barrier), zero outside [0, T), as [column][32 channels]: the four channels of a D fragment are ONE 16-byte entry
+            // (entry e = channels 4 e ...: e = 4 h + g), a column's eight entries rotated by column / 2 -- sixteen consecutive
+            // columns then cover all sixteen 16-byte slots of a bank row, reads and writes alike.  Then one output sample per
+            // thread: conv_narrow_kernel's arithmetic (channel-major FMA chain from zero, bias last), so plans that keep the
+            // output conv as a launch of its own give the same bits.
+            char* const sb = mimg0;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float out[NF][4];
-#pragma unroll
-            for (int f = 0; f < NF; ++f)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) out[f][i] = sum[h][f][i] + xr[h][f][i];
-            if (rcp != 0.f) {
-#pragma unroll
-                for (int f = 0; f < NF; ++f)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) out[f][i] = div_exact(out[f][i], p.out_div, rcp);
-            } else if (p.out_div != 1.f) {
+            for (int h = 0; h < 2; ++h) {
+                float out[NF][4];
 #pragma unroll
                 for (int f = 0; f < NF; ++f)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) out[f][i] = out[f][i] / p.out_div;
-            }
+                    for (int i = 0; i < 4; ++i) out[f][i] = sum[h][f][i] + xr[h][f][i];
+                if (rcp != 0.f) {
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const int t = cur.tw + L.colw + f * 16;
-                const bool ok = t >= cur.lo && t < cur.hi;
-                range_note4(bad, out[f][0], out[f][1], out[f][2], out[f][3], ok);
-                const unsigned voff = ok ? (unsigned)((L.row0 + 16 * h) * T + t) * 4u : kOutOfRange;
-                float v[4];
+                    for (int f = 0; f < NF; ++f)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = out[f][i];
-                    if (p.post == FV_POST_TANH) v[i] = tanhf(v[i]);
-                    else if (p.post == FV_POST_RELU) v[i] = fmaxf(v[i], 0.f);
+                        for (int i = 0; i < 4; ++i) out[f][i] = div_exact(out[f][i], p.out_div, rcp);
+                } else if (p.out_div != 1.f) {
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) out[f][i] = out[f][i] / p.out_div;
                 }
-                if (p.y_act) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) buffer_store1s(ry, voff, (unsigned)i * t4, v[i]);
+                for (int f = 0; f < NF; ++f) {
+                    const int col = L.colw + f * 16, t = cur.tw + col;
+                    const bool ok = t >= 0 && t < T;
+                    range_note4(bad, out[f][0], out[f][1], out[f][2], out[f][3], t >= cur.lo - ol && t < cur.hi + ol && ok);
+                    f32x4 v;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) buffer_store1s(ra, voff, (unsigned)i * t4, act(v[i], p.act_slope));
-                } else {
+                    for (int i = 0; i < 4; ++i) v[i] = ok ? act(out[f][i], p.act_slope) : 0.f;
+                    *reinterpret_cast<f32x4*>(sb + col * 128 + (((4 * h + (L.row0 >> 2)) + (col >> 1)) & 7) * 16) = v;
+                }
+            }
+            pair_barrier();
+            const float* const fw = reinterpret_cast<const float*>(sm + TL::OFF_F);
+            for (int c0 = L.tid; c0 < vcols - 2 * ol; c0 += TL::NT) {
+                const int col = c0 + ol, t = cur.tw + col;
+                float o = 0.f;
+#pragma unroll 1
+                for (int q = 0; q < 8; ++q) {
+                    f32x4 d[7], w[7];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) buffer_store1s(ry, voff, (unsigned)i * t4, p.act_slope != 1.f ? act(v[i], p.act_slope) : v[i]);
+                    for (int j = 0; j < 7; ++j) {
+                        const int row = col - 3 + j;
+                        d[j] = *reinterpret_cast<const f32x4*>(sb + row * 128 + ((q + (row >> 1)) & 7) * 16);
+                        w[j] = *reinterpret_cast<const f32x4*>(fw + (q * 7 + j) * 4);
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) o = fmaf(w[j][cc], d[j][cc], o);
+                }
+                o = o + fw[224];
+                if (p.post == FV_POST_TANH) o = tanhf(o);
+                else if (p.post == FV_POST_RELU) o = fmaxf(o, 0.f);
+                if (t >= cur.lo && t < cur.hi) p.fold_y[(size_t)cur.b * T + t] = o;
+            }
+            pair_barrier();
+            // the tile lay over rows BEHIND the intermediate's window too: finite values again (mrfh_kernel)
+            for (int idx = L.tid; idx < 8 * TL::FM * 4; idx += TL::NT) {
+                const int dw = idx & 3, row = (idx >> 2) % TL::FM, part = (idx >> 2) / TL::FM;
+                reinterpret_cast<float*>(mimg0 + (part >> 2) * TL::HALF + (part & 3) * TL::BLK + (TL::FM + TL::W + row) * 16)[dw] = 0.f;
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y + cur.b * ustride, ubytes);
+            const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.y_act ? p.y_act + cur.b * ustride : p.y, p.y_act ? ubytes : 0u);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float out[NF][4];
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) out[f][i] = sum[h][f][i] + xr[h][f][i];
+                if (rcp != 0.f) {
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) out[f][i] = div_exact(out[f][i], p.out_div, rcp);
+                } else if (p.out_div != 1.f) {
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) out[f][i] = out[f][i] / p.out_div;
+                }
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const int t = cur.tw + L.colw + f * 16;
+                    const bool ok = t >= cur.lo && t < cur.hi;
+                    range_note4(bad, out[f][0], out[f][1], out[f][2], out[f][3], ok);
+                    const unsigned voff = ok ? (unsigned)((L.row0 + 16 * h) * T + t) * 4u : kOutOfRange;
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = out[f][i];
+                        if (p.post == FV_POST_TANH) v[i] = tanhf(v[i]);
+                        else if (p.post == FV_POST_RELU) v[i] = fmaxf(v[i], 0.f);
+                    }
+                    if (p.y_act) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) buffer_store1s(ry, voff, (unsigned)i * t4, v[i]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) buffer_store1s(ra, voff, (unsigned)i * t4, act(v[i], p.act_slope));
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) buffer_store1s(ry, voff, (unsigned)i * t4, p.act_slope != 1.f ? act(v[i], p.act_slope) : v[i]);
+                    }
                 }
             }
         }

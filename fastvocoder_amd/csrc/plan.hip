@@ -603,10 +603,10 @@ int fv_plan_set_pair_output_conv(fv_plan_t* plan, const float* w, const float* b
     if (!plan || plan->ops.empty() || !w) return fail(FV_ERR_INVALID_ARG, "plan_set_pair_output_conv: no op / null weights");
     if (int rc = check_slot(y_slot, false)) return rc;
     Op& o = plan->ops.back();
-    if ((o.type != OP_PAIR && o.type != OP_STAGE) || o.prec != FV_PAIR_SPLIT_F16 || o.Cin != 16 || o.group != 0 ||
-        o.y2 != FV_SLOT_NONE || o.post != FV_POST_NONE || o.fold_w)
+    if ((o.type != OP_PAIR && o.type != OP_STAGE) || o.prec != FV_PAIR_SPLIT_F16 || !(o.Cin == 16 || (o.Cin == 32 && o.type == OP_STAGE)) ||
+        o.group != 0 || o.y2 != FV_SLOT_NONE || o.post != FV_POST_NONE || o.fold_w)
         return fail(FV_ERR_UNSUPPORTED, "plan_set_pair_output_conv: the last op must be an ungrouped 16-channel split-f16 "
-                    "resblock pair (or a one-launch MRF stage) without an activated twin or a post op of its own");
+                    "resblock pair (or a one-launch MRF stage of 16 or 32 channels) without an activated twin or a post op of its own");
     if (y_slot == FV_SLOT_IN || y_slot == o.x || y_slot == o.acc || y_slot == o.acc2 || y_slot == o.tmpb)
         return fail(FV_ERR_INVALID_ARG, "plan_set_pair_output_conv: the output slot aliases an operand");
     if (act_slope < 0.f || act_slope > 1.f) return fail(FV_ERR_INVALID_ARG, "plan_set_pair_output_conv: slope outside [0, 1]");

@@ -184,11 +184,13 @@ class PlanBuilder:
                     b1=self._bias(conv1), b2=self._bias(conv2), k=conv1.kernel_size[0])
 
     @staticmethod
-    def pair_fold_supported(conv1, out_conv, prec):
+    def pair_fold_supported(conv1, out_conv, prec, stage=False):
         """Can ``out_conv`` (HiFi-GAN's conv_post: 16 -> 1 channels, 7 taps, 'same' zero padding) be folded into the
-        fused pair in front of it (fv_plan_set_pair_output_conv)?"""
-        return (prec == _native.PAIR_SPLIT_F16 and conv1.in_channels == 16
-                and isinstance(out_conv, torch.nn.Conv1d) and out_conv.in_channels == 16 and out_conv.out_channels == 1
+        fused pair in front of it (fv_plan_set_pair_output_conv)?  ``stage``: into a one-launch MRF stage, which takes 32
+        channels too (HiFi-GAN large / V1: csrc/mrfw_kernels.hpp)."""
+        c = conv1.in_channels
+        return (prec == _native.PAIR_SPLIT_F16 and (c == 16 or (stage and c == 32))
+                and isinstance(out_conv, torch.nn.Conv1d) and out_conv.in_channels == c and out_conv.out_channels == 1
                 and out_conv.kernel_size[0] == 7 and out_conv.stride[0] == 1 and out_conv.dilation[0] == 1
                 and out_conv.padding[0] == 3 and out_conv.groups == 1)
 
@@ -245,9 +247,9 @@ class PlanBuilder:
                   post=POST_NONE, prec=_native.PAIR_SPLIT_F16)
         if fold is not None:
             out_conv, fslope, fpost = fold
-            if not self.pair_fold_supported(blocks[0].convs1[0], out_conv, _native.PAIR_SPLIT_F16):
+            if not self.pair_fold_supported(blocks[0].convs1[0], out_conv, _native.PAIR_SPLIT_F16, stage=True):
                 raise _native.NativeError("mrf stage: this output conv cannot be folded into the stage")
-            op.update(fold_w=effective_weight(out_conv).detach().float().reshape(16, 7).contiguous(),
+            op.update(fold_w=effective_weight(out_conv).detach().float().reshape(blocks[0].channels, 7).contiguous(),
                       fold_b=self._bias(out_conv), fold_post=fpost, act_slope=float(fslope))
         self.ops.append(op)
 

@@ -234,8 +234,9 @@ class _HiFiGANBase(NativeModule):
         if not pb.fold_post or not fused or not fused[-1] or self.num_kernels != 3:
             return False
         blocks = self.resblocks[-3:]
-        return PlanBuilder.pair_fold_supported(blocks[0].convs1[-1], self.conv_post,
-                                               pb.pair_precision(blocks[0].channels))
+        # (a 32-channel last stage -- HiFi-GAN large -- folds only as the one-launch stage: the pair kernels' fold is 16 channels)
+        return PlanBuilder.pair_fold_supported(blocks[0].convs1[-1], self.conv_post, pb.pair_precision(blocks[0].channels),
+                                               stage=fused[-1] == "s" and pb.mrf_stage_supported(blocks))
 
     def _emit_trunk(self, pb, dst, fused=None, fold_post=False, pqmf=None):
         """mel (SLOT_IN) -> tanh(conv_post(...)) in ``dst``; ``fused``: per-stage flags (_fused_flags); ``fold_post``:

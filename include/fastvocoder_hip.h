@@ -221,7 +221,7 @@ int fv_resblock1_fused_ex(int n, const float* const* x, const float* const* w1, 
  *   packed: fv_pack_mrf_stage_split_f16 of the 18 Conv1d weights and biases -- w1[3 j + p], w2[3 j + p]: [C, C, k_j];
  *   b1 / b2: arrays of 9 pointers to [C] (entries, or the arrays, may be NULL); fv_packed_mrf_stage_floats floats
  *   (0 = shape not built).  Per pair: [conv1 image | conv2 image | b1 | b2 | 1 / row prescale of conv1 | of conv2].
- *   fold_w [16, 7] != NULL (HiFi-GAN's conv_post, hifigan.py:104-106, inside the launch; C = 16, needs y = y_act = NULL):
+ *   fold_w [C, 7] != NULL (HiFi-GAN's conv_post, hifigan.py:104-106, inside the launch; needs y = y_act = NULL):
  *       fold_y[B, 1, T] = post( conv1d( lrelu(((r_0 + r_1) + r_2) / out_div, act_slope); fold_w, zero padding 3 ) + fold_b )
  *   -- the same arithmetic, bit for bit, as fv_conv1d_fused on a stored y.
  */

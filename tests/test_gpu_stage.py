@@ -315,9 +315,6 @@ def test_mrf_stage32_guards_and_refusals():
     guard.zero_()
     y = _native.mrf_stage_split_f16(_t(np.zeros_like(x)), _pack(nob, ks), ks, guard=guard)
     assert int(guard.item()) == 0 and float(y.abs().max()) == 0.0
-    # the folded output conv is a 16-channel affair
-    with pytest.raises(_native.NativeError, match="16 channels"):
-        _native.mrf_stage_split_f16(_t(x), P, ks, fold=(_t(rng.randn(16, 7).astype(np.float32)), None))
 
 
 def test_mrf_stage32_plan_op():
@@ -329,3 +326,33 @@ def test_mrf_stage32_plan_op():
     plan = _native.Plan(32)
     plan.add_mrf_stage(_native.SLOT_IN, _native.SLOT_OUT, P, 32, ks, DILS, 0.1)
     assert torch.equal(plan.run(X), _native.mrf_stage_split_f16(X, P, ks))
+
+
+@pytest.mark.parametrize("case", [(1, 37, 0), (2, 1000, 1), (1, 1531, 2), (2, 777, 3), (1, 3000, 0), (3, 640, 7)],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_mrf_stage32_with_folded_output_conv(case, tuning):
+    """HiFi-GAN large's last launch (hifigan.py:97-106 at 32 channels): stage, lrelu(0.01), conv_post (32 -> 1, 7 taps), tanh --
+    against the oracle, and bit for bit against the stage followed by the narrow conv as a launch of its own."""
+    B, T, blocks = case
+    rng = np.random.RandomState(37 * T + blocks)
+    ks = (3, 7, 11)
+    x = rng.randn(B, 32, T).astype(np.float32)
+    ws = _stage_weights(rng, ks, C=32)
+    wp = (rng.randn(1, 32, 7) / np.sqrt(32 * 7)).astype(np.float32)
+    bp = rng.randn(1).astype(np.float32)
+    ref = np.tanh(oo.conv1d(_oracle_stage(x, ws, ks), wp, bp, pad=3, pre_slope=0.01).astype(np.float64))
+    tuning("mrf_blocks", blocks)
+    X, P = _t(x), _pack(ws, ks)
+    guard = torch.zeros(1, dtype=torch.int32, device=_dev())
+    y = _native.mrf_stage_split_f16(X, P, ks, fold=(_t(wp.reshape(32, 7)), _t(bp)), act_slope=0.01, post=_native.POST_TANH, guard=guard)
+    assert tuple(y.shape) == (B, 1, T) and _rel(y, ref) <= 4e-6 and int(guard.item()) == 0
+    stage = _native.mrf_stage_split_f16(X, P, ks)
+    two = _native.conv1d_fused(stage, _native.pack_conv1d(_t(wp)), _t(bp), 1, 7, pad=3, pre_slope=0.01, post=_native.POST_TANH)
+    assert torch.equal(y, two), "folded and separate output conv differ"
+    # the plan op with the fold, without a bias
+    plan = _native.Plan(32)
+    plan.add_mrf_stage(_native.SLOT_IN, 2, P, 32, ks, DILS, 0.1)
+    plan.set_pair_output_conv(_t(wp.reshape(32, 7)), None, _native.SLOT_OUT, 0.01, _native.POST_TANH)
+    assert plan.num_ops() == 1
+    ref0 = np.tanh(oo.conv1d(_oracle_stage(x, ws, ks), wp, None, pad=3, pre_slope=0.01).astype(np.float64))
+    assert _rel(plan.run(X), ref0) <= 4e-6
