@@ -151,11 +151,27 @@ struct ConvQ2Run : ConvQ2Geom<KT_, DIL_, C_> {
     static constexpr int NFW = 4;                        // fragments per wave: 64 columns
     static constexpr int NH = C_ == kPair64Wide || C_ == kPair128Wide ? 2 : 1;     // row sixteenths per wave
     static constexpr int NSLAB = B::C / (16 * NH);       // row slabs = waves per column group
-    static constexpr int QD = NH == 2 ? 1 : 3;           // A operands this many K steps ahead (queue of QD + 1 slots; a K step of
-                                                         // the 32 x 64 tile is 768 matrix cycles per SIMD: one ahead is enough)
+#ifndef FV_Q2_DEEP
+#define FV_Q2_DEEP 1
+#endif
+    // A operands this many K steps ahead (queue of QD + 1 slots).  The 32 x 64 tiles: one (a K step is 768 matrix cycles per
+    // SIMD).  The 16 x 64 tiles: three was enough for the operands themselves (L2 hits), but the next tile's WINDOW can only be
+    // requested where no operand of this tile queues behind it -- vmcnt completes in order -- i.e. QD steps before the tile ends:
+    // at three steps (0.6 us) plus the epilogue a window that comes from another XCD's L2 or from HBM (~2 us) was waited for at
+    // every tile end [measured, tools/convq2_trace.py: ~1 us per tile].  There are 50 spare registers: five / six steps at 64
+    // channels with 3 / 7 taps (QD + 1 has to divide the tile's step count: the queue runs on from tile to tile; 44 steps at 11
+    // taps leave three) [measured, tools/forward_ab.py, batch 1: the 64-channel stage 157.0 -> 154.4 us].  At 128 channels a
+    // block has one or two tiles per launch at batch 1 -- hardly a next window to wait for -- and seven steps cost more in the
+    // run's prologue than they save (140.3 -> 144.5 us): three.
+    static constexpr int QD = NH == 2 ? 1 : !FV_Q2_DEEP || B::C == 128 ? 3 : KT_ == 3 ? 5 : KT_ == 7 ? 6 : 3;
     static constexpr int NA = 2 * NH;                    // loads per wave and K step
     static constexpr bool ILV = FV_Q2_ILV && NH == 1;    // the step's loads one per MFMA gap (below)
     static constexpr int NSEQ = 2 * B::NSTEP;            // K steps per tile: conv1's, then conv2's
+    // The residual (x itself: 4 NFW NH dwords per lane) is requested behind conv1's epilogue on the 16 x 64 wave tiles (180-190
+    // VGPRs: room for it) and lands during conv2 -- requested where it is consumed it was a round trip per tile (~1 us of the
+    // 8-25 us a tile takes at batch 1).  The 32 x 64 tiles (250 VGPRs) keep the late request.
+    static constexpr bool RES_EARLY = NH == 1;
+    static constexpr int NRES = 4 * NFW * NH;
     static constexpr int RAWK = NSEQ - QD;               // K step at which the next tile's window is requested: no A operand of
                                                          // THIS tile is issued after it, so nothing here waits for it
     static_assert(NSEQ % (QD + 1) == 0, "the A queue runs on from tile to tile: slot = K step % (QD + 1)");
@@ -278,16 +294,18 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
                 if constexpr (S == G::RAWK)
                     convh_load_raw<IMG>(raw, mb.x + nb * ustride, p.T, nwin, tid, more && !(p.dbg & 1));
                 constexpr bool raw_after = G::RAWK > S - G::QD && G::RAWK <= S;     // requested after step S's loads were
+                // (the early residual sits between the A operands of conv2's first QD steps -- issued during conv1 -- and the rest)
+                constexpr int res_after = G::RES_EARLY && S >= G::NSTEP && S < G::NSTEP + G::QD ? G::NRES : 0;
                 // (a tile's first QD steps were waited for in the epilogue of the tile before)
                 if constexpr (G::ILV) {
-                    if constexpr (S >= G::QD) wait_vm<G::NA * (G::QD - 1) + (raw_after ? G::NRAW : 0)>();
+                    if constexpr (S >= G::QD) wait_vm<G::NA * (G::QD - 1) + (raw_after ? G::NRAW : 0) + res_after>();
                     __builtin_amdgcn_sched_barrier(0);
                     load_a(IntC<S + G::QD>{}, aq[(S + G::QD) % (G::QD + 1)]);
                     if constexpr (S + 1 < S1) fetch_b(IntC<S + 1>{}, bbuf[(S + 1) & 1]);
                 } else {
                     load_a(IntC<S + G::QD>{}, aq[(S + G::QD) % (G::QD + 1)]);
                     if constexpr (S + 1 < S1) fetch_b(IntC<S + 1>{}, bbuf[(S + 1) & 1]);
-                    if constexpr (S >= G::QD) wait_vm<G::NA * G::QD + (raw_after ? G::NRAW : 0)>();
+                    if constexpr (S >= G::QD) wait_vm<G::NA * G::QD + (raw_after ? G::NRAW : 0) + res_after>();
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 f16x8 (&a)[G::NH][2] = aq[S % (G::QD + 1)];
@@ -356,6 +374,21 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
             }
             low_note(low, 1, lowm);
         }
+        float res[G::NH][G::NFW][4];
+        unsigned voff[G::NFW];
+        auto load_res = [&]() {
+            const __amdgpu_buffer_rsrc_t rr = make_rsrc(mb.x + b * ustride, ubytes);     // the residual is x itself
+#pragma unroll
+            for (int f = 0; f < G::NFW; ++f) {
+                const int col = col0 + f * 16, t = t0 + col;
+                voff[f] = col < n_out && t < c_end ? (unsigned)(row0 * p.T + t) * 4u : kOutOfRange;
+#pragma unroll
+                for (int h = 0; h < G::NH; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) res[h][f][i] = buffer_load1s(rr, voff[f], (unsigned)(16 * h + i) * t4);
+            }
+        };
+        if constexpr (G::RES_EARLY) load_res();
         pair_barrier();                                  // the intermediate is complete (and nobody reads the x image any more)
         pair_stamp(p, 8, wave, lane, it, 2);
         run(IntC<G::NSTEP>{}, IntC<G::NSEQ>{});
@@ -371,20 +404,7 @@ __device__ __forceinline__ void convq2_run_member(const PairParams& p, const Pai
                     *reinterpret_cast<const f16x8*>(base + (r0 + G::NM - (G::KT - 1) + row) * 16);
             }
         }
-        float res[G::NH][G::NFW][4];
-        unsigned voff[G::NFW];
-        {
-            const __amdgpu_buffer_rsrc_t rr = make_rsrc(mb.x + b * ustride, ubytes);     // the residual is x itself
-#pragma unroll
-            for (int f = 0; f < G::NFW; ++f) {
-                const int col = col0 + f * 16, t = t0 + col;
-                voff[f] = col < n_out && t < c_end ? (unsigned)(row0 * p.T + t) * 4u : kOutOfRange;
-#pragma unroll
-                for (int h = 0; h < G::NH; ++h)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) res[h][f][i] = buffer_load1s(rr, voff[f], (unsigned)(16 * h + i) * t4);
-            }
-        }
+        if constexpr (!G::RES_EARLY) load_res();
         pair_wait_vm0();                                 // the next window, the residual, the next tile's first A operands
         pair_stamp(p, 8, wave, lane, it, 4);
         const bool fin = mb.add1 != nullptr;
