@@ -41,9 +41,8 @@ struct ConvQGeom {
     static constexpr int STAGE_BYTES = 16384, RING = 3, AHEAD = RING - 1;
     static constexpr int WTILE = NSTEP * 8192;           // packed bytes of one 64-row tile of a conv ([tile][step][8 KB])
     static constexpr int RAWST = NST - 8;                // stage at which the next tile's raw window is requested
-    // (the residual is NOT prefetched during the last stages as in convh / convp: its 16 registers would be live together
-    // with the raw window, both operand queues and the accumulators -- the kernel is at the 256-register limit -- so it
-    // is loaded in the epilogue, an L2 round trip per 22-27 us tile)
+    // (the residual: ConvQ2Run::RES_EARLY -- requested behind conv1's epilogue on the 16 x 64 wave tiles, in the epilogue on the
+    // 32 x 64 ones, which are at the 256-register limit)
 #ifndef FV_CONVQ_BDEPTH
 #define FV_CONVQ_BDEPTH 2
 #endif
