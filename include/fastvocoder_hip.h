@@ -510,7 +510,7 @@ int fv_plan_add_resblock_pair_ex(fv_plan_t* plan, int x_slot, int y_slot, int y_
  * round trip less than the pair followed by fv_conv1d_fused. */
 int fv_plan_set_pair_output_conv(fv_plan_t* plan, const float* w, const float* bias, int y_slot, float act_slope, int post);
 /* fv_mrf_stage_split_f16 as a plan op (y_act_slot may be FV_SLOT_NONE; workspace: as there, owned by the caller for the
- * plan's lifetime, one per op).  fv_plan_set_pair_output_conv also applies to this
+ * plan's lifetime, one per op).  fv_plan_set_pair_output_conv (w [1, C, 7]: 16 or 32 channels here) also applies to this
  * op when it was appended last (the stage's own y is then not stored; y_slot receives the folded conv's [B, 1, T]). */
 int fv_plan_add_mrf_stage_split_f16(fv_plan_t* plan, int x_slot, int y_slot, int y_act_slot, const float* packed, int C,
                                     const int* k, const int* dil, float slope, float out_div, int post, float act_slope,
