@@ -10,15 +10,18 @@ mel the committed reference golden was made from, and the LAST timed output is c
 golden (<= 1e-4, the north star's bound) before anything is printed: the timed forward is the
 parity-checked forward.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weights are built on rank 0 and broadcast
-over RCCL once; every rank runs its own utterances (weak scaling: the path has no exchange step) and
+N > 1: one rank per GPU.  `python bench.py --gpus N` started as ONE process replaces itself with
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...`
+(refused when the node shows fewer than N devices); started by that launcher (WORLD_SIZE in the environment) it is
+a rank.  Weights are built on rank 0 and broadcast over RCCL once; every rank runs its own utterances (weak scaling: the path has no exchange step) and
 every step's waveforms are gathered to rank 0 INSIDE the timed region (asynchronously, overlapping the
 next step's forward); the same steps without the gather are timed too and reported beside it.
 
 The fixed job (BASELINE.json configs[4]): HiFi-GAN large, 512 utterances of 80 x 1000 per step -- strong
-scaling: rank 0 holds the mels, scatters one block per rank, every rank synthesises its block and encodes it
-to int16 on the GPU (fv_encode_16bits), rank 0 gathers the int16 waveforms; scatter, forward, encode and
-gather are all inside the timed step (the same step without scatter / gather is timed beside it), and rank 0
+scaling: rank 0 holds the mels, every rank synthesises its contiguous block in sub-batches and encodes them
+to int16 on the GPU (fv_encode_16bits), rank 0 gathers the int16 waveforms; the scatter of sub-batch i + 1 and the
+gather of sub-batch i - 1 are in flight under sub-batch i's forward (parallel.synthesize_pipelined); scatter, forward,
+encode and gather are all inside the timed step (the same step without scatter / gather is timed beside it), and rank 0
 checks gathered rows against its own single-utterance runs bit for bit.  ``--config large512`` makes it the
 headline of the line; the default run appends it as ``strong_scaling_job`` (one timed step; ``--no-job``
 skips it), so that one invocation per GPU count gives both scaling curves.
@@ -501,10 +504,15 @@ def run_job(args, dev, dist, world, rank, steps, warmup):
                 outs.append(audio.encode_16bits(w, 1.0))      # per-row peak normalise -> int16, on the GPU
         return torch.cat(outs, dim=0)
 
+    def one_sub(block):
+        with torch.no_grad():
+            return audio.encode_16bits(model(block), 1.0)
+
     def step():
         if dist is None:
             return rank_block(mels)
-        return parallel.synthesize_sharded(rank_block, mels, world, rank, scatter=True, device=dev)
+        # scatter of sub-batch i + 1 and gather of sub-batch i - 1 in flight while sub-batch i runs
+        return parallel.synthesize_pipelined(one_sub, mels, args.sub, world, rank, device=dev)
 
     rank_block(torch.from_numpy(utterance_mels(0, min(args.sub, 2))).to(dev))   # plan build, not a step
     torch.cuda.synchronize()
@@ -529,10 +537,53 @@ def run_job(args, dev, dist, world, rank, steps, warmup):
     samples_per_utt = int(pcm.shape[-1]) if rank == 0 else 240 * T_FRAMES
     workload = (f"HiFi-GAN large (conf/hifigan/large.yaml), {total_utt} utterances of mel 80x{T_FRAMES} per step "
                 f"sharded over {world} GPU(s): scatter of mels from rank 0, forward in sub-batches of {args.sub}, "
-                "int16 wav sink on the GPU, gather to rank 0 -- all inside the timed step; BASELINE.json configs[4]")
+                "int16 wav sink on the GPU, gather to rank 0 -- all inside the timed step"
+                + ("" if dist is None else ", the scatter of the next sub-batch and the gather of the last one in "
+                   "flight under the current one's forward (parallel.synthesize_pipelined)")
+                + "; BASELINE.json configs[4]")
     del model
     torch.cuda.empty_cache()
     return elapsed, samples_per_utt, total_utt, workload, extra
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch_argv(gpus, argv, port):
+    """`python bench.py --gpus N ...` started as ONE process (no WORLD_SIZE in the environment): the command it
+    replaces itself with -- the driver's own launch line, one rank per GPU of this node, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def launch_check(world, rank):
+    """`--launch-check`: the N-rank launch and the job's traffic skeleton WITHOUT the GPU -- gloo on the host cores, a
+    stand-in forward (any box, the CPU tests): proves that `bench.py --gpus N` started as one process becomes N ranks
+    that rendezvous, scatter / run / gather a job through parallel.synthesize_pipelined and print ONE line."""
+    import torch.distributed as dist
+    from fastvocoder_amd import parallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, C, T, sub = 8 * world + 3, 80, 12, 2
+    g = torch.Generator().manual_seed(11)
+    mels = torch.rand(B, C, T, generator=g)
+
+    def fwd(block):
+        return (block.sum(1).repeat_interleave(3, dim=1) * 100).to(torch.int16)
+    t0 = time.perf_counter()
+    out = parallel.synthesize_pipelined(fwd, mels if rank == 0 else None, sub, world, rank, device=torch.device("cpu"))
+    dt = time.perf_counter() - t0
+    ids = torch.tensor([rank], dtype=torch.int64)
+    dist.all_reduce(ids)
+    if rank == 0:
+        assert torch.equal(out, fwd(mels)) and int(ids) == world * (world - 1) // 2
+        print(json.dumps({"launch_check": True, "n_gpus": world, "backend": "gloo", "utterances": B, "sub": sub,
+                          "job_bit_identical_to_one_process": True, "seconds": dt}))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def world_error(gpus, world, local_rank, visible, one_gpu=False):
@@ -570,10 +621,27 @@ def main():
     ap.add_argument("--no-job", action="store_true", help="light: skip the appended strong-scaling job (configs[4])")
     ap.add_argument("--no-exact", action="store_true", help="light: skip the exact-fp32 leg")
     ap.add_argument("--no-others", action="store_true", help="light: skip BASELINE configs 1, 3, 4 (other_configs)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="no GPU: start the N ranks, run a stand-in job over gloo on the host, print one line")
     args = ap.parse_args()
     steps = args.steps if args.steps is not None else (50 if args.config == "light" else 2)
     warmup = args.warmup if args.warmup is not None else (5 if args.config == "light" else 1)
 
+    one_gpu = os.environ.get("FV_BENCH_ONE_GPU", "0") == "1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as one process (`python bench.py --gpus N`): become the N ranks -- exec the same launch line the
+        # driver uses for N > 1.  A node that cannot give every rank its own GPU is refused here, before anything starts.
+        visible = torch.cuda.device_count()
+        if not (args.launch_check or one_gpu) and visible < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible devices, this node shows {visible} "
+                     "(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?): refusing to run ranks on shared devices")
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os.execv(sys.executable, self_launch_argv(args.gpus, sys.argv[1:], free_port()))
+    if args.launch_check:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29599")
+        return launch_check(int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")))
     if _native.built_id() != _native.source_hash():
         sys.exit("libfastvocoder_hip.so was not built from this tree (python -c 'import __graft_entry__ as g; g.build()')")
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -581,7 +649,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     # FV_BENCH_ONE_GPU=1 (tests): every rank on device 0 -- world_size > 1 through the real generator on a 1-GPU box
-    one_gpu = os.environ.get("FV_BENCH_ONE_GPU", "0") == "1"
     err = world_error(args.gpus, world, local_rank, torch.cuda.device_count(), one_gpu)
     if err:
         sys.exit("bench.py: " + err)

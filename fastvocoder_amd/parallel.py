@@ -273,3 +273,99 @@ def synthesize_sharded(forward_fn, mels, world_size=None, rank=None, dst=0, grou
         a, b = shard_range(B, world_size, r)
         rows.append(bufs[r].view(wav.dtype)[: b - a])
     return torch.cat(rows, dim=0).to(wav.device)
+
+
+def synthesize_pipelined(forward_fn, mels, sub, world_size=None, rank=None, dst=0, group=None, device=None):
+    """A job in sub-batches with its traffic UNDER its compute: only ``dst`` holds ``mels [B, C, T]`` (others pass
+    None); every rank owns the contiguous block :func:`shard_range` gives it and walks it ``sub`` utterances at a
+    time.  While sub-batch i runs through ``forward_fn(block [rows, C, T]) -> [rows, n]``, the scatter of sub-batch
+    i + 1 and the gather of sub-batch i - 1 are in flight (asynchronous root scatter / gather on the communicator's
+    own stream: each peer over its own xGMI link to the root, nothing ring-shaped) -- the serial terms that are left
+    are the first scatter and the last gather.  Every rank issues the same sequence of collectives
+    (scatter 0, scatter 1, gather 0, scatter 2, gather 1, ...).  Filler rows exist on the wire only; the rows come
+    back in utterance order in ``forward_fn``'s dtype, bit-identical to one process running the same sub-batches
+    (:func:`synthesize_sharded` is the unpipelined form: one scatter, one forward_fn call, one gather).
+    Returns [B, n] on ``dst`` and None elsewhere."""
+    world_size = dist.get_world_size(group) if world_size is None else world_size
+    rank = dist.get_rank(group) if rank is None else rank
+    sub = max(int(sub), 1)
+    device = mels.device if mels is not None else device
+    staged = dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
+    wire_dev = torch.device("cpu") if staged else torch.device(device)
+    shape = torch.tensor(list(mels.shape) if rank == dst else [0, 0, 0], dtype=torch.int64, device=wire_dev)
+    dist.broadcast(shape, src=dst, group=group)
+    B, C, T = (int(v) for v in shape.tolist())
+    if B == 0:
+        return torch.zeros((0, 0), dtype=torch.float32, device=device) if rank == dst else None
+    per = (B + world_size - 1) // world_size
+    sub = min(sub, per)
+    chunks = (per + sub - 1) // sub
+    lo, hi = shard_range(B, world_size, rank)
+
+    def rows_of(r, c):
+        """[a, b) = the utterances of rank r's sub-batch c (empty past the end of its block)"""
+        a0, b0 = shard_range(B, world_size, r)
+        a = min(a0 + c * sub, b0)
+        return a, min(a + sub, b0)
+
+    def issue_scatter(c):
+        block = torch.empty((sub, C, T), dtype=torch.float32, device=wire_dev)
+        parts = None
+        if rank == dst:
+            parts = []
+            for r in range(world_size):
+                a, b = rows_of(r, c)
+                part = mels[a:b]
+                if b - a < sub:
+                    part = torch.cat([part, torch.zeros((sub - (b - a), C, T), dtype=mels.dtype, device=mels.device)], dim=0)
+                parts.append(part.contiguous().to(wire_dev))
+        work = dist.scatter(block, scatter_list=parts, src=dst, group=group, async_op=True)
+        return work, block, parts          # (the send buffers stay alive while the scatter is in flight)
+
+    meta = None                            # (samples per row, dtype) once a forward has run here
+    gathers = []                           # per sub-batch: (work, receive buffers, wire tensor)
+    nxt = issue_scatter(0)
+    for c in range(chunks):
+        cur, nxt = nxt, (issue_scatter(c + 1) if c + 1 < chunks else None)
+        cur[0].wait()
+        a, b = rows_of(rank, c)
+        block = cur[1].to(device) if staged else cur[1]
+        wav = forward_fn(block[: b - a].contiguous()).contiguous() if b > a else None
+        if meta is None:
+            # the row shape / dtype of the job: known to every rank that ran something; with B < world some rank ran
+            # nothing and learns it from the others (MAX over ranks -- the only case with a collective besides
+            # scatter / gather, and one word)
+            if B < world_size:
+                code = _dtype_code(wav.dtype) if wav is not None else -1
+                info = torch.tensor([wav.shape[1] if wav is not None else 0, max(code, -1) + 1, 1 if code == -2 else 0],
+                                    dtype=torch.int64, device=wire_dev)
+                dist.all_reduce(info, op=dist.ReduceOp.MAX, group=group)
+                if int(info[2]):
+                    raise ValueError("synthesize_pipelined: forward_fn returned a dtype the gather cannot carry")
+                meta = (int(info[0]), _DTYPES[int(info[1]) - 1])
+            else:
+                if _dtype_code(wav.dtype) == -2:
+                    raise ValueError(f"synthesize_pipelined: forward_fn returned {wav.dtype}, which the gather cannot carry")
+                meta = (int(wav.shape[1]), wav.dtype)
+        n, dtype = meta
+        if wav is None:
+            wav = torch.zeros((sub, n), dtype=dtype, device=device)
+        elif wav.shape[0] < sub:
+            wav = torch.cat([wav, torch.zeros((sub - wav.shape[0], n), dtype=dtype, device=wav.device)], dim=0)
+        wire = wav if dtype in (torch.float32, torch.float64, torch.float16) else wav.view(torch.uint8)
+        if staged:
+            wire = wire.cpu()
+        bufs = [torch.empty_like(wire) for _ in range(world_size)] if rank == dst else None
+        gathers.append((dist.gather(wire, gather_list=bufs, dst=dst, group=group, async_op=True), bufs, wire))
+    for work, _, _ in gathers:
+        work.wait()
+    if rank != dst:
+        return None
+    n, dtype = meta
+    out = torch.empty((B, n), dtype=dtype, device=device)
+    for c, (_, bufs, _) in enumerate(gathers):
+        for r in range(world_size):
+            a, b = rows_of(r, c)
+            if b > a:
+                out[a:b].copy_(bufs[r].view(dtype)[: b - a])
+    return out

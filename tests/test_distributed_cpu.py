@@ -202,6 +202,81 @@ def _worker_edges(rank, world, port):
         dist.destroy_process_group()
 
 
+def _worker_pipelined(rank, world, port):
+    """parallel.synthesize_pipelined (bench.py's job at N > 1): sub-batched, scatter of the next sub-batch and gather
+    of the last one in flight under the current forward -- the rows must come back exactly as one process makes them,
+    whatever the block / sub-batch split, and no rank may run a filler row."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(31)
+        mels = torch.rand(6 * world + 5, 8, 6, generator=g)
+
+        def sink(block):
+            return (_fake_generator(block) * 50).to(torch.int16)
+        cpu = torch.device("cpu")
+        for B, sub in ((6 * world + 5, 2), (6 * world + 5, 4), (6 * world + 5, 100), (4 * world, 2), (world + 1, 1),
+                       (world, 3), (world - 1, 2), (1, 2)):
+            calls = []
+
+            def fn(block):
+                calls.append(int(block.shape[0]))
+                return sink(block)
+            out = parallel.synthesize_pipelined(fn, mels[:B] if rank == 0 else None, sub, device=cpu)
+            lo, hi = parallel.shard_range(B, world, rank)
+            per = -(-B // world)
+            eff = min(sub, per)
+            want_calls = [min(eff, hi - a) for a in range(lo, hi, eff)]
+            assert calls == want_calls, (rank, B, sub, calls, want_calls)          # its own rows, in sub-batches, no filler
+            if rank == 0:
+                assert out.dtype == torch.int16 and torch.equal(out, sink(mels[:B])), (B, sub)
+            else:
+                assert out is None
+        # fp32 rows travel as fp32; a root that is not rank 0
+        out = parallel.synthesize_pipelined(_fake_generator, mels if rank == world - 1 else None, 3, dst=world - 1, device=cpu)
+        assert (torch.equal(out, _fake_generator(mels)) if rank == world - 1 else out is None)
+        # an empty job
+        out = parallel.synthesize_pipelined(_fake_generator, mels[:0] if rank == 0 else None, 3, device=cpu)
+        assert (out.shape[0] == 0) if rank == 0 else out is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_pipelined_job_gloo(world):
+    mp.spawn(_worker_pipelined, args=(world, _free_port()), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("gpus", [2, 8])
+def test_bench_started_as_one_process_launches_its_own_ranks(gpus):
+    """`python bench.py --gpus N` with no launcher around it (how the driver starts the N = 1 bench): it must become N
+    ranks by itself.  `--launch-check` keeps the run on the host cores (gloo, stand-in forward) so that the launch, the
+    rendezvous on 127.0.0.1 and the job's scatter / forward / gather pipeline are exercised where there is no GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--launch-check"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["launch_check"] and out["n_gpus"] == gpus and out["job_bit_identical_to_one_process"]
+
+
+def test_bench_self_launch_command_is_the_drivers():
+    import bench
+    argv = bench.self_launch_argv(8, ["--gpus", "8", "--steps", "3"], 29512)
+    assert argv[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert argv[argv.index("--nproc-per-node") + 1] == "8" and argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    assert argv[argv.index("--master-port") + 1] == "29512" and argv[-4:] == ["--gpus", "8", "--steps", "3"]
+    assert os.path.basename(argv[-5]) == "bench.py"
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharding_edge_cases_gloo(world):
     mp.spawn(_worker_edges, args=(world, _free_port()), nprocs=world, join=True)

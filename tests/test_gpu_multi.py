@@ -68,6 +68,28 @@ def _torchrun2(*args, **env):
     return json.loads(lines[0])
 
 
+def test_bench_gpus_2_started_directly_launches_its_ranks():
+    """`python bench.py --gpus 2` started as ONE process, the way the driver starts the bench: it re-executes itself
+    under torch.distributed.run (two ranks, here both on cuda:0 over gloo) and prints ONE line with both curves -- the
+    weak-scaling headline, golden-checked, and the appended strong-scaling job through parallel.synthesize_pipelined
+    (rows bit-identical to solo runs, asserted inside bench.py)."""
+    e = dict(os.environ, FV_BENCH_ONE_GPU="1", FV_BENCH_BACKEND="gloo", FV_BENCH_JOB="10")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FV_BENCH_FORCE_DIST", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(cases.ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-exact", "--sub", "2"], env=e, cwd=cases.ROOT, capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 2
+    assert out["parity"]["max_abs_vs_reference_golden"] <= 1e-4 and out["without_gather"]["ms_per_step"] > 0
+    job = out["strong_scaling_job"]
+    assert job["scaling"] == "strong" and job["n_gpus"] == 2 and "10 utterances" in job["workload"]
+    assert "synthesize_pipelined" in job["workload"] and job["without_gather"]["ms_per_step"] > 0
+
+
 def test_two_ranks_share_the_gpu_strong_scaling_job():
     """BASELINE configs[4] with world_size 2 and the real generator: root scatter of 8 mels, two HIP forwards (one
     per rank, sub-batches of 2), int16 sink, root gather -- rows bit-identical to the root's own solo runs (asserted
