@@ -263,18 +263,6 @@ def timed_steps(step, steps, warmup, dist, dev, after=None):
     return elapsed, out
 
 
-def survey_bytes_c16_stage(model, B, T_stage):
-    """SURVEY.md section 8(d) bytes of the 16-channel stage: every conv's input and output tensor once, the
-    residual read of each second conv, the weights -- the layer-by-layer (unfused) accounting."""
-    total = 0.0
-    for rb in model.resblocks[-model.num_kernels:]:
-        for c1, c2 in zip(rb.convs1, rb.convs2):
-            act = 4.0 * B * c1.in_channels * T_stage
-            total += 2 * act + 4.0 * c1.weight.numel()            # conv1: in + out
-            total += 3 * act + 4.0 * c2.weight.numel()            # conv2: in + out + residual
-    return total
-
-
 def roofline_report(model, mel, ms_per_step, reps=5):
     """Per-launch timing of the kernel families with HIP events on the launch stream (single-stream replay of the
     same forward): one event after every launch, a launch's duration = end of its predecessor to its own end (what
@@ -424,7 +412,6 @@ def roofline_report(model, mel, ms_per_step, reps=5):
     t_stage = T_FRAMES
     for up in model.ups:
         t_stage *= up.stride[0]
-    survey = survey_bytes_c16_stage(model, B, t_stage) if model.resblocks[-1].channels == 16 else 0.0
     st_ms = stage["ms"] / reps
     hbm = {
         "kernel": "the C = 16 stage of the generator (18 dilated / plain 16-channel convs on 240 000 samples): "
@@ -440,12 +427,6 @@ def roofline_report(model, mel, ms_per_step, reps=5):
         "bytes": stage["bytes"] / reps,
         "bytes_rule": "SURVEY.md section 8(d): a fused kernel is charged only its EXTERNAL tensors -- per fused-pair "
                       "launch each member's input, output (+ twin), the MRF addends and the weights, once",
-        "effective": {"what": "the same time against the layer-by-layer (unfused) bytes of SURVEY 8(d): every conv's "
-                              "input and output once + the residual read + weights -- what an unfused implementation "
-                              "at this speed would have to move",
-                      "bytes": survey,
-                      "gbs": survey / (st_ms * 1e-3) / 1e9 if st_ms > 0 else 0.0,
-                      "frac": survey / (st_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if st_ms > 0 else 0.0},
         "ms": st_ms, "launches_per_step": stage["launches"] // reps,
         "tflops": stage["flops"] / (stage["ms"] * 1e-3) / 1e12 if stage["ms"] > 0 else 0.0,
         "measured": "per-launch HIP events, completion to completion (event cost subtracted); HBM traffic by PMC: profiles/",
@@ -463,7 +444,7 @@ def roofline_report(model, mel, ms_per_step, reps=5):
             "floor_us_at_the_hbm_peak": 1e6 * stage["bytes"] / reps / (PEAK_HBM_GBS * 1e9),
             "what": "the one-launch stage against its own two floors: 3 x algorithmic FLOP at the dense f16 MFMA peak, and its "
                     "external bytes (input once, one float per sample out, weights) at 8 TB/s -- `frac` above is those bytes "
-                    "over the launch's time, a number that fusion makes SMALL; `effective` is the comparable one"}
+                    "over the launch's time, a number that fusion makes SMALL: the launch is bound by the matrix cores"}
     return roofline, hbm
 
 
@@ -788,6 +769,7 @@ def main():
             stepg, doneg = make_step(model, False)
             eg, _ = timed_steps(stepg, min(steps, 20), 2, None, dev, after=doneg)
             model.range_guard = BENCH_RANGE_GUARD
+            out["ms_per_step_default_policy"] = 1e3 * eg / min(steps, 20)   # range_guard = "auto": what a drop-in caller gets
             out["range_guard"] = {"policy": "timed steps: range_guard = 'lazy' (explicit opt-in: stream-ordered forwards, "
                                             "model.check_range() after the steps -- asserted clean); the module default "
                                             "'auto' checks every call before it returns: ms_per_step_sync_checked",
@@ -827,6 +809,21 @@ def main():
                                               "warmup": 1, "scaling": "strong", "n_gpus": world,
                                               "rtf_22k05": ej / (tot / 22050.0), "workload": wl}, **xj)
     if rank == 0:
+        # the figures a reader wants first, LAST in the line (a log tail keeps the end of it)
+        oc = out.get("other_configs", {})
+        out["summary"] = {
+            "ms_per_step": out["ms_per_step"], "ms_per_step_default_policy": out.get("ms_per_step_default_policy"),
+            "host_enqueue_ms_per_forward": out.get("host_enqueue_ms_per_forward"),
+            "host_to_host_ms": out.get("host_to_host", {}).get("ms_per_utterance"),
+            "roofline_frac": out.get("roofline", {}).get("frac"),
+            "stage16_frac_of_matrix_peak": out.get("roofline_hbm_stage", {}).get("bound_now", {}).get("frac"),
+            "config1_ms": oc.get("config1_melgan_T200_B1", {}).get("ms_per_step"),
+            "config3_ms": oc.get("config3_mb_hifigan_light_pqmf_B32", {}).get("ms_per_step"),
+            "config4_ms": oc.get("config4_basis_melgan_light_B64", {}).get("ms_per_step"),
+            "job512_ms": out.get("strong_scaling_job", {}).get("ms_per_step"),
+            "parity_max_abs": out.get("parity", {}).get("max_abs_vs_reference_golden"),
+            "cpu_baseline_samples_per_s": out.get("cpu_baseline", {}).get("value"),
+        }
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -31,12 +31,13 @@ PAD_CAUSAL = 2      # flag: pad (k-1)*dil on both sides, keep the first Tin outp
 POST_NONE, POST_TANH, POST_RELU = 0, 1, 2
 SLOT_NONE, SLOT_IN, SLOT_OUT, SLOT_TMP0, MAX_SLOTS = -1, 0, 1, 2, 32
 SLOT_AUX_IN0, SLOT_AUX_IN1, SLOT_OUT2 = 28, 29, 30    # caller-provided tensors of Plan.run(aux=..., out2=...)
-ABI_VERSION = 12
+ABI_VERSION = 13
 PAIR_F32, PAIR_SPLIT_F16 = 0, 1   # arithmetic of the fused ResBlock-pair kernels (fastvocoder_hip.h)
 
 
 ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE = -1, -2, -3
 ERR_RANGE = -4                    # fv_plan_check_range: a split-f16 kernel met an operand beyond the f16 range
+GUARD_HIGH, GUARD_LOW = 0x001, 0x100   # the two sides of a guard word (separate bytes: fastvocoder_hip.h)
 ERR_RANGE_LOW = -5                # ... only the low-side guard fired (a block's share of a tensor was small as a whole)
 
 
@@ -858,7 +859,7 @@ class Plan:
         self.in_channels = in_channels
         self._keep = []        # packed weights / biases the native plan references
         self._ws = None
-        self._ws_key = None
+        self._calls = {}       # (B, T, device) -> (output channels, output length, workspace bytes)
         self._guard = None     # GuardWord of the owning module (set_guard)
         self._dev = None       # device of the last run
         self.guarded = False   # the plan holds split-f16 launches (PlanBuilder.finalize)
@@ -1095,17 +1096,41 @@ class Plan:
         B, _, T = x.shape
         if B == 0 or T == 0:
             raise NativeError(f"plan input is empty: {tuple(x.shape)}")
-        c, n = self.output_shape(T)
-        if out is None:
-            out = torch.empty((B, c, n), dtype=torch.float32, device=x.device)
-        key = (B, T, x.device)
-        self._dev = x.device
-        if self._ws_key != key:
+        dev = x.device
+        key = (B, T, dev)
+        ent = self._calls.get(key)
+        if ent is None:
+            # once per (batch, frames, device): output shape and workspace size (two native queries), and that the plan's
+            # packed weights live where the input does
+            _on(x, *self._keep[:1])
+            c, n = self.output_shape(T)
             nbytes = lib().fv_plan_workspace_bytes(self._h, B, T)
             if nbytes < 0:
                 check(int(nbytes))
-            self._ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=x.device)
-            self._ws_key = key
+            if len(self._calls) >= 256:
+                self._calls.clear()
+            ent = self._calls[key] = (c, n, max(int(nbytes), 256))
+        c, n, nbytes = ent
+        if out is None:
+            out = torch.empty((B, c, n), dtype=torch.float32, device=dev)
+        self._dev = dev
+        if self._ws is None or self._ws.device != dev or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)      # (grows, never shrinks: one arena per plan)
+        if not aux and not out2:
+            # the common call (no auxiliary inputs, one output): one pointer check per operand, no marshalling of empties
+            if not (x.is_cuda and x.dtype is torch.float32 and x.is_contiguous()):
+                _ptr(x, "input")
+            if not (out.is_cuda and out.dtype is torch.float32 and out.is_contiguous() and out.device == dev):
+                _ptr(out, "out")
+                raise NativeError(f"out lives on {out.device}, the input on {dev}")
+            if torch.cuda.current_device() == dev.index:
+                check(lib().fv_plan_run_aux(self._h, B, T, x.data_ptr(), out.data_ptr(), None, None, None,
+                                            self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream(dev).cuda_stream))
+            else:
+                with torch.cuda.device(dev):
+                    check(lib().fv_plan_run_aux(self._h, B, T, x.data_ptr(), out.data_ptr(), None, None, None,
+                                                self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream(dev).cuda_stream))
+            return out
         second = None
         if out2:
             c2, n2 = self.slot_shape(T, SLOT_OUT2)

@@ -351,14 +351,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     pair_wait_vm0();
     if (p.guard) {
         const float bad = bad2.x + bad2.y;
-        if (bad != bad) *p.guard = 1;
+        if (bad != bad) guard_raise_high(p.guard);
         unsigned* const su = reinterpret_cast<unsigned*>(bl + 4 * G::C);
         if (lane == 0) su[wave] = low.bits;
         pair_barrier();
         if (tid == 0) {
             unsigned all = 0;
             for (int w = 0; w < 8; ++w) all |= su[w];
-            if (((all & 2u) && !(all & 1u)) || ((all & 8u) && !(all & 4u))) *p.guard = 4;
+            if (((all & 2u) && !(all & 1u)) || ((all & 8u) && !(all & 4u))) guard_raise_low(p.guard);
         }
     }
 }

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     pair_barrier();                                      // the image is complete
     if (p.guard && tid == 0) {
         const unsigned all = lowbits[0] | lowbits[1] | lowbits[2] | lowbits[3];
-        if ((all & 2u) && !(all & 1u)) *p.guard = 4;     // operands not all zero and all below kSplitLow (pairh_kernels.hpp)
+        if ((all & 2u) && !(all & 1u)) guard_raise_low(p.guard);     // operands not all zero and all below kSplitLow (pairh_kernels.hpp)
     }
     // ---- 64 columns per wave: four fragments x two row sixteenths x two K steps x three split terms ----
     const int n = lane & 15, kb = lane >> 4;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     if (p.guard) {
         const float bad = bad2.x + bad2.y;
-        if (bad != bad) *p.guard = 1;
+        if (bad != bad) guard_raise_high(p.guard);
     }
 }
 

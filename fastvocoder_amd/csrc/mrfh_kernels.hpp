@@ -607,7 +607,7 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3
         ++tile_no;
         par ^= 1;
     }
-    if (p.guard && bad != bad) *p.guard = 1;
+    if (p.guard && bad != bad) guard_raise_high(p.guard);
     {
         PairCore pc;
         pc.guard = p.guard;

@@ -21,6 +21,10 @@ int launch_mrfh(MrfParams p, int C, const int* dil, hipStream_t s) {
     const bool fold = p.fold_w != nullptr;
     if (!p.x || !p.blob || (!fold && !p.y) || (fold && (!p.fold_y || p.y || p.y_act)))
         return fail(FV_ERR_INVALID_ARG, "mrf stage: null tensor (or both an output tensor and a folded output conv)");
+    // every block reads x columns (a run's first tile starts `halo` early, plus the right-hand recompute margin) that its
+    // neighbours write as y: an output that is the input would be read half-updated (the pair entries refuse it too)
+    if (p.y == p.x || p.y_act == p.x || (p.y_act && p.y_act == p.y) || p.fold_y == p.x)
+        return fail(FV_ERR_INVALID_ARG, "mrf stage: an output tensor aliases the input (or y_act aliases y)");
     if ((reinterpret_cast<uintptr_t>(p.blob) & 15) != 0) return fail(FV_ERR_UNSUPPORTED, "mrf stage: the packed stage must be 16-byte aligned");
     if ((double)C * p.T * 4.0 >= 1073741824.0)
         return fail(FV_ERR_UNSUPPORTED, "mrf stage: one utterance's tensor (%d x %d floats) exceeds the 1 GiB buffer-descriptor "

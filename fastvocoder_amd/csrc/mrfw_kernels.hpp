@@ -600,7 +600,7 @@ __global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu((NG + 3
         if (!more) break;
         ++tile_no;
     }
-    if (p.guard && bad != bad) *p.guard = 1;
+    if (p.guard && bad != bad) guard_raise_high(p.guard);
     {
         PairCore pc;
         pc.guard = p.guard;

@@ -104,8 +104,13 @@ __device__ __forceinline__ void range_note4(float& bad, float v0, float v1, floa
     t = fmaf(v3, 0.f, t);
     bad = stored ? t : bad;
 }
+// The guard word's two sides are separate BYTES (FV_GUARD_HIGH = byte 0, FV_GUARD_LOW = byte 1): any block of any launch may
+// raise either with a plain store, and a store to one byte cannot take back what another block wrote to the other -- with
+// one 32-bit value per side the last writer won, and "overflow, then a quiet block" read as "low" (ADVICE r5).
+__device__ __forceinline__ void guard_raise_high(int* g) { reinterpret_cast<volatile unsigned char*>(g)[0] = 1; }
+__device__ __forceinline__ void guard_raise_low(int* g) { reinterpret_cast<volatile unsigned char*>(g)[1] = 1; }
 __device__ __forceinline__ void range_flag(const PairCore& p, float bad) {
-    if (p.guard && bad != bad) *p.guard = 1;
+    if (p.guard && bad != bad) guard_raise_high(p.guard);
 }
 
 // The LOW side of the domain.  h1 = f16(v) is a normal f16 number -- and the pair keeps 22 bits of v -- only for
@@ -115,7 +120,7 @@ __device__ __forceinline__ void range_flag(const PairCore& p, float bad) {
 // at pack time (a power-of-two prescale per row: api.hip row_scale_kernel); for activations every split kernel watches
 // the magnitudes of the operands it actually splits (the window conversion, the intermediate of a fused pair: ~0.6 VALU
 // instructions per element, v_max3_f32 with |.| modifiers and two compares per group), and a block one of whose operand
-// tensors was not all zero and all below kSplitLow raises the guard word (value 4): the host repeats the call on the
+// tensors was not all zero and all below kSplitLow raises the guard word (FV_GUARD_LOW): the host repeats the call on the
 // exact-fp32 kernels, as it does for the high side.  The test is per BLOCK (every channel of hundreds of samples), never per element: silence inside an
 // ordinary signal stays on the split kernels, and a false alarm costs time, not accuracy.
 constexpr float kSplitLow = 0x1p-10f;
@@ -153,7 +158,7 @@ __device__ __forceinline__ void low_flag(const PairCore& p, const LowGuard& g, f
     if (wave == 0 && lane == 0) {
         unsigned all = 0;
         for (int w = 0; w < nwaves; ++w) all |= su[w];
-        if (((all & 2u) && !(all & 1u)) || ((all & 8u) && !(all & 4u))) *p.guard = 4;
+        if (((all & 2u) && !(all & 1u)) || ((all & 8u) && !(all & 4u))) guard_raise_low(p.guard);
     }
     pair_barrier();                                      // scratch may be written again (the block's next member)
 }

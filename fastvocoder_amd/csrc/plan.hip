@@ -999,7 +999,7 @@ int fv_plan_check_range(fv_plan_t* plan, void* stream) {
     const int seen = *w;
     if (seen == 0) return 0;
     *w = 0;
-    if (seen == 4)
+    if ((seen & ~FV_GUARD_LOW) == 0)   // only the low side's byte: whatever order the blocks stored in (the sides are separate bytes)
         return fail(FV_ERR_RANGE_LOW, "a split-f16 kernel met operands that were smaller than 2^-10 throughout a block's share of a "
                                       "tensor (not all zero): the last run may carry fewer than 22 bits; repeat it on an fp32-precision plan");
     return fail(FV_ERR_RANGE, "a split-f16 kernel met an operand outside its domain (|v| >= 65520 or a non-finite value; "

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FV_ABI_VERSION 12
+#define FV_ABI_VERSION 13
 
 #define FV_ERR_INVALID_ARG (-1)
 #define FV_ERR_UNSUPPORTED (-2)
@@ -42,6 +42,10 @@ extern "C" {
  * tensor): the run's results may carry fewer than 22 bits; repeating THIS run with FV_PAIR_F32 is enough -- the condition is
  * a property of the input, not of the model */
 #define FV_ERR_RANGE_LOW (-5)
+/* the two sides of a `guard` word: separate BYTES of the int32, so that plain stores from different blocks and launches
+ * combine (a store to one byte never takes back the other) */
+#define FV_GUARD_HIGH 0x001
+#define FV_GUARD_LOW 0x100
 
 /* padding of a conv's input: zero "same" padding (torch.nn.Conv1d padding=,
  * model/generator/modules.py:193-221) or reflection padding + valid conv
@@ -171,12 +175,12 @@ int fv_resblock1_fused(int n, const float* const* x, const float* const* w1, con
  *           row's maximum) and store the inverse behind the image; the kernels multiply the accumulated sum by it inside
  *           the fused multiply-add that adds the bias (exact).  `range_flag` is raised for a non-finite weight.
  *         activations, high side: |v| < 65520.  An operand beyond the f16 range turns into inf in f16 and every output
- *           it feeds into inf / NaN: every split-f16 kernel raises its `guard` word (value 1) when a final value is not
+ *           it feeds into inf / NaN: every split-f16 kernel raises its `guard` word (FV_GUARD_HIGH: byte 0) when a final value is not
  *           finite.
  *         activations, low side: below 2^-14 the pair keeps an absolute 2^-36 instead of 22 bits -- harmless inside an
  *           ordinary tensor, a loss for one that is small as a whole (with correspondingly large weights behind it).
  *           Every kernel keeps the largest magnitude of the operands it splits; a block whose operands were not all zero
- *           and all below 2^-10 raises `guard` (value 4).
+ *           and all below 2^-10 raises `guard` (FV_GUARD_LOW: byte 1; the two sides never overwrite each other).
  *         In both cases the caller repeats the layer / the run with FV_PAIR_F32 (fv_plan_check_range).
  *       range_flag / guard: int32 words any kernel can write (device memory or pinned host memory), NULL = no check.
  *       Weights: fv_pack_pair_weight_ex(prec) images ([K step][row half][split half][lane][8 f16], then one float per
@@ -603,10 +607,10 @@ int fv_plan_num_ops(fv_plan_t* plan);
 /*
  * Range guard of a plan's split-f16 launches (FV_PAIR_SPLIT_F16 above: operands must lie inside the f16 range).
  * fv_plan_set_guard: `word` is an int32 in PINNED, DEVICE-MAPPED host memory (hipHostMalloc / torch pin_memory), owned by
- *   the caller and zero-initialised; every split-f16 kernel the plan launches sets it to 1 when one of its final values
- *   is not finite.  NULL removes the guard.
+ *   the caller and zero-initialised; every split-f16 kernel the plan launches raises FV_GUARD_HIGH in it when one of its final
+ *   values is not finite, FV_GUARD_LOW for the low side.  NULL removes the guard.
  * fv_plan_check_range: waits for `stream` (the stream of the plan's last run) to drain, then returns 0 when the word is
- *   clear; otherwise clears it and returns FV_ERR_RANGE (FV_ERR_RANGE_LOW when only the low-side guard fired): the outputs of the run(s) since the last check are not valid
+ *   clear; otherwise clears it and returns FV_ERR_RANGE (FV_ERR_RANGE_LOW when ONLY the low-side byte is set -- whatever the order the blocks wrote in): the outputs of the run(s) since the last check are not valid
  *   (inf / NaN where the fp32 reference is finite) and must be recomputed on a plan built with FV_PAIR_F32 arithmetic --
  *   fastvocoder_amd/generator/engine.py does that automatically (NativeModule.range_guard).
  */

@@ -39,10 +39,10 @@ def test_bench_light_through_the_distributed_path():
     r = out["roofline"]
     assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and r["kernel_ms_per_step"] <= out["ms_per_step"] * 1.05
     h = out["roofline_hbm_stage"]
-    assert h["effective"]["bytes"] > 6.0e8               # 18 convs x (2 or 3) x 15.36 MB, SURVEY 8(d), layer by layer
-    assert 1.5e7 < h["bytes"] < h["effective"]["bytes"] and h["frac"] < h["effective"]["frac"]   # external tensors only
+    assert 1.5e7 < h["bytes"] < 2.0e7 and "effective" not in h                                   # external tensors only
     assert h["launches_per_step"] == 1 and 0 < h["bound_now"]["frac"] < 1                       # the stage is ONE launch
     assert out["range_guard"]["timed_steps_clean"] is True
+    assert out["summary"]["ms_per_step"] == out["ms_per_step"] and out["summary"]["ms_per_step_default_policy"] > 0
 
 
 def test_bench_large512_job_shape_on_one_rank():

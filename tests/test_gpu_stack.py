@@ -172,7 +172,7 @@ def test_residual_stack_guards():
     guard.zero_()
     small = list(_stack(rng, 1, 64, 500, xs=1e-5))     # a tensor that is small as a whole: the low side (value 4)
     _run(*small, 1, 0.2, _native.PAD_REFLECT, guard=guard)
-    assert int(guard.item()) == 4
+    assert int(guard.item()) == _native.GUARD_LOW
     guard.zero_()
     quiet = list(_stack(rng, 1, 64, 500))              # silence inside an ordinary signal is not "small"
     quiet[0][:, :, 100:300] = 0.0

@@ -191,7 +191,7 @@ def test_mrf_stage_guards():
     guard.zero_()
     nob = _stage_weights(rng, ks, bias=False)
     y = _native.mrf_stage_split_f16(_t(x * np.float32(2.0 ** -14)), _pack(nob, ks), ks, guard=guard)
-    assert int(guard.item()) == 4
+    assert int(guard.item()) == _native.GUARD_LOW
     guard.zero_()
     y = _native.mrf_stage_split_f16(_t(np.zeros_like(x)), _pack(nob, ks), ks, guard=guard)
     assert int(guard.item()) == 0 and float(y.abs().max()) == 0.0
@@ -311,7 +311,7 @@ def test_mrf_stage32_guards_and_refusals():
     guard.zero_()
     nob = _stage_weights(rng, ks, bias=False, C=32)
     _native.mrf_stage_split_f16(_t(x * np.float32(2.0 ** -14)), _pack(nob, ks), ks, guard=guard)
-    assert int(guard.item()) == 4
+    assert int(guard.item()) == _native.GUARD_LOW
     guard.zero_()
     y = _native.mrf_stage_split_f16(_t(np.zeros_like(x)), _pack(nob, ks), ks, guard=guard)
     assert int(guard.item()) == 0 and float(y.abs().max()) == 0.0

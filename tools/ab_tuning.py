@@ -14,7 +14,8 @@ import bench  # noqa: E402
 from fastvocoder_amd import _native  # noqa: E402
 
 DEFAULTS = {"sched": 1, "sched_switch": 4, "convh_skel": -1, "convp_skel": 5, "convq_skel": -1, "pair128_unfused": 0,
-            "convh_blocks": 0, "pair_blocks": 0, "chain": 0, "pair_dbg": 0, "shape32": -1, "shape64": -1, "units": 500}
+            "convh_blocks": 0, "pair_blocks": 0, "pair_dbg": 0, "shape32": -1, "shape64": -1, "units": 500,
+            "mrf_blocks": 0, "mrf_shape": 0, "convt_lean": 50, "convs_ringfree": -1, "convu_resident": 1}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1)
