@@ -20,11 +20,11 @@ SOURCES = ["conv_mfma.hip", "api.hip", "plan.hip", "pack.hip", "pqmf.hip", "wav_
            "pair_launch.hip", "pair_inst_c16.hip", "pair_inst_c32.hip", "pairh_inst_c16.hip", "pairh_inst_c32.hip",
            "convh_launch.hip", "convh_inst_c64.hip", "convh_inst_c128.hip", "convt_inst.hip",
            "convg_inst.hip", "convr_inst.hip", "convtn_inst.hip", "convk_inst.hip", "convq2_inst.hip",
-           "mrfh_launch.hip", "mrfh_inst_a.hip", "mrfh_inst_b.hip", "mrfw_inst.hip", "convtl_inst.hip", "convs2_inst.hip", "convu2_inst.hip"] + \
+           "convq3_inst.hip", "mrfh_launch.hip", "mrfh_inst_a.hip", "mrfh_inst_b.hip", "mrfw_inst.hip", "convtl_inst.hip", "convs2_inst.hip", "convu2_inst.hip"] + \
           [f"conv_inst_s{i}.hip" for i in range(6)]
 HEADERS = ["fv_internal.h", "conv_kernels.hpp", "pair_kernels.hpp", "pair_inst.hpp", "pairh_kernels.hpp",
            "pairh_inst.hpp", "convh_kernels.hpp", "convh_inst.hpp", "convr_kernels.hpp",
-           "convtn_kernels.hpp", "convk_kernels.hpp", "convq2_kernels.hpp", "mrfh_kernels.hpp", "mrfh_inst.hpp", "mrfw_kernels.hpp", "convtl_kernels.hpp", "convs2_kernels.hpp", "convu2_kernels.hpp", "api_internal.h"]
+           "convtn_kernels.hpp", "convk_kernels.hpp", "convq2_kernels.hpp", "convq3_kernels.hpp", "mrfh_kernels.hpp", "mrfh_inst.hpp", "mrfw_kernels.hpp", "convtl_kernels.hpp", "convs2_kernels.hpp", "convu2_kernels.hpp", "api_internal.h"]
 
 PAD_ZERO, PAD_REFLECT = 0, 1
 PAD_CAUSAL = 2      # flag: pad (k-1)*dil on both sides, keep the first Tin outputs (CausalConv1d)

@@ -313,7 +313,7 @@ static const TuningEntry kTuningTable[] = {
     {"sched_switch", &Tuning::sched_switch}, {"convh_skel", &Tuning::convh_skel}, {"convp_skel", &Tuning::convp_skel},
     {"convq_skel", &Tuning::convq_skel},   {"pair128_unfused", &Tuning::pair128_unfused},
     {"convg_rows64", &Tuning::convg_rows64}, {"stack_items", &Tuning::stack_items}, {"stack_wide", &Tuning::stack_wide},
-    {"convp_wide", &Tuning::convp_wide},   {"convq_wide", &Tuning::convq_wide},
+    {"convp_wide", &Tuning::convp_wide},   {"convq_wide", &Tuning::convq_wide},  {"convp_pp", &Tuning::convp_pp},
     {"convh_rows64", &Tuning::convh_rows64},  {"convt_rows64", &Tuning::convt_rows64},
     {"pairh_skel", &Tuning::pairh_skel},   {"pair_skel", &Tuning::pair_skel},    {"convh_blocks", &Tuning::convh_blocks},
     {"pair_blocks", &Tuning::pair_blocks}, {"sum3_min", &Tuning::sum3_min},      {"lds_budget", &Tuning::lds_budget},

@@ -419,12 +419,18 @@ extern template int launch_convq2_dil<3, kPair64Wide>(const PairParams&, size_t,
 extern template int launch_convq2_dil<5, kPair64Wide>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convq2_dil<1, kPair128Wide>(const PairParams&, size_t, hipStream_t);
 extern template int launch_convq2_dil<3, kPair128Wide>(const PairParams&, size_t, hipStream_t);
+template <int DIL>
+int launch_convq3_dil(const PairParams& p, hipStream_t s);                  // convq3_inst.hip: two wave groups one conv phase apart
+extern template int launch_convq3_dil<1>(const PairParams&, hipStream_t);
+extern template int launch_convq3_dil<3>(const PairParams&, hipStream_t);
+extern template int launch_convq3_dil<5>(const PairParams&, hipStream_t);
 
 // everything launch_convp does in front of the launch: validation, member order, tile counts, LDS layout, block schedule
-// (form: 1 convq2_kernel<DIL, 64> -- 128-column tiles; 2 convq2_kernel<DIL, 65> -- 256-column tiles)
+// (form: 1 convq2_kernel<DIL, 64> -- 128-column tiles; 2 convq2_kernel<DIL, 65> -- 256-column tiles; 3 convq3_kernel<DIL> -- two
+// wave groups per block, each on 64-column tiles of its own share: 2 nblk shares, LDS laid out by the kernel)
 static int prepare_convp(PairParams& p, int dil, size_t& lds_out, double& flops, double& bytes, int form) {
     const int C = 64;
-    const int NMc = form == 2 ? 256 : 128;           // intermediate columns per tile
+    const int NMc = form == 2 ? 256 : form == 3 ? 64 : 128;           // intermediate columns per tile
     if (dil != 1 && dil != 3 && dil != 5) return fail(FV_ERR_UNSUPPORTED, "resblock pair: dilation %d (1, 3 or 5)", dil);
     if (p.n_members < 1 || p.n_members > 3) return fail(FV_ERR_INVALID_ARG, "resblock pair: %d members", p.n_members);
     if ((double)C * p.T * 4.0 >= 1073741824.0)
@@ -468,6 +474,22 @@ static int prepare_convp(PairParams& p, int dil, size_t& lds_out, double& flops,
     const size_t lds = floats * 4;
     if (lds > 160 * 1024) return fail(FV_ERR_UNSUPPORTED, "resblock pair: %zu bytes of LDS", lds);
     long long nblk = tuning().convh_blocks > 0 ? tuning().convh_blocks : device_cu_count();
+    if (form == 3) {
+        // one share per wave group: 2 nblk contiguous, cost-balanced shares of the concatenated items
+        if (nblk > kSchedBlocks) nblk = kSchedBlocks;
+        if (2 * nblk > items) nblk = (items + 1) / 2;
+        p.nblk = (int)nblk;
+        p.sched_on = 0;
+        warm_run_costs(p, items, NMc);
+        long long n[3] = {0, 0, 0};
+        for (int i = 0; i < p.n_members; ++i) n[i] = p.m[i].n_items;
+        pair_cut_schedule(p, 2 * p.nblk, n);
+        if (p.sched_on != 2) return fail(FV_ERR_UNSUPPORTED, "resblock pair: %lld items do not fit the share table", items);
+        p.dbg = tuning().pair_dbg;
+        p.trace = reinterpret_cast<unsigned long long*>(tuning().trace_ptr);
+        lds_out = 0;
+        return 0;
+    }
     if (nblk > items) nblk = items;
     p.nblk = (int)nblk;
     pair_schedule(p, p.nblk);
@@ -491,10 +513,11 @@ int launch_convp(PairParams p, int dil, hipStream_t s) {
     // (32 x 64 wave tiles) from Tuning::convp_wide tenths of such a tile per CU up
     long long wide_items = 0;
     for (int i = 0; i < p.n_members; ++i) wide_items += (long long)p.B * ((p.T + 256 - p.m[i].k) / (257 - p.m[i].k));
-    const int form = wide_items * 10 >= (long long)tuning().convp_wide * device_cu_count() ? 2 : 1;
+    const int form = tuning().convp_pp ? 3 : wide_items * 10 >= (long long)tuning().convp_wide * device_cu_count() ? 2 : 1;
     if (int rc = prepare_convp(p, dil, lds, flops, bytes, form)) return rc;
     profile_begin(s);
-    const int rc = form == 2 ? (dil == 1 ? launch_convq2_dil<1, kPair64Wide>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, kPair64Wide>(p, lds, s) : launch_convq2_dil<5, kPair64Wide>(p, lds, s))
+    const int rc = form == 3 ? (dil == 1 ? launch_convq3_dil<1>(p, s) : dil == 3 ? launch_convq3_dil<3>(p, s) : launch_convq3_dil<5>(p, s))
+                   : form == 2 ? (dil == 1 ? launch_convq2_dil<1, kPair64Wide>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, kPair64Wide>(p, lds, s) : launch_convq2_dil<5, kPair64Wide>(p, lds, s))
                              : (dil == 1 ? launch_convq2_dil<1, 64>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, 64>(p, lds, s) : launch_convq2_dil<5, 64>(p, lds, s));
     profile_end(s, FV_KERNEL_CONVH64, flops, bytes);
     return rc;

@@ -158,6 +158,10 @@ struct Tuning {
     int convt_lean = 50;      // ... on the lean kernel (convtl_kernels.hpp) up to this many (64 x 64 item, chunk) units per CU, in tenths; 0: never
     int convq_wide = 20;         // fused 128-channel pairs, dilation 1 / 3: 128-column tiles per CU (in tenths) from which the wide form runs
     int convp_wide = 20;         // fused 64-channel pairs: 256-column tiles per CU (in tenths) from which the wide no-ring form runs
+    int convp_pp = 0;            // fused 64-channel pairs as two wave groups one conv phase apart (convq3_kernels.hpp): 1 always, 0 never.
+                                 // [measured, round 6: identical bits, 5-15 % SLOWER than convq2_kernel at batch 1 and 8 -- the VALU
+                                 // instructions of one wave do not run beside the MFMAs of another wave of the same SIMD
+                                 // (tools/pingpong_probe.hip, profiles/r06_pingpong.txt); kept as the measured form of that experiment]
     int stack_wide = 10;         // residual stacks of 256 channels: tiles of 64 columns per CU (in tenths) from which the wide tile runs
                                  // (Basis-MelGAN, 1000 frames: batch 1 -- 250 such tiles in its second stage -- 0.238 narrow / 0.248 wide,
                                  // batch 2 0.384 / 0.359, batch 3 0.624 / 0.534)

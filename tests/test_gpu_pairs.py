@@ -374,7 +374,7 @@ def test_conv1d_split_f16_reflection_rejects():
 def tuning():
     """fv_tuning_set for the duration of a test (process-wide switches of the launchers: restored afterwards)."""
     defaults = {"sched": 1, "sched_switch": 4, "convh_blocks": 0, "pair_blocks": 0, "pair128_unfused": 0, "convg_rows64": -1,
-                "convh_rows64": -1, "convt_rows64": -1, "convp_wide": 20, "convq_wide": 20, "convt_lean": 50, "convs_ringfree": -1, "convu_resident": 1}
+                "convh_rows64": -1, "convt_rows64": -1, "convp_wide": 20, "convq_wide": 20, "convt_lean": 50, "convs_ringfree": -1, "convu_resident": 1, "convp_pp": 0}
     yield _native.tuning_set
     for k, v in defaults.items():
         _native.tuning_set(k, v)
@@ -586,10 +586,16 @@ def test_pair_tile_forms_give_the_same_bits(tuning):
         b1s, b2s = [_t(m[2]) for m in ms], [_t(m[4]) for m in ms]
         refs = [_pair_ref(x, w1, b1, w2, b2, dil, 0.1) for x, w1, b1, w2, b2 in ms]
         outs = {}
-        for wide in (1 << 20, 0):            # narrow tiles only; wide tiles wherever they exist
-            tuning("convp_wide", wide)
-            tuning("convq_wide", wide)
-            for blocks in (0, 3):
+        # (wide: narrow tiles only / wide tiles wherever they exist; 64 channels, "pp": convq3_kernel -- two wave groups one
+        # conv phase apart, each on 64-column tiles of its own share -- on full, three- and one-block grids)
+        for wide in (1 << 20, 0, "pp"):
+            if wide == "pp" and C != 64:
+                continue
+            tuning("convp_pp", 1 if wide == "pp" else 0)
+            if wide != "pp":
+                tuning("convp_wide", wide)
+                tuning("convq_wide", wide)
+            for blocks in (0, 3, 1) if wide == "pp" else (0, 3):
                 tuning("convh_blocks", blocks)
                 ys = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, prec=SPLIT)
                 merged = torch.empty_like(xs[0])
@@ -599,6 +605,7 @@ def test_pair_tile_forms_give_the_same_bits(tuning):
         tuning("convh_blocks", 0)
         tuning("convp_wide", 20)
         tuning("convq_wide", 20)
+        tuning("convp_pp", 0)
         base = outs[(1 << 20, 0)]
         for y, ref in zip(base[:3], refs):
             assert _rel(y, ref) <= 4e-6

@@ -787,8 +787,8 @@ def _sweep_lengths(n_random, t_max, batch_for_policy=(1, 3)):
 @pytest.mark.parametrize("name,path,t_max,n_random,fuse", [
     ("hifigan", "conf/hifigan/light.yaml", 1500, 5, True),
     ("hifigan", "conf/hifigan/light.yaml", 1500, 5, (16, 32)),
-    ("hifigan", "conf/hifigan/large.yaml", 360, 6, True),
-    ("hifigan", "conf/hifigan/large.yaml", 360, 6, (16, 32)),
+    ("hifigan", "conf/hifigan/large.yaml", 360, 9, True),
+    ("hifigan", "conf/hifigan/large.yaml", 360, 9, (16, 32)),
     ("multiband-hifigan", "conf/multiband-hifigan/light.yaml", 1500, 5, True),
 ], ids=["hifigan_light", "hifigan_light_one_launch_stages", "hifigan_large", "hifigan_large_one_launch_stages", "mb_light"])
 def test_random_lengths_vs_aten_port(name, path, t_max, n_random, fuse):
