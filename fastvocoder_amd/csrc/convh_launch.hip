@@ -113,13 +113,34 @@ void pair_cut_schedule(PairParams& p, int nblk, const long long* n) {
         items += n[m];
     }
     if (items >= (1LL << 31)) return;
-    for (int i = 0; i < nblk; ++i) {
-        long long g = 0, base = 0;
-        for (int m = 0; m < p.n_members; ++m) {
-            g += host_share(i, total, base, p.m[m].cost, n[m], nblk);
-            base += n[m] * p.m[m].cost;
+    // The table depends on (shares, item counts, costs) only: a forward asks for the same handful of tables call after call
+    // (nblk x members divisions each, ~5 us of host time per launch) -- kept per shape, as pair_schedule's are.
+    typedef std::array<long long, 8> Key;
+    typedef std::array<unsigned, 2 * kSchedBlocks> Table;
+    static std::mutex mu;
+    static std::map<Key, Table> cache;
+    Key key = {nblk, p.n_members, 0, 0, 0, 0, 0, 0};
+    for (int m = 0; m < p.n_members; ++m) {
+        key[2 + 2 * m] = n[m];
+        key[3 + 2 * m] = p.m[m].cost;
+    }
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = cache.find(key);
+        if (it == cache.end()) {
+            Table t = {};
+            for (int i = 0; i < nblk; ++i) {
+                long long g = 0, base = 0;
+                for (int m = 0; m < p.n_members; ++m) {
+                    g += host_share(i, total, base, p.m[m].cost, n[m], nblk);
+                    base += n[m] * p.m[m].cost;
+                }
+                t[i] = (unsigned)g;
+            }
+            if (cache.size() >= 512) cache.clear();
+            it = cache.emplace(key, t).first;
         }
-        p.sched[i] = (unsigned)g;
+        memcpy(p.sched, it->second.data(), sizeof(unsigned) * (size_t)nblk);
     }
     p.sched_on = 2;
 }

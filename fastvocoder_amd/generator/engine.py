@@ -900,7 +900,10 @@ class NativeModule(torch.nn.Module):
         crop (MB-large), c > 0 a tail (Basis overlap-add); either way a chunk that starts at
         frame ``lo`` produces final samples [lo*hop, lo*hop + len)."""
         B, _, T = x.shape
-        plan = plan_for(T)
+        self._fv_batch = int(B)           # (plan_for below: graphs whose shape depends on the batch are chosen for THIS batch,
+                                          # not for the last call's -- ADVICE r5)
+        plan = plan_for(min(T, chunk))            # any length's variant has the same receptive field and output-length law: ask
+                                                  # for one of the size the chunks will run at, not for a whole-length plan
         halo = plan.halo_frames
         (_, n1), (cout, n2) = plan.output_shape(halo + 64), plan.output_shape(halo + 65)
         hop = n2 - n1

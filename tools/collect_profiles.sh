@@ -2,7 +2,7 @@
 # Round profile collection on the GPU box (run from the repo root through gpurun):
 #   tools/collect_profiles.sh r02
 # writes gpurun_out/<tag>/...; turn it into the committed profiles/<tag>_* with tools/summarise_profiles.py <tag>
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$PWD
 mkdir -p $R/gpurun_out/$TAG
 export TMPDIR=/tmp
