@@ -445,6 +445,11 @@ int launch_convq3_dil(const PairParams& p, hipStream_t s);                  // c
 extern template int launch_convq3_dil<1>(const PairParams&, hipStream_t);
 extern template int launch_convq3_dil<3>(const PairParams&, hipStream_t);
 extern template int launch_convq3_dil<5>(const PairParams&, hipStream_t);
+template <int DIL>
+int launch_convq4_dil(const PairParams& p, hipStream_t s);                  // ... the same pipelines as blocks of their own, two per CU
+extern template int launch_convq4_dil<1>(const PairParams&, hipStream_t);
+extern template int launch_convq4_dil<3>(const PairParams&, hipStream_t);
+extern template int launch_convq4_dil<5>(const PairParams&, hipStream_t);
 
 // everything launch_convp does in front of the launch: validation, member order, tile counts, LDS layout, block schedule
 // (form: 1 convq2_kernel<DIL, 64> -- 128-column tiles; 2 convq2_kernel<DIL, 65> -- 256-column tiles; 3 convq3_kernel<DIL> -- two
@@ -537,7 +542,8 @@ int launch_convp(PairParams p, int dil, hipStream_t s) {
     const int form = tuning().convp_pp ? 3 : wide_items * 10 >= (long long)tuning().convp_wide * device_cu_count() ? 2 : 1;
     if (int rc = prepare_convp(p, dil, lds, flops, bytes, form)) return rc;
     profile_begin(s);
-    const int rc = form == 3 ? (dil == 1 ? launch_convq3_dil<1>(p, s) : dil == 3 ? launch_convq3_dil<3>(p, s) : launch_convq3_dil<5>(p, s))
+    const int rc = form == 3 && tuning().convp_pp == 2 ? (dil == 1 ? launch_convq4_dil<1>(p, s) : dil == 3 ? launch_convq4_dil<3>(p, s) : launch_convq4_dil<5>(p, s))
+                   : form == 3 ? (dil == 1 ? launch_convq3_dil<1>(p, s) : dil == 3 ? launch_convq3_dil<3>(p, s) : launch_convq3_dil<5>(p, s))
                    : form == 2 ? (dil == 1 ? launch_convq2_dil<1, kPair64Wide>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, kPair64Wide>(p, lds, s) : launch_convq2_dil<5, kPair64Wide>(p, lds, s))
                              : (dil == 1 ? launch_convq2_dil<1, 64>(p, lds, s) : dil == 3 ? launch_convq2_dil<3, 64>(p, lds, s) : launch_convq2_dil<5, 64>(p, lds, s));
     profile_end(s, FV_KERNEL_CONVH64, flops, bytes);

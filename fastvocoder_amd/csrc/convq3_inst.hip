@@ -9,6 +9,17 @@ int launch_convq3_dil(const PairParams& p, hipStream_t s) {
     FV_HIP(hipGetLastError());
     return 0;
 }
+template <int DIL>
+int launch_convq4_dil(const PairParams& p, hipStream_t s) {
+    constexpr size_t lds = ConvQ3Lds<DIL>::GROUP;
+    if (int rc = allow_dynamic_lds(reinterpret_cast<const void*>(convq4_kernel<DIL>), lds)) return rc;
+    hipLaunchKernelGGL((convq4_kernel<DIL>), dim3(2 * p.nblk), dim3(256), lds, s, p);
+    FV_HIP(hipGetLastError());
+    return 0;
+}
+template int launch_convq4_dil<1>(const PairParams&, hipStream_t);
+template int launch_convq4_dil<3>(const PairParams&, hipStream_t);
+template int launch_convq4_dil<5>(const PairParams&, hipStream_t);
 template int launch_convq3_dil<1>(const PairParams&, hipStream_t);
 template int launch_convq3_dil<3>(const PairParams&, hipStream_t);
 template int launch_convq3_dil<5>(const PairParams&, hipStream_t);

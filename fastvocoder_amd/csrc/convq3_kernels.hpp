@@ -27,7 +27,9 @@
 // itself takes ~6 000 beside the other group's K loop, and that K loop 6 000-7 500 instead of 4 800: on one SIMD the MFMA
 // stream of one wave and the VALU / LDS instructions of another share the issue slot -- tools/pingpong_probe.hip: MFMA waves
 // 271 us alone, v_fma waves 382 us alone, both together 607 us (the sum) when they share SIMDs, 490 us (the maximum) when the
-// two roles sit on different SIMDs; the same for v_mfma_f32_32x32x16_f16; s_setprio either way changes nothing.  A slot is the
+// two roles sit on different SIMDs; the same for v_mfma_f32_32x32x16_f16; s_setprio either way changes nothing, and neither does
+// which of the two waves is the older one (second collection of the probe: even a side wave that only issues eight
+// ds_read_b128 + waits per iteration takes the sum).  A slot is the
 // SUM of the two phases, and the 64-column tiles convert more halo per output column: the three-member launch of HiFi-GAN
 // light's 64-channel stage takes 61-66 us against convq2_kernel's 53-57 at batch 1, 403-413 against 348-384 at batch 8.
 // Not the default (Tuning::convp_pp = 0); kept, with its bit-identity test, as the measured form of the experiment.
@@ -384,6 +386,52 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (mb.k == 11) convq3_run_member<ConvQ3Run<11, DIL>, LD>(q, mb, lo, hi, sm, gw, lane, wave);
         else if (mb.k == 7) convq3_run_member<ConvQ3Run<7, DIL>, LD>(q, mb, lo, hi, sm, gw, lane, wave);
         else convq3_run_member<ConvQ3Run<3, DIL>, LD>(q, mb, lo, hi, sm, gw, lane, wave);
+    }
+}
+
+// The same group pipeline as a block of its OWN: four waves (one per SIMD), 54 KB of LDS, two blocks per CU -- the two tile
+// streams of a CU coupled by nothing (no shared barrier: a wave that waits, for memory or at its own block's barrier, leaves
+// its SIMD to the other block's wave).  2 nblk blocks, share = block.
+template <int DIL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void convq4_kernel(PairParams p) {
+    typedef ConvQ3Lds<DIL> LD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* const sm = reinterpret_cast<char*>(smem);
+    PairParams q;
+    q.n_members = p.n_members; q.B = p.B; q.T = p.T; q.nblk = p.nblk; q.slope = p.slope; q.out_div = p.out_div;
+    q.act_slope = p.act_slope; q.post = p.post; q.dbg = p.dbg; q.trace = p.trace; q.guard = p.guard;
+    int n_items[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) n_items[m] = p.m[m].n_items;
+    asm volatile("" ::"s"(q.n_members), "s"(q.B), "s"(q.T), "s"(q.nblk), "s"(q.slope), "s"(q.out_div), "s"(q.act_slope),
+                 "s"(q.post), "s"(q.dbg), "s"(q.trace), "s"(n_items[0]), "s"(n_items[1]), "s"(n_items[2]), "s"(q.guard));
+    const int share = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    int g_lo = (int)p.sched[share];
+    int g_hi = share + 1 < 2 * q.nblk ? (int)p.sched[share + 1]
+                                      : n_items[0] + (q.n_members > 1 ? n_items[1] : 0) + (q.n_members > 2 ? n_items[2] : 0);
+    asm volatile("" ::"s"(g_lo), "s"(g_hi));
+    {
+        char* const mimg = sm + LD::OFF_M;
+        for (int idx = tid; idx < 2 * 8 * 64; idx += 256)
+            reinterpret_cast<float*>(mimg + ((idx >> 6) * 80 + 64) * 16)[idx & 63] = 0.f;
+    }
+    if (g_lo >= g_hi) return;
+    int off = 0;
+    for (int m = 0; m < q.n_members; ++m) {
+        const int n = m == 0 ? n_items[0] : m == 1 ? n_items[1] : n_items[2];
+        const int lo = min(max(g_lo - off, 0), n), hi = min(max(g_hi - off, 0), n);
+        off += n;
+        if (lo >= hi) continue;
+        PairMember mb;
+        mb.x = p.m[m].x; mb.w1 = p.m[m].w1; mb.w2 = p.m[m].w2; mb.b1 = p.m[m].b1; mb.b2 = p.m[m].b2; mb.add1 = p.m[m].add1;
+        mb.add2 = p.m[m].add2; mb.y = p.m[m].y; mb.y_act = p.m[m].y_act; mb.k = p.m[m].k; mb.n_tiles = p.m[m].n_tiles;
+        asm volatile("" ::"s"(mb.x), "s"(mb.w1), "s"(mb.w2), "s"(mb.b1), "s"(mb.b2), "s"(mb.add1), "s"(mb.add2), "s"(mb.y),
+                     "s"(mb.y_act), "s"(mb.k), "s"(mb.n_tiles));
+        if (mb.k == 11) convq3_run_member<ConvQ3Run<11, DIL>, LD>(q, mb, lo, hi, sm, wave, lane, wave);
+        else if (mb.k == 7) convq3_run_member<ConvQ3Run<7, DIL>, LD>(q, mb, lo, hi, sm, wave, lane, wave);
+        else convq3_run_member<ConvQ3Run<3, DIL>, LD>(q, mb, lo, hi, sm, wave, lane, wave);
     }
 }
 

@@ -158,7 +158,7 @@ struct Tuning {
     int convt_lean = 50;      // ... on the lean kernel (convtl_kernels.hpp) up to this many (64 x 64 item, chunk) units per CU, in tenths; 0: never
     int convq_wide = 20;         // fused 128-channel pairs, dilation 1 / 3: 128-column tiles per CU (in tenths) from which the wide form runs
     int convp_wide = 20;         // fused 64-channel pairs: 256-column tiles per CU (in tenths) from which the wide no-ring form runs
-    int convp_pp = 0;            // fused 64-channel pairs as two wave groups one conv phase apart (convq3_kernels.hpp): 1 always, 0 never.
+    int convp_pp = 0;            // fused 64-channel pairs as two wave groups one conv phase apart (convq3_kernels.hpp): 0 never, 1 always (convq3_kernel: one 8-wave block), 2 always as four-wave blocks, two per CU (convq4_kernel).
                                  // [measured, round 6: identical bits, 5-15 % SLOWER than convq2_kernel at batch 1 and 8 -- the VALU
                                  // instructions of one wave do not run beside the MFMAs of another wave of the same SIMD
                                  // (tools/pingpong_probe.hip, profiles/r06_pingpong.txt); kept as the measured form of that experiment]

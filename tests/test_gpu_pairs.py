@@ -588,14 +588,15 @@ def test_pair_tile_forms_give_the_same_bits(tuning):
         outs = {}
         # (wide: narrow tiles only / wide tiles wherever they exist; 64 channels, "pp": convq3_kernel -- two wave groups one
         # conv phase apart, each on 64-column tiles of its own share -- on full, three- and one-block grids)
-        for wide in (1 << 20, 0, "pp"):
-            if wide == "pp" and C != 64:
+        # ("pp2": convq4_kernel -- the same group pipeline as four-wave blocks of their own, two per CU)
+        for wide in (1 << 20, 0, "pp", "pp2"):
+            if wide in ("pp", "pp2") and C != 64:
                 continue
-            tuning("convp_pp", 1 if wide == "pp" else 0)
-            if wide != "pp":
+            tuning("convp_pp", 1 if wide == "pp" else 2 if wide == "pp2" else 0)
+            if wide not in ("pp", "pp2"):
                 tuning("convp_wide", wide)
                 tuning("convq_wide", wide)
-            for blocks in (0, 3, 1) if wide == "pp" else (0, 3):
+            for blocks in (0, 3, 1) if wide in ("pp", "pp2") else (0, 3):
                 tuning("convh_blocks", blocks)
                 ys = _native.resblock1_fused(xs, h1, h2, b1s, b2s, list(ks), dil, 0.1, prec=SPLIT)
                 merged = torch.empty_like(xs[0])

@@ -10,14 +10,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // MODE bit 0: waves 0-3 run MFMAs; bit 1: waves 4-7 run the side work.  SHAPE 0: 16x16x32, 1: 32x32x16.  SIDE 0: v_fma, 1: ds_read_b128
-template <int MODE, int SHAPE, int SIDE, int ROLE = 0>   // ROLE 0: MFMA waves = 0-3; 1: even waves; 2: waves 0, 1, 4, 5
+template <int MODE, int SHAPE, int SIDE, int ROLE = 0, int PRIO = 0>   // ROLE 0: MFMA waves = 0-3; 1: even waves; 2: waves 0, 1, 4, 5; 3: MFMA waves = 4-7 (the YOUNGER half)
+// PRIO 1: the side waves at s_setprio 3; 2: the MFMA waves at s_setprio 3
 __global__ __launch_bounds__(512) void work(float* out, int iters, int side_per_iter) {
     __shared__ float lds[16384];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 16384; i += 512) lds[i] = i;
     __syncthreads();
     float s = 0.f;
-    const bool mf = ROLE == 0 ? wave < 4 : ROLE == 1 ? (wave & 1) == 0 : (wave & 2) == 0;
+    const bool mf = ROLE == 0 ? wave < 4 : ROLE == 1 ? (wave & 1) == 0 : ROLE == 2 ? (wave & 2) == 0 : wave >= 4;
+    if (PRIO == 1 && !mf) __builtin_amdgcn_s_setprio(3);
+    if (PRIO == 2 && mf) __builtin_amdgcn_s_setprio(3);
     if (mf) {
         if (MODE & 1) {
             f16x8 a, b;
@@ -102,6 +105,16 @@ void roles(float* d) {
     printf("role map %d (0: MFMA waves 0-3; 1: even waves; 2: waves 0,1,4,5): MFMA alone %.1f, v_fma alone %.1f, both %.1f us\n", ROLE, m, v, b);
 }
 
+template <int ROLE, int PRIO, int SIDE>
+void prio_row(float* d) {
+    const int iters = 2000, side = SIDE == 0 ? 64 : 8;
+    const float m = run(work<1, 0, SIDE, ROLE, PRIO>, d, iters, 0), v = run(work<2, 0, SIDE, ROLE, PRIO>, d, iters, side),
+                b = run(work<3, 0, SIDE, ROLE, PRIO>, d, iters, side);
+    printf("   MFMA waves %s, s_setprio 3 on %s, side = %s: MFMA alone %.1f, side alone %.1f, both %.1f us (sum %.1f, max %.1f)\n",
+           ROLE == 0 ? "0-3 (older)" : "4-7 (younger)", PRIO == 0 ? "nobody" : PRIO == 1 ? "the side waves" : "the MFMA waves",
+           SIDE == 0 ? "v_pk_fma chains" : "ds_read_b128 + wait", m, v, b, m + v, m > v ? m : v);
+}
+
 int main() {
     float* d; hipMalloc(&d, (size_t)256 * 512 * 4);
     roles<0>(d); roles<1>(d); roles<2>(d);
@@ -109,5 +122,10 @@ int main() {
     table<1, 0>(d, "v_mfma_f32_32x32x16_f16", "v_fma_f32 chains");
     table<0, 1>(d, "v_mfma_f32_16x16x32_f16", "ds_read_b128");
     table<1, 1>(d, "v_mfma_f32_32x32x16_f16", "ds_read_b128");
+    printf("who yields to whom on one SIMD (one MFMA wave + one side wave per SIMD)\n");
+    prio_row<0, 0, 0>(d); prio_row<0, 1, 0>(d); prio_row<0, 2, 0>(d);
+    prio_row<3, 0, 0>(d); prio_row<3, 1, 0>(d); prio_row<3, 2, 0>(d);
+    prio_row<0, 0, 1>(d); prio_row<0, 1, 1>(d); prio_row<0, 2, 1>(d);
+    prio_row<3, 0, 1>(d); prio_row<3, 1, 1>(d); prio_row<3, 2, 1>(d);
     return 0;
 }

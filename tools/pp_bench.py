@@ -32,7 +32,7 @@ b2 = [t(rng.randn(C) * 0.1) for _ in ks]
 outs = [torch.empty_like(x) for x in xs]
 res = {}
 for dil in (1, 3, 5):
-    for pp in (0, 1):
+    for pp in (0, 1, 2):
         _native.tuning_set("convp_pp", pp)
         for _ in range(5):
             ys = _native.resblock1_fused(xs, w1, w2, b1, b2, list(ks), dil, 0.1, prec=SPLIT, outs=outs)
@@ -45,12 +45,12 @@ for dil in (1, 3, 5):
         us = 1e6 * (time.perf_counter() - t0) / n
         res[(dil, pp)] = [y.clone() for y in ys]
         print(f"B={B} dil={dil} pp={pp}: {us:8.1f} us per three-member launch")
-    same = all(torch.equal(a, b) for a, b in zip(res[(dil, 0)], res[(dil, 1)]))
+    same = all(torch.equal(a, b) and torch.equal(a, c) for a, b, c in zip(res[(dil, 0)], res[(dil, 1)], res[(dil, 2)]))
     print(f"   identical bits: {same}")
 bench.T_FRAMES = 1000
 model, cfg, sd = bench.build_model("light", dev, None, 0)
 mel = torch.from_numpy(bench.utterance_mels(0, B)).to(dev)
-for pp in (0, 1, 0, 1):
+for pp in (0, 1, 2, 0, 1, 2):
     _native.tuning_set("convp_pp", pp)
     with torch.no_grad():
         for _ in range(5):
