@@ -1183,6 +1183,65 @@ def test_weights_of_any_magnitude_stay_on_the_split_kernels():
     assert float(want.abs().max()) > 0.05 and _err(got, want.cpu().numpy()) <= 2e-5
 
 
+@pytest.mark.parametrize("path,T,spread", [("conf/hifigan/light.yaml", 200, 8), ("conf/hifigan/light.yaml", 77, 11),
+                                           ("conf/hifigan/large.yaml", 40, 8)],
+                         ids=["light_2^16", "light_2^22", "large_2^16"])
+def test_channel_scales_of_a_trained_model_stay_inside_the_tolerance(path, T, spread):
+    """No trained checkpoint exists here (the reference names a URL only), and seeded weights give every channel of a layer
+    the same scale -- a trained vocoder does not: a few loud channels beside nearly dead ones.  So: every intermediate
+    channel of every ResBlock pair gets its own power-of-two gain, log-uniform over 2^(2 spread) (conv1's row and bias times
+    g, conv2's column times 1 / g: the same function in exact arithmetic, leaky ReLU being homogeneous), i.e. inside ONE
+    split-f16 operand tile magnitudes differ by up to 2^16 (2^22), rows of conv2 mix weights of that spread, and the row
+    prescale sees the largest only.  The split kernels must still be within 1e-4 of the ATen port ON THESE WEIGHTS, agree
+    with the unscaled model, and raise no guard."""
+    cfg = cases.load_conf(path)
+    mel = seeded_mel(T, seed=77)
+    plain, _ = _model("hifigan", cfg, seed=0)
+    m, _ = _model("hifigan", cfg, seed=0)
+    m.remove_weight_norm()
+    rng = np.random.RandomState(1234)
+    with torch.no_grad():
+        for rb in m.resblocks:
+            for c1, c2 in zip(rb.convs1, rb.convs2):
+                g = torch.from_numpy((2.0 ** rng.randint(-spread, spread + 1, size=c1.weight.shape[0])).astype(np.float32)).to(c1.weight.device)
+                c1.weight.mul_(g[:, None, None])
+                c1.bias.mul_(g)
+                c2.weight.mul_(1.0 / g[None, :, None])
+        want = plain.inference(mel)
+        got = m.inference(mel)
+    assert m._fv_policy()[0] == "split" and not m.check_range()
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    ref = torch_port.inference("hifigan", mel, sd, cfg).numpy()
+    assert float(np.abs(ref).max()) > 0.05
+    assert _err(got, ref) <= TOL and _err(got, want.cpu().numpy()) <= TOL
+    print(f"{path} spread 2^{2 * spread}: {_err(got, ref):.2e} from the port, {_err(got, want.cpu().numpy()):.2e} from the unscaled model")
+
+
+@pytest.mark.parametrize("name,path", [("hifigan", "conf/hifigan/light.yaml"), ("melgan", "conf/melgan/original.yaml"),
+                                       ("multiband-hifigan", "conf/multiband-hifigan/light.yaml")])
+def test_silence_and_transients_in_the_mel(name, path):
+    """What a real utterance looks like and the seeded mels do not: the reference normalises its mels into [0, 1] WITH clipping
+    (/root/reference/data/audio.py:159-160), so silence is a stretch of exact zeros and loud frames sit at exactly 1; and a
+    caller with un-normalised log-mels feeds a floor of log(1e-5) with isolated peaks.  Blocks of the split kernels then see
+    exact zeros, constant columns and transients.  Every sample against the ATen port; whatever the guard decides, the
+    call returns the reference's values."""
+    cfg = cases.load_conf(path)
+    m, sd = _model(name, cfg, seed=0)
+    folded = torch_port.fold_state_dict(sd)
+    T = 360
+    mel = np.array(seeded_mel(T, seed=91), copy=True)
+    mel[40:150] = 0.0                                   # silence after the clip
+    mel[150:156] = 1.0                                  # an onset at the ceiling
+    mel[200:260] = np.float32(np.log(1e-5))             # an un-normalised floor
+    mel[230] += 20.0                                    # ... with one frame far above it
+    mel[300:, 40:] = 0.0                                # band-limited tail
+    with torch.no_grad():
+        got = m.inference(mel)
+    ref = torch_port.inference(name, mel, folded, cfg).numpy()
+    assert bool(torch.isfinite(got).all()) and _err(got, ref) <= TOL
+    print(f"{name}: {_err(got, ref):.2e}, policy after the call: {m._fv_policy()[0]}")
+
+
 def test_generator_below_the_low_side_repeats_on_fp32():
     """The low side of the domain end to end: conv_pre 2^-20 times too quiet (conv_post undoes it) -- the first split-f16
     layer sees a tensor that is small as a whole, the guard fires (4), `inference` repeats the call on the exact-fp32
