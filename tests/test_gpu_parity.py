@@ -785,11 +785,11 @@ def _sweep_lengths(n_random, t_max, batch_for_policy=(1, 3)):
 
 
 @pytest.mark.parametrize("name,path,t_max,n_random,fuse", [
-    ("hifigan", "conf/hifigan/light.yaml", 1100, 4, True),
-    ("hifigan", "conf/hifigan/light.yaml", 1100, 4, (16, 32)),
-    ("hifigan", "conf/hifigan/large.yaml", 300, 10, True),
-    ("hifigan", "conf/hifigan/large.yaml", 300, 10, (16, 32)),
-    ("multiband-hifigan", "conf/multiband-hifigan/light.yaml", 1100, 4, True),
+    ("hifigan", "conf/hifigan/light.yaml", 1500, 10, True),
+    ("hifigan", "conf/hifigan/light.yaml", 1500, 10, (16, 32)),
+    ("hifigan", "conf/hifigan/large.yaml", 360, 12, True),
+    ("hifigan", "conf/hifigan/large.yaml", 360, 12, (16, 32)),
+    ("multiband-hifigan", "conf/multiband-hifigan/light.yaml", 1500, 10, True),
 ], ids=["hifigan_light", "hifigan_light_one_launch_stages", "hifigan_large", "hifigan_large_one_launch_stages", "mb_light"])
 def test_random_lengths_vs_aten_port(name, path, t_max, n_random, fuse):
     """Whole shipped generators at >= 25 lengths in [1, t_max] against the validated ATen port on the host, EVERY sample, 1e-4
