@@ -823,6 +823,51 @@ def test_random_lengths_vs_aten_port(name, path, t_max, n_random, fuse):
     print(f"{name} {path} fuse_stage={fuse}: {len(lengths)} lengths, worst {worst:.2e}")
 
 
+@pytest.mark.parametrize("name,path,t_max,n_random", [
+    ("melgan", "conf/melgan/original.yaml", 700, 22),
+    ("basis-melgan", "conf/basis-melgan/light.yaml", 1500, 22),
+    ("multiband-hifigan", "conf/multiband-hifigan/large.yaml", 300, 22),
+], ids=["melgan", "basis_melgan_light", "mb_large"])
+def test_random_lengths_vs_aten_port_other_generators(name, path, t_max, n_random):
+    """The randomized-length sweep for the generators the round-6 sweep above left out: MelGAN and Basis-MelGAN (every
+    ResidualStack is ONE launch whose reflection padding, `modules.py:296-382`, is cut per tile: the short lengths are where a
+    tile holds both reflected ends), MB-HiFi-GAN large (256-channel convs conv by conv + PQMF).  >= 25 lengths, every sample
+    against the ATen port, 1e-4; batch 1 through `inference`, batch 3 through `forward` at six of them (Basis-MelGAN's
+    `forward` returns the bias-removed pair `(est_source, weight)`, `basis_melgan.py:139-162`: both are compared).  The
+    shortest length is the reference's own: ReflectionPad1d(3) in front of the first conv needs T >= 4."""
+    cfg = cases.load_conf(path)
+    m, sd = _model(name, cfg, seed=0)
+    folded = torch_port.fold_state_dict(sd)
+    rng = np.random.RandomState(707)
+    lo = 4 if "melgan" in name else 1
+    ts = {lo, lo + 1, lo + 2, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200, 255, 256, 257, t_max}
+    ts.update(int(v) for v in rng.randint(lo, t_max + 1, size=n_random))
+    lengths = sorted(t for t in ts if lo <= t <= t_max)
+    assert len(lengths) >= 25, lengths
+    batched = set(lengths[:3] + lengths[len(lengths) // 3::4][:3])
+    worst = 0.0
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 32))
+    with torch.no_grad():
+        for T in lengths:
+            mel = seeded_mel(T, seed=7000 + T)
+            err = _err(m.inference(mel), torch_port.inference(name, mel, folded, cfg).numpy())
+            assert err <= TOL, (T, err)
+            worst = max(worst, err)
+            if T in batched:
+                x = seeded_mel(T, seed=9000 + T, batch=3)
+                got, ref = m(torch.from_numpy(x)), torch_port.forward(name, x, folded, cfg)
+                pairs = list(zip(got, ref)) if isinstance(ref, tuple) else [(got, ref)]
+                assert not isinstance(ref, tuple) or len(got) == len(ref)
+                for g, r in pairs:
+                    err = _err(g, r.numpy())
+                    assert err <= TOL, (T, "batch 3", err)
+                    worst = max(worst, err)
+    torch.set_num_threads(threads)
+    assert not m.check_range()
+    print(f"{name} {path}: {len(lengths)} lengths, worst {worst:.2e}")
+
+
 def test_batch_rows_are_independent_and_bit_identical():
     """Utterances never mix: row b of a batched forward equals the single-row call
     bit for bit (this is what makes N-GPU sharding exact)."""
