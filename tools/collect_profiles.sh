@@ -8,10 +8,12 @@ mkdir -p $R/gpurun_out/$TAG
 export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-job --no-exact --no-others"
 # --- the headline bench (BASELINE config 2): kernel stats, HBM traffic (two PMC passes), matrix-pipe counters ---
+# (the kernel-stats pass is the bench command as it is -- sustained-rate prewarm included, so its per-kernel averages are the
+#  sustained ones the line reports; the counter passes run without the prewarm: counts per dispatch do not depend on the clock)
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/stats -o bench -- $B --steps 20 --warmup 3 > $R/gpurun_out/$TAG/bench_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/$TAG/fetch -o bench -- $B --steps 5 --warmup 2 > $R/gpurun_out/$TAG/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/$TAG/write -o bench -- $B --steps 5 --warmup 2 > $R/gpurun_out/$TAG/bench_write.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $R/gpurun_out/$TAG/mfma -o bench -- $B --steps 5 --warmup 2 > $R/gpurun_out/$TAG/bench_mfma.log 2>&1
+FV_BENCH_PREWARM_S=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/$TAG/fetch -o bench -- $B --steps 5 --warmup 2 > $R/gpurun_out/$TAG/bench_fetch.log 2>&1
+FV_BENCH_PREWARM_S=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/$TAG/write -o bench -- $B --steps 5 --warmup 2 > $R/gpurun_out/$TAG/bench_write.log 2>&1
+FV_BENCH_PREWARM_S=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $R/gpurun_out/$TAG/mfma -o bench -- $B --steps 5 --warmup 2 > $R/gpurun_out/$TAG/bench_mfma.log 2>&1
 python $R/bench.py --steps 50 --warmup 5 > $R/gpurun_out/$TAG/bench.json 2>/dev/null
 # --- the other BASELINE configs (tools/bench_configs.py indices: 0 MelGAN B=1, 2 MB-light B=32, 3 Basis B=64, 4 HiFi-GAN large B=64) ---
 for i in 0 2 3 4; do
