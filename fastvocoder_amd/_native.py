@@ -265,6 +265,7 @@ def lib():
     L.fv_plan_set_guard.argtypes = [vp, vp]
     L.fv_plan_check_range.argtypes = [vp, vp]
     L.fv_tuning_set.argtypes = [ctypes.c_char_p, i]
+    L.fv_debug_pair_schedule.argtypes = [i, ctypes.POINTER(i), ctypes.POINTER(i), i, i, i, ctypes.POINTER(ctypes.c_uint)]
     L.fv_plan_set_group.argtypes = [vp, i]
     L.fv_plan_output_shape.argtypes = [vp, i, ctypes.POINTER(i), ctypes.POINTER(i64)]
     L.fv_plan_workspace_bytes.argtypes = [vp, i, i]
@@ -348,6 +349,29 @@ class GuardWord:
 def tuning_set(key, value):
     """Test / tuning hook (fv_tuning_set): one of the launchers' switches, process-wide."""
     check(lib().fv_tuning_set(key.encode(), int(value)))
+
+
+def debug_pair_schedule(n_items, cost, nblk, mode=0, three_members=False):
+    """Test hook (fv_debug_pair_schedule, host only): the block schedule of a fused-pair launch.  Returns
+    ``(sched_on, shares)``: sched_on 1 -- ``shares[b][m] = (lo, count)``, member m's items of block b (pair_schedule);
+    2 -- ``shares[i]`` = first item of share i in the members' concatenated item sequence (pair_cut_schedule); 0 -- no
+    table for this shape (``shares`` is None)."""
+    n = len(n_items)
+    arr = ctypes.c_int * n
+    table = (ctypes.c_uint * 512)()
+    rc = lib().fv_debug_pair_schedule(n, arr(*[int(v) for v in n_items]), arr(*[int(v) for v in cost]), int(nblk), int(mode),
+                                      1 if three_members else 0, table)
+    check(rc if rc < 0 else 0)
+    if rc == 1:
+        out = []
+        for b in range(nblk):
+            w0, w1 = table[2 * b], table[2 * b + 1]
+            e = [w0 & 0xFFFF, w0 >> 16, w1 & 0xFFFF]
+            out.append([(v & 2047, v >> 11) for v in e[:n]])
+        return 1, out
+    if rc == 2:
+        return 2, [int(table[i]) for i in range(nblk)]
+    return 0, None
 
 
 def _flag_ptr(flag):

@@ -867,6 +867,28 @@ int fv_tuning_set(const char* key, int value) {
     return fail(FV_ERR_INVALID_ARG, "tuning_set: unknown key '%s'", key);
 }
 
+int fv_debug_pair_schedule(int n_members, const int* n_items, const int* cost, int nblk, int mode, int three_members,
+                           unsigned* table) {
+    if (!n_items || !cost || !table) return fail(FV_ERR_INVALID_ARG, "debug_pair_schedule: null argument");
+    if (n_members < 1 || n_members > 3) return fail(FV_ERR_INVALID_ARG, "debug_pair_schedule: %d members", n_members);
+    if (mode != 0 && mode != 1) return fail(FV_ERR_INVALID_ARG, "debug_pair_schedule: mode %d", mode);
+    if (nblk < 1 || nblk > (mode == 0 ? fv::kSchedBlocks : 2 * fv::kSchedBlocks))
+        return fail(FV_ERR_INVALID_ARG, "debug_pair_schedule: %d blocks", nblk);
+    fv::PairParams p = {};
+    p.n_members = n_members;
+    long long n[3] = {0, 0, 0};
+    for (int m = 0; m < n_members; ++m) {
+        if (n_items[m] < 0 || cost[m] < 1) return fail(FV_ERR_INVALID_ARG, "debug_pair_schedule: member %d", m);
+        p.m[m].n_items = n_items[m];
+        p.m[m].cost = cost[m];
+        n[m] = n_items[m];
+    }
+    if (mode == 0) fv::pair_schedule(p, nblk, three_members != 0);
+    else fv::pair_cut_schedule(p, nblk, n);
+    memcpy(table, p.sched, sizeof(p.sched));
+    return p.sched_on;
+}
+
 int fv_profile_enable(int on) {
     g_prof_on = on != 0;
     g_prof_need_start = true;

@@ -623,6 +623,21 @@ int fv_plan_check_range(fv_plan_t* plan, void* stream);
  * path reads no environment variable; a process started with FV_TUNING=1 reads FV_<KEY> once at its first launch.
  */
 int fv_tuning_set(const char* key, int value);
+/*
+ * Test hook, host only (no device is touched): the block schedule a fused-pair / split-f16 conv launch of n_members (1 .. 3)
+ * members with n_items[m] items of cost[m] each hands to its nblk persistent blocks (csrc/convh_launch.hip) -- the
+ * tables the kernels index with blockIdx, as the CPU suite checks them (every item to exactly one block, shares in
+ * order, the makespan bound).  The reference has no counterpart: it leaves the partition to ATen.
+ *   mode 0: pair_schedule -- longest-processing-time-first over indivisible items for launches with few items per block
+ *           (three_members != 0: three-member launches are scheduled too, as the 128-channel launcher asks);
+ *   mode 1: pair_cut_schedule -- the contiguous cost-balanced cut, shares 0 .. nblk - 1 (nblk <= 512).
+ * table: 512 words.  Returns what the kernel would see as sched_on: 1 -- two words per block, member m's items
+ * [lo, lo + count) as lo (11 bits) | count (5 bits) << 11, word 0 = member 0 | member 1 << 16, word 1 = member 2;
+ * 2 -- table[i] = first item of share i in the members' concatenated item sequence; 0 -- no table for this shape (the
+ * kernel cuts by arithmetic); or a negative FV_ERR_* code.
+ */
+int fv_debug_pair_schedule(int n_members, const int* n_items, const int* cost, int nblk, int mode, int three_members,
+                           unsigned* table);
 
 /* ------------------------------------------------------------------ *
  * measurement hook (bench.py): per-launch timing of the dominant kernel

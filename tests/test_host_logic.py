@@ -413,3 +413,59 @@ def test_stage32_policy_follows_the_window_arithmetic():
     assert not fit(0, cus) and fit(264, 1) and not fit(265, 1)
     # the limit for many windows: 324 / 384 of every further window is final
     assert fit(10 ** 7, cus)
+
+
+def test_block_schedules_cover_every_item_exactly_once():
+    """The tables the fused-pair kernels index with blockIdx (csrc/convh_launch.hip pair_schedule / pair_cut_schedule, through the
+    host-only test hook fv_debug_pair_schedule): seeded random shapes plus the headline's.
+    Longest-processing-time-first schedule: every member's items are handed out as consecutive ranges in block order that
+    tile [0, n_items) exactly; no block exceeds mean + the largest item + one member switch (the greedy bound).
+    Contiguous cut: the share starts are non-decreasing from 0, inside the item sequence, and a share costs at most the
+    mean + one item."""
+    rng = np.random.RandomState(1234)
+    shapes = [([149, 138, 130], [49, 33, 17], 256, True), ([149, 138], [49, 33], 256, False),
+              ([339, 328, 318], [49, 33, 17], 256, True), ([1, 1, 1], [49, 33, 17], 3, True), ([5], [17], 4, True)]
+    for _ in range(60):
+        nm = int(rng.randint(2, 4))
+        nblk = int(rng.choice([2, 3, 7, 64, 200, 256]))
+        cost = sorted((int(c) for c in rng.randint(5, 100, size=nm)), reverse=True)
+        items = [int(v) for v in rng.randint(1, 2 * nblk + 2, size=nm)]
+        shapes.append((items, cost, nblk, bool(rng.randint(0, 2))))
+    seen_lpt = 0
+    for items, cost, nblk, three in shapes:
+        on, shares = _native.debug_pair_schedule(items, cost, nblk, mode=0, three_members=three)
+        assert on in (0, 1), (items, cost, nblk, on)
+        if on == 1:
+            seen_lpt += 1
+            at = [0] * len(items)
+            load = []
+            for b in range(nblk):
+                t, members = 0, 0
+                for m, (lo, cnt) in enumerate(shares[b]):
+                    if cnt:
+                        assert lo == at[m], (items, cost, nblk, b, m)
+                        at[m] += cnt
+                        t += cnt * cost[m]
+                        members += 1
+                load.append((t, members))
+            assert at == items, (items, cost, nblk, at)
+            mean = sum(n * c for n, c in zip(items, cost)) / nblk
+            worst = max(t + 4 * max(0, k - 1) for t, k in load)        # Tuning::sched_switch = 4 per extra member
+            assert worst <= mean + max(cost) + 4 * len(items), (items, cost, nblk, worst, mean)
+        on, starts = _native.debug_pair_schedule(items, cost, nblk, mode=1)
+        assert on == 2
+        total_items = sum(items)
+        assert starts[0] == 0 and all(a <= b for a, b in zip(starts, starts[1:])) and starts[-1] <= total_items
+        seq = [c for n, c in zip(items, cost) for _ in range(n)]
+        mean = sum(seq) / nblk
+        bounds = starts + [total_items]
+        for i in range(nblk):
+            assert sum(seq[bounds[i]:bounds[i + 1]]) <= mean + max(cost) + 1e-9, (items, cost, nblk, i)
+    assert seen_lpt >= 10
+    # the headline's 128-channel launch (HiFi-GAN light, 8000 columns): 417 items on 256 blocks, makespan 70 against a mean of 54.9
+    on, shares = _native.debug_pair_schedule([149, 138, 130], [49, 33, 17], 256, mode=0, three_members=True)
+    assert on == 1
+    worst = max(sum(cnt * c for (lo, cnt), c in zip(sh, [49, 33, 17])) + 4 * max(0, sum(1 for lo, cnt in sh if cnt) - 1) for sh in shares)
+    assert worst == 70
+    with pytest.raises(_native.NativeError):
+        _native.debug_pair_schedule([1, 2, 3, 4], [1, 1, 1, 1], 8)
