@@ -1,6 +1,8 @@
 // What does a dependent launch cost as a function of its kernel-argument block, its dynamic LDS and its block size?
 //   hipcc --offload-arch=gfx950 -O3 tools/launch_probe.hip -o tools/launch_probe.bin && tools/launch_probe.bin
 // N back-to-back launches on one stream of a kernel whose every thread does one store; time per launch by events.
+// With kernels this short the loop runs at the slower of the host's enqueue rate and the device's dispatch rate: the figures
+// are an UPPER bound for the device's dispatch-to-dispatch time, and what 2 KB of arguments add may be host time.
 // (The fused-pair launches pass their block schedule by value: a 2.3 KB argument block -- is that visible on the device?)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
