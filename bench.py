@@ -240,7 +240,8 @@ def other_configs(dev):
 # idle, two rounds alike: 0-16 ms 0.64, 16-30 ms 0.58, 30-500 ms 0.567-0.575 (the governor's boost), from ~600 ms on 0.580-0.585
 # and flat to 2.9 s; tools/warm_ab.sh: 20 steps after 5 warm-up steps 0.615 ms/step, 200 after 20: 0.559].  The driver's
 # `--steps 20 --warmup 5` is a 15 ms window at the start of that curve: it times the governor's ramp, and a window 100 ms later
-# times its boost.  The headline is the SUSTAINED rate -- what a server under load delivers: 0.75 s of untimed forwards, then W
+# times its boost.  The headline is the SUSTAINED rate -- SURVEY.md section 8(d): "device-synchronised, steady state"; what a
+# server under load delivers: 0.75 s of untimed forwards, then W
 # warm-up steps and EXACTLY K timed steps as the contract says.  The line carries the un-prewarmed figure of the same K steps
 # beside it (`cold_start`) and what was run here (`prewarm`).
 PREWARM_S = float(os.environ.get("FV_BENCH_PREWARM_S", "0.75"))
