@@ -277,6 +277,7 @@ def lib():
     L.fv_plan_num_ops.argtypes = [vp]
     L.fv_profile_enable.argtypes = [i]
     L.fv_profile_bracket_cost.argtypes = [vp, i, ctypes.POINTER(ctypes.c_double)]
+    L.fv_profile_mfma_f16_rate.argtypes = [vp, i64, i, i, vp, ctypes.POINTER(ctypes.c_double)]
     L.fv_profile_collect.argtypes = [i, ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     if L.fv_version() != ABI_VERSION:
@@ -1205,6 +1206,17 @@ def profile_bracket_cost(n=200):
     ms = ctypes.c_double()
     check(lib().fv_profile_bracket_cost(torch.cuda.current_stream().cuda_stream, n, ctypes.byref(ms)))
     return ms.value
+
+
+def profile_mfma_f16_rate(launches=40, iters=20000):
+    """The device's achievable dense f16 matrix rate in TFLOP/s (fv_profile_mfma_f16_rate: nothing but v_mfma_f32_16x16x32_f16 on
+    registers, timed over the last half of ``launches`` back-to-back launches on the current stream)."""
+    props = torch.cuda.get_device_properties(torch.cuda.current_device())
+    scratch = torch.empty(512 * 2 * props.multi_processor_count, dtype=torch.float32, device="cuda")
+    tf = ctypes.c_double()
+    check(lib().fv_profile_mfma_f16_rate(scratch.data_ptr(), scratch.numel(), int(launches), int(iters),
+                                         torch.cuda.current_stream().cuda_stream, ctypes.byref(tf)))
+    return tf.value
 
 
 def profile_collect(kind=-1):

@@ -923,6 +923,64 @@ int fv_profile_bracket_cost(void* stream, int n, double* ms_per_bracket) {
     return 0;
 }
 
+// A dense stream of v_mfma_f32_16x16x32_f16 from registers: the matrix rate the device sustains when nothing else is asked of it.
+typedef _Float16 peak_f16x8 __attribute__((ext_vector_type(8)));
+typedef float peak_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void profile_mfma_f16_kernel(float* out, int iters) {
+    const int lane = threadIdx.x & 63;
+    // eight operand pairs, one per accumulator, all different per lane and element and of both signs (products of order 1e-3):
+    // consecutive MFMAs see different operands, as in a GEMM (the same pair every time would leave the multipliers' inputs
+    // unchanged from one instruction to the next -- and the device's clock higher than any real kernel sees)
+    peak_f16x8 a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            a[j][i] = (_Float16)(0.03125f * (float)(((lane * 7 + i * 13 + j * 17) % 29) - 14) + 0.001f * (float)j);
+            b[j][i] = (_Float16)(0.0078125f * (float)(((lane * 11 + i * 5 + j * 23) % 31) - 15) - 0.0007f * (float)j);
+        }
+    peak_f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = peak_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; it += 8) {          // (iters: rounded up to a multiple of 8 by the host)
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[(j + r) & 7], acc[j], 0, 0, 0);
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = t;
+}
+
+int fv_profile_mfma_f16_rate(float* scratch, long long scratch_floats, int launches, int iters, void* stream, double* tflops) {
+    if (!scratch || !tflops || launches < 2 || iters < 1)
+        return fail(FV_ERR_INVALID_ARG, "profile_mfma_f16_rate: launches=%d iters=%d", launches, iters);
+    iters = (iters + 7) / 8 * 8;
+    const int blocks = 2 * fv::device_cu_count();
+    if (scratch_floats < 512LL * blocks)
+        return fail(FV_ERR_INVALID_ARG, "profile_mfma_f16_rate: scratch of %lld floats, %lld needed", scratch_floats, 512LL * blocks);
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    FV_HIP(hipEventCreate(&e0));
+    FV_HIP(hipEventCreate(&e1));
+    const int first = launches / 2;
+    for (int i = 0; i < launches; ++i) {
+        if (i == first) FV_HIP(hipEventRecord(e0, s));
+        hipLaunchKernelGGL(profile_mfma_f16_kernel, dim3(blocks), dim3(512), 0, s, scratch, iters);
+    }
+    FV_HIP(hipEventRecord(e1, s));
+    FV_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FV_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    const double flop = (double)(launches - first) * blocks * 8.0 * iters * 8.0 * 16384.0;
+    *tflops = ms > 0.f ? flop / ((double)ms * 1e-3) / 1e12 : 0.0;
+    return 0;
+}
+
 int fv_profile_collect(int kind, int64_t* launches, double* ms, double* flops, double* bytes) {
     if (int rc = profile_resolve()) return rc;
     double tms = 0, tf = 0, tb = 0;

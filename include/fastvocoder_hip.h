@@ -669,6 +669,13 @@ int fv_profile_enable(int on);
  * in rocprofv3's dispatch durations); the end-event record is one more packet -- a chain of n (null kernel, event)
  * pairs against a chain of n null kernels */
 int fv_profile_bracket_cost(void* stream, int n, double* ms_per_bracket);
+/* The device's ACHIEVABLE dense f16 matrix rate, for the `roofline` object of bench.py (fractions against the
+ * nominal AND the measured peak): `launches` back-to-back launches of a kernel that does nothing but v_mfma_f32_16x16x32_f16 on
+ * registers (two blocks of 8 waves per CU, eight independent accumulators per wave, `iters` x 8 MFMAs per wave, operands that
+ * differ per lane), timed by events over the LAST half of the launches -- so that with enough of them the figure is the
+ * sustained one.  scratch: >= 512 * 2 * (number of CUs) floats of device memory (one value per thread is stored so that the
+ * loop cannot be dropped).  *tflops: executed f16 FLOP (16 384 per MFMA) / second / 1e12. */
+int fv_profile_mfma_f16_rate(float* scratch, long long scratch_floats, int launches, int iters, void* stream, double* tflops);
 int fv_profile_collect(int kind, int64_t* launches, double* ms, double* flops, double* bytes);
 
 #ifdef __cplusplus

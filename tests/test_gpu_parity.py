@@ -59,6 +59,13 @@ def test_native_library_is_loaded():
         assert "libfastvocoder_hip.so" in f.read()
 
 
+def test_measured_matrix_peak_hook_is_sane():
+    """fv_profile_mfma_f16_rate (bench.py's `roofline.peak_measured`): a dense stream of v_mfma_f32_16x16x32_f16 from registers
+    cannot beat the nominal 2.5 PFLOP/s and, on an MI355X, does not fall below a third of it."""
+    tf = _native.profile_mfma_f16_rate(launches=8, iters=4000)
+    assert 800.0 < tf < 2600.0, tf
+
+
 # ---------------------------------------------------------------------------
 # operators vs the C oracle
 # ---------------------------------------------------------------------------
