@@ -1021,6 +1021,42 @@ def test_time_chunked_shipped_hifigan_light():
     assert _err(got, whole.cpu().numpy()) <= 1e-5
 
 
+@pytest.mark.parametrize("name,path,t_hi", [
+    ("hifigan", "conf/hifigan/light.yaml", 900), ("melgan", "conf/melgan/original.yaml", 500),
+    ("multiband-hifigan", "conf/multiband-hifigan/light.yaml", 900), ("basis-melgan", "conf/basis-melgan/light.yaml", 900),
+], ids=["hifigan_light", "melgan", "mb_light", "basis_light"])
+def test_random_chunking_of_shipped_generators(name, path, t_hi):
+    """SURVEY 8 f-4 on the shipped generators at seeded random (length, chunk) pairs: the stitched chunks equal the
+    whole-utterance run (1e-5: the same arithmetic per sample in other tile shapes) AND the ATen port of the reference on the
+    whole utterance (1e-4) -- chunks shorter than the receptive-field halo, a last chunk of one frame, MelGAN's reflection
+    padding (`modules.py:355-356`) applying at the utterance's ends only, never at a chunk boundary."""
+    cfg = cases.load_conf(path)
+    m, sd = _model(name, cfg, seed=0)
+    folded = torch_port.fold_state_dict(sd)
+    rng = np.random.RandomState(808)
+    pairs = [(int(rng.randint(40, t_hi + 1)), None) for _ in range(5)]
+    pairs = [(T, int(rng.randint(3, T))) for T, _ in pairs] + [(129, 128), (130, 5), (257, 64)]
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 32))
+    worst = 0.0
+    with torch.no_grad():
+        for T, chunk in pairs:
+            mel = seeded_mel(T, seed=12000 + T)
+            m.max_frames_per_run = 16384
+            whole = m.inference(mel).cpu().numpy()
+            m.max_frames_per_run = chunk
+            got = m.inference(mel).cpu().numpy()
+            assert got.shape == whole.shape, (T, chunk)
+            assert np.abs(got - whole).max() <= 1e-5, (T, chunk, float(np.abs(got - whole).max()))
+            err = _err(torch.from_numpy(got), torch_port.inference(name, mel, folded, cfg).numpy())
+            assert err <= TOL, (T, chunk, err)
+            worst = max(worst, err)
+    torch.set_num_threads(threads)
+    m.max_frames_per_run = 16384
+    assert not m.check_range()
+    print(f"{name}: {len(pairs)} (length, chunk) pairs, worst vs the port {worst:.2e}")
+
+
 def test_errors_are_loud():
     with pytest.raises(_native.NativeError):
         fa.HiFiGANGenerator()(torch.zeros(1, 80, 8))      # CPU module: no fallback
