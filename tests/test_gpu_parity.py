@@ -875,6 +875,43 @@ def test_random_lengths_vs_aten_port_other_generators(name, path, t_max, n_rando
     print(f"{name} {path}: {len(lengths)} lengths, worst {worst:.2e}")
 
 
+@pytest.mark.parametrize("name,path,t_max", [
+    ("hifigan", "conf/hifigan/light.yaml", 1200), ("melgan", "conf/melgan/original.yaml", 600),
+    ("multiband-hifigan", "conf/multiband-hifigan/light.yaml", 1200), ("basis-melgan", "conf/basis-melgan/light.yaml", 1200),
+], ids=["hifigan_light", "melgan", "mb_light", "basis_light"])
+def test_random_lengths_on_the_exact_fp32_kernels(name, path, t_max):
+    """The kernels a call is REPEATED on when the range guard fires (`precision = "f32"`: exact-fp32 MFMA everywhere,
+    csrc/conv_kernels.hpp / pair_kernels.hpp) over the same kind of length sweep, every sample against the ATen port: the
+    fallback a user never sees unless it is needed has to be right at every length too."""
+    cfg = cases.load_conf(path)
+    m, sd = _model(name, cfg, seed=0)
+    m.precision = "f32"
+    folded = torch_port.fold_state_dict(sd)
+    rng = np.random.RandomState(909)
+    lo = 4 if "melgan" in name else 1
+    ts = {lo, lo + 1, 9, 16, 17, 43, 63, 64, 65, 127, 129, 256, 1000 if t_max >= 1000 else t_max, t_max}
+    ts.update(int(v) for v in rng.randint(lo, t_max + 1, size=8))
+    lengths = sorted(t for t in ts if lo <= t <= t_max)
+    worst = 0.0
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 32))
+    with torch.no_grad():
+        for i, T in enumerate(lengths):
+            mel = seeded_mel(T, seed=15000 + T)
+            err = _err(m.inference(mel), torch_port.inference(name, mel, folded, cfg).numpy())
+            assert err <= TOL, (T, err)
+            worst = max(worst, err)
+            if i % 5 == 0:
+                x = seeded_mel(T, seed=16000 + T, batch=2)
+                got, ref = m(torch.from_numpy(x)), torch_port.forward(name, x, folded, cfg)
+                for g, r in (list(zip(got, ref)) if isinstance(ref, tuple) else [(got, ref)]):
+                    err = _err(g, r.numpy())
+                    assert err <= TOL, (T, "batch 2", err)
+                    worst = max(worst, err)
+    torch.set_num_threads(threads)
+    print(f"{name} precision=f32: {len(lengths)} lengths, worst {worst:.2e}")
+
+
 def test_batch_rows_are_independent_and_bit_identical():
     """Utterances never mix: row b of a batched forward equals the single-row call
     bit for bit (this is what makes N-GPU sharding exact)."""
