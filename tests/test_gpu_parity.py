@@ -912,6 +912,48 @@ def test_random_lengths_on_the_exact_fp32_kernels(name, path, t_max):
     print(f"{name} precision=f32: {len(lengths)} lengths, worst {worst:.2e}")
 
 
+@pytest.mark.parametrize("name,path,B,T", [
+    ("hifigan", "conf/hifigan/light.yaml", 12, 500), ("hifigan", "conf/hifigan/large.yaml", 6, 250),
+    ("multiband-hifigan", "conf/multiband-hifigan/light.yaml", 12, 500), ("basis-melgan", "conf/basis-melgan/light.yaml", 12, 500),
+    ("melgan", "conf/melgan/original.yaml", 8, 300),
+], ids=["hifigan_light_B12", "hifigan_large_B6", "mb_light_B12", "basis_light_B12", "melgan_B8"])
+def test_saturated_kernel_forms_vs_aten_port(name, path, B, T):
+    """Batches large enough for the launchers to pick the forms they use at saturation (256- / 128-column pair tiles at 64 / 128
+    channels, the ring-free 256-channel conv, the resident-image upsampler, the one-launch 32-channel stage) against the
+    ATen port on EVERY sample of every utterance -- until now those forms met the oracle through bit-identity with the
+    batch-1 forms only.  (Which form ran is the launchers' decision by items per CU -- convh_launch.hip `wide`, `form`;
+    HiFi-GAN light shows it in its launch count: 13 here against 15 at batch 1.)"""
+    cfg = cases.load_conf(path)
+    m, sd = _model(name, cfg, seed=0)
+    folded = torch_port.fold_state_dict(sd)
+    x = seeded_mel(T, seed=21000 + T, batch=B)
+
+    def kinds(inp):
+        torch.cuda.synchronize()
+        _native.profile_collect(-1)
+        _native.profile_enable(True)
+        with torch.no_grad():
+            out = m(inp)
+        torch.cuda.synchronize()
+        _native.profile_enable(False)
+        return out, int(_native.profile_collect(-1)["launches"])
+
+    xd = torch.from_numpy(x).to(_dev())
+    got, n_launches = kinds(xd)
+    assert n_launches > 0
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 64))
+    ref = torch_port.forward(name, x, folded, cfg)
+    torch.set_num_threads(threads)
+    worst = 0.0
+    for g, r in (list(zip(got, ref)) if isinstance(ref, tuple) else [(got, ref)]):
+        err = _err(g, r.numpy())
+        assert err <= TOL, (name, B, T, err)
+        worst = max(worst, err)
+    assert not m.check_range()
+    print(f"{name} {path} B={B} T={T}: worst {worst:.2e}, {n_launches} launches")
+
+
 def test_batch_rows_are_independent_and_bit_identical():
     """Utterances never mix: row b of a batched forward equals the single-row call
     bit for bit (this is what makes N-GPU sharding exact)."""
