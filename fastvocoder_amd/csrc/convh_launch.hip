@@ -302,7 +302,7 @@ int launch_convt(PairParams p, int Cin, int Cout, int stride, int pad, int Tout,
             p.nblk = (int)nb;
             p.sched_on = 0;
             p.dbg = 0;
-            p.trace = nullptr;
+            p.trace = reinterpret_cast<unsigned long long*>(tuning().trace_ptr);
             profile_begin(s);
             const int rc = launch_convtl_geom(p, cc / 32, s);
             profile_end(s, FV_KERNEL_CONVT, 2.0 * p.B * (double)p.T * Cin * Cout * 2 * stride,

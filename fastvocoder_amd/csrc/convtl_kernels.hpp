@@ -85,7 +85,10 @@ __device__ __forceinline__ void convtl_run(const PairParams& p, const PairMember
     };
     int item = item0, chunk = 0, b, ntile, mtile;
     decode(item, b, ntile, mtile);
+    pair_stamp(p, 8, wave, lane, 7, 12);                 // (tuning aid, -DFV_PAIR_TRACE: tools/convtl_trace.py) run start
     load_window(b, 0, ntile);
+    pair_stamp(p, 8, wave, lane, 7, 13);
+    int traced = 0;                                      // chunks stamped so far (the first seven of a block)
     bool fresh = true;                                   // the image has to be built from the window in the registers
     f32x4 hi[2], lo[2];
     float bv[4], sv[4];
@@ -98,6 +101,7 @@ __device__ __forceinline__ void convtl_run(const PairParams& p, const PairMember
         const bool last = nchunk == 0, more = nitem < hi_item;
         int nb = b, nnt = ntile, nmt_ = mtile;
         if (more && last) decode(nitem, nb, nnt, nmt_);
+        pair_stamp(p, 8, wave, lane, traced, 0);
         // ---- this chunk's A operands: the wave's sixteen rows, every K step, L2 -> registers (in flight during the conversion)
         f16x8 A[G::NSTEP][2];
         {
@@ -137,8 +141,10 @@ __device__ __forceinline__ void convtl_run(const PairParams& p, const PairMember
                     }
             }
             convh_convert<G>(raw, ximg, p.slope, tid, low, 0);
+            pair_stamp(p, 8, wave, lane, traced, 1);
             pair_barrier();                              // image complete
         }
+        pair_stamp(p, 8, wave, lane, traced, 2);
         const bool reuse = more && last && nch == 1 && nb == b && nnt == ntile;
         if ((more || !last) && !reuse) load_window(last ? nb : b, last ? 0 : nchunk, last ? nnt : ntile);
         // ---- K loop: no barrier, B operands one step ahead
@@ -170,6 +176,7 @@ __device__ __forceinline__ void convtl_run(const PairParams& p, const PairMember
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        pair_stamp(p, 8, wave, lane, traced, 3);
         // ---- epilogue of the item's last chunk: y[co][ups u + phase - pad] -- a lane's four rows are four consecutive phases:
         // inside one output channel four consecutive samples, one 16-byte store (convt_kernel's epilogue)
         if (last) {
@@ -211,8 +218,11 @@ __device__ __forceinline__ void convtl_run(const PairParams& p, const PairMember
                 }
             }
         }
+        pair_stamp(p, 8, wave, lane, traced, 4);
         if (!more && last) break;
         if (!reuse) pair_barrier();                      // every wave is done with the image: the next window may overwrite it
+        pair_stamp(p, 8, wave, lane, traced, 5);
+        ++traced;
         fresh = !reuse;
         item = nitem;
         chunk = nchunk;
@@ -220,6 +230,10 @@ __device__ __forceinline__ void convtl_run(const PairParams& p, const PairMember
         ntile = nnt;
         mtile = nmt_;
     }
+#ifdef FV_PAIR_TRACE
+    pair_wait_vm0();
+    pair_stamp(p, 8, wave, lane, 7, 14);                 // the stores have drained
+#endif
     range_flag(p, bad);
     pair_barrier();
     low_flag(p, low, scratch, wave, lane, G::NW);
